@@ -1,0 +1,574 @@
+"""CPU oracle for the phaseless-AFQMC walker-propagation hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a from-scratch numpy/scipy
+restatement of the reference algorithm (pauxy-qmc/pauxy); it is imported only
+by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py``.  Nothing under ``pauxy_amd/`` imports it: the product path runs on
+the HIP library or fails.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the genuine
+reference (scratch copy of /root/reference/pauxy) in the build container and
+stores its inputs/outputs as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors and against the known-answer
+constants lifted from the reference's own tests.
+
+Each function cites the reference file:line it follows (paths relative to
+/root/reference/pauxy).  All arrays are numpy, complex128 unless noted, C order.
+A walker's Slater matrix is ``phi[M, na+nb]`` (alpha columns first).
+
+The per-walker functions deliberately keep the reference's per-walker loop
+structure and numpy/scipy call choices (scipy.linalg.inv / numpy.linalg.slogdet /
+scipy.linalg.qr, one dense dot per operator) so that, timed on host cores, they
+are a fair stand-in ("port") for the reference CPU path.
+"""
+import cmath
+import math
+
+import numpy
+import scipy.linalg
+
+
+# --------------------------------------------------------------------------
+# Green's functions / overlaps
+# --------------------------------------------------------------------------
+def greens_function(phi, psi, na, nb, log_shift=0.0):
+    """walkers/single_det.py:295-321 (same maths as estimators/greens_function.py:41-73).
+
+    Returns (det, Ghalf[2], G[2,M,M]).  G is the "1-G" convention:
+    G_s = conj(psi_s) . inv(phi_s^T conj(psi_s)) . phi_s^T
+    """
+    M = phi.shape[0]
+    G = numpy.zeros((2, M, M), dtype=numpy.complex128)
+    Ghalf = [None, None]
+    O = numpy.dot(phi[:, :na].T, psi[:, :na].conj())
+    Ghalf[0] = numpy.dot(scipy.linalg.inv(O), phi[:, :na].T)
+    G[0] = numpy.dot(psi[:, :na].conj(), Ghalf[0])
+    sign_a, logdet_a = numpy.linalg.slogdet(O)
+    sign_b, logdet_b = 1.0, 0.0
+    if nb > 0:
+        O = numpy.dot(phi[:, na:].T, psi[:, na:].conj())
+        sign_b, logdet_b = numpy.linalg.slogdet(O)
+        Ghalf[1] = numpy.dot(scipy.linalg.inv(O), phi[:, na:].T)
+        G[1] = numpy.dot(psi[:, na:].conj(), Ghalf[1])
+    else:
+        Ghalf[1] = numpy.zeros((0, M), dtype=numpy.complex128)
+    det = sign_a * sign_b * numpy.exp(logdet_a + logdet_b - log_shift)
+    return det, Ghalf, G
+
+
+def calc_overlap(phi, psi, na, nb, log_shift=0.0):
+    """walkers/single_det.py:170-199.
+
+    The reference partitions with ``na = self.ndown`` (single_det.py:183), which
+    is only right for na == nb; this restatement uses the correct partition and
+    parity is claimed for na == nb (every BASELINE configuration).
+    """
+    Oa = numpy.dot(psi[:, :na].conj().T, phi[:, :na])
+    sign_a, logdet_a = numpy.linalg.slogdet(Oa)
+    sign_b, logdet_b = 1.0, 0.0
+    if nb > 0:
+        Ob = numpy.dot(psi[:, na:].conj().T, phi[:, na:])
+        sign_b, logdet_b = numpy.linalg.slogdet(Ob)
+    return sign_a * sign_b * numpy.exp(logdet_a + logdet_b - log_shift)
+
+
+def gab(A, B):
+    """estimators/greens_function.py:5-38."""
+    inv_O = scipy.linalg.inv((A.conj().T).dot(B))
+    return B.dot(inv_O.dot(A.conj().T))
+
+
+def gab_mod(A, B):
+    """estimators/greens_function.py:41-73."""
+    O = numpy.dot(B.T, A.conj())
+    GHalf = numpy.dot(scipy.linalg.inv(O), B.T)
+    G = numpy.dot(A.conj(), GHalf)
+    return (G, GHalf)
+
+
+# --------------------------------------------------------------------------
+# One-body propagation
+# --------------------------------------------------------------------------
+def kinetic_real(phi, BH1, na):
+    """propagation/operations.py:29-52 (in place)."""
+    phi[:, :na] = BH1[0].dot(phi[:, :na])
+    phi[:, na:] = BH1[1].dot(phi[:, na:])
+
+
+# --------------------------------------------------------------------------
+# Force bias / HS potential, per system
+# --------------------------------------------------------------------------
+def force_bias_generic(Ghalf, rchol, na, nb, M, sqrt_dt, mf_shift):
+    """propagation/generic.py:130-152 (dense branch)."""
+    vbias = numpy.dot(rchol[:na * M].T, Ghalf[0].ravel())
+    vbias = vbias + numpy.dot(rchol[na * M:(na + nb) * M].T, Ghalf[1].ravel())
+    return -sqrt_dt * (1j * vbias - mf_shift)
+
+
+def force_bias_generic_full(G, hs_pot, sqrt_dt, mf_shift):
+    """propagation/generic.py:109-128 (construct_force_bias_slow)."""
+    vbias = numpy.dot(hs_pot.T, G[0].ravel())
+    vbias = vbias + numpy.dot(hs_pot.T, G[1].ravel())
+    return -sqrt_dt * (1j * vbias - mf_shift)
+
+
+def vhs_generic(hs_pot, xshifted, M, sqrt_dt):
+    """propagation/generic.py:164-179."""
+    VHS = hs_pot.dot(xshifted)
+    return 1j * sqrt_dt * VHS.reshape(M, M)
+
+
+def force_bias_hubbard(G, U, sqrt_dt, mf_shift):
+    """propagation/hubbard.py:404-407 (charge decomposition)."""
+    vbias = 1j * U ** 0.5 * (numpy.diag(G[0]) + numpy.diag(G[1]))
+    return -sqrt_dt * (vbias - mf_shift)
+
+
+def vhs_hubbard(xshifted, U, sqrt_dt):
+    """propagation/hubbard.py:409-413: dense diagonal matrix."""
+    return numpy.diag(sqrt_dt * 1j * U ** 0.5 * xshifted)
+
+
+def force_bias_hubbard_spin(G, U, sqrt_dt, mf_shift):
+    """propagation/hubbard.py:469-473 (spin decomposition)."""
+    vbias = U ** 0.5 * numpy.diag(G[0] - G[1])
+    return -sqrt_dt * (vbias - mf_shift)
+
+
+def vhs_hubbard_spin(xshifted, U, dt):
+    """propagation/hubbard.py:475-480: one diagonal per spin."""
+    ut_fac = (dt * U) ** 0.5
+    return numpy.array([numpy.diag(-ut_fac * xshifted),
+                        numpy.diag(ut_fac * xshifted)])
+
+
+def force_bias_ueg(G, iA, iB, sqrt_dt):
+    """propagation/planewave.py:57-76.  iA, iB: scipy.sparse csc [M*M, nq]."""
+    M = G.shape[-1]
+    nq = iA.shape[1]
+    Gvec = G.reshape(2, M * M)
+    vbias = numpy.zeros(2 * nq, dtype=numpy.complex128)
+    vbias[:nq] = Gvec[0].T * iA + Gvec[1].T * iA
+    vbias[nq:] = Gvec[0].T * iB + Gvec[1].T * iB
+    return -sqrt_dt * vbias
+
+
+def vhs_ueg(iA, iB, xshifted, M, sqrt_dt):
+    """propagation/planewave.py:94-112."""
+    nq = iA.shape[1]
+    VHS = iA * xshifted[:nq] + iB * xshifted[nq:]
+    return sqrt_dt * VHS.reshape(M, M)
+
+
+# --------------------------------------------------------------------------
+# Two-body propagator
+# --------------------------------------------------------------------------
+def apply_exponential(phi, VHS, order=6):
+    """propagation/continuous.py:82-111: truncated Taylor series, in place."""
+    Temp = numpy.array(phi, copy=True)
+    for n in range(1, order + 1):
+        Temp = VHS.dot(Temp) / n
+        phi += Temp
+    return phi
+
+
+def shift_fields(xi, xbar, mf_shift, sqrt_dt):
+    """propagation/continuous.py:140-158: clip |xbar_i|>1 to unit modulus, then
+    shifted field and the two constant factors.  Returns (xshifted, cmf, cfb, ntrig)."""
+    xbar = numpy.array(xbar, dtype=numpy.complex128, copy=True)
+    ntrig = 0
+    for i in range(xbar.shape[0]):
+        a = numpy.absolute(xbar[i])
+        if a > 1.0:
+            ntrig += 1
+            xbar[i] /= a
+    xshifted = xi - xbar
+    cmf = -sqrt_dt * xshifted.dot(mf_shift)
+    cfb = xi.dot(xbar) - 0.5 * xbar.dot(xbar)
+    return xshifted, cmf, cfb, ntrig
+
+
+def apply_bound_hybrid(ehyb, eshift, ebound):
+    """propagation/continuous.py:202-214.  Returns (ehyb, triggered)."""
+    if abs(eshift) < 1e-10:
+        return ehyb, 0
+    es = complex(eshift).real
+    if ehyb.real > es + ebound:
+        return es + ebound + 1j * ehyb.imag, 1
+    if ehyb.real < es - ebound:
+        return es - ebound + 1j * ehyb.imag, 1
+    return ehyb, 0
+
+
+def update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, dt):
+    """propagation/continuous.py:264-292.  ``w`` is a dict with keys weight, ot,
+    ovlp, hybrid_energy.  On an infinite importance function the reference
+    raises NameError (undefined ``ot_new``, :291); here the weight is set to 0."""
+    ebound = (2.0 / dt) ** 0.5
+    ovlp_ratio = ovlp_new / ovlp
+    ehyb = -(cmath.log(ovlp_ratio) + cfb + cmf) / dt
+    ehyb, trig = apply_bound_hybrid(ehyb, eshift, ebound)
+    imp = cmath.exp(-dt * (0.5 * (ehyb + w['hybrid_energy']) - eshift))
+    (magn, phase) = cmath.polar(imp)
+    w['hybrid_energy'] = ehyb
+    if not math.isinf(magn):
+        dtheta = (-dt * ehyb - cfb).imag
+        cosine_fac = max(0, math.cos(dtheta))
+        w['weight'] *= magn * cosine_fac
+        w['ot'] = ovlp_new
+        w['ovlp'] = ovlp_new
+    else:
+        w['ot'] = ovlp_new
+        w['weight'] = 0.0
+    return trig
+
+
+# --------------------------------------------------------------------------
+# Local energies
+# --------------------------------------------------------------------------
+def local_energy_generic_cholesky_opt(H1, ecore, G, Ghalf, rchol, na, nb):
+    """estimators/generic.py:156-221 (half-rotated Cholesky energy)."""
+    M = H1.shape[-1]
+    e1b = numpy.sum(H1[0] * G[0]) + numpy.sum(H1[1] * G[1])
+    naux = rchol.shape[1]
+    Ga, Gb = Ghalf[0], Ghalf[1]
+    Xa = rchol[:na * M].T.dot(Ga.ravel())
+    Xb = rchol[na * M:(na + nb) * M].T.dot(Gb.ravel())
+    ecoul = numpy.dot(Xa, Xa)
+    ecoul += numpy.dot(Xb, Xb)
+    ecoul += 2 * numpy.dot(Xa, Xb)
+    rchol_a = rchol[:na * M].T
+    rchol_b = rchol[na * M:(na + nb) * M].T
+    Ta = numpy.zeros((naux, na, na), dtype=rchol.dtype)
+    Tb = numpy.zeros((naux, nb, nb), dtype=rchol.dtype)
+    GaT = Ga.T
+    GbT = Gb.T
+    for x in range(naux):
+        Ta[x] = rchol_a[x].reshape((na, M)).dot(GaT)
+        Tb[x] = rchol_b[x].reshape((nb, M)).dot(GbT)
+    exxa = numpy.tensordot(Ta, Ta, axes=((0, 1, 2), (0, 2, 1)))
+    exxb = numpy.tensordot(Tb, Tb, axes=((0, 1, 2), (0, 2, 1)))
+    e2b = 0.5 * (ecoul - (exxa + exxb))
+    return (e1b + e2b + ecore, e1b + ecore, e2b)
+
+
+def local_energy_generic_cholesky(H1, ecore, G, chol):
+    """estimators/generic.py:398-434 (full-G Cholesky energy; chol is [M*M, K])."""
+    M = H1.shape[-1]
+    e1b = numpy.sum(H1[0] * G[0]) + numpy.sum(H1[1] * G[1])
+    nchol = chol.shape[-1]
+    Ga, Gb = G[0], G[1]
+    Xa = numpy.dot(chol.T, Ga.ravel())
+    Xb = numpy.dot(chol.T, Gb.ravel())
+    ecoul = numpy.dot(Xa, Xa)
+    ecoul += numpy.dot(Xb, Xb)
+    ecoul += 2 * numpy.dot(Xa, Xb)
+    cv = chol.reshape((M, M, nchol))
+    # T[l,k,n] = sum_i L[i,k,n] G[i,l];  exx = sum_{nlk} T[l,k,n] T[k,l,n]
+    Ta = numpy.tensordot(Ga, cv, axes=((0), (0)))
+    exxa = numpy.tensordot(Ta, Ta, axes=((0, 1, 2), (1, 0, 2)))
+    Tb = numpy.tensordot(Gb, cv, axes=((0), (0)))
+    exxb = numpy.tensordot(Tb, Tb, axes=((0, 1, 2), (1, 0, 2)))
+    e2b = 0.5 * (ecoul - (exxa + exxb))
+    return (e1b + e2b + ecore, e1b + ecore, e2b)
+
+
+def local_energy_hubbard(T, U, G):
+    """estimators/hubbard.py:93-114 (the 'symmetric' branch is overwritten there)."""
+    ke = numpy.sum(T[0] * G[0] + T[1] * G[1])
+    pe = U * numpy.dot(G[0].diagonal(), G[1].diagonal())
+    return (ke + pe, ke, pe)
+
+
+def local_energy_ueg(H1diag, vqvec, vol, ikpq_i, ikpq_kpq, ipmq_i, ipmq_pmq, G):
+    """estimators/ueg.py:27-88 with the Cython gathers of
+    estimators/ueg_kernels.pyx:42-75 restated as fancy-index sums.
+    H1diag: [2, M] diagonal of H1; index lists: ragged, one int array per q."""
+    nq = len(vqvec)
+    ke = 0.0
+    for s in (0, 1):
+        ke = ke + numpy.dot(H1diag[s], numpy.diag(G[s]))
+    Gkpq = numpy.zeros((2, nq), dtype=numpy.complex128)
+    Gpmq = numpy.zeros((2, nq), dtype=numpy.complex128)
+    Gprod = numpy.zeros((2, nq), dtype=numpy.complex128)
+    for s in (0, 1):
+        Gs = G[s]
+        for iq in range(nq):
+            ki, kk = ikpq_i[iq], ikpq_kpq[iq]
+            pi, pp = ipmq_i[iq], ipmq_pmq[iq]
+            Gkpq[s, iq] = Gs[ki, kk].sum()
+            Gpmq[s, iq] = Gs[pi, pp].sum()
+            if len(ki) and len(pi):
+                # sum_{a,b} G[pi[b], kk[a]] * G[ki[a], pp[b]]
+                A = Gs[numpy.ix_(pi, kk)]      # [b, a]
+                B = Gs[numpy.ix_(ki, pp)]      # [a, b]
+                Gprod[s, iq] = numpy.sum(A * B.T)
+    fac = 1.0 / (2.0 * vol)
+    essa = fac * vqvec.dot(Gkpq[0] * Gpmq[0] - Gprod[0])
+    essb = fac * vqvec.dot(Gkpq[1] * Gpmq[1] - Gprod[1])
+    eos = fac * vqvec.dot(Gkpq[0] * Gpmq[1]) + fac * vqvec.dot(Gkpq[1] * Gpmq[0])
+    pe = essa + essb + eos
+    return (ke + pe, ke, pe)
+
+
+# --------------------------------------------------------------------------
+# Re-orthogonalisation
+# --------------------------------------------------------------------------
+def reortho(phi, na, nb, detR_shift=0.0):
+    """walkers/single_det.py:215-255.  In place; returns detR (product of |R_ii|
+    over both spins).  Caller applies ``ot /= detR``."""
+    (phi[:, :na], Rup) = scipy.linalg.qr(phi[:, :na], mode='economic')
+    Rup_diag = numpy.diag(Rup)
+    signs_up = numpy.sign(Rup_diag)
+    phi[:, :na] = numpy.dot(phi[:, :na], numpy.diag(signs_up))
+    log_det = numpy.sum(numpy.log(numpy.abs(Rup_diag)))
+    if nb > 0:
+        (phi[:, na:], Rdn) = scipy.linalg.qr(phi[:, na:], mode='economic')
+        Rdn_diag = numpy.diag(Rdn)
+        signs_dn = numpy.sign(Rdn_diag)
+        phi[:, na:] = numpy.dot(phi[:, na:], numpy.diag(signs_dn))
+        log_det += numpy.sum(numpy.log(numpy.abs(Rdn_diag)))
+    return numpy.exp(log_det - detR_shift)
+
+
+# --------------------------------------------------------------------------
+# Population control (comb)
+# --------------------------------------------------------------------------
+def comb_parent_ix(weights, target, r):
+    """walkers/handler.py:269-286: comb teeth against cumulative weights."""
+    n = len(weights)
+    parent_ix = numpy.zeros(n, dtype='i')
+    total_weight = sum(weights)
+    cprobs = numpy.cumsum(weights)
+    comb = [(i + r) * (total_weight / target) for i in range(target)]
+    iw = 0
+    ic = 0
+    while ic < len(comb):
+        if comb[ic] < cprobs[iw]:
+            parent_ix[iw] += 1
+            ic += 1
+        else:
+            iw += 1
+    return parent_ix
+
+
+def comb_pairs(parent_ix):
+    """walkers/handler.py:295-301: (clone, kill) pairs; ``zip`` truncates, so a
+    parent with multiplicity >= 3 is copied once only."""
+    kill = numpy.where(parent_ix == 0)[0]
+    clone = numpy.where(parent_ix > 1)[0]
+    return list(zip(clone.tolist(), kill.tolist()))
+
+
+# --------------------------------------------------------------------------
+# The step loop (single rank), restating qmc/afqmc.py:200-255 +
+# estimators/mixed.py:133-289 + walkers/handler.py:225-338
+# --------------------------------------------------------------------------
+EST = dict(uweight=0, weight=1, enumer=2, edenom=3, eproj=4, e1b=5, e2b=6,
+           ehyb=7, ovlp=8, time=9)   # estimators/mixed.py:460-469
+
+
+class RefModel(object):
+    """Plain-array bundle of everything the hot path reads.
+
+    kind: 'generic' | 'hubbard' | 'hubbard_spin' | 'ueg'
+    """
+
+    def __init__(self, kind, M, na, nb, psi, BH1, mf_shift, dt, **kw):
+        self.kind = kind
+        self.M, self.na, self.nb = M, na, nb
+        self.psi = psi
+        self.BH1 = BH1
+        self.mf_shift = numpy.asarray(mf_shift, dtype=numpy.complex128)
+        self.dt = dt
+        self.sqrt_dt = dt ** 0.5
+        self.exp_order = kw.get('exp_order', 6)
+        self.__dict__.update(kw)
+        self.nfields = len(self.mf_shift)
+
+    # -- system dispatch ------------------------------------------------
+    def force_bias(self, Ghalf, G):
+        if self.kind == 'generic':
+            return force_bias_generic(Ghalf, self.rchol, self.na, self.nb, self.M,
+                                      self.sqrt_dt, self.mf_shift)
+        if self.kind == 'hubbard':
+            return force_bias_hubbard(G, self.U, self.sqrt_dt, self.mf_shift)
+        if self.kind == 'hubbard_spin':
+            return force_bias_hubbard_spin(G, self.U, self.sqrt_dt, self.mf_shift)
+        if self.kind == 'ueg':
+            return force_bias_ueg(G, self.iA, self.iB, self.sqrt_dt)
+        raise ValueError(self.kind)
+
+    def vhs(self, xs):
+        if self.kind == 'generic':
+            return vhs_generic(self.hs_pot, xs, self.M, self.sqrt_dt)
+        if self.kind == 'hubbard':
+            return vhs_hubbard(xs, self.U, self.sqrt_dt)
+        if self.kind == 'hubbard_spin':
+            return vhs_hubbard_spin(xs, self.U, self.dt)
+        if self.kind == 'ueg':
+            return vhs_ueg(self.iA, self.iB, xs, self.M, self.sqrt_dt)
+        raise ValueError(self.kind)
+
+    def local_energy(self, G, Ghalf):
+        if self.kind == 'generic':
+            return local_energy_generic_cholesky_opt(self.H1, self.ecore, G, Ghalf,
+                                                     self.rchol, self.na, self.nb)
+        if self.kind in ('hubbard', 'hubbard_spin'):
+            return local_energy_hubbard(self.H1, self.U, G)
+        if self.kind == 'ueg':
+            e = local_energy_ueg(self.H1diag, self.vqvec, self.vol, self.ikpq_i,
+                                 self.ikpq_kpq, self.ipmq_i, self.ipmq_pmq, G)
+            return e
+        raise ValueError(self.kind)
+
+
+def new_walker(model, phi0, weight=1.0):
+    """walkers/walker.py:24-61 + single_det.py:64-67 (the state the loop touches)."""
+    phi = numpy.array(phi0, dtype=numpy.complex128, copy=True)
+    ot = calc_overlap(phi, model.psi, model.na, model.nb)
+    return dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
+                hybrid_energy=0.0, total_weight=0.0, detR=1.0)
+
+
+def propagate_walker_phaseless(model, w, xi, eshift):
+    """propagation/continuous.py:232-262 with the two-body part of :113-173.
+    ``xi`` is the real normal field vector the reference draws at :133.
+    Returns (nfb_trig, nhe_trig)."""
+    na, nb = model.na, model.nb
+    ovlp, Ghalf, G = greens_function(w['phi'], model.psi, na, nb)
+    kinetic_real(w['phi'], model.BH1, na)
+    xbar = model.force_bias(Ghalf, G)
+    xs, cmf, cfb, ntrig = shift_fields(xi, xbar, model.mf_shift, model.sqrt_dt)
+    VHS = model.vhs(xs)
+    if VHS.ndim == 3:
+        apply_exponential(w['phi'][:, :na], VHS[0], model.exp_order)
+        if nb > 0:
+            apply_exponential(w['phi'][:, na:], VHS[1], model.exp_order)
+    else:
+        apply_exponential(w['phi'][:, :na], VHS, model.exp_order)
+        if nb > 0:
+            apply_exponential(w['phi'][:, na:], VHS, model.exp_order)
+    kinetic_real(w['phi'], model.BH1, na)
+    ovlp_new = calc_overlap(w['phi'], model.psi, na, nb)
+    htrig = update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, model.dt)
+    return ntrig, htrig
+
+
+def pop_control(model, walkers, target, r):
+    """walkers/handler.py:225-338 for one rank.  ``r`` is the uniform the
+    reference draws at :276.  Returns parent_ix."""
+    if len(walkers) == 1:
+        return None
+    weights = numpy.array([abs(w['weight']) for w in walkers])
+    total_weight = sum(weights)
+    scale = total_weight / target
+    if total_weight < 1e-8:
+        raise RuntimeError("total weight %g" % total_weight)
+    for w in walkers:
+        w['total_weight'] = total_weight
+        w['unscaled_weight'] = w['weight']
+        w['weight'] = w['weight'] / scale
+    parent_ix = comb_parent_ix(weights / scale, target, r)
+    for (c, k) in comb_pairs(parent_ix):
+        src = walkers[c]
+        dst = walkers[k]
+        for key, val in src.items():
+            dst[key] = numpy.array(val, copy=True) if isinstance(val, numpy.ndarray) else val
+    for w in walkers:
+        w['weight'] = 1.0
+    return parent_ix
+
+
+def mixed_update(model, est, walkers, step, energy_eval_freq):
+    """estimators/mixed.py:180-225 (importance-sampling branch, le_oratio == 1)."""
+    for w in walkers:
+        if step % energy_eval_freq == 0:
+            _, Ghalf, G = greens_function(w['phi'], model.psi, model.na, model.nb)
+            E, T, V = model.local_energy(G, Ghalf)
+            est[EST['enumer']] += w['weight'] * complex(E).real
+            est[EST['e1b']] += w['weight'] * complex(T).real
+            est[EST['e2b']] += w['weight'] * complex(V).real
+            est[EST['edenom']] += w['weight']
+        est[EST['uweight']] += w['unscaled_weight']
+        est[EST['weight']] += w['weight']
+        est[EST['ovlp']] += w['weight'] * abs(w['ot'])
+        est[EST['ehyb']] += w['weight'] * w['hybrid_energy']
+
+
+def block_reduce(est, nsteps):
+    """estimators/mixed.py:256-274 for one rank.  Returns (global_estimates, eshift)."""
+    es = est.copy()
+    es[EST['uweight']:EST['weight'] + 1] /= nsteps
+    es[EST['ehyb']:EST['time'] + 1] /= nsteps
+    gs = es.copy()
+    gs[EST['eproj']] = gs[EST['enumer']]
+    gs[EST['eproj']:EST['e2b'] + 1] = gs[EST['eproj']:EST['e2b'] + 1] / gs[EST['edenom']]
+    gs[EST['ehyb']] /= gs[EST['weight']]
+    gs[EST['ovlp']] /= gs[EST['weight']]
+    return gs, numpy.array([gs[EST['ehyb']], gs[EST['eproj']]])
+
+
+def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
+              npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
+              record=None, verbose=False):
+    """qmc/afqmc.py:200-255 for one rank.
+
+    xi_source(step, iw) -> real [nfields] normal field for walker iw (called
+    only for live walkers, in walker order, exactly as numpy.random.normal at
+    propagation/continuous.py:133); r_source(step) -> comb uniform.
+    ``record`` (optional list) receives per-step dict(weight, ot, hybrid_energy,
+    parent_ix).  Returns list of per-block global estimates.
+
+    ``verbose`` mirrors the driver flag: the step-0 estimates are reduced and
+    zeroed only when it is set (qmc/afqmc.py:220-221); otherwise they stay in
+    the accumulator and are folded into the first block, as in the reference.
+    """
+    if energy_eval_freq is None:
+        energy_eval_freq = nsteps
+    ntot = len(walkers)
+    for w in walkers:
+        w['total_weight'] = ntot       # walkers/handler.py:164
+    neqlb = int(eqlb_time / model.dt)
+    est = numpy.zeros(10, dtype=numpy.complex128)
+    blocks = []
+    eshift_pair = numpy.array([0, 0], dtype=numpy.complex128)
+    eshift = 0
+    # step-0 estimator pass (qmc/afqmc.py:214-221)
+    mixed_update(model, est, walkers, 0, energy_eval_freq)
+    if verbose:
+        gs, eshift_pair = block_reduce(est, 1)
+        blocks.append(gs)
+        est[:] = 0
+    for step in range(1, nsteps * nblocks + 1):
+        if step % nstblz == 0:
+            for w in walkers:
+                detR = reortho(w['phi'], model.na, model.nb)
+                w['detR'] = detR
+                w['ot'] = w['ot'] / detR
+                w['ovlp'] = w['ot']
+        for iw, w in enumerate(walkers):
+            if abs(w['weight']) > 1e-8:
+                propagate_walker_phaseless(model, w, xi_source(step, iw), eshift)
+            if (abs(w['weight']) > w['total_weight'] * 0.10) and step > 1:
+                w['weight'] = w['total_weight'] * 0.10
+        parent_ix = None
+        if step % npop_control == 0:
+            parent_ix = pop_control(model, walkers, ntot, r_source(step))
+        mixed_update(model, est, walkers, step, energy_eval_freq)
+        if record is not None:
+            record.append(dict(
+                weight=numpy.array([w['weight'] for w in walkers]),
+                unscaled_weight=numpy.array([w['unscaled_weight'] for w in walkers]),
+                ot=numpy.array([w['ot'] for w in walkers]),
+                hybrid_energy=numpy.array([w['hybrid_energy'] for w in walkers]),
+                parent_ix=None if parent_ix is None else parent_ix.copy()))
+        if step % nsteps == 0:
+            gs, eshift_pair = block_reduce(est, nsteps)
+            blocks.append(gs)
+            est[:] = 0
+        if step < neqlb:
+            eshift = eshift_pair[0].real if hybrid else eshift_pair[1].real
+        else:
+            eshift += (eshift_pair[0].real - eshift)
+    return blocks

@@ -1,0 +1,187 @@
+"""Pin the CPU oracle (oracle/afqmc_ref.py) against vectors produced by the
+genuine reference (tests/golden/make_golden.py) and against the known-answer
+constants of the reference's own tests.  CPU only."""
+import numpy
+import pytest
+
+from oracle import afqmc_ref as ref
+from tests.helpers import generic_model, hubbard_model, ueg_model
+
+RTOL = 1e-11
+
+
+def close(a, b, tol=RTOL):
+    a = numpy.asarray(a)
+    b = numpy.asarray(b)
+    scale = max(1.0, float(numpy.max(numpy.abs(b)))) if b.size else 1.0
+    assert numpy.max(numpy.abs(a - b)) <= tol * scale, numpy.max(numpy.abs(a - b)) / scale
+
+
+def check_single_walker_ops(d, tag, model):
+    na, nb, M = model.na, model.nb, model.M
+    phi = d[tag + 'phi']
+    det, Ghalf, G = ref.greens_function(phi, model.psi, na, nb)
+    close(det, d[tag + 'det'])
+    close(Ghalf[0], d[tag + 'Ghalf_a'])
+    close(Ghalf[1], d[tag + 'Ghalf_b'])
+    close(G, d[tag + 'G'])
+    if tag + 'ovlp' in d:
+        close(ref.calc_overlap(phi, model.psi, na, nb), d[tag + 'ovlp'])
+        # same determinant as the Green's function overlap
+        close(ref.calc_overlap(phi, model.psi, na, nb), det)
+    xbar = model.force_bias(Ghalf, G)
+    close(xbar, d[tag + 'xbar'])
+    xi = d[tag + 'xi']
+    xs, cmf, cfb, ntrig = ref.shift_fields(xi, d[tag + 'xbar_big'], model.mf_shift, model.sqrt_dt)
+    assert ntrig >= 1
+    close(xs, d[tag + 'xs_clip'])
+    close(cmf, d[tag + 'cmf_clip'])
+    close(cfb, d[tag + 'cfb_clip'])
+    xs, cmf, cfb, ntrig = ref.shift_fields(xi, xbar, model.mf_shift, model.sqrt_dt)
+    VHS = model.vhs(xs)
+    close(VHS, d[tag + 'VHS'])
+    p2 = phi.copy()
+    if VHS.ndim == 3:
+        ref.apply_exponential(p2[:, :na], VHS[0])
+        ref.apply_exponential(p2[:, na:], VHS[1])
+    else:
+        ref.apply_exponential(p2[:, :na], VHS)
+        ref.apply_exponential(p2[:, na:], VHS)
+    close(p2, d[tag + 'phi_exp'])
+    p3 = phi.copy()
+    ref.kinetic_real(p3, model.BH1, na)
+    close(p3, d[tag + 'phi_kin'])
+    close(numpy.array(model.local_energy(G, Ghalf)), d[tag + 'energy'])
+    if tag + 'step_phi' in d:
+        w = ref.new_walker(model, phi)
+        w['hybrid_energy'] = 0.25 + 0.1j
+        ref.propagate_walker_phaseless(model, w, xi, 0.3)
+        close(w['phi'], d[tag + 'step_phi'])
+        close(w['weight'], d[tag + 'step_weight'])
+        close(w['ot'], d[tag + 'step_ot'])
+        close(w['hybrid_energy'], d[tag + 'step_ehyb'])
+    p4 = phi.copy()
+    detR = ref.reortho(p4, na, nb)
+    close(p4, d[tag + 'phi_qr'])
+    close(detR, d[tag + 'detR'])
+
+
+def test_generic_ops(golden):
+    d = golden('generic_ops.npz')
+    for tag in ('A_', 'B_'):
+        check_single_walker_ops(d, tag, generic_model(d, tag))
+
+
+def test_generic_energy_known_answers(golden):
+    """estimators/tests/test_generic.py:45-47,62-64: half-rotated == full-G energy."""
+    d = golden('generic_ops.npz')
+    m = generic_model(d, 'A_')
+    pinned = (20.6826247016273, 23.0173528796140, -2.3347281779866)
+    G = d['A_trialG']
+    GH = [d['A_trialGH_a'], d['A_trialGH_b']]
+    e_opt = ref.local_energy_generic_cholesky_opt(m.H1, m.ecore, G, GH, m.rchol, m.na, m.nb)
+    e_full = ref.local_energy_generic_cholesky(m.H1, m.ecore, G, m.hs_pot)
+    for e in (e_opt, e_full, d['A_e_opt'], d['A_e_full']):
+        assert numpy.array(e).real == pytest.approx(pinned, rel=1e-10)
+
+
+def test_hubbard_ops(golden):
+    d = golden('hubbard_ops.npz')
+    check_single_walker_ops(d, 'C_', hubbard_model(d, 'C_', 'hubbard'))
+    check_single_walker_ops(d, 'S_', hubbard_model(d, 'S_', 'hubbard_spin'))
+
+
+def test_hubbard_spin_known_answer(golden):
+    """propagation/tests/test_hubbard.py:118-136: walker.ovlp.real == 0.765551499039435."""
+    d = golden('hubbard_ops.npz')
+    m = hubbard_model(d, 'S_', 'hubbard_spin')
+    w = ref.new_walker(m, m.psi)
+    ref.propagate_walker_phaseless(m, w, d['pin_xi'], 0.0)
+    assert w['ovlp'].real == pytest.approx(0.765551499039435, rel=1e-11)
+    assert abs(w['ovlp'].imag) < 1e-12
+
+
+def test_ueg_ops(golden):
+    d = golden('ueg_ops.npz')
+    m = ueg_model(d, 'U_')
+    check_single_walker_ops(d, 'U_', m)
+    # propagation/tests/test_planewave.py:12-38
+    _, Ghalf, G = ref.greens_function(d['pw_phi'], m.psi, m.na, m.nb)
+    fb = m.force_bias(Ghalf, G)
+    assert numpy.linalg.norm(fb) == pytest.approx(0.16660828645573392, rel=1e-11)
+    vhs = m.vhs(d['pw_xi'] - fb)
+    assert numpy.linalg.norm(vhs) == pytest.approx(0.1467322554815581, rel=1e-11)
+
+
+def run_traj(d, model):
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(model, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+
+    def xi_source(step, iw):
+        x = xi[step - 1, iw]
+        assert not numpy.isnan(x[0]), "oracle propagated a walker the reference skipped"
+        return x
+
+    rec = []
+    blocks = ref.run_afqmc(model, walkers, xi_source, lambda step: r[step - 1],
+                           int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
+                           npop_control=int(d['npop_control']),
+                           energy_eval_freq=int(d['energy_eval_freq']), record=rec)
+    return walkers, rec, blocks
+
+
+def check_traj(d, model, tol=1e-8):
+    walkers, rec, blocks = run_traj(d, model)
+    W = numpy.array([x['weight'] for x in rec])
+    close(W, d['weight'], tol)
+    close(numpy.array([x['unscaled_weight'] for x in rec]), d['unscaled_weight'], tol)
+    close(numpy.array([x['ot'] for x in rec]), d['ot'], tol)
+    close(numpy.array([x['hybrid_energy'] for x in rec]), d['ehyb'], tol)
+    pix = numpy.array([x['parent_ix'] for x in rec if x['parent_ix'] is not None])
+    assert numpy.array_equal(pix, d['parent_ix'])
+    B = numpy.array(blocks)
+    gold = d['blocks']                      # [nblocks+1, 1 + 10]: step, estimates
+    close(B[:, :9], gold[:, 1:10], tol)
+    close(numpy.array([w['phi'] for w in walkers]), d['final_phi'], tol)
+    # final estimator pass pinned by the reference's driver tests
+    est = numpy.zeros(10, dtype=numpy.complex128)
+    ref.mixed_update(model, est, walkers, 0, 1)
+    close(est[:9], d['final_estimates'][:9], tol)
+    return est
+
+
+def test_traj_generic(golden):
+    d = golden('traj_generic.npz')
+    est = check_traj(d, generic_model(d, ''))
+    # qmc/tests/test_afqmc.py:227
+    assert est[ref.EST['enumer']].real == pytest.approx(3.8763193646854273, rel=1e-9)
+
+
+def test_traj_hubbard(golden):
+    d = golden('traj_hubbard.npz')
+    est = check_traj(d, hubbard_model(d, '', 'hubbard'))
+    # qmc/tests/test_afqmc.py:186
+    assert est[ref.EST['enumer']].real == pytest.approx(-152.91937839611, rel=1e-9)
+
+
+def test_traj_hubbard_c1(golden):
+    d = golden('traj_hubbard_c1.npz')
+    check_traj(d, hubbard_model(d, '', 'hubbard'))
+    assert d['parent_ix'].shape[0] == 20           # comb every 5 steps
+
+
+def test_traj_ueg(golden):
+    d = golden('traj_ueg.npz')
+    est = check_traj(d, ueg_model(d, '', 'sys_'))
+    # qmc/tests/test_afqmc.py:87-92
+    assert est[ref.EST['enumer']].real == pytest.approx(16.33039729324558, rel=1e-9)
+    assert est[ref.EST['uweight']].real == pytest.approx(9.75405059997262, rel=1e-9)
+
+
+def test_comb_truncation_quirk():
+    """walkers/handler.py:301: zip(clone, kill) copies a multiplicity-3 parent once."""
+    w = numpy.array([3.0, 1e-9, 1e-9, 1.0 - 2e-9])
+    pix = ref.comb_parent_ix(w / (w.sum() / 4), 4, 0.5)
+    assert list(pix) == [3, 0, 0, 1]
+    assert ref.comb_pairs(pix) == [(0, 1)]
