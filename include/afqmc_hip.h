@@ -1,0 +1,190 @@
+/*
+ * afqmc_hip.h -- C ABI of libafqmc_hip.so: MI355X (gfx950) phaseless-AFQMC
+ * walker propagation, Green's functions and local energies, walker-batched.
+ *
+ * The reference (pauxy-qmc/pauxy) has no FFI on this path: the hot path sits
+ * behind the Python plug-in objects Propagator / Walkers / Estimators that
+ * pauxy/qmc/afqmc.py drives.  Each entry point below therefore cites the
+ * reference *Python* function it replaces (paths relative to the reference's
+ * pauxy/ package); pauxy_amd/ holds the Python classes that bind these entry
+ * points with ctypes behind the reference's own class/method names
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - plain C: opaque handle, pointers, ints, doubles.  Every function returns
+ *    0 (AFQ_OK) or a negative AFQ_E* code; afq_last_error() gives the text.
+ *  - "c128" = complex128 as numpy stores it: interleaved (re, im) doubles,
+ *    C order.  Host arrays are only read unless documented "out".
+ *  - one handle per GPU, owned by one host thread; calls on one handle are
+ *    serialised by the caller.  All work is queued on the handle's HIP stream;
+ *    functions that return data to the host synchronise that stream first.
+ *  - the handle owns every device allocation.
+ */
+#ifndef AFQMC_HIP_H
+#define AFQMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct afq_handle afq_handle;
+
+#define AFQ_OK            0
+#define AFQ_EINVAL       (-1)   /* bad argument                                  */
+#define AFQ_ESTATE       (-2)   /* call order: system/trial/propagator/walkers   */
+#define AFQ_EHIP         (-3)   /* HIP runtime error (text in afq_last_error)    */
+#define AFQ_ENOMEM       (-4)
+#define AFQ_EUNSUPPORTED (-5)
+#define AFQ_EWEIGHT      (-6)   /* total weight < 1e-8 (walkers/handler.py:236)  */
+
+/* system kinds */
+#define AFQ_SYS_GENERIC 1
+#define AFQ_SYS_HUBBARD 2
+#define AFQ_SYS_UEG     3
+
+/* propagator flags (propagation/continuous.py:18-37) */
+#define AFQ_PROP_HYBRID          1   /* hybrid weight update (default)            */
+#define AFQ_PROP_FORCE_BIAS      2
+#define AFQ_PROP_FREE_PROJECTION 4
+#define AFQ_PROP_HUBBARD_SPIN    8   /* charge_decomposition: false               */
+
+/* walker fields for afq_walkers_set / afq_walkers_get.
+ * per-walker shapes: PHI c128[M, na+nb]; WEIGHT, UNSCALED_WEIGHT, DETR f64;
+ * OT, HYBRID_ENERGY, PHASE, ELOC c128; GHALF c128[na+nb, M] (alpha rows first);
+ * G c128[2, M, M]; XBAR, XSHIFTED c128[K]; ENERGY c128[3]                       */
+enum afq_field {
+    AFQ_F_PHI = 0,
+    AFQ_F_WEIGHT = 1,
+    AFQ_F_UNSCALED_WEIGHT = 2,
+    AFQ_F_OT = 3,
+    AFQ_F_HYBRID_ENERGY = 4,
+    AFQ_F_PHASE = 5,
+    AFQ_F_DETR = 6,
+    AFQ_F_ELOC = 7,
+    AFQ_F_GHALF = 8,
+    AFQ_F_G = 9,
+    AFQ_F_XBAR = 10,
+    AFQ_F_XSHIFTED = 11,
+    AFQ_F_ENERGY = 12,
+    AFQ_F_COUNT_
+};
+
+/* index of each accumulator in the estimates vector (estimators/mixed.py:460-469) */
+enum afq_estimate {
+    AFQ_EST_UWEIGHT = 0, AFQ_EST_WEIGHT = 1, AFQ_EST_ENUMER = 2, AFQ_EST_EDENOM = 3,
+    AFQ_EST_EPROJ = 4, AFQ_EST_E1B = 5, AFQ_EST_E2B = 6, AFQ_EST_EHYB = 7,
+    AFQ_EST_OVLP = 8, AFQ_EST_TIME = 9, AFQ_EST_COUNT_ = 10
+};
+
+/* ---- lifetime ----------------------------------------------------------- */
+int afq_version(void);
+int afq_create(int device_id, afq_handle **out);
+int afq_destroy(afq_handle *h);
+const char *afq_last_error(afq_handle *h);
+int afq_sync(afq_handle *h);
+
+/* ---- read-only inputs of the path --------------------------------------- */
+/* systems/generic.py:74-166 arrays.  hs_pot f64[M*M, K] (= chol_vecs);
+ * rchol c128[(na+nb)*M, K], row i*M+p, alpha block first
+ * (trial_wavefunction/multi_slater.py:402-409); H1 c128[2,M,M].              */
+int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb,
+                           const double *hs_pot, const double *rchol,
+                           const double *H1, double ecore);
+/* systems/hubbard.py:46-104.  T c128[2,M,M]; fields K = M.                    */
+int afq_set_system_hubbard(afq_handle *h, int M, int na, int nb, double U,
+                           const double *T);
+/* systems/ueg.py:43-191,336-428.  iA, iB: CSC [M*M, nq] (colptr int64[nq+1],
+ * rowidx int64[nnz], val c128[nnz]); the four ragged index lists of
+ * systems/ueg.py:139-176 as offsets int64[nq+1] + flat int64 indices;
+ * vqvec f64[nq]; H1diag f64[2,M]; fields K = 2*nq.                            */
+int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
+                       const int64_t *iA_colptr, const int64_t *iA_row, const double *iA_val,
+                       const int64_t *iB_colptr, const int64_t *iB_row, const double *iB_val,
+                       const int64_t *kpq_off, const int64_t *kpq_i, const int64_t *kpq_kpq,
+                       const int64_t *pmq_off, const int64_t *pmq_i, const int64_t *pmq_pmq,
+                       const double *vqvec, double vol, const double *H1diag, double ecore);
+/* trial determinant psi c128[M, na+nb] (trial.psi after walkers/handler.py:61) */
+int afq_set_trial(afq_handle *h, const double *psi);
+/* propagation/continuous.py:13-80 + <system>.construct_one_body_propagator:
+ * BH1 c128[2,M,M], mf_shift c128[K], dt, expansion_order, AFQ_PROP_* flags.    */
+int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
+                       double dt, int exp_order, int flags);
+
+/* ---- walker population (walkers/handler.py:36-164, walkers/walker.py:24-61) */
+int afq_walkers_alloc(afq_handle *h, int nw);
+int afq_walkers_set(afq_handle *h, int field, const void *host, int first, int count);
+int afq_walkers_get(afq_handle *h, int field, void *host, int first, int count);
+/* device pointer of a field (row `first`), for zero-copy plumbing */
+int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *bytes_per_walker);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* walkers/single_det.py:295-321 for every walker: Ghalf (+ full G when
+ * want_G or the system needs it) and det(phi^T psi*) -> ovlp_out c128[nw]
+ * (may be NULL).                                                            */
+int afq_greens(afq_handle *h, int want_G, double *ovlp_out);
+/* walkers/single_det.py:170-199 for every walker -> ovlp_out c128[nw]         */
+int afq_calc_overlap(afq_handle *h, double *ovlp_out);
+/* propagation/continuous.py:232-262 (phaseless) or :175-200 (free projection)
+ * for every live walker (|weight| > 1e-8, qmc/afqmc.py:232).
+ * xi: host f64[nw, K] normal fields (row iw used only if walker iw is live),
+ * or NULL to draw them on the device (afq_rng_seed).                         */
+int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im);
+/* walkers/handler.py:166-181 -> walkers/single_det.py:215-255; detR f64[nw] out (may be NULL) */
+int afq_reortho(afq_handle *h, double *detR_out);
+/* estimators/mixed.py:383-437 dispatch for every walker, from the current
+ * Ghalf/G (call afq_greens first): E c128[nw,3] = (E, E1, E2); may be NULL.   */
+int afq_local_energy(afq_handle *h, double *E_out);
+
+/* unit-test hooks (reference: <system propagator>.construct_force_bias /
+ * construct_VHS, Continuous.apply_exponential, operations.kinetic_real)       */
+int afq_force_bias(afq_handle *h, double *xbar_out);                 /* c128[nw,K] */
+int afq_shift_fields(afq_handle *h, const double *xi, const double *xbar,
+                     double *xs_out, double *cmf_out, double *cfb_out); /* continuous.py:140-158 */
+int afq_vhs(afq_handle *h, const double *xs, double *vhs_out);       /* c128[nw,nv,M,M] */
+int afq_vhs_count(afq_handle *h, int *nv);                           /* 1, or 2 for spin HS */
+int afq_apply_exponential(afq_handle *h, const double *vhs);         /* phi <- Taylor(vhs) phi */
+int afq_kinetic(afq_handle *h);                                      /* phi <- BH1 phi */
+
+/* ---- driver glue that must stay on the device between steps --------------- */
+/* qmc/afqmc.py:235-236: weight > frac*total_weight -> frac*total_weight        */
+int afq_cap_weights(afq_handle *h, double frac, double total_weight);
+/* walkers/handler.py:225-338 for a single rank: rescale, comb with the uniform
+ * r, clone/kill, weights reset to 1.  parent_ix int32[nw] out (may be NULL);
+ * total_weight_out f64 (may be NULL).                                          */
+int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
+                        int32_t *parent_ix, double *total_weight_out);
+/* multi-rank building blocks: scale weights by 1/scale saving unscaled_weight
+ * (handler.py:244-246); copy walker src -> dst inside this GPU; pack / unpack
+ * the minimal walker state (phi + scalars) to a device buffer for transport;
+ * reset all weights to 1 (handler.py:337-338).                                 */
+int afq_walkers_scale_weights(afq_handle *h, double scale);
+int afq_walkers_copy(afq_handle *h, int src, int dst);
+int afq_walker_pack_bytes(afq_handle *h, int64_t *bytes);
+int afq_walker_pack(afq_handle *h, int iw, void *dev_buf);
+int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf);
+int afq_walkers_reset_weights(afq_handle *h);
+/* estimators/mixed.py:180-225: accumulate the 10 mixed estimators over all
+ * walkers on the device; eval_energy != 0 runs afq_greens + afq_local_energy. */
+int afq_estimates_update(afq_handle *h, int eval_energy);
+int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
+
+/* ---- misc ------------------------------------------------------------------ */
+int afq_rng_seed(afq_handle *h, uint64_t seed, uint64_t stream);
+/* counters: [0]=nfb_trig (continuous.py:150), [1]=nhe_trig (:210,213)          */
+int afq_counters(afq_handle *h, int64_t *out, int reset);
+/* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields
+ * [3] vhs [4] exponential [5] overlap+weight [6] reortho [7] energy            */
+int afq_timers(afq_handle *h, double *out_ms, int reset);
+int afq_enable_timers(afq_handle *h, int on);
+/* HIP stream of the handle (hipStream_t as void*) */
+int afq_stream(afq_handle *h, void **stream);
+/* duration of the last afq_local_energy exchange kernel, HIP events on the
+ * handle's stream (bench.py roofline)                                          */
+int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFQMC_HIP_H */

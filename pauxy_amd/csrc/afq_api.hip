@@ -1,0 +1,769 @@
+// C ABI of libafqmc_hip.so (see include/afqmc_hip.h): handle lifetime, uploads of
+// the read-only inputs, walker storage, and the sequencing of the kernels that
+// make up one propagation step (propagation/continuous.py:232-262).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "afq_internal.h"
+
+namespace {
+
+template <class T> int dev_alloc(afq_handle *h, T **p, size_t n) {
+    if (*p) { hipFree(*p); *p = nullptr; }
+    if (n == 0) return AFQ_OK;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return AFQ_ENOMEM; }
+    return AFQ_OK;
+}
+
+template <class T> int dev_upload(afq_handle *h, T **p, const void *src, size_t n) {
+    int rc = dev_alloc(h, p, n);
+    if (rc) return rc;
+    if (n) AFQ_HIP(h, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return AFQ_OK;
+}
+
+template <class T> void dev_free(T *&p) { if (p) { hipFree(p); p = nullptr; } }
+
+void free_system(afq_handle *h) {
+    dev_free(h->hs_pot); dev_free(h->rchol_re); dev_free(h->rchol_im);
+    for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
+    dev_free(h->H1); dev_free(h->rH1);
+    dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val);
+    dev_free(h->iB_colptr); dev_free(h->iB_row); dev_free(h->iB_val);
+    dev_free(h->iA_rowptr); dev_free(h->iA_col); dev_free(h->iA_rval);
+    dev_free(h->iB_rowptr); dev_free(h->iB_col); dev_free(h->iB_rval);
+    dev_free(h->kpq_off); dev_free(h->kpq_i); dev_free(h->kpq_kpq);
+    dev_free(h->pmq_off); dev_free(h->pmq_i); dev_free(h->pmq_pmq);
+    dev_free(h->vqvec); dev_free(h->H1diag);
+    h->kind = 0;
+}
+
+void free_walkers(afq_handle *h) {
+    dev_free(h->phi); dev_free(h->phi_t); dev_free(h->phi_t2);
+    dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR);
+    dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
+    dev_free(h->ghalf); dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
+    dev_free(h->xi); dev_free(h->vbias); dev_free(h->xbar); dev_free(h->xs);
+    dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
+    dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
+    dev_free(h->alive); dev_free(h->parent_ix);
+    if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }
+    h->exx_part_len = 0; h->gfrag_bytes = 0; h->nw = 0;
+}
+
+// rH1[i, q] = sum_p conj(psi[p, i]) H1_s[p, q]  (s = spin of orbital i)
+int build_rH1(afq_handle *h, const std::vector<double> &H1, const std::vector<double> &psi) {
+    const int M = h->M, nt = h->nt;
+    std::vector<double> r((size_t)nt * M * 2, 0.0);
+    for (int i = 0; i < nt; ++i) {
+        const int s = i < h->na ? 0 : 1;
+        for (int p = 0; p < M; ++p) {
+            const double cr = psi[((size_t)p * nt + i) * 2], ci = -psi[((size_t)p * nt + i) * 2 + 1];
+            if (cr == 0.0 && ci == 0.0) continue;
+            const double *hrow = &H1[(((size_t)s * M + p) * M) * 2];
+            double *out = &r[(size_t)i * M * 2];
+            for (int q = 0; q < M; ++q) {
+                const double hr = hrow[2 * q], hi = hrow[2 * q + 1];
+                out[2 * q] += cr * hr - ci * hi;
+                out[2 * q + 1] += cr * hi + ci * hr;
+            }
+        }
+    }
+    return dev_upload(h, &h->rH1, r.data(), (size_t)nt * M);
+}
+
+}  // namespace
+
+// host copies kept for derived operands (small: H1 and psi only)
+struct afq_host_cache {
+    std::vector<double> H1, psi;
+};
+static afq_host_cache *cache_of(afq_handle *h);
+
+struct afq_handle_full : afq_handle {
+    afq_host_cache cache;
+};
+static afq_host_cache *cache_of(afq_handle *h) { return &static_cast<afq_handle_full *>(h)->cache; }
+
+static int maybe_build_rH1(afq_handle *h) {
+    afq_host_cache *c = cache_of(h);
+    if (h->kind == 0 || !h->have_trial || c->H1.empty()) return AFQ_OK;
+    return build_rH1(h, c->H1, c->psi);
+}
+
+extern "C" {
+
+int afq_version(void) { return 1; }
+
+int afq_create(int device_id, afq_handle **out) {
+    if (!out) return AFQ_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AFQ_EHIP;
+    if (device_id < 0 || device_id >= ndev) return AFQ_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return AFQ_EHIP;
+    afq_handle_full *h = new afq_handle_full();
+    h->device = device_id;
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return AFQ_EHIP; }
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    hipEventCreate(&h->ev_e0); hipEventCreate(&h->ev_e1);
+    if (hipMalloc(&h->estimates, sizeof(cplx) * AFQ_EST_COUNT_) != hipSuccess ||
+        hipMalloc(&h->counters, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc(&h->scal, sizeof(double) * 8) != hipSuccess) { delete h; return AFQ_ENOMEM; }
+    hipMemset(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_);
+    hipMemset(h->counters, 0, sizeof(unsigned long long) * 4);
+    hipMemset(h->scal, 0, sizeof(double) * 8);
+    *out = h;
+    return AFQ_OK;
+}
+
+int afq_destroy(afq_handle *h) {
+    if (!h) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_walkers(h);
+    free_system(h);
+    dev_free(h->psi); dev_free(h->BH1); dev_free(h->mf_shift);
+    dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
+    hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
+    hipStreamDestroy(h->stream);
+    delete static_cast<afq_handle_full *>(h);
+    return AFQ_OK;
+}
+
+const char *afq_last_error(afq_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int afq_sync(afq_handle *h) {
+    if (!h) return AFQ_EINVAL;
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    return AFQ_OK;
+}
+
+int afq_stream(afq_handle *h, void **stream) {
+    if (!h || !stream) return AFQ_EINVAL;
+    *stream = (void *)h->stream;
+    return AFQ_OK;
+}
+
+// ------------------------------------------------------------------ systems
+static int set_dims(afq_handle *h, int kind, int M, int K, int na, int nb) {
+    if (M <= 0 || K <= 0 || na <= 0 || nb < 0 || na > M || nb > M) AFQ_FAIL(h, AFQ_EINVAL, "bad dimensions");
+    hipSetDevice(h->device);
+    free_system(h);
+    free_walkers(h);
+    h->have_trial = false; h->have_prop = false;
+    h->kind = kind; h->M = M; h->K = K; h->na = na; h->nb = nb; h->nt = na + nb;
+    return AFQ_OK;
+}
+
+int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const double *hs_pot,
+                           const double *rchol, const double *H1, double ecore) {
+    if (!h || !hs_pot || !rchol || !H1) return AFQ_EINVAL;
+    int rc = set_dims(h, AFQ_SYS_GENERIC, M, K, na, nb);
+    if (rc) return rc;
+    h->ecore = ecore;
+    const size_t mm = (size_t)M * M, nq = (size_t)h->nt * M;
+    {   // hs_pot^T : [K, M*M] so that a VHS B-fragment is contiguous
+        std::vector<double> t((size_t)K * mm);
+        for (size_t r = 0; r < mm; ++r)
+            for (int n = 0; n < K; ++n) t[(size_t)n * mm + r] = hs_pot[r * K + n];
+        if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
+    }
+    {   // split rchol into planar re / im
+        std::vector<double> re(nq * K), im;
+        bool real = true;
+        for (size_t e = 0; e < nq * K; ++e) {
+            re[e] = rchol[2 * e];
+            if (rchol[2 * e + 1] != 0.0) real = false;
+        }
+        h->rchol_real = real;
+        if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
+        if (!real) {
+            im.resize(nq * K);
+            for (size_t e = 0; e < nq * K; ++e) im[e] = rchol[2 * e + 1];
+            if ((rc = dev_upload(h, &h->rchol_im, im.data(), im.size()))) return rc;
+        }
+    }
+    if ((rc = k_prepare_energy_operands(h, rchol))) return rc;
+    if ((rc = dev_upload(h, &h->H1, H1, 2 * mm))) return rc;
+    cache_of(h)->H1.assign(H1, H1 + 4 * mm);
+    return AFQ_OK;
+}
+
+int afq_set_system_hubbard(afq_handle *h, int M, int na, int nb, double U, const double *T) {
+    if (!h || !T) return AFQ_EINVAL;
+    int rc = set_dims(h, AFQ_SYS_HUBBARD, M, M, na, nb);
+    if (rc) return rc;
+    h->U = U; h->ecore = 0.0;
+    const size_t mm = (size_t)M * M;
+    if ((rc = dev_upload(h, &h->H1, T, 2 * mm))) return rc;
+    cache_of(h)->H1.assign(T, T + 4 * mm);
+    return AFQ_OK;
+}
+
+static int csc_to_csr(afq_handle *h, int nrow, int ncol, const int64_t *cp, const int64_t *row, const double *val,
+                      int64_t **rp_d, int64_t **col_d, cplx **val_d) {
+    const int64_t nnz = cp[ncol];
+    std::vector<int64_t> rp(nrow + 1, 0), col(nnz);
+    std::vector<double> v(2 * nnz);
+    for (int64_t z = 0; z < nnz; ++z) rp[row[z] + 1]++;
+    for (int r = 0; r < nrow; ++r) rp[r + 1] += rp[r];
+    std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+    for (int c = 0; c < ncol; ++c)
+        for (int64_t z = cp[c]; z < cp[c + 1]; ++z) {
+            const int64_t d = fill[row[z]]++;
+            col[d] = c; v[2 * d] = val[2 * z]; v[2 * d + 1] = val[2 * z + 1];
+        }
+    int rc;
+    if ((rc = dev_upload(h, rp_d, rp.data(), rp.size()))) return rc;
+    if ((rc = dev_upload(h, col_d, col.data(), col.size()))) return rc;
+    return dev_upload(h, val_d, v.data(), (size_t)nnz);
+}
+
+int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64_t *iA_colptr,
+                       const int64_t *iA_row, const double *iA_val, const int64_t *iB_colptr,
+                       const int64_t *iB_row, const double *iB_val, const int64_t *kpq_off,
+                       const int64_t *kpq_i, const int64_t *kpq_kpq, const int64_t *pmq_off,
+                       const int64_t *pmq_i, const int64_t *pmq_pmq, const double *vqvec, double vol,
+                       const double *H1diag, double ecore) {
+    if (!h || !iA_colptr || !iB_colptr || !kpq_off || !pmq_off || !vqvec || !H1diag) return AFQ_EINVAL;
+    int rc = set_dims(h, AFQ_SYS_UEG, M, 2 * nq, na, nb);
+    if (rc) return rc;
+    h->nq = nq; h->vol = vol; h->ecore = ecore;
+    h->nnzA = iA_colptr[nq]; h->nnzB = iB_colptr[nq];
+    if ((rc = dev_upload(h, &h->iA_colptr, iA_colptr, (size_t)nq + 1))) return rc;
+    if ((rc = dev_upload(h, &h->iA_row, iA_row, (size_t)h->nnzA))) return rc;
+    if ((rc = dev_upload(h, &h->iA_val, iA_val, (size_t)h->nnzA))) return rc;
+    if ((rc = dev_upload(h, &h->iB_colptr, iB_colptr, (size_t)nq + 1))) return rc;
+    if ((rc = dev_upload(h, &h->iB_row, iB_row, (size_t)h->nnzB))) return rc;
+    if ((rc = dev_upload(h, &h->iB_val, iB_val, (size_t)h->nnzB))) return rc;
+    if ((rc = csc_to_csr(h, M * M, nq, iA_colptr, iA_row, iA_val, &h->iA_rowptr, &h->iA_col, &h->iA_rval))) return rc;
+    if ((rc = csc_to_csr(h, M * M, nq, iB_colptr, iB_row, iB_val, &h->iB_rowptr, &h->iB_col, &h->iB_rval))) return rc;
+    if ((rc = dev_upload(h, &h->kpq_off, kpq_off, (size_t)nq + 1))) return rc;
+    if ((rc = dev_upload(h, &h->kpq_i, kpq_i, (size_t)kpq_off[nq]))) return rc;
+    if ((rc = dev_upload(h, &h->kpq_kpq, kpq_kpq, (size_t)kpq_off[nq]))) return rc;
+    if ((rc = dev_upload(h, &h->pmq_off, pmq_off, (size_t)nq + 1))) return rc;
+    if ((rc = dev_upload(h, &h->pmq_i, pmq_i, (size_t)pmq_off[nq]))) return rc;
+    if ((rc = dev_upload(h, &h->pmq_pmq, pmq_pmq, (size_t)pmq_off[nq]))) return rc;
+    if ((rc = dev_upload(h, &h->vqvec, vqvec, (size_t)nq))) return rc;
+    if ((rc = dev_upload(h, &h->H1diag, H1diag, (size_t)2 * M))) return rc;
+    cache_of(h)->H1.clear();
+    return AFQ_OK;
+}
+
+int afq_set_trial(afq_handle *h, const double *psi) {
+    if (!h || !psi) return AFQ_EINVAL;
+    if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the trial");
+    hipSetDevice(h->device);
+    const size_t n = (size_t)h->M * h->nt;
+    int rc = dev_upload(h, &h->psi, psi, n);
+    if (rc) return rc;
+    cache_of(h)->psi.assign(psi, psi + 2 * n);
+    h->have_trial = true;
+    return maybe_build_rH1(h);
+}
+
+int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift, double dt, int exp_order,
+                       int flags) {
+    if (!h || !BH1 || !mf_shift || dt <= 0 || exp_order < 0) return AFQ_EINVAL;
+    if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the propagator");
+    if (!(flags & AFQ_PROP_HYBRID) && !(flags & AFQ_PROP_FREE_PROJECTION))
+        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "local-energy weight update (hybrid=False) is not implemented");
+    hipSetDevice(h->device);
+    int rc;
+    if ((rc = dev_upload(h, &h->BH1, BH1, (size_t)2 * h->M * h->M))) return rc;
+    if ((rc = dev_upload(h, &h->mf_shift, mf_shift, (size_t)h->K))) return rc;
+    h->dt = dt; h->sqrt_dt = std::pow(dt, 0.5); h->exp_order = exp_order;
+    if (flags & AFQ_PROP_FREE_PROJECTION) flags &= ~AFQ_PROP_FORCE_BIAS;   // continuous.py:30-33
+    const int old_nv = h->nv; const bool old_diag = h->vhs_diag;
+    h->flags = flags;
+    h->vhs_diag = h->kind == AFQ_SYS_HUBBARD;
+    h->nv = (h->kind == AFQ_SYS_HUBBARD && (flags & AFQ_PROP_HUBBARD_SPIN)) ? 2 : 1;
+    h->have_prop = true;
+    if (h->nw && (old_nv != h->nv || old_diag != h->vhs_diag || !h->vhs)) {
+        const size_t per = h->vhs_diag ? (size_t)h->nv * h->M : (size_t)h->nv * h->M * h->M;
+        if ((rc = dev_alloc(h, &h->vhs, per * h->nw))) return rc;
+    }
+    return AFQ_OK;
+}
+
+// ------------------------------------------------------------------ walkers
+int afq_walkers_alloc(afq_handle *h, int nw) {
+    if (!h || nw <= 0) return AFQ_EINVAL;
+    if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before allocating walkers");
+    hipSetDevice(h->device);
+    free_walkers(h);
+    const size_t per = (size_t)h->M * h->nt, K = h->K, n = nw;
+    int rc;
+#define A_(ptr, cnt) if ((rc = dev_alloc(h, &(ptr), (cnt)))) return rc;
+    A_(h->phi, per * n) A_(h->phi_t, per * n) A_(h->phi_t2, per * n)
+    A_(h->weight, n) A_(h->unscaled, n) A_(h->detR, n)
+    A_(h->ot, n) A_(h->ehyb, n) A_(h->phase, n) A_(h->eloc, n)
+    A_(h->ghalf, per * n) A_(h->ovlp_old, n) A_(h->ovlp_new, n)
+    A_(h->xi, K * n) A_(h->xbar, K * n) A_(h->xs, K * n) A_(h->cmf, n) A_(h->cfb, n)
+    A_(h->energy, 3 * n) A_(h->alive, n) A_(h->parent_ix, n)
+    // force-bias contraction slices: enough wave-tasks to fill 1024 SIMDs
+    h->fb_split = 1;
+    if (h->kind == AFQ_SYS_GENERIC) {
+        const long tiles = (long)((nw + 31) / 32) * ((h->K + 31) / 32) * 2;
+        int sp = (int)std::max(1L, std::min(8L, 1024 / std::max(1L, tiles)));
+        const int nmax = std::max(h->na, h->nb) * h->M;
+        while (sp > 1 && nmax / sp < 64) --sp;
+        h->fb_split = sp;
+        A_(h->vbias, (size_t)2 * sp * n * K)
+    } else if (h->kind == AFQ_SYS_UEG) {
+        A_(h->vbias, n * K)
+    }
+    if (h->kind == AFQ_SYS_UEG) A_(h->G, (size_t)2 * h->M * h->M * n)
+    {
+        const size_t pv = h->kind == AFQ_SYS_HUBBARD ? (size_t)2 * h->M : (size_t)h->M * h->M;
+        A_(h->vhs, pv * n)
+    }
+#undef A_
+    AFQ_HIP(h, hipMalloc(&h->pack_tmp, std::max((size_t)nw * 2 * sizeof(int), (size_t)4096)));
+    h->nw = nw;
+    // defaults of walkers/walker.py:24-61
+    std::vector<double> one(nw, 1.0), zero2(2 * (size_t)nw, 0.0), one2(2 * (size_t)nw, 0.0);
+    for (int i = 0; i < nw; ++i) one2[2 * i] = 1.0;
+    AFQ_HIP(h, hipMemcpy(h->weight, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->unscaled, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->detR, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->ot, one2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->phase, one2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->ehyb, zero2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemcpy(h->eloc, zero2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemset(h->phi, 0, sizeof(cplx) * per * n));
+    AFQ_HIP(h, hipMemset(h->ghalf, 0, sizeof(cplx) * per * n));
+    AFQ_HIP(h, hipMemset(h->energy, 0, sizeof(cplx) * 3 * n));
+    AFQ_HIP(h, hipMemset(h->xi, 0, sizeof(double) * K * n));
+    return AFQ_OK;
+}
+
+static int field_info(afq_handle *h, int field, void **base, size_t *bytes) {
+    const size_t per = (size_t)h->M * h->nt;
+    switch (field) {
+    case AFQ_F_PHI: *base = h->phi; *bytes = per * sizeof(cplx); break;
+    case AFQ_F_WEIGHT: *base = h->weight; *bytes = sizeof(double); break;
+    case AFQ_F_UNSCALED_WEIGHT: *base = h->unscaled; *bytes = sizeof(double); break;
+    case AFQ_F_OT: *base = h->ot; *bytes = sizeof(cplx); break;
+    case AFQ_F_HYBRID_ENERGY: *base = h->ehyb; *bytes = sizeof(cplx); break;
+    case AFQ_F_PHASE: *base = h->phase; *bytes = sizeof(cplx); break;
+    case AFQ_F_DETR: *base = h->detR; *bytes = sizeof(double); break;
+    case AFQ_F_ELOC: *base = h->eloc; *bytes = sizeof(cplx); break;
+    case AFQ_F_GHALF: *base = h->ghalf; *bytes = per * sizeof(cplx); break;
+    case AFQ_F_G: *base = h->G; *bytes = (size_t)2 * h->M * h->M * sizeof(cplx); break;
+    case AFQ_F_XBAR: *base = h->xbar; *bytes = (size_t)h->K * sizeof(cplx); break;
+    case AFQ_F_XSHIFTED: *base = h->xs; *bytes = (size_t)h->K * sizeof(cplx); break;
+    case AFQ_F_ENERGY: *base = h->energy; *bytes = 3 * sizeof(cplx); break;
+    default: AFQ_FAIL(h, AFQ_EINVAL, "unknown walker field");
+    }
+    if (!*base) AFQ_FAIL(h, AFQ_ESTATE, "walker field not allocated (afq_walkers_alloc / afq_greens first)");
+    return AFQ_OK;
+}
+
+int afq_walkers_set(afq_handle *h, int field, const void *host, int first, int count) {
+    if (!h || !host) return AFQ_EINVAL;
+    if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
+    if (first < 0 || count < 0 || first + count > h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker range out of bounds");
+    hipSetDevice(h->device);
+    void *base; size_t bytes;
+    int rc = field_info(h, field, &base, &bytes);
+    if (rc) return rc;
+    AFQ_HIP(h, hipMemcpyAsync((char *)base + bytes * first, host, bytes * count, hipMemcpyHostToDevice, h->stream));
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    return AFQ_OK;
+}
+
+int afq_walkers_get(afq_handle *h, int field, void *host, int first, int count) {
+    if (!h || !host) return AFQ_EINVAL;
+    if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
+    if (first < 0 || count < 0 || first + count > h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker range out of bounds");
+    hipSetDevice(h->device);
+    void *base; size_t bytes;
+    int rc = field_info(h, field, &base, &bytes);
+    if (rc) return rc;
+    AFQ_HIP(h, hipMemcpyAsync(host, (char *)base + bytes * first, bytes * count, hipMemcpyDeviceToHost, h->stream));
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    return AFQ_OK;
+}
+
+int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *bytes_per_walker) {
+    if (!h || !dev_ptr) return AFQ_EINVAL;
+    void *base; size_t bytes;
+    int rc = field_info(h, field, &base, &bytes);
+    if (rc) return rc;
+    *dev_ptr = base;
+    if (bytes_per_walker) *bytes_per_walker = (int64_t)bytes;
+    return AFQ_OK;
+}
+
+// ----------------------------------------------------------------- hot path
+static int need_ready(afq_handle *h, bool prop) {
+    if (!h->kind || !h->have_trial || !h->nw) AFQ_FAIL(h, AFQ_ESTATE, "system, trial and walkers must be set");
+    if (prop && !h->have_prop) AFQ_FAIL(h, AFQ_ESTATE, "propagator not set");
+    hipSetDevice(h->device);
+    return AFQ_OK;
+}
+
+static int ensure_G(afq_handle *h) {
+    if (!h->G) {
+        int rc = dev_alloc(h, &h->G, (size_t)2 * h->M * h->M * h->nw);
+        if (rc) return rc;
+    }
+    return AFQ_OK;
+}
+
+static int copy_out(afq_handle *h, void *host, const void *dev, size_t bytes) {
+    if (!host) return AFQ_OK;
+    AFQ_HIP(h, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    return AFQ_OK;
+}
+
+int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    {
+        PhaseTimer t(h, T_GREENS);
+        if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        if (want_G || h->kind == AFQ_SYS_UEG) {
+            if ((rc = ensure_G(h))) return rc;
+            if ((rc = k_full_G(h))) return rc;
+        }
+    }
+    return copy_out(h, ovlp_out, h->ovlp_old, sizeof(cplx) * h->nw);
+}
+
+int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    {
+        PhaseTimer t(h, T_OVLP);
+        if ((rc = k_overlap(h, h->ovlp_new))) return rc;
+    }
+    return copy_out(h, ovlp_out, h->ovlp_new, sizeof(cplx) * h->nw);
+}
+
+// force bias from the current Ghalf / G -> h->xbar (unclipped)
+static int force_bias(afq_handle *h) {
+    int rc;
+    if (h->flags & AFQ_PROP_FORCE_BIAS) {
+        if (h->kind == AFQ_SYS_GENERIC) { if ((rc = k_force_bias_generic(h))) return rc; }
+        else if (h->kind == AFQ_SYS_UEG) { if ((rc = k_vbias_ueg(h))) return rc; }
+    }
+    return k_xbar(h);
+}
+
+static int build_vhs(afq_handle *h) {
+    if (h->kind == AFQ_SYS_GENERIC) return k_vhs_generic(h);
+    if (h->kind == AFQ_SYS_HUBBARD) return k_vhs_hubbard(h);
+    return k_vhs_ueg(h);
+}
+
+static int apply_exp(afq_handle *h, const cplx *vhs) {
+    if (h->vhs_diag) return k_apply_exponential_diag(h, vhs);
+    return k_apply_exponential(h, vhs);
+}
+
+int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if ((rc = k_alive(h))) return rc;
+    if (xi) {
+        AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
+    } else {
+        if ((rc = k_rng_normal(h))) return rc;
+    }
+    const bool fp = (h->flags & AFQ_PROP_FREE_PROJECTION) != 0;
+    if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
+        PhaseTimer t(h, T_GREENS);                         // continuous.py:245
+        if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        if (h->kind == AFQ_SYS_UEG && (h->flags & AFQ_PROP_FORCE_BIAS)) {
+            if ((rc = ensure_G(h))) return rc;
+            if ((rc = k_full_G(h))) return rc;
+        }
+    }
+    { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }            // :251
+    {
+        PhaseTimer t(h, T_FB);                                                      // :133-158
+        if ((rc = force_bias(h))) return rc;
+        if ((rc = k_fields(h))) return rc;
+    }
+    { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                // :161
+    { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }        // :162-171
+    { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }            // :258
+    {
+        PhaseTimer t(h, T_OVLP);                                                    // :261-262
+        if ((rc = k_overlap(h, h->ovlp_new))) return rc;
+        if ((rc = k_update_weight(h, cmake(eshift_re, eshift_im)))) return rc;
+    }
+    return AFQ_OK;
+}
+
+int afq_reortho(afq_handle *h, double *detR_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    { PhaseTimer t(h, T_QR); if ((rc = k_reortho(h))) return rc; }
+    return copy_out(h, detR_out, h->detR, sizeof(double) * h->nw);
+}
+
+static int local_energy(afq_handle *h) {
+    if (h->kind == AFQ_SYS_GENERIC) return k_energy_generic(h);
+    if (h->kind == AFQ_SYS_HUBBARD) return k_energy_hubbard(h);
+    if (!h->G) AFQ_FAIL(h, AFQ_ESTATE, "afq_greens must run before afq_local_energy");
+    return k_energy_ueg(h);
+}
+
+int afq_local_energy(afq_handle *h, double *E_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (!h->rH1 && h->kind != AFQ_SYS_UEG) AFQ_FAIL(h, AFQ_ESTATE, "half-rotated H1 missing (set trial)");
+    { PhaseTimer t(h, T_ENERGY); if ((rc = local_energy(h))) return rc; }
+    return copy_out(h, E_out, h->energy, sizeof(cplx) * 3 * h->nw);
+}
+
+int afq_last_energy_kernel_ms(afq_handle *h, double *ms) {
+    if (!h || !ms) return AFQ_EINVAL;
+    if (!h->energy_ev_valid) AFQ_FAIL(h, AFQ_ESTATE, "no exchange kernel launched yet");
+    AFQ_HIP(h, hipEventSynchronize(h->ev_e1));
+    float f = 0;
+    AFQ_HIP(h, hipEventElapsedTime(&f, h->ev_e0, h->ev_e1));
+    *ms = f;
+    return AFQ_OK;
+}
+
+// ---------------------------------------------------------------- test hooks
+int afq_force_bias(afq_handle *h, double *xbar_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if ((rc = force_bias(h))) return rc;
+    return copy_out(h, xbar_out, h->xbar, sizeof(cplx) * (size_t)h->nw * h->K);
+}
+
+int afq_shift_fields(afq_handle *h, const double *xi, const double *xbar, double *xs_out, double *cmf_out,
+                     double *cfb_out) {
+    if (!h || !xi || !xbar) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    const size_t n = (size_t)h->nw * h->K;
+    AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    AFQ_HIP(h, hipMemcpyAsync(h->xbar, xbar, sizeof(cplx) * n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = k_fields_explicit(h, h->xi, h->xbar, h->xs, h->cmf, h->cfb))) return rc;
+    if ((rc = copy_out(h, xs_out, h->xs, sizeof(cplx) * n))) return rc;
+    if ((rc = copy_out(h, cmf_out, h->cmf, sizeof(cplx) * h->nw))) return rc;
+    return copy_out(h, cfb_out, h->cfb, sizeof(cplx) * h->nw);
+}
+
+int afq_vhs_count(afq_handle *h, int *nv) {
+    if (!h || !nv) return AFQ_EINVAL;
+    *nv = h->nv;
+    return AFQ_OK;
+}
+
+// Dense M x M matrices out, whatever the internal storage
+int afq_vhs(afq_handle *h, const double *xs, double *vhs_out) {
+    if (!h || !xs || !vhs_out) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    const size_t n = (size_t)h->nw * h->K;
+    AFQ_HIP(h, hipMemcpyAsync(h->xs, xs, sizeof(cplx) * n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = build_vhs(h))) return rc;
+    const size_t mm = (size_t)h->M * h->M;
+    if (!h->vhs_diag) return copy_out(h, vhs_out, h->vhs, sizeof(cplx) * mm * h->nv * h->nw);
+    std::vector<double> d((size_t)2 * h->nw * h->nv * h->M);
+    if ((rc = copy_out(h, d.data(), h->vhs, sizeof(cplx) * (size_t)h->nw * h->nv * h->M))) return rc;
+    std::memset(vhs_out, 0, sizeof(cplx) * mm * h->nv * h->nw);
+    for (size_t b = 0; b < (size_t)h->nw * h->nv; ++b)
+        for (int p = 0; p < h->M; ++p) {
+            vhs_out[2 * (b * mm + (size_t)p * h->M + p)] = d[2 * (b * h->M + p)];
+            vhs_out[2 * (b * mm + (size_t)p * h->M + p) + 1] = d[2 * (b * h->M + p) + 1];
+        }
+    return AFQ_OK;
+}
+
+int afq_apply_exponential(afq_handle *h, const double *vhs) {
+    if (!h || !vhs) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if ((rc = k_alive(h))) return rc;
+    const size_t mm = (size_t)h->M * h->M;
+    if (!h->vhs_diag) {
+        AFQ_HIP(h, hipMemcpyAsync(h->vhs, vhs, sizeof(cplx) * mm * h->nv * h->nw, hipMemcpyHostToDevice, h->stream));
+    } else {
+        std::vector<double> d((size_t)2 * h->nw * h->nv * h->M);
+        for (size_t b = 0; b < (size_t)h->nw * h->nv; ++b)
+            for (int p = 0; p < h->M; ++p) {
+                d[2 * (b * h->M + p)] = vhs[2 * (b * mm + (size_t)p * h->M + p)];
+                d[2 * (b * h->M + p) + 1] = vhs[2 * (b * mm + (size_t)p * h->M + p) + 1];
+            }
+        AFQ_HIP(h, hipMemcpy(h->vhs, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice));
+    }
+    if ((rc = apply_exp(h, h->vhs))) return rc;
+    return afq_sync(h);
+}
+
+int afq_kinetic(afq_handle *h) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if ((rc = k_alive(h))) return rc;
+    if ((rc = k_onebody(h))) return rc;
+    return afq_sync(h);
+}
+
+// -------------------------------------------------------------- driver glue
+int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    return k_cap_weights(h, frac, total_weight);
+}
+
+int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *parent_ix,
+                        double *total_weight_out) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (h->nw == 1) return AFQ_OK;                       // handler.py:226-227
+    if ((rc = k_comb(h, r, target_weight))) return rc;
+    double sc[2];
+    if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;
+    if (total_weight_out) *total_weight_out = sc[0];
+    if (sc[1] < 0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8");
+    return copy_out(h, parent_ix, h->parent_ix, sizeof(int) * h->nw);
+}
+
+int afq_walkers_scale_weights(afq_handle *h, double scale) {
+    if (!h || scale == 0.0) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    return k_scale_weights(h, scale);
+}
+
+int afq_walkers_reset_weights(afq_handle *h) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    return k_reset_weights(h);
+}
+
+// packed walker: phi | ot, ehyb, phase, eloc (c128) | unscaled_weight, detR, weight, pad (f64)
+int afq_walker_pack_bytes(afq_handle *h, int64_t *bytes) {
+    if (!h || !bytes) return AFQ_EINVAL;
+    *bytes = (int64_t)(sizeof(cplx) * ((size_t)h->M * h->nt + 4) + sizeof(double) * 4);
+    return AFQ_OK;
+}
+
+static int pack_io(afq_handle *h, int iw, char *buf, bool pack) {
+    const size_t per = (size_t)h->M * h->nt;
+    struct Item { void *p; size_t b; };
+    const Item items[] = {{h->phi + per * iw, per * sizeof(cplx)}, {h->ot + iw, sizeof(cplx)},
+                          {h->ehyb + iw, sizeof(cplx)}, {h->phase + iw, sizeof(cplx)},
+                          {h->eloc + iw, sizeof(cplx)}, {h->unscaled + iw, sizeof(double)},
+                          {h->detR + iw, sizeof(double)}, {h->weight + iw, sizeof(double)}};
+    size_t off = 0;
+    for (const Item &it : items) {
+        if (pack) AFQ_HIP(h, hipMemcpyAsync(buf + off, it.p, it.b, hipMemcpyDeviceToDevice, h->stream));
+        else AFQ_HIP(h, hipMemcpyAsync(it.p, buf + off, it.b, hipMemcpyDeviceToDevice, h->stream));
+        off += it.b;
+    }
+    return AFQ_OK;
+}
+
+int afq_walker_pack(afq_handle *h, int iw, void *dev_buf) {
+    if (!h || !dev_buf) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (iw < 0 || iw >= h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker index out of range");
+    return pack_io(h, iw, (char *)dev_buf, true);
+}
+
+int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
+    if (!h || !dev_buf) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (iw < 0 || iw >= h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker index out of range");
+    return pack_io(h, iw, (char *)dev_buf, false);
+}
+
+int afq_walkers_copy(afq_handle *h, int src, int dst) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (src < 0 || dst < 0 || src >= h->nw || dst >= h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker index out of range");
+    if (src == dst) return AFQ_OK;
+    const size_t per = (size_t)h->M * h->nt;
+#define C_(ptr, n) AFQ_HIP(h, hipMemcpyAsync((ptr) + (size_t)dst * (n), (ptr) + (size_t)src * (n), sizeof(*(ptr)) * (n), hipMemcpyDeviceToDevice, h->stream));
+    C_(h->phi, per) C_(h->ot, 1) C_(h->ehyb, 1) C_(h->phase, 1) C_(h->eloc, 1)
+    C_(h->unscaled, 1) C_(h->detR, 1) C_(h->weight, 1)
+#undef C_
+    return AFQ_OK;
+}
+
+int afq_estimates_update(afq_handle *h, int eval_energy) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (eval_energy) {
+        {
+            PhaseTimer t(h, T_GREENS);
+            if ((rc = k_greens(h, h->ovlp_old))) return rc;
+            if (h->kind == AFQ_SYS_UEG) {
+                if ((rc = ensure_G(h))) return rc;
+                if ((rc = k_full_G(h))) return rc;
+            }
+        }
+        PhaseTimer t(h, T_ENERGY);
+        if ((rc = local_energy(h))) return rc;
+    }
+    return k_estimates(h, eval_energy);
+}
+
+int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
+    if (!h || !est_out) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    int rc = copy_out(h, est_out, h->estimates, sizeof(cplx) * AFQ_EST_COUNT_);
+    if (rc) return rc;
+    if (zero) AFQ_HIP(h, hipMemsetAsync(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_, h->stream));
+    return AFQ_OK;
+}
+
+// ---------------------------------------------------------------------- misc
+int afq_rng_seed(afq_handle *h, uint64_t seed, uint64_t stream) {
+    if (!h) return AFQ_EINVAL;
+    h->rng_seed = seed; h->rng_stream = stream; h->rng_counter = 0;
+    return AFQ_OK;
+}
+
+int afq_counters(afq_handle *h, int64_t *out, int reset) {
+    if (!h || !out) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    unsigned long long c[4];
+    int rc = copy_out(h, c, h->counters, sizeof(c));
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) out[i] = (int64_t)c[i];
+    if (reset) AFQ_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(c), h->stream));
+    return AFQ_OK;
+}
+
+int afq_enable_timers(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    h->timers_on = on != 0;
+    return AFQ_OK;
+}
+
+int afq_timers(afq_handle *h, double *out_ms, int reset) {
+    if (!h || !out_ms) return AFQ_EINVAL;
+    for (int i = 0; i < T_COUNT; ++i) { out_ms[i] = h->t_ms[i]; if (reset) h->t_ms[i] = 0.0; }
+    return AFQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Internal declarations shared by the translation units of libafqmc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/afqmc_hip.h"
+
+typedef double2 cplx;   // (x = re, y = im), same bytes as numpy complex128
+
+__host__ __device__ inline cplx cmake(double r, double i) { return make_double2(r, i); }
+__host__ __device__ inline cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplx cmul(cplx a, cplx b) {
+    return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__host__ __device__ inline cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+__host__ __device__ inline cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+// a += b*c
+__host__ __device__ inline void cfma(cplx &a, cplx b, cplx c) {
+    a.x = fma(b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
+    a.y = fma(b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
+}
+__host__ __device__ inline double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
+__device__ inline cplx cdiv(cplx a, cplx b) {
+    // Smith's algorithm (what C99/numpy use) to avoid overflow
+    if (fabs(b.x) >= fabs(b.y)) {
+        double r = b.y / b.x, d = b.x + b.y * r;
+        return cmake((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    } else {
+        double r = b.x / b.y, d = b.x * r + b.y;
+        return cmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+    }
+}
+
+enum { T_GREENS = 0, T_ONEBODY, T_FB, T_VHS, T_EXP, T_OVLP, T_QR, T_ENERGY, T_COUNT };
+
+struct afq_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- system
+    int kind = 0;
+    int M = 0, K = 0, na = 0, nb = 0, nt = 0;
+    double ecore = 0.0;
+    // generic
+    double *hs_pot = nullptr;       // f64 [M*M, K]
+    bool rchol_real = true;
+    double *rchol_re = nullptr;     // f64 [nt*M, K]
+    double *rchol_im = nullptr;     // f64 [nt*M, K] or null when real
+    double *rchol_frag[2] = {nullptr, nullptr};   // energy-kernel A operand, fragment order, per spin
+    double *rchol_frag_im[2] = {nullptr, nullptr};
+    cplx *H1 = nullptr;             // [2, M, M]
+    cplx *rH1 = nullptr;            // half-rotated H1: [nt, M]; rH1[i][q] = sum_p conj(psi[p,i]) H1_s[p,q]
+    // hubbard
+    double U = 0.0;
+    // ueg
+    int nq = 0;
+    int64_t nnzA = 0, nnzB = 0;
+    int64_t *iA_colptr = nullptr, *iA_row = nullptr; cplx *iA_val = nullptr;
+    int64_t *iB_colptr = nullptr, *iB_row = nullptr; cplx *iB_val = nullptr;
+    // row-major (CSR over M*M rows) copies for the VHS gather
+    int64_t *iA_rowptr = nullptr, *iA_col = nullptr; cplx *iA_rval = nullptr;
+    int64_t *iB_rowptr = nullptr, *iB_col = nullptr; cplx *iB_rval = nullptr;
+    int64_t *kpq_off = nullptr, *kpq_i = nullptr, *kpq_kpq = nullptr;
+    int64_t *pmq_off = nullptr, *pmq_i = nullptr, *pmq_pmq = nullptr;
+    double *vqvec = nullptr; double vol = 1.0; double *H1diag = nullptr;
+
+    // ---- trial
+    bool have_trial = false;
+    cplx *psi = nullptr;            // [M, nt]
+
+    // ---- propagator
+    bool have_prop = false;
+    cplx *BH1 = nullptr;            // [2, M, M]
+    cplx *mf_shift = nullptr;       // [K]
+    double dt = 0.0, sqrt_dt = 0.0;
+    int exp_order = 6;
+    int flags = AFQ_PROP_HYBRID | AFQ_PROP_FORCE_BIAS;
+    int nv = 1;                     // VHS matrices per walker (2 for Hubbard spin HS)
+    bool vhs_diag = false;          // Hubbard: VHS stored as diagonals [nw, nv, M]
+
+    // ---- walkers
+    int nw = 0;
+    cplx *phi = nullptr;            // [nw, M, nt]
+    cplx *phi_t = nullptr;          // scratch [nw, M, nt] (Taylor term ping)
+    cplx *phi_t2 = nullptr;         // scratch [nw, M, nt] (Taylor term pong)
+    double *weight = nullptr, *unscaled = nullptr, *detR = nullptr;
+    cplx *ot = nullptr, *ehyb = nullptr, *phase = nullptr, *eloc = nullptr;
+    cplx *ghalf = nullptr;          // [nw, nt, M]
+    cplx *G = nullptr;              // [nw, 2, M, M] (allocated on demand)
+    cplx *ovlp_old = nullptr, *ovlp_new = nullptr;   // [nw]
+    double *xi = nullptr;           // [nw, K]
+    int fb_split = 1;               // contraction slices of the force-bias GEMM
+    cplx *vbias = nullptr;          // [fb_split*2, nw, K] partial per-spin Coulomb vectors X_a, X_b
+    cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
+    cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
+    cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag
+    cplx *lu_ws = nullptr;          // [nw, 2, N, N] workspace for large N
+    cplx *energy = nullptr;         // [nw, 3]
+    cplx *exx_part = nullptr;       // exchange partial sums
+    int64_t exx_part_len = 0;
+    double *gfrag = nullptr;        // Ghalf in MFMA fragment order (energy kernel B operand)
+    size_t gfrag_bytes = 0;
+    hipEvent_t ev_e0 = nullptr, ev_e1 = nullptr;   // brackets the exchange kernel
+    bool energy_ev_valid = false;
+    cplx *estimates = nullptr;      // [10]
+    unsigned long long *counters = nullptr;   // [4]
+    int *alive = nullptr;           // [nw]
+    int *parent_ix = nullptr;       // [nw]
+    double *scal = nullptr;         // [8] device scalars (total weight, ...)
+    void *pack_tmp = nullptr;
+
+    // rng
+    uint64_t rng_seed = 0, rng_stream = 0, rng_counter = 0;
+
+    // timers
+    bool timers_on = false;
+    double t_ms[T_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_energy_ms = 0.0;
+};
+
+#define AFQ_HIP(h, call)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            return AFQ_EHIP;                                                    \
+        }                                                                       \
+    } while (0)
+
+#define AFQ_FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+struct PhaseTimer {
+    afq_handle *h; int slot;
+    PhaseTimer(afq_handle *h_, int s) : h(h_), slot(s) {
+        if (h->timers_on) hipEventRecord(h->ev0, h->stream);
+    }
+    ~PhaseTimer() {
+        if (h->timers_on) {
+            hipEventRecord(h->ev1, h->stream);
+            hipEventSynchronize(h->ev1);
+            float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            h->t_ms[slot] += ms;
+        }
+    }
+};
+
+// ---- launchers implemented in the kernel translation units -----------------
+// k_gemm.hip
+int k_onebody(afq_handle *h);                               // phi <- BH1 phi (all live walkers)
+int k_force_bias_generic(afq_handle *h);                    // ghalf -> vbias[2,nw,K]
+int k_vhs_generic(afq_handle *h);                           // xs -> vhs
+int k_apply_exponential(afq_handle *h, const cplx *vhs);    // phi <- sum_n vhs^n/n! phi
+int k_full_G(afq_handle *h);                                // G = conj(psi) ghalf
+// k_small.hip
+int k_alive(afq_handle *h);
+int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det
+int k_overlap(afq_handle *h, cplx *det_out);                // det(psi^H phi)
+int k_fields(afq_handle *h);                                // vbias -> xbar(clipped), xs, cmf, cfb
+int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d, cplx *cfb_d);
+int k_xbar(afq_handle *h);                                  // vbias / G -> xbar (unclipped), system dispatch
+int k_update_weight(afq_handle *h, cplx eshift);
+int k_reortho(afq_handle *h);
+int k_cap_weights(afq_handle *h, double frac, double total_weight);
+int k_comb(afq_handle *h, double r, double target);
+int k_scale_weights(afq_handle *h, double scale);
+int k_reset_weights(afq_handle *h);
+int k_estimates(afq_handle *h, int have_energy);
+int k_rng_normal(afq_handle *h);
+// k_energy.hip
+int k_energy_generic(afq_handle *h);
+int k_prepare_energy_operands(afq_handle *h, const double *rchol_host);
+// k_models.hip (Hubbard / UEG)
+int k_vhs_hubbard(afq_handle *h);
+int k_apply_exponential_diag(afq_handle *h, const cplx *vhs_diag);
+int k_energy_hubbard(afq_handle *h);
+int k_vbias_ueg(afq_handle *h);
+int k_vhs_ueg(afq_handle *h);
+int k_energy_ueg(afq_handle *h);

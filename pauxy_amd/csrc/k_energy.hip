@@ -1,0 +1,319 @@
+// Half-rotated Cholesky local energy (estimators/generic.py:156-221), all
+// walkers at once.
+//
+//   e1b   = sum_s sum_{pq} H1_s[p,q] G_s[p,q] = sum_{s,i,q} rH1[i,q] Ghalf_s[i,q]
+//   X_s   = rchol_s^T vec(Ghalf_s)                (the force-bias contraction)
+//   ecoul = (X_a + X_b).(X_a + X_b)
+//   T_s[x,i,j] = sum_p rchol_s[(i,p),x] Ghalf_s[j,p]
+//   exx   = sum_s sum_{x,i,j} T_s[x,i,j] T_s[x,j,i]
+//
+// The exchange term is the dense contraction (2 K N^2 M real x complex MACs per
+// walker) and runs on fp64 MFMA with the Cholesky index x on the tile rows and
+// the WALKER index on the tile columns: a 16x16 tile is (16 x) x (16 walkers)
+// for one fixed orbital pair (i,j).  With that choice
+//   * every tile is full (no padding of N=25 to 32),
+//   * T[x,i,j] and T[x,j,i] of the same (x, walker) sit in the same lane and
+//     register of two accumulators, so the trace T_ij T_ji is a lane-local
+//     multiply: the K x N x N intermediate never leaves registers.
+// Operands are stored in MFMA fragment order so every fragment load is one
+// fully coalesced 512-byte wavefront load:
+//   afrag[s][i][xt][ks][lane] = rchol_s[(i, p = 4 ks + lane/16), x = 16 xt + lane%16]   (built once)
+//   gfrag[orb][c][wt][ks][lane] = (re|im) Ghalf[w = 16 wt + lane%16][orb][p = 4 ks + lane/16]
+#include "mfma_gemm.h"
+
+#define EXX_CHUNKS 2      // wave-tasks per (spin, x-tile, walker-tile) cell
+
+struct ExxArgs {
+    int M, K, nw, nt, nks, nxt, nwt;
+    int ns[2], goff[2];
+    const double *afrag[2];
+    const double *afrag_im[2];
+    const double *gfrag;
+    cplx *part;               // [2, nxt, nwt, EXX_CHUNKS, 16]
+};
+
+__device__ inline void cmul_acc(double &sr, double &si, const d4_t &ar, const d4_t &ai, const d4_t &br,
+                                const d4_t &bi, double f) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sr += f * (ar[r] * br[r] - ai[r] * bi[r]);
+        si += f * (ar[r] * bi[r] + ai[r] * br[r]);
+    }
+}
+
+template <bool RC>
+__global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long ncell = 2L * a.nxt * a.nwt;
+    if (task >= ncell * EXX_CHUNKS) return;
+    const int chunk = (int)(task % EXX_CHUNKS);
+    const long cell = task / EXX_CHUNKS;
+    const int wt = (int)(cell % a.nwt);
+    const int xt = (int)((cell / a.nwt) % a.nxt);
+    const int s = (int)(cell / ((long)a.nwt * a.nxt));
+    const int ns = a.ns[s];
+    double sr = 0.0, si = 0.0;
+    if (ns > 0) {
+        const int nblk = (ns + 1) / 2;
+        const int npairs = nblk * (nblk + 1) / 2;
+        const int p_lo = (int)((long)npairs * chunk / EXX_CHUNKS);
+        const int p_hi = (int)((long)npairs * (chunk + 1) / EXX_CHUNKS);
+        const long astride_i = (long)a.nxt * a.nks * 64;      // doubles between orbitals in afrag
+        const long gstride_o = 2L * a.nwt * a.nks * 64;       // doubles between orbitals in gfrag
+        const long gstride_c = (long)a.nwt * a.nks * 64;
+        const double *A0 = a.afrag[s] + (long)xt * a.nks * 64 + lane;
+        const double *A0i = RC ? a.afrag_im[s] + (long)xt * a.nks * 64 + lane : nullptr;
+        const double *G0 = a.gfrag + (long)a.goff[s] * gstride_o + (long)wt * a.nks * 64 + lane;
+        int pidx = 0;
+        for (int ib = 0; ib < nblk; ++ib) {
+            for (int jb = ib; jb < nblk; ++jb, ++pidx) {
+                if (pidx < p_lo || pidx >= p_hi) continue;
+                const int i0 = 2 * ib, j0 = 2 * jb;
+                const int ci = (i0 + 1 < ns) ? 2 : 1, cj = (j0 + 1 < ns) ? 2 : 1;
+                if (ib == jb) {
+                    // tiles D[a][b] = T[i_a, i_b]
+                    d4_t Dr[2][2], Di[2][2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) { Dr[x][y] = (d4_t){0, 0, 0, 0}; Di[x][y] = (d4_t){0, 0, 0, 0}; }
+                    for (int ks = 0; ks < a.nks; ++ks) {
+                        double Ar[2], Ai[2], Br[2], Bi[2];
+#pragma unroll
+                        for (int x = 0; x < 2; ++x) {
+                            if (x < ci) {
+                                Ar[x] = A0[(long)(i0 + x) * astride_i + ks * 64];
+                                Ai[x] = RC ? A0i[(long)(i0 + x) * astride_i + ks * 64] : 0.0;
+                                Br[x] = G0[(long)(i0 + x) * gstride_o + ks * 64];
+                                Bi[x] = G0[(long)(i0 + x) * gstride_o + gstride_c + ks * 64];
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                            for (int y = 0; y < 2; ++y)
+                                if (x < ci && y < ci) {
+                                    Dr[x][y] = mfma16(Ar[x], Br[y], Dr[x][y]);
+                                    Di[x][y] = mfma16(Ar[x], Bi[y], Di[x][y]);
+                                    if (RC) {
+                                        Dr[x][y] = mfma16(-Ai[x], Bi[y], Dr[x][y]);
+                                        Di[x][y] = mfma16(Ai[x], Br[y], Di[x][y]);
+                                    }
+                                }
+                    }
+                    cmul_acc(sr, si, Dr[0][0], Di[0][0], Dr[0][0], Di[0][0], 1.0);
+                    if (ci == 2) {
+                        cmul_acc(sr, si, Dr[1][1], Di[1][1], Dr[1][1], Di[1][1], 1.0);
+                        cmul_acc(sr, si, Dr[0][1], Di[0][1], Dr[1][0], Di[1][0], 2.0);
+                    }
+                } else {
+                    // T[x][y] = tile(i_x, j_y), S[y][x] = tile(j_y, i_x)
+                    d4_t Tr[2][2], Ti[2][2], Sr[2][2], Si[2][2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) {
+                            Tr[x][y] = (d4_t){0, 0, 0, 0}; Ti[x][y] = (d4_t){0, 0, 0, 0};
+                            Sr[x][y] = (d4_t){0, 0, 0, 0}; Si[x][y] = (d4_t){0, 0, 0, 0};
+                        }
+                    for (int ks = 0; ks < a.nks; ++ks) {
+                        double Air[2], Aii[2], Ajr[2], Aji[2], Bir[2], Bii[2], Bjr[2], Bji[2];
+#pragma unroll
+                        for (int x = 0; x < 2; ++x) {
+                            if (x < ci) {
+                                Air[x] = A0[(long)(i0 + x) * astride_i + ks * 64];
+                                Aii[x] = RC ? A0i[(long)(i0 + x) * astride_i + ks * 64] : 0.0;
+                                Bir[x] = G0[(long)(i0 + x) * gstride_o + ks * 64];
+                                Bii[x] = G0[(long)(i0 + x) * gstride_o + gstride_c + ks * 64];
+                            }
+                            if (x < cj) {
+                                Ajr[x] = A0[(long)(j0 + x) * astride_i + ks * 64];
+                                Aji[x] = RC ? A0i[(long)(j0 + x) * astride_i + ks * 64] : 0.0;
+                                Bjr[x] = G0[(long)(j0 + x) * gstride_o + ks * 64];
+                                Bji[x] = G0[(long)(j0 + x) * gstride_o + gstride_c + ks * 64];
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                            for (int y = 0; y < 2; ++y)
+                                if (x < ci && y < cj) {
+                                    Tr[x][y] = mfma16(Air[x], Bjr[y], Tr[x][y]);
+                                    Ti[x][y] = mfma16(Air[x], Bji[y], Ti[x][y]);
+                                    Sr[y][x] = mfma16(Ajr[y], Bir[x], Sr[y][x]);
+                                    Si[y][x] = mfma16(Ajr[y], Bii[x], Si[y][x]);
+                                    if (RC) {
+                                        Tr[x][y] = mfma16(-Aii[x], Bji[y], Tr[x][y]);
+                                        Ti[x][y] = mfma16(Aii[x], Bjr[y], Ti[x][y]);
+                                        Sr[y][x] = mfma16(-Aji[y], Bii[x], Sr[y][x]);
+                                        Si[y][x] = mfma16(Aji[y], Bir[x], Si[y][x]);
+                                    }
+                                }
+                    }
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y)
+                            if (x < ci && y < cj) cmul_acc(sr, si, Tr[x][y], Ti[x][y], Sr[y][x], Si[y][x], 2.0);
+                }
+            }
+        }
+    }
+    // sum the 4 row groups of each walker column
+    sr += __shfl_xor(sr, 16); si += __shfl_xor(si, 16);
+    sr += __shfl_xor(sr, 32); si += __shfl_xor(si, 32);
+    if (lane < 16) a.part[task * 16 + lane] = cmake(sr, si);
+}
+
+// Ghalf [nw, nt, M] -> fragment order (see header comment)
+__global__ void gfrag_kernel(const cplx *ghalf, double *gfrag, int nw, int nt, int M, int nwt, int nks) {
+    const int lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (orb, wt, ks)
+    const long nf = (long)nt * nwt * nks;
+    if (f >= nf) return;
+    const int ks = (int)(f % nks);
+    const int wt = (int)((f / nks) % nwt);
+    const int orb = (int)(f / ((long)nks * nwt));
+    const int w = wt * 16 + (lane & 15), p = ks * 4 + (lane >> 4);
+    cplx v = cmake(0.0, 0.0);
+    if (w < nw && p < M) v = ghalf[((long)w * nt + orb) * M + p];
+    gfrag[(((long)orb * 2 + 0) * nwt + wt) * nks * 64 + (long)ks * 64 + lane] = v.x;
+    gfrag[(((long)orb * 2 + 1) * nwt + wt) * nks * 64 + (long)ks * 64 + lane] = v.y;
+}
+
+struct EFinArgs {
+    int M, K, nw, nt, nsplit, nxt, nwt;
+    double ecore;
+    const cplx *rH1, *ghalf, *vbias, *part;
+    cplx *energy;
+};
+
+__global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
+    __shared__ double red[8];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    // one-body
+    double e1r = 0, e1i = 0;
+    const long nq = (long)a.nt * a.M;
+    const cplx *gh = a.ghalf + (long)w * nq;
+    for (long q = tid; q < nq; q += 256) {
+        const cplx h = a.rH1[q], g = gh[q];
+        e1r += h.x * g.x - h.y * g.y;
+        e1i += h.x * g.y + h.y * g.x;
+    }
+    // Coulomb
+    double ecr = 0, eci = 0;
+    for (int n = tid; n < a.K; n += 256) {
+        cplx x = cmake(0.0, 0.0);
+        for (int b = 0; b < 2 * a.nsplit; ++b) x = cadd(x, a.vbias[((long)b * a.nw + w) * a.K + n]);
+        ecr += x.x * x.x - x.y * x.y;
+        eci += 2.0 * x.x * x.y;
+    }
+    // exchange partials of this walker
+    double exr = 0, exi = 0;
+    const int wt = w >> 4, wl = w & 15;
+    const int np = 2 * a.nxt * EXX_CHUNKS;
+    for (int t = tid; t < np; t += 256) {
+        const int chunk = t % EXX_CHUNKS;
+        const int xt = (t / EXX_CHUNKS) % a.nxt;
+        const int s = t / (EXX_CHUNKS * a.nxt);
+        const long task = (((long)s * a.nxt + xt) * a.nwt + wt) * EXX_CHUNKS + chunk;
+        const cplx v = a.part[task * 16 + wl];
+        exr += v.x; exi += v.y;
+    }
+    // block sums
+    double v[6] = {e1r, e1i, ecr, eci, exr, exi};
+    for (int k = 0; k < 6; ++k) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = x;
+        __syncthreads();
+        v[k] = red[0] + red[1] + red[2] + red[3];
+    }
+    if (tid == 0) {
+        const double e2r = 0.5 * (v[2] - v[4]), e2i = 0.5 * (v[3] - v[5]);
+        a.energy[3 * w + 0] = cmake(v[0] + e2r + a.ecore, v[1] + e2i);
+        a.energy[3 * w + 1] = cmake(v[0] + a.ecore, v[1]);
+        a.energy[3 * w + 2] = cmake(e2r, e2i);
+    }
+}
+
+// Builds afrag from the host rchol (c128 [(na+nb) M, K]); called once from
+// afq_set_system_generic.  Also decides real / complex rchol.
+int k_prepare_energy_operands(afq_handle *h, const double *rchol_host) {
+    const int M = h->M, K = h->K;
+    const int nks = (M + 3) / 4, nxt = (K + 15) / 16;
+    for (int s = 0; s < 2; ++s) {
+        const int ns = s == 0 ? h->na : h->nb, off = s == 0 ? 0 : h->na;
+        if (ns == 0) continue;
+        const size_t n = (size_t)ns * nxt * nks * 64;
+        std::vector<double> fr(n, 0.0), fi;
+        if (!h->rchol_real) fi.assign(n, 0.0);
+        for (int i = 0; i < ns; ++i)
+            for (int xt = 0; xt < nxt; ++xt)
+                for (int ks = 0; ks < nks; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int x = xt * 16 + (l & 15), p = ks * 4 + (l >> 4);
+                        if (x >= K || p >= M) continue;
+                        const size_t src = (((size_t)(off + i) * M + p) * K + x) * 2;
+                        const size_t dst = (((size_t)i * nxt + xt) * nks + ks) * 64 + l;
+                        fr[dst] = rchol_host[src];
+                        if (!h->rchol_real) fi[dst] = rchol_host[src + 1];
+                    }
+        AFQ_HIP(h, hipMalloc(&h->rchol_frag[s], n * sizeof(double)));
+        AFQ_HIP(h, hipMemcpy(h->rchol_frag[s], fr.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        if (!h->rchol_real) {
+            AFQ_HIP(h, hipMalloc(&h->rchol_frag_im[s], n * sizeof(double)));
+            AFQ_HIP(h, hipMemcpy(h->rchol_frag_im[s], fi.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    return AFQ_OK;
+}
+
+int k_energy_generic(afq_handle *h) {
+    const int M = h->M, K = h->K;
+    const int nks = (M + 3) / 4, nxt = (K + 15) / 16, nwt = (h->nw + 15) / 16;
+    // Coulomb vectors: the force-bias contraction on the current Ghalf
+    int rc = k_force_bias_generic(h);
+    if (rc) return rc;
+    const size_t gbytes = sizeof(double) * (size_t)h->nt * 2 * nwt * nks * 64;
+    if (!h->gfrag || h->gfrag_bytes < gbytes) {
+        if (h->gfrag) hipFree(h->gfrag);
+        AFQ_HIP(h, hipMalloc(&h->gfrag, gbytes));
+        h->gfrag_bytes = gbytes;
+    }
+    const long ntask = 2L * nxt * nwt * EXX_CHUNKS;
+    if (h->exx_part_len < ntask * 16) {
+        if (h->exx_part) hipFree(h->exx_part);
+        AFQ_HIP(h, hipMalloc(&h->exx_part, sizeof(cplx) * ntask * 16));
+        h->exx_part_len = ntask * 16;
+    }
+    {
+        const long nf = (long)h->nt * nwt * nks;
+        hipLaunchKernelGGL(gfrag_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, h->stream, h->ghalf,
+                           h->gfrag, h->nw, h->nt, M, nwt, nks);
+        AFQ_HIP(h, hipGetLastError());
+    }
+    ExxArgs a;
+    a.M = M; a.K = K; a.nw = h->nw; a.nt = h->nt; a.nks = nks; a.nxt = nxt; a.nwt = nwt;
+    a.ns[0] = h->na; a.ns[1] = h->nb; a.goff[0] = 0; a.goff[1] = h->na;
+    a.afrag[0] = h->rchol_frag[0]; a.afrag[1] = h->rchol_frag[1];
+    a.afrag_im[0] = h->rchol_frag_im[0]; a.afrag_im[1] = h->rchol_frag_im[1];
+    a.gfrag = h->gfrag; a.part = h->exx_part;
+    AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
+    if (h->rchol_real)
+        hipLaunchKernelGGL(exx_kernel<false>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL(exx_kernel<true>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
+    h->energy_ev_valid = true;
+    EFinArgs f;
+    f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
+    f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
+    f.energy = h->energy;
+    hipLaunchKernelGGL(energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}

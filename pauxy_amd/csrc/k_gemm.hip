@@ -1,0 +1,221 @@
+// Walker-batched dense contractions on the fp64 MFMA tile engine:
+//   one-body propagator  phi_s <- BH1[s] phi_s        (propagation/operations.py:29-52)
+//   force bias           X_s[w,n] = sum_q Ghalf_s[w,q] rchol_s[q,n]   (propagation/generic.py:130-152)
+//   HS potential         VHS[w] = i sqrt(dt) reshape(hs_pot xs[w])    (propagation/generic.py:164-179)
+//   Taylor propagator    phi <- sum_{n<=order} VHS^n/n! phi           (propagation/continuous.py:82-111)
+//   full Green's fn      G_s = conj(psi_s) Ghalf_s                    (walkers/single_det.py:312,319)
+#include "mfma_gemm.h"
+
+// ---------------------------------------------------------------- one body
+struct OneBodyProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true;
+    int batch, rows, cols, kdim;     // batch = nw, rows = M, cols = ns, kdim = M
+    int nt, off;                     // phi row stride, first column of this spin
+    const cplx *B1;                  // BH1[s]  [M, M]
+    const cplx *src;                 // phi     [nw, M, nt]
+    cplx *dst;
+    const int *alive;
+    __device__ bool active(int b) const { return alive[b] != 0; }
+    __device__ cplx loadA(int, int row, int k) const { return B1[(long)row * kdim + k]; }
+    __device__ cplx loadB(int b, int k, int col) const {
+        return src[((long)b * kdim + k) * nt + off + col];
+    }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        dst[((long)b * rows + row) * nt + off + col] = cmake(re, im);
+    }
+};
+
+__global__ void copy_dead_kernel(const cplx *src, cplx *dst, const int *alive, long per) {
+    const int w = blockIdx.y;
+    if (alive[w]) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x)
+        dst[w * per + i] = src[w * per + i];
+}
+
+int k_onebody(afq_handle *h) {
+    const int M = h->M;
+    for (int s = 0; s < 2; ++s) {
+        const int ns = s == 0 ? h->na : h->nb;
+        if (ns == 0) continue;
+        OneBodyProb p;
+        p.batch = h->nw; p.rows = M; p.cols = ns; p.kdim = M;
+        p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
+        p.B1 = h->BH1 + (long)s * M * M;
+        p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
+        if (ns > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+        else AFQ_HIP(h, (launch_mfma_gemm<2, 1>(p, h->stream)));
+    }
+    // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
+    hipLaunchKernelGGL(copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
+                       h->alive, (long)M * h->nt);
+    AFQ_HIP(h, hipGetLastError());
+    cplx *t = h->phi; h->phi = h->phi_t; h->phi_t = t;
+    return AFQ_OK;
+}
+
+// -------------------------------------------------------------- force bias
+// rows = walkers, cols = fields, contraction over q = (i, p) of one spin,
+// split into `nsplit` slices; partial sums go to vbias[(slice*2 + s), w, n].
+template <bool RC>
+struct ForceBiasProb {
+    static constexpr bool A_CPLX = true, B_CPLX = RC;
+    int batch, rows, cols, kdim;     // batch = 2*nsplit, rows = nw, cols = K, kdim = slice length
+    int nsplit, M, K, nt, na, nb;
+    const cplx *ghalf;               // [nw, nt, M]
+    const double *rre, *rim;         // [nt*M, K]
+    cplx *out;                       // [nsplit*2, nw, K]
+    __device__ bool active(int) const { return true; }
+    __device__ void slice(int b, int &s, long &q0, int &len) const {
+        s = b & 1;
+        const int sl = b >> 1;
+        const int ns = s == 0 ? na : nb;
+        const long tot = (long)ns * M;
+        const long per = (tot + nsplit - 1) / nsplit;
+        q0 = sl * per;
+        long l = tot - q0; if (l > per) l = per; if (l < 0) l = 0;
+        len = (int)l;
+    }
+    __device__ cplx loadA(int b, int row, int k) const {
+        int s, len; long q0; slice(b, s, q0, len);
+        if (k >= len) return cmake(0.0, 0.0);
+        return ghalf[(long)row * nt * M + (long)(s ? na : 0) * M + q0 + k];
+    }
+    __device__ cplx loadB(int b, int k, int col) const {
+        int s, len; long q0; slice(b, s, q0, len);
+        if (k >= len) return cmake(0.0, 0.0);
+        const long idx = ((long)(s ? na : 0) * M + q0 + k) * K + col;
+        return cmake(rre[idx], RC ? rim[idx] : 0.0);
+    }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        out[((long)b * rows + row) * K + col] = cmake(re, im);
+    }
+};
+
+int k_force_bias_generic(afq_handle *h) {
+    const int nmax = (h->na > h->nb ? h->na : h->nb) * h->M;
+    const int nsplit = h->fb_split;
+    const int per = (nmax + nsplit - 1) / nsplit;
+    if (h->rchol_real) {
+        ForceBiasProb<false> p;
+        p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
+        p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
+        p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = nullptr; p.out = h->vbias;
+        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+    } else {
+        ForceBiasProb<true> p;
+        p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
+        p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
+        p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = h->rchol_im; p.out = h->vbias;
+        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+    }
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------- VHS
+// rows = walkers, cols = (p,q) pairs, contraction over fields.
+// hsT is hs_pot transposed, [K, M*M], so a B fragment is 128 contiguous bytes.
+struct VhsProb {
+    static constexpr bool A_CPLX = true, B_CPLX = false;
+    int batch, rows, cols, kdim;     // 1, nw, M*M, K
+    const cplx *xs;                  // [nw, K]
+    const double *hsT;               // [K, M*M]
+    cplx *out;                       // [nw, M*M]
+    double sqrt_dt;
+    const int *alive;
+    __device__ bool active(int) const { return true; }
+    __device__ cplx loadA(int, int row, int k) const { return xs[(long)row * kdim + k]; }
+    __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * cols + col], 0.0); }
+    __device__ void store(int, int row, int col, double re, double im) const {
+        // i*sqrt(dt)*(re + i im)
+        out[(long)row * cols + col] = cmake(-sqrt_dt * im, sqrt_dt * re);
+    }
+};
+
+int k_vhs_generic(afq_handle *h) {
+    VhsProb p;
+    p.batch = 1; p.rows = h->nw; p.cols = h->M * h->M; p.kdim = h->K;
+    p.xs = h->xs; p.hsT = h->hs_pot; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
+    if (h->nw > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 4>(p, h->stream)));
+    else AFQ_HIP(h, (launch_mfma_gemm<1, 4>(p, h->stream)));
+    return AFQ_OK;
+}
+
+// ------------------------------------------------------------ Taylor series
+struct TaylorProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true;
+    int batch, rows, cols, kdim;     // nw, M, ncols, M
+    int nt, off;
+    long vstride;                    // elements between walkers in vhs
+    const cplx *vhs;                 // [nw, (nv,) M, M] (already offset to the spin's matrix)
+    const cplx *tin;                 // [nw, M, nt]
+    cplx *tout, *phi;
+    double inv_n;
+    const int *alive;
+    __device__ bool active(int b) const { return alive[b] != 0; }
+    __device__ cplx loadA(int b, int row, int k) const { return vhs[b * vstride + (long)row * kdim + k]; }
+    __device__ cplx loadB(int b, int k, int col) const { return tin[((long)b * kdim + k) * nt + off + col]; }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        const long idx = ((long)b * rows + row) * nt + off + col;
+        const cplx t = cmake(re * inv_n, im * inv_n);
+        tout[idx] = t;
+        const cplx o = phi[idx];
+        phi[idx] = cmake(o.x + t.x, o.y + t.y);
+    }
+};
+
+int k_apply_exponential(afq_handle *h, const cplx *vhs) {
+    const int M = h->M;
+    const long per = (long)M * h->nt;
+    AFQ_HIP(h, hipMemcpyAsync(h->phi_t, h->phi, sizeof(cplx) * per * h->nw, hipMemcpyDeviceToDevice, h->stream));
+    cplx *tin = h->phi_t, *tout = h->phi_t2;
+    for (int n = 1; n <= h->exp_order; ++n) {
+        for (int s = 0; s < h->nv; ++s) {
+            TaylorProb p;
+            p.batch = h->nw; p.rows = M; p.kdim = M; p.nt = h->nt;
+            if (h->nv == 1) { p.cols = h->nt; p.off = 0; }
+            else { p.cols = s == 0 ? h->na : h->nb; p.off = s == 0 ? 0 : h->na; }
+            if (p.cols == 0) continue;
+            p.vstride = (long)h->nv * M * M;
+            p.vhs = vhs + (long)s * M * M;
+            p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
+            if (p.cols > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+            else AFQ_HIP(h, (launch_mfma_gemm<2, 1>(p, h->stream)));
+        }
+        cplx *t = tin; tin = tout; tout = t;
+    }
+    return AFQ_OK;
+}
+
+// ------------------------------------------------------------------ full G
+struct FullGProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true;
+    int batch, rows, cols, kdim;     // nw, M, M, ns
+    int nt, off, spin, M;
+    const cplx *psi;                 // [M, nt]
+    const cplx *ghalf;               // [nw, nt, M]
+    cplx *G;                         // [nw, 2, M, M]
+    __device__ bool active(int) const { return true; }
+    __device__ cplx loadA(int, int row, int k) const { return cconj(psi[(long)row * nt + off + k]); }
+    __device__ cplx loadB(int b, int k, int col) const { return ghalf[((long)b * nt + off + k) * M + col]; }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        G[(((long)b * 2 + spin) * M + row) * M + col] = cmake(re, im);
+    }
+};
+
+int k_full_G(afq_handle *h) {
+    const int M = h->M;
+    for (int s = 0; s < 2; ++s) {
+        const int ns = s == 0 ? h->na : h->nb;
+        if (ns == 0) {
+            AFQ_HIP(h, hipMemset2DAsync(h->G + (long)s * M * M, sizeof(cplx) * 2 * M * M, 0,
+                                        sizeof(cplx) * M * M, h->nw, h->stream));
+            continue;
+        }
+        FullGProb p;
+        p.batch = h->nw; p.rows = M; p.cols = M; p.kdim = ns; p.nt = h->nt;
+        p.off = s == 0 ? 0 : h->na; p.spin = s; p.M = M;
+        p.psi = h->psi; p.ghalf = h->ghalf; p.G = h->G;
+        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+    }
+    return AFQ_OK;
+}

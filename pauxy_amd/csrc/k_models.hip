@@ -1,0 +1,249 @@
+// Model-specific pieces that are NOT dense contractions:
+//   Hubbard: diagonal HS potential (propagation/hubbard.py:409-413, :475-480), its
+//            degree-n Taylor propagator as a row scaling, energy (estimators/hubbard.py:93-114)
+//   UEG:     sparse force bias / HS potential (propagation/planewave.py:57-112) and the
+//            index-list energy (estimators/ueg.py:27-88, ueg_kernels.pyx:42-75)
+// These are HBM/gather bound: coalesced loads, one wavefront per output where a
+// reduction is needed, no MFMA.
+#include "afq_internal.h"
+
+// ------------------------------------------------------------------ Hubbard
+__global__ void vhs_hubbard_kernel(const cplx *xs, cplx *vd, int nw, int M, int nv, double sqrt_dt, double dt,
+                                   double U, int spin) {
+    const int w = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= M) return;
+    const cplx x = xs[(long)w * M + n];
+    if (!spin) {
+        // sqrt(dt) * i sqrt(U) * x
+        const double f = sqrt_dt * sqrt(U);
+        vd[(long)w * M + n] = cmake(-f * x.y, f * x.x);
+    } else {
+        const double f = sqrt(dt * U);           // (dt U)^0.5, propagation/hubbard.py:445
+        vd[((long)w * 2 + 0) * M + n] = cmake(-f * x.x, -f * x.y);
+        vd[((long)w * 2 + 1) * M + n] = cmake(f * x.x, f * x.y);
+    }
+}
+
+int k_vhs_hubbard(afq_handle *h) {
+    const int spin = (h->flags & AFQ_PROP_HUBBARD_SPIN) ? 1 : 0;
+    hipLaunchKernelGGL(vhs_hubbard_kernel, dim3((h->M + 127) / 128, h->nw), dim3(128), 0, h->stream, h->xs,
+                       h->vhs, h->nw, h->M, h->nv, h->sqrt_dt, h->dt, h->U, spin);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// phi[p, col] <- sum_{n<=order} d_p^n / n! phi[p, col], same recurrence as
+// propagation/continuous.py:104-107 (Temp = d*Temp/n; phi += Temp)
+__global__ void exp_diag_kernel(cplx *phi, const cplx *vd, const int *alive, int M, int nt, int na, int nv,
+                                int order) {
+    const int w = blockIdx.y;
+    if (!alive[w]) return;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= (long)M * nt) return;
+    const int p = (int)(e / nt), col = (int)(e % nt);
+    const int s = (nv == 2 && col >= na) ? 1 : 0;
+    const cplx d = vd[((long)w * nv + s) * M + p];
+    cplx acc = phi[(long)w * M * nt + e];
+    cplx t = acc;
+    for (int n = 1; n <= order; ++n) {
+        t = cmul(d, t);
+        t = cmake(t.x / n, t.y / n);
+        acc = cadd(acc, t);
+    }
+    phi[(long)w * M * nt + e] = acc;
+}
+
+int k_apply_exponential_diag(afq_handle *h, const cplx *vd) {
+    const long per = (long)h->M * h->nt;
+    hipLaunchKernelGGL(exp_diag_kernel, dim3((unsigned)((per + 255) / 256), h->nw), dim3(256), 0, h->stream,
+                       h->phi, vd, h->alive, h->M, h->nt, h->na, h->nv, h->exp_order);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// ke = sum_s sum_{i,q} rT[i,q] Ghalf_s[i,q];  pe = U sum_n G_up[n,n] G_dn[n,n]
+__global__ __launch_bounds__(256) void energy_hubbard_kernel(const cplx *rH1, const cplx *ghalf, const cplx *psi,
+                                                             cplx *energy, int M, int na, int nb, int nt,
+                                                             double U) {
+    __shared__ double red[8];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const cplx *gh = ghalf + (long)w * nt * M;
+    double kr = 0, ki = 0, pr = 0, pi = 0;
+    for (long q = tid; q < (long)nt * M; q += 256) {
+        const cplx a = rH1[q], g = gh[q];
+        kr += a.x * g.x - a.y * g.y;
+        ki += a.x * g.y + a.y * g.x;
+    }
+    for (int n = tid; n < M; n += 256) {
+        cplx g[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+        for (int s = 0; s < 2; ++s) {
+            const int ns = s == 0 ? na : nb, off = s == 0 ? 0 : na;
+            for (int i = 0; i < ns; ++i) cfma(g[s], cconj(psi[(long)n * nt + off + i]), gh[(long)(off + i) * M + n]);
+        }
+        const cplx t = cmul(g[0], g[1]);
+        pr += U * t.x; pi += U * t.y;
+    }
+    double v[4] = {kr, ki, pr, pi};
+    for (int k = 0; k < 4; ++k) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = x;
+        __syncthreads();
+        v[k] = red[0] + red[1] + red[2] + red[3];
+    }
+    if (tid == 0) {
+        energy[3 * w + 0] = cmake(v[0] + v[2], v[1] + v[3]);
+        energy[3 * w + 1] = cmake(v[0], v[1]);
+        energy[3 * w + 2] = cmake(v[2], v[3]);
+    }
+}
+
+int k_energy_hubbard(afq_handle *h) {
+    hipLaunchKernelGGL(energy_hubbard_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->rH1, h->ghalf, h->psi,
+                       h->energy, h->M, h->na, h->nb, h->nt, h->U);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// ---------------------------------------------------------------------- UEG
+// vbias[w, q]      = sum_{nz in column q of iA} val * (G_up + G_dn)[row]
+// vbias[w, nq + q] = same with iB                      (propagation/planewave.py:70-73)
+// one wavefront per (walker, column); G is the full [2, M, M] Green's function.
+__global__ void vbias_ueg_kernel(const cplx *G, cplx *vbias, int nw, int M, int nq, const int64_t *Acp,
+                                 const int64_t *Arow, const cplx *Aval, const int64_t *Bcp,
+                                 const int64_t *Brow, const cplx *Bval) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= (long)nw * 2 * nq) return;
+    const int w = (int)(item / (2 * nq));
+    const int col = (int)(item % (2 * nq));
+    const bool isB = col >= nq;
+    const int q = isB ? col - nq : col;
+    const int64_t *cp = isB ? Bcp : Acp, *row = isB ? Brow : Arow;
+    const cplx *val = isB ? Bval : Aval;
+    const cplx *Ga = G + (long)w * 2 * M * M, *Gb = Ga + (long)M * M;
+    double sr = 0, si = 0;
+    for (int64_t z = cp[q] + lane; z < cp[q + 1]; z += 64) {
+        const int64_t r = row[z];
+        const cplx g = cadd(Ga[r], Gb[r]), v = val[z];
+        sr += g.x * v.x - g.y * v.y;
+        si += g.x * v.y + g.y * v.x;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sr += __shfl_down(sr, off); si += __shfl_down(si, off); }
+    if (lane == 0) vbias[(long)w * 2 * nq + col] = cmake(sr, si);
+}
+
+int k_vbias_ueg(afq_handle *h) {
+    const long items = (long)h->nw * 2 * h->nq;
+    hipLaunchKernelGGL(vbias_ueg_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, h->stream, h->G,
+                       h->vbias, h->nw, h->M, h->nq, h->iA_colptr, h->iA_row, h->iA_val, h->iB_colptr,
+                       h->iB_row, h->iB_val);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// VHS[w, r] = sqrt(dt) * (sum_{nz in row r of iA} val xs[q] + sum_{nz in row r of iB} val xs[nq+q])
+// (propagation/planewave.py:109-112); one thread per (walker, matrix element), CSR rows are short.
+__global__ void vhs_ueg_kernel(const cplx *xs, cplx *vhs, int nw, int M, int nq, double sqrt_dt,
+                               const int64_t *Arp, const int64_t *Acol, const cplx *Aval, const int64_t *Brp,
+                               const int64_t *Bcol, const cplx *Bval) {
+    const int w = blockIdx.y;
+    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (r >= (long)M * M) return;
+    const cplx *x = xs + (long)w * 2 * nq;
+    cplx acc = cmake(0.0, 0.0);
+    for (int64_t z = Arp[r]; z < Arp[r + 1]; ++z) cfma(acc, Aval[z], x[Acol[z]]);
+    for (int64_t z = Brp[r]; z < Brp[r + 1]; ++z) cfma(acc, Bval[z], x[nq + Bcol[z]]);
+    vhs[(long)w * M * M + r] = cmake(sqrt_dt * acc.x, sqrt_dt * acc.y);
+}
+
+int k_vhs_ueg(afq_handle *h) {
+    const long mm = (long)h->M * h->M;
+    hipLaunchKernelGGL(vhs_ueg_kernel, dim3((unsigned)((mm + 255) / 256), h->nw), dim3(256), 0, h->stream, h->xs,
+                       h->vhs, h->nw, h->M, h->nq, h->sqrt_dt, h->iA_rowptr, h->iA_col, h->iA_rval,
+                       h->iB_rowptr, h->iB_col, h->iB_rval);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// Energy: one workgroup per walker; each wavefront takes q-vectors in turn and
+// gathers Gkpq, Gpmq and the exchange double sum for both spins.
+__global__ __launch_bounds__(256) void energy_ueg_kernel(const cplx *G, cplx *energy, int M, int nq,
+                                                         const int64_t *kpq_off, const int64_t *kpq_i,
+                                                         const int64_t *kpq_kpq, const int64_t *pmq_off,
+                                                         const int64_t *pmq_i, const int64_t *pmq_pmq,
+                                                         const double *vqvec, double vol, const double *H1diag) {
+    __shared__ double red[8];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cplx *Gs[2] = {G + (long)w * 2 * M * M, G + (long)w * 2 * M * M + (long)M * M};
+    double ker = 0, kei = 0;
+    for (int e = tid; e < 2 * M; e += 256) {
+        const int s = e / M, i = e % M;
+        const cplx g = Gs[s][(long)i * M + i];
+        ker += H1diag[e] * g.x; kei += H1diag[e] * g.y;
+    }
+    double per = 0, pei = 0;
+    for (int q = wave; q < nq; q += 4) {
+        const int64_t k0 = kpq_off[q], nk = kpq_off[q + 1] - k0;
+        const int64_t p0 = pmq_off[q], np = pmq_off[q + 1] - p0;
+        cplx gk[2], gp[2], gx[2];
+        for (int s = 0; s < 2; ++s) {
+            double ar = 0, ai = 0, br = 0, bi = 0, cr = 0, ci = 0;
+            for (int64_t z = lane; z < nk; z += 64) {
+                const cplx g = Gs[s][kpq_i[k0 + z] * M + kpq_kpq[k0 + z]];
+                ar += g.x; ai += g.y;
+            }
+            for (int64_t z = lane; z < np; z += 64) {
+                const cplx g = Gs[s][pmq_i[p0 + z] * M + pmq_pmq[p0 + z]];
+                br += g.x; bi += g.y;
+            }
+            // sum_{a,b} G[pmq_i[b], kpq[a]] * G[kpq_i[a], pmq[b]]
+            for (int64_t z = lane; z < nk * np; z += 64) {
+                const int64_t ia = z / np, ibb = z % np;
+                const cplx g1 = Gs[s][pmq_i[p0 + ibb] * M + kpq_kpq[k0 + ia]];
+                const cplx g2 = Gs[s][kpq_i[k0 + ia] * M + pmq_pmq[p0 + ibb]];
+                cr += g1.x * g2.x - g1.y * g2.y;
+                ci += g1.x * g2.y + g1.y * g2.x;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                ar += __shfl_xor(ar, off); ai += __shfl_xor(ai, off);
+                br += __shfl_xor(br, off); bi += __shfl_xor(bi, off);
+                cr += __shfl_xor(cr, off); ci += __shfl_xor(ci, off);
+            }
+            gk[s] = cmake(ar, ai); gp[s] = cmake(br, bi); gx[s] = cmake(cr, ci);
+        }
+        if (lane == 0) {
+            // (Gkpq Gpmq - Gprod)_aa + (..)_bb + Gkpq_a Gpmq_b + Gkpq_b Gpmq_a
+            cplx t = csub(cmul(gk[0], gp[0]), gx[0]);
+            t = cadd(t, csub(cmul(gk[1], gp[1]), gx[1]));
+            t = cadd(t, cmul(gk[0], gp[1]));
+            t = cadd(t, cmul(gk[1], gp[0]));
+            const double f = vqvec[q] / (2.0 * vol);
+            per += f * t.x; pei += f * t.y;
+        }
+    }
+    double v[4] = {ker, kei, per, pei};
+    for (int k = 0; k < 4; ++k) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        v[k] = red[0] + red[1] + red[2] + red[3];
+    }
+    if (tid == 0) {
+        energy[3 * w + 0] = cmake(v[0] + v[2], v[1] + v[3]);
+        energy[3 * w + 1] = cmake(v[0], v[1]);
+        energy[3 * w + 2] = cmake(v[2], v[3]);
+    }
+}
+
+int k_energy_ueg(afq_handle *h) {
+    hipLaunchKernelGGL(energy_ueg_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->G, h->energy, h->M, h->nq,
+                       h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
+                       h->H1diag);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}

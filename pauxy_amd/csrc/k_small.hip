@@ -1,0 +1,654 @@
+// Per-walker small dense work: overlap matrices, LU (determinant + solve for
+// the half-rotated Green's function), Gram-Schmidt re-orthogonalisation, the
+// field shift / clipping, the phaseless weight update, population control and
+// the mixed-estimator accumulation.  One workgroup per walker; panels live in
+// LDS when they fit and in a global workspace otherwise.
+#include "afq_internal.h"
+
+#define NTHR 256
+
+// --------------------------------------------------------------------------
+__global__ void alive_kernel(const double *weight, int *alive, int nw) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) alive[w] = fabs(weight[w]) > 1e-8 ? 1 : 0;   // qmc/afqmc.py:232
+}
+
+int k_alive(afq_handle *h) {
+    hipLaunchKernelGGL(alive_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
+                       h->alive, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+// LU with partial pivoting of an n x n complex matrix O (row-major, leading
+// dimension n) held in LDS or global memory.  All NTHR threads cooperate.
+// perm[i] = source row of pivoted row i.  Returns (on every thread) nothing;
+// thread 0 accumulates phase and log|det| into *ph, *la.
+__device__ inline void lu_factor(cplx *O, int n, int *perm, int *piv_s, cplx *ph, double *la) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += NTHR) perm[i] = i;
+    if (tid == 0) { *ph = cmake(1.0, 0.0); *la = 0.0; }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        // pivot search by wave 0: LAPACK izamax metric |re| + |im|
+        if (tid < 64) {
+            double best = -1.0; int bi = k;
+            for (int i = k + tid; i < n; i += 64) {
+                const cplx v = O[(long)i * n + k];
+                const double m = fabs(v.x) + fabs(v.y);
+                if (m > best) { best = m; bi = i; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_down(best, off);
+                const int oi = __shfl_down(bi, off);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) *piv_s = bi;
+        }
+        __syncthreads();
+        const int p = *piv_s;
+        if (p != k) {
+            for (int j = tid; j < n; j += NTHR) {
+                const cplx t = O[(long)k * n + j];
+                O[(long)k * n + j] = O[(long)p * n + j];
+                O[(long)p * n + j] = t;
+            }
+            if (tid == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+        }
+        __syncthreads();
+        const cplx d = O[(long)k * n + k];
+        if (tid == 0) {
+            const double a = hypot(d.x, d.y);
+            cplx u = cmake(d.x / a, d.y / a);
+            if (p != k) u = cmake(-u.x, -u.y);
+            *ph = cmul(*ph, u);
+            *la += log(a);
+        }
+        for (int i = k + 1 + tid; i < n; i += NTHR) O[(long)i * n + k] = cdiv(O[(long)i * n + k], d);
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += NTHR) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            cplx v = O[(long)i * n + j];
+            const cplx l = O[(long)i * n + k], u = O[(long)k * n + j];
+            v.x = fma(-l.x, u.x, v.x); v.x = fma(l.y, u.y, v.x);
+            v.y = fma(-l.x, u.y, v.y); v.y = fma(-l.y, u.x, v.y);
+            O[(long)i * n + j] = v;
+        }
+        __syncthreads();
+    }
+}
+
+struct GreensArgs {
+    int M, na, nb, nt, nw;
+    const cplx *phi, *psi;
+    cplx *ghalf;        // may be null (determinant only)
+    cplx *det;          // [nw]
+    cplx *ws;           // global workspace [nw, nmax*nmax] when O does not fit LDS
+    int o_in_lds;
+    int only_alive;
+    const int *alive;
+};
+
+// One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
+// (walkers/single_det.py:310,316); Ghalf_s = O^-1 phi_s^T solved column by
+// column from the LU factors; det = prod over spins of det O.
+__global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int perm[256];
+    __shared__ int piv_s;
+    __shared__ cplx ph_s;
+    __shared__ double la_s;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (a.only_alive && !a.alive[w]) return;
+    const int M = a.M, nt = a.nt;
+    const cplx *phi = a.phi + (long)w * M * nt;
+    cplx phase = cmake(1.0, 0.0);
+    double logabs = 0.0;
+    for (int s = 0; s < 2; ++s) {
+        const int n = s == 0 ? a.na : a.nb;
+        const int off = s == 0 ? 0 : a.na;
+        if (n == 0) continue;
+        cplx *O = a.o_in_lds ? (cplx *)smem : a.ws + (long)w * ((a.na > a.nb ? a.na : a.nb) * (long)(a.na > a.nb ? a.na : a.nb));
+        for (int e = tid; e < n * n; e += NTHR) {
+            const int i = e / n, j = e % n;
+            cplx acc = cmake(0.0, 0.0);
+            for (int p = 0; p < M; ++p) {
+                const cplx x = phi[(long)p * nt + off + i];
+                const cplx y = a.psi[(long)p * nt + off + j];
+                // x * conj(y)
+                acc.x = fma(x.x, y.x, acc.x); acc.x = fma(x.y, y.y, acc.x);
+                acc.y = fma(x.y, y.x, acc.y); acc.y = fma(-x.x, y.y, acc.y);
+            }
+            O[(long)i * n + j] = acc;
+        }
+        __syncthreads();
+        lu_factor(O, n, perm, &piv_s, &ph_s, &la_s);
+        if (tid == 0) { phase = cmul(phase, ph_s); logabs += la_s; }
+        if (a.ghalf) {
+            // column c of Ghalf_s: solve L U x = P phi_s^T[:, c]
+            cplx *gh = a.ghalf + ((long)w * nt + off) * M;
+            for (int c = tid; c < M; c += NTHR) {
+                for (int i = 0; i < n; ++i) {
+                    cplx acc = phi[(long)c * nt + off + perm[i]];
+                    for (int j = 0; j < i; ++j) {
+                        const cplx l = O[(long)i * n + j], y = gh[(long)j * M + c];
+                        acc.x = fma(-l.x, y.x, acc.x); acc.x = fma(l.y, y.y, acc.x);
+                        acc.y = fma(-l.x, y.y, acc.y); acc.y = fma(-l.y, y.x, acc.y);
+                    }
+                    gh[(long)i * M + c] = acc;
+                }
+                for (int i = n - 1; i >= 0; --i) {
+                    cplx acc = gh[(long)i * M + c];
+                    for (int j = i + 1; j < n; ++j) {
+                        const cplx u = O[(long)i * n + j], x = gh[(long)j * M + c];
+                        acc.x = fma(-u.x, x.x, acc.x); acc.x = fma(u.y, x.y, acc.x);
+                        acc.y = fma(-u.x, x.y, acc.y); acc.y = fma(-u.y, x.x, acc.y);
+                    }
+                    gh[(long)i * M + c] = cdiv(acc, O[(long)i * n + i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double e = exp(logabs);
+        a.det[w] = cmake(phase.x * e, phase.y * e);
+    }
+}
+
+static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) {
+    GreensArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
+    a.phi = h->phi; a.psi = h->psi; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
+    const size_t need = sizeof(cplx) * (size_t)nmax * nmax;
+    a.o_in_lds = need <= 64 * 1024;
+    a.only_alive = only_alive; a.alive = h->alive;
+    if (!a.o_in_lds && !h->lu_ws)
+        AFQ_HIP(h, hipMalloc(&h->lu_ws, sizeof(cplx) * (size_t)h->nw * nmax * nmax));
+    a.ws = h->lu_ws;
+    hipLaunchKernelGGL(greens_kernel, dim3(h->nw), dim3(NTHR), a.o_in_lds ? need : 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_greens(afq_handle *h, cplx *det_out) { return launch_greens(h, h->ghalf, det_out, 0); }
+// det(psi^H phi) == det(phi^T conj(psi)) (transpose), so the same factorisation serves
+// walkers/single_det.py:170-199
+int k_overlap(afq_handle *h, cplx *det_out) { return launch_greens(h, nullptr, det_out, 0); }
+
+// --------------------------------------------------------------------------
+// force bias from the contraction output, per system
+struct XbarArgs {
+    int kind, flags, M, K, na, nb, nt, nw, nsplit, nq;
+    double sqrt_dt, U;
+    const cplx *vbias, *mf, *ghalf, *psi;
+    cplx *xbar;
+};
+
+__global__ void xbar_kernel(XbarArgs a) {
+    const int w = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.K) return;
+    cplx out = cmake(0.0, 0.0);
+    if (a.flags & AFQ_PROP_FORCE_BIAS) {
+        if (a.kind == AFQ_SYS_GENERIC) {
+            // propagation/generic.py:150-152: -sqrt(dt) (i vbias - mf_shift)
+            cplx v = cmake(0.0, 0.0);
+            for (int b = 0; b < 2 * a.nsplit; ++b) v = cadd(v, a.vbias[((long)b * a.nw + w) * a.K + n]);
+            const cplx m = a.mf[n];
+            out = cmake(-a.sqrt_dt * (-v.y - m.x), -a.sqrt_dt * (v.x - m.y));
+        } else if (a.kind == AFQ_SYS_HUBBARD) {
+            // diag of G_s = conj(psi_s) Ghalf_s at site n
+            cplx g[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+            for (int s = 0; s < 2; ++s) {
+                const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+                for (int i = 0; i < ns; ++i) {
+                    const cplx c = cconj(a.psi[(long)n * a.nt + off + i]);
+                    cfma(g[s], c, a.ghalf[((long)w * a.nt + off + i) * a.M + n]);
+                }
+            }
+            const cplx m = a.mf[n];
+            const double su = sqrt(a.U);
+            cplx vb;
+            if (a.flags & AFQ_PROP_HUBBARD_SPIN) {       // propagation/hubbard.py:472
+                vb = cmake(su * (g[0].x - g[1].x), su * (g[0].y - g[1].y));
+            } else {                                      // propagation/hubbard.py:406: i sqrt(U) (n_up + n_dn)
+                const cplx t = cadd(g[0], g[1]);
+                vb = cmake(-su * t.y, su * t.x);
+            }
+            out = cmake(-a.sqrt_dt * (vb.x - m.x), -a.sqrt_dt * (vb.y - m.y));
+        } else {
+            // UEG: propagation/planewave.py:76 (vbias filled by the sparse kernel)
+            const cplx v = a.vbias[(long)w * a.K + n];
+            out = cmake(-a.sqrt_dt * v.x, -a.sqrt_dt * v.y);
+        }
+    }
+    a.xbar[(long)w * a.K + n] = out;
+}
+
+int k_xbar(afq_handle *h) {
+    XbarArgs a;
+    a.kind = h->kind; a.flags = h->flags; a.M = h->M; a.K = h->K; a.na = h->na; a.nb = h->nb;
+    a.nt = h->nt; a.nw = h->nw; a.nsplit = h->fb_split; a.nq = h->nq;
+    a.sqrt_dt = h->sqrt_dt; a.U = h->U;
+    a.vbias = h->vbias; a.mf = h->mf_shift; a.ghalf = h->ghalf; a.psi = h->psi; a.xbar = h->xbar;
+    hipLaunchKernelGGL(xbar_kernel, dim3((h->K + 127) / 128, h->nw), dim3(128), 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double *red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// propagation/continuous.py:140-158: clip, shift, constant factors
+__global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, const double *xi, cplx *xbar,
+                                                      const cplx *mf, cplx *xs, cplx *cmf, cplx *cfb,
+                                                      unsigned long long *counters, const int *alive) {
+    __shared__ double red[8];
+    const int w = blockIdx.x;
+    if (alive && !alive[w]) return;
+    double s_mf_r = 0, s_mf_i = 0, s_xx_r = 0, s_xx_i = 0, s_bb_r = 0, s_bb_i = 0;
+    unsigned int ntrig = 0;
+    for (int n = threadIdx.x; n < K; n += NTHR) {
+        cplx b = xbar[(long)w * K + n];
+        const double ab = hypot(b.x, b.y);
+        if (ab > 1.0) { b.x /= ab; b.y /= ab; ++ntrig; }
+        const double x = xi[(long)w * K + n];
+        const cplx sft = cmake(x - b.x, -b.y);
+        xbar[(long)w * K + n] = b;
+        xs[(long)w * K + n] = sft;
+        const cplx m = mf[n];
+        s_mf_r += sft.x * m.x - sft.y * m.y;
+        s_mf_i += sft.x * m.y + sft.y * m.x;
+        s_xx_r += x * b.x; s_xx_i += x * b.y;
+        s_bb_r += b.x * b.x - b.y * b.y;
+        s_bb_i += 2.0 * b.x * b.y;
+    }
+    s_mf_r = block_sum(s_mf_r, red); s_mf_i = block_sum(s_mf_i, red);
+    s_xx_r = block_sum(s_xx_r, red); s_xx_i = block_sum(s_xx_i, red);
+    s_bb_r = block_sum(s_bb_r, red); s_bb_i = block_sum(s_bb_i, red);
+    const double nt = block_sum((double)ntrig, red);
+    if (threadIdx.x == 0) {
+        cmf[w] = cmake(-sqrt_dt * s_mf_r, -sqrt_dt * s_mf_i);
+        cfb[w] = cmake(s_xx_r - 0.5 * s_bb_r, s_xx_i - 0.5 * s_bb_i);
+        if (nt > 0 && counters) atomicAdd(&counters[0], (unsigned long long)nt);
+    }
+}
+
+int k_fields(afq_handle *h) {
+    hipLaunchKernelGGL(fields_kernel, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d,
+                      cplx *cfb_d) {
+    hipLaunchKernelGGL(fields_kernel, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
+                       (cplx *)xbar_d, h->mf_shift, xs_d, cmf_d, cfb_d, (unsigned long long *)nullptr,
+                       (const int *)nullptr);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+__device__ inline cplx clog_(cplx z) { return cmake(log(hypot(z.x, z.y)), atan2(z.y, z.x)); }
+__device__ inline cplx cexp_(cplx z) {
+    const double e = exp(z.x);
+    double s, c; sincos(z.y, &s, &c);
+    return cmake(e * c, e * s);
+}
+
+struct WeightArgs {
+    int nw, flags;
+    double dt;
+    cplx eshift;
+    const int *alive;
+    const cplx *ovlp_old, *ovlp_new, *cmf, *cfb;
+    double *weight;
+    cplx *ot, *ehyb, *phase;
+    unsigned long long *counters;
+};
+
+// propagation/continuous.py:264-292 (hybrid) and :194-200 (free projection)
+__global__ void weight_kernel(WeightArgs a) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nw || !a.alive[w]) return;
+    const cplx on = a.ovlp_new[w];
+    if (a.flags & AFQ_PROP_FREE_PROJECTION) {
+        const cplx e = cexp_(cmake(a.cmf[w].x + a.dt * a.eshift.x, a.cmf[w].y + a.dt * a.eshift.y));
+        const double magn = hypot(e.x, e.y), dth = atan2(e.y, e.x);
+        a.weight[w] *= magn;
+        double s, c; sincos(dth, &s, &c);
+        a.phase[w] = cmul(a.phase[w], cmake(c, s));
+        a.ot[w] = on;
+        return;
+    }
+    const cplx ratio = cdiv(on, a.ovlp_old[w]);
+    const cplx lg = clog_(ratio);
+    cplx eh = cmake(-(lg.x + a.cfb[w].x + a.cmf[w].x) / a.dt, -(lg.y + a.cfb[w].y + a.cmf[w].y) / a.dt);
+    const double ebound = sqrt(2.0 / a.dt);
+    if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {       // continuous.py:206
+        if (eh.x > a.eshift.x + ebound) { eh.x = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
+        else if (eh.x < a.eshift.x - ebound) { eh.x = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
+    }
+    const cplx old = a.ehyb[w];
+    const cplx arg = cmake(-a.dt * (0.5 * (eh.x + old.x) - a.eshift.x), -a.dt * (0.5 * (eh.y + old.y) - a.eshift.y));
+    const cplx imp = cexp_(arg);
+    const double magn = hypot(imp.x, imp.y);
+    a.ehyb[w] = eh;
+    a.ot[w] = on;
+    if (!isinf(magn)) {
+        const double dtheta = -a.dt * eh.y - a.cfb[w].y;
+        const double cf = fmax(0.0, cos(dtheta));
+        a.weight[w] *= magn * cf;
+    } else {
+        a.weight[w] = 0.0;
+    }
+}
+
+int k_update_weight(afq_handle *h, cplx eshift) {
+    WeightArgs a;
+    a.nw = h->nw; a.flags = h->flags; a.dt = h->dt; a.eshift = eshift; a.alive = h->alive;
+    a.ovlp_old = h->ovlp_old; a.ovlp_new = h->ovlp_new; a.cmf = h->cmf; a.cfb = h->cfb;
+    a.weight = h->weight; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase; a.counters = h->counters;
+    hipLaunchKernelGGL(weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+// Re-orthogonalisation: classical Gram-Schmidt applied twice per column.  With
+// R_jj = ||v|| > 0 this is the unique QR with positive diagonal, i.e. exactly
+// what the reference obtains from LAPACK QR followed by the sign fix
+// (walkers/single_det.py:225-242); detR = prod_j R_jj over both spins.
+struct QrArgs {
+    int M, na, nb, nt, nw, in_lds, flags;
+    cplx *phi;
+    cplx *ws;           // global panel [nw, nmax, M] when it does not fit LDS
+    double *detR, *weight;
+    cplx *ot;
+};
+
+__global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cplx coef[256];
+    __shared__ double red[8];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = a.M, nt = a.nt;
+    cplx *phi = a.phi + (long)w * M * nt;
+    const int nmax = a.na > a.nb ? a.na : a.nb;
+    cplx *Q = a.in_lds ? (cplx *)smem : a.ws + (long)w * nmax * M;     // Q[i][p], column i contiguous
+    double logdet = 0.0;
+    for (int s = 0; s < 2; ++s) {
+        const int n = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+        if (n == 0) continue;
+        for (int e = tid; e < n * M; e += NTHR) {
+            const int p = e / n, i = e % n;
+            Q[(long)i * M + p] = phi[(long)p * nt + off + i];
+        }
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            cplx *v = Q + (long)j * M;
+            for (int pass = 0; pass < 2 && j > 0; ++pass) {
+                for (int i = wave; i < j; i += NTHR / 64) {
+                    const cplx *q = Q + (long)i * M;
+                    double sr = 0, si = 0;
+                    for (int p = lane; p < M; p += 64) {
+                        const cplx x = q[p], y = v[p];      // conj(x) * y
+                        sr += x.x * y.x + x.y * y.y;
+                        si += x.x * y.y - x.y * y.x;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) { sr += __shfl_down(sr, o); si += __shfl_down(si, o); }
+                    if (lane == 0) coef[i] = cmake(sr, si);
+                }
+                __syncthreads();
+                for (int p = tid; p < M; p += NTHR) {
+                    cplx y = v[p];
+                    for (int i = 0; i < j; ++i) {
+                        const cplx c = coef[i], x = Q[(long)i * M + p];
+                        y.x = fma(-c.x, x.x, y.x); y.x = fma(c.y, x.y, y.x);
+                        y.y = fma(-c.x, x.y, y.y); y.y = fma(-c.y, x.x, y.y);
+                    }
+                    v[p] = y;
+                }
+                __syncthreads();
+            }
+            double nn = 0.0;
+            for (int p = tid; p < M; p += NTHR) nn += cabs2(v[p]);
+            nn = block_sum(nn, red);
+            const double r = sqrt(nn), inv = 1.0 / r;
+            logdet += log(r);
+            for (int p = tid; p < M; p += NTHR) v[p] = cscale(v[p], inv);
+            __syncthreads();
+        }
+        for (int e = tid; e < n * M; e += NTHR) {
+            const int p = e / n, i = e % n;
+            phi[(long)p * nt + off + i] = Q[(long)i * M + p];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double d = exp(logdet);
+        a.detR[w] = d;
+        a.ot[w] = cmake(a.ot[w].x / d, a.ot[w].y / d);           // single_det.py:253
+        if (a.flags & AFQ_PROP_FREE_PROJECTION) a.weight[w] *= d;  // walkers/handler.py:178-181
+    }
+}
+
+int k_reortho(afq_handle *h) {
+    QrArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.flags = h->flags;
+    a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot;
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    const size_t need = sizeof(cplx) * (size_t)nmax * h->M;
+    a.in_lds = need <= 64 * 1024;
+    a.ws = h->phi_t2;       // scratch panel (nmax*M <= M*nt elements per walker)
+    hipLaunchKernelGGL(reortho_kernel, dim3(h->nw), dim3(NTHR), a.in_lds ? need : 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+__global__ void cap_kernel(double *weight, int nw, double cap) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw && fabs(weight[w]) > cap) weight[w] = cap;       // qmc/afqmc.py:235-236
+}
+
+int k_cap_weights(afq_handle *h, double frac, double total_weight) {
+    hipLaunchKernelGGL(cap_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
+                       frac * total_weight);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+__global__ void scale_kernel(double *weight, double *unscaled, int nw, double scale) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) { unscaled[w] = weight[w]; weight[w] = weight[w] / scale; }   // handler.py:244-246
+}
+
+int k_scale_weights(afq_handle *h, double scale) {
+    hipLaunchKernelGGL(scale_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
+                       h->unscaled, h->nw, scale);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+__global__ void reset_kernel(double *weight, int nw) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) weight[w] = 1.0;                                   // handler.py:337-338
+}
+
+int k_reset_weights(afq_handle *h) {
+    hipLaunchKernelGGL(reset_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// Single-rank comb (walkers/handler.py:225-301).  The cumulative sums and the
+// walk over the comb teeth are inherently sequential and must reproduce the
+// reference's left-to-right double additions, so one thread does them (nw adds).
+// scal[0] = total weight (before scaling), scal[1] = number of (clone, kill) pairs.
+__global__ void comb_plan_kernel(double *weight, double *unscaled, int nw, double r, double target,
+                                 int *parent_ix, int *pairs, double *scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int i = 0; i < nw; ++i) total += fabs(weight[i]);
+    scal[0] = total;
+    if (total < 1e-8) { scal[1] = -1.0; return; }
+    const double scale = total / target;
+    double tot2 = 0.0;
+    for (int i = 0; i < nw; ++i) {
+        unscaled[i] = weight[i];
+        const double a = fabs(weight[i]) / scale;     // global_weights / scale (handler.py:248)
+        weight[i] = weight[i] / scale;
+        tot2 += a;
+        parent_ix[i] = 0;
+    }
+    const int ntarget = (int)target;
+    const double step = tot2 / target;
+    int iw = 0, ic = 0;
+    double cprob = fabs(unscaled[0]) / scale;
+    while (ic < ntarget && iw < nw) {
+        const double tooth = (ic + r) * step;
+        if (tooth < cprob) { parent_ix[iw] += 1; ++ic; }
+        else { ++iw; if (iw < nw) cprob += fabs(unscaled[iw]) / scale; }
+    }
+    // zip(clone, kill): handler.py:295-301
+    int ik = 0, np = 0;
+    for (int c = 0; c < nw; ++c) {
+        if (parent_ix[c] > 1) {
+            while (ik < nw && parent_ix[ik] != 0) ++ik;
+            if (ik >= nw) break;
+            pairs[2 * np] = c; pairs[2 * np + 1] = ik; ++np; ++ik;
+        }
+    }
+    scal[1] = (double)np;
+}
+
+struct CloneArgs {
+    long per;
+    cplx *phi, *ot, *ehyb, *phase, *eloc;
+    double *unscaled, *detR;
+    const int *pairs;
+    const double *scal;
+};
+
+__global__ void clone_kernel(CloneArgs a) {
+    const int pr = blockIdx.y;
+    if (pr >= (int)a.scal[1]) return;
+    const int src = a.pairs[2 * pr], dst = a.pairs[2 * pr + 1];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
+        a.phi[dst * a.per + i] = a.phi[src * a.per + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.ot[dst] = a.ot[src]; a.ehyb[dst] = a.ehyb[src]; a.phase[dst] = a.phase[src];
+        a.eloc[dst] = a.eloc[src]; a.unscaled[dst] = a.unscaled[src]; a.detR[dst] = a.detR[src];
+    }
+}
+
+int k_comb(afq_handle *h, double r, double target) {
+    int *pairs = (int *)h->pack_tmp;
+    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(64), 0, h->stream, h->weight, h->unscaled, h->nw, r,
+                       target, h->parent_ix, pairs, h->scal);
+    AFQ_HIP(h, hipGetLastError());
+    CloneArgs a;
+    a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
+    a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = pairs; a.scal = h->scal;
+    // at most nw/2 pairs
+    hipLaunchKernelGGL(clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return k_reset_weights(h);
+}
+
+// --------------------------------------------------------------------------
+// estimators/mixed.py:211-225: one workgroup, deterministic tree sums.
+__global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy, const double *weight,
+                                                         const double *unscaled, const cplx *ot,
+                                                         const cplx *ehyb, const cplx *energy, cplx *est) {
+    __shared__ double red[8];
+    double uw = 0, wt = 0, ov = 0, ehr = 0, ehi = 0, en = 0, e1 = 0, e2 = 0;
+    for (int w = threadIdx.x; w < nw; w += NTHR) {
+        const double x = weight[w];
+        uw += unscaled[w]; wt += x;
+        ov += x * hypot(ot[w].x, ot[w].y);
+        ehr += x * ehyb[w].x; ehi += x * ehyb[w].y;
+        if (have_energy) { en += x * energy[3 * w].x; e1 += x * energy[3 * w + 1].x; e2 += x * energy[3 * w + 2].x; }
+    }
+    uw = block_sum(uw, red); wt = block_sum(wt, red); ov = block_sum(ov, red);
+    ehr = block_sum(ehr, red); ehi = block_sum(ehi, red);
+    en = block_sum(en, red); e1 = block_sum(e1, red); e2 = block_sum(e2, red);
+    if (threadIdx.x == 0) {
+        est[AFQ_EST_UWEIGHT].x += uw; est[AFQ_EST_WEIGHT].x += wt; est[AFQ_EST_OVLP].x += ov;
+        est[AFQ_EST_EHYB].x += ehr; est[AFQ_EST_EHYB].y += ehi;
+        if (have_energy) {
+            est[AFQ_EST_ENUMER].x += en; est[AFQ_EST_E1B].x += e1; est[AFQ_EST_E2B].x += e2;
+            est[AFQ_EST_EDENOM].x += wt;
+        }
+    }
+}
+
+int k_estimates(afq_handle *h, int have_energy) {
+    hipLaunchKernelGGL(estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, h->weight,
+                       h->unscaled, h->ot, h->ehyb, h->energy, h->estimates);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller: the device stream of
+// auxiliary fields used when the host passes xi == NULL (performance mode; the
+// parity mode uploads numpy's legacy MT19937 normals instead).
+__device__ inline void philox_round(unsigned int &c0, unsigned int &c1, unsigned int &c2, unsigned int &c3,
+                                    unsigned int k0, unsigned int k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned int h0 = (unsigned int)(p0 >> 32), l0 = (unsigned int)p0;
+    const unsigned int h1 = (unsigned int)(p1 >> 32), l1 = (unsigned int)p1;
+    const unsigned int n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+}
+
+__global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, unsigned long long stream,
+                                  unsigned long long counter) {
+    const long pair = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (2 * pair >= n) return;
+    unsigned int c0 = (unsigned int)pair, c1 = (unsigned int)(pair >> 32);
+    unsigned int c2 = (unsigned int)counter, c3 = (unsigned int)(counter >> 32) ^ (unsigned int)(stream * 0x9E3779B9u);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    // two 53-bit uniforms in (0, 1]
+    const unsigned long long a = (((unsigned long long)c0 << 32) | c1) >> 11;
+    const unsigned long long b = (((unsigned long long)c2 << 32) | c3) >> 11;
+    const double u1 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)b + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c; sincospi(2.0 * u2, &s, &c);
+    xi[2 * pair] = rad * c;
+    if (2 * pair + 1 < n) xi[2 * pair + 1] = rad * s;
+}
+
+int k_rng_normal(afq_handle *h) {
+    const long n = (long)h->nw * h->K;
+    const long pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(rng_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, h->xi, n,
+                       (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
+                       (unsigned long long)h->rng_counter);
+    AFQ_HIP(h, hipGetLastError());
+    h->rng_counter += 1;
+    return AFQ_OK;
+}

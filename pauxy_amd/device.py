@@ -1,0 +1,270 @@
+"""Thin numpy-facing wrapper over the C ABI: one ``AfqDevice`` per GPU.
+
+Every array crossing this boundary is a C-contiguous numpy array; complex128
+arrays are passed as their interleaved (re, im) storage, exactly what
+``include/afqmc_hip.h`` documents.  All arithmetic happens in the library.
+"""
+import ctypes
+
+import numpy
+
+from pauxy_amd import _lib as L
+
+
+def _c128(a, shape=None):
+    a = numpy.ascontiguousarray(a, dtype=numpy.complex128)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _f64(a, shape=None):
+    a = numpy.ascontiguousarray(a, dtype=numpy.float64)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _i64(a):
+    return numpy.ascontiguousarray(a, dtype=numpy.int64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _flatten_ragged(lists):
+    off = numpy.zeros(len(lists) + 1, dtype=numpy.int64)
+    off[1:] = numpy.cumsum([len(x) for x in lists])
+    flat = numpy.concatenate([numpy.asarray(x, dtype=numpy.int64) for x in lists]) if off[-1] else \
+        numpy.zeros(0, dtype=numpy.int64)
+    return off, _i64(flat)
+
+
+class AfqDevice(object):
+    def __init__(self, device_id=0):
+        self.lib = L.load()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.afq_create(int(device_id), ctypes.byref(self.h))
+        if rc != 0:
+            raise L.AfqError(rc, "afq_create failed (no usable MI355X device %d?)" % device_id)
+        self.device_id = device_id
+        self.kind = None
+        self.nw = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise L.AfqError(rc, self.lib.afq_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.afq_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._ck(self.lib.afq_sync(self.h))
+
+    # -- inputs -----------------------------------------------------------
+    def set_system_generic(self, hs_pot, rchol, H1, ecore, na, nb):
+        H1 = _c128(H1)
+        M = H1.shape[-1]
+        hs_pot = _f64(hs_pot)
+        K = hs_pot.shape[1]
+        assert hs_pot.shape == (M * M, K)
+        rchol = _c128(rchol, ((na + nb) * M, K))
+        self._ck(self.lib.afq_set_system_generic(self.h, M, K, na, nb, _p(hs_pot), _p(rchol), _p(H1),
+                                                 float(numpy.real(ecore))))
+        self.kind, self.M, self.K, self.na, self.nb = 'generic', M, K, na, nb
+
+    def set_system_hubbard(self, T, U, na, nb):
+        T = _c128(T)
+        M = T.shape[-1]
+        self._ck(self.lib.afq_set_system_hubbard(self.h, M, na, nb, float(U), _p(T)))
+        self.kind, self.M, self.K, self.na, self.nb = 'hubbard', M, M, na, nb
+
+    def set_system_ueg(self, iA, iB, ikpq_i, ikpq_kpq, ipmq_i, ipmq_pmq, vqvec, vol, H1diag, ecore, na, nb):
+        iA = iA.tocsc()
+        iB = iB.tocsc()
+        iA.sort_indices()
+        iB.sort_indices()
+        H1diag = _f64(H1diag)
+        M = H1diag.shape[-1]
+        nq = iA.shape[1]
+        koff, ki = _flatten_ragged(ikpq_i)
+        _, kk = _flatten_ragged(ikpq_kpq)
+        poff, pi = _flatten_ragged(ipmq_i)
+        _, pp = _flatten_ragged(ipmq_pmq)
+        arrs = [_i64(iA.indptr), _i64(iA.indices), _c128(iA.data), _i64(iB.indptr), _i64(iB.indices),
+                _c128(iB.data), koff, ki, kk, poff, pi, pp, _f64(vqvec)]
+        self._ck(self.lib.afq_set_system_ueg(self.h, M, nq, na, nb, *[_p(a) for a in arrs], float(vol),
+                                             _p(H1diag), float(ecore)))
+        self.kind, self.M, self.K, self.na, self.nb = 'ueg', M, 2 * nq, na, nb
+
+    def set_trial(self, psi):
+        psi = _c128(psi, (self.M, self.na + self.nb))
+        self._ck(self.lib.afq_set_trial(self.h, _p(psi)))
+
+    def set_propagator(self, BH1, mf_shift, dt, exp_order=6, hybrid=True, force_bias=True,
+                       free_projection=False, hubbard_spin=False):
+        BH1 = _c128(BH1, (2, self.M, self.M))
+        mf = _c128(mf_shift, (self.K,))
+        flags = ((L.AFQ_PROP_HYBRID if hybrid else 0) | (L.AFQ_PROP_FORCE_BIAS if force_bias else 0) |
+                 (L.AFQ_PROP_FREE_PROJECTION if free_projection else 0) |
+                 (L.AFQ_PROP_HUBBARD_SPIN if hubbard_spin else 0))
+        self._ck(self.lib.afq_set_propagator(self.h, _p(BH1), _p(mf), float(dt), int(exp_order), flags))
+        nv = ctypes.c_int()
+        self._ck(self.lib.afq_vhs_count(self.h, ctypes.byref(nv)))
+        self.nv = nv.value
+
+    # -- walkers ----------------------------------------------------------
+    def walkers_alloc(self, nw):
+        self._ck(self.lib.afq_walkers_alloc(self.h, int(nw)))
+        self.nw = int(nw)
+
+    def _field_spec(self, field):
+        M, nt, K = self.M, self.na + self.nb, self.K
+        return {
+            L.F_PHI: ((M, nt), numpy.complex128), L.F_WEIGHT: ((), numpy.float64),
+            L.F_UNSCALED_WEIGHT: ((), numpy.float64), L.F_OT: ((), numpy.complex128),
+            L.F_HYBRID_ENERGY: ((), numpy.complex128), L.F_PHASE: ((), numpy.complex128),
+            L.F_DETR: ((), numpy.float64), L.F_ELOC: ((), numpy.complex128),
+            L.F_GHALF: ((nt, M), numpy.complex128), L.F_G: ((2, M, M), numpy.complex128),
+            L.F_XBAR: ((K,), numpy.complex128), L.F_XSHIFTED: ((K,), numpy.complex128),
+            L.F_ENERGY: ((3,), numpy.complex128),
+        }[field]
+
+    def set(self, field, values, first=0):
+        shape, dt = self._field_spec(field)
+        values = numpy.ascontiguousarray(values, dtype=dt)
+        if values.shape == shape:
+            values = values.reshape((1,) + shape)
+        assert values.shape[1:] == shape, (values.shape, shape)
+        self._ck(self.lib.afq_walkers_set(self.h, field, _p(values), int(first), values.shape[0]))
+
+    def get(self, field, first=0, count=None):
+        shape, dt = self._field_spec(field)
+        count = self.nw - first if count is None else count
+        out = numpy.empty((count,) + shape, dtype=dt)
+        self._ck(self.lib.afq_walkers_get(self.h, field, _p(out), int(first), int(count)))
+        return out
+
+    # -- hot path ---------------------------------------------------------
+    def greens(self, want_G=False, fetch=True):
+        out = numpy.empty(self.nw, dtype=numpy.complex128) if fetch else None
+        self._ck(self.lib.afq_greens(self.h, int(bool(want_G)), _p(out)))
+        return out
+
+    def calc_overlap(self, fetch=True):
+        out = numpy.empty(self.nw, dtype=numpy.complex128) if fetch else None
+        self._ck(self.lib.afq_calc_overlap(self.h, _p(out)))
+        return out
+
+    def propagate(self, xi, eshift):
+        if xi is not None:
+            xi = _f64(xi, (self.nw, self.K))
+        es = complex(eshift)
+        self._ck(self.lib.afq_propagate(self.h, _p(xi), es.real, es.imag))
+
+    def reortho(self, fetch=True):
+        out = numpy.empty(self.nw, dtype=numpy.float64) if fetch else None
+        self._ck(self.lib.afq_reortho(self.h, _p(out)))
+        return out
+
+    def local_energy(self, fetch=True):
+        out = numpy.empty((self.nw, 3), dtype=numpy.complex128) if fetch else None
+        self._ck(self.lib.afq_local_energy(self.h, _p(out)))
+        return out
+
+    def force_bias(self):
+        out = numpy.empty((self.nw, self.K), dtype=numpy.complex128)
+        self._ck(self.lib.afq_force_bias(self.h, _p(out)))
+        return out
+
+    def shift_fields(self, xi, xbar):
+        xi = _f64(xi, (self.nw, self.K))
+        xbar = _c128(xbar, (self.nw, self.K))
+        xs = numpy.empty((self.nw, self.K), dtype=numpy.complex128)
+        cmf = numpy.empty(self.nw, dtype=numpy.complex128)
+        cfb = numpy.empty(self.nw, dtype=numpy.complex128)
+        self._ck(self.lib.afq_shift_fields(self.h, _p(xi), _p(xbar), _p(xs), _p(cmf), _p(cfb)))
+        return xs, cmf, cfb
+
+    def vhs(self, xs):
+        xs = _c128(xs, (self.nw, self.K))
+        out = numpy.empty((self.nw, self.nv, self.M, self.M), dtype=numpy.complex128)
+        self._ck(self.lib.afq_vhs(self.h, _p(xs), _p(out)))
+        return out
+
+    def apply_exponential(self, vhs):
+        vhs = _c128(vhs, (self.nw, self.nv, self.M, self.M))
+        self._ck(self.lib.afq_apply_exponential(self.h, _p(vhs)))
+
+    def kinetic(self):
+        self._ck(self.lib.afq_kinetic(self.h))
+
+    # -- driver glue ------------------------------------------------------
+    def cap_weights(self, frac, total_weight):
+        self._ck(self.lib.afq_cap_weights(self.h, float(frac), float(total_weight)))
+
+    def popcontrol_comb(self, r, target, fetch=True):
+        pix = numpy.zeros(self.nw, dtype=numpy.int32) if fetch else None
+        tw = ctypes.c_double(0.0)
+        self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), _p(pix), ctypes.byref(tw)))
+        return pix, tw.value
+
+    def scale_weights(self, scale):
+        self._ck(self.lib.afq_walkers_scale_weights(self.h, float(scale)))
+
+    def reset_weights(self):
+        self._ck(self.lib.afq_walkers_reset_weights(self.h))
+
+    def copy_walker(self, src, dst):
+        self._ck(self.lib.afq_walkers_copy(self.h, int(src), int(dst)))
+
+    def pack_bytes(self):
+        n = ctypes.c_int64()
+        self._ck(self.lib.afq_walker_pack_bytes(self.h, ctypes.byref(n)))
+        return n.value
+
+    def pack(self, iw, dev_ptr):
+        self._ck(self.lib.afq_walker_pack(self.h, int(iw), ctypes.c_void_p(dev_ptr)))
+
+    def unpack(self, iw, dev_ptr):
+        self._ck(self.lib.afq_walker_unpack(self.h, int(iw), ctypes.c_void_p(dev_ptr)))
+
+    def estimates_update(self, eval_energy):
+        self._ck(self.lib.afq_estimates_update(self.h, int(bool(eval_energy))))
+
+    def estimates_get(self, zero=False):
+        out = numpy.empty(10, dtype=numpy.complex128)
+        self._ck(self.lib.afq_estimates_get(self.h, _p(out), int(bool(zero))))
+        return out
+
+    def rng_seed(self, seed, stream=0):
+        self._ck(self.lib.afq_rng_seed(self.h, int(seed), int(stream)))
+
+    def counters(self, reset=False):
+        out = numpy.zeros(4, dtype=numpy.int64)
+        self._ck(self.lib.afq_counters(self.h, _p(out), int(reset)))
+        return out
+
+    def enable_timers(self, on=True):
+        self._ck(self.lib.afq_enable_timers(self.h, int(on)))
+
+    def timers(self, reset=False):
+        out = numpy.zeros(8, dtype=numpy.float64)
+        self._ck(self.lib.afq_timers(self.h, _p(out), int(reset)))
+        return dict(zip(['greens', 'one_body', 'force_bias', 'vhs', 'exponential', 'overlap_weight',
+                         'reortho', 'energy'], out))
+
+    def last_energy_kernel_ms(self):
+        ms = ctypes.c_double()
+        self._ck(self.lib.afq_last_energy_kernel_ms(self.h, ctypes.byref(ms)))
+        return ms.value

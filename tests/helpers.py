@@ -49,3 +49,21 @@ def ueg_model(d, tag, systag=''):
                         ikpq_i=ragged(d, 'ikpq_i', systag), ikpq_kpq=ragged(d, 'ikpq_kpq', systag),
                         ipmq_i=ragged(d, 'ipmq_i', systag), ipmq_pmq=ragged(d, 'ipmq_pmq', systag),
                         ecore=float(d[systag + 'ecore']))
+
+
+def make_device(model, nw, device_id=0, **prop_kw):
+    """RefModel (plain arrays) -> AfqDevice with nw walkers allocated."""
+    from pauxy_amd.device import AfqDevice
+    dev = AfqDevice(device_id)
+    if model.kind == 'generic':
+        dev.set_system_generic(model.hs_pot, model.rchol, model.H1, model.ecore, model.na, model.nb)
+    elif model.kind in ('hubbard', 'hubbard_spin'):
+        dev.set_system_hubbard(model.H1, model.U, model.na, model.nb)
+        prop_kw.setdefault('hubbard_spin', model.kind == 'hubbard_spin')
+    elif model.kind == 'ueg':
+        dev.set_system_ueg(model.iA, model.iB, model.ikpq_i, model.ikpq_kpq, model.ipmq_i, model.ipmq_pmq,
+                           model.vqvec, model.vol, model.H1diag, model.ecore, model.na, model.nb)
+    dev.set_trial(model.psi)
+    dev.set_propagator(model.BH1, model.mf_shift, model.dt, exp_order=model.exp_order, **prop_kw)
+    dev.walkers_alloc(nw)
+    return dev
