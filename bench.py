@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole-step phaseless-AFQMC throughput in walker-steps/s
+on the BASELINE configs[2] workload (generic Hamiltonian, Nbasis=100, Nchol=500,
+RHF trial with 25+25 electrons, 256 walkers per GPU), plus the fp64-MFMA roofline
+fraction of the Cholesky exchange-energy kernel and the CPU-oracle baseline.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full AFQMC step over the rank's walker batch in the reference's
+cadence (qmc/afqmc.py:223-255): re-orthogonalisation every 10 steps, comb
+population control every 5, Green's function + local energy every 10, hybrid
+weight update and estimator accumulation every step.  Auxiliary fields are drawn
+on the device (Philox) inside the step.  Inputs are synthetic (SURVEY section 8d
+generator, seed 7) and resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, K, N = 100, 500, 25
+NW_PER_GPU = 256
+DT = 0.005
+NSTBLZ, NPOP, NSTEPS_BLOCK = 10, 5, 10
+PEAK_F64_MFMA_TFLOPS = 78.6          # MI355X fp64 matrix peak
+
+
+def exchange_flops_per_walker(M, K, na, nb):
+    # 4 flops per real x complex MAC; T_s[x,i,j] costs K*N_s^2*M MACs per spin
+    return 4.0 * K * M * (na * na + nb * nb)
+
+
+def build_inputs():
+    from pauxy_amd.systems import synthetic_generic
+    from pauxy_amd.trial import rhf_trial_generic
+    system = synthetic_generic(M, K, (N, N), seed=7)
+    trial = rhf_trial_generic(system)
+    return system, trial
+
+
+def cpu_baseline(system, trial, nw_cpu=16, nsteps=10):
+    """Oracle ("port") timed on the host cores over a bounded sample of the same
+    workload: nw_cpu walkers x nsteps steps in the same cadence."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd.propagation.setup import generic_propagator_arrays
+    BH1, mf = generic_propagator_arrays(system, trial, DT)
+    model = ref.RefModel('generic', M, N, N, trial.psi, BH1, mf, DT, hs_pot=system.hs_pot,
+                         rchol=trial._rchol, H1=system.H1.astype(complex), ecore=system.ecore)
+    walkers = [ref.new_walker(model, trial.psi) for _ in range(nw_cpu)]
+    rng = numpy.random.RandomState(11)
+    t0 = time.time()
+    ref.run_afqmc(model, walkers, lambda s, w: rng.normal(size=K), lambda s: rng.random_sample(),
+                  nsteps, 1, nstblz=NSTBLZ, npop_control=NPOP, energy_eval_freq=NSTEPS_BLOCK)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": nw_cpu * nsteps / dt, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d walkers x %d steps (1 block incl. step-0 and step-%d energy evaluations), numpy/scipy "
+                      "per-walker loop of oracle/afqmc_ref.py, %.1f s" % (nw_cpu, nsteps, nsteps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--walkers-per-gpu", type=int, default=NW_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from pauxy_amd.comm import TorchComm
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+
+    from pauxy_amd.qmc.afqmc import AFQMC
+    system, trial = build_inputs()
+    nw = args.walkers_per_gpu
+    options = {
+        'qmc': {'timestep': DT, 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
+                'pop_control_freq': NPOP, 'num_walkers': nw * world, 'rng_seed': 7},
+        'propagator': {'device_rng': not args.host_rng, 'rng_seed': 7, 'rng_stream': rank},
+        'estimators': {'mixed': {'verbose': False}},
+    }
+    afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
+    dev = afqmc.psi.dev
+
+    def barrier():
+        dev.sync()
+        torch.cuda.synchronize()
+        if comm is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eshift = afqmc.run_batched(args.warmup, first_step=1, eshift=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    afqmc.run_batched(args.steps, first_step=args.warmup + 1, eshift=eshift)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the dominant MFMA kernel: the exchange contraction, timed live
+    # with HIP events on the library's own stream (afq_last_energy_kernel_ms)
+    ker_ms = []
+    dev.greens(want_G=False, fetch=False)
+    for _ in range(5):
+        dev.local_energy(fetch=False)
+        ker_ms.append(dev.last_energy_kernel_ms())
+    ker_ms = float(numpy.median(ker_ms))
+    flops = exchange_flops_per_walker(M, K, N, N) * nw
+    achieved = flops / (ker_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        total_walkers = nw * world
+        out = {
+            "metric": "walker_steps_per_sec",
+            "value": total_walkers * args.steps / elapsed,
+            "unit": "walker-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "generic Cholesky AFQMC: Nbasis=100, Nchol=500, RHF trial 25+25 electrons, "
+                                   "%d walkers/GPU, dt=0.005, reortho/10, comb/5, energy/10 "
+                                   "(BASELINE configs[2])" % nw,
+                       "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox"},
+            "roofline": {"bound": "mfma", "kernel": "exx_kernel (Cholesky exchange energy)",
+                         "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": ker_ms, "flops_per_launch": flops},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(system, trial)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if comm is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""Communicators with the (small) mpi4py surface PAUXY's hot path uses.
+
+The reference talks MPI (mpi4py) in exactly three places on this path:
+population control (walkers/handler.py:232,291,313,322), the estimator reduction
+(estimators/mixed.py:261,273) and set-up broadcasts.  ``TorchComm`` provides the
+same method names over ``torch.distributed`` -- backend "nccl" (= RCCL over
+xGMI) with one process per GPU on the MI355X node, "gloo" on CPU for tests -- so
+``Walkers.pop_control(comm)`` / ``Mixed.print_step(comm, ...)`` read like the
+reference.  ``FakeComm`` is the size-1 communicator (reference: qmc/comm.py:1-32,
+completed with the methods the driver actually calls).
+
+All messages here are tiny (<= 16 KiB all-gather of weights, 160 B estimator
+sum) or point-to-point walker copies; there is no bandwidth-bound collective.
+"""
+import numpy
+
+
+class FakeComm(object):
+    rank = 0
+    size = 1
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+    def barrier(self):
+        pass
+
+    Barrier = barrier
+
+    def bcast(self, obj, root=0):
+        return obj
+
+    def Bcast(self, buf, root=0):
+        return buf
+
+    def Allgather(self, send, recv):
+        recv[...] = numpy.asarray(send).reshape(recv.shape)
+
+    def Reduce(self, send, recv, op=None, root=0):
+        recv[...] = send
+
+    def Allreduce(self, send, recv, op=None):
+        recv[...] = send
+
+    # walker transport (device or host tensors); never called at size 1
+    def send_tensor(self, t, dest, tag=0):
+        raise RuntimeError("send on a size-1 communicator")
+
+    def recv_tensor(self, t, source, tag=0):
+        raise RuntimeError("recv on a size-1 communicator")
+
+
+class TorchComm(object):
+    """mpi4py-like facade over an initialised torch.distributed process group."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch = torch
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+        self.device = device
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    Barrier = barrier
+
+    def bcast(self, obj, root=0):
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=root, group=self.group, device=self.device)
+        return box[0]
+
+    def _to_dev(self, a):
+        t = self._torch.from_numpy(numpy.ascontiguousarray(a))
+        if self._torch.is_complex(t):
+            t = self._torch.view_as_real(t)
+        return t.to(self.device)
+
+    def Bcast(self, buf, root=0):
+        t = self._to_dev(buf)
+        self._dist.broadcast(t, src=root, group=self.group)
+        out = t.cpu().numpy()
+        if numpy.iscomplexobj(buf):
+            out = out.view(numpy.complex128).reshape(buf.shape)
+        buf[...] = out.reshape(buf.shape)
+        return buf
+
+    def Allgather(self, send, recv):
+        s = self._to_dev(numpy.asarray(send, dtype=recv.dtype))
+        out = self._torch.empty((self.size,) + tuple(s.shape), dtype=s.dtype, device=self.device)
+        self._dist.all_gather_into_tensor(out, s, group=self.group)
+        o = out.cpu().numpy()
+        if numpy.iscomplexobj(recv):
+            o = o.view(numpy.complex128)
+        recv[...] = o.reshape(recv.shape)
+
+    def Allreduce(self, send, recv, op=None):
+        s = self._to_dev(numpy.asarray(send, dtype=recv.dtype))
+        self._dist.all_reduce(s, op=self._dist.ReduceOp.SUM, group=self.group)
+        o = s.cpu().numpy()
+        if numpy.iscomplexobj(recv):
+            o = o.view(numpy.complex128)
+        recv[...] = o.reshape(recv.shape)
+
+    def Reduce(self, send, recv, op=None, root=0):
+        # every rank ends with the sum; only `root` is documented to hold it (mixed.py:261)
+        self.Allreduce(send, recv)
+
+    def send_tensor(self, t, dest, tag=0):
+        self._dist.send(t, dst=dest, group=self.group, tag=tag)
+
+    def recv_tensor(self, t, source, tag=0):
+        self._dist.recv(t, src=source, group=self.group, tag=tag)

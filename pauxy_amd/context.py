@@ -1,0 +1,84 @@
+"""One device context (AfqDevice + upload state) per (system, trial) pair.
+
+PAUXY's driver builds the propagator, the estimators and the walkers as three
+independent objects from the same ``system`` / ``trial`` (qmc/afqmc.py:149-182).
+Here all three must talk to ONE library handle on one GPU; this module hands
+that shared handle out, keyed by the identity of the system and trial objects.
+"""
+import os
+
+import numpy
+
+from pauxy_amd.device import AfqDevice
+
+_contexts = {}
+
+
+def local_device_id():
+    for key in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0
+
+
+def trial_psi(trial):
+    """trial.psi is [ndet, M, ne] until the walker handler strips the leading
+    axis for ndets == 1 (walkers/handler.py:61); accept both."""
+    psi = numpy.asarray(trial.psi)
+    if psi.ndim == 3:
+        if psi.shape[0] != 1:
+            raise NotImplementedError("multi-determinant trials are not on the device path yet")
+        psi = psi[0]
+    return psi
+
+
+class Context(object):
+    def __init__(self, system, trial, device_id=None):
+        self.system = system
+        self.trial = trial
+        self.dev = AfqDevice(local_device_id() if device_id is None else device_id)
+        self._upload_system()
+        self.dev.set_trial(trial_psi(trial))
+        self.propagator_set = False
+
+    def _upload_system(self):
+        s, t, dev = self.system, self.trial, self.dev
+        na, nb = s.nup, s.ndown
+        if s.name == "Generic":
+            rchol = getattr(t, '_rchol', None)
+            if rchol is None:
+                raise ValueError("Generic system needs half-rotated Cholesky vectors (trial.half_rotate)")
+            hs = numpy.asarray(s.hs_pot)
+            if numpy.iscomplexobj(hs):
+                if numpy.abs(hs.imag).max() > 0:
+                    raise NotImplementedError("complex Cholesky vectors are not supported on the device path")
+                hs = hs.real
+            M = s.nbasis
+            dev.set_system_generic(hs, numpy.asarray(rchol)[:(na + nb) * M], numpy.asarray(s.H1, dtype=complex),
+                                   s.ecore, na, nb)
+        elif s.name == "Hubbard":
+            dev.set_system_hubbard(numpy.asarray(s.T, dtype=complex), s.U, na, nb)
+        elif s.name == "UEG":
+            H1diag = numpy.array([numpy.diag(s.H1[0]).real, numpy.diag(s.H1[1]).real])
+            dev.set_system_ueg(s.iA, s.iB, s.ikpq_i, s.ikpq_kpq, s.ipmq_i, s.ipmq_pmq, s.vqvec, s.vol, H1diag,
+                               s.ecore, na, nb)
+        else:
+            raise NotImplementedError("system %r has no device path" % s.name)
+
+    def close(self):
+        self.dev.close()
+
+
+def get_context(system, trial, device_id=None):
+    key = (id(system), id(trial))
+    ctx = _contexts.get(key)
+    if ctx is None or ctx.system is not system or ctx.trial is not trial:
+        ctx = Context(system, trial, device_id)
+        _contexts[key] = ctx
+    return ctx
+
+
+def release_context(system, trial):
+    ctx = _contexts.pop((id(system), id(trial)), None)
+    if ctx is not None:
+        ctx.close()

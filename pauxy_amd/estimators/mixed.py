@@ -1,0 +1,140 @@
+"""Mixed estimator on the device, behind PAUXY's ``Mixed`` surface.
+
+Mirrors pauxy/estimators/mixed.py:33-371 (``Mixed``: ``update``, ``print_step``,
+``get_shift``, ``names``, ``estimates``) and the free function
+``local_energy`` (:383-437).  ``update`` accumulates the ten estimators of
+:460-469 with one device launch (plus the batched Green's function + local
+energy launches on energy steps) instead of a Python loop over walkers.
+
+Output: the per-block rows are kept in ``self.blocks`` (and printed when
+``verbose``); the reference's HDF5 layout (estimators/utils.py:279-327) is an
+I/O format outside the hot path.
+"""
+import time
+
+import numpy
+
+
+class _Enum(dict):
+    __getattr__ = dict.__getitem__
+
+
+def get_estimator_enum(thermal=False):
+    keys = ['uweight', 'weight', 'enumer', 'edenom', 'eproj', 'e1b', 'e2b', 'ehyb', 'ovlp', 'time']
+    return _Enum((k, v) for v, k in enumerate(keys))
+
+
+class Mixed(object):
+    def __init__(self, mixed, system, root, filename, qmc, trial, dtype=complex):
+        self.eval_energy = mixed.get('evaluate_energy', True)
+        self.calc_one_rdm = mixed.get('one_rdm', False)
+        if self.calc_one_rdm or mixed.get('two_rdm', None) is not None:
+            raise NotImplementedError("RDM accumulation is outside the device hot path")
+        self.energy_eval_freq = mixed.get('energy_eval_freq', None)
+        if self.energy_eval_freq is None:
+            self.energy_eval_freq = qmc.nsteps                      # mixed.py:78-80
+        self.verbose = mixed.get('verbose', True)
+        self.nsteps = qmc.nsteps
+        self.header = ['Iteration', 'WeightFactor', 'Weight', 'ENumer', 'EDenom', 'ETotal', 'E1Body',
+                       'E2Body', 'EHybrid', 'Overlap', 'Time']
+        self.nreg = len(self.header[1:])
+        self.dtype = dtype
+        self.names = get_estimator_enum()
+        self.estimates = numpy.zeros(self.nreg, dtype=dtype)
+        self.estimates[self.names.time] = time.time()
+        self.global_estimates = numpy.zeros(self.nreg, dtype=dtype)
+        self.eshift = numpy.array([0, 0])
+        self.blocks = []
+        self.root = root
+
+    def update(self, system, qmc, trial, psi, step, free_projection=False):
+        """mixed.py:133-233, importance-sampling branch (:210-225)."""
+        if free_projection:
+            raise NotImplementedError("free-projection estimators (mixed.py:151-175) are not on the device path yet")
+        psi._end_sweep()
+        psi._flush()
+        dev = psi.dev
+        do_energy = (step % self.energy_eval_freq == 0)
+        if do_energy and not self.eval_energy:
+            # E, T, V = 0 but the denominator still accumulates (mixed.py:215-221)
+            dev.estimates_update(False)
+            est = dev.estimates_get(zero=True)
+            est[self.names.edenom] += est[self.names.weight]
+        else:
+            dev.estimates_update(do_energy)
+            est = dev.estimates_get(zero=True)
+        self.estimates[:self.names.time] += est[:self.names.time]
+        if do_energy:
+            psi._greens_version = psi.phi_version           # the launch refreshed Ghalf
+
+    def print_step(self, comm, nprocs, step, nsteps=None, free_projection=False):
+        """mixed.py:235-289."""
+        if step % self.nsteps != 0:
+            return
+        if nsteps is None:
+            nsteps = self.nsteps
+        es = self.estimates
+        ns = self.names
+        es[ns.time] = (time.time() - es[ns.time]) / nprocs
+        es[ns.uweight:ns.weight + 1] /= nsteps
+        es[ns.ehyb:ns.time + 1] /= nsteps
+        comm.Reduce(es, self.global_estimates, op=None)
+        gs = self.global_estimates
+        if comm.rank == 0:
+            gs[ns.eproj] = gs[ns.enumer]
+            gs[ns.eproj:ns.e2b + 1] = gs[ns.eproj:ns.e2b + 1] / gs[ns.edenom]
+            gs[ns.ehyb] /= gs[ns.weight]
+            gs[ns.ovlp] /= gs[ns.weight]
+            eshift = numpy.array([gs[ns.ehyb], gs[ns.eproj]])
+        else:
+            eshift = numpy.array([0, 0])
+        eshift = comm.bcast(eshift, root=0)
+        self.eshift = eshift
+        if comm.rank == 0:
+            row = [step] + list(gs[:ns.time + 1])
+            self.blocks.append(numpy.array(row))
+            if self.verbose:
+                print(" ".join("{: .10e}".format(x) for x in numpy.array(row).real))
+        self.zero()
+
+    def get_shift(self, hybrid=True):
+        """mixed.py:345-360."""
+        return self.eshift[0].real if hybrid else self.eshift[1].real
+
+    def projected_energy(self):
+        return (self.estimates[self.names.enumer] / self.estimates[self.names.edenom]).real
+
+    def zero(self):
+        self.estimates[:] = 0
+        self.global_estimates[:] = 0
+        self.estimates[self.names.time] = time.time()
+
+    def print_key(self, eol='', encode=False):
+        pass
+
+    def print_header(self, eol='', encode=False):
+        print(" ".join("{:>17s}".format(x) for x in self.header) + eol)
+
+    def setup_output(self, filename):
+        pass
+
+
+def local_energy(system, G, Ghalf=None, two_rdm=None, rchol=None, eri=None, C0=None, ecoul0=None,
+                 exxa0=None, exxb0=None, UVT=None, device=None):
+    """pauxy.estimators.mixed.local_energy (mixed.py:383-437) for ONE Green's
+    function, evaluated by the device energy kernels.  ``device`` is the
+    AfqDevice that already holds ``system`` (see pauxy_amd.context); ``Ghalf``
+    is required for Generic / Hubbard, ``G`` for UEG."""
+    from pauxy_amd import _lib as L
+    if device is None:
+        raise ValueError("local_energy needs the AfqDevice holding the system (device=...)")
+    if device.nw < 1:
+        device.walkers_alloc(1)
+    if device.kind == 'ueg':
+        device.set(L.F_G, numpy.asarray(G, dtype=numpy.complex128), 0)
+    else:
+        if Ghalf is None:
+            raise NotImplementedError("full-G Cholesky energy (estimators/generic.py:398-434) is not on the device path yet")
+        device.set(L.F_GHALF, numpy.concatenate([Ghalf[0], Ghalf[1]]).astype(numpy.complex128), 0)
+    E = device.local_energy()[0]
+    return (complex(E[0]), complex(E[1]), complex(E[2]))

@@ -1,0 +1,125 @@
+"""Step loop over the device objects.
+
+This is the *caller* of the hot path, restated from pauxy/qmc/afqmc.py:200-255
+so that tests and ``bench.py`` can drive Propagator / Walkers / Estimators in
+exactly the order the reference driver does (orthogonalise -> propagate every
+live walker -> weight cap -> population control -> estimators -> energy shift).
+PAUXY's own ``AFQMC`` can drive the same three objects unchanged.
+
+Two loops are provided:
+  * ``run``          -- the reference's per-walker loop, line for line (parity mode);
+  * ``run_batched``  -- the same sequence with every per-walker Python loop
+                        replaced by one batched device call and no host round
+                        trip inside a step except at population control.
+"""
+import time
+
+import numpy
+
+from pauxy_amd.comm import FakeComm
+from pauxy_amd.estimators.handler import Estimators
+from pauxy_amd.propagation.continuous import get_propagator_driver
+from pauxy_amd.qmc.options import QMCOpts
+from pauxy_amd.walkers.handler import Walkers
+
+
+class AFQMC(object):
+    def __init__(self, comm=None, options=None, system=None, trial=None, verbose=0):
+        self.comm = comm if comm is not None else FakeComm()
+        options = options or {}
+        self.system = system
+        self.trial = trial
+        self.qmc = QMCOpts(options.get('qmc', options.get('qmc_options', {})), system)
+        if self.qmc.rng_seed is not None:
+            # qmc/utils.py:3-16: one global stream per rank, seed + rank
+            numpy.random.seed(self.qmc.rng_seed + self.comm.rank)
+        prop_opt = dict(options.get('propagator', {}))
+        prop_opt.setdefault('hubbard_stratonovich', 'continuous')
+        self.propagators = get_propagator_driver(system, trial, self.qmc, options=prop_opt, verbose=verbose)
+        est_opts = options.get('estimators', options.get('estimates', {}))
+        self.estimators = Estimators(est_opts, self.comm.rank == 0, self.qmc, system, trial,
+                                     self.propagators.BT_BP, verbose)
+        self.qmc.nwalkers = max(1, int(self.qmc.nwalkers / self.comm.size))       # afqmc.py:167-176
+        self.qmc.ntot_walkers = self.qmc.nwalkers * self.comm.size
+        self.psi = Walkers(system, trial, self.qmc, walker_opts=options.get('walkers', {}), comm=self.comm)
+        self.setup_timers()
+
+    def setup_timers(self):
+        self.tortho = self.tprop = self.testim = self.tpopc = self.tstep = 0.0
+
+    # ------------------------------------------------------------- parity loop
+    def run(self, psi=None, comm=None, verbose=False, on_step=None):
+        """qmc/afqmc.py:200-255."""
+        comm = comm or self.comm
+        if psi is not None:
+            self.psi = psi
+        self.setup_timers()
+        mixed = self.estimators.estimators['mixed']
+        eshift = 0
+        mixed.update(self.system, self.qmc, self.trial, self.psi, 0, self.propagators.free_projection)
+        if verbose:
+            mixed.print_step(comm, comm.size, 0, 1)
+        for step in range(1, self.qmc.total_steps + 1):
+            start_step = time.time()
+            if step % self.qmc.nstblz == 0:
+                start = time.time()
+                self.psi.orthogonalise(self.trial, self.propagators.free_projection)
+                self.tortho += time.time() - start
+            start = time.time()
+            for w in self.psi.walkers:
+                if abs(w.weight) > 1e-8:
+                    self.propagators.propagate_walker(w, self.system, self.trial, eshift)
+                if (abs(w.weight) > w.total_weight * 0.10) and step > 1:
+                    w.weight = w.total_weight * 0.10
+            self.tprop += time.time() - start
+            if step % self.qmc.npop_control == 0:
+                start = time.time()
+                self.psi.pop_control(comm)
+                self.tpopc += time.time() - start
+            start = time.time()
+            self.estimators.update(self.system, self.qmc, self.trial, self.psi, step,
+                                   self.propagators.free_projection)
+            self.testim += time.time() - start
+            if on_step is not None:
+                on_step(step, self.psi)
+            self.estimators.print_step(comm, comm.size, step)
+            if step < self.qmc.neqlb:
+                eshift = mixed.get_shift(self.propagators.hybrid)
+            else:
+                eshift += (mixed.get_shift() - eshift)
+            self.tstep += time.time() - start_step
+
+    # ------------------------------------------------------------ batched loop
+    def step_batched(self, step, eshift):
+        """One step of run() with batched device calls only."""
+        psi, dev = self.psi, self.psi.dev
+        if step % self.qmc.nstblz == 0:
+            dev.reortho(fetch=False)
+        self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
+        if step > 1:
+            dev.cap_weights(0.10, psi.total_weight)
+        if step % self.qmc.npop_control == 0:
+            psi._invalidate()
+            psi.pop_control(self.comm)
+        do_energy = step % self.estimators.estimators['mixed'].energy_eval_freq == 0
+        dev.estimates_update(do_energy)
+
+    def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0):
+        """Steps first_step .. first_step+nsteps_total-1; returns the final eshift."""
+        mixed = self.estimators.estimators['mixed']
+        n = self.qmc.total_steps if nsteps_total is None else nsteps_total
+        ns = mixed.names
+        for step in range(first_step, first_step + n):
+            self.step_batched(step, eshift)
+            if step % self.qmc.nsteps == 0:
+                est = self.psi.dev.estimates_get(zero=True)
+                mixed.estimates[:ns.time] += est[:ns.time]
+                mixed.print_step(self.comm, self.comm.size, step)
+            if step < self.qmc.neqlb:
+                eshift = mixed.get_shift(self.propagators.hybrid)
+            else:
+                eshift += (mixed.get_shift() - eshift)
+        return eshift
+
+    def finalise(self, verbose=False):
+        pass

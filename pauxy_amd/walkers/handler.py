@@ -1,0 +1,387 @@
+"""Walker population living in HBM, behind PAUXY's ``Walkers`` surface.
+
+Mirrors pauxy/walkers/handler.py:19-164 (constructor, attributes),
+:166-181 (``orthogonalise``), :225-338 (``pop_control`` + ``comb``) and the
+per-walker objects of pauxy/walkers/single_det.py: ``psi.walkers[i]`` is a light
+proxy whose attributes (``weight``, ``ot``, ``phi`` ...) read and write the
+batched device arrays, and whose methods (``greens_function``, ``local_energy``,
+``reortho`` ...) trigger ONE batched launch for the whole population and hand
+back this walker's row.
+
+Scalars (weight, ot, hybrid energy ...) are mirrored on the host so the
+unchanged PAUXY driver can read ``w.weight`` inside its per-walker loop without
+one device round trip per walker: the mirror is refreshed once after each
+batched launch and flushed back before the next one if the driver wrote to it.
+"""
+import sys
+
+import numpy
+
+from pauxy_amd import _lib as L
+from pauxy_amd.context import get_context, trial_psi
+
+_SCALARS = {
+    'weight': (L.F_WEIGHT, numpy.float64),
+    'unscaled_weight': (L.F_UNSCALED_WEIGHT, numpy.float64),
+    'ot': (L.F_OT, numpy.complex128),
+    'hybrid_energy': (L.F_HYBRID_ENERGY, numpy.complex128),
+    'phase': (L.F_PHASE, numpy.complex128),
+    'detR': (L.F_DETR, numpy.float64),
+    'eloc': (L.F_ELOC, numpy.complex128),
+}
+
+
+def comb_parent_ix(weights, target, r):
+    """Comb teeth against cumulative weights (walkers/handler.py:269-286);
+    sequential on purpose: the decisions must not depend on summation order."""
+    n = len(weights)
+    parent_ix = numpy.zeros(n, dtype='i')
+    total_weight = sum(weights)
+    cprobs = numpy.cumsum(weights)
+    step = total_weight / target
+    iw = 0
+    ic = 0
+    while ic < target and iw < n:
+        if (ic + r) * step < cprobs[iw]:
+            parent_ix[iw] += 1
+            ic += 1
+        else:
+            iw += 1
+    return parent_ix
+
+
+def comb_pairs(parent_ix):
+    """zip(clone, kill) of walkers/handler.py:295-301 (truncating)."""
+    kill = numpy.where(parent_ix == 0)[0]
+    clone = numpy.where(parent_ix > 1)[0]
+    return list(zip(clone.tolist(), kill.tolist()))
+
+
+class WalkerView(object):
+    """Proxy for walker ``i`` of a device-resident population (the attribute
+    and method surface of pauxy/walkers/single_det.py:11-364 that the hot path,
+    the driver and the estimators touch)."""
+
+    def __init__(self, handler, i):
+        object.__setattr__(self, '_h', handler)
+        object.__setattr__(self, '_i', i)
+        object.__setattr__(self, '_pending', False)
+        object.__setattr__(self, 'total_weight', 0.0)
+        object.__setattr__(self, 'old_total_weight', 0.0)
+        object.__setattr__(self, 'le_oratio', 1.0)
+        object.__setattr__(self, 'field_configs', None)
+        object.__setattr__(self, 'stack', None)
+        object.__setattr__(self, 'alive', 1)
+        object.__setattr__(self, 'log_shift', 0.0)
+        object.__setattr__(self, 'detR_shift', 0.0)
+        object.__setattr__(self, 'log_detR', 0.0)
+        object.__setattr__(self, 'log_detR_shift', 0.0)
+
+    # -- scalar attributes through the host mirror
+    def __getattr__(self, name):
+        if name in _SCALARS:
+            v = self._h._mirror(name)[self._i]
+            return complex(v) if numpy.iscomplexobj(v) else float(v)
+        if name == 'ovlp':
+            return complex(self._h._mirror('ot')[self._i])
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in _SCALARS:
+            self._h._mirror(name)[self._i] = value
+            self._h._dirty.add(name)
+        elif name == 'ovlp':
+            self._h._mirror('ot')[self._i] = value
+            self._h._dirty.add('ot')
+        else:
+            object.__setattr__(self, name, value)
+
+    @property
+    def nup(self):
+        return self._h.dev.na
+
+    @property
+    def ndown(self):
+        return self._h.dev.nb
+
+    @property
+    def phi(self):
+        return self._h.dev.get(L.F_PHI, self._i, 1)[0]
+
+    @phi.setter
+    def phi(self, value):
+        self._h.dev.set(L.F_PHI, numpy.asarray(value, dtype=numpy.complex128), self._i)
+        self._h.phi_version += 1
+
+    @property
+    def Gmod(self):
+        self._h._ensure_greens()
+        gh = self._h.dev.get(L.F_GHALF, self._i, 1)[0]
+        na = self._h.dev.na
+        return [gh[:na], gh[na:]]
+
+    @property
+    def G(self):
+        self._h._ensure_greens(want_G=True)
+        return self._h.dev.get(L.F_G, self._i, 1)[0]
+
+    # -- methods (walkers/single_det.py)
+    def greens_function(self, trial):
+        """single_det.py:295-321: batched for the whole population, returns this walker's det."""
+        return complex(self._h._ensure_greens()[self._i])
+
+    def calc_overlap(self, trial):
+        """single_det.py:170-199."""
+        self._h._flush()
+        return complex(self._h.dev.calc_overlap()[self._i])
+
+    def local_energy(self, system, two_rdm=None, rchol=None, eri=None, UVT=None):
+        """single_det.py:340-364 -> estimators/mixed.py:383-437."""
+        E = self._h._ensure_energy()[self._i]
+        return (complex(E[0]), complex(E[1]), complex(E[2]))
+
+    def reortho(self, trial):
+        """single_det.py:215-255."""
+        return float(self._h._ensure_reortho()[self._i])
+
+    def get_buffer(self):
+        """Minimal state for transport (the reference ships every numeric
+        attribute, walkers/walker.py:63-100; everything else here is derived)."""
+        return numpy.concatenate([self.phi.ravel(), numpy.array(
+            [self.weight, self.unscaled_weight, self.ot, self.hybrid_energy, self.phase, self.detR, self.eloc],
+            dtype=numpy.complex128)])
+
+    def set_buffer(self, buff):
+        n = self._h.dev.M * (self._h.dev.na + self._h.dev.nb)
+        self.phi = buff[:n].reshape(self._h.dev.M, -1)
+        (self.weight, self.unscaled_weight) = (buff[n].real, buff[n + 1].real)
+        (self.ot, self.hybrid_energy, self.phase) = (buff[n + 2], buff[n + 3], buff[n + 4])
+        (self.detR, self.eloc) = (buff[n + 5].real, buff[n + 6])
+
+
+class Walkers(object):
+    """Drop-in for pauxy.walkers.handler.Walkers (single-determinant walkers)."""
+
+    def __init__(self, system, trial, qmc, walker_opts={}, verbose=False, comm=None, nprop_tot=None,
+                 nbp=None, device_id=None):
+        self.nwalkers = qmc.nwalkers
+        self.ntot_walkers = qmc.ntot_walkers
+        self.write_freq = walker_opts.get('write_freq', 0)
+        self.write_file = walker_opts.get('write_file', 'restart.h5')
+        self.use_log_shift = walker_opts.get('use_log_shift', False)
+        self.read_file = walker_opts.get('read_file', None)
+        self.write_restart = False
+        if self.write_freq > 0 or self.read_file is not None:
+            raise NotImplementedError("HDF5 walker restart files are outside the device hot path")
+        if self.use_log_shift:
+            raise NotImplementedError("use_log_shift is not supported")
+        if nbp is not None:
+            raise NotImplementedError("back-propagation field history is not on the device path yet")
+        if getattr(trial, 'ndets', 1) != 1:
+            raise NotImplementedError("multi-determinant walkers are not on the device path yet")
+        self.walker_type = 'SD'
+        if getattr(trial, 'name', '') == 'MultiSlater' and numpy.asarray(trial.psi).ndim == 3:
+            trial.psi = trial.psi[0]                       # walkers/handler.py:61
+        self.pcont_method = walker_opts.get('population_control', 'comb')
+        if self.pcont_method != 'comb':
+            raise NotImplementedError("only the comb population control is implemented")
+        self.min_weight = walker_opts.get('min_weight', 0.1)
+        self.max_weight = walker_opts.get('max_weight', 4.0)
+        self.ctx = get_context(system, trial, device_id)
+        self.dev = self.ctx.dev
+        self.system, self.trial = system, trial
+        self.dev.walkers_alloc(self.nwalkers)
+        self.nw = self.nwalkers
+        self.target_weight = qmc.ntot_walkers
+        # host mirrors of the per-walker scalars
+        self._host = {}
+        self._valid = set()
+        self._dirty = set()
+        self.phi_version = 0
+        self._greens_version = -1
+        self._greens_has_G = False
+        self._energy_version = -1
+        self._reortho_version = -1
+        self._det = None
+        self._energy = None
+        # initial population: trial.init, weight walker_opts['weight'] (walkers/walker.py:24-29)
+        init = numpy.asarray(getattr(trial, 'init', trial_psi(trial)), dtype=numpy.complex128)
+        phi0 = numpy.broadcast_to(init, (self.nw,) + init.shape).copy()
+        self.dev.set(L.F_PHI, phi0)
+        w0 = walker_opts.get('weight', 1.0)
+        self.dev.set(L.F_WEIGHT, numpy.full(self.nw, w0))
+        self.dev.set(L.F_UNSCALED_WEIGHT, numpy.full(self.nw, w0))
+        ot = self.dev.calc_overlap()                       # single_det.py:65-67
+        self.dev.set(L.F_OT, ot)
+        self.walkers = [WalkerView(self, i) for i in range(self.nw)]
+        self.set_total_weight(qmc.ntot_walkers)
+        # E_L of the initial walkers (single_det.py:86-92) is evaluated lazily on request
+        self.buff_size = init.size + 7
+        self.walker_buffer = numpy.zeros(self.buff_size, dtype=numpy.complex128)
+
+    # ------------------------------------------------------------ mirrors
+    def _mirror(self, name):
+        if name not in self._valid:
+            field, _ = _SCALARS[name]
+            self._host[name] = self.dev.get(field)
+            self._valid.add(name)
+        return self._host[name]
+
+    def _flush(self):
+        """Upload host-side writes before any device launch."""
+        for name in list(self._dirty):
+            self.dev.set(_SCALARS[name][0], self._host[name])
+        self._dirty.clear()
+
+    def _invalidate(self, *names):
+        for n in (names or _SCALARS.keys()):
+            if n in self._dirty:
+                continue
+            self._valid.discard(n)
+
+    # ------------------------------------------------- batched lazy kernels
+    def _ensure_greens(self, want_G=False):
+        if self._greens_version != self.phi_version or (want_G and not self._greens_has_G):
+            self._flush()
+            self._det = self.dev.greens(want_G=want_G or self.dev.kind == 'ueg')
+            self._greens_version = self.phi_version
+            self._greens_has_G = want_G or self.dev.kind == 'ueg'
+        return self._det
+
+    def _ensure_energy(self):
+        if self._energy_version != self.phi_version:
+            self._ensure_greens()
+            self._energy = self.dev.local_energy()
+            self._energy_version = self.phi_version
+        return self._energy
+
+    def _ensure_reortho(self):
+        if self._reortho_version != self.phi_version:
+            self._flush()
+            self._detR = self.dev.reortho()
+            self.phi_version += 1
+            self._reortho_version = self.phi_version
+            self._invalidate('ot', 'detR', 'weight')
+        return self._detR
+
+    def _end_sweep(self):
+        """Called by every once-per-step entry point of the driver (pop_control,
+        orthogonalise, Mixed.update): whatever per-walker 'already propagated'
+        marks are left from the sweep that just ended are dropped."""
+        for w in self.walkers:
+            w._pending = False
+
+    # ---------------------------------------------------------- reference API
+    def orthogonalise(self, trial, free_projection):
+        """walkers/handler.py:166-181 (one batched Gram-Schmidt launch; the
+        free-projection weight/phase update is applied on the device)."""
+        self._end_sweep()
+        self._reortho_version = -1
+        self._ensure_reortho()
+
+    def set_total_weight(self, total_weight):
+        for w in self.walkers:
+            w.total_weight = total_weight
+            w.old_total_weight = total_weight
+        self.total_weight = total_weight
+
+    def copy_historic_wfn(self):
+        pass
+
+    def add_field_config(self, *a, **k):
+        raise NotImplementedError("back propagation is not on the device path yet")
+
+    def write_walkers(self, comm):
+        raise NotImplementedError("HDF5 walker restart files are outside the device hot path")
+
+    def recompute_greens_function(self, trial, time_slice=None):
+        self._greens_version = -1
+        self._ensure_greens()
+
+    def pop_control(self, comm):
+        """walkers/handler.py:225-338 (comb).  Size-1 communicator: one device
+        launch.  Several ranks: all-gather of |weights|, identical comb on every
+        rank from rank 0's uniform, point-to-point copies of the cloned walkers."""
+        self._end_sweep()
+        if self.ntot_walkers == 1:
+            return
+        self._flush()
+        size = 1 if comm is None else comm.size
+        if size == 1:
+            r = numpy.random.random()                      # handler.py:276
+            try:
+                parent_ix, total = self.dev.popcontrol_comb(r, self.target_weight)
+            except L.AfqError as e:
+                if e.code == -6:
+                    print("# Warning: total weight is below 1e-8.  Something is seriously wrong.")
+                    sys.exit()
+                raise
+            self.last_parent_ix = parent_ix
+        else:
+            total = self._pop_control_distributed(comm)
+        self.set_total_weight(total)
+        self.phi_version += 1
+        self._invalidate()
+
+    def _pop_control_distributed(self, comm):
+        nw = self.nw
+        weights = numpy.abs(self.dev.get(L.F_WEIGHT))
+        global_weights = numpy.empty(nw * comm.size)
+        comm.Allgather(weights, global_weights)            # handler.py:232
+        total_weight = sum(global_weights)
+        if total_weight < 1e-8:
+            if comm.rank == 0:
+                print("# Warning: total weight is {:13.8e}.  Something is seriously wrong.".format(total_weight))
+            sys.exit()
+        scale = total_weight / self.target_weight
+        self.dev.scale_weights(scale)                      # handler.py:244-246
+        r = numpy.random.random() if comm.rank == 0 else None
+        r = comm.bcast(r, root=0)
+        parent_ix = comb_parent_ix(global_weights / scale, self.target_weight, r)
+        self.last_parent_ix = parent_ix
+        transport = WalkerTransport(self.dev, comm)
+        for i, (c, k) in enumerate(comb_pairs(parent_ix)):
+            src_rank, dst_rank = c // nw, k // nw
+            if src_rank == dst_rank:
+                if src_rank == comm.rank:
+                    self.dev.copy_walker(c % nw, k % nw)
+            elif src_rank == comm.rank:
+                transport.send(c % nw, dst_rank, tag=i)
+            elif dst_rank == comm.rank:
+                transport.recv(k % nw, src_rank, tag=i)
+        transport.finish()
+        self.dev.reset_weights()                           # handler.py:337-338
+        return total_weight
+
+
+class WalkerTransport(object):
+    """Moves packed walkers (phi + scalars, ``afq_walker_pack``) between ranks
+    through device tensors: RCCL send/recv over xGMI on the GPU node."""
+
+    def __init__(self, dev, comm):
+        import torch
+        self.torch = torch
+        self.dev = dev
+        self.comm = comm
+        self.nbytes = dev.pack_bytes()
+        self.device = comm.device
+
+    def _buf(self):
+        return self.torch.empty(self.nbytes // 8, dtype=self.torch.float64, device=self.device)
+
+    def send(self, iw, dest, tag):
+        buf = self._buf()
+        self.dev.pack(iw, buf.data_ptr())
+        self.dev.sync()
+        self.comm.send_tensor(buf, dest, tag)
+
+    def recv(self, iw, source, tag):
+        buf = self._buf()
+        self.comm.recv_tensor(buf, source, tag)
+        if buf.is_cuda:
+            self.torch.cuda.current_stream(buf.device).synchronize()
+        self.dev.unpack(iw, buf.data_ptr())
+        self.dev.sync()
+
+    def finish(self):
+        self.comm.barrier()

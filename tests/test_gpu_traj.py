@@ -1,0 +1,120 @@
+"""Trajectory parity: replay the random numbers the genuine reference drew
+(auxiliary fields per live walker + the comb uniform, golden fixtures) through
+the device objects driven by the restated step loop, and compare every step's
+walker weights / overlaps / hybrid energies, the comb decisions and the block
+estimates with what the reference produced.  Tolerance 1e-8 relative on 100-step
+trajectories (fp64, LAPACK-vs-device summation order); discrete decisions
+(parent_ix, dead walkers) must match exactly."""
+import numpy
+import pytest
+
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.context import release_context
+from pauxy_amd.qmc.afqmc import AFQMC
+from tests.helpers import ragged
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def close(a, b, tol=TOL):
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(numpy.max(numpy.abs(b))))
+    err = float(numpy.max(numpy.abs(a - b))) / scale
+    assert err <= tol, err
+
+
+class Replay(object):
+    """Stands in for numpy.random.{normal,random}: hands back the recorded draws."""
+
+    def __init__(self, d):
+        xi = d['xi']
+        self.rows = iter([xi[s, w] for s in range(xi.shape[0]) for w in range(xi.shape[1])
+                          if not numpy.isnan(xi[s, w, 0])])
+        self.r = iter([x for x in d['r'] if not numpy.isnan(x)])
+
+    def normal(self, loc, scale, size):
+        row = next(self.rows)
+        assert len(row) == size
+        return row
+
+    def random(self):
+        return next(self.r)
+
+
+def replay(d, system, trial, prop_opts, monkeypatch):
+    options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
+                       'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
+                       'num_walkers': d['phi0'].shape[0]},
+               'propagator': prop_opts,
+               'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
+    afqmc = AFQMC(options=options, system=system, trial=trial)
+    close(afqmc.propagators.propagator.BH1, d['BH1'], 1e-12)
+    close(afqmc.propagators.propagator.mf_shift, d['mf_shift'], 1e-12)
+    rp = Replay(d)
+    monkeypatch.setattr(numpy.random, 'normal', rp.normal)
+    monkeypatch.setattr(numpy.random, 'random', rp.random)
+    rec = dict(weight=[], unscaled=[], ot=[], ehyb=[], pix=[])
+
+    def on_step(step, psi):
+        rec['weight'].append(psi._mirror('weight').copy())
+        rec['unscaled'].append(psi._mirror('unscaled_weight').copy())
+        rec['ot'].append(psi._mirror('ot').copy())
+        rec['ehyb'].append(psi._mirror('hybrid_energy').copy())
+        if step % afqmc.qmc.npop_control == 0:
+            rec['pix'].append(psi.last_parent_ix.copy())
+
+    afqmc.run(verbose=False, on_step=on_step)
+    close(numpy.array(rec['weight']), d['weight'])
+    close(numpy.array(rec['unscaled']), d['unscaled_weight'])
+    close(numpy.array(rec['ot']), d['ot'])
+    close(numpy.array(rec['ehyb']), d['ehyb'])
+    assert numpy.array_equal(numpy.array(rec['pix']), d['parent_ix'])
+    mixed = afqmc.estimators.estimators['mixed']
+    blocks = numpy.array(mixed.blocks)
+    close(blocks[:, 1:10], d['blocks'][:, 1:10])
+    close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'])
+    # the final estimator pass the reference's driver tests pin
+    mixed.update(system, afqmc.qmc, trial, afqmc.psi, 0)
+    close(mixed.estimates[:9], d['final_estimates'][:9])
+    assert afqmc.propagators.nfb_trig == int(d['nfb_trig'])
+    assert afqmc.propagators.nhe_trig == int(d['nhe_trig'])
+    est = mixed.estimates.copy()
+    release_context(system, trial)
+    return est
+
+
+def test_traj_generic(golden, monkeypatch):
+    d = golden('traj_generic.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    est = replay(d, s, t, {}, monkeypatch)
+    assert est[2].real == pytest.approx(3.8763193646854273, rel=1e-8)        # qmc/tests/test_afqmc.py:227
+
+
+def test_traj_hubbard(golden, monkeypatch):
+    d = golden('traj_hubbard.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Hubbard(4, 4, na, nb, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    est = replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch)
+    assert est[2].real == pytest.approx(-152.91937839611, rel=1e-8)          # qmc/tests/test_afqmc.py:186
+
+
+def test_traj_hubbard_c1(golden, monkeypatch):
+    """BASELINE configs[0]: 4x4 U=4 half filling, 10 walkers, comb every 5 steps."""
+    d = golden('traj_hubbard_c1.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch)
+
+
+def test_traj_ueg(golden, monkeypatch):
+    d = golden('traj_ueg.npz')
+    s = systems.UEG(float(d['sys_rs']), 7, 7, float(d['sys_ecut']))
+    t = trial_mod.hartree_fock_ueg(s)
+    est = replay(d, s, t, {}, monkeypatch)
+    assert est[2].real == pytest.approx(16.33039729324558, rel=1e-8)         # qmc/tests/test_afqmc.py:87
+    assert est[0].real == pytest.approx(9.75405059997262, rel=1e-8)

@@ -1,0 +1,86 @@
+"""Host-side set-up (systems / trial / propagator constants) against arrays
+recorded from the genuine reference.  CPU only."""
+import numpy
+import pytest
+
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.propagation import setup
+from pauxy_amd.qmc.options import QMCOpts
+from tests.helpers import ragged, ueg_sparse
+
+
+def close(a, b, tol=1e-12):
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(numpy.max(numpy.abs(b)))) if b.size else 1.0
+    assert float(numpy.max(numpy.abs(a - b))) <= tol * scale
+
+
+def test_generic_setup(golden):
+    d = golden('generic_ops.npz')
+    for tag in ('A_', 'B_'):
+        na, nb = [int(x) for x in d[tag + 'nelec']]
+        h1e = d[tag + 'h1e']
+        s = systems.Generic((na, nb), numpy.array([h1e, h1e]), d[tag + 'chol'], float(d[tag + 'ecore']))
+        close(s.h1e_mod, d[tag + 'h1e_mod'])
+        t = trial_mod.SingleDetTrial(s, d[tag + 'psi'])
+        close(t._rchol, d[tag + 'rchol'])
+        BH1, mf = setup.generic_propagator_arrays(s, t, float(d[tag + 'dt']))
+        close(mf, d[tag + 'mf_shift'])
+        close(BH1, d[tag + 'BH1'])
+
+
+def test_hubbard_setup(golden):
+    d = golden('hubbard_ops.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    close(s.T, d['T'])
+    close(s.h1e_mod, d['h1e_mod'])
+    for tag, charge in (('C_', True), ('S_', False)):
+        t = trial_mod.SingleDetTrial(s, d[tag + 'psi'], name='UHF')
+        BH1, mf = setup.hubbard_propagator_arrays(s, t, float(d[tag + 'dt']), charge)
+        close(mf, d[tag + 'mf_shift'])
+        close(BH1, d[tag + 'BH1'])
+
+
+def test_ueg_setup(golden):
+    d = golden('ueg_ops.npz')
+    s = systems.UEG(float(d['rs']), 7, 7, float(d['ecut']))
+    assert s.nbasis == len(d['sp_eigv'])
+    close(s.sp_eigv, d['sp_eigv'])
+    assert numpy.array_equal(s.basis, d['basis'])
+    assert numpy.array_equal(s.qvecs, d['qvecs'])
+    close(s.vqvec, d['vqvec'])
+    close(s.vol, d['vol'])
+    close(s.ecore, d['ecore'])
+    close(numpy.diag(s.h1e_mod[0]), d['h1e_mod_diag'])
+    iA, iB = ueg_sparse(d, s.nbasis)
+    assert abs(s.iA - iA).max() < 1e-14
+    assert abs(s.iB - iB).max() < 1e-14
+    for name in ('ikpq_i', 'ikpq_kpq', 'ipmq_i', 'ipmq_pmq'):
+        for a, b in zip(getattr(s, name), ragged(d, name)):
+            assert numpy.array_equal(a, b)
+    t = trial_mod.hartree_fock_ueg(s)
+    close(t.psi, d['U_psi'])
+    BH1, mf = setup.ueg_propagator_arrays(s, t, float(d['U_dt']))
+    close(BH1, d['U_BH1'])
+
+
+def test_uhf_trial_is_a_fixed_point():
+    s = systems.Hubbard(4, 4, 8, 8, 4.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    na = s.nup
+    nu = numpy.sum(numpy.abs(t.psi[:, :na]) ** 2, axis=1)
+    nd = numpy.sum(numpy.abs(t.psi[:, na:]) ** 2, axis=1)
+    assert nu.sum() == pytest.approx(8) and nd.sum() == pytest.approx(8)
+    e, v = numpy.linalg.eigh(s.T[0] + numpy.diag(0.4 * nd))
+    P = t.psi[:, :na] @ t.psi[:, :na].conj().T
+    Pref = v[:, :na] @ v[:, :na].T
+    assert numpy.abs(P - Pref).max() < 1e-5
+
+
+def test_qmc_options_defaults():
+    q = QMCOpts({})
+    assert (q.nwalkers, q.dt, q.nsteps, q.nblocks, q.nstblz, q.npop_control) == (10, 0.005, 10, 1000, 10, 1)
+    assert q.neqlb == int(2.0 / 0.005)
+    q = QMCOpts({'timestep': 0.01, 'steps': 5, 'blocks': 3, 'pop_control': 5, 'seed': 8})
+    assert (q.dt, q.nsteps, q.total_steps, q.npop_control, q.rng_seed) == (0.01, 5, 15, 5, 8)
