@@ -104,9 +104,9 @@ class TorchComm(object):
 
     def Allgather(self, send, recv):
         s = self._to_dev(numpy.asarray(send, dtype=recv.dtype))
-        out = self._torch.empty((self.size,) + tuple(s.shape), dtype=s.dtype, device=self.device)
-        self._dist.all_gather_into_tensor(out, s, group=self.group)
-        o = out.cpu().numpy()
+        parts = [self._torch.empty_like(s) for _ in range(self.size)]
+        self._dist.all_gather(parts, s, group=self.group)
+        o = self._torch.stack(parts).cpu().numpy()
         if numpy.iscomplexobj(recv):
             o = o.view(numpy.complex128)
         recv[...] = o.reshape(recv.shape)

@@ -44,14 +44,20 @@ __device__ inline void cmul_acc(double &sr, double &si, const d4_t &ar, const d4
 template <bool RC>
 __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
     const int lane = threadIdx.x & 63;
-    const long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long ncell = 2L * a.nxt * a.nwt;
-    if (task >= ncell * EXX_CHUNKS) return;
-    const int chunk = (int)(task % EXX_CHUNKS);
-    const long cell = task / EXX_CHUNKS;
-    const int wt = (int)(cell % a.nwt);
-    const int xt = (int)((cell / a.nwt) % a.nxt);
-    const int s = (int)(cell / ((long)a.nwt * a.nxt));
+    // XCD affinity: workgroup g runs on XCD g % 8 (round-robin dispatch); give each
+    // XCD the walker tiles wt = xcd, xcd + 8, ... so that the Ghalf fragments it
+    // reads (640 KB per walker tile and spin at C3) stay resident in its 4 MiB L2
+    // while the rchol fragments stream through.
+    const int xcd = blockIdx.x & 7;
+    const int nj = (a.nwt + 7) >> 3;
+    const long t = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int chunk = (int)(t % EXX_CHUNKS);
+    const int j = (int)((t / EXX_CHUNKS) % nj);
+    const int xt = (int)((t / ((long)EXX_CHUNKS * nj)) % a.nxt);
+    const int s = (int)(t / ((long)EXX_CHUNKS * nj * a.nxt));
+    const int wt = xcd + 8 * j;
+    if (s >= 2 || wt >= a.nwt) return;
+    const long task = (((long)s * a.nxt + xt) * a.nwt + wt) * EXX_CHUNKS + chunk;
     const int ns = a.ns[s];
     double sr = 0.0, si = 0.0;
     if (ns > 0) {
@@ -302,10 +308,12 @@ int k_energy_generic(afq_handle *h) {
     a.afrag_im[0] = h->rchol_frag_im[0]; a.afrag_im[1] = h->rchol_frag_im[1];
     a.gfrag = h->gfrag; a.part = h->exx_part;
     AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
+    const long per_xcd = 2L * nxt * ((nwt + 7) / 8) * EXX_CHUNKS;
+    const unsigned nblk = (unsigned)(8 * ((per_xcd + 3) / 4));
     if (h->rchol_real)
-        hipLaunchKernelGGL(exx_kernel<false>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(exx_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, a);
     else
-        hipLaunchKernelGGL(exx_kernel<true>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(exx_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
     h->energy_ev_valid = true;

@@ -6,6 +6,36 @@
 //   full Green's fn      G_s = conj(psi_s) Ghalf_s                    (walkers/single_det.py:312,319)
 #include "mfma_gemm.h"
 
+// Pick the (TM, TN) register tiling that needs the fewest whole rounds of the
+// chip's 1024 SIMDs (one wave-task per SIMD per round), with a small bias
+// towards larger tiles (more MFMAs per fragment load).
+struct TileChoice { int tm, tn; };
+static TileChoice pick_tiles(int batch, int rows, int cols, const TileChoice *cand, int ncand) {
+    double best = 1e300; TileChoice bc = cand[0];
+    for (int c = 0; c < ncand; ++c) {
+        const long tasks = mfma_gemm_tasks(batch, rows, cols, cand[c].tm, cand[c].tn);
+        const long rounds = (tasks + 1023) / 1024;
+        const double cost = (double)rounds * (cand[c].tm * cand[c].tn + 0.35 * (cand[c].tm + cand[c].tn));
+        if (cost < best) { best = cost; bc = cand[c]; }
+    }
+    return bc;
+}
+#define DISPATCH_TILES(h, p, tc, MAP, WPB)                                                         \
+    do {                                                                                           \
+        hipError_t e__;                                                                            \
+        typedef decltype(p) P__;                                                                   \
+        if (tc.tm == 1 && tc.tn == 1) e__ = launch_mfma_gemm<1, 1, P__, MAP>(p, (h)->stream, WPB);      \
+        else if (tc.tm == 1 && tc.tn == 2) e__ = launch_mfma_gemm<1, 2, P__, MAP>(p, (h)->stream, WPB); \
+        else if (tc.tm == 2 && tc.tn == 1) e__ = launch_mfma_gemm<2, 1, P__, MAP>(p, (h)->stream, WPB); \
+        else if (tc.tm == 2 && tc.tn == 2) e__ = launch_mfma_gemm<2, 2, P__, MAP>(p, (h)->stream, WPB); \
+        else if (tc.tm == 1 && tc.tn == 4) e__ = launch_mfma_gemm<1, 4, P__, MAP>(p, (h)->stream, WPB); \
+        else if (tc.tm == 2 && tc.tn == 4) e__ = launch_mfma_gemm<2, 4, P__, MAP>(p, (h)->stream, WPB); \
+        else e__ = launch_mfma_gemm<2, 2, P__, MAP>(p, (h)->stream, WPB);                               \
+        AFQ_HIP(h, e__);                                                                           \
+    } while (0)
+static const TileChoice kCplxTiles[] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+static const TileChoice kMixedTiles[] = {{2, 4}, {2, 2}, {1, 4}, {1, 2}, {1, 1}};
+
 // ---------------------------------------------------------------- one body
 struct OneBodyProb {
     static constexpr bool A_CPLX = true, B_CPLX = true;
@@ -42,8 +72,8 @@ int k_onebody(afq_handle *h) {
         p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
         p.B1 = h->BH1 + (long)s * M * M;
         p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
-        if (ns > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
-        else AFQ_HIP(h, (launch_mfma_gemm<2, 1>(p, h->stream)));
+        const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
+        DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
     }
     // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
     hipLaunchKernelGGL(copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
@@ -100,13 +130,15 @@ int k_force_bias_generic(afq_handle *h) {
         p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
         p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
         p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = nullptr; p.out = h->vbias;
-        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+        const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kMixedTiles, 5);
+        DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
     } else {
         ForceBiasProb<true> p;
         p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
         p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
         p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = h->rchol_im; p.out = h->vbias;
-        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+        const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
+        DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
     }
     return AFQ_OK;
 }
@@ -135,8 +167,16 @@ int k_vhs_generic(afq_handle *h) {
     VhsProb p;
     p.batch = 1; p.rows = h->nw; p.cols = h->M * h->M; p.kdim = h->K;
     p.xs = h->xs; p.hsT = h->hs_pot; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
-    if (h->nw > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 4>(p, h->stream)));
-    else AFQ_HIP(h, (launch_mfma_gemm<1, 4>(p, h->stream)));
+    static const TileChoice cand[] = {{2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 2}};
+    const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, cand, 5);
+    // all tile rows (walker blocks) of one hs_pot column panel in one workgroup: the
+    // 40 MB hs_pot streams from HBM once, its panel is shared through L1/L2
+    const int tiles_m = (p.rows + 16 * tc.tm - 1) / (16 * tc.tm);
+    int wpb = tiles_m <= 8 ? (tiles_m < 1 ? 1 : tiles_m) : 8;
+    const long ntask = mfma_gemm_tasks(p.batch, p.rows, p.cols, tc.tm, tc.tn);
+    while (wpb > 1 && ntask / wpb < 200) wpb >>= 1;      // keep >= ~1 workgroup per CU
+    if (tc.tm == 2 && tc.tn == 5) AFQ_HIP(h, (launch_mfma_gemm<2, 5, VhsProb, MAP_ROWS_FAST>(p, h->stream, wpb)));
+    else DISPATCH_TILES(h, p, tc, MAP_ROWS_FAST, wpb);
     return AFQ_OK;
 }
 
@@ -178,8 +218,11 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.vstride = (long)h->nv * M * M;
             p.vhs = vhs + (long)s * M * M;
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
-            if (p.cols > 16) AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
-            else AFQ_HIP(h, (launch_mfma_gemm<2, 1>(p, h->stream)));
+            const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
+            // one workgroup = every tile of one walker (its VHS and T panels stay in one L1/L2)
+            const long per = mfma_gemm_tasks(1, p.rows, p.cols, tc.tm, tc.tn);
+            const int wpb = per <= 8 ? (int)per : 4;
+            DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, wpb);
         }
         cplx *t = tin; tin = tout; tout = t;
     }
@@ -215,7 +258,8 @@ int k_full_G(afq_handle *h) {
         p.batch = h->nw; p.rows = M; p.cols = M; p.kdim = ns; p.nt = h->nt;
         p.off = s == 0 ? 0 : h->na; p.spin = s; p.M = M;
         p.psi = h->psi; p.ghalf = h->ghalf; p.G = h->G;
-        AFQ_HIP(h, (launch_mfma_gemm<2, 2>(p, h->stream)));
+        const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
+        DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
     }
     return AFQ_OK;
 }

@@ -3,7 +3,7 @@
 // field shift / clipping, the phaseless weight update, population control and
 // the mixed-estimator accumulation.  One workgroup per walker; panels live in
 // LDS when they fit and in a global workspace otherwise.
-#include "afq_internal.h"
+#include "mfma_gemm.h"
 
 #define NTHR 256
 
@@ -158,12 +158,195 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
     }
 }
 
+
+// --------------------------------------------------------------------------
+// Fast path for N <= 45 electrons per spin (the overlap matrix and its inverse
+// fit LDS twice over).  One 512-thread workgroup per walker: waves 0-3 work on
+// spin up, waves 4-7 on spin down, in lock step.
+//   phase 1  O = phi_s^T conj(psi_s)            fp64 MFMA, one 16x16 tile per wave at a time
+//   phase 2  in-place Gauss-Jordan inverse with row pivoting + determinant, one wave per spin,
+//            the whole N x N update of a pivot step spread over the 64 lanes
+//   phase 3  Ghalf_s = O^-1 phi_s^T             fp64 MFMA, A fragment from LDS
+// (reference: scipy.linalg.inv + numpy.dot + slogdet, walkers/single_det.py:310-320)
+template <bool INVERSE>
+__global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cplx ph_s[2];
+    __shared__ double la_s[2];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (a.only_alive && !a.alive[w]) return;
+    const int g = tid >> 8, wave = (tid >> 6) & 3, lane = tid & 63;
+    const int M = a.M, nt = a.nt;
+    const int nmax = a.na > a.nb ? a.na : a.nb;
+    const int n = g == 0 ? a.na : a.nb, off = g == 0 ? 0 : a.na;
+    cplx *O = (cplx *)smem + (long)g * (nmax * nmax + 2 * nmax);
+    cplx *colk = O + nmax * nmax, *rowk = colk + nmax;
+    int *piv = (int *)((cplx *)smem + 2L * (nmax * nmax + 2 * nmax)) + g * nmax;
+    const cplx *phi = a.phi + (long)w * M * nt;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nt16 = (n + 15) >> 4;
+    // ---- phase 1
+    for (int t = wave; t < nt16 * nt16; t += 4) {
+        const int ti = t / nt16, tj = t % nt16;
+        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
+        const int ia = ti * 16 + lr, jb = tj * 16 + lr;
+        for (int p0 = 0; p0 < M; p0 += 4) {
+            const int p = p0 + lk;
+            cplx x = cmake(0.0, 0.0), y = cmake(0.0, 0.0);
+            if (p < M) {
+                if (ia < n) x = phi[(long)p * nt + off + ia];
+                if (jb < n) y = a.psi[(long)p * nt + off + jb];
+            }
+            // x * conj(y)
+            accR = mfma16(x.x, y.x, accR);
+            accR = mfma16(x.y, y.y, accR);
+            accI = mfma16(x.y, y.x, accI);
+            accI = mfma16(-x.x, y.y, accI);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
+            if (i < n && j < n) O[i * n + j] = cmake(accR[r], accI[r]);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2
+    if (wave == 0) {
+        cplx ph = cmake(1.0, 0.0);
+        double la = 0.0;
+        const int cw_shift = n <= 32 ? 5 : 6;
+        const int cj = lane & ((1 << cw_shift) - 1), ri = lane >> cw_shift, rstep = 64 >> cw_shift;
+        for (int k = 0; k < n; ++k) {
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + lane; i < n; i += 64) {
+                const cplx v = O[i * n + k];
+                const double m = fabs(v.x) + fabs(v.y);
+                if (m > best) { best = m; bi = i; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const int p = bi;
+            if (p != k) {
+                for (int j = lane; j < n; j += 64) {
+                    const cplx t = O[k * n + j];
+                    O[k * n + j] = O[p * n + j];
+                    O[p * n + j] = t;
+                }
+            }
+            if (lane == 0) piv[k] = p;
+            __builtin_amdgcn_wave_barrier();
+            const cplx d = O[k * n + k];
+            const double ab = hypot(d.x, d.y);
+            cplx u = cmake(d.x / ab, d.y / ab);
+            if (p != k) u = cmake(-u.x, -u.y);
+            ph = cmul(ph, u);
+            la += log(ab);
+            const cplx dinv = cdiv(cmake(1.0, 0.0), d);
+            for (int i = lane; i < n; i += 64) colk[i] = O[i * n + k];
+            for (int j = lane; j < n; j += 64) rowk[j] = cmul(O[k * n + j], dinv);
+            __builtin_amdgcn_wave_barrier();
+            if (INVERSE) {
+                if (cj < n) {
+                    const cplx rk = rowk[cj];
+                    for (int i = ri; i < n; i += rstep) {
+                        cplx v;
+                        if (i == k) v = (cj == k) ? dinv : rk;
+                        else {
+                            const cplx f = colk[i];
+                            if (cj == k) { const cplx t = cmul(f, dinv); v = cmake(-t.x, -t.y); }
+                            else {
+                                v = O[i * n + cj];
+                                v.x = fma(-f.x, rk.x, v.x); v.x = fma(f.y, rk.y, v.x);
+                                v.y = fma(-f.x, rk.y, v.y); v.y = fma(-f.y, rk.x, v.y);
+                            }
+                        }
+                        O[i * n + cj] = v;
+                    }
+                }
+            } else {
+                if (cj < n && cj > k) {
+                    const cplx rk = rowk[cj];
+                    for (int i = k + 1 + ri; i < n; i += rstep) {
+                        const cplx f = colk[i];
+                        cplx v = O[i * n + cj];
+                        v.x = fma(-f.x, rk.x, v.x); v.x = fma(f.y, rk.y, v.x);
+                        v.y = fma(-f.x, rk.y, v.y); v.y = fma(-f.y, rk.x, v.y);
+                        O[i * n + cj] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (INVERSE) {
+            for (int k = n - 1; k >= 0; --k) {
+                const int p = piv[k];
+                if (p != k) {
+                    for (int i = lane; i < n; i += 64) {
+                        const cplx t = O[i * n + k];
+                        O[i * n + k] = O[i * n + p];
+                        O[i * n + p] = t;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) { ph_s[g] = ph; la_s[g] = la; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double e = exp(la_s[0] + la_s[1]);
+        const cplx p2 = cmul(ph_s[0], ph_s[1]);
+        a.det[w] = cmake(p2.x * e, p2.y * e);
+    }
+    // ---- phase 3
+    if (INVERSE && a.ghalf && n > 0) {
+        cplx *gh = a.ghalf + ((long)w * nt + off) * M;
+        const int mt16 = (M + 15) >> 4;
+        for (int t = wave; t < nt16 * mt16; t += 4) {
+            const int ti = t / mt16, tc = t % mt16;
+            d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
+            const int ia = ti * 16 + lr, c = tc * 16 + lr;
+            for (int j0 = 0; j0 < n; j0 += 4) {
+                const int j = j0 + lk;
+                cplx x = cmake(0.0, 0.0), y = cmake(0.0, 0.0);
+                if (j < n) {
+                    if (ia < n) x = O[ia * n + j];
+                    if (c < M) y = phi[(long)c * nt + off + j];
+                }
+                accR = mfma16(x.x, y.x, accR);
+                accR = mfma16(-x.y, y.y, accR);
+                accI = mfma16(x.x, y.y, accI);
+                accI = mfma16(x.y, y.x, accI);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + lk + 4 * r, cc = tc * 16 + lr;
+                if (i < n && cc < M) gh[(long)i * M + cc] = cmake(accR[r], accI[r]);
+            }
+        }
+    }
+}
+
 static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) {
     GreensArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
+    if (nmax <= 45) {
+        a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
+        const size_t lds = sizeof(cplx) * 2 * ((size_t)nmax * nmax + 2 * nmax) + sizeof(int) * 2 * nmax;
+        if (ghalf)
+            hipLaunchKernelGGL(greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
+        else
+            hipLaunchKernelGGL(greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+        AFQ_HIP(h, hipGetLastError());
+        return AFQ_OK;
+    }
     const size_t need = sizeof(cplx) * (size_t)nmax * nmax;
     a.o_in_lds = need <= 64 * 1024;
     a.only_alive = only_alive; a.alive = h->alive;
@@ -502,41 +685,57 @@ int k_reset_weights(afq_handle *h) {
 // walk over the comb teeth are inherently sequential and must reproduce the
 // reference's left-to-right double additions, so one thread does them (nw adds).
 // scal[0] = total weight (before scaling), scal[1] = number of (clone, kill) pairs.
-__global__ void comb_plan_kernel(double *weight, double *unscaled, int nw, double r, double target,
-                                 int *parent_ix, int *pairs, double *scal) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double total = 0.0;
-    for (int i = 0; i < nw; ++i) total += fabs(weight[i]);
-    scal[0] = total;
-    if (total < 1e-8) { scal[1] = -1.0; return; }
-    const double scale = total / target;
-    double tot2 = 0.0;
-    for (int i = 0; i < nw; ++i) {
-        unscaled[i] = weight[i];
-        const double a = fabs(weight[i]) / scale;     // global_weights / scale (handler.py:248)
+__global__ __launch_bounds__(256) void comb_plan_kernel(double *weight, double *unscaled, int nw, double r,
+                                                         double target, int *parent_ix, int *pairs,
+                                                         double *scal) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *aw = (double *)smem;              // |w| then |w| / scale
+    int *pix = (int *)(aw + nw);
+    __shared__ double s_total, s_scale;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nw; i += 256) { aw[i] = fabs(weight[i]); pix[i] = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0;
+        for (int i = 0; i < nw; ++i) total += aw[i];          // sum(global_weights), handler.py:233
+        s_total = total;
+        s_scale = total / target;
+        scal[0] = total;
+    }
+    __syncthreads();
+    if (s_total < 1e-8) { if (tid == 0) scal[1] = -1.0; return; }
+    const double scale = s_scale;
+    for (int i = tid; i < nw; i += 256) {
+        unscaled[i] = weight[i];                              // handler.py:245
         weight[i] = weight[i] / scale;
-        tot2 += a;
-        parent_ix[i] = 0;
+        aw[i] = aw[i] / scale;                                // global_weights / scale, handler.py:248
     }
-    const int ntarget = (int)target;
-    const double step = tot2 / target;
-    int iw = 0, ic = 0;
-    double cprob = fabs(unscaled[0]) / scale;
-    while (ic < ntarget && iw < nw) {
-        const double tooth = (ic + r) * step;
-        if (tooth < cprob) { parent_ix[iw] += 1; ++ic; }
-        else { ++iw; if (iw < nw) cprob += fabs(unscaled[iw]) / scale; }
-    }
-    // zip(clone, kill): handler.py:295-301
-    int ik = 0, np = 0;
-    for (int c = 0; c < nw; ++c) {
-        if (parent_ix[c] > 1) {
-            while (ik < nw && parent_ix[ik] != 0) ++ik;
-            if (ik >= nw) break;
-            pairs[2 * np] = c; pairs[2 * np + 1] = ik; ++np; ++ik;
+    __syncthreads();
+    if (tid == 0) {
+        double tot2 = 0.0;
+        for (int i = 0; i < nw; ++i) tot2 += aw[i];           // sum(weights), handler.py:274
+        const int ntarget = (int)target;
+        const double step = tot2 / target;
+        int iw = 0, ic = 0;
+        double cprob = aw[0];                                 // running numpy.cumsum
+        while (ic < ntarget && iw < nw) {
+            const double tooth = (ic + r) * step;
+            if (tooth < cprob) { pix[iw] += 1; ++ic; }
+            else { ++iw; if (iw < nw) cprob += aw[iw]; }
         }
+        // zip(clone, kill): handler.py:295-301
+        int ik = 0, np = 0;
+        for (int c = 0; c < nw; ++c) {
+            if (pix[c] > 1) {
+                while (ik < nw && pix[ik] != 0) ++ik;
+                if (ik >= nw) break;
+                pairs[2 * np] = c; pairs[2 * np + 1] = ik; ++np; ++ik;
+            }
+        }
+        scal[1] = (double)np;
     }
-    scal[1] = (double)np;
+    __syncthreads();
+    for (int i = tid; i < nw; i += 256) parent_ix[i] = pix[i];
 }
 
 struct CloneArgs {
@@ -561,8 +760,8 @@ __global__ void clone_kernel(CloneArgs a) {
 
 int k_comb(afq_handle *h, double r, double target) {
     int *pairs = (int *)h->pack_tmp;
-    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(64), 0, h->stream, h->weight, h->unscaled, h->nw, r,
-                       target, h->parent_ix, pairs, h->scal);
+    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + sizeof(int)) * (size_t)h->nw,
+                       h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
     AFQ_HIP(h, hipGetLastError());
     CloneArgs a;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;

@@ -1,10 +1,16 @@
 // fp64 MFMA tile engine for gfx950: one wavefront owns a TM x TN block of
-// 16x16 output tiles and walks the contraction index 4 at a time with
-// v_mfma_f64_16x16x4_f64.  Complex operands are interleaved (re, im) in
-// memory and are split into real MFMAs in registers:
+// 16x16 output tiles and walks the contraction index 8 at a time with two
+// v_mfma_f64_16x16x4_f64 per (tile, operand pair).  Complex operands are
+// interleaved (re, im) in memory and are split into real MFMAs in registers:
 //   Cr += Ar*Br + (-Ai)*Bi ;  Ci += Ar*Bi + Ai*Br      (4 real MFMAs / fragment pair)
 // Fragment maps (gfx950, f64 16x16x4):  A: lane l holds A[l&15][l>>4];
 // B: lane l holds B[l>>4][l&15];  C/D register r of lane l is C[(l>>4)+4r][l&15].
+// Inside a chunk of 8 contraction indices lane group g = l>>4 takes k = k0+2g
+// for the first MFMA and k0+2g+1 for the second, so that a lane's two A
+// elements are adjacent in memory (row-major A): 16 rows x 128 contiguous bytes
+// per wavefront load.  Fragments of chunk c+1 are loaded into a second register
+// set before the MFMAs of chunk c issue (software prefetch), so the L2 latency
+// hides under >= 16 x 64 MFMA cycles.
 #pragma once
 #include "afq_internal.h"
 
@@ -22,19 +28,67 @@ __device__ inline d4_t mfma16(double a, double b, d4_t c) {
 //   __device__ cplx loadB(int b, int k, int col);
 //   __device__ void store(int b, int row, int col, double re, double im);
 template <int TM, int TN, class P>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(P p) {
+struct FragSet {
+    cplx a[TM][2], b[TN][2];
+    __device__ inline void load(const P &p, int bt, int row0, int col0, int k0, int lr, int lk) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = k0 + 2 * lk + s;
+            const bool kok = k < p.kdim;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = row0 + i * 16 + lr;
+                a[i][s] = (kok && row < p.rows) ? p.loadA(bt, row, k) : cmake(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + j * 16 + lr;
+                b[j][s] = (kok && col < p.cols) ? p.loadB(bt, k, col) : cmake(0.0, 0.0);
+            }
+        }
+    }
+};
+
+// Task -> (batch, tile row, tile column) maps.  Workgroups are dealt round-robin
+// over the 8 XCDs (blockIdx % 8 labels the XCD, each with a private 4 MiB L2),
+// so the map decides which operand panels share an L2 / an L1:
+//   MAP_COLS_FAST  consecutive waves walk tile columns of one tile row (share the A panel)
+//   MAP_ROWS_FAST  consecutive waves walk tile rows of one tile column (share the B panel)
+//   MAP_BATCH_XCD  batch b runs on XCD b % 8: each batch's operand slices stay in one L2
+enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2 };
+
+template <int TM, int TN, class P, int MAP = MAP_COLS_FAST>
+__global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const int tiles_m = (p.rows + 16 * TM - 1) / (16 * TM);
     const int tiles_n = (p.cols + 16 * TN - 1) / (16 * TN);
-    const long ntask = (long)p.batch * tiles_m * tiles_n;
-    const long task = (long)blockIdx.x * wpb + wave;
-    if (task >= ntask) return;
-    const int b = (int)(task / ((long)tiles_m * tiles_n));
-    const int rem = (int)(task % ((long)tiles_m * tiles_n));
-    // consecutive waves share the A panel (same tile row), walk tile columns
-    const int tm = rem / tiles_n, tn = rem % tiles_n;
+    const long per_batch = (long)tiles_m * tiles_n;
+    const long ntask = (long)p.batch * per_batch;
+    int b, tm, tn;
+    if (MAP == MAP_BATCH_XCD) {
+        // blockIdx = slot * nb8 + (b % nb8): with nb8 = min(batch, 8) consecutive
+        // workgroups (consecutive XCDs) take different batches
+        const int nb8 = p.batch < 8 ? p.batch : 8;
+        const long wg_per_group = (per_batch * ((p.batch + nb8 - 1) / nb8) + wpb - 1) / wpb;
+        const int grp = blockIdx.x % nb8;
+        const long slot = blockIdx.x / nb8;
+        if (slot >= wg_per_group) return;
+        const long t = slot * wpb + wave;          // task index inside this XCD group
+        const long bb = t / per_batch;
+        b = grp + (int)bb * nb8;
+        if (b >= p.batch) return;
+        const int rem = (int)(t % per_batch);
+        tm = rem / tiles_n; tn = rem % tiles_n;
+    } else {
+        const long task = (long)blockIdx.x * wpb + wave;
+        if (task >= ntask) return;
+        b = (int)(task / per_batch);
+        const int rem = (int)(task % per_batch);
+        if (MAP == MAP_ROWS_FAST) { tn = rem / tiles_m; tm = rem % tiles_m; }
+        else { tm = rem / tiles_n; tn = rem % tiles_n; }
+    }
     if (!p.active(b)) return;
     const int row0 = tm * 16 * TM, col0 = tn * 16 * TN;
     const int lr = lane & 15, lk = lane >> 4;
@@ -49,29 +103,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(P p) {
             accI[i][j] = (d4_t){0, 0, 0, 0};
         }
 
-    for (int k0 = 0; k0 < p.kdim; k0 += 4) {
-        const int k = k0 + lk;
-        const bool kok = k < p.kdim;
-        cplx a[TM], bb[TN];
+    FragSet<TM, TN, P> cur, nxt;
+    cur.load(p, b, row0, col0, 0, lr, lk);
+    for (int k0 = 0; k0 < p.kdim; k0 += 8) {
+        if (k0 + 8 < p.kdim) nxt.load(p, b, row0, col0, k0 + 8, lr, lk);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = row0 + i * 16 + lr;
-            a[i] = (kok && row < p.rows) ? p.loadA(b, row, k) : cmake(0.0, 0.0);
-        }
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = col0 + j * 16 + lr;
-            bb[j] = (kok && col < p.cols) ? p.loadB(b, k, col) : cmake(0.0, 0.0);
-        }
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                accR[i][j] = mfma16(a[i].x, bb[j].x, accR[i][j]);
-                if (P::A_CPLX && P::B_CPLX) accR[i][j] = mfma16(-a[i].y, bb[j].y, accR[i][j]);
-                if (P::B_CPLX) accI[i][j] = mfma16(a[i].x, bb[j].y, accI[i][j]);
-                if (P::A_CPLX) accI[i][j] = mfma16(a[i].y, bb[j].x, accI[i][j]);
-            }
+                for (int j = 0; j < TN; ++j) {
+                    accR[i][j] = mfma16(cur.a[i][s].x, cur.b[j][s].x, accR[i][j]);
+                    if (P::A_CPLX && P::B_CPLX) accR[i][j] = mfma16(-cur.a[i][s].y, cur.b[j][s].y, accR[i][j]);
+                    if (P::B_CPLX) accI[i][j] = mfma16(cur.a[i][s].x, cur.b[j][s].y, accI[i][j]);
+                    if (P::A_CPLX) accI[i][j] = mfma16(cur.a[i][s].y, cur.b[j][s].x, accI[i][j]);
+                }
+        cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -86,14 +133,26 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(P p) {
             }
 }
 
-template <int TM, int TN, class P>
+template <int TM, int TN, class P, int MAP = MAP_COLS_FAST>
 inline hipError_t launch_mfma_gemm(const P &p, hipStream_t stream, int waves_per_block = 4) {
     const long tiles_m = (p.rows + 16 * TM - 1) / (16 * TM);
     const long tiles_n = (p.cols + 16 * TN - 1) / (16 * TN);
-    const long ntask = (long)p.batch * tiles_m * tiles_n;
+    const long per_batch = tiles_m * tiles_n;
+    const long ntask = (long)p.batch * per_batch;
     if (ntask == 0) return hipSuccess;
-    const long nblk = (ntask + waves_per_block - 1) / waves_per_block;
-    hipLaunchKernelGGL((mfma_gemm_kernel<TM, TN, P>), dim3((unsigned)nblk), dim3(64 * waves_per_block), 0,
+    long nblk = (ntask + waves_per_block - 1) / waves_per_block;
+    if (MAP == MAP_BATCH_XCD) {
+        const int nb8 = p.batch < 8 ? p.batch : 8;
+        const long wg_per_group = (per_batch * ((p.batch + nb8 - 1) / nb8) + waves_per_block - 1) / waves_per_block;
+        nblk = wg_per_group * nb8;
+    }
+    hipLaunchKernelGGL((mfma_gemm_kernel<TM, TN, P, MAP>), dim3((unsigned)nblk), dim3(64 * waves_per_block), 0,
                        stream, p);
     return hipGetLastError();
+}
+
+// wave-tasks a (TM, TN) tiling produces, for picking a shape that fills the
+// 1024 SIMDs of the chip in whole rounds
+inline long mfma_gemm_tasks(int batch, int rows, int cols, int TM, int TN) {
+    return (long)batch * ((rows + 16 * TM - 1) / (16 * TM)) * ((cols + 16 * TN - 1) / (16 * TN));
 }

@@ -324,34 +324,39 @@ class Walkers(object):
         self._invalidate()
 
     def _pop_control_distributed(self, comm):
-        nw = self.nw
-        weights = numpy.abs(self.dev.get(L.F_WEIGHT))
-        global_weights = numpy.empty(nw * comm.size)
-        comm.Allgather(weights, global_weights)            # handler.py:232
-        total_weight = sum(global_weights)
-        if total_weight < 1e-8:
-            if comm.rank == 0:
-                print("# Warning: total weight is {:13.8e}.  Something is seriously wrong.".format(total_weight))
-            sys.exit()
-        scale = total_weight / self.target_weight
-        self.dev.scale_weights(scale)                      # handler.py:244-246
-        r = numpy.random.random() if comm.rank == 0 else None
-        r = comm.bcast(r, root=0)
-        parent_ix = comb_parent_ix(global_weights / scale, self.target_weight, r)
-        self.last_parent_ix = parent_ix
-        transport = WalkerTransport(self.dev, comm)
-        for i, (c, k) in enumerate(comb_pairs(parent_ix)):
-            src_rank, dst_rank = c // nw, k // nw
-            if src_rank == dst_rank:
-                if src_rank == comm.rank:
-                    self.dev.copy_walker(c % nw, k % nw)
-            elif src_rank == comm.rank:
-                transport.send(c % nw, dst_rank, tag=i)
-            elif dst_rank == comm.rank:
-                transport.recv(k % nw, src_rank, tag=i)
-        transport.finish()
-        self.dev.reset_weights()                           # handler.py:337-338
-        return total_weight
+        total, self.last_parent_ix = pop_control_distributed(self.dev, comm, self.nw, self.target_weight)
+        return total
+
+
+def pop_control_distributed(dev, comm, nw, target_weight):
+    """walkers/handler.py:225-338 across ranks.  ``dev`` is the rank's AfqDevice
+    (anything with get/scale_weights/copy_walker/pack/unpack/reset_weights)."""
+    weights = numpy.abs(dev.get(L.F_WEIGHT))
+    global_weights = numpy.empty(nw * comm.size)
+    comm.Allgather(weights, global_weights)                # handler.py:232
+    total_weight = sum(global_weights)
+    if total_weight < 1e-8:
+        if comm.rank == 0:
+            print("# Warning: total weight is {:13.8e}.  Something is seriously wrong.".format(total_weight))
+        sys.exit()
+    scale = total_weight / target_weight
+    dev.scale_weights(scale)                               # handler.py:244-246
+    r = numpy.random.random() if comm.rank == 0 else None  # handler.py:276
+    r = comm.bcast(r, root=0)
+    parent_ix = comb_parent_ix(global_weights / scale, target_weight, r)
+    transport = WalkerTransport(dev, comm)
+    for i, (c, k) in enumerate(comb_pairs(parent_ix)):
+        src_rank, dst_rank = c // nw, k // nw
+        if src_rank == dst_rank:
+            if src_rank == comm.rank:
+                dev.copy_walker(c % nw, k % nw)
+        elif src_rank == comm.rank:
+            transport.send(c % nw, dst_rank, tag=i)
+        elif dst_rank == comm.rank:
+            transport.recv(k % nw, src_rank, tag=i)
+    transport.finish()
+    dev.reset_weights()                                    # handler.py:337-338
+    return total_weight, parent_ix
 
 
 class WalkerTransport(object):

@@ -1,0 +1,169 @@
+"""Multi-rank population control on CPU: 2 processes, gloo backend.
+
+Parity definition for N ranks: the N-rank run must equal the
+1-rank oracle with N*nw walkers given the same comb uniform.  The device is
+replaced by a numpy stand-in with the same method surface (there is no GPU
+here); the code under test is the rank logic: all-gather of weights, the comb
+decided identically on every rank, packed walker send/recv, weight reset."""
+import ctypes
+import os
+import socket
+
+import numpy
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import afqmc_ref as ref
+from pauxy_amd import _lib as L
+from pauxy_amd.comm import TorchComm, FakeComm
+from pauxy_amd.walkers.handler import pop_control_distributed, comb_parent_ix, comb_pairs
+
+NW, M, NE = 4, 3, 2
+
+
+class NumpyDevice(object):
+    """Stand-in for AfqDevice (tests only): same packed layout as afq_walker_pack."""
+
+    def __init__(self, phi, weight):
+        self.phi = phi.copy()
+        self.weight = weight.copy()
+        self.unscaled = weight.copy()
+        self.ot = numpy.ones(len(weight), dtype=complex)
+
+    def get(self, field):
+        assert field == L.F_WEIGHT
+        return self.weight.copy()
+
+    def scale_weights(self, scale):
+        self.unscaled = self.weight.copy()
+        self.weight = self.weight / scale
+
+    def reset_weights(self):
+        self.weight[:] = 1.0
+
+    def copy_walker(self, src, dst):
+        self.phi[dst] = self.phi[src]
+        self.unscaled[dst] = self.unscaled[src]
+        self.ot[dst] = self.ot[src]
+
+    def pack_bytes(self):
+        return 16 * (M * NE + 4) + 8 * 4
+
+    def _flat(self, iw):
+        return numpy.concatenate([self.phi[iw].ravel().view(numpy.float64),
+                                  numpy.array([self.ot[iw]]).view(numpy.float64), numpy.zeros(6),
+                                  [self.unscaled[iw], 0.0, self.weight[iw], 0.0]])
+
+    def pack(self, iw, ptr):
+        buf = numpy.ascontiguousarray(self._flat(iw))
+        ctypes.memmove(ptr, buf.ctypes.data, buf.nbytes)
+
+    def unpack(self, iw, ptr):
+        buf = numpy.empty(self.pack_bytes() // 8)
+        ctypes.memmove(buf.ctypes.data, ptr, buf.nbytes)
+        n = 2 * M * NE
+        self.phi[iw] = buf[:n].view(numpy.complex128).reshape(M, NE)
+        self.ot[iw] = buf[n:n + 2].view(numpy.complex128)[0]
+        self.unscaled[iw] = buf[n + 8]
+        self.weight[iw] = buf[n + 10]
+
+    def sync(self):
+        pass
+
+
+def population(seed=5):
+    rng = numpy.random.RandomState(seed)
+    phi = rng.rand(2 * NW, M, NE) + 1j * rng.rand(2 * NW, M, NE)
+    w = numpy.array([3.1, 2.5, 0.9, 1.4, 0.01, 0.03, 2.2, 0.04])
+    return phi, w
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _work(rank, out)
+    except Exception as e:          # surface failures instead of hanging the parent
+        out.put((rank, repr(e)))
+        raise
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _work(rank, out):
+    comm = TorchComm()
+    phi, w = population()
+    dev = NumpyDevice(phi[rank * NW:(rank + 1) * NW], w[rank * NW:(rank + 1) * NW])
+    numpy.random.seed(123)            # only rank 0's draw is used
+    total, pix = pop_control_distributed(dev, comm, NW, 2 * NW)
+    est = numpy.array([dev.unscaled.sum(), 0.0], dtype=numpy.complex128)
+    red = numpy.zeros_like(est)
+    comm.Reduce(est, red, root=0)
+    out.put((rank, dev.phi, dev.weight, dev.unscaled, total, pix, red))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_comb_matches_single_rank_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for rr in res:
+        assert len(rr) == 7, rr
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-rank oracle with the same uniform
+    numpy.random.seed(123)
+    r = numpy.random.random()
+    phi, w = population()
+    walkers = [dict(phi=phi[i].copy(), weight=w[i], unscaled_weight=w[i], ot=1.0, ovlp=1.0, hybrid_energy=0.0,
+                    total_weight=0.0) for i in range(2 * NW)]
+    pix = ref.pop_control(None, walkers, 2 * NW, r)
+    assert pix.max() > 1 and (pix == 0).any()          # the case really clones and kills
+    got_phi = numpy.concatenate([res[0][1], res[1][1]])
+    assert numpy.array_equal(got_phi, numpy.array([x['phi'] for x in walkers]))
+    assert numpy.array_equal(numpy.concatenate([res[0][2], res[1][2]]), numpy.ones(2 * NW))
+    assert numpy.allclose(numpy.concatenate([res[0][3], res[1][3]]),
+                          numpy.array([x['unscaled_weight'] for x in walkers]), rtol=0, atol=0)
+    for rr in res:
+        assert rr[4] == pytest.approx(w.sum(), rel=1e-15)
+        assert numpy.array_equal(rr[5], pix)
+        assert rr[6][0].real == pytest.approx(sum(x['unscaled_weight'] for x in walkers), rel=1e-14)
+    # cross-rank clone really happened in this case
+    assert any(c // NW != k // NW for c, k in comb_pairs(pix))
+
+
+def test_comb_host_matches_oracle_and_quirks():
+    w = numpy.array([3.0, 1e-9, 1e-9, 1.0 - 2e-9])
+    a = comb_parent_ix(w / (w.sum() / 4), 4, 0.5)
+    b = ref.comb_parent_ix(w / (w.sum() / 4), 4, 0.5)
+    assert numpy.array_equal(a, b) and list(a) == [3, 0, 0, 1]
+    assert comb_pairs(a) == [(0, 1)]                   # zip truncation, walkers/handler.py:301
+    rng = numpy.random.RandomState(0)
+    for _ in range(50):
+        w = rng.rand(16) * rng.choice([0.01, 1.0, 5.0], 16)
+        r = rng.rand()
+        sc = w.sum() / 16
+        assert numpy.array_equal(comb_parent_ix(w / sc, 16, r), ref.comb_parent_ix(w / sc, 16, r))
+
+
+def test_fake_comm_surface():
+    c = FakeComm()
+    buf = numpy.zeros(3)
+    c.Allgather(numpy.arange(3.0), buf)
+    assert numpy.array_equal(buf, numpy.arange(3.0))
+    assert c.bcast({'a': 1})['a'] == 1 and c.rank == 0 and c.size == 1
