@@ -3,6 +3,7 @@
 // make up one propagation step (propagation/continuous.py:232-262).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include "afq_internal.h"
 
@@ -114,6 +115,9 @@ int afq_create(int device_id, afq_handle **out) {
     hipMemset(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_);
     hipMemset(h->counters, 0, sizeof(unsigned long long) * 4);
     hipMemset(h->scal, 0, sizeof(double) * 8);
+    if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
+    hipMemset(h->zero_page, 0, 256);
+    h->no_ring = getenv("AFQ_NO_RING") != nullptr;
     *out = h;
     return AFQ_OK;
 }
@@ -126,6 +130,7 @@ int afq_destroy(afq_handle *h) {
     free_system(h);
     dev_free(h->psi); dev_free(h->BH1); dev_free(h->mf_shift);
     dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
+    if (h->zero_page) hipFree(h->zero_page);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
     hipStreamDestroy(h->stream);
@@ -165,24 +170,29 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
     if (rc) return rc;
     h->ecore = ecore;
     const size_t mm = (size_t)M * M, nq = (size_t)h->nt * M;
-    {   // hs_pot^T : [K, M*M] so that a VHS B-fragment is contiguous
-        std::vector<double> t((size_t)K * mm);
+    h->ld_hs = (long)((mm + 1) & ~(size_t)1);
+    h->ld_rc = (long)((K + 1) & ~1);
+    {   // hs_pot^T : [K, ld_hs] so that a VHS B-fragment is contiguous (even, zero-padded rows:
+        // the LDS-DMA path moves 16-byte pairs of doubles)
+        std::vector<double> t((size_t)K * h->ld_hs, 0.0);
         for (size_t r = 0; r < mm; ++r)
-            for (int n = 0; n < K; ++n) t[(size_t)n * mm + r] = hs_pot[r * K + n];
+            for (int n = 0; n < K; ++n) t[(size_t)n * h->ld_hs + r] = hs_pot[r * K + n];
         if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
     }
-    {   // split rchol into planar re / im
-        std::vector<double> re(nq * K), im;
+    {   // split rchol into planar re / im, rows padded to ld_rc
+        std::vector<double> re(nq * h->ld_rc, 0.0), im;
         bool real = true;
-        for (size_t e = 0; e < nq * K; ++e) {
-            re[e] = rchol[2 * e];
-            if (rchol[2 * e + 1] != 0.0) real = false;
-        }
+        for (size_t q = 0; q < nq; ++q)
+            for (int n = 0; n < K; ++n) {
+                re[q * h->ld_rc + n] = rchol[2 * (q * K + n)];
+                if (rchol[2 * (q * K + n) + 1] != 0.0) real = false;
+            }
         h->rchol_real = real;
         if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
         if (!real) {
-            im.resize(nq * K);
-            for (size_t e = 0; e < nq * K; ++e) im[e] = rchol[2 * e + 1];
+            im.assign(nq * h->ld_rc, 0.0);
+            for (size_t q = 0; q < nq; ++q)
+                for (int n = 0; n < K; ++n) im[q * h->ld_rc + n] = rchol[2 * (q * K + n) + 1];
             if ((rc = dev_upload(h, &h->rchol_im, im.data(), im.size()))) return rc;
         }
     }
@@ -309,6 +319,12 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     if (h->kind == AFQ_SYS_GENERIC) {
         const long tiles = (long)((nw + 31) / 32) * ((h->K + 31) / 32) * 2;
         int sp = (int)std::max(1L, std::min(8L, 1024 / std::max(1L, tiles)));
+        if (nw > 32) {
+            // work-group-tiled kernel (64 walkers x 128 fields per work-group): aim at >= 512 work-groups
+            const long wgt = (long)((nw + 63) / 64) * ((h->K + 127) / 128) * 2;
+            sp = (int)std::max(1L, std::min(16L, (512 + wgt - 1) / wgt));
+        }
+        if (getenv("AFQ_FB_SPLIT")) sp = atoi(getenv("AFQ_FB_SPLIT"));
         const int nmax = std::max(h->na, h->nb) * h->M;
         while (sp > 1 && nmax / sp < 64) --sp;
         h->fb_split = sp;

@@ -45,10 +45,11 @@ struct afq_handle {
     int M = 0, K = 0, na = 0, nb = 0, nt = 0;
     double ecore = 0.0;
     // generic
-    double *hs_pot = nullptr;       // f64 [M*M, K]
+    double *hs_pot = nullptr;       // f64, TRANSPOSED: [K, ld_hs] with ld_hs = M*M rounded up to even (zero pad)
+    long ld_hs = 0, ld_rc = 0;      // leading dimensions of hs_pot^T and of rchol_re/im (K rounded up to even)
     bool rchol_real = true;
-    double *rchol_re = nullptr;     // f64 [nt*M, K]
-    double *rchol_im = nullptr;     // f64 [nt*M, K] or null when real
+    double *rchol_re = nullptr;     // f64 [nt*M, ld_rc]
+    double *rchol_im = nullptr;     // f64 [nt*M, ld_rc] or null when real
     double *rchol_frag[2] = {nullptr, nullptr};   // energy-kernel A operand, fragment order, per spin
     double *rchol_frag_im[2] = {nullptr, nullptr};
     cplx *H1 = nullptr;             // [2, M, M]
@@ -111,6 +112,8 @@ struct afq_handle {
     int *parent_ix = nullptr;       // [nw]
     double *scal = nullptr;         // [8] device scalars (total weight, ...)
     void *pack_tmp = nullptr;
+    void *zero_page = nullptr;      // 256 zero bytes: source of out-of-range LDS-DMA loads
+    bool no_ring = false;           // AFQ_NO_RING=1: register-prefetch GEMM engine only (A/B runs)
 
     // rng
     uint64_t rng_seed = 0, rng_stream = 0, rng_counter = 0;

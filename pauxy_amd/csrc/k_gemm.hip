@@ -4,7 +4,8 @@
 //   HS potential         VHS[w] = i sqrt(dt) reshape(hs_pot xs[w])    (propagation/generic.py:164-179)
 //   Taylor propagator    phi <- sum_{n<=order} VHS^n/n! phi           (propagation/continuous.py:82-111)
 //   full Green's fn      G_s = conj(psi_s) Ghalf_s                    (walkers/single_det.py:312,319)
-#include "mfma_gemm.h"
+#include <cstdlib>
+#include "mfma_gemm_wg.h"
 
 // Pick the (TM, TN) register tiling that needs the fewest whole rounds of the
 // chip's 1024 SIMDs (one wave-task per SIMD per round), with a small bias
@@ -50,6 +51,8 @@ struct OneBodyProb {
     __device__ cplx loadB(int b, int k, int col) const {
         return src[((long)b * kdim + k) * nt + off + col];
     }
+    __device__ const cplx *ptrA(int, int row, int k) const { return B1 + (long)row * kdim + k; }
+    __device__ const cplx *ptrB(int b, int k, int col) const { return src + ((long)b * kdim + k) * nt + off + col; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         dst[((long)b * rows + row) * nt + off + col] = cmake(re, im);
     }
@@ -72,8 +75,13 @@ int k_onebody(afq_handle *h) {
         p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
         p.B1 = h->BH1 + (long)s * M * M;
         p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
-        const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
-        DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
+        if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
+            // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
+            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST>(p, h->stream, h->zero_page)));
+        } else {
+            const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
+            DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
+        }
     }
     // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
     hipLaunchKernelGGL(copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
@@ -86,57 +94,83 @@ int k_onebody(afq_handle *h) {
 // -------------------------------------------------------------- force bias
 // rows = walkers, cols = fields, contraction over q = (i, p) of one spin,
 // split into `nsplit` slices; partial sums go to vbias[(slice*2 + s), w, n].
+#define FB_MAX_BATCH 32
 template <bool RC>
 struct ForceBiasProb {
     static constexpr bool A_CPLX = true, B_CPLX = RC;
-    int batch, rows, cols, kdim;     // batch = 2*nsplit, rows = nw, cols = K, kdim = slice length
-    int nsplit, M, K, nt, na, nb;
-    const cplx *ghalf;               // [nw, nt, M]
+    int batch, rows, cols, kdim;     // batch = 2*nsplit, rows = nw, cols = K, kdim = longest slice
+    long astride;                    // elements between walkers in ghalf
+    int K;
+    long ldr;                        // leading dimension of rre / rim
+    // per batch: first contraction index inside [0, nt*M) and slice length (host-computed)
+    long q0[FB_MAX_BATCH];
+    int len[FB_MAX_BATCH];
+    const cplx *ghalf;               // [nw, nt*M]
     const double *rre, *rim;         // [nt*M, K]
-    cplx *out;                       // [nsplit*2, nw, K]
+    cplx *out;                       // [batch, nw, K]
     __device__ bool active(int) const { return true; }
-    __device__ void slice(int b, int &s, long &q0, int &len) const {
-        s = b & 1;
-        const int sl = b >> 1;
-        const int ns = s == 0 ? na : nb;
-        const long tot = (long)ns * M;
-        const long per = (tot + nsplit - 1) / nsplit;
-        q0 = sl * per;
-        long l = tot - q0; if (l > per) l = per; if (l < 0) l = 0;
-        len = (int)l;
-    }
     __device__ cplx loadA(int b, int row, int k) const {
-        int s, len; long q0; slice(b, s, q0, len);
-        if (k >= len) return cmake(0.0, 0.0);
-        return ghalf[(long)row * nt * M + (long)(s ? na : 0) * M + q0 + k];
+        if (k >= len[b]) return cmake(0.0, 0.0);
+        return ghalf[row * astride + q0[b] + k];
     }
     __device__ cplx loadB(int b, int k, int col) const {
-        int s, len; long q0; slice(b, s, q0, len);
-        if (k >= len) return cmake(0.0, 0.0);
-        const long idx = ((long)(s ? na : 0) * M + q0 + k) * K + col;
+        if (k >= len[b]) return cmake(0.0, 0.0);
+        const long idx = (q0[b] + k) * ldr + col;
         return cmake(rre[idx], RC ? rim[idx] : 0.0);
     }
+    // ring engine (real rchol only): slices are zero-padded by clamping k to the slice
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        return k < len[b] ? ghalf + row * astride + q0[b] + k : zero;
+    }
+    __device__ const double *ptrB(int b, int k, int col) const {
+        return k < len[b] ? rre + (q0[b] + k) * ldr + col : (const double *)zero;
+    }
+    const cplx *zero;
     __device__ void store(int b, int row, int col, double re, double im) const {
         out[((long)b * rows + row) * K + col] = cmake(re, im);
     }
 };
 
+template <bool RC>
+static void fill_force_bias(ForceBiasProb<RC> &p, afq_handle *h) {
+    const int nsplit = h->fb_split, M = h->M;
+    p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.K = h->K;
+    p.astride = (long)h->nt * M;
+    p.ldr = h->ld_rc;
+    int kmax = 0;
+    for (int b = 0; b < p.batch; ++b) {
+        const int s = b & 1, sl = b >> 1;
+        const long tot = (long)(s == 0 ? h->na : h->nb) * M;
+        const long per = (tot + nsplit - 1) / nsplit;
+        long l = tot - sl * per; if (l > per) l = per; if (l < 0) l = 0;
+        p.q0[b] = (long)(s ? h->na : 0) * M + sl * per;
+        p.len[b] = (int)l;
+        if (l > kmax) kmax = (int)l;
+    }
+    p.kdim = kmax;
+    p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = h->rchol_im; p.out = h->vbias;
+    p.zero = (const cplx *)h->zero_page;
+}
+
 int k_force_bias_generic(afq_handle *h) {
-    const int nmax = (h->na > h->nb ? h->na : h->nb) * h->M;
-    const int nsplit = h->fb_split;
-    const int per = (nmax + nsplit - 1) / nsplit;
+    if (2 * h->fb_split > FB_MAX_BATCH) AFQ_FAIL(h, AFQ_EINVAL, "force-bias split too large");
     if (h->rchol_real) {
         ForceBiasProb<false> p;
-        p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
-        p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
-        p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = nullptr; p.out = h->vbias;
+        fill_force_bias(p, h);
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kMixedTiles, 5);
-        DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
+        if (h->nw > 32 && !h->no_ring) {
+            // work-group tile 64 walkers x 64 fields, operands shared through the LDS ring
+            static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 1;
+            if (cfg == 1) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+        } else {
+            DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
+        }
     } else {
         ForceBiasProb<true> p;
-        p.batch = 2 * nsplit; p.rows = h->nw; p.cols = h->K; p.kdim = per;
-        p.nsplit = nsplit; p.M = h->M; p.K = h->K; p.nt = h->nt; p.na = h->na; p.nb = h->nb;
-        p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = h->rchol_im; p.out = h->vbias;
+        fill_force_bias(p, h);
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
         DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
     }
@@ -150,13 +184,16 @@ struct VhsProb {
     static constexpr bool A_CPLX = true, B_CPLX = false;
     int batch, rows, cols, kdim;     // 1, nw, M*M, K
     const cplx *xs;                  // [nw, K]
-    const double *hsT;               // [K, M*M]
+    const double *hsT;               // [K, ldb]
+    long ldb;
     cplx *out;                       // [nw, M*M]
     double sqrt_dt;
     const int *alive;
     __device__ bool active(int) const { return true; }
     __device__ cplx loadA(int, int row, int k) const { return xs[(long)row * kdim + k]; }
-    __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * cols + col], 0.0); }
+    __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * ldb + col], 0.0); }
+    __device__ const cplx *ptrA(int, int row, int k) const { return xs + (long)row * kdim + k; }
+    __device__ const double *ptrB(int, int k, int col) const { return hsT + (long)k * ldb + col; }
     __device__ void store(int, int row, int col, double re, double im) const {
         // i*sqrt(dt)*(re + i im)
         out[(long)row * cols + col] = cmake(-sqrt_dt * im, sqrt_dt * re);
@@ -166,16 +203,25 @@ struct VhsProb {
 int k_vhs_generic(afq_handle *h) {
     VhsProb p;
     p.batch = 1; p.rows = h->nw; p.cols = h->M * h->M; p.kdim = h->K;
-    p.xs = h->xs; p.hsT = h->hs_pot; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
+    p.xs = h->xs; p.hsT = h->hs_pot; p.ldb = h->ld_hs; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
+    if (h->nw > 32 && !h->no_ring) {
+        // work-group tile 64 walkers x 160 (p,q) pairs; hs_pot^T panels shared through the LDS ring
+        static const int cfg = getenv("AFQ_VHS_CFG") ? atoi(getenv("AFQ_VHS_CFG")) : 0;
+        if (cfg == 1) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 4) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        return AFQ_OK;
+    }
     static const TileChoice cand[] = {{2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 2}};
     const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, cand, 5);
-    // all tile rows (walker blocks) of one hs_pot column panel in one workgroup: the
-    // 40 MB hs_pot streams from HBM once, its panel is shared through L1/L2
     const int tiles_m = (p.rows + 16 * tc.tm - 1) / (16 * tc.tm);
     int wpb = tiles_m <= 8 ? (tiles_m < 1 ? 1 : tiles_m) : 8;
     const long ntask = mfma_gemm_tasks(p.batch, p.rows, p.cols, tc.tm, tc.tn);
     while (wpb > 1 && ntask / wpb < 200) wpb >>= 1;      // keep >= ~1 workgroup per CU
-    if (tc.tm == 2 && tc.tn == 5) AFQ_HIP(h, (launch_mfma_gemm<2, 5, VhsProb, MAP_ROWS_FAST>(p, h->stream, wpb)));
+    if (tc.tm == 2 && tc.tn == 5)
+        AFQ_HIP(h, (launch_mfma_gemm<2, 5, VhsProb, MAP_ROWS_FAST>(p, h->stream, wpb)));
     else DISPATCH_TILES(h, p, tc, MAP_ROWS_FAST, wpb);
     return AFQ_OK;
 }
@@ -194,6 +240,8 @@ struct TaylorProb {
     __device__ bool active(int b) const { return alive[b] != 0; }
     __device__ cplx loadA(int b, int row, int k) const { return vhs[b * vstride + (long)row * kdim + k]; }
     __device__ cplx loadB(int b, int k, int col) const { return tin[((long)b * kdim + k) * nt + off + col]; }
+    __device__ const cplx *ptrA(int b, int row, int k) const { return vhs + b * vstride + (long)row * kdim + k; }
+    __device__ const cplx *ptrB(int b, int k, int col) const { return tin + ((long)b * kdim + k) * nt + off + col; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         const long idx = ((long)b * rows + row) * nt + off + col;
         const cplx t = cmake(re * inv_n, im * inv_n);
@@ -218,6 +266,11 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.vstride = (long)h->nv * M * M;
             p.vhs = vhs + (long)s * M * M;
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
+            if (!h->no_ring && M > 64 && M <= 128 && p.cols > 32 && p.cols <= 64 && h->nw >= 64) {
+                // one work-group (8 waves, 128 x 64 tile) = one walker: VHS[w] and T[w] pass the LDS ring once
+                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST>(p, h->stream, h->zero_page)));
+                continue;
+            }
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
             // one workgroup = every tile of one walker (its VHS and T panels stay in one L1/L2)
             const long per = mfma_gemm_tasks(1, p.rows, p.cols, tc.tm, tc.tn);

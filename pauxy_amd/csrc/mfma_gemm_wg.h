@@ -1,0 +1,178 @@
+// Work-group-tiled fp64 MFMA GEMM with a shared LDS ring.
+//
+// WM x WN waves form one work-group; wave (wm, wn) owns TM x TN 16x16 tiles, so
+// the work-group tile is (16 TM WM) x (16 TN WN).  Per chunk of 8 contraction
+// indices every operand fragment of the work-group tile is brought into LDS
+// ONCE (global_load_lds_dwordx4, fragment order, see mfma_gemm_ring.h) and read
+// by all the waves that need it: an A fragment by the WN waves of its tile row,
+// a B fragment by the WM waves of its tile column.  That multiplies the flops
+// per byte fetched from L2 by ~WM (resp. WN) over the one-wave-one-block
+// engines, which is what the K-long, output-small contractions (force bias:
+// 256 x 5000 x 500) need: they are L2-miss-bandwidth bound otherwise.
+//
+// Pipeline (ring of D slots, one raw s_barrier per chunk):
+//   iteration c:  s_waitcnt vmcnt((D-2) * LPW)   own DMA of chunk c has landed
+//                 s_barrier                      everyone's DMA of chunk c has landed and
+//                                                everyone is done reading chunk c-1
+//                 issue DMA of chunk c+D-1 into slot (c-1) % D
+//                 ds_read fragments of chunk c (inline asm), s_waitcnt lgkmcnt(0)
+//                 MFMAs
+// Every wave issues exactly LPW loads per chunk (its share of the A and B
+// fragments, padded with zero-page loads into a scratch KB) so the counted
+// vmcnt is a compile-time constant.
+#pragma once
+#include "mfma_gemm_ring.h"
+
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP>
+__global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
+    static_assert(P::A_CPLX, "A operand must be complex");
+    static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = WM * WN;
+    constexpr int RT = WM * TM, CT = WN * TN;              // tile rows / cols of the work-group tile
+    constexpr int NA = RT * 2;                             // A fragments per chunk (1 KB each)
+    constexpr int NB = P::B_CPLX ? CT * 2 : CT;            // B fragments (1 KB each)
+    constexpr int LPA = (NA + NW - 1) / NW, LPB = (NB + NW - 1) / NW, LPW = LPA + LPB;
+    constexpr int CHUNK = (NA + NB) * 1024;
+    constexpr int NWAIT = (D - 2) * LPW;
+    static_assert(NWAIT <= 63, "vmcnt field is 6 bits");
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
+    const int tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
+    const long per_batch = (long)tiles_m * tiles_n;
+    int b, tm, tn;
+    if (MAP == MAP_BATCH_XCD) {
+        const int nb8 = p.batch < 8 ? p.batch : 8;
+        const int grp = blockIdx.x % nb8;
+        const long t = blockIdx.x / nb8;
+        b = grp + (int)(t / per_batch) * nb8;
+        if (b >= p.batch) return;
+        const int rem = (int)(t % per_batch);
+        tm = rem / tiles_n; tn = rem % tiles_n;
+    } else {
+        const long t = blockIdx.x;
+        b = (int)(t / per_batch);
+        const int rem = (int)(t % per_batch);
+        if (MAP == MAP_ROWS_FAST) { tn = rem / tiles_m; tm = rem % tiles_m; }
+        else { tm = rem / tiles_n; tn = rem % tiles_n; }
+    }
+    if (!p.active(b)) return;                              // uniform over the work-group
+    const int row0 = tm * 16 * RT, col0 = tn * 16 * CT;
+    const int lr = lane & 15, lk = lane >> 4;
+    unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
+    const unsigned ring_l = lds_addr(smem);
+    const int nchunks = (p.kdim + 7) >> 3;
+    const int b_half = lane >> 5, b_lp = lane & 31;
+    const int b_kk = b_lp >> 3, b_cc = (b_lp & 7) * 2;
+
+    auto issue = [&](int c, int slot) {
+        unsigned char *dst = smem + (size_t)slot * CHUNK;
+        const int k0 = c * 8;
+#pragma unroll
+        for (int t = 0; t < LPA; ++t) {
+            const int f = wave + t * NW;                   // A fragment index: tile row f>>1, sub-step f&1
+            const int k = k0 + 2 * lk + (f & 1), row = row0 + (f >> 1) * 16 + lr;
+            const bool ok = f < NA && k < p.kdim && row < p.rows;
+            const void *src = ok ? (const void *)p.ptrA(b, row, k) : zero16;
+            glds16(src, f < NA ? dst + f * 1024 : scratch);
+        }
+#pragma unroll
+        for (int t = 0; t < LPB; ++t) {
+            const int f = wave + t * NW;
+            const void *src = zero16;
+            if (P::B_CPLX) {
+                const int k = k0 + 2 * lk + (f & 1), col = col0 + (f >> 1) * 16 + lr;
+                if (f < NB && k < p.kdim && col < p.cols) src = (const void *)p.ptrB(b, k, col);
+            } else {
+                const int k = k0 + 2 * b_kk + b_half, col = col0 + f * 16 + b_cc;
+                if (f < NB && k < p.kdim && col < p.cols) src = (const void *)p.ptrB(b, k, col);
+            }
+            glds16(src, f < NB ? dst + (NA + f) * 1024 : scratch);
+        }
+    };
+
+    d4_t accR[TM][TN], accI[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            accR[i][j] = (d4_t){0, 0, 0, 0};
+            accI[i][j] = (d4_t){0, 0, 0, 0};
+        }
+
+#pragma unroll
+    for (int c = 0; c < D - 1; ++c) issue(c, c);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(c + D - 1, (c + D - 1) & (D - 1));
+        const unsigned sl = ring_l + (c & (D - 1)) * CHUNK;
+        d2_t a[TM][2];
+        d2_t bc[TN][2];
+        double br[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a[i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (P::B_CPLX) bc[j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
+                else br[j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (P::B_CPLX) {
+                        accR[i][j] = mfma16(a[i][s][0], bc[j][s][0], accR[i][j]);
+                        accI[i][j] = mfma16(a[i][s][0], bc[j][s][1], accI[i][j]);
+                        accR[i][j] = mfma16(-a[i][s][1], bc[j][s][1], accR[i][j]);
+                        accI[i][j] = mfma16(a[i][s][1], bc[j][s][0], accI[i][j]);
+                    } else {
+                        accR[i][j] = mfma16(a[i][s][0], br[j][s], accR[i][j]);
+                        accI[i][j] = mfma16(a[i][s][1], br[j][s], accI[i][j]);
+                    }
+                }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int wrow0 = row0 + wm * TM * 16, wcol0 = col0 + wn * TN * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wrow0 + i * 16 + lk + 4 * r;
+                const int col = wcol0 + j * 16 + lr;
+                if (row < p.rows && col < p.cols) p.store(b, row, col, accR[i][j][r], accI[i][j][r]);
+            }
+}
+
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP>
+inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
+    constexpr int RT = WM * TM, CT = WN * TN;
+    constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
+    const long tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
+    const long tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
+    const long per_batch = tiles_m * tiles_n;
+    long nblk = (long)p.batch * per_batch;
+    if (nblk == 0) return hipSuccess;
+    if (MAP == MAP_BATCH_XCD) {
+        const int nb8 = p.batch < 8 ? p.batch : 8;
+        nblk = per_batch * ((p.batch + nb8 - 1) / nb8) * nb8;
+    }
+    const size_t lds = (size_t)D * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
+    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, p, zero16);
+    return hipGetLastError();
+}

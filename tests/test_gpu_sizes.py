@@ -1,0 +1,83 @@
+"""Mid-size parity (odd dimensions, nw not a multiple of 16, na != nb): exercises
+the work-group-tiled LDS-ring GEMMs, tile-edge predication and the zero-padded
+leading dimensions.  HIP library vs the CPU oracle on every walker."""
+import numpy
+import pytest
+
+from oracle import afqmc_ref as ref
+from pauxy_amd import _lib as L
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.propagation import setup
+from tests.helpers import make_device
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def close(a, b, tol=TOL):
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(numpy.max(numpy.abs(b))))
+    err = float(numpy.max(numpy.abs(a - b))) / scale
+    assert err <= tol, err
+
+
+def build(M, K, na, nb, complex_trial, seed=3, dt=0.01):
+    rng = numpy.random.RandomState(seed)
+    s = systems.synthetic_generic(M, K, (na, nb), seed=seed)
+    e, v = numpy.linalg.eigh(s.H1[0])
+    psi = numpy.zeros((M, na + nb), dtype=complex)
+    psi[:, :na] = v[:, :na]
+    psi[:, na:] = v[:, :nb]
+    if complex_trial:
+        psi = psi + 0.05 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb))
+    t = trial_mod.SingleDetTrial(s, psi)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, na, nb, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=0.37)
+    return model, rng
+
+
+@pytest.mark.parametrize("M,K,na,nb,nw,cplx", [(37, 45, 7, 6, 70, False), (24, 50, 5, 5, 130, True)])
+def test_midsize_generic(M, K, na, nb, nw, cplx):
+    model, rng = build(M, K, na, nb, cplx)
+    dev = make_device(model, nw)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    dev.set(L.F_PHI, phis)
+    det = dev.greens(want_G=True)
+    refs = [ref.greens_function(p, model.psi, na, nb) for p in phis]
+    close(det, numpy.array([r[0] for r in refs]))
+    close(dev.get(L.F_GHALF), numpy.array([numpy.concatenate([r[1][0], r[1][1]]) for r in refs]))
+    close(dev.get(L.F_G), numpy.array([r[2] for r in refs]))
+    xbar = dev.force_bias()
+    close(xbar, numpy.array([model.force_bias(r[1], r[2]) for r in refs]))
+    xi = rng.normal(size=(nw, K))
+    xs = numpy.array([ref.shift_fields(xi[i], xbar[i], model.mf_shift, model.sqrt_dt)[0] for i in range(nw)])
+    vhs = dev.vhs(xs)
+    close(vhs[:, 0], numpy.array([model.vhs(x) for x in xs]))
+    E = dev.local_energy()
+    close(E, numpy.array([model.local_energy(r[2], r[1]) for r in refs]))
+    # full step: half the walkers dead
+    w0 = numpy.ones(nw)
+    w0[::3] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, na, nb) for p in phis]))
+    dev.propagate(xi, -1.5)
+    out_phi, out_w, out_e = dev.get(L.F_PHI), dev.get(L.F_WEIGHT), dev.get(L.F_HYBRID_ENERGY)
+    for i in range(nw):
+        if w0[i] == 0.0:
+            assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+            continue
+        w = ref.new_walker(model, phis[i])
+        ref.propagate_walker_phaseless(model, w, xi[i], -1.5)
+        close(out_phi[i], w['phi'])
+        close(out_w[i], w['weight'])
+        close(out_e[i], w['hybrid_energy'])
+    detR = dev.reortho()
+    q = dev.get(L.F_PHI)
+    for i in range(0, nw, 7):
+        p = out_phi[i].copy()
+        d = ref.reortho(p, na, nb)
+        close(q[i], p)
+        close(detR[i], d)
+    dev.close()
