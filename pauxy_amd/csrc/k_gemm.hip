@@ -77,7 +77,7 @@ int k_onebody(afq_handle *h) {
         p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
         if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
             // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
-            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST>(p, h->stream, h->zero_page)));
+            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else {
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
             DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
@@ -268,7 +268,7 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
             if (!h->no_ring && M > 64 && M <= 128 && p.cols > 32 && p.cols <= 64 && h->nw >= 64) {
                 // one work-group (8 waves, 128 x 64 tile) = one walker: VHS[w] and T[w] pass the LDS ring once
-                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST>(p, h->stream, h->zero_page)));
+                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 continue;
             }
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);

@@ -3,6 +3,7 @@
 // field shift / clipping, the phaseless weight update, population control and
 // the mixed-estimator accumulation.  One workgroup per walker; panels live in
 // LDS when they fit and in a global workspace otherwise.
+#include <cstdlib>
 #include "mfma_gemm.h"
 
 #define NTHR 256
@@ -89,6 +90,7 @@ struct GreensArgs {
     int o_in_lds;
     int only_alive;
     const int *alive;
+    int dbg;            // timing experiments only (AFQ_GREENS_DBG): 1 skip pivot loop, 2 skip phase 3, 4 skip phase 1
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -168,40 +170,65 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
 //            the whole N x N update of a pivot step spread over the 64 lanes
 //   phase 3  Ghalf_s = O^-1 phi_s^T             fp64 MFMA, A fragment from LDS
 // (reference: scipy.linalg.inv + numpy.dot + slogdet, walkers/single_det.py:310-320)
+#define GS_KSMAX 32       // k-steps of 4 supported by the fast Green's kernel (M <= 128)
 template <bool INVERSE>
 __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cplx ph_s[2];
     __shared__ double la_s[2];
+    __shared__ unsigned long long pmax_s[2][48];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (a.only_alive && !a.alive[w]) return;
     const int g = tid >> 8, wave = (tid >> 6) & 3, lane = tid & 63;
+    unsigned long long *pmax = pmax_s[g];
+    if ((tid & 255) < 48) pmax[tid & 255] = 0ull;
     const int M = a.M, nt = a.nt;
     const int nmax = a.na > a.nb ? a.na : a.nb;
     const int n = g == 0 ? a.na : a.nb, off = g == 0 ? 0 : a.na;
     cplx *O = (cplx *)smem + (long)g * (nmax * nmax + 2 * nmax);
     cplx *colk = O + nmax * nmax, *rowk = colk + nmax;
     int *piv = (int *)((cplx *)smem + 2L * (nmax * nmax + 2 * nmax)) + g * nmax;
-    const cplx *phi = a.phi + (long)w * M * nt;
+    cplx *phi_l = (cplx *)smem + 2L * (nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1);   // [M, nt] copy of the walker
+    const cplx *phi_g = a.phi + (long)w * M * nt;
     const int lr = lane & 15, lk = lane >> 4;
     const int nt16 = (n + 15) >> 4;
-    // ---- phase 1
-    for (int t = wave; t < nt16 * nt16; t += 4) {
+    const int nks = (M + 3) >> 2;
+    // ---- phase 0: the walker's Slater matrix into LDS, one coalesced sweep
+    for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
+    // ---- phase 1: O = phi_s^T conj(psi_s).  The trial fragments of the wave's first tile are
+    // fetched up front (all loads in flight at once); phi fragments come from LDS.
+    for (int t = wave; t < ((a.dbg & 4) ? 0 : nt16 * nt16); t += 4) {
         const int ti = t / nt16, tj = t % nt16;
-        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
         const int ia = ti * 16 + lr, jb = tj * 16 + lr;
-        for (int p0 = 0; p0 < M; p0 += 4) {
-            const int p = p0 + lk;
-            cplx x = cmake(0.0, 0.0), y = cmake(0.0, 0.0);
-            if (p < M) {
-                if (ia < n) x = phi[(long)p * nt + off + ia];
-                if (jb < n) y = a.psi[(long)p * nt + off + jb];
+        const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;     // clamped: loads stay unconditional
+        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
+#pragma unroll
+        for (int half = 0; half < GS_KSMAX / 16; ++half) {
+            if (half * 16 < nks) {
+                cplx yb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int p = (half * 16 + u) * 4 + lk;
+                    const cplx y = a.psi[(long)(p < M ? p : M - 1) * nt + off + jbc];
+                    yb[u] = (p < M && jb < n) ? y : cmake(0.0, 0.0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // all 16 trial-fragment loads in flight before any MFMA
+                if (t == wave && half == 0) __syncthreads();   // phi_l complete (each wave passes here once)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int ks = half * 16 + u;
+                    if (ks < nks) {
+                        const int p = ks * 4 + lk;
+                        cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];
+                        if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
+                        const cplx y = yb[u];
+                        accR = mfma16(x.x, y.x, accR);             // x * conj(y)
+                        accR = mfma16(x.y, y.y, accR);
+                        accI = mfma16(x.y, y.x, accI);
+                        accI = mfma16(-x.x, y.y, accI);
+                    }
+                }
             }
-            // x * conj(y)
-            accR = mfma16(x.x, y.x, accR);
-            accR = mfma16(x.y, y.y, accR);
-            accI = mfma16(x.y, y.x, accI);
-            accI = mfma16(-x.x, y.y, accI);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -209,47 +236,82 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
             if (i < n && j < n) O[i * n + j] = cmake(accR[r], accI[r]);
         }
     }
+    if (wave >= nt16 * nt16 || (a.dbg & 4)) __syncthreads();  // waves without a tile still owe the phase-0 barrier
     __syncthreads();
     // ---- phase 2
-    if (wave == 0) {
+    if (wave == 0 && !(a.dbg & 1)) {
+        // det = prod of pivots, kept as (mantissa, binary exponent) so that neither log, exp nor
+        // hypot sits on the per-pivot critical path
         cplx ph = cmake(1.0, 0.0);
-        double la = 0.0;
+        int la = 0;
         const int cw_shift = n <= 32 ? 5 : 6;
         const int cj = lane & ((1 << cw_shift) - 1), ri = lane >> cw_shift, rstep = 64 >> cw_shift;
         for (int k = 0; k < n; ++k) {
-            double best = -1.0;
-            int bi = k;
-            for (int i = k + lane; i < n; i += 64) {
-                const cplx v = O[i * n + k];
-                const double m = fabs(v.x) + fabs(v.y);
-                if (m > best) { best = m; bi = i; }
+            // column k -> colk; pivot = first row with the largest |re|+|im| (LAPACK izamax metric):
+            // one LDS atomic max on the bit pattern of the (non-negative) metric, then a ballot
+            unsigned long long mbits = 0;
+            if (lane < n) {
+                const cplx v = O[lane * n + k];
+                colk[lane] = v;
+                if (lane >= k) {
+                    mbits = (unsigned long long)__double_as_longlong(fabs(v.x) + fabs(v.y));
+                    atomicMax(&pmax[k], mbits);
+                }
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            const int p = bi;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long mx = pmax[k];
+            const unsigned long long hit = __ballot(lane >= k && lane < n && mbits == mx);
+            const int p = hit ? __ffsll((long long)hit) - 1 : k;
             if (p != k) {
                 for (int j = lane; j < n; j += 64) {
                     const cplx t = O[k * n + j];
                     O[k * n + j] = O[p * n + j];
                     O[p * n + j] = t;
                 }
+                if (lane == 0) { const cplx t = colk[k]; colk[k] = colk[p]; colk[p] = t; }
             }
             if (lane == 0) piv[k] = p;
             __builtin_amdgcn_wave_barrier();
-            const cplx d = O[k * n + k];
-            const double ab = hypot(d.x, d.y);
-            cplx u = cmake(d.x / ab, d.y / ab);
-            if (p != k) u = cmake(-u.x, -u.y);
-            ph = cmul(ph, u);
-            la += log(ab);
-            const cplx dinv = cdiv(cmake(1.0, 0.0), d);
-            for (int i = lane; i < n; i += 64) colk[i] = O[i * n + k];
+            const cplx d = colk[k];
+            ph = cmul(ph, p != k ? cmake(-d.x, -d.y) : d);
+            {
+                int e;
+                (void)frexp(fmax(fabs(ph.x), fabs(ph.y)), &e);
+                ph = cmake(ldexp(ph.x, -e), ldexp(ph.y, -e));
+                la += e;
+            }
+            const double dn = 1.0 / (d.x * d.x + d.y * d.y);
+            const cplx dinv = cmake(d.x * dn, -d.y * dn);
             for (int j = lane; j < n; j += 64) rowk[j] = cmul(O[k * n + j], dinv);
             __builtin_amdgcn_wave_barrier();
-            if (INVERSE) {
+            if (n <= 32) {
+                // n x n update with every LDS read of the step in flight before the arithmetic:
+                // lane (ri, cj) owns rows ri, ri+2, ... of column cj; 16 rows per lane, unrolled
+                if (cj < n && (INVERSE || cj > k)) {
+                    const cplx rk = rowk[cj];
+                    cplx v[16], f[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int i = ri + 2 * t;
+                        if (i < n) { v[t] = O[i * n + cj]; f[t] = colk[i]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int i = ri + 2 * t;
+                        if (i < n && (INVERSE || i > k)) {
+                            cplx o;
+                            if (INVERSE && i == k) o = (cj == k) ? dinv : rk;
+                            else if (INVERSE && cj == k) { const cplx m = cmul(f[t], dinv); o = cmake(-m.x, -m.y); }
+                            else {
+                                o = v[t];
+                                o.x = fma(-f[t].x, rk.x, o.x); o.x = fma(f[t].y, rk.y, o.x);
+                                o.y = fma(-f[t].x, rk.y, o.y); o.y = fma(-f[t].y, rk.x, o.y);
+                            }
+                            O[i * n + cj] = o;
+                        }
+                    }
+                }
+            } else if (INVERSE) {
                 if (cj < n) {
                     const cplx rk = rowk[cj];
                     for (int i = ri; i < n; i += rstep) {
@@ -294,16 +356,16 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (lane == 0) { ph_s[g] = ph; la_s[g] = la; }
+        if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
     }
     __syncthreads();
     if (tid == 0) {
-        const double e = exp(la_s[0] + la_s[1]);
-        const cplx p2 = cmul(ph_s[0], ph_s[1]);
-        a.det[w] = cmake(p2.x * e, p2.y * e);
+        const cplx p2 = (a.dbg & 1) ? cmake(1.0, 0.0) : cmul(ph_s[0], ph_s[1]);
+        const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
+        a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
     }
     // ---- phase 3
-    if (INVERSE && a.ghalf && n > 0) {
+    if (INVERSE && a.ghalf && n > 0 && !(a.dbg & 2)) {
         cplx *gh = a.ghalf + ((long)w * nt + off) * M;
         const int mt16 = (M + 15) >> 4;
         for (int t = wave; t < nt16 * mt16; t += 4) {
@@ -315,7 +377,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
                 cplx x = cmake(0.0, 0.0), y = cmake(0.0, 0.0);
                 if (j < n) {
                     if (ia < n) x = O[ia * n + j];
-                    if (c < M) y = phi[(long)c * nt + off + j];
+                    if (c < M) y = phi_l[c * nt + off + j];
                 }
                 accR = mfma16(x.x, y.x, accR);
                 accR = mfma16(-x.y, y.y, accR);
@@ -337,19 +399,36 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) 
     a.phi = h->phi; a.psi = h->psi; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
-    if (nmax <= 45) {
+    if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
-        const size_t lds = sizeof(cplx) * 2 * ((size_t)nmax * nmax + 2 * nmax) + sizeof(int) * 2 * nmax;
-        if (ghalf)
+        static const int dbg = getenv("AFQ_GREENS_DBG") ? atoi(getenv("AFQ_GREENS_DBG")) : 0;
+        a.dbg = dbg;
+        if (h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "fast Green's kernel supports M <= 128");
+        const size_t lds = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) +
+                                           (size_t)h->M * h->nt);
+        static size_t lds_set[2] = {0, 0};      // raise the dynamic-LDS cap once per kernel, not per launch
+        if (ghalf) {
+            if (lds > lds_set[1]) {
+                AFQ_HIP(h, hipFuncSetAttribute((const void *)greens_small_kernel<true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_set[1] = lds;
+            }
             hipLaunchKernelGGL(greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
-        else
+        } else {
+            if (lds > lds_set[0]) {
+                AFQ_HIP(h, hipFuncSetAttribute((const void *)greens_small_kernel<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_set[0] = lds;
+            }
             hipLaunchKernelGGL(greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+        }
         AFQ_HIP(h, hipGetLastError());
         return AFQ_OK;
     }
     const size_t need = sizeof(cplx) * (size_t)nmax * nmax;
     a.o_in_lds = need <= 64 * 1024;
     a.only_alive = only_alive; a.alive = h->alive;
+    a.dbg = 0;
     if (!a.o_in_lds && !h->lu_ws)
         AFQ_HIP(h, hipMalloc(&h->lu_ws, sizeof(cplx) * (size_t)h->nw * nmax * nmax));
     a.ws = h->lu_ws;

@@ -209,8 +209,12 @@ inline hipError_t launch_mfma_gemm_ring(const P &p, hipStream_t stream, int wave
     }
     const size_t lds = ring_bytes_per_wave<TM, TN, P::B_CPLX>(D) * waves_per_block;
     auto kern = mfma_gemm_ring_kernel<TM, TN, D, P, MAP>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t lds_set = 0;              // one per template instantiation: set the cap once
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * waves_per_block), lds, stream, p, zero16);
     return hipGetLastError();
 }

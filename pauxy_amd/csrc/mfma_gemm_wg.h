@@ -23,7 +23,10 @@
 #pragma once
 #include "mfma_gemm_ring.h"
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP>
+// K3M: complex x complex products by the 3-multiplication (Karatsuba) form
+//   P1 = Ar Br, P2 = Ai Bi, P3 = (Ar+Ai)(Br+Bi);  Cr = P1 - P2, Ci = P3 - P1 - P2
+// (3 real MFMAs per fragment pair instead of 4; error is bounded normwise, ~1e-16 |A||B|).
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
     static_assert(P::A_CPLX, "A operand must be complex");
     static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
@@ -93,13 +96,14 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
         }
     };
 
-    d4_t accR[TM][TN], accI[TM][TN];
+    d4_t accR[TM][TN], accI[TM][TN], acc3[K3M ? TM : 1][K3M ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             accR[i][j] = (d4_t){0, 0, 0, 0};
             accI[i][j] = (d4_t){0, 0, 0, 0};
+            if (K3M) acc3[i][j] = (d4_t){0, 0, 0, 0};
         }
 
 #pragma unroll
@@ -131,7 +135,11 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (P::B_CPLX) {
+                    if (P::B_CPLX && K3M) {
+                        accR[i][j] = mfma16(a[i][s][0], bc[j][s][0], accR[i][j]);                          // P1
+                        accI[i][j] = mfma16(a[i][s][1], bc[j][s][1], accI[i][j]);                          // P2
+                        acc3[i][j] = mfma16(a[i][s][0] + a[i][s][1], bc[j][s][0] + bc[j][s][1], acc3[i][j]);  // P3
+                    } else if (P::B_CPLX) {
                         accR[i][j] = mfma16(a[i][s][0], bc[j][s][0], accR[i][j]);
                         accI[i][j] = mfma16(a[i][s][0], bc[j][s][1], accI[i][j]);
                         accR[i][j] = mfma16(-a[i][s][1], bc[j][s][1], accR[i][j]);
@@ -143,6 +151,16 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
                 }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (P::B_CPLX && K3M) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const d4_t p1 = accR[i][j], p2 = accI[i][j];
+                accR[i][j] = p1 - p2;
+                accI[i][j] = acc3[i][j] - p1 - p2;
+            }
+    }
     const int wrow0 = row0 + wm * TM * 16, wcol0 = col0 + wn * TN * 16;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
 }
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;
     constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
@@ -170,9 +188,13 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
         nblk = per_batch * ((p.batch + nb8 - 1) / nb8) * nb8;
     }
     const size_t lds = (size_t)D * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
-    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M>;
+    static size_t lds_set = 0;              // one per template instantiation: set the cap once
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, p, zero16);
     return hipGetLastError();
 }
