@@ -1,0 +1,135 @@
+"""BASELINE-size parity on the GPU.
+
+At the full sizes of BASELINE configs[1..3] the oracle still finishes one walker
+in well under a second, so a sample of walkers of each full-size batch is checked
+DIRECTLY against the oracle (one complete propagation step + local energy), and
+every walker is checked through size-independent properties:
+  * the Green's function is a rank-N projector: G.G = G, trace G_s = N_s
+  * re-orthogonalisation: columns orthonormal, ot * detR invariant
+  * zero HS potential leaves phi unchanged by the Taylor propagator
+  * dead walkers are not touched
+"""
+import numpy
+import pytest
+
+from oracle import afqmc_ref as ref
+from pauxy_amd import _lib as L
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.propagation import setup
+from tests.helpers import make_device
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol):
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(numpy.max(numpy.abs(b))))
+    err = float(numpy.max(numpy.abs(a - b))) / scale
+    assert err <= tol, err
+
+
+def generic_c3(nw):
+    M, K, N, dt = 100, 500, 25, 0.005
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=0.0)
+    return model
+
+
+def hubbard_c4():
+    s = systems.Hubbard(16, 16, 128, 128, 8.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    dt = 0.005
+    BH1, mf = setup.hubbard_propagator_arrays(s, t, dt, True)
+    return ref.RefModel('hubbard', 256, 128, 128, t.psi, BH1, mf, dt, U=8.0, H1=s.T.astype(complex))
+
+
+def ueg_c2():
+    s = systems.UEG(2.0, 7, 7, 4.0)
+    assert s.nbasis == 93 and s.nchol == 750
+    t = trial_mod.hartree_fock_ueg(s)
+    dt = 0.005
+    BH1, mf = setup.ueg_propagator_arrays(s, t, dt)
+    H1diag = numpy.array([numpy.diag(s.H1[0]), numpy.diag(s.H1[1])])
+    return ref.RefModel('ueg', s.nbasis, 7, 7, t.psi, BH1, mf, dt, iA=s.iA, iB=s.iB, H1diag=H1diag,
+                        vqvec=s.vqvec, vol=s.vol, ikpq_i=s.ikpq_i, ikpq_kpq=s.ikpq_kpq, ipmq_i=s.ipmq_i,
+                        ipmq_pmq=s.ipmq_pmq, ecore=s.ecore)
+
+
+def run_fullsize(model, nw, sample, tol_op=1e-10, tol_step=1e-9):
+    rng = numpy.random.RandomState(5)
+    M, na, nb, K = model.M, model.na, model.nb, model.nfields
+    dev = make_device(model, nw)
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, M, na + nb) + 1j * rng.rand(nw, M, na + nb))
+    dev.set(L.F_PHI, phis)
+    # ---- projector property of the Green's function, all walkers
+    det = dev.greens(want_G=True)
+    G = dev.get(L.F_G)
+    for w in range(0, nw, max(1, nw // 16)):
+        for s_, n in ((0, na), (1, nb)):
+            close(G[w, s_] @ G[w, s_], G[w, s_], 1e-9)
+            assert abs(numpy.trace(G[w, s_]) - n) < 1e-8 * n
+    E = dev.local_energy()
+    # ---- sampled walkers against the oracle: Green's function, energy
+    for w in sample:
+        d, gh, Gr = ref.greens_function(phis[w], model.psi, na, nb)
+        close(det[w], d, tol_op)
+        close(G[w], Gr, tol_op)
+        close(E[w], numpy.array(model.local_energy(Gr, gh)), tol_op)
+    # ---- one full step, some walkers dead
+    xi = rng.normal(size=(nw, K))
+    w0 = numpy.ones(nw)
+    w0[1::5] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, det)
+    dev.propagate(xi, 0.0)
+    out_phi, out_w, out_e, out_ot = (dev.get(L.F_PHI), dev.get(L.F_WEIGHT), dev.get(L.F_HYBRID_ENERGY),
+                                     dev.get(L.F_OT))
+    dead = numpy.nonzero(w0 == 0.0)[0]
+    assert numpy.array_equal(out_phi[dead], phis[dead]) and numpy.all(out_w[dead] == 0.0)
+    for w in sample:
+        if w0[w] == 0.0:
+            continue
+        wk = ref.new_walker(model, phis[w])
+        ref.propagate_walker_phaseless(model, wk, xi[w], 0.0)
+        close(out_phi[w], wk['phi'], tol_step)
+        close(out_w[w], wk['weight'], tol_step)
+        close(out_e[w], wk['hybrid_energy'], tol_step)
+        close(out_ot[w], wk['ot'], tol_step)
+    # ---- zero HS potential: Taylor propagator is the identity
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, numpy.ones(nw))
+    dev.apply_exponential(numpy.zeros((nw, dev.nv, M, M), dtype=complex))
+    assert numpy.array_equal(dev.get(L.F_PHI), phis)
+    # ---- re-orthogonalisation invariants, all walkers
+    ot0 = dev.calc_overlap()
+    dev.set(L.F_OT, ot0)
+    detR = dev.reortho()
+    q = dev.get(L.F_PHI)
+    ot1 = dev.calc_overlap()
+    close(ot1 * detR, ot0, 1e-9)                      # detR * ot == ovlp (walkers/tests/test_single_det.py)
+    close(dev.get(L.F_OT), ot0 / detR, 1e-12)
+    for w in range(0, nw, max(1, nw // 8)):
+        for sl in (slice(0, na), slice(na, na + nb)):
+            close(q[w][:, sl].conj().T @ q[w][:, sl], numpy.eye(sl.stop - sl.start), 1e-11)
+    for w in sample[:2]:
+        p = phis[w].copy()
+        d = ref.reortho(p, na, nb)
+        close(q[w], p, 1e-9)
+        close(detR[w], d, 1e-9)
+    dev.close()
+
+
+def test_c3_generic_256_walkers():
+    run_fullsize(generic_c3(256), 256, [0, 100, 255])
+
+
+def test_c4_hubbard_16x16():
+    run_fullsize(hubbard_c4(), 32, [0, 31])
+
+
+def test_c2_ueg_93_planewaves():
+    run_fullsize(ueg_c2(), 64, [0, 63])
