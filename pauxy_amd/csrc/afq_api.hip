@@ -118,6 +118,7 @@ int afq_create(int device_id, afq_handle **out) {
     if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->zero_page, 0, 256);
     h->no_ring = getenv("AFQ_NO_RING") != nullptr;
+    h->no_fused = getenv("AFQ_NO_FUSED") != nullptr;
     *out = h;
     return AFQ_OK;
 }
@@ -504,15 +505,23 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
             if ((rc = k_full_G(h))) return rc;
         }
     }
-    { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }            // :251
+    // The force bias reads Ghalf of the un-propagated walker, so building the HS potential commutes
+    // with the first one-body product; the fused path uses that to run B exp(V) B in one launch.
+    const bool fused = k_prop_fused_supported(h);
+    if (!fused) { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }   // :251
     {
         PhaseTimer t(h, T_FB);                                                      // :133-158
         if ((rc = force_bias(h))) return rc;
         if ((rc = k_fields(h))) return rc;
     }
     { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                // :161
-    { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }        // :162-171
-    { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }            // :258
+    if (fused) {
+        PhaseTimer t(h, T_EXP);                                                     // :251, :162-171, :258
+        if ((rc = k_prop_fused(h))) return rc;
+    } else {
+        { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }    // :162-171
+        { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }        // :258
+    }
     {
         PhaseTimer t(h, T_OVLP);                                                    // :261-262
         if ((rc = k_overlap(h, h->ovlp_new))) return rc;

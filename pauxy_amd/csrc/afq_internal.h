@@ -113,6 +113,7 @@ struct afq_handle {
     double *scal = nullptr;         // [8] device scalars (total weight, ...)
     void *pack_tmp = nullptr;
     void *zero_page = nullptr;      // 256 zero bytes: source of out-of-range LDS-DMA loads
+    bool no_fused = false;          // AFQ_NO_FUSED=1: separate one-body / Taylor launches (A/B runs)
     bool no_ring = false;           // AFQ_NO_RING=1: register-prefetch GEMM engine only (A/B runs)
 
     // rng
@@ -158,6 +159,9 @@ int k_force_bias_generic(afq_handle *h);                    // ghalf -> vbias[2,
 int k_vhs_generic(afq_handle *h);                           // xs -> vhs
 int k_apply_exponential(afq_handle *h, const cplx *vhs);    // phi <- sum_n vhs^n/n! phi
 int k_full_G(afq_handle *h);                                // G = conj(psi) ghalf
+// k_fused.hip
+int k_prop_fused_supported(afq_handle *h);
+int k_prop_fused(afq_handle *h);                           // phi <- B exp(V) B phi for live walkers, in place
 // k_small.hip
 int k_alive(afq_handle *h);
 int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det

@@ -1,0 +1,248 @@
+// Fused per-walker propagator:   phi <- B . [ sum_{n<=order} V^n / n! ] . B . phi
+// (propagation/continuous.py:251, :162-171 with :82-111, :258) in ONE launch.
+//
+// One 512-thread work-group (8 waves) per live walker.  The walker's Slater
+// matrix never leaves the CU between the 2 + order + 2 matrix products:
+//   * T (the current right-hand operand, M x (na+nb) complex) lives in LDS in
+//     MFMA B-fragment order: [k-chunk of 8][column-tile slot a0 a1 b0 b1][sub-step][64 lanes x 16 B]
+//   * the running Taylor sum lives in registers (each wave owns 2 x 2 tiles)
+//   * the left operands (BH1[0], BH1[1], VHS[w] x order, BH1[0], BH1[1]) stream through a
+//     3-slot LDS ring as ONE continuous sequence of k-chunks filled by global_load_lds
+//     (A-fragment order), so the pipeline never drains between products
+//   * complex products use the 3-multiplication form (see mfma_gemm_wg.h)
+// One raw s_barrier per k-chunk; two more per product to hand the result back into T.
+// Replaces 2 x 2 one-body launches + order Taylor launches + 3 copy kernels + the
+// phi ping-pong buffers of the unfused path; dead walkers (qmc/afqmc.py:232) are skipped
+// in place.
+// Limits: M <= 104 (13 chunks of T = 104 KB of LDS), na, nb <= 32, one VHS matrix per walker.
+#include "mfma_gemm_wg.h"
+
+#define PF_D 3
+
+struct PropFusedArgs {
+    int M, na, nb, nt, order;
+    const cplx *BH1;            // [2, M, M]
+    const cplx *vhs;            // [nw, M, M]
+    cplx *phi;                  // [nw, M, nt], updated in place
+    const int *alive;
+    const void *zero16;
+};
+
+__device__ inline d2_t lds_read_c(unsigned addr) { return lds_read_b128(addr); }
+
+__global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int w = blockIdx.x;
+    if (!a.alive[w]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int M = a.M, nt = a.nt;
+    const int NCH = (M + 7) >> 3;
+    // ---- LDS carve
+    unsigned char *Tf = smem;                                   // [NCH][4][2][1024]
+    unsigned char *ring = smem + (size_t)NCH * 8192;            // [PF_D][8 row tiles][2][1024]
+    const unsigned tf_l = lds_addr(Tf), ring_l = lds_addr(ring);
+    cplx *phi = a.phi + (long)w * M * nt;
+    const cplx *vhs = a.vhs + (long)w * M * M;
+
+    // ---- A stream: global chunk g = phase * NCH + c; phases: B0 B1 V..V B0 B1
+    const int nphase = 4 + a.order;
+    const int G = nphase * NCH;
+    auto a_base = [&](int phase) -> const cplx * {
+        if (phase < 2) return a.BH1 + (long)phase * M * M;
+        if (phase < 2 + a.order) return vhs;
+        return a.BH1 + (long)(phase - 2 - a.order) * M * M;
+    };
+    int gi = 0, gi_phase = 0, gi_c = 0, gi_slot = 0;            // next chunk to issue
+    auto issueA = [&]() {
+        const cplx *A = a_base(gi_phase < nphase ? gi_phase : 0);
+        unsigned char *dst = ring + (size_t)gi_slot * 16384;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int f = wave + t * 8;                          // fragment: row tile f>>1, sub-step f&1
+            const int row = (f >> 1) * 16 + lr, k = gi_c * 8 + 2 * lk + (f & 1);
+            const void *src = (gi < G && row < M && k < M) ? (const void *)(A + (long)row * M + k) : a.zero16;
+            glds16(src, dst + f * 1024);
+        }
+        ++gi;
+        if (++gi_c == NCH) { gi_c = 0; ++gi_phase; }
+        if (++gi_slot == PF_D) gi_slot = 0;
+    };
+    issueA(); issueA();                                          // PF_D - 1 chunks in flight
+
+    // ---- phi[w] -> T (B-fragment order), padding zeroed
+    for (int e = tid; e < NCH * 512; e += 512) ((d2_t *)Tf)[e] = (d2_t){0.0, 0.0};
+    __syncthreads();
+    for (int e = tid; e < M * nt; e += 512) {
+        const int p = e / nt, col = e % nt;
+        const int s = col >= a.na ? 1 : 0, j = col - (s ? a.na : 0);
+        const int slot = 2 * s + (j >> 4);
+        const unsigned off = (((p >> 3) * 4 + slot) * 2 + (p & 1)) * 1024 + ((((p & 7) >> 1) * 16) + (j & 15)) * 16;
+        *(cplx *)(Tf + off) = phi[e];
+    }
+    __syncthreads();
+
+    // accumulator-layout address of element (row tile ti, reg r) of column slot cs for this lane
+    auto t_ok = [&](int ti, int r) -> bool { return 2 * ti + (r >> 1) < NCH; };   // rows past the last chunk do not exist
+    auto t_addr = [&](int ti, int r, int cs) -> unsigned {
+        const int c = 2 * ti + (r >> 1);
+        const int g = (lk >> 1) + 2 * (r & 1), s = lk & 1;
+        return (unsigned)((((c * 4 + cs) * 2 + s) * 1024) + (g * 16 + lr) * 16);
+    };
+
+    int ring_slot = 0;                                           // slot of the chunk being consumed
+    int gcons = 0;                                               // chunks consumed so far
+    // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
+    auto next_chunk = [&]() -> unsigned {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issueA();
+        const unsigned sl = ring_l + ring_slot * 16384;
+        if (++ring_slot == PF_D) ring_slot = 0;
+        ++gcons;
+        return sl;
+    };
+
+    // ------------------------------------------------------------------ one-body product
+    // wave v owns row tile v and the (up to) two column tiles of spin s
+    auto one_body = [&](int s, bool to_global) {
+        d4_t P1[2], P2[2], P3[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0}; }
+        const int ns_ = s ? a.nb : a.na, off_ = s ? a.na : 0;
+        const int ncs = (ns_ + 15) >> 4;
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned sl = next_chunk();
+            d2_t av[2], bv[2][2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                av[ss] = lds_read_c(sl + (wave * 2 + ss) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + 2 * s + j) * 2 + ss) * 1024 + lane * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < ncs) {
+                        P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
+                        P2[j] = mfma16(av[ss][1], bv[j][ss][1], P2[j]);
+                        P3[j] = mfma16(av[ss][0] + av[ss][1], bv[j][ss][0] + bv[j][ss][1], P3[j]);
+                    }
+        }
+        __builtin_amdgcn_s_barrier();                            // everyone finished reading T(spin s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < ncs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double re = P1[j][r] - P2[j][r], im = P3[j][r] - P1[j][r] - P2[j][r];
+                    if (to_global) {
+                        const int row = wave * 16 + lk + 4 * r, col = j * 16 + lr;
+                        if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+                    } else if (t_ok(wave, r)) {
+                        *(d2_t *)(Tf + t_addr(wave, r, 2 * s + j)) = (d2_t){re, im};
+                    }
+                }
+            }
+    };
+
+    one_body(0, false);
+    one_body(1, false);
+    __syncthreads();                                             // T = B phi complete
+
+    // ------------------------------------------------------------------ Taylor series
+    const int wm = wave >> 1, wn = wave & 1;                     // rows {2wm, 2wm+1}, spin wn's column tiles
+    const int ncs_w = ((wn ? a.nb : a.na) + 15) >> 4;
+    d4_t SR[2][2], SI[2][2];                                     // running sum, this wave's tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d2_t v = (d2_t){0.0, 0.0};
+                if (j < ncs_w && t_ok(2 * wm + i, r)) v = *(const d2_t *)(Tf + t_addr(2 * wm + i, r, 2 * wn + j));
+                SR[i][j][r] = v[0]; SI[i][j][r] = v[1];
+            }
+    for (int n = 1; n <= a.order; ++n) {
+        d4_t P1[2][2], P2[2][2], P3[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0}; }
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned sl = next_chunk();
+            d2_t av[2][2], bv[2][2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[i][ss] = lds_read_c(sl + ((2 * wm + i) * 2 + ss) * 1024 + lane * 16);
+                    bv[i][ss] = lds_read_c(tf_l + ((c * 4 + 2 * wn + i) * 2 + ss) * 1024 + lane * 16);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j < ncs_w) {
+                            P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
+                            P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
+                            P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
+                        }
+        }
+        __builtin_amdgcn_s_barrier();                            // everyone finished reading T_{n-1}
+        const double inv_n = 1.0 / n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (j < ncs_w) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double re = (P1[i][j][r] - P2[i][j][r]) * inv_n;
+                        const double im = (P3[i][j][r] - P1[i][j][r] - P2[i][j][r]) * inv_n;
+                        SR[i][j][r] += re; SI[i][j][r] += im;
+                        // T_n (next right-hand operand); after the last term T holds the SUM instead
+                        const bool last = n == a.order;
+                        if (t_ok(2 * wm + i, r))
+                            *(d2_t *)(Tf + t_addr(2 * wm + i, r, 2 * wn + j)) =
+                                last ? (d2_t){SR[i][j][r], SI[i][j][r]} : (d2_t){re, im};
+                    }
+                }
+        __syncthreads();                                         // T_n visible
+    }
+    if (a.order == 0) __syncthreads();
+
+    one_body(0, true);
+    one_body(1, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int k_prop_fused_supported(afq_handle *h) {
+    return !h->no_fused && !h->vhs_diag && h->nv == 1 && h->M <= 104 && h->na <= 32 && h->nb <= 32 && h->nb > 0;
+}
+
+int k_prop_fused(afq_handle *h) {
+    PropFusedArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
+    a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
+    const int NCH = (h->M + 7) / 8;
+    const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        AFQ_HIP(h, hipFuncSetAttribute((const void *)prop_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(prop_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
