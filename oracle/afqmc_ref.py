@@ -223,6 +223,39 @@ def update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, dt):
     return trig
 
 
+def apply_bound_local_energy(eloc, eshift, ebound):
+    """propagation/continuous.py:216-230 (returns the complex eloc when inside the bounds,
+    a real number when clamped -- as the reference does)."""
+    if abs(eshift) < 1e-10:
+        return eloc, 0
+    es = complex(eshift).real
+    if eloc.real > es + ebound:
+        return es + ebound, 1
+    if eloc.real < es - ebound:
+        return es - ebound, 1
+    return eloc, 0
+
+
+def update_weight_local_energy(w, eloc, ovlp, ovlp_new, eshift, dt):
+    """propagation/continuous.py:294-318.  ``eloc`` is the local energy of the walker
+    BEFORE the step (walker.local_energy(system) uses the G of the Green's function
+    evaluated at the start of propagate_walker_phaseless)."""
+    ebound = (2.0 / dt) ** 0.5
+    ovlp_ratio = ovlp_new / ovlp
+    re_eloc, trig = apply_bound_local_energy(eloc, eshift, ebound)
+    magn = numpy.exp(-0.5 * dt * complex(re_eloc + w['eloc'] - eshift).real)
+    w['eloc'] = eloc
+    if not math.isinf(magn):
+        dtheta = cmath.phase(ovlp_ratio)
+        cosine_fac = max(0, math.cos(dtheta))
+        w['weight'] *= magn * cosine_fac
+        w['ot'] = ovlp_new
+    else:
+        w['ot'] = ovlp_new
+        w['weight'] = 0.0
+    return trig
+
+
 # --------------------------------------------------------------------------
 # Local energies
 # --------------------------------------------------------------------------
@@ -428,10 +461,33 @@ def new_walker(model, phi0, weight=1.0):
     phi = numpy.array(phi0, dtype=numpy.complex128, copy=True)
     ot = calc_overlap(phi, model.psi, model.na, model.nb)
     return dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
-                hybrid_energy=0.0, total_weight=0.0, detR=1.0)
+                hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0)
 
 
-def propagate_walker_phaseless(model, w, xi, eshift):
+def propagate_walker_free(model, w, xi, eshift):
+    """propagation/continuous.py:175-200 (no force bias)."""
+    na, nb = model.na, model.nb
+    kinetic_real(w['phi'], model.BH1, na)
+    xbar = numpy.zeros(model.nfields)
+    xs, cmf, cfb, ntrig = shift_fields(xi, xbar, model.mf_shift, model.sqrt_dt)
+    VHS = model.vhs(xs)
+    if VHS.ndim == 3:
+        apply_exponential(w['phi'][:, :na], VHS[0], model.exp_order)
+        apply_exponential(w['phi'][:, na:], VHS[1], model.exp_order)
+    else:
+        apply_exponential(w['phi'][:, :na], VHS, model.exp_order)
+        apply_exponential(w['phi'][:, na:], VHS, model.exp_order)
+    kinetic_real(w['phi'], model.BH1, na)
+    ovlp_new = calc_overlap(w['phi'], model.psi, na, nb)
+    (magn, dtheta) = cmath.polar(cmath.exp(cmf + model.dt * eshift))
+    w['weight'] *= magn
+    w['phase'] *= cmath.exp(1j * dtheta)
+    w['ot'] = ovlp_new
+    w['ovlp'] = ovlp_new
+    return 0, 0
+
+
+def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
     """propagation/continuous.py:232-262 with the two-body part of :113-173.
     ``xi`` is the real normal field vector the reference draws at :133.
     Returns (nfb_trig, nhe_trig)."""
@@ -451,7 +507,11 @@ def propagate_walker_phaseless(model, w, xi, eshift):
             apply_exponential(w['phi'][:, na:], VHS, model.exp_order)
     kinetic_real(w['phi'], model.BH1, na)
     ovlp_new = calc_overlap(w['phi'], model.psi, na, nb)
-    htrig = update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, model.dt)
+    if hybrid:
+        htrig = update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, model.dt)
+    else:
+        eloc = complex(model.local_energy(G, Ghalf)[0])
+        htrig = update_weight_local_energy(w, eloc, ovlp, ovlp_new, eshift, model.dt)
     return ntrig, htrig
 
 
@@ -480,8 +540,24 @@ def pop_control(model, walkers, target, r):
     return parent_ix
 
 
-def mixed_update(model, est, walkers, step, energy_eval_freq):
-    """estimators/mixed.py:180-225 (importance-sampling branch, le_oratio == 1)."""
+def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=False):
+    """estimators/mixed.py:180-225 (importance-sampling branch, le_oratio == 1) and
+    :151-175 (free projection: wfac = weight * ot * phase)."""
+    if free_projection:
+        for w in walkers:
+            wfac = w['weight'] * w['ot'] * w['phase']
+            if step % energy_eval_freq == 0:
+                _, Ghalf, G = greens_function(w['phi'], model.psi, model.na, model.nb)
+                E, T, V = model.local_energy(G, Ghalf)
+                est[EST['enumer']] += wfac * E
+                est[EST['e1b']] += wfac * T
+                est[EST['e2b']] += wfac * V
+                est[EST['edenom']] += wfac
+            est[EST['uweight']] += w['unscaled_weight']
+            est[EST['weight']] += wfac
+            est[EST['ehyb']] += wfac * w['hybrid_energy']
+            est[EST['ovlp']] += w['weight'] * abs(w['ot'])
+        return
     for w in walkers:
         if step % energy_eval_freq == 0:
             _, Ghalf, G = greens_function(w['phi'], model.psi, model.na, model.nb)
@@ -511,7 +587,7 @@ def block_reduce(est, nsteps):
 
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
-              record=None, verbose=False):
+              record=None, verbose=False, free_projection=False):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -535,7 +611,7 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
     eshift_pair = numpy.array([0, 0], dtype=numpy.complex128)
     eshift = 0
     # step-0 estimator pass (qmc/afqmc.py:214-221)
-    mixed_update(model, est, walkers, 0, energy_eval_freq)
+    mixed_update(model, est, walkers, 0, energy_eval_freq, free_projection)
     if verbose:
         gs, eshift_pair = block_reduce(est, 1)
         blocks.append(gs)
@@ -547,21 +623,30 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
                 w['detR'] = detR
                 w['ot'] = w['ot'] / detR
                 w['ovlp'] = w['ot']
+                if free_projection:                    # walkers/handler.py:178-181
+                    (magn, dtheta) = cmath.polar(detR)
+                    w['weight'] *= magn
+                    w['phase'] *= cmath.exp(1j * dtheta)
         for iw, w in enumerate(walkers):
             if abs(w['weight']) > 1e-8:
-                propagate_walker_phaseless(model, w, xi_source(step, iw), eshift)
+                if free_projection:
+                    propagate_walker_free(model, w, xi_source(step, iw), eshift)
+                else:
+                    propagate_walker_phaseless(model, w, xi_source(step, iw), eshift, hybrid)
             if (abs(w['weight']) > w['total_weight'] * 0.10) and step > 1:
                 w['weight'] = w['total_weight'] * 0.10
         parent_ix = None
         if step % npop_control == 0:
             parent_ix = pop_control(model, walkers, ntot, r_source(step))
-        mixed_update(model, est, walkers, step, energy_eval_freq)
+        mixed_update(model, est, walkers, step, energy_eval_freq, free_projection)
         if record is not None:
             record.append(dict(
                 weight=numpy.array([w['weight'] for w in walkers]),
                 unscaled_weight=numpy.array([w['unscaled_weight'] for w in walkers]),
                 ot=numpy.array([w['ot'] for w in walkers]),
                 hybrid_energy=numpy.array([w['hybrid_energy'] for w in walkers]),
+                phase=numpy.array([w['phase'] for w in walkers]),
+                eloc=numpy.array([w['eloc'] for w in walkers]),
                 parent_ix=None if parent_ix is None else parent_ix.copy()))
         if step % nsteps == 0:
             gs, eshift_pair = block_reduce(est, nsteps)

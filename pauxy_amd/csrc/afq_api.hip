@@ -280,8 +280,6 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
                        int flags) {
     if (!h || !BH1 || !mf_shift || dt <= 0 || exp_order < 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the propagator");
-    if (!(flags & AFQ_PROP_HYBRID) && !(flags & AFQ_PROP_FREE_PROJECTION))
-        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "local-energy weight update (hybrid=False) is not implemented");
     hipSetDevice(h->device);
     int rc;
     if ((rc = dev_upload(h, &h->BH1, BH1, (size_t)2 * h->M * h->M))) return rc;
@@ -481,6 +479,8 @@ static int build_vhs(afq_handle *h) {
     return k_vhs_ueg(h);
 }
 
+static int local_energy(afq_handle *h);
+
 static int apply_exp(afq_handle *h, const cplx *vhs) {
     if (h->vhs_diag) return k_apply_exponential_diag(h, vhs);
     return k_apply_exponential(h, vhs);
@@ -500,9 +500,15 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
         PhaseTimer t(h, T_GREENS);                         // continuous.py:245
         if ((rc = k_greens(h, h->ovlp_old))) return rc;
-        if (h->kind == AFQ_SYS_UEG && (h->flags & AFQ_PROP_FORCE_BIAS)) {
+        const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
+        if (h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) {
             if ((rc = ensure_G(h))) return rc;
             if ((rc = k_full_G(h))) return rc;
+        }
+        if (le) {
+            // walker.local_energy(system) of the un-propagated walker (continuous.py:296)
+            PhaseTimer te(h, T_ENERGY);
+            if ((rc = local_energy(h))) return rc;
         }
     }
     // The force bias reads Ghalf of the un-propagated walker, so building the HS potential commutes

@@ -581,7 +581,8 @@ struct WeightArgs {
     const int *alive;
     const cplx *ovlp_old, *ovlp_new, *cmf, *cfb;
     double *weight;
-    cplx *ot, *ehyb, *phase;
+    cplx *ot, *ehyb, *phase, *eloc;
+    const cplx *energy;         // [nw, 3] local energy of the walker before the step (hybrid == false)
     unsigned long long *counters;
 };
 
@@ -600,6 +601,22 @@ __global__ void weight_kernel(WeightArgs a) {
         return;
     }
     const cplx ratio = cdiv(on, a.ovlp_old[w]);
+    if (!(a.flags & AFQ_PROP_HYBRID)) {
+        // local-energy weight update, propagation/continuous.py:294-318 (+ :216-230)
+        const cplx el = a.energy[3 * w];
+        double re = el.x;
+        const double ebound = sqrt(2.0 / a.dt);
+        if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {
+            if (re > a.eshift.x + ebound) { re = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
+            else if (re < a.eshift.x - ebound) { re = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
+        }
+        const double magn = exp(-0.5 * a.dt * (re + a.eloc[w].x - a.eshift.x));
+        a.eloc[w] = el;
+        a.ot[w] = on;
+        if (!isinf(magn)) a.weight[w] *= magn * fmax(0.0, cos(atan2(ratio.y, ratio.x)));
+        else a.weight[w] = 0.0;
+        return;
+    }
     const cplx lg = clog_(ratio);
     cplx eh = cmake(-(lg.x + a.cfb[w].x + a.cmf[w].x) / a.dt, -(lg.y + a.cfb[w].y + a.cmf[w].y) / a.dt);
     const double ebound = sqrt(2.0 / a.dt);
@@ -627,6 +644,7 @@ int k_update_weight(afq_handle *h, cplx eshift) {
     a.nw = h->nw; a.flags = h->flags; a.dt = h->dt; a.eshift = eshift; a.alive = h->alive;
     a.ovlp_old = h->ovlp_old; a.ovlp_new = h->ovlp_new; a.cmf = h->cmf; a.cfb = h->cfb;
     a.weight = h->weight; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase; a.counters = h->counters;
+    a.eloc = h->eloc; a.energy = h->energy;
     hipLaunchKernelGGL(weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
@@ -853,34 +871,53 @@ int k_comb(afq_handle *h, double r, double target) {
 
 // --------------------------------------------------------------------------
 // estimators/mixed.py:211-225: one workgroup, deterministic tree sums.
-__global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy, const double *weight,
+// estimators/mixed.py:151-175, 211-225: one workgroup, deterministic tree sums.
+__global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy, int fp, const double *weight,
                                                          const double *unscaled, const cplx *ot,
-                                                         const cplx *ehyb, const cplx *energy, cplx *est) {
+                                                         const cplx *ehyb, const cplx *phase, const cplx *energy,
+                                                         cplx *est) {
     __shared__ double red[8];
-    double uw = 0, wt = 0, ov = 0, ehr = 0, ehi = 0, en = 0, e1 = 0, e2 = 0;
+    // v[0]=uweight  v[1..2]=weight  v[3]=ovlp  v[4..5]=ehyb  v[6..7]=enumer  v[8..9]=e1b  v[10..11]=e2b
+    double v[12];
+    for (int k = 0; k < 12; ++k) v[k] = 0.0;
     for (int w = threadIdx.x; w < nw; w += NTHR) {
         const double x = weight[w];
-        uw += unscaled[w]; wt += x;
-        ov += x * hypot(ot[w].x, ot[w].y);
-        ehr += x * ehyb[w].x; ehi += x * ehyb[w].y;
-        if (have_energy) { en += x * energy[3 * w].x; e1 += x * energy[3 * w + 1].x; e2 += x * energy[3 * w + 2].x; }
-    }
-    uw = block_sum(uw, red); wt = block_sum(wt, red); ov = block_sum(ov, red);
-    ehr = block_sum(ehr, red); ehi = block_sum(ehi, red);
-    en = block_sum(en, red); e1 = block_sum(e1, red); e2 = block_sum(e2, red);
-    if (threadIdx.x == 0) {
-        est[AFQ_EST_UWEIGHT].x += uw; est[AFQ_EST_WEIGHT].x += wt; est[AFQ_EST_OVLP].x += ov;
-        est[AFQ_EST_EHYB].x += ehr; est[AFQ_EST_EHYB].y += ehi;
+        // importance sampling: wfac = weight (mixed.py:217-225); free projection: weight*ot*phase (:154)
+        cplx wf = cmake(x, 0.0);
+        if (fp) wf = cscale(cmul(ot[w], phase[w]), x);
+        v[0] += unscaled[w];
+        v[1] += wf.x; v[2] += wf.y;
+        v[3] += x * hypot(ot[w].x, ot[w].y);
+        const cplx eh = cmul(wf, ehyb[w]);
+        v[4] += eh.x; v[5] += eh.y;
         if (have_energy) {
-            est[AFQ_EST_ENUMER].x += en; est[AFQ_EST_E1B].x += e1; est[AFQ_EST_E2B].x += e2;
-            est[AFQ_EST_EDENOM].x += wt;
+            if (fp) {
+                const cplx e0 = cmul(wf, energy[3 * w]), e1 = cmul(wf, energy[3 * w + 1]), e2 = cmul(wf, energy[3 * w + 2]);
+                v[6] += e0.x; v[7] += e0.y; v[8] += e1.x; v[9] += e1.y; v[10] += e2.x; v[11] += e2.y;
+            } else {
+                v[6] += x * energy[3 * w].x; v[8] += x * energy[3 * w + 1].x; v[10] += x * energy[3 * w + 2].x;
+            }
+        }
+    }
+    for (int k = 0; k < 12; ++k) v[k] = block_sum(v[k], red);
+    if (threadIdx.x == 0) {
+        est[AFQ_EST_UWEIGHT].x += v[0];
+        est[AFQ_EST_WEIGHT].x += v[1]; est[AFQ_EST_WEIGHT].y += v[2];
+        est[AFQ_EST_OVLP].x += v[3];
+        est[AFQ_EST_EHYB].x += v[4]; est[AFQ_EST_EHYB].y += v[5];
+        if (have_energy) {
+            est[AFQ_EST_ENUMER].x += v[6]; est[AFQ_EST_ENUMER].y += v[7];
+            est[AFQ_EST_E1B].x += v[8]; est[AFQ_EST_E1B].y += v[9];
+            est[AFQ_EST_E2B].x += v[10]; est[AFQ_EST_E2B].y += v[11];
+            est[AFQ_EST_EDENOM].x += v[1]; est[AFQ_EST_EDENOM].y += v[2];
         }
     }
 }
 
 int k_estimates(afq_handle *h, int have_energy) {
-    hipLaunchKernelGGL(estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, h->weight,
-                       h->unscaled, h->ot, h->ehyb, h->energy, h->estimates);
+    const int fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
+    hipLaunchKernelGGL(estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, fp, h->weight,
+                       h->unscaled, h->ot, h->ehyb, h->phase, h->energy, h->estimates);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }

@@ -48,9 +48,9 @@ class Mixed(object):
         self.root = root
 
     def update(self, system, qmc, trial, psi, step, free_projection=False):
-        """mixed.py:133-233, importance-sampling branch (:210-225)."""
-        if free_projection:
-            raise NotImplementedError("free-projection estimators (mixed.py:151-175) are not on the device path yet")
+        """mixed.py:133-233: importance-sampling branch (:210-225) or, when the propagator was
+        built with free_projection, the complex wfac = weight*ot*phase accumulation of :151-175
+        (the device handle knows which from afq_set_propagator)."""
         psi._end_sweep()
         psi._flush()
         dev = psi.dev

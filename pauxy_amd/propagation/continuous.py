@@ -122,7 +122,7 @@ class Continuous(object):
                 xi[iw] = numpy.random.normal(0.0, 1.0, dev.K)         # continuous.py:133
         dev.propagate(xi, eshift)
         psi.phi_version += 1
-        psi._invalidate('weight', 'ot', 'hybrid_energy', 'phase')
+        psi._invalidate('weight', 'ot', 'hybrid_energy', 'phase', 'eloc')
 
     def _propagate_walker(self, walker, system, trial, eshift):
         if walker._pending:

@@ -378,7 +378,7 @@ def record_trajectory(afqmc, comm, out):
     nsteps = afqmc.qmc.total_steps
     xi = numpy.full((nsteps + 1, nw, K), numpy.nan)
     rr = numpy.full(nsteps + 1, numpy.nan)
-    traj = dict(weight=[], unscaled_weight=[], ot=[], ehyb=[], parent_ix=[])
+    traj = dict(weight=[], unscaled_weight=[], ot=[], ehyb=[], parent_ix=[], phase=[], eloc=[])
     state = dict(step=0, iw=0)
     out['phi0'] = numpy.array([w.phi for w in psi.walkers])
     _normal, _random = numpy.random.normal, numpy.random.random
@@ -407,6 +407,8 @@ def record_trajectory(afqmc, comm, out):
         traj['unscaled_weight'].append([w.unscaled_weight for w in psi_.walkers])
         traj['ot'].append([w.ot for w in psi_.walkers])
         traj['ehyb'].append([w.hybrid_energy for w in psi_.walkers])
+        traj['phase'].append([w.phase for w in psi_.walkers])
+        traj['eloc'].append([w.eloc for w in psi_.walkers])
         state['step'] = step + 1
         return est_update(system, qmc, trial, psi_, step, fp)
 
@@ -428,6 +430,8 @@ def record_trajectory(afqmc, comm, out):
     out['unscaled_weight'] = numpy.array(traj['unscaled_weight'], dtype=numpy.float64)
     out['ot'] = numpy.array(traj['ot'], dtype=numpy.complex128)
     out['ehyb'] = numpy.array(traj['ehyb'], dtype=numpy.complex128)
+    out['phase'] = numpy.array(traj['phase'], dtype=numpy.complex128)
+    out['eloc'] = numpy.array(traj['eloc'], dtype=numpy.complex128)
     out['parent_ix'] = numpy.array(pix, dtype=numpy.int32).reshape(len(pix), -1)
     store = h5py._STORE[afqmc.estimators.filename]
     keys = sorted(k for k in store if k.startswith('basic/energies/'))
@@ -446,7 +450,7 @@ def record_trajectory(afqmc, comm, out):
     out['nhe_trig'] = prop.nhe_trig
     # final-state estimator pass the reference's driver tests pin
     mixed = afqmc.estimators.estimators['mixed']
-    mixed.update(afqmc.system, afqmc.qmc, afqmc.trial, afqmc.psi, 0)
+    mixed.update(afqmc.system, afqmc.qmc, afqmc.trial, afqmc.psi, 0, prop.free_projection)
     out['final_estimates'] = mixed.estimates.copy()
     out['final_phi'] = numpy.array([w.phi for w in psi.walkers])
 
@@ -475,7 +479,7 @@ def make_traj_generic():
     numpy.savez_compressed(os.path.join(HERE, 'traj_generic.npz'), **out)
 
 
-def make_traj_hubbard(name, nup, pin=None, nwalkers=10, npop=1, blocks=10):
+def make_traj_hubbard(name, nup, pin=None, nwalkers=10, npop=1, blocks=10, prop_extra=None):
     # qmc/tests/test_afqmc.py:145-188 (continuous HS, UHF trial)
     out = {}
     options = {'verbosity': 0, 'get_sha1': False,
@@ -485,8 +489,12 @@ def make_traj_hubbard(name, nup, pin=None, nwalkers=10, npop=1, blocks=10):
                'trial': {'name': 'UHF'},
                'estimates': {'mixed': {'energy_eval_freq': 1}},
                'propagator': {'hubbard_stratonovich': 'continuous'}}
+    if prop_extra:
+        options['propagator'].update(prop_extra)
     comm = MPI.COMM_WORLD
     afqmc = AFQMC(comm=comm, options=options)
+    out['free_projection'] = bool(afqmc.propagators.free_projection)
+    out['hybrid'] = bool(afqmc.propagators.hybrid)
     out['T'] = afqmc.system.T
     out['U'] = afqmc.system.U
     record_trajectory(afqmc, comm, out)
@@ -523,6 +531,12 @@ if __name__ == '__main__':
     # BASELINE configs[0]: 4x4 U=4 half filling, 10 walkers, comb every 5 steps
     make_traj_hubbard('traj_hubbard_c1.npz', 8, nwalkers=10, npop=5, blocks=10)
     make_traj_ueg()
+    # free projection (propagation/continuous.py:175-200, estimators/mixed.py:151-175) and the
+    # local-energy weight update (continuous.py:294-318), same 4x4 U=4 model
+    make_traj_hubbard('traj_hubbard_fp.npz', 8, nwalkers=10, npop=5, blocks=4,
+                      prop_extra={'free_projection': True})
+    make_traj_hubbard('traj_hubbard_le.npz', 8, nwalkers=10, npop=5, blocks=4,
+                      prop_extra={'hybrid': False})
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -55,13 +55,15 @@ def replay(d, system, trial, prop_opts, monkeypatch):
     rp = Replay(d)
     monkeypatch.setattr(numpy.random, 'normal', rp.normal)
     monkeypatch.setattr(numpy.random, 'random', rp.random)
-    rec = dict(weight=[], unscaled=[], ot=[], ehyb=[], pix=[])
+    rec = dict(weight=[], unscaled=[], ot=[], ehyb=[], pix=[], phase=[], eloc=[])
 
     def on_step(step, psi):
         rec['weight'].append(psi._mirror('weight').copy())
         rec['unscaled'].append(psi._mirror('unscaled_weight').copy())
         rec['ot'].append(psi._mirror('ot').copy())
         rec['ehyb'].append(psi._mirror('hybrid_energy').copy())
+        rec['phase'].append(psi._mirror('phase').copy())
+        rec['eloc'].append(psi._mirror('eloc').copy())
         if step % afqmc.qmc.npop_control == 0:
             rec['pix'].append(psi.last_parent_ix.copy())
 
@@ -70,13 +72,16 @@ def replay(d, system, trial, prop_opts, monkeypatch):
     close(numpy.array(rec['unscaled']), d['unscaled_weight'])
     close(numpy.array(rec['ot']), d['ot'])
     close(numpy.array(rec['ehyb']), d['ehyb'])
+    if 'phase' in d:
+        close(numpy.array(rec['phase']), d['phase'])
+        close(numpy.array(rec['eloc']), d['eloc'])
     assert numpy.array_equal(numpy.array(rec['pix']), d['parent_ix'])
     mixed = afqmc.estimators.estimators['mixed']
     blocks = numpy.array(mixed.blocks)
     close(blocks[:, 1:10], d['blocks'][:, 1:10])
     close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'])
     # the final estimator pass the reference's driver tests pin
-    mixed.update(system, afqmc.qmc, trial, afqmc.psi, 0)
+    mixed.update(system, afqmc.qmc, trial, afqmc.psi, 0, afqmc.propagators.free_projection)
     close(mixed.estimates[:9], d['final_estimates'][:9])
     assert afqmc.propagators.nfb_trig == int(d['nfb_trig'])
     assert afqmc.propagators.nhe_trig == int(d['nhe_trig'])
@@ -109,6 +114,22 @@ def test_traj_hubbard_c1(golden, monkeypatch):
     s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
     t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
     replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch)
+
+
+def test_traj_hubbard_free_projection(golden, monkeypatch):
+    """propagation/continuous.py:175-200, walkers/handler.py:178-181, estimators/mixed.py:151-175."""
+    d = golden('traj_hubbard_fp.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    replay(d, s, t, {'hubbard_stratonovich': 'continuous', 'free_projection': True}, monkeypatch)
+
+
+def test_traj_hubbard_local_energy_weights(golden, monkeypatch):
+    """propagation/continuous.py:294-318 (hybrid: False)."""
+    d = golden('traj_hubbard_le.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    replay(d, s, t, {'hubbard_stratonovich': 'continuous', 'hybrid': False}, monkeypatch)
 
 
 def test_traj_ueg(golden, monkeypatch):

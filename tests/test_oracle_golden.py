@@ -113,7 +113,7 @@ def test_ueg_ops(golden):
     assert numpy.linalg.norm(vhs) == pytest.approx(0.1467322554815581, rel=1e-11)
 
 
-def run_traj(d, model):
+def run_traj(d, model, **kw):
     nw = d['phi0'].shape[0]
     walkers = [ref.new_walker(model, d['phi0'][i]) for i in range(nw)]
     xi, r = d['xi'], d['r']
@@ -127,12 +127,16 @@ def run_traj(d, model):
     blocks = ref.run_afqmc(model, walkers, xi_source, lambda step: r[step - 1],
                            int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
                            npop_control=int(d['npop_control']),
-                           energy_eval_freq=int(d['energy_eval_freq']), record=rec)
+                           energy_eval_freq=int(d['energy_eval_freq']), record=rec, **kw)
     return walkers, rec, blocks
 
 
-def check_traj(d, model, tol=1e-8):
-    walkers, rec, blocks = run_traj(d, model)
+def check_traj(d, model, tol=1e-8, **kw):
+    walkers, rec, blocks = run_traj(d, model, **kw)
+    fp = kw.get('free_projection', False)
+    if 'phase' in d:
+        close(numpy.array([x['phase'] for x in rec]), d['phase'], tol)
+        close(numpy.array([x['eloc'] for x in rec]), d['eloc'], tol)
     W = numpy.array([x['weight'] for x in rec])
     close(W, d['weight'], tol)
     close(numpy.array([x['unscaled_weight'] for x in rec]), d['unscaled_weight'], tol)
@@ -146,7 +150,7 @@ def check_traj(d, model, tol=1e-8):
     close(numpy.array([w['phi'] for w in walkers]), d['final_phi'], tol)
     # final estimator pass pinned by the reference's driver tests
     est = numpy.zeros(10, dtype=numpy.complex128)
-    ref.mixed_update(model, est, walkers, 0, 1)
+    ref.mixed_update(model, est, walkers, 0, 1, fp)
     close(est[:9], d['final_estimates'][:9], tol)
     return est
 
@@ -169,6 +173,20 @@ def test_traj_hubbard_c1(golden):
     d = golden('traj_hubbard_c1.npz')
     check_traj(d, hubbard_model(d, '', 'hubbard'))
     assert d['parent_ix'].shape[0] == 20           # comb every 5 steps
+
+
+def test_traj_hubbard_free_projection(golden):
+    """propagation/continuous.py:175-200 + estimators/mixed.py:151-175."""
+    d = golden('traj_hubbard_fp.npz')
+    assert bool(d['free_projection'])
+    check_traj(d, hubbard_model(d, '', 'hubbard'), free_projection=True)
+
+
+def test_traj_hubbard_local_energy_weights(golden):
+    """propagation/continuous.py:294-318 (hybrid: False)."""
+    d = golden('traj_hubbard_le.npz')
+    assert not bool(d['hybrid'])
+    check_traj(d, hubbard_model(d, '', 'hubbard'), hybrid=False)
 
 
 def test_traj_ueg(golden):
