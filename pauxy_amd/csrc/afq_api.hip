@@ -47,6 +47,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ghalf); dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias); dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
+    dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
     dev_free(h->alive); dev_free(h->parent_ix);
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }
@@ -129,7 +130,7 @@ int afq_destroy(afq_handle *h) {
     hipStreamSynchronize(h->stream);
     free_walkers(h);
     free_system(h);
-    dev_free(h->psi); dev_free(h->BH1); dev_free(h->mf_shift);
+    dev_free(h->psi); dev_free(h->psic); dev_free(h->BH1); dev_free(h->mf_shift);
     dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
     if (h->zero_page) hipFree(h->zero_page);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
@@ -272,6 +273,11 @@ int afq_set_trial(afq_handle *h, const double *psi) {
     int rc = dev_upload(h, &h->psi, psi, n);
     if (rc) return rc;
     cache_of(h)->psi.assign(psi, psi + 2 * n);
+    {
+        std::vector<double> pc(psi, psi + 2 * n);
+        for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
+        if ((rc = dev_upload(h, &h->psic, pc.data(), n))) return rc;
+    }
     h->have_trial = true;
     return maybe_build_rH1(h);
 }

@@ -71,6 +71,7 @@ struct afq_handle {
     // ---- trial
     bool have_trial = false;
     cplx *psi = nullptr;            // [M, nt]
+    cplx *psic = nullptr;           // conj(psi) [M, nt] (B operand of the overlap GEMM)
 
     // ---- propagator
     bool have_prop = false;
@@ -98,7 +99,11 @@ struct afq_handle {
     cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
     cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
     cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag
-    cplx *lu_ws = nullptr;          // [nw, 2, N, N] workspace for large N
+    cplx *lu_ws = nullptr;          // [nw, N, N] workspace of the generic Green's kernel (N > 128)
+    cplx *big_ws = nullptr;         // [2 nw, N, N] overlap matrices / inverses (k_bigdet.hip)
+    cplx *big_ws2 = nullptr;        // [2 nw, N, N] second workspace (Cholesky-QR)
+    cplx *detm = nullptr;           // [2 nw] determinant mantissas
+    int *dete = nullptr;            // [2 nw] determinant exponents
     cplx *energy = nullptr;         // [nw, 3]
     cplx *exx_part = nullptr;       // exchange partial sums
     int64_t exx_part_len = 0;
@@ -162,6 +167,9 @@ int k_full_G(afq_handle *h);                                // G = conj(psi) gha
 // k_fused.hip
 int k_prop_fused_supported(afq_handle *h);
 int k_prop_fused(afq_handle *h);                           // phi <- B exp(V) B phi for live walkers, in place
+// k_bigdet.hip
+int k_greens_big_supported(afq_handle *h);
+int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det);   // ghalf may be null (overlap only)
 // k_small.hip
 int k_alive(afq_handle *h);
 int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det

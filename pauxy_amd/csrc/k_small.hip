@@ -399,6 +399,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) 
     a.phi = h->phi; a.psi = h->psi; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
+    if (k_greens_big_supported(h)) return k_greens_big(h, ghalf, det);
     if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
         static const int dbg = getenv("AFQ_GREENS_DBG") ? atoi(getenv("AFQ_GREENS_DBG")) : 0;

@@ -131,5 +131,16 @@ def test_c4_hubbard_16x16():
     run_fullsize(hubbard_c4(), 32, [0, 31])
 
 
+def test_hubbard_large_n_ragged():
+    """45 < N <= 128 with na != nb and no dimension a multiple of 16: the GEMM + register-resident
+    Gauss-Jordan Green's function (k_bigdet.hip), every walker against the oracle."""
+    s = systems.Hubbard(9, 8, 50, 47, 4.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    dt = 0.01
+    BH1, mf = setup.hubbard_propagator_arrays(s, t, dt, True)
+    model = ref.RefModel('hubbard', 72, 50, 47, t.psi, BH1, mf, dt, U=4.0, H1=s.T.astype(complex))
+    run_fullsize(model, 11, list(range(11)))
+
+
 def test_c2_ueg_93_planewaves():
     run_fullsize(ueg_c2(), 64, [0, 63])
