@@ -47,7 +47,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ghalf); dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias); dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
-    dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete);
+    dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
     dev_free(h->alive); dev_free(h->parent_ix);
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }

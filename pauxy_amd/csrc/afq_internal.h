@@ -104,6 +104,8 @@ struct afq_handle {
     cplx *big_ws2 = nullptr;        // [2 nw, N, N] second workspace (Cholesky-QR)
     cplx *detm = nullptr;           // [2 nw] determinant mantissas
     int *dete = nullptr;            // [2 nw] determinant exponents
+    double *qr_logd = nullptr;      // [2, 2 nw] log det R per Cholesky-QR pass
+    int *qr_fail = nullptr;         // [nw] Cholesky breakdown -> Gram-Schmidt fallback
     cplx *energy = nullptr;         // [nw, 3]
     cplx *exx_part = nullptr;       // exchange partial sums
     int64_t exx_part_len = 0;
@@ -170,6 +172,7 @@ int k_prop_fused(afq_handle *h);                           // phi <- B exp(V) B 
 // k_bigdet.hip
 int k_greens_big_supported(afq_handle *h);
 int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det);   // ghalf may be null (overlap only)
+int k_reortho_big(afq_handle *h);                           // Cholesky-QR2; sets qr_fail for breakdowns
 // k_small.hip
 int k_alive(afq_handle *h);
 int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det

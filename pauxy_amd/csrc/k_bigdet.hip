@@ -308,3 +308,224 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
     }
     return AFQ_OK;
 }
+
+// ==========================================================================================
+// Re-orthogonalisation for large N by Cholesky-QR2 (walkers/single_det.py:225-254: economic QR
+// with the sign convention diag(R) > 0, which is exactly the R of the Cholesky factorisation of
+// phi^H phi).  Two passes of
+//     S = X^H X  (GEMM)      S = R^H R,  T = R^-1  (register-resident kernel)      X <- X T  (GEMM)
+// with X = phi_s then Q_1; det R = prod sqrt(D) over both passes.  One pass loses orthogonality
+// like eps cond(phi)^2, the second pass restores it to eps as long as cond(phi) < ~1e7; a
+// non-positive pivot flags the walker and the Gram-Schmidt kernel (k_small.hip) redoes it.
+struct GramProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true, A_CONJ = true;
+    int batch, rows, cols, kdim;     // 2 nw, nmax, nmax, M
+    int nt, na, nb, ld;
+    const cplx *x;                   // [nw, M, nt]
+    cplx *S;                         // [2 nw, ld * ld]
+    const cplx *zero;
+    __device__ bool active(int) const { return true; }
+    __device__ cplx loadA(int, int, int) const { return cmake(0, 0); }
+    __device__ cplx loadB(int, int, int) const { return cmake(0, 0); }
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return row < ns ? x + ((long)(b >> 1) * kdim + k) * nt + (s ? na : 0) + row : zero;
+    }
+    __device__ const cplx *ptrB(int b, int k, int col) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return col < ns ? x + ((long)(b >> 1) * kdim + k) * nt + (s ? na : 0) + col : zero;
+    }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        S[(long)b * ld * ld + (long)row * ld + col] = cmake(re, im);
+    }
+};
+
+struct QProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true;
+    int batch, rows, cols, kdim;     // 2 nw, M, nmax, nmax
+    int nt, na, nb, ld;
+    const cplx *x;                   // [nw, M, nt]
+    const cplx *Tt;                  // [2 nw, ld * ld]: Tt[c][j] = T[j][c]
+    cplx *out;                       // [nw, M, nt]
+    const int *fail;                 // walkers flagged by the Cholesky kernel are left alone
+    const cplx *zero;
+    __device__ bool active(int b) const { return fail[b >> 1] == 0; }
+    __device__ cplx loadA(int, int, int) const { return cmake(0, 0); }
+    __device__ cplx loadB(int, int, int) const { return cmake(0, 0); }
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return k < ns ? x + ((long)(b >> 1) * rows + row) * nt + (s ? na : 0) + k : zero;
+    }
+    __device__ const cplx *ptrB(int b, int k, int col) const {
+        const int ns = (b & 1) ? nb : na;
+        return (k < ns && col < ns) ? Tt + (long)b * ld * ld + (long)col * ld + k : zero;
+    }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        const int s = b & 1, ns = s ? nb : na;
+        if (col < ns) out[((long)(b >> 1) * rows + row) * nt + (s ? na : 0) + col] = cmake(re, im);
+    }
+};
+
+struct CholArgs {
+    int na, nb, ld;
+    const cplx *S;                   // [2 nw, ld * ld] Hermitian positive definite
+    cplx *Tt;                        // [2 nw, ld * ld] transposed inverse Cholesky factor
+    double *logd;                    // [2 nw] log det R of this pass
+    int *fail;                       // [nw]
+};
+
+// Forward elimination of [S | I] in place without pivoting (same thread <-> element map and
+// register residency as gj_big_kernel; one barrier per step because the pivot is known):
+// after step k the slots (i > k, k) hold -m_i = column k of the unit-lower inverse factor, so at the
+// end v[i][j] (j < i) = Ltilde^-1[i][j] with S = Ltilde D Ltilde^H, and
+//     T = R^-1 = Ltilde^-H D^-1/2,   Tt[i][j] = T[j][i] = conj(v[i][j]) / sqrt(D_i).
+__global__ __launch_bounds__(512) void chol_linv_kernel(CholArgs a) {
+    __shared__ cplx colk[2][GJ_N], rowk[2][GJ_N];
+    __shared__ double piv[GJ_N];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (b & 1) ? a.nb : a.na;
+    const cplx *S = a.S + (long)b * a.ld * a.ld;
+    cplx *Tt = a.Tt + (long)b * a.ld * a.ld;
+    const int tr = tid >> 5, tc = tid & 31;
+    double vr[8][4], vi[8][4];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int i = tr + 16 * x, j = tc + 32 * y;
+            const cplx t = (i < n && j < n) ? S[(long)i * a.ld + j] : cmake(0.0, 0.0);
+            vr[x][y] = t.x; vi[x][y] = t.y;
+        }
+    if (tid < GJ_N) piv[tid] = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int y0 = 0; y0 < 4; ++y0) {
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 32 * y0 + kk;
+            if (k >= n) break;
+            const int buf = k & 1;
+            if (tc == kk) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) colk[buf][tr + 16 * x] = cmake(vr[x][y0], vi[x][y0]);
+            }
+            if (wave == ((k & 15) >> 1)) {
+                const int x0 = k >> 4;
+                const bool mine = tr == (k & 15);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    if (x0 == x) {
+                        if (mine) {
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) {
+                                const int j = tc + 32 * y;
+                                rowk[buf][j] = (j == k) ? cmake(1.0, 0.0) : cmake(vr[x][y], vi[x][y]);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const double d = colk[buf][k].x;
+            bad = bad || !(d > 0.0);
+            const double dinv = 1.0 / d;
+            if (tid == 0) piv[k] = d;
+            double rkx[4], rky[4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { const cplx t = rowk[buf][tc + 32 * y]; rkx[y] = t.x; rky[y] = t.y; }
+            if (tc == kk) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { vr[x][y0] = 0.0; vi[x][y0] = 0.0; }
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int i = tr + 16 * x;
+                const cplx c = colk[buf][i];
+                const double fx = i > k ? c.x * dinv : 0.0, fy = i > k ? c.y * dinv : 0.0;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    double ox = vr[x][y], oy = vi[x][y];
+                    ox = fma(-fx, rkx[y], ox); ox = fma(fy, rky[y], ox);
+                    oy = fma(-fx, rky[y], oy); oy = fma(-fy, rkx[y], oy);
+                    vr[x][y] = ox; vi[x][y] = oy;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        const int i = tr + 16 * x;
+        if (i >= n) continue;
+        const double rs = 1.0 / sqrt(piv[i]);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int j = tc + 32 * y;
+            if (j >= n) continue;
+            cplx t = cmake(0.0, 0.0);
+            if (j < i) t = cmake(vr[x][y] * rs, -vi[x][y] * rs);
+            else if (j == i) t = cmake(rs, 0.0);
+            Tt[(long)i * a.ld + j] = t;
+        }
+    }
+    if (wave == 0) {
+        double l = log(piv[lane]) + log(piv[lane + 64]);
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o);
+        if (lane == 0) {
+            a.logd[b] = 0.5 * l;
+            if (bad) a.fail[b >> 1] = 1;
+        }
+    }
+}
+
+__global__ void qr_finish_kernel(const double *logd, const int *fail, double *detR, cplx *ot, double *weight,
+                                 int nw, int free_projection) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw || fail[w]) return;
+    const double d = exp(logd[2 * w] + logd[2 * w + 1] + logd[2 * nw + 2 * w] + logd[2 * nw + 2 * w + 1]);
+    detR[w] = d;
+    ot[w] = cmake(ot[w].x / d, ot[w].y / d);             // single_det.py:253
+    if (free_projection) weight[w] *= d;                   // walkers/handler.py:178-181
+}
+
+int k_reortho_big(afq_handle *h) {
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    const int nb2 = 2 * h->nw;
+    const size_t wsn = (size_t)nb2 * nmax * nmax;
+    if (!h->big_ws) AFQ_HIP(h, hipMalloc(&h->big_ws, sizeof(cplx) * wsn));
+    if (!h->big_ws2) AFQ_HIP(h, hipMalloc(&h->big_ws2, sizeof(cplx) * wsn));
+    if (!h->qr_logd) {
+        AFQ_HIP(h, hipMalloc(&h->qr_logd, sizeof(double) * 2 * nb2));
+        AFQ_HIP(h, hipMalloc(&h->qr_fail, sizeof(int) * h->nw));
+    }
+    AFQ_HIP(h, hipMemsetAsync(h->qr_fail, 0, sizeof(int) * h->nw, h->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        const cplx *src = pass == 0 ? h->phi : h->phi_t;
+        cplx *dst = pass == 0 ? h->phi_t : h->phi;
+        {
+            GramProb p;
+            p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
+            p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
+            p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
+            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        }
+        {
+            CholArgs a;
+            a.na = h->na; a.nb = h->nb; a.ld = nmax;
+            a.S = h->big_ws; a.Tt = h->big_ws2; a.logd = h->qr_logd + (size_t)pass * nb2; a.fail = h->qr_fail;
+            hipLaunchKernelGGL(chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            AFQ_HIP(h, hipGetLastError());
+        }
+        {
+            QProb p;
+            p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
+            p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
+            p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
+            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        }
+    }
+    hipLaunchKernelGGL(qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,
+                       h->qr_fail, h->detR, h->ot, h->weight, h->nw, (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}

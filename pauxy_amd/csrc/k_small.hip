@@ -662,6 +662,7 @@ struct QrArgs {
     cplx *ws;           // global panel [nw, nmax, M] when it does not fit LDS
     double *detR, *weight;
     cplx *ot;
+    const int *only;    // when set: redo only the walkers flagged by the Cholesky-QR path
 };
 
 __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
     __shared__ cplx coef[256];
     __shared__ double red[8];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.only && !a.only[w]) return;
     const int M = a.M, nt = a.nt;
     cplx *phi = a.phi + (long)w * M * nt;
     const int nmax = a.na > a.nb ? a.na : a.nb;
@@ -734,7 +736,14 @@ int k_reortho(afq_handle *h) {
     QrArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.flags = h->flags;
     a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot;
+    a.only = nullptr;
     const int nmax = h->na > h->nb ? h->na : h->nb;
+    static const bool no_cholqr = getenv("AFQ_NO_CHOLQR") != nullptr;
+    if (k_greens_big_supported(h) && !no_cholqr) {
+        int rc = k_reortho_big(h);
+        if (rc) return rc;
+        a.only = h->qr_fail;
+    }
     const size_t need = sizeof(cplx) * (size_t)nmax * h->M;
     a.in_lds = need <= 64 * 1024;
     a.ws = h->phi_t2;       // scratch panel (nmax*M <= M*nt elements per walker)

@@ -26,6 +26,10 @@
 // K3M: complex x complex products by the 3-multiplication (Karatsuba) form
 //   P1 = Ar Br, P2 = Ai Bi, P3 = (Ar+Ai)(Br+Bi);  Cr = P1 - P2, Ci = P3 - P1 - P2
 // (3 real MFMAs per fragment pair instead of 4; error is bounded normwise, ~1e-16 |A||B|).
+// optional problem trait: static constexpr bool A_CONJ = true contracts with conj(A)
+template <class P, class = void> struct gemm_conj_a { static constexpr bool value = false; };
+template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static constexpr bool value = P::A_CONJ; };
+
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
     static_assert(P::A_CPLX, "A operand must be complex");
@@ -129,6 +133,12 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if (gemm_conj_a<P>::value) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[i][s][1] = -a[i][s][1];
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll

@@ -142,5 +142,36 @@ def test_hubbard_large_n_ragged():
     run_fullsize(model, 11, list(range(11)))
 
 
+def test_large_n_reortho_breakdown_fallback():
+    """Cholesky-QR2 breaks down on a numerically rank-deficient walker; the flagged walker must be
+    redone by the Gram-Schmidt kernel and the healthy walkers must be unaffected."""
+    s = systems.Hubbard(9, 8, 50, 47, 4.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    BH1, mf = setup.hubbard_propagator_arrays(s, t, 0.01, True)
+    model = ref.RefModel('hubbard', 72, 50, 47, t.psi, BH1, mf, 0.01, U=4.0, H1=s.T.astype(complex))
+    rng = numpy.random.RandomState(11)
+    nw = 5
+    dev = make_device(model, nw)
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, 72, 97) + 1j * rng.rand(nw, 72, 97))
+    phis[2][:, 7] = phis[2][:, 3] * (1.0 + 1e-9) + 1e-10 * rng.rand(72)     # cond ~ 1e9
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_OT, numpy.ones(nw, dtype=complex))
+    detR = dev.reortho()
+    q = dev.get(L.F_PHI)
+    assert numpy.all(numpy.isfinite(detR)) and numpy.all(numpy.isfinite(q.view(float)))
+    for w in range(nw):
+        for sl in (slice(0, 50), slice(50, 97)):
+            close(q[w][:, sl].conj().T @ q[w][:, sl], numpy.eye(sl.stop - sl.start), 1e-10)
+        if w != 2:
+            p = phis[w].copy()
+            d = ref.reortho(p, 50, 47)
+            close(q[w], p, 1e-9)
+            close(detR[w], d, 1e-9)
+    # span preserved for the repaired walker: Q Q^H phi = phi
+    qa = q[2][:, :50]
+    close(qa @ (qa.conj().T @ phis[2][:, :50]), phis[2][:, :50], 1e-9)
+    dev.close()
+
+
 def test_c2_ueg_93_planewaves():
     run_fullsize(ueg_c2(), 64, [0, 63])
