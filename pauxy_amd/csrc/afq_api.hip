@@ -120,6 +120,7 @@ int afq_create(int device_id, afq_handle **out) {
     hipMemset(h->zero_page, 0, 256);
     h->no_ring = getenv("AFQ_NO_RING") != nullptr;
     h->no_fused = getenv("AFQ_NO_FUSED") != nullptr;
+    h->greens_cache = getenv("AFQ_NO_GREENS_CACHE") == nullptr;
     *out = h;
     return AFQ_OK;
 }
@@ -167,6 +168,7 @@ static int set_dims(afq_handle *h, int kind, int M, int K, int na, int nb) {
 
 int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const double *hs_pot,
                            const double *rchol, const double *H1, double ecore) {
+    if (h) h->greens_valid = false;
     if (!h || !hs_pot || !rchol || !H1) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_GENERIC, M, K, na, nb);
     if (rc) return rc;
@@ -205,6 +207,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
 }
 
 int afq_set_system_hubbard(afq_handle *h, int M, int na, int nb, double U, const double *T) {
+    if (h) h->greens_valid = false;
     if (!h || !T) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_HUBBARD, M, M, na, nb);
     if (rc) return rc;
@@ -240,6 +243,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
                        const int64_t *kpq_i, const int64_t *kpq_kpq, const int64_t *pmq_off,
                        const int64_t *pmq_i, const int64_t *pmq_pmq, const double *vqvec, double vol,
                        const double *H1diag, double ecore) {
+    if (h) h->greens_valid = false;
     if (!h || !iA_colptr || !iB_colptr || !kpq_off || !pmq_off || !vqvec || !H1diag) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_UEG, M, 2 * nq, na, nb);
     if (rc) return rc;
@@ -266,6 +270,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
 }
 
 int afq_set_trial(afq_handle *h, const double *psi) {
+    if (h) h->greens_valid = false;
     if (!h || !psi) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the trial");
     hipSetDevice(h->device);
@@ -284,6 +289,7 @@ int afq_set_trial(afq_handle *h, const double *psi) {
 
 int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift, double dt, int exp_order,
                        int flags) {
+    if (h) h->greens_valid = false;
     if (!h || !BH1 || !mf_shift || dt <= 0 || exp_order < 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the propagator");
     hipSetDevice(h->device);
@@ -306,6 +312,7 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
 
 // ------------------------------------------------------------------ walkers
 int afq_walkers_alloc(afq_handle *h, int nw) {
+    if (h) h->greens_valid = false;
     if (!h || nw <= 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before allocating walkers");
     hipSetDevice(h->device);
@@ -385,6 +392,7 @@ static int field_info(afq_handle *h, int field, void **base, size_t *bytes) {
 }
 
 int afq_walkers_set(afq_handle *h, int field, const void *host, int first, int count) {
+    if (h && (field == AFQ_F_PHI || field == AFQ_F_GHALF)) h->greens_valid = false;
     if (!h || !host) return AFQ_EINVAL;
     if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
     if (first < 0 || count < 0 || first + count > h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker range out of bounds");
@@ -411,6 +419,7 @@ int afq_walkers_get(afq_handle *h, int field, void *host, int first, int count) 
 }
 
 int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *bytes_per_walker) {
+    if (h) { h->greens_valid = false; h->greens_cache = false; }   // the caller may write through the pointer
     if (!h || !dev_ptr) return AFQ_EINVAL;
     void *base; size_t bytes;
     int rc = field_info(h, field, &base, &bytes);
@@ -444,6 +453,7 @@ static int copy_out(afq_handle *h, void *host, const void *dev, size_t bytes) {
 }
 
 int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -459,6 +469,7 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
 }
 
 int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -505,7 +516,9 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     const bool fp = (h->flags & AFQ_PROP_FREE_PROJECTION) != 0;
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
         PhaseTimer t(h, T_GREENS);                         // continuous.py:245
-        if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        if (h->greens_valid) std::swap(h->ovlp_old, h->ovlp_new);   // computed at the end of the last step
+        else if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        h->greens_valid = false;
         const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
         if (h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) {
             if ((rc = ensure_G(h))) return rc;
@@ -536,13 +549,20 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     }
     {
         PhaseTimer t(h, T_OVLP);                                                    // :261-262
-        if ((rc = k_overlap(h, h->ovlp_new))) return rc;
+        // The overlap of the propagated walker is the determinant of the matrix whose inverse the next
+        // step's Green's function needs (continuous.py:245 of step n+1), so factorise once: this call
+        // leaves Ghalf of the NEW phi behind and the next afq_propagate / afq_estimates_update reuses it.
+        if (h->greens_cache && !fp) {
+            if ((rc = k_greens(h, h->ovlp_new))) return rc;
+            h->greens_valid = true;
+        } else if ((rc = k_overlap(h, h->ovlp_new))) return rc;
         if ((rc = k_update_weight(h, cmake(eshift_re, eshift_im)))) return rc;
     }
     return AFQ_OK;
 }
 
 int afq_reortho(afq_handle *h, double *detR_out) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -627,6 +647,7 @@ int afq_vhs(afq_handle *h, const double *xs, double *vhs_out) {
 }
 
 int afq_apply_exponential(afq_handle *h, const double *vhs) {
+    if (h) h->greens_valid = false;
     if (!h || !vhs) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -648,6 +669,7 @@ int afq_apply_exponential(afq_handle *h, const double *vhs) {
 }
 
 int afq_kinetic(afq_handle *h) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -666,6 +688,7 @@ int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
 
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *parent_ix,
                         double *total_weight_out) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -724,6 +747,7 @@ int afq_walker_pack(afq_handle *h, int iw, void *dev_buf) {
 }
 
 int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
+    if (h) h->greens_valid = false;
     if (!h || !dev_buf) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -732,6 +756,7 @@ int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
 }
 
 int afq_walkers_copy(afq_handle *h, int src, int dst) {
+    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -752,7 +777,7 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
     if (eval_energy) {
         {
             PhaseTimer t(h, T_GREENS);
-            if ((rc = k_greens(h, h->ovlp_old))) return rc;
+            if (!h->greens_valid && (rc = k_greens(h, h->ovlp_old))) return rc;
             if (h->kind == AFQ_SYS_UEG) {
                 if ((rc = ensure_G(h))) return rc;
                 if ((rc = k_full_G(h))) return rc;

@@ -120,6 +120,10 @@ struct afq_handle {
     double *scal = nullptr;         // [8] device scalars (total weight, ...)
     void *pack_tmp = nullptr;
     void *zero_page = nullptr;      // 256 zero bytes: source of out-of-range LDS-DMA loads
+    // Ghalf / ovlp_new describe the CURRENT phi of every walker (set by the end-of-step Green's
+    // function of afq_propagate, cleared by everything that writes phi, psi or Ghalf)
+    bool greens_valid = false;
+    bool greens_cache = true;       // AFQ_NO_GREENS_CACHE=1 or a handed-out device pointer turns it off
     bool no_fused = false;          // AFQ_NO_FUSED=1: separate one-body / Taylor launches (A/B runs)
     bool no_ring = false;           // AFQ_NO_RING=1: register-prefetch GEMM engine only (A/B runs)
 
