@@ -183,6 +183,18 @@ int afq_stream(afq_handle *h, void **stream);
 /* duration of the last afq_local_energy exchange kernel, HIP events on the
  * handle's stream (bench.py roofline)                                          */
 int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
+/* Per-launch durations of the hot kernels, HIP events recorded on the handle's
+ * stream around the launch (no host synchronisation until _get): bench.py's
+ * live roofline measurement over its timed region.  afq_kernel_trace(h, 1)
+ * clears and starts recording (up to 4096 launches per kind), (h, 0) stops.   */
+#define AFQ_K_PROPAGATOR 0   /* fused B exp(V) B kernel (k_fused.hip)          */
+#define AFQ_K_EXCHANGE 1     /* Cholesky exchange-energy kernel (k_energy.hip) */
+#define AFQ_K_VHS 2          /* HS potential GEMM                              */
+#define AFQ_K_FORCE_BIAS 3   /* force-bias GEMM                                */
+#define AFQ_K_GREENS 4       /* Green's function kernel (N <= 45 path)         */
+#define AFQ_K_COUNT 5
+int afq_kernel_trace(afq_handle *h, int on);
+int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int *n_out);
 
 #ifdef __cplusplus
 }

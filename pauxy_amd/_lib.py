@@ -65,6 +65,8 @@ SIGNATURES = {
     "afq_enable_timers": [_h, c_int],
     "afq_stream": [_h, POINTER(c_void_p)],
     "afq_last_energy_kernel_ms": [_h, POINTER(c_double)],
+    "afq_kernel_trace": [_h, c_int],
+    "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],
 }
 
 
@@ -105,3 +107,6 @@ def load(path=None):
     if path is None:
         _lib = lib
     return lib
+
+# afq_kernel_trace kinds (include/afqmc_hip.h AFQ_K_*)
+K_PROPAGATOR, K_EXCHANGE, K_VHS, K_FORCE_BIAS, K_GREENS = range(5)

@@ -136,6 +136,7 @@ int afq_destroy(afq_handle *h) {
     if (h->zero_page) hipFree(h->zero_page);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
+    for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
     hipStreamDestroy(h->stream);
     delete static_cast<afq_handle_full *>(h);
     return AFQ_OK;
@@ -825,6 +826,27 @@ int afq_enable_timers(afq_handle *h, int on) {
 int afq_timers(afq_handle *h, double *out_ms, int reset) {
     if (!h || !out_ms) return AFQ_EINVAL;
     for (int i = 0; i < T_COUNT; ++i) { out_ms[i] = h->t_ms[i]; if (reset) h->t_ms[i] = 0.0; }
+    return AFQ_OK;
+}
+
+int afq_kernel_trace(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    h->ktrace_on = on != 0;
+    if (on) for (int k = 0; k < AFQ_K_COUNT; ++k) h->ktrace_used[k] = 0;
+    return AFQ_OK;
+}
+
+int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int *n_out) {
+    if (!h || !n_out || kind < 0 || kind >= AFQ_K_COUNT || (max_n > 0 && !ms_out)) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    const int n = h->ktrace_used[kind] < max_n ? h->ktrace_used[kind] : max_n;
+    for (int i = 0; i < n; ++i) {
+        float f = 0;
+        AFQ_HIP(h, hipEventElapsedTime(&f, h->ktrace_ev[kind][2 * i], h->ktrace_ev[kind][2 * i + 1]));
+        ms_out[i] = f;
+    }
+    *n_out = h->ktrace_used[kind];
     return AFQ_OK;
 }
 

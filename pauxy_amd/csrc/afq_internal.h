@@ -113,6 +113,9 @@ struct afq_handle {
     size_t gfrag_bytes = 0;
     hipEvent_t ev_e0 = nullptr, ev_e1 = nullptr;   // brackets the exchange kernel
     bool energy_ev_valid = false;
+    bool ktrace_on = false;
+    std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
+    int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
     cplx *estimates = nullptr;      // [10]
     unsigned long long *counters = nullptr;   // [4]
     int *alive = nullptr;           // [nw]
@@ -160,6 +163,24 @@ struct PhaseTimer {
             float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1);
             h->t_ms[slot] += ms;
         }
+    }
+};
+
+// Brackets ONE kernel launch with a start/stop event pair on the handle's stream when
+// afq_kernel_trace is on; nothing is synchronised here (afq_kernel_trace_get reads the pairs).
+struct KernelTrace {
+    afq_handle *h; int kind, idx;
+    KernelTrace(afq_handle *h_, int k) : h(h_), kind(k), idx(-1) {
+        if (!h->ktrace_on || h->ktrace_used[k] >= 4096) return;
+        idx = h->ktrace_used[k];
+        std::vector<hipEvent_t> &ev = h->ktrace_ev[k];
+        while ((int)ev.size() < 2 * idx + 2) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
+        hipEventRecord(ev[2 * idx], h->stream);
+    }
+    ~KernelTrace() {
+        if (idx < 0) return;
+        hipEventRecord(h->ktrace_ev[kind][2 * idx + 1], h->stream);
+        h->ktrace_used[kind] = idx + 1;
     }
 };
 

@@ -559,12 +559,15 @@ int k_energy_generic(afq_handle *h) {
     a.afrag_im[0] = h->rchol_frag_im[0]; a.afrag_im[1] = h->rchol_frag_im[1];
     a.gfrag = h->gfrag; a.part = h->exx_part;
     AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
+    {
+    KernelTrace kt(h, AFQ_K_EXCHANGE);
     const long per_xcd = 2L * nxt * ((nwt + 7) / 8) * EXX_CHUNKS;
     const unsigned nblk = (unsigned)(8 * ((per_xcd + 3) / 4));
     if (h->rchol_real)
         hipLaunchKernelGGL(exx_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, a);
     else
         hipLaunchKernelGGL(exx_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, a);
+    }
     AFQ_HIP(h, hipGetLastError());
     AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
     h->energy_ev_valid = true;

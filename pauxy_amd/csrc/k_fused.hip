@@ -242,6 +242,7 @@ int k_prop_fused(afq_handle *h) {
                                        (int)lds));
         lds_set = lds;
     }
+    KernelTrace kt(h, AFQ_K_PROPAGATOR);
     hipLaunchKernelGGL(prop_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;

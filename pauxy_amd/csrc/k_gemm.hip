@@ -161,7 +161,10 @@ int k_force_bias_generic(afq_handle *h) {
         if (h->nw > 32 && !h->no_ring) {
             // work-group tile 64 walkers x 64 fields, operands shared through the LDS ring
             static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 1;
-            if (cfg == 1) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            if (cfg == 1) {
+                KernelTrace kt(h, AFQ_K_FORCE_BIAS);
+                AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            }
             else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
@@ -211,7 +214,10 @@ int k_vhs_generic(afq_handle *h) {
         else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 4) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else {
+            KernelTrace kt(h, AFQ_K_VHS);
+            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        }
         return AFQ_OK;
     }
     static const TileChoice cand[] = {{2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 2}};

@@ -414,6 +414,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) 
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 lds_set[1] = lds;
             }
+            KernelTrace kt(h, AFQ_K_GREENS);
             hipLaunchKernelGGL(greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
         } else {
             if (lds > lds_set[0]) {

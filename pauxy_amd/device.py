@@ -264,6 +264,17 @@ class AfqDevice(object):
         return dict(zip(['greens', 'one_body', 'force_bias', 'vhs', 'exponential', 'overlap_weight',
                          'reortho', 'energy'], out))
 
+    def kernel_trace(self, on=True):
+        """Start (and clear) / stop per-launch HIP-event timing of the hot kernels."""
+        self._ck(self.lib.afq_kernel_trace(self.h, int(on)))
+
+    def kernel_trace_get(self, kind, max_n=4096):
+        """Durations [ms] of the traced launches of kernel ``kind`` (_lib.K_*)."""
+        out = numpy.zeros(max_n, dtype=numpy.float64)
+        n = ctypes.c_int()
+        self._ck(self.lib.afq_kernel_trace_get(self.h, int(kind), _p(out), max_n, ctypes.byref(n)))
+        return out[:min(n.value, max_n)]
+
     def last_energy_kernel_ms(self):
         ms = ctypes.c_double()
         self._ck(self.lib.afq_last_energy_kernel_ms(self.h, ctypes.byref(ms)))

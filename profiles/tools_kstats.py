@@ -1,5 +1,5 @@
-import csv, sys, glob
-f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_stats.csv'))[-1]
+import csv, sys, glob, os
+f = max(glob.glob(sys.argv[1] + '/*/*kernel_stats.csv'), key=os.path.getmtime)
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
