@@ -401,10 +401,72 @@ EST = dict(uweight=0, weight=1, enumer=2, edenom=3, eproj=4, e1b=5, e2b=6,
            ehyb=7, ovlp=8, time=9)   # estimators/mixed.py:460-469
 
 
+
+# --------------------------------------------------------------------------
+# Multi-determinant trial |psi_T> = sum_d c_d |D_d>  
+# --------------------------------------------------------------------------
+def msd_greens_function(phi, psi, coeffs, na, nb):
+    """walkers/multi_det.py:194-229.  psi[ndet, M, na+nb].  Returns (tot_ovlp,
+    weights[ndet] = conj(c_d) <D_d|phi>, Gi[ndet, 2, M, M]).  Determinants whose
+    overlap is below 1e-16 are skipped by the reference (their Gi keeps the
+    previous content); here they get zero weight and a zero Gi."""
+    ndet, M = psi.shape[0], psi.shape[1]
+    Gi = numpy.zeros((ndet, 2, M, M), dtype=numpy.complex128)
+    weights = numpy.zeros(ndet, dtype=numpy.complex128)
+    tot = 0.0
+    for ix in range(ndet):
+        det = psi[ix]
+        Oup = numpy.dot(phi[:, :na].T, det[:, :na].conj())
+        ovlp = scipy.linalg.det(Oup)
+        if abs(ovlp) < 1e-16:
+            continue
+        Gi[ix, 0] = numpy.dot(det[:, :na].conj(), numpy.dot(scipy.linalg.inv(Oup), phi[:, :na].T))
+        Odn = numpy.dot(phi[:, na:].T, det[:, na:].conj())
+        ovlp *= scipy.linalg.det(Odn)
+        if abs(ovlp) < 1e-16:
+            continue
+        Gi[ix, 1] = numpy.dot(det[:, na:].conj(), numpy.dot(scipy.linalg.inv(Odn), phi[:, na:].T))
+        weights[ix] = coeffs[ix].conj() * ovlp
+        tot += weights[ix]
+    return tot, weights, Gi
+
+
+def msd_calc_overlap(phi, psi, coeffs, na, nb, weights_out=None):
+    """walkers/multi_det.py:135-162.  The reference also refreshes walker.weights here (:160);
+    pass ``weights_out`` to receive them."""
+    tot = 0.0
+    for ix in range(psi.shape[0]):
+        Oup = numpy.dot(psi[ix, :, :na].conj().T, phi[:, :na])
+        Odn = numpy.dot(psi[ix, :, na:].conj().T, phi[:, na:])
+        wd = coeffs[ix].conj() * scipy.linalg.det(Oup) * scipy.linalg.det(Odn)
+        if weights_out is not None:
+            weights_out[ix] = wd
+        tot += wd
+    return tot
+
+
+def force_bias_msd(Gi, weights, hs_pot, sqrt_dt, mf_shift):
+    """propagation/generic.py:154-157 with walkers/multi_det.py:283-290: for every field
+    vbias_n = sum_d w_d (G_d^a + G_d^b) . V_n / sum_d w_d (one vectorised dot here)."""
+    Gw = numpy.einsum('d,dpq->pq', weights, Gi[:, 0] + Gi[:, 1]) / numpy.sum(weights)
+    vbias = numpy.dot(hs_pot.T, Gw.ravel())
+    return -sqrt_dt * (1j * vbias - mf_shift)
+
+
+def local_energy_msd(H1, ecore, Gi, weights, chol):
+    """estimators/mixed.py:439-448 with the full-G Cholesky energy (estimators/generic.py:398-434)."""
+    num = numpy.zeros(3, dtype=numpy.complex128)
+    for w, G in zip(weights, Gi):
+        num += w * numpy.array(local_energy_generic_cholesky(H1, ecore, G, chol))
+    return tuple(num / numpy.sum(weights))
+
+
 class RefModel(object):
     """Plain-array bundle of everything the hot path reads.
 
-    kind: 'generic' | 'hubbard' | 'hubbard_spin' | 'ueg'
+    kind: 'generic' | 'generic_msd' | 'hubbard' | 'hubbard_spin' | 'ueg'.  For
+    'generic_msd' psi is [ndet, M, na+nb] and ``coeffs`` [ndet] is required; the
+    second and third items the Green's function returns are then (weights, Gi).
     """
 
     def __init__(self, kind, M, na, nb, psi, BH1, mf_shift, dt, **kw):
@@ -419,8 +481,21 @@ class RefModel(object):
         self.__dict__.update(kw)
         self.nfields = len(self.mf_shift)
 
+    # -- trial dispatch -------------------------------------------------
+    def greens(self, phi):
+        if self.kind == 'generic_msd':
+            return msd_greens_function(phi, self.psi, self.coeffs, self.na, self.nb)
+        return greens_function(phi, self.psi, self.na, self.nb)
+
+    def overlap(self, phi):
+        if self.kind == 'generic_msd':
+            return msd_calc_overlap(phi, self.psi, self.coeffs, self.na, self.nb)
+        return calc_overlap(phi, self.psi, self.na, self.nb)
+
     # -- system dispatch ------------------------------------------------
     def force_bias(self, Ghalf, G):
+        if self.kind == 'generic_msd':
+            return force_bias_msd(G, Ghalf, self.hs_pot, self.sqrt_dt, self.mf_shift)
         if self.kind == 'generic':
             return force_bias_generic(Ghalf, self.rchol, self.na, self.nb, self.M,
                                       self.sqrt_dt, self.mf_shift)
@@ -433,7 +508,7 @@ class RefModel(object):
         raise ValueError(self.kind)
 
     def vhs(self, xs):
-        if self.kind == 'generic':
+        if self.kind in ('generic', 'generic_msd'):
             return vhs_generic(self.hs_pot, xs, self.M, self.sqrt_dt)
         if self.kind == 'hubbard':
             return vhs_hubbard(xs, self.U, self.sqrt_dt)
@@ -444,6 +519,8 @@ class RefModel(object):
         raise ValueError(self.kind)
 
     def local_energy(self, G, Ghalf):
+        if self.kind == 'generic_msd':
+            return local_energy_msd(self.H1, self.ecore, G, Ghalf, self.hs_pot)
         if self.kind == 'generic':
             return local_energy_generic_cholesky_opt(self.H1, self.ecore, G, Ghalf,
                                                      self.rchol, self.na, self.nb)
@@ -459,7 +536,7 @@ class RefModel(object):
 def new_walker(model, phi0, weight=1.0):
     """walkers/walker.py:24-61 + single_det.py:64-67 (the state the loop touches)."""
     phi = numpy.array(phi0, dtype=numpy.complex128, copy=True)
-    ot = calc_overlap(phi, model.psi, model.na, model.nb)
+    ot = model.overlap(phi)
     return dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
                 hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0)
 
@@ -478,7 +555,7 @@ def propagate_walker_free(model, w, xi, eshift):
         apply_exponential(w['phi'][:, :na], VHS, model.exp_order)
         apply_exponential(w['phi'][:, na:], VHS, model.exp_order)
     kinetic_real(w['phi'], model.BH1, na)
-    ovlp_new = calc_overlap(w['phi'], model.psi, na, nb)
+    ovlp_new = model.overlap(w['phi'])
     (magn, dtheta) = cmath.polar(cmath.exp(cmf + model.dt * eshift))
     w['weight'] *= magn
     w['phase'] *= cmath.exp(1j * dtheta)
@@ -492,7 +569,7 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
     ``xi`` is the real normal field vector the reference draws at :133.
     Returns (nfb_trig, nhe_trig)."""
     na, nb = model.na, model.nb
-    ovlp, Ghalf, G = greens_function(w['phi'], model.psi, na, nb)
+    ovlp, Ghalf, G = model.greens(w['phi'])
     kinetic_real(w['phi'], model.BH1, na)
     xbar = model.force_bias(Ghalf, G)
     xs, cmf, cfb, ntrig = shift_fields(xi, xbar, model.mf_shift, model.sqrt_dt)
@@ -506,10 +583,16 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
         if nb > 0:
             apply_exponential(w['phi'][:, na:], VHS, model.exp_order)
     kinetic_real(w['phi'], model.BH1, na)
-    ovlp_new = calc_overlap(w['phi'], model.psi, na, nb)
+    ovlp_new = model.overlap(w['phi'])
     if hybrid:
         htrig = update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, model.dt)
     else:
+        if model.kind == 'generic_msd':
+            # Reference behaviour (continuous.py:296 after :261): the energy is evaluated AFTER
+            # calc_overlap refreshed walker.weights for the propagated walker (multi_det.py:160), but
+            # with the Green's functions Gi of the un-propagated walker.
+            Ghalf = numpy.zeros(len(model.coeffs), dtype=numpy.complex128)
+            msd_calc_overlap(w['phi'], model.psi, model.coeffs, na, nb, weights_out=Ghalf)
         eloc = complex(model.local_energy(G, Ghalf)[0])
         htrig = update_weight_local_energy(w, eloc, ovlp, ovlp_new, eshift, model.dt)
     return ntrig, htrig
@@ -547,7 +630,7 @@ def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=Fa
         for w in walkers:
             wfac = w['weight'] * w['ot'] * w['phase']
             if step % energy_eval_freq == 0:
-                _, Ghalf, G = greens_function(w['phi'], model.psi, model.na, model.nb)
+                _, Ghalf, G = model.greens(w['phi'])
                 E, T, V = model.local_energy(G, Ghalf)
                 est[EST['enumer']] += wfac * E
                 est[EST['e1b']] += wfac * T
@@ -560,7 +643,7 @@ def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=Fa
         return
     for w in walkers:
         if step % energy_eval_freq == 0:
-            _, Ghalf, G = greens_function(w['phi'], model.psi, model.na, model.nb)
+            _, Ghalf, G = model.greens(w['phi'])
             E, T, V = model.local_energy(G, Ghalf)
             est[EST['enumer']] += w['weight'] * complex(E).real
             est[EST['e1b']] += w['weight'] * complex(T).real

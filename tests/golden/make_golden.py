@@ -132,7 +132,8 @@ from pauxy.estimators.mixed import local_energy                  # noqa: E402
 from pauxy.estimators.generic import (                           # noqa: E402
     local_energy_generic_cholesky, local_energy_generic_cholesky_opt)
 from pauxy.utils.misc import dotdict                             # noqa: E402
-from pauxy.utils.testing import generate_hamiltonian, get_random_nomsd  # noqa: E402
+from pauxy.utils.testing import generate_hamiltonian, get_random_nomsd, get_random_phmsd  # noqa: E402
+from pauxy.walkers.multi_det import MultiDetWalker               # noqa: E402
 from pauxy.qmc.afqmc import AFQMC                                # noqa: E402
 
 
@@ -522,7 +523,134 @@ def make_traj_ueg():
     numpy.savez_compressed(os.path.join(HERE, 'traj_ueg.npz'), **out)
 
 
+
+def msd_system(out, tag=''):
+    """propagation/tests/test_generic.py:52-62: 10 orbitals, 5+5 electrons, seed 7."""
+    numpy.random.seed(7)
+    nmo, nelec = 10, (5, 5)
+    h1e, chol, enuc, eri = generate_hamiltonian(nmo, nelec, cplx=False)
+    system = Generic(nelec=nelec, h1e=numpy.array([h1e, h1e]),
+                     chol=chol.reshape((-1, nmo * nmo)).T.copy(), ecore=0)
+    out[tag + 'h1e'] = h1e
+    out[tag + 'chol'] = system.chol_vecs
+    out[tag + 'ecore'] = 0.0
+    out[tag + 'nelec'] = numpy.array(nelec)
+    return system
+
+
+def msd_record_trial(out, tag, trial, prop):
+    out[tag + 'psi'] = numpy.array(trial.psi)
+    out[tag + 'coeffs'] = numpy.array(trial.coeffs)
+    out[tag + 'init'] = numpy.array(trial.init)
+    out[tag + 'ortho'] = bool(trial.ortho_expansion)
+    out[tag + 'BH1'] = prop.propagator.BH1
+    out[tag + 'mf_shift'] = prop.propagator.mf_shift
+
+
+def msd_steps(system, trial, hybrid, out, tag, nsteps=10, eshift=None):
+    """The loop of propagation/tests/test_generic.py:52-92 with the drawn fields recorded."""
+    qmc = dotdict({'dt': 0.005, 'nstblz': 5})
+    prop = Continuous(system, trial, qmc, options={'hybrid': hybrid})
+    walker = MultiDetWalker(system, trial)
+    msd_record_trial(out, tag, trial, prop)
+    out[tag + 'phi0'] = walker.phi.copy()
+    out[tag + 'ot0'] = walker.ot
+    out[tag + 'ovlps0'] = walker.ovlps.copy()
+    out[tag + 'weights0'] = walker.weights.copy()
+    out[tag + 'Gi0'] = walker.Gi.copy()
+    out[tag + 'xbar0'] = numpy.array(prop.propagator.construct_force_bias(system, walker, trial))
+    out[tag + 'energy0'] = numpy.array(walker.local_energy(system))
+    xi = []
+    _normal = numpy.random.normal
+
+    def normal(*a, **k):
+        x = _normal(*a, **k)
+        xi.append(numpy.array(x))
+        return x
+
+    rec = dict(phi=[], weight=[], ot=[], ehyb=[], eloc=[])
+    numpy.random.normal = normal
+    try:
+        for i in range(nsteps):
+            prop.propagate_walker(walker, system, trial, eshift)
+            rec['phi'].append(walker.phi.copy())
+            rec['weight'].append(walker.weight)
+            rec['ot'].append(walker.ot)
+            rec['ehyb'].append(walker.hybrid_energy)
+            rec['eloc'].append(walker.eloc)
+    finally:
+        numpy.random.normal = _normal
+    out[tag + 'xi'] = numpy.array(xi)
+    out[tag + 'eshift'] = eshift
+    out[tag + 'step_phi'] = numpy.array(rec['phi'])
+    out[tag + 'step_weight'] = numpy.array(rec['weight'], dtype=numpy.float64)
+    out[tag + 'step_ot'] = numpy.array(rec['ot'], dtype=numpy.complex128)
+    out[tag + 'step_ehyb'] = numpy.array(rec['ehyb'], dtype=numpy.complex128)
+    out[tag + 'step_eloc'] = numpy.array(rec['eloc'], dtype=numpy.complex128)
+    detR = walker.reortho(trial)
+    out[tag + 'phi_qr'] = walker.phi.copy()
+    out[tag + 'detR'] = detR
+    return walker
+
+
+def make_msd_ops():
+    """Multi-determinant trials: the reference's two pinned PHMSD runs and a
+    non-orthogonal (NOMSD) expansion on the same Hamiltonian."""
+    out = {}
+    # P_: particle-hole expansion, hybrid False (test_generic.py:52-72, weight 0.68797524675701)
+    system = msd_system(out)
+    wfn, init = get_random_phmsd(system, ndet=3, init=True)
+    trial = MultiSlater(system, wfn, init=init)
+    trial.calculate_energy(system)
+    w = msd_steps(system, trial, False, out, 'PL_', eshift=trial.energy)
+    assert abs(w.weight - 0.68797524675701) < 1e-12, w.weight
+    # same system and trial, hybrid True (test_generic.py:74-92, weight 0.7430443466368197)
+    system = msd_system({})
+    wfn, init = get_random_phmsd(system, ndet=3, init=True)
+    trial = MultiSlater(system, wfn, init=init)
+    trial.calculate_energy(system)
+    w = msd_steps(system, trial, True, out, 'PH_', eshift=trial.energy)
+    assert abs(w.weight - 0.7430443466368197) < 1e-12, w.weight
+    # N_: non-orthogonal complex expansion, walker started from a perturbed first determinant
+    system = msd_system({})
+    coeffs, wfn = get_random_nomsd(system, ndet=3, cplx=True)
+    # determinants that overlap well with each other: common reference + complex noise
+    e, v = numpy.linalg.eigh(system.H1[0])
+    ref = numpy.concatenate([v[:, :5], v[:, :5]], axis=1)
+    wfn = ref[None] + 0.15 * wfn
+    init = ref + 0.1 * rand_phi(10, 10)
+    trial = MultiSlater(system, (coeffs, wfn), init=init)
+    msd_steps(system, trial, True, out, 'N_', eshift=0.3)
+    numpy.savez_compressed(os.path.join(HERE, 'msd_ops.npz'), **out)
+
+
+def make_traj_msd():
+    """The unchanged driver (qmc/afqmc.py) with a 3-determinant NOMSD trial: 8 walkers, comb every
+    5 steps, re-orthogonalisation every 5, energy every step."""
+    out = {}
+    system = msd_system(out)
+    coeffs, wfn = get_random_nomsd(system, ndet=3, cplx=True)
+    e, v = numpy.linalg.eigh(system.H1[0])
+    ref = numpy.concatenate([v[:, :5], v[:, :5]], axis=1)
+    wfn = ref[None] + 0.15 * wfn
+    trial = MultiSlater(system, (coeffs, wfn), init=ref.astype(numpy.complex128))
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.005, 'steps': 5, 'blocks': 8, 'rng_seed': 8, 'nwalkers': 8,
+                       'pop_control_freq': 5, 'stabilise_freq': 5},
+               'estimates': {'mixed': {'energy_eval_freq': 1}}}
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, system=system, trial=trial, options=options)
+    out['coeffs'] = numpy.array(trial.coeffs)
+    record_trajectory(afqmc, comm, out)
+    out['psi'] = numpy.array(trial.psi)
+    numpy.savez_compressed(os.path.join(HERE, 'traj_msd.npz'), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'msd':
+        make_msd_ops()
+        make_traj_msd()
+        sys.exit(0)
     make_generic_ops()
     make_hubbard_ops()
     make_ueg_ops()
@@ -537,6 +665,8 @@ if __name__ == '__main__':
                       prop_extra={'free_projection': True})
     make_traj_hubbard('traj_hubbard_le.npz', 8, nwalkers=10, npop=5, blocks=4,
                       prop_extra={'hybrid': False})
+    make_msd_ops()
+    make_traj_msd()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -31,6 +31,16 @@ def generic_model(d, tag, rchol=None):
                         H1=numpy.array([h1e, h1e]), ecore=float(d[tag + 'ecore']))
 
 
+def msd_model(d, tag, systag=''):
+    """Multi-determinant generic model from msd_ops.npz / traj_msd.npz."""
+    na, nb = [int(x) for x in d[systag + 'nelec']]
+    h1e = d[systag + 'h1e']
+    M = h1e.shape[0]
+    return ref.RefModel('generic_msd', M, na, nb, d[tag + 'psi'], d[tag + 'BH1'], d[tag + 'mf_shift'], 0.005,
+                        coeffs=d[tag + 'coeffs'], hs_pot=d[systag + 'chol'], H1=numpy.array([h1e, h1e]),
+                        ecore=float(d[systag + 'ecore']))
+
+
 def hubbard_model(d, tag, kind):
     na, nb = [int(x) for x in d['nelec']]
     M = d['T'].shape[-1]

@@ -5,7 +5,7 @@ import numpy
 import pytest
 
 from oracle import afqmc_ref as ref
-from tests.helpers import generic_model, hubbard_model, ueg_model
+from tests.helpers import generic_model, hubbard_model, msd_model, ueg_model
 
 RTOL = 1e-11
 
@@ -195,6 +195,53 @@ def test_traj_ueg(golden):
     # qmc/tests/test_afqmc.py:87-92
     assert est[ref.EST['enumer']].real == pytest.approx(16.33039729324558, rel=1e-9)
     assert est[ref.EST['uweight']].real == pytest.approx(9.75405059997262, rel=1e-9)
+
+
+def check_msd_steps(d, tag, hybrid):
+    m = msd_model(d, tag)
+    phi0 = d[tag + 'phi0']
+    tot, weights, Gi = m.greens(phi0)
+    close(tot, d[tag + 'ot0'])
+    close(weights, d[tag + 'weights0'])
+    close(Gi, d[tag + 'Gi0'])
+    close(m.overlap(phi0), d[tag + 'ot0'])
+    close(m.force_bias(weights, Gi), d[tag + 'xbar0'])
+    close(numpy.array(m.local_energy(Gi, weights)), d[tag + 'energy0'])
+    w = ref.new_walker(m, phi0)
+    eshift = complex(d[tag + 'eshift'])
+    for i, xi in enumerate(d[tag + 'xi']):
+        ref.propagate_walker_phaseless(m, w, xi, eshift, hybrid=hybrid)
+        close(w['phi'], d[tag + 'step_phi'][i], 1e-9)
+        close(w['weight'], d[tag + 'step_weight'][i], 1e-9)
+        close(w['ot'], d[tag + 'step_ot'][i], 1e-9)
+        if hybrid:
+            close(w['hybrid_energy'], d[tag + 'step_ehyb'][i], 1e-9)
+        else:
+            close(w['eloc'], d[tag + 'step_eloc'][i], 1e-9)
+    return w
+
+
+def test_msd_phmsd_known_answers(golden):
+    """propagation/tests/test_generic.py:52-92: walker weight after 10 steps with a 3-determinant
+    particle-hole trial, local-energy and hybrid weight updates."""
+    d = golden('msd_ops.npz')
+    w = check_msd_steps(d, 'PL_', False)
+    assert w['weight'] == pytest.approx(0.68797524675701, rel=1e-10)
+    w = check_msd_steps(d, 'PH_', True)
+    assert w['weight'] == pytest.approx(0.7430443466368197, rel=1e-10)
+
+
+def test_msd_nomsd_ops(golden):
+    d = golden('msd_ops.npz')
+    assert not bool(d['N_ortho'])
+    check_msd_steps(d, 'N_', True)
+
+
+def test_traj_msd(golden):
+    """Unchanged reference driver with a 3-determinant NOMSD trial (8 walkers, comb/5, reortho/5)."""
+    d = golden('traj_msd.npz')
+    check_traj(d, msd_model(d, ''))
+    assert d['parent_ix'].shape[0] == 8
 
 
 def test_comb_truncation_quirk():

@@ -39,6 +39,11 @@ def run(name, system, trial, nw, dt, steps, warmup, prop=None, npop=5):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["C1", "C2", "C4"]
+    if "C5sd" in which:
+        # BASELINE configs[4] sizes with a single-determinant RHF trial (the NOMSD trial is a "next" row)
+        s = systems.synthetic_generic(400, 2000, (50, 50), seed=7)
+        run("C5 sizes, single determinant: generic M=400 K=2000 50+50, 256 walkers", s,
+            trial_mod.rhf_trial_generic(s), 256, 0.005, 10, 5)
     if "C1" in which:
         s = systems.Hubbard(4, 4, 8, 8, 4.0)
         run("C1 Hubbard 4x4 U=4 8+8, 10 walkers", s, trial_mod.uhf_trial_hubbard(s), 10, 0.01, 400, 50)
