@@ -107,6 +107,20 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
                        const double *vqvec, double vol, const double *H1diag, double ecore);
 /* trial determinant psi c128[M, na+nb] (trial.psi after walkers/handler.py:61) */
 int afq_set_trial(afq_handle *h, const double *psi);
+/* Multi-determinant (NOMSD / PHMSD) trial |psi_T> = sum_d c_d |D_d> for a generic system, replacing
+ * the single-determinant operands of afq_set_system_generic / afq_set_trial.  Call after the
+ * system and before afq_walkers_alloc.
+ *   psi    [ndet, M, na+nb] c128     pauxy/trial_wavefunction/multi_slater.py:36-38 (trial.psi)
+ *   coeffs [ndet] c128               trial.coeffs (enter as conj(c_d), walkers/multi_det.py:226)
+ *   rchol  [ndet, (na+nb) M, K] c128 per-determinant half rotation, multi_slater.py:370-409
+ * Green's function / overlap, force bias and local energy then follow walkers/multi_det.py:194-257,
+ * 135-162, propagation/generic.py:154-157 and estimators/mixed.py:439-448 (the per-determinant
+ * energy is evaluated in its half-rotated form, algebraically equal to the reference's full-G form). */
+int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double *coeffs, const double *rchol);
+/* weights conj(c_d) <D_d|phi_w> of the last Green's function / overlap evaluation: [nw, ndet] c128
+ * (MultiDetWalker.weights, walkers/multi_det.py:226)                                                  */
+int afq_walkers_det_weights(afq_handle *h, double *weights_out);
+
 /* propagation/continuous.py:13-80 + <system>.construct_one_body_propagator:
  * BH1 c128[2,M,M], mf_shift c128[K], dt, expansion_order, AFQ_PROP_* flags.    */
 int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,

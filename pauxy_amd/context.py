@@ -25,9 +25,7 @@ def trial_psi(trial):
     """trial.psi is [ndet, M, ne] until the walker handler strips the leading
     axis for ndets == 1 (walkers/handler.py:61); accept both."""
     psi = numpy.asarray(trial.psi)
-    if psi.ndim == 3:
-        if psi.shape[0] != 1:
-            raise NotImplementedError("multi-determinant trials are not on the device path yet")
+    if psi.ndim == 3 and psi.shape[0] == 1:
         psi = psi[0]
     return psi
 
@@ -38,7 +36,15 @@ class Context(object):
         self.trial = trial
         self.dev = AfqDevice(local_device_id() if device_id is None else device_id)
         self._upload_system()
-        self.dev.set_trial(trial_psi(trial))
+        psi = trial_psi(trial)
+        if psi.ndim == 3:
+            # multi-determinant expansion: per-determinant half-rotated Cholesky vectors, stacked as in
+            # trial_wavefunction/multi_slater.py:370-409
+            if system.name != "Generic":
+                raise NotImplementedError("multi-determinant trials need a Generic system")
+            self.dev.set_trial_multi(psi, numpy.asarray(trial.coeffs), numpy.asarray(trial._rchol))
+        else:
+            self.dev.set_trial(psi)
         self.propagator_set = False
 
     def _upload_system(self):

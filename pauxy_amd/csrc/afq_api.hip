@@ -26,7 +26,51 @@ template <class T> int dev_upload(afq_handle *h, T **p, const void *src, size_t 
 
 template <class T> void dev_free(T *&p) { if (p) { hipFree(p); p = nullptr; } }
 
+// ---- multi-determinant operand sets: psi / psic / rH1 / rchol_* of the handle are views of dets[cur_det]
+void stash_det(afq_handle *h) {
+    if (h->ndet <= 1) return;
+    afq_handle::DetOps &o = h->dets[h->cur_det];
+    o.psi = h->psi; o.psic = h->psic; o.rH1 = h->rH1; o.rchol_re = h->rchol_re; o.rchol_im = h->rchol_im;
+    for (int s = 0; s < 2; ++s) { o.rchol_frag[s] = h->rchol_frag[s]; o.rchol_frag_im[s] = h->rchol_frag_im[s]; }
+}
+
+void select_det(afq_handle *h, int d) {
+    if (h->ndet <= 1 || d == h->cur_det) return;
+    stash_det(h);
+    const afq_handle::DetOps &o = h->dets[d];
+    h->psi = o.psi; h->psic = o.psic; h->rH1 = o.rH1; h->rchol_re = o.rchol_re; h->rchol_im = o.rchol_im;
+    for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = o.rchol_frag[s]; h->rchol_frag_im[s] = o.rchol_frag_im[s]; }
+    h->cur_det = d;
+    if (h->nw) {
+        h->ghalf = h->ghalf_all + (size_t)d * h->nw * h->M * h->nt;
+        if (h->vbias_all) h->vbias = h->vbias_all + (size_t)d * 2 * h->fb_split * h->nw * h->K;
+    }
+}
+
+void free_dets(afq_handle *h) {
+    if (h->ndet > 1) {
+        stash_det(h);
+        for (afq_handle::DetOps &o : h->dets) {
+            if (o.psi) hipFree(o.psi);
+            if (o.psic) hipFree(o.psic);
+            if (o.rH1) hipFree(o.rH1);
+            if (o.rchol_re) hipFree(o.rchol_re);
+            if (o.rchol_im) hipFree(o.rchol_im);
+            for (int s = 0; s < 2; ++s) {
+                if (o.rchol_frag[s]) hipFree(o.rchol_frag[s]);
+                if (o.rchol_frag_im[s]) hipFree(o.rchol_frag_im[s]);
+            }
+        }
+        h->psi = nullptr; h->psic = nullptr; h->rH1 = nullptr; h->rchol_re = nullptr; h->rchol_im = nullptr;
+        for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; }
+    }
+    h->dets.clear();
+    h->ndet = 1; h->cur_det = 0;
+    if (h->coeffs) { hipFree(h->coeffs); h->coeffs = nullptr; }
+}
+
 void free_system(afq_handle *h) {
+    free_dets(h);
     dev_free(h->hs_pot); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     dev_free(h->H1); dev_free(h->rH1);
@@ -44,8 +88,9 @@ void free_walkers(afq_handle *h) {
     dev_free(h->phi); dev_free(h->phi_t); dev_free(h->phi_t2);
     dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR);
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
-    dev_free(h->ghalf); dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
-    dev_free(h->xi); dev_free(h->vbias); dev_free(h->xbar); dev_free(h->xs);
+    dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
+    dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr;
+    dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all); dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
     dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
@@ -87,6 +132,16 @@ struct afq_handle_full : afq_handle {
     afq_host_cache cache;
 };
 static afq_host_cache *cache_of(afq_handle *h) { return &static_cast<afq_handle_full *>(h)->cache; }
+
+static int upload_psi(afq_handle *h, const double *psi) {
+    const size_t n = (size_t)h->M * h->nt;
+    int rc = dev_upload(h, &h->psi, psi, n);
+    if (rc) return rc;
+    cache_of(h)->psi.assign(psi, psi + 2 * n);
+    std::vector<double> pc(psi, psi + 2 * n);
+    for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
+    return dev_upload(h, &h->psic, pc.data(), n);
+}
 
 static int maybe_build_rH1(afq_handle *h) {
     afq_host_cache *c = cache_of(h);
@@ -167,6 +222,35 @@ static int set_dims(afq_handle *h, int kind, int M, int K, int na, int nb) {
     return AFQ_OK;
 }
 
+// half-rotated Cholesky vectors of ONE determinant into the handle's current operand slots:
+// planar re / im [nt*M, ld_rc] for the force-bias GEMM + fragment-ordered copies for the exchange kernel
+static bool rchol_is_real(const double *rchol, size_t n) {
+    for (size_t i = 0; i < n; ++i) if (rchol[2 * i + 1] != 0.0) return false;
+    return true;
+}
+
+static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
+    const size_t nq = (size_t)h->nt * h->M;
+    const int K = h->K;
+    int rc;
+    std::vector<double> re(nq * h->ld_rc, 0.0);
+    for (size_t q = 0; q < nq; ++q)
+        for (int n = 0; n < K; ++n) re[q * h->ld_rc + n] = rchol[2 * (q * K + n)];
+    h->rchol_real = real;
+    if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
+    if (!real) {
+        std::vector<double> im(nq * h->ld_rc, 0.0);
+        for (size_t q = 0; q < nq; ++q)
+            for (int n = 0; n < K; ++n) im[q * h->ld_rc + n] = rchol[2 * (q * K + n) + 1];
+        if ((rc = dev_upload(h, &h->rchol_im, im.data(), im.size()))) return rc;
+    }
+    for (int s = 0; s < 2; ++s) {
+        if (h->rchol_frag[s]) { hipFree(h->rchol_frag[s]); h->rchol_frag[s] = nullptr; }
+        if (h->rchol_frag_im[s]) { hipFree(h->rchol_frag_im[s]); h->rchol_frag_im[s] = nullptr; }
+    }
+    return k_prepare_energy_operands(h, rchol);
+}
+
 int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const double *hs_pot,
                            const double *rchol, const double *H1, double ecore) {
     if (h) h->greens_valid = false;
@@ -184,24 +268,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
             for (int n = 0; n < K; ++n) t[(size_t)n * h->ld_hs + r] = hs_pot[r * K + n];
         if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
     }
-    {   // split rchol into planar re / im, rows padded to ld_rc
-        std::vector<double> re(nq * h->ld_rc, 0.0), im;
-        bool real = true;
-        for (size_t q = 0; q < nq; ++q)
-            for (int n = 0; n < K; ++n) {
-                re[q * h->ld_rc + n] = rchol[2 * (q * K + n)];
-                if (rchol[2 * (q * K + n) + 1] != 0.0) real = false;
-            }
-        h->rchol_real = real;
-        if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
-        if (!real) {
-            im.assign(nq * h->ld_rc, 0.0);
-            for (size_t q = 0; q < nq; ++q)
-                for (int n = 0; n < K; ++n) im[q * h->ld_rc + n] = rchol[2 * (q * K + n) + 1];
-            if ((rc = dev_upload(h, &h->rchol_im, im.data(), im.size()))) return rc;
-        }
-    }
-    if ((rc = k_prepare_energy_operands(h, rchol))) return rc;
+    if ((rc = upload_rchol(h, rchol, rchol_is_real(rchol, nq * K)))) return rc;
     if ((rc = dev_upload(h, &h->H1, H1, 2 * mm))) return rc;
     cache_of(h)->H1.assign(H1, H1 + 4 * mm);
     return AFQ_OK;
@@ -274,18 +341,47 @@ int afq_set_trial(afq_handle *h, const double *psi) {
     if (h) h->greens_valid = false;
     if (!h || !psi) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the trial");
+    if (h->ndet > 1) AFQ_FAIL(h, AFQ_ESTATE, "a multi-determinant trial is set; set the system again first");
     hipSetDevice(h->device);
-    const size_t n = (size_t)h->M * h->nt;
-    int rc = dev_upload(h, &h->psi, psi, n);
+    int rc = upload_psi(h, psi);
     if (rc) return rc;
-    cache_of(h)->psi.assign(psi, psi + 2 * n);
-    {
-        std::vector<double> pc(psi, psi + 2 * n);
-        for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
-        if ((rc = dev_upload(h, &h->psic, pc.data(), n))) return rc;
-    }
     h->have_trial = true;
     return maybe_build_rH1(h);
+}
+
+int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double *coeffs, const double *rchol) {
+    if (h) h->greens_valid = false;
+    if (!h || !psi || !coeffs || !rchol || ndet < 1) return AFQ_EINVAL;
+    if (h->kind != AFQ_SYS_GENERIC) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "multi-determinant trials need a generic system");
+    if (h->nw) AFQ_FAIL(h, AFQ_ESTATE, "set the trial before allocating walkers");
+    hipSetDevice(h->device);
+    // drop the operands afq_set_system_generic uploaded for a single determinant
+    free_dets(h);
+    dev_free(h->psi); dev_free(h->psic); dev_free(h->rH1); dev_free(h->rchol_re); dev_free(h->rchol_im);
+    for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
+    const size_t npsi = (size_t)h->M * h->nt, nrc = npsi * h->K;
+    const bool real = rchol_is_real(rchol, nrc * ndet);
+    h->ndet = ndet; h->cur_det = 0;
+    h->dets.assign(ndet > 1 ? ndet : 0, afq_handle::DetOps());
+    int rc;
+    for (int d = 0; d < ndet; ++d) {
+        if (ndet > 1) {
+            // fresh (null) slots for determinant d; stash_det records what the uploads allocate
+            if (d > 0) {
+                stash_det(h);
+                h->psi = nullptr; h->psic = nullptr; h->rH1 = nullptr; h->rchol_re = nullptr; h->rchol_im = nullptr;
+                for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; }
+                h->cur_det = d;
+            }
+        }
+        if ((rc = upload_psi(h, psi + 2 * npsi * d))) return rc;
+        if ((rc = upload_rchol(h, rchol + 2 * nrc * d, real))) return rc;
+        h->have_trial = true;
+        if ((rc = maybe_build_rH1(h))) return rc;
+    }
+    select_det(h, 0);
+    if ((rc = dev_upload(h, &h->coeffs, coeffs, (size_t)ndet))) return rc;
+    return AFQ_OK;
 }
 
 int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift, double dt, int exp_order,
@@ -324,7 +420,9 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     A_(h->phi, per * n) A_(h->phi_t, per * n) A_(h->phi_t2, per * n)
     A_(h->weight, n) A_(h->unscaled, n) A_(h->detR, n)
     A_(h->ot, n) A_(h->ehyb, n) A_(h->phase, n) A_(h->eloc, n)
-    A_(h->ghalf, per * n) A_(h->ovlp_old, n) A_(h->ovlp_new, n)
+    A_(h->ghalf_all, per * n * h->ndet) A_(h->ovlp_old, n) A_(h->ovlp_new, n)
+    h->ghalf = h->ghalf_all + (size_t)h->cur_det * n * per;
+    if (h->ndet > 1) { A_(h->detd, n * h->ndet) A_(h->detw, n * h->ndet) A_(h->energy_all, 3 * n * h->ndet) }
     A_(h->xi, K * n) A_(h->xbar, K * n) A_(h->xs, K * n) A_(h->cmf, n) A_(h->cfb, n)
     A_(h->energy, 3 * n) A_(h->alive, n) A_(h->parent_ix, n)
     // force-bias contraction slices: enough wave-tasks to fill 1024 SIMDs
@@ -341,9 +439,11 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
         const int nmax = std::max(h->na, h->nb) * h->M;
         while (sp > 1 && nmax / sp < 64) --sp;
         h->fb_split = sp;
-        A_(h->vbias, (size_t)2 * sp * n * K)
+        A_(h->vbias_all, (size_t)2 * sp * n * K * h->ndet)
+        h->vbias = h->vbias_all + (size_t)h->cur_det * 2 * sp * n * K;
     } else if (h->kind == AFQ_SYS_UEG) {
-        A_(h->vbias, n * K)
+        A_(h->vbias_all, n * K)
+        h->vbias = h->vbias_all;
     }
     if (h->kind == AFQ_SYS_UEG) A_(h->G, (size_t)2 * h->M * h->M * n)
     {
@@ -431,6 +531,8 @@ int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *by
 }
 
 // ----------------------------------------------------------------- hot path
+static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf);
+
 static int need_ready(afq_handle *h, bool prop) {
     if (!h->kind || !h->have_trial || !h->nw) AFQ_FAIL(h, AFQ_ESTATE, "system, trial and walkers must be set");
     if (prop && !h->have_prop) AFQ_FAIL(h, AFQ_ESTATE, "propagator not set");
@@ -460,7 +562,7 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
     if (rc) return rc;
     {
         PhaseTimer t(h, T_GREENS);
-        if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
         if (want_G || h->kind == AFQ_SYS_UEG) {
             if ((rc = ensure_G(h))) return rc;
             if ((rc = k_full_G(h))) return rc;
@@ -476,16 +578,37 @@ int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
     if (rc) return rc;
     {
         PhaseTimer t(h, T_OVLP);
-        if ((rc = k_overlap(h, h->ovlp_new))) return rc;
+        if ((rc = greens_any(h, h->ovlp_new, false))) return rc;
     }
     return copy_out(h, ovlp_out, h->ovlp_new, sizeof(cplx) * h->nw);
 }
 
 // force bias from the current Ghalf / G -> h->xbar (unclipped)
+// Green's function (with_ghalf) or overlap only, for every determinant of the trial.  Multi-determinant:
+// per-determinant Ghalf_d / <D_d|phi> into the slices, then weights conj(c_d) <D_d|phi> and their sum
+// (walkers/multi_det.py:194-229 and :135-162).
+static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf) {
+    int rc;
+    if (h->ndet <= 1) return with_ghalf ? k_greens(h, det_out) : k_overlap(h, det_out);
+    for (int d = 0; d < h->ndet; ++d) {
+        select_det(h, d);
+        cplx *dd = h->detd + (size_t)d * h->nw;
+        if ((rc = with_ghalf ? k_greens(h, dd) : k_overlap(h, dd))) { select_det(h, 0); return rc; }
+    }
+    select_det(h, 0);
+    return k_msd_combine(h, det_out);
+}
+
 static int force_bias(afq_handle *h) {
     int rc;
     if (h->flags & AFQ_PROP_FORCE_BIAS) {
-        if (h->kind == AFQ_SYS_GENERIC) { if ((rc = k_force_bias_generic(h))) return rc; }
+        if (h->kind == AFQ_SYS_GENERIC) {
+            for (int d = 0; d < h->ndet; ++d) {
+                select_det(h, d);
+                if ((rc = k_force_bias_generic(h))) { select_det(h, 0); return rc; }
+            }
+            select_det(h, 0);
+        }
         else if (h->kind == AFQ_SYS_UEG) { if ((rc = k_vbias_ueg(h))) return rc; }
     }
     return k_xbar(h);
@@ -498,6 +621,7 @@ static int build_vhs(afq_handle *h) {
 }
 
 static int local_energy(afq_handle *h);
+static int local_energy_dets(afq_handle *h);
 
 static int apply_exp(afq_handle *h, const cplx *vhs) {
     if (h->vhs_diag) return k_apply_exponential_diag(h, vhs);
@@ -518,7 +642,7 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
         PhaseTimer t(h, T_GREENS);                         // continuous.py:245
         if (h->greens_valid) std::swap(h->ovlp_old, h->ovlp_new);   // computed at the end of the last step
-        else if ((rc = k_greens(h, h->ovlp_old))) return rc;
+        else if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
         h->greens_valid = false;
         const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
         if (h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) {
@@ -528,7 +652,11 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         if (le) {
             // walker.local_energy(system) of the un-propagated walker (continuous.py:296)
             PhaseTimer te(h, T_ENERGY);
-            if ((rc = local_energy(h))) return rc;
+            // Multi-determinant: the reference combines the per-determinant energies of the UN-propagated
+            // walker with the weights calc_overlap refreshes for the PROPAGATED walker
+            // (continuous.py:296 after :261, multi_det.py:160), so only the per-determinant part runs here.
+            if (h->ndet > 1) { if ((rc = local_energy_dets(h))) return rc; }
+            else if ((rc = local_energy(h))) return rc;
         }
     }
     // The force bias reads Ghalf of the un-propagated walker, so building the HS potential commutes
@@ -554,9 +682,12 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         // step's Green's function needs (continuous.py:245 of step n+1), so factorise once: this call
         // leaves Ghalf of the NEW phi behind and the next afq_propagate / afq_estimates_update reuses it.
         if (h->greens_cache && !fp) {
-            if ((rc = k_greens(h, h->ovlp_new))) return rc;
+            if ((rc = greens_any(h, h->ovlp_new, true))) return rc;
             h->greens_valid = true;
-        } else if ((rc = k_overlap(h, h->ovlp_new))) return rc;
+        } else if ((rc = greens_any(h, h->ovlp_new, false))) return rc;
+        if (h->ndet > 1 && !fp && !(h->flags & AFQ_PROP_HYBRID)) {
+            if ((rc = k_msd_energy_combine(h))) return rc;
+        }
         if ((rc = k_update_weight(h, cmake(eshift_re, eshift_im)))) return rc;
     }
     return AFQ_OK;
@@ -571,7 +702,27 @@ int afq_reortho(afq_handle *h, double *detR_out) {
     return copy_out(h, detR_out, h->detR, sizeof(double) * h->nw);
 }
 
+// per-determinant energies E[G_d] from the half-rotated operands of determinant d (algebraically the
+// full-G energy of estimators/generic.py:398-434 evaluated on G_d = conj(psi_d) Ghalf_d)
+static int local_energy_dets(afq_handle *h) {
+    cplx *final_e = h->energy;
+    int rc = AFQ_OK;
+    for (int d = 0; d < h->ndet && !rc; ++d) {
+        select_det(h, d);
+        h->energy = h->energy_all + (size_t)d * 3 * h->nw;
+        rc = k_energy_generic(h);
+    }
+    h->energy = final_e;
+    select_det(h, 0);
+    return rc;
+}
+
 static int local_energy(afq_handle *h) {
+    if (h->kind == AFQ_SYS_GENERIC && h->ndet > 1) {
+        int rc = local_energy_dets(h);
+        if (rc) return rc;
+        return k_msd_energy_combine(h);              // estimators/mixed.py:439-448
+    }
     if (h->kind == AFQ_SYS_GENERIC) return k_energy_generic(h);
     if (h->kind == AFQ_SYS_HUBBARD) return k_energy_hubbard(h);
     if (!h->G) AFQ_FAIL(h, AFQ_ESTATE, "afq_greens must run before afq_local_energy");
@@ -778,7 +929,7 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
     if (eval_energy) {
         {
             PhaseTimer t(h, T_GREENS);
-            if (!h->greens_valid && (rc = k_greens(h, h->ovlp_old))) return rc;
+            if (!h->greens_valid && (rc = greens_any(h, h->ovlp_old, true))) return rc;
             if (h->kind == AFQ_SYS_UEG) {
                 if ((rc = ensure_G(h))) return rc;
                 if ((rc = k_full_G(h))) return rc;
@@ -827,6 +978,14 @@ int afq_timers(afq_handle *h, double *out_ms, int reset) {
     if (!h || !out_ms) return AFQ_EINVAL;
     for (int i = 0; i < T_COUNT; ++i) { out_ms[i] = h->t_ms[i]; if (reset) h->t_ms[i] = 0.0; }
     return AFQ_OK;
+}
+
+int afq_walkers_det_weights(afq_handle *h, double *weights_out) {
+    if (!h || !weights_out) return AFQ_EINVAL;
+    if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
+    hipSetDevice(h->device);
+    if (h->ndet <= 1) AFQ_FAIL(h, AFQ_ESTATE, "single-determinant trial: the overlap is the only weight");
+    return copy_out(h, weights_out, h->detw, sizeof(cplx) * (size_t)h->nw * h->ndet);
 }
 
 int afq_kernel_trace(afq_handle *h, int on) {

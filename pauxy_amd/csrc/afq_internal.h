@@ -73,6 +73,22 @@ struct afq_handle {
     cplx *psi = nullptr;            // [M, nt]
     cplx *psic = nullptr;           // conj(psi) [M, nt] (B operand of the overlap GEMM)
 
+    // multi-determinant trial: the trial-dependent operands of every determinant;
+    // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one
+    struct DetOps {
+        cplx *psi = nullptr, *psic = nullptr, *rH1 = nullptr;
+        double *rchol_re = nullptr, *rchol_im = nullptr;
+        double *rchol_frag[2] = {nullptr, nullptr}, *rchol_frag_im[2] = {nullptr, nullptr};
+    };
+    int ndet = 1, cur_det = 0;
+    std::vector<DetOps> dets;       // size ndet when ndet > 1
+    cplx *coeffs = nullptr;         // [ndet] device copy of the CI coefficients
+    cplx *detd = nullptr;           // [ndet, nw] per-determinant overlaps <D_d|phi_w>
+    cplx *detw = nullptr;           // [nw, ndet] weights conj(c_d) <D_d|phi_w> of the last evaluation
+    cplx *ghalf_all = nullptr;      // owning pointers of the per-determinant slices
+    cplx *vbias_all = nullptr;
+    cplx *energy_all = nullptr;     // [ndet, nw, 3] per-determinant local energies
+
     // ---- propagator
     bool have_prop = false;
     cplx *BH1 = nullptr;            // [2, M, M]
@@ -204,7 +220,9 @@ int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det
 int k_overlap(afq_handle *h, cplx *det_out);                // det(psi^H phi)
 int k_fields(afq_handle *h);                                // vbias -> xbar(clipped), xs, cmf, cfb
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d, cplx *cfb_d);
-int k_xbar(afq_handle *h);                                  // vbias / G -> xbar (unclipped), system dispatch
+int k_xbar(afq_handle *h);
+int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
+int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch
 int k_update_weight(afq_handle *h, cplx eshift);
 int k_reortho(afq_handle *h);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);

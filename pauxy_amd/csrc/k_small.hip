@@ -451,6 +451,9 @@ struct XbarArgs {
     double sqrt_dt, U;
     const cplx *vbias, *mf, *ghalf, *psi;
     cplx *xbar;
+    int ndet;               // > 1: vbias holds ndet slices of det_stride elements, combined with detw
+    long det_stride;
+    const cplx *detw;       // [nw, ndet]
 };
 
 __global__ void xbar_kernel(XbarArgs a) {
@@ -462,7 +465,22 @@ __global__ void xbar_kernel(XbarArgs a) {
         if (a.kind == AFQ_SYS_GENERIC) {
             // propagation/generic.py:150-152: -sqrt(dt) (i vbias - mf_shift)
             cplx v = cmake(0.0, 0.0);
-            for (int b = 0; b < 2 * a.nsplit; ++b) v = cadd(v, a.vbias[((long)b * a.nw + w) * a.K + n]);
+            if (a.ndet > 1) {
+                // propagation/generic.py:154-157 + walkers/multi_det.py:283-290:
+                // vbias_n = sum_d w_d <V_n G_d> / sum_d w_d; <V_n G_d> = rchol_d^T vec(Ghalf_d)
+                cplx num = cmake(0.0, 0.0), den = cmake(0.0, 0.0);
+                for (int d = 0; d < a.ndet; ++d) {
+                    cplx x = cmake(0.0, 0.0);
+                    const cplx *vb = a.vbias + (long)d * a.det_stride;
+                    for (int b = 0; b < 2 * a.nsplit; ++b) x = cadd(x, vb[((long)b * a.nw + w) * a.K + n]);
+                    const cplx wd = a.detw[(long)w * a.ndet + d];
+                    cfma(num, wd, x);
+                    den = cadd(den, wd);
+                }
+                v = cdiv(num, den);
+            } else {
+                for (int b = 0; b < 2 * a.nsplit; ++b) v = cadd(v, a.vbias[((long)b * a.nw + w) * a.K + n]);
+            }
             const cplx m = a.mf[n];
             out = cmake(-a.sqrt_dt * (-v.y - m.x), -a.sqrt_dt * (v.x - m.y));
         } else if (a.kind == AFQ_SYS_HUBBARD) {
@@ -500,7 +518,52 @@ int k_xbar(afq_handle *h) {
     a.nt = h->nt; a.nw = h->nw; a.nsplit = h->fb_split; a.nq = h->nq;
     a.sqrt_dt = h->sqrt_dt; a.U = h->U;
     a.vbias = h->vbias; a.mf = h->mf_shift; a.ghalf = h->ghalf; a.psi = h->psi; a.xbar = h->xbar;
+    a.ndet = h->ndet; a.detw = h->detw; a.det_stride = (long)2 * h->fb_split * h->nw * h->K;
+    if (h->ndet > 1) a.vbias = h->vbias_all;
     hipLaunchKernelGGL(xbar_kernel, dim3((h->K + 127) / 128, h->nw), dim3(128), 0, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// --------------------------------------------------------------------------
+// multi-determinant trial: weights and weighted averages (walkers/multi_det.py:194-229,135-162)
+__global__ void msd_combine_kernel(const cplx *detd, const cplx *coeffs, cplx *detw, cplx *det_out, int nw,
+                                   int ndet) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    cplx tot = cmake(0.0, 0.0);
+    for (int d = 0; d < ndet; ++d) {
+        const cplx wd = cmul(cconj(coeffs[d]), detd[(long)d * nw + w]);
+        detw[(long)w * ndet + d] = wd;
+        tot = cadd(tot, wd);
+    }
+    det_out[w] = tot;
+}
+
+int k_msd_combine(afq_handle *h, cplx *det_out) {
+    hipLaunchKernelGGL(msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd, h->coeffs,
+                       h->detw, det_out, h->nw, h->ndet);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// estimators/mixed.py:439-448: E = sum_d w_d E[G_d] / sum_d w_d, component-wise
+__global__ void msd_energy_combine_kernel(const cplx *energy_all, const cplx *detw, cplx *energy, int nw,
+                                          int ndet) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    cplx num[3] = {cmake(0.0, 0.0), cmake(0.0, 0.0), cmake(0.0, 0.0)}, den = cmake(0.0, 0.0);
+    for (int d = 0; d < ndet; ++d) {
+        const cplx wd = detw[(long)w * ndet + d];
+        for (int c = 0; c < 3; ++c) cfma(num[c], wd, energy_all[((long)d * nw + w) * 3 + c]);
+        den = cadd(den, wd);
+    }
+    for (int c = 0; c < 3; ++c) energy[(long)w * 3 + c] = cdiv(num[c], den);
+}
+
+int k_msd_energy_combine(afq_handle *h) {
+    hipLaunchKernelGGL(msd_energy_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream,
+                       h->energy_all, h->detw, h->energy, h->nw, h->ndet);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }

@@ -108,8 +108,26 @@ class AfqDevice(object):
         self.kind, self.M, self.K, self.na, self.nb = 'ueg', M, 2 * nq, na, nb
 
     def set_trial(self, psi):
+        self.ndet = 1
         psi = _c128(psi, (self.M, self.na + self.nb))
         self._ck(self.lib.afq_set_trial(self.h, _p(psi)))
+
+    def set_trial_multi(self, psi, coeffs, rchol):
+        """psi [ndet, M, na+nb], coeffs [ndet], rchol [ndet * (na+nb) M, K] (stacked per determinant)."""
+        nt = self.na + self.nb
+        psi = _c128(psi)
+        ndet = psi.shape[0]
+        psi = _c128(psi, (ndet, self.M, nt))
+        coeffs = _c128(coeffs, (ndet,))
+        rchol = _c128(rchol, (ndet * nt * self.M, self.K))
+        self._ck(self.lib.afq_set_trial_multi(self.h, ndet, _p(psi), _p(coeffs), _p(rchol)))
+        self.ndet = ndet
+
+    def det_weights(self):
+        """conj(c_d) <D_d|phi_w> of the last Green's function / overlap evaluation, [nw, ndet]."""
+        out = numpy.zeros((self.nw, self.ndet), dtype=numpy.complex128)
+        self._ck(self.lib.afq_walkers_det_weights(self.h, _p(out)))
+        return out
 
     def set_propagator(self, BH1, mf_shift, dt, exp_order=6, hybrid=True, force_bias=True,
                        free_projection=False, hubbard_spin=False):

@@ -31,8 +31,6 @@ class _SystemPropagator(object):
         self.isqrt_dt = 1j * self.sqrt_dt
         name = system.name
         if name == "Generic":
-            if getattr(trial, 'ndets', 1) > 1:
-                raise NotImplementedError("multi-determinant trials are not on the device path yet")
             self.BH1, self.mf_shift = setup.generic_propagator_arrays(system, trial, qmc.dt)
             self.mf_core = system.ecore + 0.5 * numpy.dot(self.mf_shift, self.mf_shift)   # generic.py:49
         elif name == "Hubbard":

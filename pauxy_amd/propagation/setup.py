@@ -16,7 +16,13 @@ def generic_propagator_arrays(system, trial, dt):
     """mf_shift = i hs_pot^T vec(G_up + G_dn) (generic.py:78-79);
     BH1[s] = expm(-dt/2 (h1e_mod[s] - i reshape(hs_pot mf_shift))) (generic.py:103-107)."""
     nb = system.nbasis
-    mf_shift = 1j * numpy.dot(system.hs_pot.T, (trial.G[0] + trial.G[1]).ravel())
+    if getattr(trial, 'ndets', 1) > 1:
+        # generic.py:82-86: one contract_one_body per field; it is linear in the integrals, so one
+        # contraction of hs_pot with the trial's (unnormalised) transition density does all fields
+        gamma, denom = trial.one_body_density()
+        mf_shift = 1j * numpy.dot(system.hs_pot.T, gamma.ravel()) / denom
+    else:
+        mf_shift = 1j * numpy.dot(system.hs_pot.T, (trial.G[0] + trial.G[1]).ravel())
     shift = 1j * system.hs_pot.dot(mf_shift).reshape(nb, nb)
     H1 = system.h1e_mod - numpy.array([shift, shift])
     BH1 = numpy.array([scipy.linalg.expm(-0.5 * dt * H1[0]), scipy.linalg.expm(-0.5 * dt * H1[1])])

@@ -79,6 +79,115 @@ class SingleDetTrial(object):
     rot_hs_pot = rot_chol
 
 
+def _adjugate(S):
+    """adj(S) = det(S) S^-1, computed through the SVD so that it is also defined for singular S
+    (orthogonal determinants): adj(S) = det(U) det(V^H) V adj(Sigma) U^H."""
+    n = S.shape[0]
+    if n == 0:
+        return numpy.zeros((0, 0), dtype=numpy.complex128)
+    U, sv, Vh = numpy.linalg.svd(S)
+    adj_sig = numpy.array([numpy.prod(numpy.delete(sv, i)) for i in range(n)])
+    return numpy.linalg.det(U) * numpy.linalg.det(Vh) * (Vh.conj().T * adj_sig).dot(U.conj().T)
+
+
+class MultiDetTrial(object):
+    """Multi-determinant trial |psi_T> = sum_d c_d |D_d>: trial_wavefunction/multi_slater.py:17-97.
+
+    ``wfn`` is ``(coeffs, psi[ndet, M, na+nb])`` (non-orthogonal expansion) or
+    ``(coeffs, occa, occb)`` (particle-hole expansion over an orthonormal orbital set,
+    multi_slater.py:169-190).  Set-up only: the per-determinant half-rotated Cholesky vectors are
+    stacked as in the reference (``_rchol[d * M (na+nb) : ...]``, multi_slater.py:370-409)."""
+
+    def __init__(self, system, wfn, init=None, name="MultiSlater"):
+        self.name = name
+        self.type = name
+        na, nb, M = system.nup, system.ndown, system.nbasis
+        self._nalpha, self._nbeta, self._nbasis = na, nb, M
+        if len(wfn) == 3:
+            coeffs, occa, occb = wfn
+            I = numpy.eye(M, dtype=numpy.complex128)
+            self.psi = numpy.zeros((len(coeffs), M, na + nb), dtype=numpy.complex128)
+            for d, (oa, ob) in enumerate(zip(occa, occb)):
+                self.psi[d, :, :na] = I[:, list(oa)]
+                self.psi[d, :, na:] = I[:, list(ob)]
+            self.ortho_expansion = True
+        else:
+            coeffs, psi = wfn
+            self.psi = numpy.array(psi, dtype=numpy.complex128)
+            self.ortho_expansion = False
+        self.coeffs = numpy.array(coeffs, dtype=numpy.complex128)
+        self.ndets = len(self.coeffs)
+        assert self.psi.shape == (self.ndets, M, na + nb)
+        self.G = None                                # multi_slater.py:64-66
+        self.GH = None
+        self.init = self.psi[0].copy() if init is None else numpy.array(init, dtype=numpy.complex128)
+        self.split_trial_local_energy = False
+        self._rchol = None
+        self._eri = None
+        self._UVT = None
+        self._mem_required = 0.0
+        self.le_oratio = 1.0
+        self.error = False
+        if system.name == "Generic":
+            self.half_rotate(system)
+
+    def half_rotate(self, system, comm=None):
+        M, na, nb = self._nbasis, self._nalpha, self._nbeta
+        chol = system.chol_vecs.reshape((M, M, -1))
+        nchol = chol.shape[-1]
+        per = M * (na + nb)
+        rchol = numpy.zeros((self.ndets * per, nchol), dtype=numpy.complex128)
+        for d, psi in enumerate(self.psi):
+            rchol[d * per:d * per + M * na] = numpy.tensordot(psi[:, :na].conj(), chol,
+                                                              axes=((0), (0))).reshape((na * M, nchol))
+            rchol[d * per + M * na:(d + 1) * per] = numpy.tensordot(psi[:, na:].conj(), chol,
+                                                                    axes=((0), (0))).reshape((nb * M, nchol))
+        self._rchol = rchol
+        self._rot_hs_pot = rchol
+        self._mem_required = rchol.nbytes / (1024.0 ** 3)
+
+    def rot_chol(self, idet=0, spin=None):
+        stride = self._nbasis * (self._nalpha + self._nbeta)
+        alpha = self._nbasis * self._nalpha
+        if spin is None:
+            return self._rchol[idet * stride:(idet + 1) * stride]
+        if spin == 0:
+            return self._rchol[idet * stride:idet * stride + alpha]
+        return self._rchol[idet * stride + alpha:(idet + 1) * stride]
+
+    rot_hs_pot = rot_chol
+
+    def one_body_density(self):
+        """(Gamma[M, M], denom) with contract_one_body(ints) = sum_pq ints[p, q] Gamma[p, q] / denom.
+
+        trial_wavefunction/multi_slater.py:234-257 sums cfac_ij <D_i| ints |D_j> over determinant pairs
+        with cfac_ij = conj(c_i) conj(c_j) (sic, both conjugated) and divides by sum cfac_ij <D_i|D_j>.
+        The transition elements are evaluated with the adjugate of the overlap matrix, which covers the
+        non-orthogonal branch (gab_mod_ovlp) and the orthogonal one (Slater-Condon rules,
+        estimators/ci.py:291-311) alike."""
+        na, M = self._nalpha, self._nbasis
+        gamma = numpy.zeros((M, M), dtype=numpy.complex128)
+        denom = 0.0
+        for i in range(self.ndets):
+            for j in range(self.ndets):
+                cfac = self.coeffs[i].conj() * self.coeffs[j].conj()
+                Ai, Aj = self.psi[i], self.psi[j]
+                Sa = Ai[:, :na].conj().T.dot(Aj[:, :na])
+                Sb = Ai[:, na:].conj().T.dot(Aj[:, na:])
+                da = numpy.linalg.det(Sa) if Sa.size else 1.0
+                db = numpy.linalg.det(Sb) if Sb.size else 1.0
+                # <D_i| p^+ q |D_j> = [A_j adj(S) A_i^H]_{q p} times the other spin's overlap
+                ta = Aj[:, :na].dot(_adjugate(Sa)).dot(Ai[:, :na].conj().T)
+                tb = Aj[:, na:].dot(_adjugate(Sb)).dot(Ai[:, na:].conj().T)
+                gamma += cfac * (ta.T * db + tb.T * da)
+                denom += cfac * da * db
+        return gamma, denom
+
+    def contract_one_body(self, ints):
+        gamma, denom = self.one_body_density()
+        return numpy.dot(numpy.asarray(ints).ravel(), gamma.ravel()) / denom
+
+
 def rhf_trial_generic(system):
     """RHF-like trial for the synthetic generic Hamiltonian: lowest eigenvectors
     of h1e."""

@@ -114,6 +114,12 @@ class WalkerView(object):
         self._h.phi_version += 1
 
     @property
+    def weights(self):
+        """MultiDetWalker.weights (walkers/multi_det.py:226): conj(c_d) <D_d|phi> per determinant."""
+        self._h._ensure_greens()
+        return self._h.dev.det_weights()[self._i]
+
+    @property
     def Gmod(self):
         self._h._ensure_greens()
         gh = self._h.dev.get(L.F_GHALF, self._i, 1)[0]
@@ -177,10 +183,9 @@ class Walkers(object):
             raise NotImplementedError("use_log_shift is not supported")
         if nbp is not None:
             raise NotImplementedError("back-propagation field history is not on the device path yet")
-        if getattr(trial, 'ndets', 1) != 1:
-            raise NotImplementedError("multi-determinant walkers are not on the device path yet")
-        self.walker_type = 'SD'
-        if getattr(trial, 'name', '') == 'MultiSlater' and numpy.asarray(trial.psi).ndim == 3:
+        self.walker_type = 'SD' if getattr(trial, 'ndets', 1) == 1 else 'MSD'     # walkers/handler.py:53-68
+        if (self.walker_type == 'SD' and getattr(trial, 'name', '') == 'MultiSlater'
+                and numpy.asarray(trial.psi).ndim == 3):
             trial.psi = trial.psi[0]                       # walkers/handler.py:61
         self.pcont_method = walker_opts.get('population_control', 'comb')
         if self.pcont_method != 'comb':
@@ -205,7 +210,11 @@ class Walkers(object):
         self._det = None
         self._energy = None
         # initial population: trial.init, weight walker_opts['weight'] (walkers/walker.py:24-29)
-        init = numpy.asarray(getattr(trial, 'init', trial_psi(trial)), dtype=numpy.complex128)
+        init = getattr(trial, 'init', None)
+        if init is None:
+            init = trial_psi(trial)
+            init = init[0] if init.ndim == 3 else init
+        init = numpy.asarray(init, dtype=numpy.complex128)
         phi0 = numpy.broadcast_to(init, (self.nw,) + init.shape).copy()
         self.dev.set(L.F_PHI, phi0)
         w0 = walker_opts.get('weight', 1.0)

@@ -139,3 +139,13 @@ def test_traj_ueg(golden, monkeypatch):
     est = replay(d, s, t, {}, monkeypatch)
     assert est[2].real == pytest.approx(16.33039729324558, rel=1e-8)         # qmc/tests/test_afqmc.py:87
     assert est[0].real == pytest.approx(9.75405059997262, rel=1e-8)
+
+
+def test_traj_msd(golden, monkeypatch):
+    """the unchanged driver with a 3-determinant non-orthogonal trial
+    (walkers/multi_det.py, propagation/generic.py:154-157, estimators/mixed.py:439-448)."""
+    d = golden('traj_msd.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.MultiDetTrial(s, (d['coeffs'], d['psi']), init=d['phi0'][0])
+    replay(d, s, t, {}, monkeypatch)
