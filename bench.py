@@ -140,7 +140,9 @@ def main():
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR,
          8.0 * M * M * nt * (6 + 2) * nw),
         ("exx_kernel (Cholesky exchange energy)", L.K_EXCHANGE, exchange_flops_per_walker(M, K, N, N) * nw),
-        ("mfma_gemm_wg_kernel<VhsProb> (HS potential)", L.K_VHS, 4.0 * M * M * K * nw),
+        # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted
+        ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS,
+         4.0 * (M * (M + 1) // 2) * K * nw),
         ("mfma_gemm_wg_kernel<ForceBiasProb> (force bias)", L.K_FORCE_BIAS, 4.0 * K * nt * M * nw),
     ]
     rows = []

@@ -71,7 +71,7 @@ void free_dets(afq_handle *h) {
 
 void free_system(afq_handle *h) {
     free_dets(h);
-    dev_free(h->hs_pot); dev_free(h->rchol_re); dev_free(h->rchol_im);
+    dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     dev_free(h->H1); dev_free(h->rH1);
     dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val);
@@ -259,15 +259,39 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
     if (rc) return rc;
     h->ecore = ecore;
     const size_t mm = (size_t)M * M, nq = (size_t)h->nt * M;
-    h->ld_hs = (long)((mm + 1) & ~(size_t)1);
-    h->ld_rc = (long)((K + 1) & ~1);
-    {   // hs_pot^T : [K, ld_hs] so that a VHS B-fragment is contiguous (even, zero-padded rows:
-        // the LDS-DMA path moves 16-byte pairs of doubles)
-        std::vector<double> t((size_t)K * h->ld_hs, 0.0);
-        for (size_t r = 0; r < mm; ++r)
-            for (int n = 0; n < K; ++n) t[(size_t)n * h->ld_hs + r] = hs_pot[r * K + n];
-        if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
+    {   // hs_pot^T : [K, ld_hs] so that a VHS B-fragment is contiguous (even, zero-padded rows: the
+        // LDS-DMA path moves 16-byte pairs of doubles).  Cholesky matrices of real orbitals are
+        // symmetric in (p, q); then only the columns p <= q are kept and the VHS GEMM does half the work.
+        bool sym = getenv("AFQ_VHS_FULL") == nullptr;
+        for (int p = 0; p < M && sym; ++p)
+            for (int q = p + 1; q < M && sym; ++q) {
+                const double *a = hs_pot + ((size_t)p * M + q) * K, *b = hs_pot + ((size_t)q * M + p) * K;
+                for (int n = 0; n < K; ++n) if (a[n] != b[n]) { sym = false; break; }
+            }
+        h->hs_sym = sym;
+        if (sym) {
+            const size_t np = (size_t)M * (M + 1) / 2;
+            h->ld_hs = (long)((np + 1) & ~(size_t)1);
+            std::vector<double> t((size_t)K * h->ld_hs, 0.0);
+            std::vector<int> pq(2 * np);
+            size_t c = 0;
+            for (int p = 0; p < M; ++p)
+                for (int q = p; q < M; ++q, ++c) {
+                    pq[2 * c] = p; pq[2 * c + 1] = q;
+                    const double *a = hs_pot + ((size_t)p * M + q) * K;
+                    for (int n = 0; n < K; ++n) t[(size_t)n * h->ld_hs + c] = a[n];
+                }
+            if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
+            if ((rc = dev_upload(h, &h->hs_pair, pq.data(), np))) return rc;
+        } else {
+            h->ld_hs = (long)((mm + 1) & ~(size_t)1);
+            std::vector<double> t((size_t)K * h->ld_hs, 0.0);
+            for (size_t r = 0; r < mm; ++r)
+                for (int n = 0; n < K; ++n) t[(size_t)n * h->ld_hs + r] = hs_pot[r * K + n];
+            if ((rc = dev_upload(h, &h->hs_pot, t.data(), t.size()))) return rc;
+        }
     }
+    h->ld_rc = (long)((K + 1) & ~1);
     if ((rc = upload_rchol(h, rchol, rchol_is_real(rchol, nq * K)))) return rc;
     if ((rc = dev_upload(h, &h->H1, H1, 2 * mm))) return rc;
     cache_of(h)->H1.assign(H1, H1 + 4 * mm);

@@ -46,6 +46,8 @@ struct afq_handle {
     double ecore = 0.0;
     // generic
     double *hs_pot = nullptr;       // f64, TRANSPOSED: [K, ld_hs] with ld_hs = M*M rounded up to even (zero pad)
+    bool hs_sym = false;            // L_n symmetric: hs_pot holds only the columns (p <= q), [K, ld_hs]
+    int2 *hs_pair = nullptr;        // [M(M+1)/2] (p, q) of every packed column
     long ld_hs = 0, ld_rc = 0;      // leading dimensions of hs_pot^T and of rchol_re/im (K rounded up to even)
     bool rchol_real = true;
     double *rchol_re = nullptr;     // f64 [nt*M, ld_rc]

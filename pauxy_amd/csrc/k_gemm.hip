@@ -192,6 +192,11 @@ struct VhsProb {
     cplx *out;                       // [nw, M*M]
     double sqrt_dt;
     const int *alive;
+    // symmetric Cholesky matrices (L_n[p,q] == L_n[q,p], the usual case): only the M(M+1)/2 columns
+    // p <= q are contracted and every result is stored at (p,q) and (q,p); pair[col] = (p, q)
+    const int2 *pair;
+    int M;
+    long mm;
     __device__ bool active(int) const { return true; }
     __device__ cplx loadA(int, int row, int k) const { return xs[(long)row * kdim + k]; }
     __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * ldb + col], 0.0); }
@@ -199,21 +204,42 @@ struct VhsProb {
     __device__ const double *ptrB(int, int k, int col) const { return hsT + (long)k * ldb + col; }
     __device__ void store(int, int row, int col, double re, double im) const {
         // i*sqrt(dt)*(re + i im)
-        out[(long)row * cols + col] = cmake(-sqrt_dt * im, sqrt_dt * re);
+        const cplx v = cmake(-sqrt_dt * im, sqrt_dt * re);
+        if (pair) {
+            const int2 pq = pair[col];
+            cplx *o = out + (long)row * mm;
+            o[pq.x * M + pq.y] = v;
+            if (pq.x != pq.y) o[pq.y * M + pq.x] = v;
+        } else {
+            out[(long)row * mm + col] = v;
+        }
     }
 };
 
 int k_vhs_generic(afq_handle *h) {
     VhsProb p;
-    p.batch = 1; p.rows = h->nw; p.cols = h->M * h->M; p.kdim = h->K;
+    p.batch = 1; p.rows = h->nw; p.cols = h->hs_sym ? h->M * (h->M + 1) / 2 : h->M * h->M; p.kdim = h->K;
     p.xs = h->xs; p.hsT = h->hs_pot; p.ldb = h->ld_hs; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
+    p.pair = h->hs_sym ? h->hs_pair : nullptr; p.M = h->M; p.mm = (long)h->M * h->M;
     if (h->nw > 32 && !h->no_ring) {
         // work-group tile 64 walkers x 160 (p,q) pairs; hs_pot^T panels shared through the LDS ring
-        static const int cfg = getenv("AFQ_VHS_CFG") ? atoi(getenv("AFQ_VHS_CFG")) : 0;
+        // measured at C3 (tools/sweep_vhs_cfg.sh): packed symmetric columns 75.8 us with the 32 x 160 tile
+        // (cfg 7), 116 us with the 64 x 160 tile that is best for the full M^2 columns (100 us)
+        static const int cfg_env = getenv("AFQ_VHS_CFG") ? atoi(getenv("AFQ_VHS_CFG")) : -1;
+        const int cfg = cfg_env >= 0 ? cfg_env : (h->hs_sym ? 7 : 0);
         if (cfg == 1) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 4) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 5) AFQ_HIP(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 6) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 1, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 7) {
+            KernelTrace kt(h, AFQ_K_VHS);
+            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        }
+        else if (cfg == 8) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 9) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 10) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else {
             KernelTrace kt(h, AFQ_K_VHS);
             AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));

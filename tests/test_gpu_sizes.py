@@ -81,3 +81,19 @@ def test_midsize_generic(M, K, na, nb, nw, cplx):
         close(q[i], p)
         close(detR[i], d)
     dev.close()
+
+
+def test_vhs_nonsymmetric_cholesky():
+    """The HS-potential GEMM contracts only the columns p <= q when every L_n is symmetric (the
+    usual case, all other generic tests); a non-symmetric hs_pot must take the full-column path."""
+    model, rng = build(21, 30, 4, 3, False)
+    hs = model.hs_pot.copy()
+    hs[5 * 21 + 7, :] += 0.01 * rng.rand(30)            # L_n[5,7] != L_n[7,5]
+    model.hs_pot = hs
+    nw = 40
+    dev = make_device(model, nw)
+    xs = rng.normal(size=(nw, 30)) + 1j * rng.normal(size=(nw, 30))
+    vhs = dev.vhs(xs)
+    close(vhs[:, 0], numpy.array([model.vhs(x) for x in xs]))
+    assert abs(vhs[0, 0, 5, 7] - vhs[0, 0, 7, 5]) > 1e-6
+    dev.close()
