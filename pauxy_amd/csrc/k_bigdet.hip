@@ -12,6 +12,7 @@
 // This replaces the generic work-group LU + per-column substitution kernel, which is latency bound
 // on global memory (14.7 ms per call at C4); the pieces above take ~0.1 + 0.3 + 0.15 ms.
 #include "mfma_gemm_wg.h"
+#include "gj_wave.h"
 
 #define GJ_N 128
 
@@ -478,6 +479,53 @@ __global__ __launch_bounds__(512) void chol_linv_kernel(CholArgs a) {
     }
 }
 
+// n <= 32: one wave per matrix, four matrices per work-group, everything in registers (gj_wave.h)
+__global__ __launch_bounds__(256) void chol_small_kernel(CholArgs a, int nmat) {
+    __shared__ cplx rowk_s[4][32];
+    __shared__ double piv_s[4][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= nmat) return;
+    const int n = __builtin_amdgcn_readfirstlane((b & 1) ? a.nb : a.na);
+    const cplx *S = a.S + (long)b * a.ld * a.ld;
+    cplx *Tt = a.Tt + (long)b * a.ld * a.ld;
+    cplx *rowk = rowk_s[wave];
+    double *piv = piv_s[wave];
+    const int h = lane >> 5, r = lane & 31;
+    double vr[16], vi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = 16 * h + j;
+        const cplx t = (r < n && c < n) ? S[(long)r * a.ld + c] : cmake(0.0, 0.0);
+        vr[j] = t.x; vi[j] = t.y;
+    }
+    if (lane < 32) piv[lane] = 1.0;
+    bool bad = false;
+    __builtin_amdgcn_wave_barrier();
+    const int nit = (n + 7) >> 3;
+    for (int it = 0; it < nit; ++it) chol_block8(vr, vi, it, n, lane, rowk, piv, bad);
+    __builtin_amdgcn_wave_barrier();
+    if (r < n) {
+        const int rot = 8 * (nit & 1);
+        const double rs = 1.0 / sqrt(piv[r]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = 16 * h + ((j + rot) & 15);
+            if (c >= n) continue;
+            cplx t = cmake(0.0, 0.0);
+            if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
+            else if (c == r) t = cmake(rs, 0.0);
+            Tt[(long)r * a.ld + c] = t;
+        }
+    }
+    double l = lane < 32 ? log(piv[lane]) : 0.0;
+    for (int o = 16; o > 0; o >>= 1) l += __shfl_down(l, o);
+    if (lane == 0) {
+        a.logd[b] = 0.5 * l;
+        if (bad) a.fail[b >> 1] = 1;
+    }
+}
+
 __global__ void qr_finish_kernel(const double *logd, const int *fail, double *detR, cplx *ot, double *weight,
                                  int nw, int free_projection) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,7 +561,8 @@ int k_reortho_big(afq_handle *h) {
             CholArgs a;
             a.na = h->na; a.nb = h->nb; a.ld = nmax;
             a.S = h->big_ws; a.Tt = h->big_ws2; a.logd = h->qr_logd + (size_t)pass * nb2; a.fail = h->qr_fail;
-            hipLaunchKernelGGL(chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            if (nmax <= 32) hipLaunchKernelGGL(chol_small_kernel, dim3((nb2 + 3) / 4), dim3(256), 0, h->stream, a, nb2);
+            else hipLaunchKernelGGL(chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
             AFQ_HIP(h, hipGetLastError());
         }
         {

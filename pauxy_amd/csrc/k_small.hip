@@ -5,6 +5,7 @@
 // LDS when they fit and in a global workspace otherwise.
 #include <cstdlib>
 #include "mfma_gemm.h"
+#include "gj_wave.h"
 
 #define NTHR 256
 
@@ -160,154 +161,6 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
     }
 }
 
-
-// --------------------------------------------------------------------------
-// Register-resident Gauss-Jordan inverse of an n x n complex matrix, n <= 32, by ONE wave:
-// lane (h = lane >> 5, r = lane & 31) keeps row r, columns 16 h .. 16 h + 15, in VGPRs.  Per pivot
-// step (fully unrolled, so every register index is static): the half that owns column k hands it
-// to the other half with v_permlane32_swap, a DPP wave maximum of a packed (|pivot|, row) key picks
-// the pivot row among the rows not used yet (implicit pivoting: no row swaps), the pivot row crosses
-// the wave through 32 x 16 bytes of LDS, and every lane updates its 16 entries.  The division by the
-// pivot is deferred: row p is only scaled once, at the end.  No barrier, no atomics; the matrix never
-// returns to LDS until the inverse is stored un-permuted (A^-1[step(i)][prow[j]] = W[i][j]).
-// det A = sign(prow) prod_k d_k is returned as mantissa / binary exponent.
-__device__ inline unsigned gj_wave_max_u32(unsigned v) {
-#define AFQ_DPP_MAX(ctrl, rmask)                                                                         \
-    { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);      \
-      v = v > t ? v : t; }
-    AFQ_DPP_MAX(0x111, 0xf) AFQ_DPP_MAX(0x112, 0xf) AFQ_DPP_MAX(0x114, 0xf) AFQ_DPP_MAX(0x118, 0xf)
-    AFQ_DPP_MAX(0x142, 0xa) AFQ_DPP_MAX(0x143, 0xc)
-#undef AFQ_DPP_MAX
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// value of half hk (lanes 32 hk ..) handed to both halves (hk wave-uniform)
-__device__ inline double gj_bcast_half(double x, int hk) {
-    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)(hk ? b[1] : b[0]), (int)(hk ? a[1] : a[0]));
-}
-
-// Eight pivot steps k = 8 it .. 8 it + 7 with static register indices: physical register u holds
-// the column that is active at step u of the block (the caller swaps the two halves of the
-// register array after every block).  The body is a loop of <= 4 iterations over this block so that
-// the code (8 steps ~ 14 KB) stays in the instruction cache instead of streaming 32 unrolled steps.
-__device__ inline void gj_block8(double (&vr)[16], double (&vi)[16], int it, int n, int lane, bool &used,
-                                 double &sx, double &sy, int &mystep, cplx *rowk, cplx *piv, int *prow) {
-    const int h = lane >> 5, r = lane & 31;
-    const int hk = it >> 1;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = 8 * it + u;
-        if (k < n) {
-            // 1. column k to every lane of its row
-            const double fx = gj_bcast_half(vr[u], hk), fy = gj_bcast_half(vi[u], hk);
-            // 2. pivot row: largest fp32-rounded |re| + |im| among unused rows, ties -> lowest row
-            const unsigned mb = __float_as_uint((float)(fabs(fx) + fabs(fy)));
-            const unsigned key = (used || r >= n) ? 0u : ((((mb >> 6) + 1u) << 5) | (unsigned)(31 - r));
-            const int p = 31 - (int)(gj_wave_max_u32(key) & 31u);
-            const bool isp = r == p;
-            used = used || isp;
-            // 3. slot (., k) becomes the identity column of the pivot row; the (unscaled) pivot row goes
-            //    to LDS first so that its round trip overlaps the reciprocal below
-            if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
-            if (isp) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) rowk[16 * h + j] = cmake(vr[j], vi[j]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            cplx rk[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) rk[j] = rowk[16 * h + j];
-            __builtin_amdgcn_sched_barrier(0);
-            // 4. pivot value (uniform), its reciprocal, multipliers (zero for the pivot row itself)
-            const double dx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), p),
-                                               __builtin_amdgcn_readlane(__double2loint(fx), p));
-            const double dy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fy), p),
-                                               __builtin_amdgcn_readlane(__double2loint(fy), p));
-            // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is a 12-deep
-            // dependent chain on the per-pivot critical path; this one is 5 deep, < 1 ulp off)
-            const double nn = dx * dx + dy * dy;
-            double dn = __builtin_amdgcn_rcp(nn);
-            dn = fma(fma(-nn, dn, 1.0), dn, dn);
-            dn = fma(fma(-nn, dn, 1.0), dn, dn);
-            const double ix = dx * dn, iy = -dy * dn;
-            if (lane == 0) { piv[k] = cmake(dx, dy); prow[k] = p; }
-            if (isp) { sx = ix; sy = iy; mystep = k; }
-            const double mx = isp ? 0.0 : fx * ix - fy * iy, my = isp ? 0.0 : fx * iy + fy * ix;
-            __builtin_amdgcn_sched_barrier(0);
-            // 5. eliminate
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                vr[j] = fma(-mx, rk[j].x, vr[j]); vr[j] = fma(my, rk[j].y, vr[j]);
-                vi[j] = fma(-mx, rk[j].y, vi[j]); vi[j] = fma(-my, rk[j].x, vi[j]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double t = vr[j]; vr[j] = vr[j + 8]; vr[j + 8] = t;
-        t = vi[j]; vi[j] = vi[j + 8]; vi[j + 8] = t;
-    }
-}
-
-// O: n x n row-major in LDS (overwritten with the inverse when write_inverse); returns det via ph / la
-__device__ inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
-                                 cplx &ph, int &la) {
-    const int h = lane >> 5, r = lane & 31;
-    double vr[16], vi[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c = 16 * h + j;
-        const cplx t = (r < n && c < n) ? O[r * n + c] : cmake(0.0, 0.0);
-        vr[j] = t.x; vi[j] = t.y;
-    }
-    if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
-    bool used = false;
-    double sx = 1.0, sy = 0.0;
-    int mystep = r;
-    __builtin_amdgcn_wave_barrier();
-    n = __builtin_amdgcn_readfirstlane(n);
-    const int nit = (n + 7) >> 3;
-    for (int it = 0; it < nit; ++it) gj_block8(vr, vi, it, n, lane, used, sx, sy, mystep, rowk, piv, prow);
-    __builtin_amdgcn_wave_barrier();
-    if (write_inverse && r < n) {
-        const int rot = 8 * (nit & 1);           // the register halves were swapped nit times
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = 16 * h + ((j + rot) & 15);
-            if (c < n) O[mystep * n + prow[c]] = cmake(vr[j] * sx - vi[j] * sy, vr[j] * sy + vi[j] * sx);
-        }
-    }
-    // determinant: product of the pivots (lanes 0..31, normalised after every multiply) and the
-    // parity of the pivot permutation from its inversion count
-    const cplx d = piv[lane & 31];
-    double px = d.x, py = d.y;
-    int e;
-    (void)frexp(fmax(fabs(px), fabs(py)), &e);
-    px = ldexp(px, -e); py = ldexp(py, -e);
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const double qx = __shfl_xor(px, off), qy = __shfl_xor(py, off);
-        const int qe = __shfl_xor(e, off);
-        const double tx = px * qx - py * qy, ty = px * qy + py * qx;
-        int e2;
-        (void)frexp(fmax(fabs(tx), fabs(ty)), &e2);
-        px = ldexp(tx, -e2); py = ldexp(ty, -e2);
-        e += qe + e2;
-    }
-    int inv = 0;
-    if (lane < n) {
-        const int pr = prow[lane];
-        for (int j = lane + 1; j < n; ++j) inv += prow[j] < pr ? 1 : 0;
-    }
-    const unsigned long long odd = __ballot((inv & 1) != 0);
-    const double sg = (__popcll(odd) & 1) ? -1.0 : 1.0;
-    ph = cmake(sg * px, sg * py);
-    la = e;
-}
 
 // --------------------------------------------------------------------------
 // Fast path for N <= 45 electrons per spin (the overlap matrix and its inverse
@@ -958,7 +811,10 @@ int k_reortho(afq_handle *h) {
     a.only = nullptr;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     static const bool no_cholqr = getenv("AFQ_NO_CHOLQR") != nullptr;
-    if (k_greens_big_supported(h) && !no_cholqr) {
+    // Cholesky-QR2 on the GEMM engines: always for 45 < N <= 128; for smaller N once the population is
+    // large enough that seven launches beat the one latency-bound Gram-Schmidt work-group per walker
+    const bool small_ok = nmax <= 45 && h->nb > 0 && !h->no_ring && h->nw >= 64 && h->M >= 32;
+    if ((k_greens_big_supported(h) || small_ok) && !no_cholqr) {
         int rc = k_reortho_big(h);
         if (rc) return rc;
         a.only = h->qr_fail;
