@@ -162,11 +162,14 @@ int afq_apply_exponential(afq_handle *h, const double *vhs);         /* phi <- T
 int afq_kinetic(afq_handle *h);                                      /* phi <- BH1 phi */
 
 /* ---- driver glue that must stay on the device between steps --------------- */
-/* qmc/afqmc.py:235-236: weight > frac*total_weight -> frac*total_weight        */
+/* qmc/afqmc.py:235-236: weight > frac*total_weight -> frac*total_weight.  A negative
+ * total_weight means "the total weight the last afq_popcontrol_comb measured" (kept on the
+ * device; the population size before the first comb), which needs no host round trip.     */
 int afq_cap_weights(afq_handle *h, double frac, double total_weight);
 /* walkers/handler.py:225-338 for a single rank: rescale, comb with the uniform
  * r, clone/kill, weights reset to 1.  parent_ix int32[nw] out (may be NULL);
- * total_weight_out f64 (may be NULL).                                          */
+ * total_weight_out f64 (may be NULL).  With BOTH outputs NULL the call only enqueues
+ * work (no host synchronisation, no AFQ_EWEIGHT check).                         */
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
                         int32_t *parent_ix, double *total_weight_out);
 /* multi-rank building blocks: scale weights by 1/scale saving unscaled_weight

@@ -477,6 +477,10 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
 #undef A_
     AFQ_HIP(h, hipMalloc(&h->pack_tmp, std::max((size_t)nw * 2 * sizeof(int), (size_t)4096)));
     h->nw = nw;
+    {   // walker.total_weight starts as the population size (walkers/handler.py:164)
+        const double tw0 = (double)nw;
+        AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
+    }
     // defaults of walkers/walker.py:24-61
     std::vector<double> one(nw, 1.0), zero2(2 * (size_t)nw, 0.0), one2(2 * (size_t)nw, 0.0);
     for (int i = 0; i < nw; ++i) one2[2 * i] = 1.0;
@@ -623,7 +627,7 @@ static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf) {
     return k_msd_combine(h, det_out);
 }
 
-static int force_bias(afq_handle *h) {
+static int force_bias(afq_handle *h, bool with_xbar = true) {
     int rc;
     if (h->flags & AFQ_PROP_FORCE_BIAS) {
         if (h->kind == AFQ_SYS_GENERIC) {
@@ -635,7 +639,7 @@ static int force_bias(afq_handle *h) {
         }
         else if (h->kind == AFQ_SYS_UEG) { if ((rc = k_vbias_ueg(h))) return rc; }
     }
-    return k_xbar(h);
+    return with_xbar ? k_xbar(h) : AFQ_OK;
 }
 
 static int build_vhs(afq_handle *h) {
@@ -656,11 +660,11 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
-    if ((rc = k_alive(h))) return rc;
     if (xi) {
+        if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
     } else {
-        if ((rc = k_rng_normal(h))) return rc;
+        if ((rc = k_rng_normal(h))) return rc;           // draws the fields and sets the alive flags
     }
     const bool fp = (h->flags & AFQ_PROP_FREE_PROJECTION) != 0;
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
@@ -689,8 +693,8 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (!fused) { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }   // :251
     {
         PhaseTimer t(h, T_FB);                                                      // :133-158
-        if ((rc = force_bias(h))) return rc;
-        if ((rc = k_fields(h))) return rc;
+        if ((rc = force_bias(h, false))) return rc;
+        if ((rc = k_xbar_fields(h))) return rc;
     }
     { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                // :161
     if (fused) {
@@ -870,10 +874,12 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *
     if (rc) return rc;
     if (h->nw == 1) return AFQ_OK;                       // handler.py:226-227
     if ((rc = k_comb(h, r, target_weight))) return rc;
+    if (!parent_ix && !total_weight_out) return AFQ_OK;  // asynchronous: nothing read back, no host sync
     double sc[2];
     if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;
     if (total_weight_out) *total_weight_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8");
+    if (!parent_ix) return AFQ_OK;
     return copy_out(h, parent_ix, h->parent_ix, sizeof(int) * h->nw);
 }
 

@@ -223,6 +223,7 @@ int k_overlap(afq_handle *h, cplx *det_out);                // det(psi^H phi)
 int k_fields(afq_handle *h);                                // vbias -> xbar(clipped), xs, cmf, cfb
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d, cplx *cfb_d);
 int k_xbar(afq_handle *h);
+int k_xbar_fields(afq_handle *h);                           // xbar + clip + shift in one launch
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch
 int k_update_weight(afq_handle *h, cplx eshift);

@@ -464,10 +464,7 @@ struct XbarArgs {
     const cplx *detw;       // [nw, ndet]
 };
 
-__global__ void xbar_kernel(XbarArgs a) {
-    const int w = blockIdx.y;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= a.K) return;
+__device__ inline cplx xbar_value(const XbarArgs &a, int w, int n) {
     cplx out = cmake(0.0, 0.0);
     if (a.flags & AFQ_PROP_FORCE_BIAS) {
         if (a.kind == AFQ_SYS_GENERIC) {
@@ -487,7 +484,16 @@ __global__ void xbar_kernel(XbarArgs a) {
                 }
                 v = cdiv(num, den);
             } else {
-                for (int b = 0; b < 2 * a.nsplit; ++b) v = cadd(v, a.vbias[((long)b * a.nw + w) * a.K + n]);
+                // fixed summation order, four partial slices in flight at a time
+                const int nb2 = 2 * a.nsplit;
+                const cplx *vb = a.vbias + (long)w * a.K + n;
+                const long bs = (long)a.nw * a.K;
+                int b = 0;
+                for (; b + 3 < nb2; b += 4) {
+                    const cplx t0 = vb[b * bs], t1 = vb[(b + 1) * bs], t2 = vb[(b + 2) * bs], t3 = vb[(b + 3) * bs];
+                    v = cadd(cadd(cadd(cadd(v, t0), t1), t2), t3);
+                }
+                for (; b < nb2; ++b) v = cadd(v, vb[b * bs]);
             }
             const cplx m = a.mf[n];
             out = cmake(-a.sqrt_dt * (-v.y - m.x), -a.sqrt_dt * (v.x - m.y));
@@ -517,10 +523,17 @@ __global__ void xbar_kernel(XbarArgs a) {
             out = cmake(-a.sqrt_dt * v.x, -a.sqrt_dt * v.y);
         }
     }
-    a.xbar[(long)w * a.K + n] = out;
+    return out;
 }
 
-int k_xbar(afq_handle *h) {
+__global__ void xbar_kernel(XbarArgs a) {
+    const int w = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.K) return;
+    a.xbar[(long)w * a.K + n] = xbar_value(a, w, n);
+}
+
+static XbarArgs xbar_args(afq_handle *h) {
     XbarArgs a;
     a.kind = h->kind; a.flags = h->flags; a.M = h->M; a.K = h->K; a.na = h->na; a.nb = h->nb;
     a.nt = h->nt; a.nw = h->nw; a.nsplit = h->fb_split; a.nq = h->nq;
@@ -528,6 +541,11 @@ int k_xbar(afq_handle *h) {
     a.vbias = h->vbias; a.mf = h->mf_shift; a.ghalf = h->ghalf; a.psi = h->psi; a.xbar = h->xbar;
     a.ndet = h->ndet; a.detw = h->detw; a.det_stride = (long)2 * h->fb_split * h->nw * h->K;
     if (h->ndet > 1) a.vbias = h->vbias_all;
+    return a;
+}
+
+int k_xbar(afq_handle *h) {
+    const XbarArgs a = xbar_args(h);
     hipLaunchKernelGGL(xbar_kernel, dim3((h->K + 127) / 128, h->nw), dim3(128), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
@@ -589,16 +607,19 @@ __device__ inline double block_sum(double v, double *red) {
 }
 
 // propagation/continuous.py:140-158: clip, shift, constant factors
+// FUSED: the force bias of (w, n) is evaluated here from the contraction output (xbar_value) instead
+// of being read back from a separate xbar_kernel launch
+template <bool FUSED>
 __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, const double *xi, cplx *xbar,
                                                       const cplx *mf, cplx *xs, cplx *cmf, cplx *cfb,
-                                                      unsigned long long *counters, const int *alive) {
+                                                      unsigned long long *counters, const int *alive, XbarArgs xa) {
     __shared__ double red[8];
     const int w = blockIdx.x;
     if (alive && !alive[w]) return;
     double s_mf_r = 0, s_mf_i = 0, s_xx_r = 0, s_xx_i = 0, s_bb_r = 0, s_bb_i = 0;
     unsigned int ntrig = 0;
     for (int n = threadIdx.x; n < K; n += NTHR) {
-        cplx b = xbar[(long)w * K + n];
+        cplx b = FUSED ? xbar_value(xa, w, n) : xbar[(long)w * K + n];
         const double ab = hypot(b.x, b.y);
         if (ab > 1.0) { b.x /= ab; b.y /= ab; ++ntrig; }
         const double x = xi[(long)w * K + n];
@@ -624,17 +645,25 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
 }
 
 int k_fields(afq_handle *h) {
-    hipLaunchKernelGGL(fields_kernel, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
-                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive);
+    hipLaunchKernelGGL(fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, XbarArgs());
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// force bias from the contraction output + clip + shift in one launch (the step's hot path)
+int k_xbar_fields(afq_handle *h) {
+    hipLaunchKernelGGL(fields_kernel<true>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xbar_args(h));
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }
 
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d,
                       cplx *cfb_d) {
-    hipLaunchKernelGGL(fields_kernel, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
+    hipLaunchKernelGGL(fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
                        (cplx *)xbar_d, h->mf_shift, xs_d, cmf_d, cfb_d, (unsigned long long *)nullptr,
-                       (const int *)nullptr);
+                       (const int *)nullptr, XbarArgs());
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }
@@ -833,7 +862,19 @@ __global__ void cap_kernel(double *weight, int nw, double cap) {
     if (w < nw && fabs(weight[w]) > cap) weight[w] = cap;       // qmc/afqmc.py:235-236
 }
 
+__global__ void cap_dev_kernel(double *weight, int nw, double frac, const double *scal) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const double cap = frac * scal[0];                          // total weight of the last comb
+    if (w < nw && fabs(weight[w]) > cap) weight[w] = cap;
+}
+
 int k_cap_weights(afq_handle *h, double frac, double total_weight) {
+    if (total_weight < 0.0) {
+        hipLaunchKernelGGL(cap_dev_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
+                           frac, h->scal);
+        AFQ_HIP(h, hipGetLastError());
+        return AFQ_OK;
+    }
     hipLaunchKernelGGL(cap_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
                        frac * total_weight);
     AFQ_HIP(h, hipGetLastError());
@@ -867,57 +908,87 @@ int k_reset_weights(afq_handle *h) {
 // walk over the comb teeth are inherently sequential and must reproduce the
 // reference's left-to-right double additions, so one thread does them (nw adds).
 // scal[0] = total weight (before scaling), scal[1] = number of (clone, kill) pairs.
+// exclusive prefix sum of one value per thread over a 256-thread work-group (wave shuffles + 4 wave
+// totals through LDS); *total receives the sum of all 256 values
+template <class T> __device__ inline T block_excl_scan256(T v, T *wtot, T *total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                 // wtot may still be read from a previous call
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) base += wtot[w]; tot += wtot[w]; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// Comb population control, walkers/handler.py:225-338, decided by one work-group: every thread owns a
+// contiguous chunk of walkers (sequential sums inside the chunk, prefix scans across chunks), every
+// comb tooth is located in the cumulative weights by bisection, and the clone / kill lists are
+// compacted with prefix counts so that the j-th walker with multiplicity > 1 overwrites the j-th walker
+// with multiplicity 0 -- exactly the zip(clone, kill) pairing (one copy per parent, :295-301).
 __global__ __launch_bounds__(256) void comb_plan_kernel(double *weight, double *unscaled, int nw, double r,
                                                          double target, int *parent_ix, int *pairs,
                                                          double *scal) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *aw = (double *)smem;              // |w| then |w| / scale
-    int *pix = (int *)(aw + nw);
-    __shared__ double s_total, s_scale;
+    double *cs = (double *)smem;              // |w| / scale, then its inclusive cumulative sum
+    int *pix = (int *)(cs + nw);
+    int *clone_l = pix + nw, *kill_l = clone_l + nw;
+    __shared__ double wtot_d[4];
+    __shared__ int wtot_i[4];
     const int tid = threadIdx.x;
-    for (int i = tid; i < nw; i += 256) { aw[i] = fabs(weight[i]); pix[i] = 0; }
-    __syncthreads();
-    if (tid == 0) {
-        double total = 0.0;
-        for (int i = 0; i < nw; ++i) total += aw[i];          // sum(global_weights), handler.py:233
-        s_total = total;
-        s_scale = total / target;
-        scal[0] = total;
-    }
-    __syncthreads();
-    if (s_total < 1e-8) { if (tid == 0) scal[1] = -1.0; return; }
-    const double scale = s_scale;
-    for (int i = tid; i < nw; i += 256) {
+    const int per = (nw + 255) / 256;
+    const int i0 = tid * per < nw ? tid * per : nw, i1 = (tid + 1) * per < nw ? (tid + 1) * per : nw;
+    double loc = 0.0;
+    for (int i = i0; i < i1; ++i) { const double a = fabs(weight[i]); cs[i] = a; pix[i] = 0; loc += a; }
+    double total;
+    (void)block_excl_scan256(loc, wtot_d, &total);            // sum(global_weights), handler.py:233
+    if (tid == 0) scal[0] = total;
+    if (total < 1e-8) { if (tid == 0) scal[1] = -1.0; return; }
+    const double scale = total / target;
+    loc = 0.0;
+    for (int i = i0; i < i1; ++i) {
         unscaled[i] = weight[i];                              // handler.py:245
         weight[i] = weight[i] / scale;
-        aw[i] = aw[i] / scale;                                // global_weights / scale, handler.py:248
+        const double a = cs[i] / scale;                       // global_weights / scale, handler.py:248
+        loc += a;
+        cs[i] = loc;                                          // chunk-local running sum
+    }
+    double tot2;
+    const double base = block_excl_scan256(loc, wtot_d, &tot2);   // sum(weights), handler.py:274
+    for (int i = i0; i < i1; ++i) cs[i] += base;              // numpy.cumsum(weights)
+    __syncthreads();
+    const int ntarget = (int)target;
+    const double step = tot2 / target;
+    for (int ic = tid; ic < ntarget; ic += 256) {
+        const double tooth = (ic + r) * step;
+        int lo = 0, hi = nw;                                  // smallest iw with tooth < cs[iw]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tooth < cs[mid]) hi = mid; else lo = mid + 1;
+        }
+        if (lo < nw) atomicAdd(&pix[lo], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        double tot2 = 0.0;
-        for (int i = 0; i < nw; ++i) tot2 += aw[i];           // sum(weights), handler.py:274
-        const int ntarget = (int)target;
-        const double step = tot2 / target;
-        int iw = 0, ic = 0;
-        double cprob = aw[0];                                 // running numpy.cumsum
-        while (ic < ntarget && iw < nw) {
-            const double tooth = (ic + r) * step;
-            if (tooth < cprob) { pix[iw] += 1; ++ic; }
-            else { ++iw; if (iw < nw) cprob += aw[iw]; }
-        }
-        // zip(clone, kill): handler.py:295-301
-        int ik = 0, np = 0;
-        for (int c = 0; c < nw; ++c) {
-            if (pix[c] > 1) {
-                while (ik < nw && pix[ik] != 0) ++ik;
-                if (ik >= nw) break;
-                pairs[2 * np] = c; pairs[2 * np + 1] = ik; ++np; ++ik;
-            }
-        }
-        scal[1] = (double)np;
+    int nc = 0, nk = 0;
+    for (int i = i0; i < i1; ++i) { nc += pix[i] > 1; nk += pix[i] == 0; }
+    int totc, totk;
+    int bc = block_excl_scan256(nc, wtot_i, &totc);
+    int bk = block_excl_scan256(nk, wtot_i, &totk);
+    for (int i = i0; i < i1; ++i) {
+        if (pix[i] > 1) clone_l[bc++] = i;
+        if (pix[i] == 0) kill_l[bk++] = i;
+        parent_ix[i] = pix[i];
     }
     __syncthreads();
-    for (int i = tid; i < nw; i += 256) parent_ix[i] = pix[i];
+    const int np = totc < totk ? totc : totk;
+    for (int j = tid; j < np; j += 256) { pairs[2 * j] = clone_l[j]; pairs[2 * j + 1] = kill_l[j]; }
+    if (tid == 0) scal[1] = (double)np;
 }
 
 struct CloneArgs {
@@ -942,7 +1013,7 @@ __global__ void clone_kernel(CloneArgs a) {
 
 int k_comb(afq_handle *h, double r, double target) {
     int *pairs = (int *)h->pack_tmp;
-    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + sizeof(int)) * (size_t)h->nw,
+    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + 3 * sizeof(int)) * (size_t)h->nw,
                        h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
     AFQ_HIP(h, hipGetLastError());
     CloneArgs a;
@@ -1020,9 +1091,12 @@ __device__ inline void philox_round(unsigned int &c0, unsigned int &c1, unsigned
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
 }
 
+// also refreshes the alive flags of the step (qmc/afqmc.py:232) so that the device-RNG path needs no
+// separate alive_kernel launch
 __global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, unsigned long long stream,
-                                  unsigned long long counter) {
+                                  unsigned long long counter, const double *weight, int *alive, int nw) {
     const long pair = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (pair < nw) alive[pair] = fabs(weight[pair]) > 1e-8 ? 1 : 0;
     if (2 * pair >= n) return;
     unsigned int c0 = (unsigned int)pair, c1 = (unsigned int)(pair >> 32);
     unsigned int c2 = (unsigned int)counter, c3 = (unsigned int)(counter >> 32) ^ (unsigned int)(stream * 0x9E3779B9u);
@@ -1044,10 +1118,10 @@ __global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, u
 
 int k_rng_normal(afq_handle *h) {
     const long n = (long)h->nw * h->K;
-    const long pairs = (n + 1) / 2;
+    const long pairs = std::max((n + 1) / 2, (long)h->nw);
     hipLaunchKernelGGL(rng_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, h->xi, n,
                        (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
-                       (unsigned long long)h->rng_counter);
+                       (unsigned long long)h->rng_counter, h->weight, h->alive, h->nw);
     AFQ_HIP(h, hipGetLastError());
     h->rng_counter += 1;
     return AFQ_OK;

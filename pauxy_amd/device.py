@@ -232,7 +232,10 @@ class AfqDevice(object):
         self._ck(self.lib.afq_cap_weights(self.h, float(frac), float(total_weight)))
 
     def popcontrol_comb(self, r, target, fetch=True):
-        pix = numpy.zeros(self.nw, dtype=numpy.int32) if fetch else None
+        if not fetch:        # asynchronous: the total weight stays on the device (cap_weights(frac, -1))
+            self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), None, None))
+            return None, None
+        pix = numpy.zeros(self.nw, dtype=numpy.int32)
         tw = ctypes.c_double(0.0)
         self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), _p(pix), ctypes.byref(tw)))
         return pix, tw.value

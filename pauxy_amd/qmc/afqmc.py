@@ -96,11 +96,13 @@ class AFQMC(object):
         if step % self.qmc.nstblz == 0:
             dev.reortho(fetch=False)
         self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
+        single = self.comm is None or self.comm.size == 1
         if step > 1:
-            dev.cap_weights(0.10, psi.total_weight)
+            # single rank: the total weight of the last comb is still on the device
+            dev.cap_weights(0.10, -1.0 if single else psi.total_weight)
         if step % self.qmc.npop_control == 0:
             psi._invalidate()
-            psi.pop_control(self.comm)
+            psi.pop_control(self.comm, fetch=not single)
         do_energy = step % self.estimators.estimators['mixed'].energy_eval_freq == 0
         dev.estimates_update(do_energy)
 

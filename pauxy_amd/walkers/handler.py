@@ -307,10 +307,12 @@ class Walkers(object):
         self._greens_version = -1
         self._ensure_greens()
 
-    def pop_control(self, comm):
+    def pop_control(self, comm, fetch=True):
         """walkers/handler.py:225-338 (comb).  Size-1 communicator: one device
         launch.  Several ranks: all-gather of |weights|, identical comb on every
-        rank from rank 0's uniform, point-to-point copies of the cloned walkers."""
+        rank from rank 0's uniform, point-to-point copies of the cloned walkers.
+        ``fetch=False`` (single rank, batched loop): nothing is read back, the total
+        weight stays on the device for the next weight cap."""
         self._end_sweep()
         if self.ntot_walkers == 1:
             return
@@ -318,6 +320,11 @@ class Walkers(object):
         size = 1 if comm is None else comm.size
         if size == 1:
             r = numpy.random.random()                      # handler.py:276
+            if not fetch:
+                self.dev.popcontrol_comb(r, self.target_weight, fetch=False)
+                self.phi_version += 1
+                self._invalidate()
+                return
             try:
                 parent_ix, total = self.dev.popcontrol_comb(r, self.target_weight)
             except L.AfqError as e:
