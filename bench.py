@@ -89,14 +89,24 @@ def main():
                   file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    # AFQ_BENCH_BACKEND=gloo runs the multi-rank code path with every rank on the visible GPUs modulo
+    # their count (functional check of the N > 1 logic on a 1-GPU box; RCCL needs one GPU per rank)
+    backend = os.environ.get("AFQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        os.environ["LOCAL_RANK"] = str(local_rank)        # pauxy_amd.context picks the GPU from it
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         from pauxy_amd.comm import TorchComm
-        comm = TorchComm(device=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            comm = TorchComm(device=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+            comm = TorchComm(device=torch.device("cpu"))
 
     from pauxy_amd.qmc.afqmc import AFQMC
     system, trial = build_inputs()

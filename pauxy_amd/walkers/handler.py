@@ -385,22 +385,28 @@ class WalkerTransport(object):
         self.dev = dev
         self.comm = comm
         self.nbytes = dev.pack_bytes()
-        self.device = comm.device
+        self.gpu = torch.device('cuda', dev.device_id)          # pack / unpack work on device memory
+        self.direct = getattr(comm, 'device', None) is not None and comm.device.type == 'cuda'
 
     def _buf(self):
-        return self.torch.empty(self.nbytes // 8, dtype=self.torch.float64, device=self.device)
+        return self.torch.empty(self.nbytes // 8, dtype=self.torch.float64, device=self.gpu)
 
     def send(self, iw, dest, tag):
         buf = self._buf()
         self.dev.pack(iw, buf.data_ptr())
         self.dev.sync()
-        self.comm.send_tensor(buf, dest, tag)
+        # RCCL moves the device buffer itself; a CPU backend (gloo: tests, debugging) gets a host copy
+        self.comm.send_tensor(buf if self.direct else buf.cpu(), dest, tag)
 
     def recv(self, iw, source, tag):
         buf = self._buf()
-        self.comm.recv_tensor(buf, source, tag)
-        if buf.is_cuda:
-            self.torch.cuda.current_stream(buf.device).synchronize()
+        if self.direct:
+            self.comm.recv_tensor(buf, source, tag)
+        else:
+            host = self.torch.empty(self.nbytes // 8, dtype=self.torch.float64)
+            self.comm.recv_tensor(host, source, tag)
+            buf.copy_(host)
+        self.torch.cuda.current_stream(buf.device).synchronize()
         self.dev.unpack(iw, buf.data_ptr())
         self.dev.sync()
 
