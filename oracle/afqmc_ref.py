@@ -217,9 +217,12 @@ def update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, dt):
         w['weight'] *= magn * cosine_fac
         w['ot'] = ovlp_new
         w['ovlp'] = ovlp_new
+        # back-propagation bookkeeping (continuous.py:284-289, walkers/stack.py:51-76)
+        w['_wfac'] = (imp / magn, cosine_fac) if magn > 1e-16 else (0.0, 0.0)
     else:
         w['ot'] = ovlp_new
         w['weight'] = 0.0
+        w['_wfac'] = None
     return trig
 
 
@@ -244,15 +247,19 @@ def update_weight_local_energy(w, eloc, ovlp, ovlp_new, eshift, dt):
     ovlp_ratio = ovlp_new / ovlp
     re_eloc, trig = apply_bound_local_energy(eloc, eshift, ebound)
     magn = numpy.exp(-0.5 * dt * complex(re_eloc + w['eloc'] - eshift).real)
+    w_eloc_old = w['eloc']
     w['eloc'] = eloc
     if not math.isinf(magn):
         dtheta = cmath.phase(ovlp_ratio)
         cosine_fac = max(0, math.cos(dtheta))
         w['weight'] *= magn * cosine_fac
         w['ot'] = ovlp_new
+        wfac_imag = numpy.exp(-0.5 * dt * complex(eloc + w_eloc_old - eshift).imag)   # continuous.py:299
+        w['_wfac'] = (wfac_imag, cosine_fac) if magn > 1e-16 else (0.0, 0.0)
     else:
         w['ot'] = ovlp_new
         w['weight'] = 0.0
+        w['_wfac'] = None
     return trig
 
 
@@ -400,6 +407,88 @@ def comb_pairs(parent_ix):
 EST = dict(uweight=0, weight=1, enumer=2, edenom=3, eproj=4, e1b=5, e2b=6,
            ehyb=7, ovlp=8, time=9)   # estimators/mixed.py:460-469
 
+
+
+
+# --------------------------------------------------------------------------
+# Back-propagation
+# --------------------------------------------------------------------------
+def bp_new(nfields, nbp):
+    """walkers/stack.py:19-32 (FieldConfig with nprop_tot == nbp)."""
+    return dict(configs=numpy.zeros((nbp, nfields), dtype=numpy.complex128),
+                cos_fac=numpy.zeros(nbp), weight_fac=numpy.zeros(nbp, dtype=numpy.complex128),
+                step=0, nbp=nbp)
+
+
+def bp_push(fc, config, wfac):
+    """walkers/stack.py:51-76 (FieldConfig.update)."""
+    fc['configs'][fc['step']] = config
+    fc['weight_fac'][fc['step']] = wfac[0]
+    fc['cos_fac'][fc['step']] = numpy.real(wfac[1])
+    fc['step'] += 1
+
+
+def bp_copy(fc):
+    return dict(configs=fc['configs'].copy(), cos_fac=fc['cos_fac'].copy(), weight_fac=fc['weight_fac'].copy(),
+                step=fc['step'], nbp=fc['nbp'])
+
+
+def exponentiate_matrix(Mx, order=6):
+    """utils/linalg.py:163-170."""
+    T = numpy.copy(Mx)
+    EXPM = numpy.identity(Mx.shape[0], dtype=Mx.dtype)
+    for n in range(1, order + 1):
+        EXPM += T
+        T = Mx.dot(T) / (n + 1)
+    return EXPM
+
+
+def reortho_qr(A):
+    """utils/linalg.py:82-105."""
+    (Q, R) = scipy.linalg.qr(A, mode='economic')
+    signs = numpy.diag(numpy.sign(numpy.diag(R)))
+    return Q.dot(signs), scipy.linalg.det(signs.dot(R))
+
+
+def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt):
+    """propagation/generic.py:253-290 with :181-211: apply B(x_n)^H ... B(x_1)^H to the trial,
+    most recent field configuration first, re-orthogonalising every nstblz steps (not at i == 0)."""
+    for (i, c) in enumerate(configs[::-1]):
+        VHS = 1j * dt ** 0.5 * hs_pot.dot(c).reshape(M, M)
+        EXP_VHS = exponentiate_matrix(VHS)
+        Bup = BT2[0].dot(EXP_VHS).dot(BT2[0])
+        Bdn = BT2[1].dot(EXP_VHS).dot(BT2[1])
+        phi[:, :na] = numpy.dot(Bup.conj().T, phi[:, :na])
+        phi[:, na:] = numpy.dot(Bdn.conj().T, phi[:, na:])
+        if i != 0 and i % nstblz == 0:
+            phi[:, :na], _ = reortho_qr(phi[:, :na])
+            phi[:, na:], _ = reortho_qr(phi[:, na:])
+    return phi
+
+
+def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None):
+    """estimators/back_propagation.py:127-226 (update_uhf, one_rdm only).  ``est`` is
+    [3 energies, denominator, G.flatten()]; called when the field buffers are full; resets them
+    and copies phi -> phi_old (walkers/handler.py:200-203)."""
+    M, na = model.M, model.na
+    for w in walkers:
+        fc = w['bp']
+        phi_bp = numpy.array(model.psi if init is None else init, dtype=numpy.complex128, copy=True)
+        back_propagate_generic(phi_bp, fc['configs'][:fc['step']], model.hs_pot, M, na, nstblz, model.BH1, model.dt)
+        G = numpy.array([gab(phi_bp[:, :na], w['phi_old'][:, :na]).T,
+                         gab(phi_bp[:, na:], w['phi_old'][:, na:]).T])
+        if restore_weights is not None:
+            cosine_fac = numpy.prod(fc['cos_fac'][:fc['step']])
+            ph_fac = numpy.prod(fc['weight_fac'][:fc['step']])
+            wfac = ph_fac / cosine_fac if restore_weights == "full" else ph_fac
+            weight = w['weight'] * wfac
+        else:
+            weight = w['weight']
+        est[3] += weight
+        est[4:] += weight * G.flatten()
+        fc['step'] = 0                                      # FieldConfig.reset (stack.py:124-127)
+    for w in walkers:
+        w['phi_old'] = w['phi'].copy()
 
 
 # --------------------------------------------------------------------------
@@ -586,6 +675,8 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
     ovlp_new = model.overlap(w['phi'])
     if hybrid:
         htrig = update_weight_hybrid(w, ovlp, ovlp_new, cfb, cmf, eshift, model.dt)
+        if 'bp' in w and w['_wfac'] is not None:
+            bp_push(w['bp'], xs, w['_wfac'])
     else:
         if model.kind == 'generic_msd':
             # Reference behaviour (continuous.py:296 after :261): the energy is evaluated AFTER
@@ -595,6 +686,8 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
             msd_calc_overlap(w['phi'], model.psi, model.coeffs, na, nb, weights_out=Ghalf)
         eloc = complex(model.local_energy(G, Ghalf)[0])
         htrig = update_weight_local_energy(w, eloc, ovlp, ovlp_new, eshift, model.dt)
+        if 'bp' in w and w['_wfac'] is not None:
+            bp_push(w['bp'], xs, w['_wfac'])
     return ntrig, htrig
 
 
@@ -617,7 +710,10 @@ def pop_control(model, walkers, target, r):
         src = walkers[c]
         dst = walkers[k]
         for key, val in src.items():
-            dst[key] = numpy.array(val, copy=True) if isinstance(val, numpy.ndarray) else val
+            if key == 'bp':
+                dst[key] = bp_copy(val)
+            else:
+                dst[key] = numpy.array(val, copy=True) if isinstance(val, numpy.ndarray) else val
     for w in walkers:
         w['weight'] = 1.0
     return parent_ix
@@ -670,7 +766,8 @@ def block_reduce(est, nsteps):
 
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
-              record=None, verbose=False, free_projection=False):
+              record=None, verbose=False, free_projection=False, nbp=None, bp_out=None,
+              restore_weights=None):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -685,6 +782,11 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
     """
     if energy_eval_freq is None:
         energy_eval_freq = nsteps
+    if nbp is not None:
+        # estimators/handler.py:87-92, walkers/walker.py:43,55-58: field history + phi_old per walker
+        for w in walkers:
+            w['bp'] = bp_new(model.nfields, nbp)
+            w['phi_old'] = w['phi'].copy()
     ntot = len(walkers)
     for w in walkers:
         w['total_weight'] = ntot       # walkers/handler.py:164
@@ -722,6 +824,10 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
         if step % npop_control == 0:
             parent_ix = pop_control(model, walkers, ntot, r_source(step))
         mixed_update(model, est, walkers, step, energy_eval_freq, free_projection)
+        if nbp is not None and walkers[0]['bp']['step'] == nbp:     # back_propagation.py:145-147
+            bpe = numpy.zeros(4 + 2 * model.M * model.M, dtype=numpy.complex128)
+            bp_update(model, walkers, nstblz, bpe, restore_weights)
+            bp_out.append(bpe)                                       # print_step: one Reduce per window
         if record is not None:
             record.append(dict(
                 weight=numpy.array([w['weight'] for w in walkers]),

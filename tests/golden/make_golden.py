@@ -646,7 +646,53 @@ def make_traj_msd():
     numpy.savez_compressed(os.path.join(HERE, 'traj_msd.npz'), **out)
 
 
+
+def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10):
+    """qmc/tests/test_afqmc.py:232-278: single-determinant generic run with the back-propagated
+    one-body RDM (tau_bp = 5 steps); pinned rdm[11,0,1,3].real == -0.121883381144845."""
+    out = {}
+    nmo, nelec = 11, (3, 3)
+    bp = {'tau_bp': 0.025, 'one_rdm': True}
+    if restore_weights is not None:
+        bp['restore_weights'] = restore_weights
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': blocks, 'rng_seed': 8},
+               'trial': {'name': 'MultiSlater'},
+               'estimator': {'back_propagated': bp, 'mixed': {'energy_eval_freq': 1}}}
+    numpy.random.seed(7)
+    h1e, chol, enuc, eri = generate_hamiltonian(nmo, nelec, cplx=False)
+    system = Generic(nelec=nelec, h1e=numpy.array([h1e, h1e]),
+                     chol=chol.reshape((-1, nmo * nmo)).T.copy(), ecore=enuc)
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, system=system, options=options)
+    assert afqmc.estimators.back_propagation and afqmc.estimators.nbp == 5
+    out['h1e'] = h1e
+    out['chol'] = system.chol_vecs
+    out['ecore'] = enuc
+    out['rchol'] = afqmc.trial._rchol
+    out['nbp'] = afqmc.estimators.nbp
+    out['restore_weights'] = '' if restore_weights is None else restore_weights
+    record_trajectory(afqmc, comm, out)
+    store = h5py._STORE[afqmc.estimators.filename]
+    dk = sorted(k for k in store if k.startswith('back_propagated/denominator_5/'))
+    rk = sorted(k for k in store if k.startswith('back_propagated/one_rdm_5/'))
+    assert len(dk) == len(rk) and len(dk) > 0
+    out['bp_denominator'] = numpy.array([store[k] for k in dk]).reshape(len(dk))
+    out['bp_one_rdm'] = numpy.array([store[k] for k in rk])
+    rdm = out['bp_one_rdm'] / out['bp_denominator'][:, None, None, None]
+    if restore_weights is None and blocks == 10:
+        assert abs(rdm[0, 0].trace() - nelec[0]) < 1e-10 and abs(rdm[0, 1].trace() - nelec[1]) < 1e-10
+        assert abs(rdm[11, 0, 1, 3].real - (-0.121883381144845)) < 1e-10, rdm[11, 0, 1, 3]
+        numer = out['final_estimates'][2]
+        assert abs(numer.real - 3.8763193646854273) < 1e-9, numer
+    numpy.savez_compressed(os.path.join(HERE, name), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'bp':
+        make_traj_bp()
+        make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'msd':
         make_msd_ops()
         make_traj_msd()
@@ -667,6 +713,8 @@ if __name__ == '__main__':
                       prop_extra={'hybrid': False})
     make_msd_ops()
     make_traj_msd()
+    make_traj_bp()
+    make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

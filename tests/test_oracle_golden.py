@@ -244,6 +244,37 @@ def test_traj_msd(golden):
     assert d['parent_ix'].shape[0] == 8
 
 
+def run_bp(d, restore):
+    m = generic_model(d, '')
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+    bp = []
+    ref.run_afqmc(m, walkers, lambda s, w: xi[s - 1, w], lambda s: r[s - 1], int(d['nsteps']), int(d['nblocks']),
+                  nstblz=int(d['nstblz']), npop_control=int(d['npop_control']),
+                  energy_eval_freq=int(d['energy_eval_freq']), nbp=int(d['nbp']), bp_out=bp,
+                  restore_weights=restore)
+    bp = numpy.array(bp)
+    close(bp[:, 3], d['bp_denominator'], 1e-9)
+    close(bp[:, 4:].reshape(d['bp_one_rdm'].shape), d['bp_one_rdm'], 1e-9)
+    return bp[:, 4:].reshape(d['bp_one_rdm'].shape) / bp[:, 3][:, None, None, None]
+
+
+def test_back_propagated_rdm(golden):
+    """qmc/tests/test_afqmc.py:232-278: back-propagated one-body RDM, tau_bp = 5 steps."""
+    rdm = run_bp(golden('traj_bp.npz'), None)
+    assert rdm[0, 0].trace() == pytest.approx(3.0, rel=1e-10)
+    assert rdm[0, 1].trace() == pytest.approx(3.0, rel=1e-10)
+    assert rdm[11, 0, 1, 3].real == pytest.approx(-0.121883381144845, rel=1e-9)
+
+
+def test_back_propagated_rdm_restored_weights(golden):
+    """estimators/back_propagation.py:187-199 with restore_weights == "full"."""
+    d = golden('traj_bp_full.npz')
+    assert str(d['restore_weights']) == 'full'
+    run_bp(d, 'full')
+
+
 def test_comb_truncation_quirk():
     """walkers/handler.py:301: zip(clone, kill) copies a multiplicity-3 parent once."""
     w = numpy.array([3.0, 1e-9, 1e-9, 1.0 - 2e-9])
