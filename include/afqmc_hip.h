@@ -107,6 +107,27 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
                        const double *vqvec, double vol, const double *H1diag, double ecore);
 /* trial determinant psi c128[M, na+nb] (trial.psi after walkers/handler.py:61) */
 int afq_set_trial(afq_handle *h, const double *psi);
+/* ---- back-propagated estimator --------------------------------
+ * estimators/back_propagation.py:63-226, walkers/stack.py:5-127 (FieldConfig),
+ * propagation/generic.py:181-211,253-290.  After afq_bp_configure every
+ * afq_propagate records the shifted fields x - xbar of each walker together with
+ * the phase / cosine factors of the weight update (up to nbp steps; the history,
+ * phi_old and the factors travel with the walker through the comb, afq_walkers_copy
+ * and afq_walker_pack / unpack).  Call after afq_walkers_alloc and afq_set_propagator;
+ * phi_old starts as the current phi.                                            */
+int afq_bp_configure(afq_handle *h, int nbp);
+/* FieldConfig.step of every walker: int32[nw]                                   */
+int afq_bp_steps(afq_handle *h, int32_t *steps_out);
+/* BackPropagation.update_uhf for the whole population: back-propagates phi_bp0
+ * (trial.psi or trial.init, c128[M, na+nb]) through every walker's recorded fields
+ * (most recent first, re-orthogonalised every nstblz steps), forms
+ * G_bp[w] = gab(phi_bp, phi_old)^T and returns est_out c128[4 + 2 M M] =
+ * [0, 0, 0, sum_w wt_w, sum_w wt_w G_bp[w]] with wt = weight (restore_weights 0),
+ * weight * prod(I/|I|) (1, "partial") or weight * prod(I/|I|) / prod(cos) (2, "full");
+ * then resets the histories and copies phi -> phi_old.  Energies (entries 0-2) are
+ * not evaluated (evaluate_energy is off by default in the reference).            */
+int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, double *est_out);
+
 /* Multi-determinant (NOMSD / PHMSD) trial |psi_T> = sum_d c_d |D_d> for a generic system, replacing
  * the single-determinant operands of afq_set_system_generic / afq_set_trial.  Call after the
  * system and before afq_walkers_alloc.

@@ -90,7 +90,10 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr;
-    dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all); dev_free(h->xbar); dev_free(h->xs);
+    dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
+    dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
+    dev_free(h->phi_old); dev_free(h->phi_bp); dev_free(h->BH1dag); dev_free(h->bp_xs); dev_free(h->bp_est);
+    h->nbp = 0; dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
     dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
@@ -717,6 +720,7 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
             if ((rc = k_msd_energy_combine(h))) return rc;
         }
         if ((rc = k_update_weight(h, cmake(eshift_re, eshift_im)))) return rc;
+        if (h->nbp > 0 && !fp && (rc = k_bp_push(h))) return rc;     // FieldConfig.update (continuous.py:288-289)
     }
     return AFQ_OK;
 }
@@ -900,7 +904,10 @@ int afq_walkers_reset_weights(afq_handle *h) {
 // packed walker: phi | ot, ehyb, phase, eloc (c128) | unscaled_weight, detR, weight, pad (f64)
 int afq_walker_pack_bytes(afq_handle *h, int64_t *bytes) {
     if (!h || !bytes) return AFQ_EINVAL;
-    *bytes = (int64_t)(sizeof(cplx) * ((size_t)h->M * h->nt + 4) + sizeof(double) * 4);
+    size_t b = sizeof(cplx) * ((size_t)h->M * h->nt + 4) + sizeof(double) * 4;
+    if (h->nbp > 0)   // phi_old + field history + FieldConfig.step + the two running weight factors
+        b += sizeof(cplx) * ((size_t)h->M * h->nt + (size_t)h->nbp * h->K + 1) + sizeof(double) * 2;
+    *bytes = (int64_t)b;
     return AFQ_OK;
 }
 
@@ -916,6 +923,17 @@ static int pack_io(afq_handle *h, int iw, char *buf, bool pack) {
         if (pack) AFQ_HIP(h, hipMemcpyAsync(buf + off, it.p, it.b, hipMemcpyDeviceToDevice, h->stream));
         else AFQ_HIP(h, hipMemcpyAsync(it.p, buf + off, it.b, hipMemcpyDeviceToDevice, h->stream));
         off += it.b;
+    }
+    if (h->nbp > 0) {
+        const size_t hk = (size_t)h->nbp * h->K;
+        const Item bp[] = {{h->phi_old + per * iw, per * sizeof(cplx)}, {h->bp_hist + hk * iw, hk * sizeof(cplx)},
+                           {h->bp_ph + iw, sizeof(cplx)}, {h->bp_cos + iw, sizeof(double)},
+                           {h->bp_n + iw, sizeof(int)}};
+        for (const Item &it : bp) {
+            if (pack) AFQ_HIP(h, hipMemcpyAsync(buf + off, it.p, it.b, hipMemcpyDeviceToDevice, h->stream));
+            else AFQ_HIP(h, hipMemcpyAsync(it.p, buf + off, it.b, hipMemcpyDeviceToDevice, h->stream));
+            off += it.b;
+        }
     }
     return AFQ_OK;
 }
@@ -948,6 +966,9 @@ int afq_walkers_copy(afq_handle *h, int src, int dst) {
 #define C_(ptr, n) AFQ_HIP(h, hipMemcpyAsync((ptr) + (size_t)dst * (n), (ptr) + (size_t)src * (n), sizeof(*(ptr)) * (n), hipMemcpyDeviceToDevice, h->stream));
     C_(h->phi, per) C_(h->ot, 1) C_(h->ehyb, 1) C_(h->phase, 1) C_(h->eloc, 1)
     C_(h->unscaled, 1) C_(h->detR, 1) C_(h->weight, 1)
+    if (h->nbp > 0) {
+        C_(h->phi_old, per) C_(h->bp_hist, (size_t)h->nbp * h->K) C_(h->bp_ph, 1) C_(h->bp_cos, 1) C_(h->bp_n, 1)
+    }
 #undef C_
     return AFQ_OK;
 }
@@ -1008,6 +1029,95 @@ int afq_timers(afq_handle *h, double *out_ms, int reset) {
     if (!h || !out_ms) return AFQ_EINVAL;
     for (int i = 0; i < T_COUNT; ++i) { out_ms[i] = h->t_ms[i]; if (reset) h->t_ms[i] = 0.0; }
     return AFQ_OK;
+}
+
+// ---------------------------------------------------------------- back-propagation
+int afq_bp_configure(afq_handle *h, int nbp) {
+    if (!h || nbp < 1) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation needs a single-determinant trial");
+    if (h->flags & AFQ_PROP_FREE_PROJECTION) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "no field history in free projection");
+    const size_t per = (size_t)h->M * h->nt, n = h->nw;
+    if ((rc = dev_alloc(h, &h->bp_hist, n * nbp * h->K))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_n, n))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_flag, n))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_cos, n))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_ph, n))) return rc;
+    if ((rc = dev_alloc(h, &h->phi_old, per * n))) return rc;
+    if ((rc = dev_alloc(h, &h->phi_bp, 2 * per * n))) return rc;        // phi_bp and conj(phi_bp)
+    if ((rc = dev_alloc(h, &h->BH1dag, (size_t)2 * h->M * h->M))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_xs, n * h->K))) return rc;
+    if ((rc = dev_alloc(h, &h->bp_est, (size_t)4 + 2 * h->M * h->M))) return rc;
+    h->nbp = nbp;
+    AFQ_HIP(h, hipMemsetAsync(h->bp_hist, 0, sizeof(cplx) * n * nbp * h->K, h->stream));
+    AFQ_HIP(h, hipMemsetAsync(h->bp_flag, 0, sizeof(int) * n, h->stream));
+    if ((rc = k_bp_reset(h))) return rc;
+    if ((rc = k_conj_transpose(h, h->BH1, h->BH1dag))) return rc;
+    // walkers/walker.py:43: phi_old starts as the walker itself
+    AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
+    return AFQ_OK;
+}
+
+int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
+    if (!h || !steps_out) return AFQ_EINVAL;
+    if (!h->nbp) AFQ_FAIL(h, AFQ_ESTATE, "back-propagation is not configured");
+    hipSetDevice(h->device);
+    return copy_out(h, steps_out, h->bp_n, sizeof(int) * h->nw);
+}
+
+int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, double *est_out) {
+    if (h) h->greens_valid = false;
+    if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if (!h->nbp) AFQ_FAIL(h, AFQ_ESTATE, "back-propagation is not configured");
+    const size_t per = (size_t)h->M * h->nt, n = h->nw;
+    // trial (or initial) determinant for every walker; the second half of phi_bp is upload scratch first
+    AFQ_HIP(h, hipMemcpyAsync(h->phi_bp + per * n, phi_bp0, sizeof(cplx) * per, hipMemcpyHostToDevice, h->stream));
+    if ((rc = k_bp_init(h, h->phi_bp + per * n))) return rc;
+    // borrow the step machinery: phi <- phi_bp, BH1 <- BH1^H, fields <- -conj(x), every walker "alive"
+    // while it still has recorded steps; the walkers' own overlaps / detR / weights are parked
+    cplx *s_phi = h->phi, *s_xs = h->xs, *s_BH1 = h->BH1, *s_ot = h->ot;
+    double *s_detR = h->detR;
+    const int s_flags = h->flags;
+    cplx *tmp_ot = nullptr; double *tmp_detR = nullptr;
+    if ((rc = dev_alloc(h, &tmp_ot, n)) || (rc = dev_alloc(h, &tmp_detR, n))) return rc;
+    h->phi = h->phi_bp; h->xs = h->bp_xs; h->BH1 = h->BH1dag; h->ot = tmp_ot; h->detR = tmp_detR;
+    h->flags &= ~AFQ_PROP_FREE_PROJECTION;
+    const bool fused = k_prop_fused_supported(h);
+    rc = AFQ_OK;
+    for (int i = 0; i < h->nbp && !rc; ++i) {                       // propagation/generic.py:279-288
+        if ((rc = k_bp_fields(h, i))) break;
+        if ((rc = build_vhs(h))) break;
+        if (fused) rc = k_prop_fused(h);
+        else {
+            if ((rc = k_onebody(h))) break;
+            if ((rc = apply_exp(h, h->vhs))) break;
+            rc = k_onebody(h);
+        }
+        if (!rc && i != 0 && i % nstblz == 0) rc = k_reortho(h);    // utils/linalg.py:82-105 on both spins
+    }
+    h->phi = s_phi; h->xs = s_xs; h->BH1 = s_BH1; h->ot = s_ot; h->detR = s_detR; h->flags = s_flags;
+    dev_free(tmp_ot); dev_free(tmp_detR);
+    if (rc) return rc;
+    // G_bp[w] = gab(phi_bp, phi_old)^T (back_propagation.py:156-157) = the Green's function of phi_old with
+    // phi_bp[w] in the role of the trial
+    if ((rc = k_conj_copy(h, h->phi_bp, h->phi_bp + per * n, (long)(per * n)))) return rc;
+    cplx *s_psi = h->psi, *s_psic = h->psic;
+    h->phi = h->phi_old; h->psi = h->phi_bp; h->psic = h->phi_bp + per * n; h->psi_stride = (long)per;
+    rc = k_greens(h, h->ovlp_old);
+    if (!rc) rc = ensure_G(h);
+    if (!rc) rc = k_full_G(h);
+    h->phi = s_phi; h->psi = s_psi; h->psic = s_psic; h->psi_stride = 0;
+    if (rc) return rc;
+    AFQ_HIP(h, hipMemsetAsync(h->bp_est, 0, sizeof(cplx) * ((size_t)4 + 2 * h->M * h->M), h->stream));
+    if ((rc = k_bp_accumulate(h, restore_weights))) return rc;
+    // FieldConfig.reset + Walkers.copy_historic_wfn (walkers/stack.py:124-127, handler.py:200-203)
+    if ((rc = k_bp_reset(h))) return rc;
+    AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = k_alive(h))) return rc;
+    return copy_out(h, est_out, h->bp_est, sizeof(cplx) * ((size_t)4 + 2 * h->M * h->M));
 }
 
 int afq_walkers_det_weights(afq_handle *h, double *weights_out) {

@@ -74,6 +74,7 @@ struct afq_handle {
     bool have_trial = false;
     cplx *psi = nullptr;            // [M, nt]
     cplx *psic = nullptr;           // conj(psi) [M, nt] (B operand of the overlap GEMM)
+    long psi_stride = 0;            // elements between per-walker 'trials' (back-propagation only; 0 = shared psi)
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one
@@ -90,6 +91,19 @@ struct afq_handle {
     cplx *ghalf_all = nullptr;      // owning pointers of the per-determinant slices
     cplx *vbias_all = nullptr;
     cplx *energy_all = nullptr;     // [ndet, nw, 3] per-determinant local energies
+
+    // ---- back-propagation (estimators/back_propagation.py, walkers/stack.py FieldConfig)
+    int nbp = 0;                    // field configurations kept per walker (0 = off)
+    cplx *bp_hist = nullptr;        // [nw, nbp, K] shifted fields x - xbar of the last steps
+    int *bp_n = nullptr;            // [nw] FieldConfig.step
+    int *bp_flag = nullptr;         // [nw] set by the weight kernel when this step's fields are recorded
+    double *bp_cos = nullptr;       // [nw] running product of the cosine factors
+    cplx *bp_ph = nullptr;          // [nw] running product of I / |I|
+    cplx *phi_old = nullptr;        // [nw, M, nt] walker at the start of the back-propagation window
+    cplx *phi_bp = nullptr;         // [nw, M, nt] back-propagated trial (+ its conjugate behind it)
+    cplx *BH1dag = nullptr;         // [2, M, M] BH1^H
+    cplx *bp_xs = nullptr;          // [nw, K]
+    cplx *bp_est = nullptr;         // [4 + 2 M M]
 
     // ---- propagator
     bool have_prop = false;
@@ -223,6 +237,13 @@ int k_overlap(afq_handle *h, cplx *det_out);                // det(psi^H phi)
 int k_fields(afq_handle *h);                                // vbias -> xbar(clipped), xs, cmf, cfb
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d, cplx *cfb_d);
 int k_xbar(afq_handle *h);
+int k_bp_push(afq_handle *h);
+int k_bp_fields(afq_handle *h, int i);
+int k_bp_init(afq_handle *h, const cplx *phi0_dev);
+int k_conj_copy(afq_handle *h, const cplx *src, cplx *dst, long n);
+int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At);
+int k_bp_accumulate(afq_handle *h, int restore);
+int k_bp_reset(afq_handle *h);
 int k_xbar_fields(afq_handle *h);                           // xbar + clip + shift in one launch
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch

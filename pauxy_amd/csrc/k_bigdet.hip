@@ -23,6 +23,7 @@ struct OvlpProb {
     int nt, na, nb, ld;
     const cplx *phi;                 // [nw, M, nt]
     const cplx *psic;                // conj(psi) [M, nt]
+    long psi_stride;                 // 0 or M*nt (per-walker trial)
     cplx *O;                         // [2 nw, ld * ld]
     const cplx *zero;
     __device__ bool active(int) const { return true; }
@@ -34,7 +35,7 @@ struct OvlpProb {
     }
     __device__ const cplx *ptrB(int b, int k, int col) const {
         const int s = b & 1, ns = s ? nb : na;
-        return col < ns ? psic + (long)k * nt + (s ? na : 0) + col : zero;
+        return col < ns ? psic + (b >> 1) * psi_stride + (long)k * nt + (s ? na : 0) + col : zero;
     }
     __device__ void store(int b, int row, int col, double re, double im) const {
         O[(long)b * ld * ld + (long)row * ld + col] = cmake(re, im);
@@ -287,7 +288,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
         OvlpProb p;
         p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
-        p.phi = h->phi; p.psic = h->psic; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
+        p.phi = h->phi; p.psic = h->psic; p.psi_stride = h->psi_stride; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
         AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OvlpProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     }
     {

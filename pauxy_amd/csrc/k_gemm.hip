@@ -320,10 +320,11 @@ struct FullGProb {
     int batch, rows, cols, kdim;     // nw, M, M, ns
     int nt, off, spin, M;
     const cplx *psi;                 // [M, nt]
+    long psi_stride;                 // 0 or M*nt (per-walker trial)
     const cplx *ghalf;               // [nw, nt, M]
     cplx *G;                         // [nw, 2, M, M]
     __device__ bool active(int) const { return true; }
-    __device__ cplx loadA(int, int row, int k) const { return cconj(psi[(long)row * nt + off + k]); }
+    __device__ cplx loadA(int b, int row, int k) const { return cconj(psi[b * psi_stride + (long)row * nt + off + k]); }
     __device__ cplx loadB(int b, int k, int col) const { return ghalf[((long)b * nt + off + k) * M + col]; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         G[(((long)b * 2 + spin) * M + row) * M + col] = cmake(re, im);
@@ -342,7 +343,7 @@ int k_full_G(afq_handle *h) {
         FullGProb p;
         p.batch = h->nw; p.rows = M; p.cols = M; p.kdim = ns; p.nt = h->nt;
         p.off = s == 0 ? 0 : h->na; p.spin = s; p.M = M;
-        p.psi = h->psi; p.ghalf = h->ghalf; p.G = h->G;
+        p.psi = h->psi; p.psi_stride = h->psi_stride; p.ghalf = h->ghalf; p.G = h->G;
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
         DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
     }

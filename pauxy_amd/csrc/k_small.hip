@@ -85,6 +85,7 @@ __device__ inline void lu_factor(cplx *O, int n, int *perm, int *piv_s, cplx *ph
 struct GreensArgs {
     int M, na, nb, nt, nw;
     const cplx *phi, *psi;
+    long psi_stride;    // 0: one trial for all walkers; M*nt: walker w uses psi + w*psi_stride
     cplx *ghalf;        // may be null (determinant only)
     cplx *det;          // [nw]
     cplx *ws;           // global workspace [nw, nmax*nmax] when O does not fit LDS
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
             cplx acc = cmake(0.0, 0.0);
             for (int p = 0; p < M; ++p) {
                 const cplx x = phi[(long)p * nt + off + i];
-                const cplx y = a.psi[(long)p * nt + off + j];
+                const cplx y = a.psi[w * a.psi_stride + (long)p * nt + off + j];
                 // x * conj(y)
                 acc.x = fma(x.x, y.x, acc.x); acc.x = fma(x.y, y.y, acc.x);
                 acc.y = fma(x.y, y.x, acc.y); acc.y = fma(-x.x, y.y, acc.y);
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int p = (half * 16 + u) * 4 + lk;
-                    const cplx y = a.psi[(long)(p < M ? p : M - 1) * nt + off + jbc];
+                    const cplx y = a.psi[w * a.psi_stride + (long)(p < M ? p : M - 1) * nt + off + jbc];
                     yb[u] = (p < M && jb < n) ? y : cmake(0.0, 0.0);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // all 16 trial-fragment loads in flight before any MFMA
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
 static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) {
     GreensArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
-    a.phi = h->phi; a.psi = h->psi; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
+    a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
     if (k_greens_big_supported(h)) return k_greens_big(h, ghalf, det);
@@ -686,12 +687,26 @@ struct WeightArgs {
     cplx *ot, *ehyb, *phase, *eloc;
     const cplx *energy;         // [nw, 3] local energy of the walker before the step (hybrid == false)
     unsigned long long *counters;
+    // back-propagation bookkeeping (continuous.py:284-289,310-315, walkers/stack.py:51-76); null = off
+    int *bp_flag;
+    double *bp_cos;
+    cplx *bp_ph;
 };
+
+__device__ inline void bp_record(const WeightArgs &a, int w, double magn, cplx wfac0, double cosine_fac) {
+    if (!a.bp_flag) return;
+    if (!(magn > 1e-16)) { wfac0 = cmake(0.0, 0.0); cosine_fac = 0.0; }
+    a.bp_flag[w] = 1;
+    a.bp_cos[w] *= cosine_fac;
+    a.bp_ph[w] = cmul(a.bp_ph[w], wfac0);
+}
 
 // propagation/continuous.py:264-292 (hybrid) and :194-200 (free projection)
 __global__ void weight_kernel(WeightArgs a) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.nw || !a.alive[w]) return;
+    if (w >= a.nw) return;
+    if (a.bp_flag) a.bp_flag[w] = 0;
+    if (!a.alive[w]) return;
     const cplx on = a.ovlp_new[w];
     if (a.flags & AFQ_PROP_FREE_PROJECTION) {
         const cplx e = cexp_(cmake(a.cmf[w].x + a.dt * a.eshift.x, a.cmf[w].y + a.dt * a.eshift.y));
@@ -713,10 +728,14 @@ __global__ void weight_kernel(WeightArgs a) {
             else if (re < a.eshift.x - ebound) { re = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
         }
         const double magn = exp(-0.5 * a.dt * (re + a.eloc[w].x - a.eshift.x));
+        const double wfac_imag = exp(-0.5 * a.dt * (el.y + a.eloc[w].y - a.eshift.y));   // continuous.py:299
         a.eloc[w] = el;
         a.ot[w] = on;
-        if (!isinf(magn)) a.weight[w] *= magn * fmax(0.0, cos(atan2(ratio.y, ratio.x)));
-        else a.weight[w] = 0.0;
+        if (!isinf(magn)) {
+            const double cf = fmax(0.0, cos(atan2(ratio.y, ratio.x)));
+            a.weight[w] *= magn * cf;
+            bp_record(a, w, magn, cmake(wfac_imag, 0.0), cf);
+        } else a.weight[w] = 0.0;
         return;
     }
     const cplx lg = clog_(ratio);
@@ -736,9 +755,122 @@ __global__ void weight_kernel(WeightArgs a) {
         const double dtheta = -a.dt * eh.y - a.cfb[w].y;
         const double cf = fmax(0.0, cos(dtheta));
         a.weight[w] *= magn * cf;
+        bp_record(a, w, magn, cmake(imp.x / magn, imp.y / magn), cf);
     } else {
         a.weight[w] = 0.0;
     }
+}
+
+// FieldConfig.update: append this step's shifted fields to the walker's history
+__global__ void bp_push_kernel(const cplx *xs, cplx *hist, int *bp_n, const int *flag, int K, int nbp) {
+    const int w = blockIdx.x;
+    if (!flag[w]) return;
+    const int n = bp_n[w];
+    if (n < nbp)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) hist[((long)w * nbp + n) * K + k] = xs[(long)w * K + k];
+    __syncthreads();
+    if (threadIdx.x == 0 && n < nbp) bp_n[w] = n + 1;
+}
+
+// fields of back-propagation step i (most recent first): B(x)^H = B(-conj(x)) for real symmetric L_n
+__global__ void bp_fields_kernel(const cplx *hist, const int *bp_n, cplx *xs, int *alive, int K, int nbp, int i) {
+    const int w = blockIdx.x;
+    const int n = bp_n[w];
+    const bool on = i < n;
+    if (threadIdx.x == 0) alive[w] = on ? 1 : 0;
+    if (!on) return;
+    const cplx *src = hist + ((long)w * nbp + (n - 1 - i)) * K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) xs[(long)w * K + k] = cmake(-src[k].x, src[k].y);
+}
+
+__global__ void bp_init_kernel(const cplx *phi0, cplx *phi_bp, long per, int nw) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < per * nw) phi_bp[i] = phi0[i % per];
+}
+
+__global__ void conj_copy_kernel(const cplx *src, cplx *dst, long n) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = cconj(src[i]);
+}
+
+__global__ void conj_transpose_kernel(const cplx *A, cplx *At, int M) {      // per spin: At = A^H
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * M) return;
+    const int r = i / M, c = i % M;
+    At[(long)s * M * M + c * M + r] = cconj(A[(long)s * M * M + i]);
+}
+
+// estimators/back_propagation.py:187-207: est[3] += w, est[4:] += w G_bp, w = weight (x restored factor)
+__global__ void bp_accumulate_kernel(const cplx *G, const double *weight, const double *bp_cos, const cplx *bp_ph,
+                                     cplx *est, int nw, long gsz, int restore) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e > gsz) return;
+    cplx acc = cmake(0.0, 0.0);
+    for (int w = 0; w < nw; ++w) {
+        cplx wt = cmake(weight[w], 0.0);
+        if (restore == 1) wt = cmul(wt, bp_ph[w]);                                       // BP-PRes (partial)
+        else if (restore == 2) wt = cmul(wt, cmake(bp_ph[w].x / bp_cos[w], bp_ph[w].y / bp_cos[w]));   // full
+        if (e == gsz) acc = cadd(acc, wt);
+        else cfma(acc, wt, G[(long)w * gsz + e]);
+    }
+    if (e == gsz) est[3] = cadd(est[3], acc);
+    else est[4 + e] = cadd(est[4 + e], acc);
+}
+
+__global__ void bp_reset_kernel(int *bp_n, double *bp_cos, cplx *bp_ph, int nw) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) { bp_n[w] = 0; bp_cos[w] = 1.0; bp_ph[w] = cmake(1.0, 0.0); }
+}
+
+int k_bp_push(afq_handle *h) {
+    hipLaunchKernelGGL(bp_push_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->xs, h->bp_hist, h->bp_n, h->bp_flag,
+                       h->K, h->nbp);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_bp_fields(afq_handle *h, int i) {
+    hipLaunchKernelGGL(bp_fields_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->bp_hist, h->bp_n, h->xs, h->alive,
+                       h->K, h->nbp, i);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_bp_init(afq_handle *h, const cplx *phi0_dev) {
+    const long per = (long)h->M * h->nt, n = per * h->nw;
+    hipLaunchKernelGGL(bp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, phi0_dev, h->phi_bp,
+                       per, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_conj_copy(afq_handle *h, const cplx *src, cplx *dst, long n) {
+    hipLaunchKernelGGL(conj_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, n);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At) {
+    hipLaunchKernelGGL(conj_transpose_kernel, dim3((h->M * h->M + 255) / 256, 2), dim3(256), 0, h->stream, A, At,
+                       h->M);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_bp_accumulate(afq_handle *h, int restore) {
+    const long gsz = 2L * h->M * h->M;
+    hipLaunchKernelGGL(bp_accumulate_kernel, dim3((unsigned)((gsz + 1 + 127) / 128)), dim3(128), 0, h->stream, h->G,
+                       h->weight, h->bp_cos, h->bp_ph, h->bp_est, h->nw, gsz, restore);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_bp_reset(afq_handle *h) {
+    hipLaunchKernelGGL(bp_reset_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->bp_n, h->bp_cos,
+                       h->bp_ph, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
 }
 
 int k_update_weight(afq_handle *h, cplx eshift) {
@@ -747,6 +879,7 @@ int k_update_weight(afq_handle *h, cplx eshift) {
     a.ovlp_old = h->ovlp_old; a.ovlp_new = h->ovlp_new; a.cmf = h->cmf; a.cfb = h->cfb;
     a.weight = h->weight; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase; a.counters = h->counters;
     a.eloc = h->eloc; a.energy = h->energy;
+    a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
     hipLaunchKernelGGL(weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
@@ -997,6 +1130,11 @@ struct CloneArgs {
     double *unscaled, *detR;
     const int *pairs;
     const double *scal;
+    // back-propagation state travels with the walker (walkers/walker.py:89-90); null when off
+    cplx *phi_old, *bp_hist, *bp_ph;
+    double *bp_cos;
+    int *bp_n;
+    long hist_per;
 };
 
 __global__ void clone_kernel(CloneArgs a) {
@@ -1005,9 +1143,16 @@ __global__ void clone_kernel(CloneArgs a) {
     const int src = a.pairs[2 * pr], dst = a.pairs[2 * pr + 1];
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
         a.phi[dst * a.per + i] = a.phi[src * a.per + i];
+    if (a.phi_old) {
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
+            a.phi_old[dst * a.per + i] = a.phi_old[src * a.per + i];
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.hist_per; i += (long)gridDim.x * blockDim.x)
+            a.bp_hist[dst * a.hist_per + i] = a.bp_hist[src * a.hist_per + i];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.ot[dst] = a.ot[src]; a.ehyb[dst] = a.ehyb[src]; a.phase[dst] = a.phase[src];
         a.eloc[dst] = a.eloc[src]; a.unscaled[dst] = a.unscaled[src]; a.detR[dst] = a.detR[src];
+        if (a.phi_old) { a.bp_ph[dst] = a.bp_ph[src]; a.bp_cos[dst] = a.bp_cos[src]; a.bp_n[dst] = a.bp_n[src]; }
     }
 }
 
@@ -1019,6 +1164,8 @@ int k_comb(afq_handle *h, double r, double target) {
     CloneArgs a;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
     a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = pairs; a.scal = h->scal;
+    a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
+    a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
     // at most nw/2 pairs
     hipLaunchKernelGGL(clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());

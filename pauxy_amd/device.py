@@ -112,6 +112,24 @@ class AfqDevice(object):
         psi = _c128(psi, (self.M, self.na + self.nb))
         self._ck(self.lib.afq_set_trial(self.h, _p(psi)))
 
+    # ---- back-propagation
+    def bp_configure(self, nbp):
+        self._ck(self.lib.afq_bp_configure(self.h, int(nbp)))
+        self.nbp = int(nbp)
+
+    def bp_steps(self):
+        out = numpy.zeros(self.nw, dtype=numpy.int32)
+        self._ck(self.lib.afq_bp_steps(self.h, _p(out)))
+        return out
+
+    def bp_update(self, phi_bp0, nstblz, restore_weights=None):
+        """-> (denominator, G_bp_sum[2, M, M]); restore_weights in (None, 'partial', 'full')."""
+        mode = {None: 0, 'partial': 1, 'full': 2}.get(restore_weights, 1)
+        phi0 = _c128(phi_bp0, (self.M, self.na + self.nb))
+        out = numpy.zeros(4 + 2 * self.M * self.M, dtype=numpy.complex128)
+        self._ck(self.lib.afq_bp_update(self.h, _p(phi0), int(nstblz), mode, _p(out)))
+        return out[3], out[4:].reshape(2, self.M, self.M)
+
     def set_trial_multi(self, psi, coeffs, rchol):
         """psi [ndet, M, na+nb], coeffs [ndet], rchol [ndet * (na+nb) M, K] (stacked per determinant)."""
         nt = self.na + self.nb

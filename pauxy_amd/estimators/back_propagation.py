@@ -1,0 +1,97 @@
+"""Back-propagated estimator on the device, behind PAUXY's ``BackPropagation`` surface.
+
+Mirrors pauxy/estimators/back_propagation.py:63-326 for RHF/UHF-type single-determinant
+trials on a Generic system: same constructor signature and attributes (``tau_bp``,
+``nmax``, ``splits``, ``calc_one_rdm``, ``restore_weights``, ``init_walker``), same
+``update`` / ``print_step`` / ``zero`` methods.  The field history (walkers/stack.py
+FieldConfig), ``phi_old`` and the back-propagation itself live on the device
+(``afq_bp_configure`` / ``afq_bp_update``); one call handles the whole population.
+
+Output: instead of the reference's HDF5 groups (``back_propagated/one_rdm_<n>`` and
+``denominator_<n>``, estimators/utils.py:308-324) the per-window results are appended to
+``self.one_rdm`` / ``self.denominator`` (lists; ``rdm()`` returns their ratio like
+pauxy.analysis.extraction.extract_rdm).
+"""
+import numpy
+
+
+class BackPropagation(object):
+    def __init__(self, bp, root, filename, qmc, system, trial, dtype, BT2):
+        self.tau_bp = bp.get('tau_bp', 0)
+        self.nmax = int(self.tau_bp / qmc.dt)
+        self.header = ['E', 'E1b', 'E2b']
+        self.calc_one_rdm = bp.get('one_rdm', True)
+        self.calc_two_rdm = bp.get('two_rdm', None)
+        self.init_walker = bp.get('init_walker', False)
+        self.nsplit = bp.get('nsplit', 1)
+        self.splits = numpy.array([(i + 1) * (self.nmax // self.nsplit) for i in range(self.nsplit)])
+        self.nreg = len(self.header)
+        self.accumulated = False
+        self.eval_energy = bp.get('evaluate_energy', False)
+        self.eval_ekt = bp.get('evaluate_ekt', False)
+        self.restore_weights = bp.get('restore_weights', None)
+        if system.name != "Generic" or getattr(trial, 'ndets', 1) != 1:
+            raise NotImplementedError("device back-propagation: Generic system, single-determinant trial")
+        if self.nsplit != 1 or self.calc_two_rdm is not None or self.eval_energy or self.eval_ekt:
+            raise NotImplementedError("device back-propagation computes the one-body RDM of the full window "
+                                      "(nsplit=1, no two_rdm / energy / EKT)")
+        if self.nmax < 1:
+            raise ValueError("tau_bp shorter than one time step")
+        M = system.nbasis
+        self.G = numpy.zeros((2, M, M), dtype=numpy.complex128)
+        self.nstblz = qmc.nstblz
+        self.BT2 = BT2
+        self.dt = qmc.dt
+        self.estimates = numpy.zeros(self.nreg + 1 + self.G.size, dtype=dtype)
+        self.global_estimates = numpy.zeros(self.nreg + 1 + self.G.size, dtype=dtype)
+        self.key = {'ETotal': "BP estimate for total energy.", 'E1B': "BP estimate for one-body energy.",
+                    'E2B': "BP estimate for two-body energy."}
+        self.root = root
+        self.one_rdm = []
+        self.denominator = []
+        self.buff_ix = 0
+        self._nsteps_seen = 0
+
+    def update(self, system, qmc, trial, psi, step, free_projection=False):
+        """back_propagation.py:127-226 (update_uhf).  ``psi.walkers[0].field_configs.step`` of the
+        reference is the device's per-walker step counter; walker 0 decides, as in the reference."""
+        psi._end_sweep()
+        psi._flush()
+        dev = psi.dev
+        buff_ix = int(dev.bp_steps()[0])
+        if buff_ix not in self.splits:
+            return
+        phi0 = numpy.asarray(trial.init if self.init_walker else trial.psi, dtype=numpy.complex128)
+        if phi0.ndim == 3:
+            phi0 = phi0[0]
+        denom, G = dev.bp_update(phi0, self.nstblz, self.restore_weights)
+        self.estimates[self.nreg] += denom
+        self.estimates[self.nreg + 1:] += G.ravel()
+        psi._greens_version = -1
+        self.accumulated = True
+        self.buff_ix = buff_ix
+
+    def print_step(self, comm, nprocs, step, nsteps=1, free_projection=False):
+        """back_propagation.py:269-316."""
+        if not self.accumulated:
+            return
+        comm.Reduce(self.estimates, self.global_estimates, op=None)
+        if comm.rank == 0:
+            weight = self.global_estimates[self.nreg]
+            self.denominator.append(numpy.array(weight))
+            if self.calc_one_rdm:
+                start = self.nreg + 1
+                self.one_rdm.append(self.global_estimates[start:start + self.G.size].reshape(self.G.shape).copy())
+        self.accumulated = False
+        self.zero()
+
+    def rdm(self):
+        """one_rdm / denominator per window (analysis/extraction.py:36-62)."""
+        return numpy.array(self.one_rdm) / numpy.array(self.denominator)[:, None, None, None]
+
+    def zero(self):
+        self.estimates[:] = 0
+        self.global_estimates[:] = 0
+
+    def setup_output(self, filename):
+        pass

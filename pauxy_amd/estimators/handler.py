@@ -1,6 +1,7 @@
 """Container the driver calls (pauxy/estimators/handler.py:56-162): owns the
-``mixed`` estimator and forwards ``update`` / ``print_step``.  Back-propagation
-and ITCF estimators are not on the device path yet."""
+``mixed`` estimator (and, when requested, ``back_prop``) and forwards ``update`` /
+``print_step``.  The ITCF estimator is not on the device path."""
+from pauxy_amd.estimators.back_propagation import BackPropagation
 from pauxy_amd.estimators.mixed import Mixed
 
 
@@ -12,13 +13,18 @@ class Estimators(object):
         mixed = estimates.get('mixed', {})
         self.estimators = {}
         self.estimators['mixed'] = Mixed(mixed, system, root, self.filename, qmc, trial, complex)
-        for key in ('back_propagation', 'back_propagated', 'itcf'):
-            if estimates.get(key) is not None:
-                raise NotImplementedError("%s estimator is not on the device path yet" % key)
-        self.back_propagation = False
+        if estimates.get('itcf') is not None:
+            raise NotImplementedError("itcf estimator is not on the device path yet")
+        bp = estimates.get('back_propagation', estimates.get('back_propagated'))     # handler.py:83-85
+        self.back_propagation = bp is not None
+        if self.back_propagation:
+            self.estimators['back_prop'] = BackPropagation(bp, root, self.filename, qmc, system, trial, complex, BT2)
+            self.nprop_tot = self.estimators['back_prop'].nmax                           # handler.py:91-92
+            self.nbp = self.estimators['back_prop'].nmax
+        else:
+            self.nprop_tot = None
+            self.nbp = None
         self.calc_itcf = False
-        self.nprop_tot = None
-        self.nbp = None
         self.json_string = ''
 
     def dump_metadata(self):

@@ -36,12 +36,13 @@ class AFQMC(object):
         prop_opt = dict(options.get('propagator', {}))
         prop_opt.setdefault('hubbard_stratonovich', 'continuous')
         self.propagators = get_propagator_driver(system, trial, self.qmc, options=prop_opt, verbose=verbose)
-        est_opts = options.get('estimators', options.get('estimates', {}))
+        est_opts = options.get('estimators', options.get('estimates', options.get('estimator', {})))
         self.estimators = Estimators(est_opts, self.comm.rank == 0, self.qmc, system, trial,
                                      self.propagators.BT_BP, verbose)
         self.qmc.nwalkers = max(1, int(self.qmc.nwalkers / self.comm.size))       # afqmc.py:167-176
         self.qmc.ntot_walkers = self.qmc.nwalkers * self.comm.size
-        self.psi = Walkers(system, trial, self.qmc, walker_opts=options.get('walkers', {}), comm=self.comm)
+        self.psi = Walkers(system, trial, self.qmc, walker_opts=options.get('walkers', {}), comm=self.comm,
+                           nprop_tot=self.estimators.nprop_tot, nbp=self.estimators.nbp)       # afqmc.py:177-182
         self.setup_timers()
 
     def setup_timers(self):

@@ -181,8 +181,8 @@ class Walkers(object):
             raise NotImplementedError("HDF5 walker restart files are outside the device hot path")
         if self.use_log_shift:
             raise NotImplementedError("use_log_shift is not supported")
-        if nbp is not None:
-            raise NotImplementedError("back-propagation field history is not on the device path yet")
+        if nbp is not None and nprop_tot is not None and nprop_tot != nbp:
+            raise NotImplementedError("ITCF field history (nprop_tot != nbp) is not on the device path")
         self.walker_type = 'SD' if getattr(trial, 'ndets', 1) == 1 else 'MSD'     # walkers/handler.py:53-68
         if (self.walker_type == 'SD' and getattr(trial, 'name', '') == 'MultiSlater'
                 and numpy.asarray(trial.psi).ndim == 3):
@@ -223,6 +223,8 @@ class Walkers(object):
         ot = self.dev.calc_overlap()                       # single_det.py:65-67
         self.dev.set(L.F_OT, ot)
         self.walkers = [WalkerView(self, i) for i in range(self.nw)]
+        self.nbp = nbp
+        self._bp_pending = nbp is not None        # afq_bp_configure needs the propagator (BH1^H): deferred
         self.set_total_weight(qmc.ntot_walkers)
         # E_L of the initial walkers (single_det.py:86-92) is evaluated lazily on request
         self.buff_size = init.size + 7
@@ -238,6 +240,10 @@ class Walkers(object):
 
     def _flush(self):
         """Upload host-side writes before any device launch."""
+        if self._bp_pending and self.ctx.propagator_set:
+            # walkers/walker.py:43,55-58: field history + phi_old (the initial walker) per walker
+            self.dev.bp_configure(self.nbp)
+            self._bp_pending = False
         for name in list(self._dirty):
             self.dev.set(_SCALARS[name][0], self._host[name])
         self._dirty.clear()

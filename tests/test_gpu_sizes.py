@@ -97,3 +97,51 @@ def test_vhs_nonsymmetric_cholesky():
     close(vhs[:, 0], numpy.array([model.vhs(x) for x in xs]))
     assert abs(vhs[0, 0, 5, 7] - vhs[0, 0, 7, 5]) > 1e-6
     dev.close()
+
+
+@pytest.mark.parametrize("M,K,na,nb,restore", [(37, 45, 7, 6, None), (120, 40, 9, 9, 'full')])
+def test_back_propagation_with_reortho(M, K, na, nb, restore):
+    """afq_bp_update against the oracle with a window longer than the stabilisation period (the
+    re-orthogonalisation inside the back-propagation, propagation/generic.py:286-288, is not reached by
+    the reference's own 5-step test), a walker copy in the middle of the window (history travels with
+    the walker) and both propagator paths (fused kernel for M=37, separate GEMMs for M=120)."""
+    model, rng = build(M, K, na, nb, True)
+    nw, nbp, nstblz = 5, 7, 3
+    dev = make_device(model, nw)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_OT, dev.calc_overlap())
+    dev.bp_configure(nbp)
+    walkers = [ref.new_walker(model, p) for p in phis]
+    for w in walkers:
+        w['bp'] = ref.bp_new(K, nbp)
+        w['phi_old'] = w['phi'].copy()
+    for step in range(nbp):
+        xi = rng.normal(size=(nw, K))
+        dev.propagate(xi, 0.2)
+        for w, x in zip(walkers, xi):
+            ref.propagate_walker_phaseless(model, w, x, 0.2)
+        if step == 3:
+            dev.copy_walker(0, 3)
+            src = walkers[0]
+            walkers[3] = {k: (ref.bp_copy(v) if k == 'bp' else (v.copy() if isinstance(v, numpy.ndarray) else v))
+                          for k, v in src.items()}
+    assert list(dev.bp_steps()) == [nbp] * nw
+    close(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]), 1e-9)
+    est = numpy.zeros(4 + 2 * M * M, dtype=complex)
+    ref.bp_update(model, walkers, nstblz, est, restore)
+    denom, G = dev.bp_update(model.psi, nstblz, restore)
+    close(denom, est[3], 1e-9)
+    close(G, est[4:].reshape(2, M, M), 1e-8)
+    assert list(dev.bp_steps()) == [0] * nw
+    # phi_old <- phi: a second window starts from the propagated walkers
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, 0.2)
+    for w, x in zip(walkers, xi):
+        ref.propagate_walker_phaseless(model, w, x, 0.2)
+    est = numpy.zeros(4 + 2 * M * M, dtype=complex)
+    ref.bp_update(model, walkers, nstblz, est, restore)
+    denom, G = dev.bp_update(model.psi, nstblz, restore)
+    close(denom, est[3], 1e-9)
+    close(G, est[4:].reshape(2, M, M), 1e-8)
+    dev.close()

@@ -43,12 +43,13 @@ class Replay(object):
         return next(self.r)
 
 
-def replay(d, system, trial, prop_opts, monkeypatch):
+def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None):
     options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
                        'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
                        'num_walkers': d['phi0'].shape[0]},
                'propagator': prop_opts,
                'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
+    options['estimators'].update(est_extra or {})
     afqmc = AFQMC(options=options, system=system, trial=trial)
     close(afqmc.propagators.propagator.BH1, d['BH1'], 1e-12)
     close(afqmc.propagators.propagator.mf_shift, d['mf_shift'], 1e-12)
@@ -86,6 +87,8 @@ def replay(d, system, trial, prop_opts, monkeypatch):
     assert afqmc.propagators.nfb_trig == int(d['nfb_trig'])
     assert afqmc.propagators.nhe_trig == int(d['nhe_trig'])
     est = mixed.estimates.copy()
+    if out is not None:
+        out['afqmc'] = afqmc
     release_context(system, trial)
     return est
 
@@ -149,3 +152,31 @@ def test_traj_msd(golden, monkeypatch):
     s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
     t = trial_mod.MultiDetTrial(s, (d['coeffs'], d['psi']), init=d['phi0'][0])
     replay(d, s, t, {}, monkeypatch)
+
+
+def run_bp(golden, monkeypatch, name, restore):
+    d = golden(name)
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    bp = {'tau_bp': 0.025, 'one_rdm': True}
+    if restore is not None:
+        bp['restore_weights'] = restore
+    out = {}
+    replay(d, s, t, {}, monkeypatch, est_extra={'back_propagated': bp}, out=out)
+    est = out['afqmc'].estimators.estimators['back_prop']
+    close(numpy.array(est.denominator), d['bp_denominator'])
+    close(numpy.array(est.one_rdm), d['bp_one_rdm'])
+    return est.rdm()
+
+
+def test_traj_back_propagation(golden, monkeypatch):
+    """SURVEY 8f-2, qmc/tests/test_afqmc.py:232-278: back-propagated one-body RDM (5-step window) next to the
+    mixed estimator, comb every step; every window's RDM and the pinned element."""
+    rdm = run_bp(golden, monkeypatch, 'traj_bp.npz', None)
+    assert rdm[0, 0].trace() == pytest.approx(3.0, rel=1e-9)
+    assert rdm[11, 0, 1, 3].real == pytest.approx(-0.121883381144845, rel=1e-7)
+
+
+def test_traj_back_propagation_restored_weights(golden, monkeypatch):
+    run_bp(golden, monkeypatch, 'traj_bp_full.npz', 'full')
