@@ -391,8 +391,11 @@ class WalkerTransport(object):
         self.dev = dev
         self.comm = comm
         self.nbytes = dev.pack_bytes()
-        self.gpu = torch.device('cuda', dev.device_id)          # pack / unpack work on device memory
-        self.direct = getattr(comm, 'device', None) is not None and comm.device.type == 'cuda'
+        # pack / unpack work on the memory the walkers live in: the GPU of an AfqDevice (host memory for
+        # the numpy stand-in of the CPU tests, which says so through ``buffer_device``)
+        self.gpu = torch.device(getattr(dev, 'buffer_device', None) or ('cuda:%d' % dev.device_id))
+        self.direct = self.gpu.type == 'cpu' or (getattr(comm, 'device', None) is not None and
+                                                comm.device.type == 'cuda')
 
     def _buf(self):
         return self.torch.empty(self.nbytes // 8, dtype=self.torch.float64, device=self.gpu)
@@ -412,7 +415,8 @@ class WalkerTransport(object):
             host = self.torch.empty(self.nbytes // 8, dtype=self.torch.float64)
             self.comm.recv_tensor(host, source, tag)
             buf.copy_(host)
-        self.torch.cuda.current_stream(buf.device).synchronize()
+        if buf.is_cuda:
+            self.torch.cuda.current_stream(buf.device).synchronize()
         self.dev.unpack(iw, buf.data_ptr())
         self.dev.sync()
 

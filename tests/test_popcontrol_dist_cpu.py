@@ -25,6 +25,7 @@ NW, M, NE = 4, 3, 2
 
 class NumpyDevice(object):
     """Stand-in for AfqDevice (tests only): same packed layout as afq_walker_pack."""
+    buffer_device = 'cpu'           # walkers live in host memory: WalkerTransport needs no staging
 
     def __init__(self, phi, weight):
         self.phi = phi.copy()
