@@ -107,6 +107,12 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
                        const double *vqvec, double vol, const double *H1diag, double ecore);
 /* trial determinant psi c128[M, na+nb] (trial.psi after walkers/handler.py:61) */
 int afq_set_trial(afq_handle *h, const double *psi);
+/* Local energy of a generic Cholesky Hamiltonian from FULL Green's functions
+ * (estimators/generic.py:398-434, local_energy_generic_cholesky; what estimators/mixed.py:383-437
+ * dispatches to when no half-rotated Ghalf is given): G c128[n, 2, M, M] -> E c128[n, 3] = (E, E1b, E2b).
+ * O(M^3 K) per Green's function; not on the per-step path.                                       */
+int afq_local_energy_full_g(afq_handle *h, const double *G, int n, double *E_out);
+
 /* ---- back-propagated estimator --------------------------------
  * estimators/back_propagation.py:63-226, walkers/stack.py:5-127 (FieldConfig),
  * propagation/generic.py:181-211,253-290.  After afq_bp_configure every
@@ -124,9 +130,10 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out);
  * G_bp[w] = gab(phi_bp, phi_old)^T and returns est_out c128[4 + 2 M M] =
  * [0, 0, 0, sum_w wt_w, sum_w wt_w G_bp[w]] with wt = weight (restore_weights 0),
  * weight * prod(I/|I|) (1, "partial") or weight * prod(I/|I|) / prod(cos) (2, "full");
- * then resets the histories and copies phi -> phi_old.  Energies (entries 0-2) are
- * not evaluated (evaluate_energy is off by default in the reference).            */
-int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, double *est_out);
+ * then resets the histories and copies phi -> phi_old.  With eval_energy the entries 0-2 are
+ * sum_w wt_w (E, E1b, E2b)[G_bp[w]] from the full-G Cholesky energy (generic systems).          */
+int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
+                  double *est_out);
 
 /* Multi-determinant (NOMSD / PHMSD) trial |psi_T> = sum_d c_d |D_d> for a generic system, replacing
  * the single-determinant operands of afq_set_system_generic / afq_set_trial.  Call after the

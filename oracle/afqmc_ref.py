@@ -466,7 +466,7 @@ def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt):
     return phi
 
 
-def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None):
+def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval_energy=False):
     """estimators/back_propagation.py:127-226 (update_uhf, one_rdm only).  ``est`` is
     [3 energies, denominator, G.flatten()]; called when the field buffers are full; resets them
     and copies phi -> phi_old (walkers/handler.py:200-203)."""
@@ -484,6 +484,8 @@ def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None):
             weight = w['weight'] * wfac
         else:
             weight = w['weight']
+        if eval_energy:      # local_energy(system, G, opt=False) -> full-G Cholesky energy (:159-163)
+            est[:3] += weight * numpy.array(local_energy_generic_cholesky(model.H1, model.ecore, G, model.hs_pot))
         est[3] += weight
         est[4:] += weight * G.flatten()
         fc['step'] = 0                                      # FieldConfig.reset (stack.py:124-127)
@@ -767,7 +769,7 @@ def block_reduce(est, nsteps):
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
               record=None, verbose=False, free_projection=False, nbp=None, bp_out=None,
-              restore_weights=None):
+              restore_weights=None, bp_energy=False):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -826,7 +828,7 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
         mixed_update(model, est, walkers, step, energy_eval_freq, free_projection)
         if nbp is not None and walkers[0]['bp']['step'] == nbp:     # back_propagation.py:145-147
             bpe = numpy.zeros(4 + 2 * model.M * model.M, dtype=numpy.complex128)
-            bp_update(model, walkers, nstblz, bpe, restore_weights)
+            bp_update(model, walkers, nstblz, bpe, restore_weights, eval_energy=bp_energy)
             bp_out.append(bpe)                                       # print_step: one Reduce per window
         if record is not None:
             record.append(dict(

@@ -67,7 +67,8 @@ SIGNATURES = {
     "afq_last_energy_kernel_ms": [_h, POINTER(c_double)],
     "afq_bp_configure": [_h, c_int],
     "afq_bp_steps": [_h, _dp],
-    "afq_bp_update": [_h, _dp, c_int, c_int, _dp],
+    "afq_bp_update": [_h, _dp, c_int, c_int, c_int, _dp],
+    "afq_local_energy_full_g": [_h, _dp, c_int, _dp],
     "afq_set_trial_multi": [_h, c_int, _dp, _dp, _dp],
     "afq_walkers_det_weights": [_h, _dp],
     "afq_kernel_trace": [_h, c_int],

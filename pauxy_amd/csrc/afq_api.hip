@@ -71,7 +71,7 @@ void free_dets(afq_handle *h) {
 
 void free_system(afq_handle *h) {
     free_dets(h);
-    dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->rchol_re); dev_free(h->rchol_im);
+    dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     dev_free(h->H1); dev_free(h->rH1);
     dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val);
@@ -1066,7 +1066,8 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
     return copy_out(h, steps_out, h->bp_n, sizeof(int) * h->nw);
 }
 
-int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, double *est_out) {
+int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
+                  double *est_out) {
     if (h) h->greens_valid = false;
     if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
     int rc = need_ready(h, true);
@@ -1112,12 +1113,32 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     h->phi = s_phi; h->psi = s_psi; h->psic = s_psic; h->psi_stride = 0;
     if (rc) return rc;
     AFQ_HIP(h, hipMemsetAsync(h->bp_est, 0, sizeof(cplx) * ((size_t)4 + 2 * h->M * h->M), h->stream));
-    if ((rc = k_bp_accumulate(h, restore_weights))) return rc;
+    if (eval_energy) {
+        // local_energy(system, G_bp, opt=False) (back_propagation.py:159-163): the full-G Cholesky energy
+        if (h->kind != AFQ_SYS_GENERIC) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagated energies: generic systems only");
+        if ((rc = k_energy_full_g(h, h->G, h->nw, h->energy))) return rc;
+    }
+    if ((rc = k_bp_accumulate(h, restore_weights, eval_energy))) return rc;
     // FieldConfig.reset + Walkers.copy_historic_wfn (walkers/stack.py:124-127, handler.py:200-203)
     if ((rc = k_bp_reset(h))) return rc;
     AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
     if ((rc = k_alive(h))) return rc;
     return copy_out(h, est_out, h->bp_est, sizeof(cplx) * ((size_t)4 + 2 * h->M * h->M));
+}
+
+int afq_local_energy_full_g(afq_handle *h, const double *G, int n, double *E_out) {
+    if (!h || !G || !E_out || n < 1) return AFQ_EINVAL;
+    if (h->kind != AFQ_SYS_GENERIC) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "full-G Cholesky energy: generic systems only");
+    hipSetDevice(h->device);
+    const size_t gsz = (size_t)2 * h->M * h->M * n;
+    cplx *Gd = nullptr, *Ed = nullptr;
+    int rc;
+    if ((rc = dev_upload(h, &Gd, G, gsz))) return rc;
+    if ((rc = dev_alloc(h, &Ed, (size_t)3 * n))) { dev_free(Gd); return rc; }
+    rc = k_energy_full_g(h, Gd, n, Ed);
+    if (!rc) rc = copy_out(h, E_out, Ed, sizeof(cplx) * 3 * n);
+    dev_free(Gd); dev_free(Ed);
+    return rc;
 }
 
 int afq_walkers_det_weights(afq_handle *h, double *weights_out) {

@@ -47,6 +47,7 @@ struct afq_handle {
     // generic
     double *hs_pot = nullptr;       // f64, TRANSPOSED: [K, ld_hs] with ld_hs = M*M rounded up to even (zero pad)
     bool hs_sym = false;            // L_n symmetric: hs_pot holds only the columns (p <= q), [K, ld_hs]
+    double *L_full = nullptr;       // [K, M, Mp] every L_n as a padded row-major matrix (full-G energy; built on first use)
     int2 *hs_pair = nullptr;        // [M(M+1)/2] (p, q) of every packed column
     long ld_hs = 0, ld_rc = 0;      // leading dimensions of hs_pot^T and of rchol_re/im (K rounded up to even)
     bool rchol_real = true;
@@ -226,6 +227,8 @@ int k_full_G(afq_handle *h);                                // G = conj(psi) gha
 // k_fused.hip
 int k_prop_fused_supported(afq_handle *h);
 int k_prop_fused(afq_handle *h);                           // phi <- B exp(V) B phi for live walkers, in place
+// k_fullg.hip
+int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev);   // estimators/generic.py:398-434
 // k_bigdet.hip
 int k_greens_big_supported(afq_handle *h);
 int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det);   // ghalf may be null (overlap only)
@@ -242,7 +245,7 @@ int k_bp_fields(afq_handle *h, int i);
 int k_bp_init(afq_handle *h, const cplx *phi0_dev);
 int k_conj_copy(afq_handle *h, const cplx *src, cplx *dst, long n);
 int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At);
-int k_bp_accumulate(afq_handle *h, int restore);
+int k_bp_accumulate(afq_handle *h, int restore, int with_energy);
 int k_bp_reset(afq_handle *h);
 int k_xbar_fields(afq_handle *h);                           // xbar + clip + shift in one launch
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw

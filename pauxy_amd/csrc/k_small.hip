@@ -803,18 +803,21 @@ __global__ void conj_transpose_kernel(const cplx *A, cplx *At, int M) {      // 
 
 // estimators/back_propagation.py:187-207: est[3] += w, est[4:] += w G_bp, w = weight (x restored factor)
 __global__ void bp_accumulate_kernel(const cplx *G, const double *weight, const double *bp_cos, const cplx *bp_ph,
-                                     cplx *est, int nw, long gsz, int restore) {
+                                     cplx *est, int nw, long gsz, int restore, const cplx *energy) {
     const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (e > gsz) return;
+    if (e > gsz + 3) return;
+    if (e > gsz && !energy) return;
     cplx acc = cmake(0.0, 0.0);
     for (int w = 0; w < nw; ++w) {
         cplx wt = cmake(weight[w], 0.0);
         if (restore == 1) wt = cmul(wt, bp_ph[w]);                                       // BP-PRes (partial)
         else if (restore == 2) wt = cmul(wt, cmake(bp_ph[w].x / bp_cos[w], bp_ph[w].y / bp_cos[w]));   // full
         if (e == gsz) acc = cadd(acc, wt);
+        else if (e > gsz) cfma(acc, wt, energy[3 * w + (e - gsz - 1)]);      // estimates[:nreg] += weight * energies
         else cfma(acc, wt, G[(long)w * gsz + e]);
     }
     if (e == gsz) est[3] = cadd(est[3], acc);
+    else if (e > gsz) est[e - gsz - 1] = cadd(est[e - gsz - 1], acc);
     else est[4 + e] = cadd(est[4 + e], acc);
 }
 
@@ -858,10 +861,11 @@ int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At) {
     return AFQ_OK;
 }
 
-int k_bp_accumulate(afq_handle *h, int restore) {
+int k_bp_accumulate(afq_handle *h, int restore, int with_energy) {
     const long gsz = 2L * h->M * h->M;
-    hipLaunchKernelGGL(bp_accumulate_kernel, dim3((unsigned)((gsz + 1 + 127) / 128)), dim3(128), 0, h->stream, h->G,
-                       h->weight, h->bp_cos, h->bp_ph, h->bp_est, h->nw, gsz, restore);
+    hipLaunchKernelGGL(bp_accumulate_kernel, dim3((unsigned)((gsz + 4 + 127) / 128)), dim3(128), 0, h->stream, h->G,
+                       h->weight, h->bp_cos, h->bp_ph, h->bp_est, h->nw, gsz, restore,
+                       with_energy ? h->energy : (const cplx *)nullptr);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }

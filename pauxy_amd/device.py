@@ -122,13 +122,22 @@ class AfqDevice(object):
         self._ck(self.lib.afq_bp_steps(self.h, _p(out)))
         return out
 
-    def bp_update(self, phi_bp0, nstblz, restore_weights=None):
-        """-> (denominator, G_bp_sum[2, M, M]); restore_weights in (None, 'partial', 'full')."""
+    def local_energy_full_g(self, G):
+        """(E, E1b, E2b) of Green's functions G[n, 2, M, M] by the full-G Cholesky energy."""
+        G = _c128(G)
+        n = G.shape[0]
+        G = _c128(G, (n, 2, self.M, self.M))
+        out = numpy.zeros((n, 3), dtype=numpy.complex128)
+        self._ck(self.lib.afq_local_energy_full_g(self.h, _p(G), n, _p(out)))
+        return out
+
+    def bp_update(self, phi_bp0, nstblz, restore_weights=None, eval_energy=False):
+        """-> (energies_sum[3], denominator, G_bp_sum[2, M, M]); restore_weights in (None, 'partial', 'full')."""
         mode = {None: 0, 'partial': 1, 'full': 2}.get(restore_weights, 1)
         phi0 = _c128(phi_bp0, (self.M, self.na + self.nb))
         out = numpy.zeros(4 + 2 * self.M * self.M, dtype=numpy.complex128)
-        self._ck(self.lib.afq_bp_update(self.h, _p(phi0), int(nstblz), mode, _p(out)))
-        return out[3], out[4:].reshape(2, self.M, self.M)
+        self._ck(self.lib.afq_bp_update(self.h, _p(phi0), int(nstblz), mode, int(bool(eval_energy)), _p(out)))
+        return out[:3], out[3], out[4:].reshape(2, self.M, self.M)
 
     def set_trial_multi(self, psi, coeffs, rchol):
         """psi [ndet, M, na+nb], coeffs [ndet], rchol [ndet * (na+nb) M, K] (stacked per determinant)."""

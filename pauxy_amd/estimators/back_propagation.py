@@ -9,7 +9,7 @@ FieldConfig), ``phi_old`` and the back-propagation itself live on the device
 
 Output: instead of the reference's HDF5 groups (``back_propagated/one_rdm_<n>`` and
 ``denominator_<n>``, estimators/utils.py:308-324) the per-window results are appended to
-``self.one_rdm`` / ``self.denominator`` (lists; ``rdm()`` returns their ratio like
+``self.one_rdm`` / ``self.denominator`` / ``self.energies`` (lists; ``rdm()`` returns their ratio like
 pauxy.analysis.extraction.extract_rdm).
 """
 import numpy
@@ -32,9 +32,9 @@ class BackPropagation(object):
         self.restore_weights = bp.get('restore_weights', None)
         if system.name != "Generic" or getattr(trial, 'ndets', 1) != 1:
             raise NotImplementedError("device back-propagation: Generic system, single-determinant trial")
-        if self.nsplit != 1 or self.calc_two_rdm is not None or self.eval_energy or self.eval_ekt:
-            raise NotImplementedError("device back-propagation computes the one-body RDM of the full window "
-                                      "(nsplit=1, no two_rdm / energy / EKT)")
+        if self.nsplit != 1 or self.calc_two_rdm is not None or self.eval_ekt:
+            raise NotImplementedError("device back-propagation covers the full window (nsplit=1): one-body RDM "
+                                      "and energies; no two_rdm / EKT")
         if self.nmax < 1:
             raise ValueError("tau_bp shorter than one time step")
         M = system.nbasis
@@ -49,6 +49,7 @@ class BackPropagation(object):
         self.root = root
         self.one_rdm = []
         self.denominator = []
+        self.energies = []
         self.buff_ix = 0
         self._nsteps_seen = 0
 
@@ -64,7 +65,8 @@ class BackPropagation(object):
         phi0 = numpy.asarray(trial.init if self.init_walker else trial.psi, dtype=numpy.complex128)
         if phi0.ndim == 3:
             phi0 = phi0[0]
-        denom, G = dev.bp_update(phi0, self.nstblz, self.restore_weights)
+        energies, denom, G = dev.bp_update(phi0, self.nstblz, self.restore_weights, self.eval_energy)
+        self.estimates[:self.nreg] += energies
         self.estimates[self.nreg] += denom
         self.estimates[self.nreg + 1:] += G.ravel()
         psi._greens_version = -1
@@ -79,6 +81,9 @@ class BackPropagation(object):
         if comm.rank == 0:
             weight = self.global_estimates[self.nreg]
             self.denominator.append(numpy.array(weight))
+            if self.eval_energy:                        # back_propagation.py:291-297
+                e = self.global_estimates[:self.nreg]
+                self.energies.append(e.copy() if free_projection else e / weight)
             if self.calc_one_rdm:
                 start = self.nreg + 1
                 self.one_rdm.append(self.global_estimates[start:start + self.G.size].reshape(self.G.shape).copy())

@@ -124,7 +124,7 @@ def local_energy(system, G, Ghalf=None, two_rdm=None, rchol=None, eri=None, C0=N
     """pauxy.estimators.mixed.local_energy (mixed.py:383-437) for ONE Green's
     function, evaluated by the device energy kernels.  ``device`` is the
     AfqDevice that already holds ``system`` (see pauxy_amd.context); ``Ghalf``
-    is required for Generic / Hubbard, ``G`` for UEG."""
+    (half-rotated form) or, without it, the full ``G`` is used for Generic; ``G`` for UEG."""
     from pauxy_amd import _lib as L
     if device is None:
         raise ValueError("local_energy needs the AfqDevice holding the system (device=...)")
@@ -134,7 +134,9 @@ def local_energy(system, G, Ghalf=None, two_rdm=None, rchol=None, eri=None, C0=N
         device.set(L.F_G, numpy.asarray(G, dtype=numpy.complex128), 0)
     else:
         if Ghalf is None:
-            raise NotImplementedError("full-G Cholesky energy (estimators/generic.py:398-434) is not on the device path yet")
+            # estimators/generic.py:398-434 (local_energy_generic_cholesky): full-G form
+            E = device.local_energy_full_g(numpy.asarray(G, dtype=numpy.complex128)[None])[0]
+            return (complex(E[0]), complex(E[1]), complex(E[2]))
         device.set(L.F_GHALF, numpy.concatenate([Ghalf[0], Ghalf[1]]).astype(numpy.complex128), 0)
     E = device.local_energy()[0]
     return (complex(E[0]), complex(E[1]), complex(E[2]))

@@ -647,7 +647,7 @@ def make_traj_msd():
 
 
 
-def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10):
+def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=False):
     """qmc/tests/test_afqmc.py:232-278: single-determinant generic run with the back-propagated
     one-body RDM (tau_bp = 5 steps); pinned rdm[11,0,1,3].real == -0.121883381144845."""
     out = {}
@@ -655,6 +655,8 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10):
     bp = {'tau_bp': 0.025, 'one_rdm': True}
     if restore_weights is not None:
         bp['restore_weights'] = restore_weights
+    if energy:
+        bp['evaluate_energy'] = True
     options = {'verbosity': 0, 'get_sha1': False,
                'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': blocks, 'rng_seed': 8},
                'trial': {'name': 'MultiSlater'},
@@ -679,6 +681,9 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10):
     assert len(dk) == len(rk) and len(dk) > 0
     out['bp_denominator'] = numpy.array([store[k] for k in dk]).reshape(len(dk))
     out['bp_one_rdm'] = numpy.array([store[k] for k in rk])
+    ek = sorted(k for k in store if k.startswith('back_propagated/energies_5/'))
+    if ek:
+        out['bp_energies'] = numpy.array([store[k] for k in ek])
     rdm = out['bp_one_rdm'] / out['bp_denominator'][:, None, None, None]
     if restore_weights is None and blocks == 10:
         assert abs(rdm[0, 0].trace() - nelec[0]) < 1e-10 and abs(rdm[0, 1].trace() - nelec[1]) < 1e-10
@@ -715,6 +720,8 @@ if __name__ == '__main__':
     make_traj_msd()
     make_traj_bp()
     make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
+    # (evaluate_energy: the reference raises TypeError at back_propagation.py:160 -- local_energy() has no
+    #  'opt' keyword -- so there is no reference output to record for back-propagated energies)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

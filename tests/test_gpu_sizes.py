@@ -129,10 +129,11 @@ def test_back_propagation_with_reortho(M, K, na, nb, restore):
     assert list(dev.bp_steps()) == [nbp] * nw
     close(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]), 1e-9)
     est = numpy.zeros(4 + 2 * M * M, dtype=complex)
-    ref.bp_update(model, walkers, nstblz, est, restore)
-    denom, G = dev.bp_update(model.psi, nstblz, restore)
+    ref.bp_update(model, walkers, nstblz, est, restore, eval_energy=True)
+    energies, denom, G = dev.bp_update(model.psi, nstblz, restore, eval_energy=True)
     close(denom, est[3], 1e-9)
     close(G, est[4:].reshape(2, M, M), 1e-8)
+    close(energies, est[:3], 1e-8)        # full-G Cholesky energy of every G_bp (estimators/generic.py:398-434)
     assert list(dev.bp_steps()) == [0] * nw
     # phi_old <- phi: a second window starts from the propagated walkers
     xi = rng.normal(size=(nw, K))
@@ -141,7 +142,8 @@ def test_back_propagation_with_reortho(M, K, na, nb, restore):
         ref.propagate_walker_phaseless(model, w, x, 0.2)
     est = numpy.zeros(4 + 2 * M * M, dtype=complex)
     ref.bp_update(model, walkers, nstblz, est, restore)
-    denom, G = dev.bp_update(model.psi, nstblz, restore)
+    energies, denom, G = dev.bp_update(model.psi, nstblz, restore)
     close(denom, est[3], 1e-9)
     close(G, est[4:].reshape(2, M, M), 1e-8)
+    assert numpy.all(energies == 0)
     dev.close()
