@@ -410,6 +410,126 @@ EST = dict(uweight=0, weight=1, enumer=2, edenom=3, eproj=4, e1b=5, e2b=6,
 
 
 
+
+# --------------------------------------------------------------------------
+# Discrete Hirsch HS transformation for the Hubbard model
+# --------------------------------------------------------------------------
+class HirschModel(object):
+    """Constants of propagation/hubbard.py:28-85 (Hirsch.__init__) for RHF/UHF-type trials."""
+
+    def __init__(self, T, U, psi, na, nb, dt, charge_decomposition=False):
+        self.kind = 'hubbard_hirsch'
+        self.M, self.na, self.nb = T.shape[-1], na, nb
+        self.psi = psi
+        self.H1 = T
+        self.U = U
+        self.dt = dt
+        self.bt2 = numpy.array([scipy.linalg.expm(-0.5 * dt * T[0]), scipy.linalg.expm(-0.5 * dt * T[1])])
+        self.BH1 = self.bt2
+        self.charge = charge_decomposition
+        if charge_decomposition:
+            self.gamma = numpy.arccosh(numpy.exp(-0.5 * dt * U + 0j))
+            auxf = numpy.array([[numpy.exp(self.gamma), numpy.exp(self.gamma)],
+                                [numpy.exp(-self.gamma), numpy.exp(-self.gamma)]])
+            self.aux_wfac = numpy.exp(0.5 * dt * U) * numpy.array([numpy.exp(-self.gamma), numpy.exp(self.gamma)])
+        else:
+            self.gamma = numpy.arccosh(numpy.exp(0.5 * dt * U))
+            auxf = numpy.array([[numpy.exp(self.gamma), numpy.exp(-self.gamma)],
+                                [numpy.exp(-self.gamma), numpy.exp(self.gamma)]])
+            self.aux_wfac = numpy.array([1.0, 1.0])
+        self.auxf = auxf * numpy.exp(-0.5 * dt * U)
+        self.delta = self.auxf - 1
+        self.nfields = self.M
+
+    def greens(self, phi):
+        return greens_function(phi, self.psi, self.na, self.nb)
+
+    def overlap(self, phi):
+        return calc_overlap(phi, self.psi, self.na, self.nb)
+
+    def local_energy(self, G, Ghalf):
+        return local_energy_hubbard(self.H1, self.U, G)
+
+
+def hirsch_inverse_overlap(model, w):
+    """walkers/single_det.py:95-115."""
+    na = model.na
+    w['inv_ovlp'] = [scipy.linalg.inv((model.psi[:, :na].conj()).T.dot(w['phi'][:, :na])),
+                     scipy.linalg.inv((model.psi[:, na:].conj()).T.dot(w['phi'][:, na:]))]
+
+
+def hirsch_calc_otrial(w):
+    """walkers/single_det.py:141-168: 1 / (det inv_ovlp_a det inv_ovlp_b)."""
+    sa, la = numpy.linalg.slogdet(w['inv_ovlp'][0])
+    sb, lb = numpy.linalg.slogdet(w['inv_ovlp'][1])
+    return 1.0 / (sa * sb * numpy.exp(la + lb))
+
+
+def hirsch_kinetic_importance_sampling(model, w):
+    """propagation/hubbard.py:148-172."""
+    kinetic_real(w['phi'], model.bt2, model.na)
+    hirsch_inverse_overlap(model, w)
+    ot_new = hirsch_calc_otrial(w)
+    ratio = ot_new / w['ot']
+    if abs(cmath.phase(ratio)) < 0.5 * math.pi:
+        w['weight'] = w['weight'] * ratio.real
+        w['ot'] = ot_new
+    else:
+        w['weight'] = 0.0
+
+
+def sherman_morrison(Ainv, u, vt):
+    """utils/linalg.py:6-30."""
+    return Ainv - (Ainv.dot(numpy.outer(u, vt)).dot(Ainv)) / (1.0 + vt.dot(Ainv).dot(u))
+
+
+def hirsch_two_body_single_site(model, w, uniform):
+    """propagation/hubbard.py:174-225.  ``uniform()`` is numpy.random.random; returns the chosen fields."""
+    na, M = model.na, model.M
+    delta = model.delta
+    fields = []
+    for i in range(M):
+        Gii = []
+        for s, sl in ((0, slice(0, na)), (1, slice(na, None))):                   # :110-122
+            q = numpy.dot(w['inv_ovlp'][s].T, w['phi'][i, sl])
+            Gii.append(numpy.dot(model.psi.conj()[i, sl], q))
+        probs = 0.5 * numpy.array([(1 + delta[0][0] * Gii[0]) * (1 + delta[0][1] * Gii[1]),
+                                   (1 + delta[1][0] * Gii[0]) * (1 + delta[1][1] * Gii[1])])   # :549-551
+        probs = probs * model.aux_wfac
+        phaseless_ratio = numpy.maximum(probs.real, [0, 0])
+        norm = sum(phaseless_ratio)
+        r = uniform()
+        if norm > 0:
+            w['weight'] = w['weight'] * norm
+            xi = 0 if r < phaseless_ratio[0] / norm else 1
+            vtup = w['phi'][i, :na] * delta[xi, 0]
+            vtdown = w['phi'][i, na:] * delta[xi, 1]
+            w['phi'][i, :na] = w['phi'][i, :na] + vtup
+            w['phi'][i, na:] = w['phi'][i, na:] + vtdown
+            w['ot'] = 2 * w['ot'] * probs[xi]                                      # single_det.py:213
+            fields.append(xi)
+            w['inv_ovlp'][0] = sherman_morrison(w['inv_ovlp'][0], model.psi[i, :na].conj(), vtup)
+            w['inv_ovlp'][1] = sherman_morrison(w['inv_ovlp'][1], model.psi[i, na:].conj(), vtdown)
+        else:
+            w['weight'] = 0
+            return fields
+    return fields
+
+
+def propagate_walker_hirsch(model, w, uniform, eshift):
+    """propagation/hubbard.py:285-312 (propagate_walker_constrained)."""
+    fields = None
+    if abs(w['weight']) > 0:
+        hirsch_kinetic_importance_sampling(model, w)
+    if abs(w['weight']) > 0:
+        fields = hirsch_two_body_single_site(model, w, uniform)
+    if abs(numpy.real(w['weight'])) > 0:
+        hirsch_kinetic_importance_sampling(model, w)
+    w['weight'] *= numpy.exp(model.dt * eshift)
+    w['ovlp'] = w['ot']
+    return fields
+
+
 # --------------------------------------------------------------------------
 # Back-propagation (SURVEY section 8f-2)
 # --------------------------------------------------------------------------
@@ -769,7 +889,7 @@ def block_reduce(est, nsteps):
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
               record=None, verbose=False, free_projection=False, nbp=None, bp_out=None,
-              restore_weights=None, bp_energy=False):
+              restore_weights=None, bp_energy=False, uniform_source=None):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -777,6 +897,10 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
     propagation/continuous.py:133); r_source(step) -> comb uniform.
     ``record`` (optional list) receives per-step dict(weight, ot, hybrid_energy,
     parent_ix).  Returns list of per-block global estimates.
+
+    Discrete Hirsch propagation (model.kind == 'hubbard_hirsch'): ``uniform_source(step)`` returns a
+    callable standing in for numpy.random.random during that step (site updates of every live walker
+    in walker order, then the comb); xi_source / r_source are unused.
 
     ``verbose`` mirrors the driver flag: the step-0 estimates are reduced and
     zeroed only when it is set (qmc/afqmc.py:220-221); otherwise they stay in
@@ -814,9 +938,12 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
                     (magn, dtheta) = cmath.polar(detR)
                     w['weight'] *= magn
                     w['phase'] *= cmath.exp(1j * dtheta)
+        uni = uniform_source(step) if uniform_source is not None else None
         for iw, w in enumerate(walkers):
             if abs(w['weight']) > 1e-8:
-                if free_projection:
+                if uni is not None:
+                    propagate_walker_hirsch(model, w, uni, eshift)
+                elif free_projection:
                     propagate_walker_free(model, w, xi_source(step, iw), eshift)
                 else:
                     propagate_walker_phaseless(model, w, xi_source(step, iw), eshift, hybrid)
@@ -824,7 +951,7 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
                 w['weight'] = w['total_weight'] * 0.10
         parent_ix = None
         if step % npop_control == 0:
-            parent_ix = pop_control(model, walkers, ntot, r_source(step))
+            parent_ix = pop_control(model, walkers, ntot, uni() if uni is not None else r_source(step))
         mixed_update(model, est, walkers, step, energy_eval_freq, free_projection)
         if nbp is not None and walkers[0]['bp']['step'] == nbp:     # back_propagation.py:145-147
             bpe = numpy.zeros(4 + 2 * model.M * model.M, dtype=numpy.complex128)

@@ -693,7 +693,92 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
     numpy.savez_compressed(os.path.join(HERE, name), **out)
 
 
+
+def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None):
+    """qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS (single-site updates, propagation/hubbard.py:12-343),
+    4x4 U=4 with 7+7 electrons, UHF trial.  Every uniform the run draws (one per site per live walker, then the
+    comb's) is recorded per step."""
+    out = {}
+    prop = {'hubbard_stratonovich': 'discrete'}
+    if charge:
+        prop['charge_decomposition'] = True
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': blocks, 'rng_seed': 8},
+               'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 7, "U": 4, 'ndown': 7},
+               'trial': {'name': 'UHF'},
+               'estimates': {'mixed': {'energy_eval_freq': 1}},
+               'propagator': prop}
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, options=options)
+    psi = afqmc.psi
+    out['T'] = afqmc.system.T
+    out['U'] = afqmc.system.U
+    out['charge'] = bool(charge)
+    out['phi0'] = numpy.array([w.phi for w in psi.walkers])
+    out['psi'] = afqmc.trial.psi
+    out['bt2'] = afqmc.propagators.bt2
+    out['nelec'] = numpy.array([afqmc.system.nup, afqmc.system.ndown])
+    draws = []
+    cur = []
+    traj = dict(weight=[], unscaled_weight=[], ot=[])
+    _random = numpy.random.random
+
+    def random(*a, **k):
+        x = _random(*a, **k)
+        cur.append(x)
+        return x
+
+    est_update = afqmc.estimators.update
+
+    def update(system, qmc, trial, psi_, step, fp):
+        traj['weight'].append([w.weight for w in psi_.walkers])
+        traj['unscaled_weight'].append([w.unscaled_weight for w in psi_.walkers])
+        traj['ot'].append([w.ot for w in psi_.walkers])
+        draws.append(numpy.array(cur))
+        del cur[:]
+        return est_update(system, qmc, trial, psi_, step, fp)
+
+    comm.bcast_log = []
+    numpy.random.random = random
+    afqmc.estimators.update = update
+    try:
+        afqmc.run(comm=comm, verbose=0)
+    finally:
+        numpy.random.random = _random
+        afqmc.estimators.update = est_update
+    pix = [d['ix'] for d in comm.bcast_log if isinstance(d, dict) and 'ix' in d]
+    out['u'] = numpy.concatenate(draws)
+    out['u_off'] = numpy.concatenate([[0], numpy.cumsum([len(d) for d in draws])])
+    out['weight'] = numpy.array(traj['weight'], dtype=numpy.float64)
+    out['unscaled_weight'] = numpy.array(traj['unscaled_weight'], dtype=numpy.float64)
+    out['ot'] = numpy.array(traj['ot'], dtype=numpy.complex128)
+    out['parent_ix'] = numpy.array(pix, dtype=numpy.int32).reshape(len(pix), -1)
+    store = h5py._STORE[afqmc.estimators.filename]
+    keys = sorted(k for k in store if k.startswith('basic/energies/'))
+    out['blocks'] = numpy.array([store[k] for k in keys])
+    out['dt'] = afqmc.qmc.dt
+    out['nsteps'] = afqmc.qmc.nsteps
+    out['nblocks'] = afqmc.qmc.nblocks
+    out['nstblz'] = afqmc.qmc.nstblz
+    out['npop_control'] = afqmc.qmc.npop_control
+    out['energy_eval_freq'] = afqmc.estimators.estimators['mixed'].energy_eval_freq
+    mixed = afqmc.estimators.estimators['mixed']
+    mixed.update(afqmc.system, afqmc.qmc, afqmc.trial, afqmc.psi, 0, afqmc.propagators.free_projection)
+    out['final_estimates'] = mixed.estimates.copy()
+    out['final_phi'] = numpy.array([w.phi for w in psi.walkers])
+    if pin is not None:
+        assert abs(out['final_estimates'][2].real - pin) < 1e-8, out['final_estimates'][2]
+    if mean_pin is not None:
+        et = out['blocks'][:, 5]          # ETotal column of the basic/energies rows
+        assert abs(numpy.mean(et[:-1]).real - mean_pin) < 1e-9, numpy.mean(et[:-1])
+    numpy.savez_compressed(os.path.join(HERE, name), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'hirsch':
+        make_traj_hirsch(pin=-152.68468568462666)
+        make_traj_hirsch('traj_hubbard_hirsch_charge.npz', charge=True, blocks=4)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'bp':
         make_traj_bp()
         make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
@@ -720,6 +805,8 @@ if __name__ == '__main__':
     make_traj_msd()
     make_traj_bp()
     make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
+    make_traj_hirsch(pin=-152.68468568462666)
+    make_traj_hirsch('traj_hubbard_hirsch_charge.npz', charge=True, blocks=4)
     # (evaluate_energy: the reference raises TypeError at back_propagation.py:160 -- local_energy() has no
     #  'opt' keyword -- so there is no reference output to record for back-propagated energies)
     for f in sorted(os.listdir(HERE)):

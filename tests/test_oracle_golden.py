@@ -275,6 +275,46 @@ def test_back_propagated_rdm_restored_weights(golden):
     run_bp(d, 'full')
 
 
+def run_hirsch(d):
+    na, nb = [int(x) for x in d['nelec']]
+    m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
+    close(m.bt2, d['bt2'])
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    u, off = d['u'], d['u_off']
+
+    def usrc(step):
+        it = iter(u[off[step - 1]:off[step]])
+        return lambda: next(it)
+
+    rec = []
+    blocks = ref.run_afqmc(m, walkers, None, None, int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
+                           npop_control=int(d['npop_control']), energy_eval_freq=int(d['energy_eval_freq']),
+                           record=rec, uniform_source=usrc, hybrid=False)
+    close(numpy.array([x['weight'] for x in rec]), d['weight'], 1e-9)
+    close(numpy.array([x['ot'] for x in rec]), d['ot'], 1e-9)
+    pix = numpy.array([x['parent_ix'] for x in rec if x['parent_ix'] is not None])
+    assert numpy.array_equal(pix, d['parent_ix'])
+    close(numpy.array(blocks)[:, :9], d['blocks'][:, 1:10], 1e-9)
+    close(numpy.array([w['phi'] for w in walkers]), d['final_phi'], 1e-9)
+    est = numpy.zeros(10, dtype=numpy.complex128)
+    ref.mixed_update(m, est, walkers, 0, 1)
+    close(est[:9], d['final_estimates'][:9], 1e-9)
+    return est, numpy.array(blocks)
+
+
+def test_traj_hubbard_hirsch(golden):
+    """qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS with single-site updates."""
+    est, blocks = run_hirsch(golden('traj_hubbard_hirsch.npz'))
+    assert est[ref.EST['enumer']].real == pytest.approx(-152.68468568462666, rel=1e-10)
+
+
+def test_traj_hubbard_hirsch_charge(golden):
+    d = golden('traj_hubbard_hirsch_charge.npz')
+    assert bool(d['charge'])
+    run_hirsch(d)
+
+
 def test_comb_truncation_quirk():
     """walkers/handler.py:301: zip(clone, kill) copies a multiplicity-3 parent once."""
     w = numpy.array([3.0, 1e-9, 1e-9, 1.0 - 2e-9])
