@@ -107,6 +107,25 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
                        const double *vqvec, double vol, const double *H1diag, double ecore);
 /* trial determinant psi c128[M, na+nb] (trial.psi after walkers/handler.py:61) */
 int afq_set_trial(afq_handle *h, const double *psi);
+/* ---- discrete Hirsch Hubbard-Stratonovich propagator -----------
+ * propagation/hubbard.py:12-343 (Hirsch, single-site updates, constrained path) for a Hubbard system and a
+ * single-determinant trial with N <= 45, M <= 128.  bt2 c128[2, M, M] = expm(-dt/2 T) (:36-37);
+ * charge_decomposition selects the charge (complex gamma) or spin HS (:66-82).
+ *   afq_propagate_hirsch   one step for every walker with |weight| > 1e-8, site uniforms from the device
+ *                          Philox stream: kinetic + importance sampling (:148-172), M single-site
+ *                          updates (:174-225), kinetic again, weight *= exp(dt eshift) (:285-312)
+ *   afq_hirsch_kinetic / afq_hirsch_two_body / afq_hirsch_finish   the same step in three calls so that a
+ *                          host driver can hand in numpy's uniforms: u f64[nw, M] (row w is read only if
+ *                          walker w survived the first kinetic step, i.e. weight != 0 after it);
+ *                          fields_out int32[nw, M] (chosen field 0/1, -1 not visited), used_out int32[nw]
+ *                          (uniforms consumed; < M only when both field probabilities vanish) -- both
+ *                          may be NULL.                                                                   */
+int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition);
+int afq_propagate_hirsch(afq_handle *h, double eshift);
+int afq_hirsch_kinetic(afq_handle *h);
+int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int32_t *used_out);
+int afq_hirsch_finish(afq_handle *h, double eshift);
+
 /* Local energy of a generic Cholesky Hamiltonian from FULL Green's functions
  * (estimators/generic.py:398-434, local_energy_generic_cholesky; what estimators/mixed.py:383-437
  * dispatches to when no half-rotated Ghalf is given): G c128[n, 2, M, M] -> E c128[n, 3] = (E, E1b, E2b).

@@ -65,6 +65,11 @@ SIGNATURES = {
     "afq_enable_timers": [_h, c_int],
     "afq_stream": [_h, POINTER(c_void_p)],
     "afq_last_energy_kernel_ms": [_h, POINTER(c_double)],
+    "afq_set_propagator_hirsch": [_h, _dp, c_double, c_int],
+    "afq_propagate_hirsch": [_h, c_double],
+    "afq_hirsch_kinetic": [_h],
+    "afq_hirsch_two_body": [_h, _dp, _dp, _dp],
+    "afq_hirsch_finish": [_h, c_double],
     "afq_bp_configure": [_h, c_int],
     "afq_bp_steps": [_h, _dp],
     "afq_bp_update": [_h, _dp, c_int, c_int, c_int, _dp],

@@ -3,6 +3,7 @@
 // make up one propagation step (propagation/continuous.py:232-262).
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include "afq_internal.h"
@@ -91,6 +92,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
+    dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
     dev_free(h->phi_old); dev_free(h->phi_bp); dev_free(h->BH1dag); dev_free(h->bp_xs); dev_free(h->bp_est);
     h->nbp = 0; dev_free(h->xbar); dev_free(h->xs);
@@ -663,6 +665,7 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
+    if (h->hirsch) AFQ_FAIL(h, AFQ_ESTATE, "discrete Hirsch propagator set: use afq_propagate_hirsch");
     if (xi) {
         if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
@@ -1029,6 +1032,117 @@ int afq_timers(afq_handle *h, double *out_ms, int reset) {
     if (!h || !out_ms) return AFQ_EINVAL;
     for (int i = 0; i < T_COUNT; ++i) { out_ms[i] = h->t_ms[i]; if (reset) h->t_ms[i] = 0.0; }
     return AFQ_OK;
+}
+
+// ---------------------------------------------------------------- discrete Hirsch propagator
+static int hirsch_buffers(afq_handle *h) {
+    if (h->hs_oinv) return AFQ_OK;
+    const size_t n = h->nw, nmax = h->na > h->nb ? h->na : h->nb;
+    int rc;
+    if ((rc = dev_alloc(h, &h->hs_oinv, n * 2 * nmax * nmax))) return rc;
+    if ((rc = dev_alloc(h, &h->hs_u, n * h->M))) return rc;
+    if ((rc = dev_alloc(h, &h->hs_fields, n * h->M))) return rc;
+    if ((rc = dev_alloc(h, &h->hs_used, n))) return rc;
+    if ((rc = dev_alloc(h, &h->hs_alive0, n))) return rc;
+    AFQ_HIP(h, hipMemsetAsync(h->hs_alive0, 0, sizeof(int) * n, h->stream));
+    return AFQ_OK;
+}
+
+static int hirsch_ready(afq_handle *h) {
+    int rc = need_ready(h, true);
+    if (rc) return rc;
+    if (!h->hirsch) AFQ_FAIL(h, AFQ_ESTATE, "the discrete Hirsch propagator is not set");
+    return hirsch_buffers(h);
+}
+
+int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition) {
+    if (h) h->greens_valid = false;
+    if (!h || !bt2 || dt <= 0) return AFQ_EINVAL;
+    if (h->kind != AFQ_SYS_HUBBARD) AFQ_FAIL(h, AFQ_ESTATE, "the Hirsch transformation needs a Hubbard system");
+    if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: single-determinant trials");
+    hipSetDevice(h->device);
+    int rc;
+    if ((rc = dev_upload(h, &h->BH1, bt2, (size_t)2 * h->M * h->M))) return rc;
+    // propagation/hubbard.py:66-82
+    typedef std::complex<double> C;
+    C gamma, auxf[2][2], wfac[2];
+    const double e = std::exp(-0.5 * dt * h->U);
+    if (charge_decomposition) {
+        gamma = std::acosh(C(e, 0.0));
+        auxf[0][0] = auxf[0][1] = std::exp(gamma);
+        auxf[1][0] = auxf[1][1] = std::exp(-gamma);
+        wfac[0] = std::exp(0.5 * dt * h->U) * std::exp(-gamma);
+        wfac[1] = std::exp(0.5 * dt * h->U) * std::exp(gamma);
+    } else {
+        gamma = C(std::acosh(std::exp(0.5 * dt * h->U)), 0.0);
+        auxf[0][0] = std::exp(gamma); auxf[0][1] = std::exp(-gamma);
+        auxf[1][0] = std::exp(-gamma); auxf[1][1] = std::exp(gamma);
+        wfac[0] = wfac[1] = C(1.0, 0.0);
+    }
+    for (int x = 0; x < 2; ++x) {
+        h->hs_wfac[x] = cmake(wfac[x].real(), wfac[x].imag());
+        for (int sp = 0; sp < 2; ++sp) {
+            const C d = auxf[x][sp] * e - 1.0;
+            h->hs_delta[x][sp] = cmake(d.real(), d.imag());
+        }
+    }
+    if (!h->mf_shift) {
+        std::vector<double> z(2 * (size_t)h->K, 0.0);
+        if ((rc = dev_upload(h, &h->mf_shift, z.data(), (size_t)h->K))) return rc;
+    }
+    h->dt = dt; h->sqrt_dt = std::sqrt(dt);
+    h->flags = 0; h->nv = 1; h->vhs_diag = true;
+    h->hirsch = true; h->have_prop = true;
+    return AFQ_OK;
+}
+
+int afq_hirsch_kinetic(afq_handle *h) {
+    if (h) h->greens_valid = false;
+    if (!h) return AFQ_EINVAL;
+    int rc = hirsch_ready(h);
+    if (rc) return rc;
+    if ((rc = k_hirsch_alive(h, 0))) return rc;                 // walkers the driver propagates (|w| > 1e-8)
+    return k_hirsch_kinetic(h);
+}
+
+int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int32_t *used_out) {
+    if (h) h->greens_valid = false;
+    if (!h || !u) return AFQ_EINVAL;
+    int rc = hirsch_ready(h);
+    if (rc) return rc;
+    AFQ_HIP(h, hipMemcpyAsync(h->hs_u, u, sizeof(double) * (size_t)h->nw * h->M, hipMemcpyHostToDevice, h->stream));
+    if ((rc = k_hirsch_alive(h, 1))) return rc;                 // if abs(walker.weight) > 0 (hubbard.py:308)
+    if ((rc = k_hirsch_two_body(h))) return rc;
+    if (fields_out && (rc = copy_out(h, fields_out, h->hs_fields, sizeof(int) * (size_t)h->nw * h->M))) return rc;
+    if (used_out && (rc = copy_out(h, used_out, h->hs_used, sizeof(int) * (size_t)h->nw))) return rc;
+    return AFQ_OK;
+}
+
+int afq_hirsch_finish(afq_handle *h, double eshift) {
+    if (h) h->greens_valid = false;
+    if (!h) return AFQ_EINVAL;
+    int rc = hirsch_ready(h);
+    if (rc) return rc;
+    if ((rc = k_hirsch_alive(h, 1))) return rc;                 // if abs(walker.weight.real) > 0 (:310)
+    if ((rc = k_hirsch_kinetic(h))) return rc;
+    if ((rc = k_hirsch_eshift(h, std::exp(h->dt * eshift)))) return rc;
+    return k_alive(h);
+}
+
+int afq_propagate_hirsch(afq_handle *h, double eshift) {
+    if (h) h->greens_valid = false;
+    if (!h) return AFQ_EINVAL;
+    int rc = hirsch_ready(h);
+    if (rc) return rc;
+    if ((rc = k_hirsch_alive(h, 0))) return rc;
+    if ((rc = k_hirsch_kinetic(h))) return rc;
+    if ((rc = k_rng_uniform(h, h->hs_u, (long)h->nw * h->M))) return rc;
+    if ((rc = k_hirsch_alive(h, 1))) return rc;
+    if ((rc = k_hirsch_two_body(h))) return rc;
+    if ((rc = k_hirsch_alive(h, 1))) return rc;
+    if ((rc = k_hirsch_kinetic(h))) return rc;
+    if ((rc = k_hirsch_eshift(h, std::exp(h->dt * eshift)))) return rc;
+    return k_alive(h);
 }
 
 // ---------------------------------------------------------------- back-propagation

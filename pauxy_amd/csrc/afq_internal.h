@@ -106,6 +106,16 @@ struct afq_handle {
     cplx *bp_xs = nullptr;          // [nw, K]
     cplx *bp_est = nullptr;         // [4 + 2 M M]
 
+    // ---- discrete Hirsch propagator (propagation/hubbard.py:12-343)
+    bool hirsch = false;
+    cplx hs_delta[2][2];            // auxf - 1, [field][spin]
+    cplx hs_wfac[2];                // aux_wfac
+    cplx *hs_oinv = nullptr;        // [nw, 2, nmax, nmax] inverse overlaps O^-1 (= inv_ovlp^T of the reference)
+    double *hs_u = nullptr;         // [nw, M] uniforms of the site updates
+    int *hs_fields = nullptr;       // [nw, M] chosen fields (-1: not visited)
+    int *hs_used = nullptr;         // [nw] uniforms consumed
+    int *hs_alive0 = nullptr;       // [nw] walkers the driver propagates this step (|w| > 1e-8)
+
     // ---- propagator
     bool have_prop = false;
     cplx *BH1 = nullptr;            // [2, M, M]
@@ -227,6 +237,12 @@ int k_full_G(afq_handle *h);                                // G = conj(psi) gha
 // k_fused.hip
 int k_prop_fused_supported(afq_handle *h);
 int k_prop_fused(afq_handle *h);                           // phi <- B exp(V) B phi for live walkers, in place
+// k_hirsch.hip
+int k_hirsch_alive(afq_handle *h, int mode);
+int k_hirsch_kinetic(afq_handle *h);
+int k_hirsch_two_body(afq_handle *h);
+int k_hirsch_eshift(afq_handle *h, double fac);
+int k_rng_uniform(afq_handle *h, double *u, long n);
 // k_fullg.hip
 int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev);   // estimators/generic.py:398-434
 // k_bigdet.hip
@@ -237,6 +253,7 @@ int k_reortho_big(afq_handle *h);                           // Cholesky-QR2; set
 int k_alive(afq_handle *h);
 int k_greens(afq_handle *h, cplx *det_out);                 // ghalf + det
 int k_overlap(afq_handle *h, cplx *det_out);                // det(psi^H phi)
+int k_inverse_overlap(afq_handle *h, cplx *oinv, cplx *det_out);   // O^-1 [nw,2,nmax,nmax] + det, live walkers
 int k_fields(afq_handle *h);                                // vbias -> xbar(clipped), xs, cmf, cfb
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d, cplx *cfb_d);
 int k_xbar(afq_handle *h);

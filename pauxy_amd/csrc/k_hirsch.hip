@@ -1,0 +1,192 @@
+// Discrete Hirsch Hubbard-Stratonovich propagation for the Hubbard model (constrained-path AFQMC with
+// single-site updates), propagation/hubbard.py:12-343, SURVEY section 8f-4.
+//
+// One step of a walker is  kinetic half step + importance sampling -> M sequential single-site updates ->
+// kinetic half step + importance sampling -> weight *= exp(dt eshift).  The kinetic parts reuse the one-body
+// GEMM and the Green's-function kernel (which hands out O^-1, O = phi^T conj(psi)); the site loop is one
+// work-group per walker with both inverse overlaps in LDS: per site two N x N mat-vecs, the overlap ratios of
+// the two field values (:549-551), the choice of the field from a uniform number, a row scaling of phi and a
+// Sherman-Morrison rank-1 update of the inverse (utils/linalg.py:6-30, walkers/single_det.py:117-139).
+#include "afq_internal.h"
+
+struct HirschArgs {
+    int M, na, nb, nt, nw, nmax;
+    cplx *phi;
+    const cplx *psi;
+    cplx *oinv;
+    double *weight;
+    cplx *ot;
+    const double *u;                 // [nw, M]
+    int *fields, *used;
+    const int *alive;
+    cplx delta[2][2], wfac[2];
+};
+
+__global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cplx q_s[2][48], a_s[2][48], gii_s[2], den_s[2];
+    __shared__ int xi_s, stop_s;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (!a.alive[w]) { if (tid == 0) a.used[w] = 0; return; }
+    const int M = a.M, nt = a.nt, nmax = a.nmax;
+    cplx *inv = (cplx *)smem;                                  // [2][nmax][nmax] : O^-1
+    cplx *phi = a.phi + (long)w * M * nt;
+    const cplx *og = a.oinv + (long)w * 2 * nmax * nmax;
+    for (int e = tid; e < 2 * nmax * nmax; e += 256) inv[e] = og[e];
+    double weight = a.weight[w];
+    cplx ot = a.ot[w];
+    int used = 0;
+    __syncthreads();
+    for (int i = 0; i < M; ++i) {
+        // q_k = sum_l O^-1[k][l] phi[i,l];  a_l = sum_k O^-1[k][l] conj(psi[i,k])   (both spins)
+        for (int t = tid; t < 2 * 2 * nmax; t += 256) {
+            const int s = t / (2 * nmax), r = t % (2 * nmax), which = r / nmax, k = r % nmax;
+            const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+            if (k >= ns) continue;
+            const cplx *iv = inv + (long)s * nmax * nmax;
+            cplx acc = cmake(0.0, 0.0);
+            if (which == 0) {
+                for (int l = 0; l < ns; ++l) cfma(acc, iv[k * nmax + l], phi[(long)i * nt + off + l]);
+                q_s[s][k] = acc;
+            } else {
+                for (int l = 0; l < ns; ++l) cfma(acc, iv[l * nmax + k], cconj(a.psi[(long)i * nt + off + l]));
+                a_s[s][k] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid < 2) {                                        // G_ii of spin tid (hubbard.py:110-122)
+            const int s = tid, ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+            cplx g = cmake(0.0, 0.0);
+            for (int k = 0; k < ns; ++k) cfma(g, cconj(a.psi[(long)i * nt + off + k]), q_s[s][k]);
+            gii_s[s] = g;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            cplx probs[2];
+            for (int x = 0; x < 2; ++x) {
+                const cplx r0 = cadd(cmake(1.0, 0.0), cmul(a.delta[x][0], gii_s[0]));
+                const cplx r1 = cadd(cmake(1.0, 0.0), cmul(a.delta[x][1], gii_s[1]));
+                const cplx r = cmul(r0, r1);
+                probs[x] = cmul(cmake(0.5 * r.x, 0.5 * r.y), a.wfac[x]);          // :551, :198
+            }
+            const double p0 = fmax(probs[0].x, 0.0), p1 = fmax(probs[1].x, 0.0);
+            const double norm = p0 + p1;
+            const double r = a.u[(long)w * M + i];
+            ++used;
+            if (norm > 0) {
+                weight *= norm;
+                const int xi = r < p0 / norm ? 0 : 1;
+                ot = cmul(cmake(2.0 * ot.x, 2.0 * ot.y), probs[xi]);                 // single_det.py:213
+                xi_s = xi; stop_s = 0;
+                a.fields[(long)w * M + i] = xi;
+                // Sherman-Morrison denominators 1 + vt . (inv u) with vt = phi[i,:] delta
+                for (int s = 0; s < 2; ++s) {
+                    const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+                    cplx d = cmake(0.0, 0.0);
+                    for (int l = 0; l < ns; ++l) cfma(d, phi[(long)i * nt + off + l], a_s[s][l]);
+                    den_s[s] = cadd(cmake(1.0, 0.0), cmul(a.delta[xi][s], d));
+                }
+            } else {
+                weight = 0.0; stop_s = 1;
+            }
+        }
+        __syncthreads();
+        if (stop_s) break;
+        const int xi = xi_s;
+        // O^-1[k][l] -= b_k a_l / denom with b_k = q_k delta  (inv_ovlp - inv u vt inv / (1 + vt inv u))
+        for (int e = tid; e < 2 * nmax * nmax; e += 256) {
+            const int s = e / (nmax * nmax), r = e % (nmax * nmax), k = r / nmax, l = r % nmax;
+            const int ns = s == 0 ? a.na : a.nb;
+            if (k >= ns || l >= ns) continue;
+            const cplx b = cmul(q_s[s][k], a.delta[xi][s]);
+            inv[e] = csub(inv[e], cdiv(cmul(b, a_s[s][l]), den_s[s]));
+        }
+        // phi[i, :] <- phi[i, :] (1 + delta)
+        for (int c = tid; c < nt; c += 256) {
+            const int s = c < a.na ? 0 : 1;
+            const cplx f = cadd(cmake(1.0, 0.0), a.delta[xi][s]);
+            phi[(long)i * nt + c] = cmul(phi[(long)i * nt + c], f);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { a.weight[w] = weight; a.ot[w] = ot; a.used[w] = used; }
+}
+
+// kinetic importance sampling (hubbard.py:163-172) after phi <- bt2 phi and the new overlap
+__global__ void hirsch_kin_weight_kernel(double *weight, cplx *ot, const cplx *ot_new, const int *alive, int nw) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw || !alive[w]) return;
+    const cplx ratio = cdiv(ot_new[w], ot[w]);
+    if (fabs(atan2(ratio.y, ratio.x)) < 0.5 * 3.14159265358979323846) {
+        weight[w] *= ratio.x;
+        ot[w] = ot_new[w];
+    } else {
+        weight[w] = 0.0;
+    }
+}
+
+// mode 0: alive = alive0 = |w| > 1e-8 (the driver's test, qmc/afqmc.py:232); 1: alive = alive0 && |w| > 0
+__global__ void hirsch_alive_kernel(const double *weight, int *alive, int *alive0, int nw, int mode) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    if (mode == 0) { const int al = fabs(weight[w]) > 1e-8 ? 1 : 0; alive0[w] = al; alive[w] = al; }
+    else alive[w] = (alive0[w] && fabs(weight[w]) > 0.0) ? 1 : 0;
+}
+
+__global__ void hirsch_eshift_kernel(double *weight, const int *alive0, int nw, double fac) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw && alive0[w]) weight[w] *= fac;                 // hubbard.py:312
+}
+
+__global__ void hirsch_fill_kernel(int *fields, long n) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) fields[i] = -1;
+}
+
+int k_hirsch_alive(afq_handle *h, int mode) {
+    hipLaunchKernelGGL(hirsch_alive_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->alive,
+                       h->hs_alive0, h->nw, mode);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+// phi <- bt2 phi, inverse overlap, importance sampling, for the walkers flagged alive
+int k_hirsch_kinetic(afq_handle *h) {
+    int rc;
+    if ((rc = k_onebody(h))) return rc;
+    if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;
+    hipLaunchKernelGGL(hirsch_kin_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
+                       h->ovlp_new, h->alive, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_hirsch_two_body(afq_handle *h) {
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    {
+        const long n = (long)h->nw * h->M;
+        hipLaunchKernelGGL(hirsch_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_fields, n);
+    }
+    HirschArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.nmax = nmax;
+    a.phi = h->phi; a.psi = h->psi; a.oinv = h->hs_oinv; a.weight = h->weight; a.ot = h->ot; a.u = h->hs_u;
+    a.fields = h->hs_fields; a.used = h->hs_used; a.alive = h->alive;
+    for (int x = 0; x < 2; ++x) { a.wfac[x] = h->hs_wfac[x]; for (int s = 0; s < 2; ++s) a.delta[x][s] = h->hs_delta[x][s]; }
+    const size_t lds = sizeof(cplx) * 2 * (size_t)nmax * nmax;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        AFQ_HIP(h, hipFuncSetAttribute((const void *)hirsch_two_body_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(hirsch_two_body_kernel, dim3(h->nw), dim3(256), lds, h->stream, a);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_hirsch_eshift(afq_handle *h, double fac) {
+    hipLaunchKernelGGL(hirsch_eshift_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->hs_alive0,
+                       h->nw, fac);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}

@@ -87,6 +87,7 @@ struct GreensArgs {
     const cplx *phi, *psi;
     long psi_stride;    // 0: one trial for all walkers; M*nt: walker w uses psi + w*psi_stride
     cplx *ghalf;        // may be null (determinant only)
+    cplx *oinv;         // optional [nw, 2, nmax, nmax]: O^-1 (O = phi^T conj(psi)), row-major, leading dim nmax
     cplx *det;          // [nw]
     cplx *ws;           // global workspace [nw, nmax*nmax] when O does not fit LDS
     int o_in_lds;
@@ -373,6 +374,10 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
         const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
     }
+    if (INVERSE && a.oinv) {
+        cplx *oo = a.oinv + ((long)w * 2 + g) * nmax * nmax;
+        for (int e = tid & 255; e < n * n; e += 256) oo[(e / n) * nmax + (e % n)] = O[e];
+    }
     // ---- phase 3
     if (INVERSE && a.ghalf && n > 0 && !(a.dbg & 2)) {
         cplx *gh = a.ghalf + ((long)w * nt + off) * M;
@@ -402,13 +407,17 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
     }
 }
 
-static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) {
+static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, cplx *oinv = nullptr) {
     GreensArgs a;
+    a.oinv = oinv;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
-    if (k_greens_big_supported(h)) return k_greens_big(h, ghalf, det);
+    if (k_greens_big_supported(h)) {
+        if (oinv) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "O^-1 output: N <= 45 only");
+        return k_greens_big(h, ghalf, det);
+    }
     if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
         static const int dbg = getenv("AFQ_GREENS_DBG") ? atoi(getenv("AFQ_GREENS_DBG")) : 0;
@@ -417,7 +426,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive) 
         const size_t lds = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) +
                                            (size_t)h->M * h->nt);
         static size_t lds_set[2] = {0, 0};      // raise the dynamic-LDS cap once per kernel, not per launch
-        if (ghalf) {
+        if (ghalf || oinv) {
             if (lds > lds_set[1]) {
                 AFQ_HIP(h, hipFuncSetAttribute((const void *)greens_small_kernel<true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -452,6 +461,12 @@ int k_greens(afq_handle *h, cplx *det_out) { return launch_greens(h, h->ghalf, d
 // det(psi^H phi) == det(phi^T conj(psi)) (transpose), so the same factorisation serves
 // walkers/single_det.py:170-199
 int k_overlap(afq_handle *h, cplx *det_out) { return launch_greens(h, nullptr, det_out, 0); }
+// O^-1 of every walker and spin (+ determinant), no Ghalf: the discrete Hirsch propagator's inverse overlap
+int k_inverse_overlap(afq_handle *h, cplx *oinv, cplx *det_out) {
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    if (nmax > 45 || h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: N <= 45, M <= 128");
+    return launch_greens(h, nullptr, det_out, 1, oinv);
+}
 
 // --------------------------------------------------------------------------
 // force bias from the contraction output, per system
@@ -1265,6 +1280,34 @@ __global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, u
     double s, c; sincospi(2.0 * u2, &s, &c);
     xi[2 * pair] = rad * c;
     if (2 * pair + 1 < n) xi[2 * pair + 1] = rad * s;
+}
+
+// uniforms in [0, 1) (53 bits), same counter-based stream
+__global__ void rng_uniform_kernel(double *u, long n, unsigned long long seed, unsigned long long stream,
+                                   unsigned long long counter) {
+    const long pair = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (2 * pair >= n) return;
+    unsigned int c0 = (unsigned int)pair, c1 = (unsigned int)(pair >> 32);
+    unsigned int c2 = (unsigned int)counter, c3 = (unsigned int)(counter >> 32) ^ (unsigned int)(stream * 0x9E3779B9u);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned long long a = (((unsigned long long)c0 << 32) | c1) >> 11;
+    const unsigned long long b = (((unsigned long long)c2 << 32) | c3) >> 11;
+    u[2 * pair] = (double)a * (1.0 / 9007199254740992.0);
+    if (2 * pair + 1 < n) u[2 * pair + 1] = (double)b * (1.0 / 9007199254740992.0);
+}
+
+int k_rng_uniform(afq_handle *h, double *u, long n) {
+    const long pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, u, n,
+                       (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
+                       (unsigned long long)h->rng_counter);
+    AFQ_HIP(h, hipGetLastError());
+    h->rng_counter += 1;
+    return AFQ_OK;
 }
 
 int k_rng_normal(afq_handle *h) {

@@ -112,6 +112,28 @@ class AfqDevice(object):
         psi = _c128(psi, (self.M, self.na + self.nb))
         self._ck(self.lib.afq_set_trial(self.h, _p(psi)))
 
+    # ---- discrete Hirsch propagator
+    def set_propagator_hirsch(self, bt2, dt, charge_decomposition=False):
+        bt2 = _c128(bt2, (2, self.M, self.M))
+        self._ck(self.lib.afq_set_propagator_hirsch(self.h, _p(bt2), float(dt), int(bool(charge_decomposition))))
+        self.nv = 1
+
+    def propagate_hirsch(self, eshift):
+        self._ck(self.lib.afq_propagate_hirsch(self.h, float(numpy.real(eshift))))
+
+    def hirsch_kinetic(self):
+        self._ck(self.lib.afq_hirsch_kinetic(self.h))
+
+    def hirsch_two_body(self, u):
+        u = numpy.ascontiguousarray(u, dtype=numpy.float64).reshape(self.nw, self.M)
+        fields = numpy.zeros((self.nw, self.M), dtype=numpy.int32)
+        used = numpy.zeros(self.nw, dtype=numpy.int32)
+        self._ck(self.lib.afq_hirsch_two_body(self.h, _p(u), _p(fields), _p(used)))
+        return fields, used
+
+    def hirsch_finish(self, eshift):
+        self._ck(self.lib.afq_hirsch_finish(self.h, float(numpy.real(eshift))))
+
     # ---- back-propagation
     def bp_configure(self, nbp):
         self._ck(self.lib.afq_bp_configure(self.h, int(nbp)))

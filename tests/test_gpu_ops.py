@@ -209,3 +209,66 @@ def test_full_g_energy(golden):
     e = device_local_energy(None, G[1], device=dev)
     close(numpy.array(e), Efull[1])
     dev.close()
+
+
+@pytest.mark.parametrize("charge", [False, True])
+def test_hirsch_single_step(golden, charge):
+    """propagation/hubbard.py:148-225,285-312 step by step against the oracle: kinetic importance sampling,
+    the site loop (chosen fields must match exactly), second kinetic step, eshift factor; one dead walker."""
+    from pauxy_amd.device import AfqDevice
+    d = golden('traj_hubbard_hirsch.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, 0.01, charge)
+    nw, M = 6, m.M
+    rng = numpy.random.RandomState(9)
+    dev = AfqDevice(0)
+    dev.set_system_hubbard(m.H1, m.U, na, nb)
+    dev.set_trial(m.psi)
+    dev.set_propagator_hirsch(m.bt2, 0.01, charge)
+    dev.walkers_alloc(nw)
+    phis = numpy.array([m.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    w0 = numpy.array([1.0, 0.7, 0.0, 1.3, 1.0, 0.4])
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, w0)
+    ot0 = dev.calc_overlap()
+    dev.set(L.F_OT, ot0)
+    walkers = [ref.new_walker(m, p, weight=w) for p, w in zip(phis, w0)]
+    u = rng.rand(nw, M)
+    dev.hirsch_kinetic()
+    for wk in walkers:
+        if abs(wk['weight']) > 1e-8:
+            ref.hirsch_kinetic_importance_sampling(m, wk)
+    close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]))
+    close(dev.get(L.F_OT), numpy.array([wk['ot'] for wk in walkers]))
+    fields, used = dev.hirsch_two_body(u)
+    for iw, wk in enumerate(walkers):
+        if abs(w0[iw]) > 1e-8 and abs(wk['weight']) > 0:
+            it = iter(u[iw])
+            f = ref.hirsch_two_body_single_site(m, wk, lambda: next(it))
+            assert list(fields[iw]) == f and used[iw] == M
+        else:
+            assert used[iw] == 0 and numpy.all(fields[iw] == -1)
+    close(dev.get(L.F_PHI), numpy.array([wk['phi'] for wk in walkers]))
+    close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]))
+    close(dev.get(L.F_OT), numpy.array([wk['ot'] for wk in walkers]))
+    dev.hirsch_finish(-0.3)
+    for iw, wk in enumerate(walkers):
+        if abs(w0[iw]) > 1e-8:
+            if abs(numpy.real(wk['weight'])) > 0:
+                ref.hirsch_kinetic_importance_sampling(m, wk)
+            wk['weight'] *= numpy.exp(0.01 * -0.3)
+    close(dev.get(L.F_PHI), numpy.array([wk['phi'] for wk in walkers]))
+    close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]))
+    close(dev.get(L.F_OT), numpy.array([wk['ot'] for wk in walkers]))
+    live = numpy.nonzero(dev.get(L.F_WEIGHT) != 0)[0]            # ot is only refreshed while the walker survives
+    close(dev.get(L.F_OT)[live], dev.calc_overlap()[live])      # the tracked overlap is the true overlap
+    # device-RNG step: same kernels, Philox uniforms
+    dev.rng_seed(5, 0)
+    before = dev.get(L.F_PHI)
+    dev.propagate_hirsch(0.0)
+    after, wt = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+    assert numpy.all(numpy.isfinite(wt)) and wt[2] == 0.0 and numpy.array_equal(after[2], before[2])
+    assert numpy.abs(after[0] - before[0]).max() > 1e-6
+    live = numpy.nonzero(wt != 0)[0]
+    close(dev.get(L.F_OT)[live], dev.calc_overlap()[live])
+    dev.close()

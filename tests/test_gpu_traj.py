@@ -180,3 +180,53 @@ def test_traj_back_propagation(golden, monkeypatch):
 
 def test_traj_back_propagation_restored_weights(golden, monkeypatch):
     run_bp(golden, monkeypatch, 'traj_bp_full.npz', 'full')
+
+
+def run_hirsch(golden, monkeypatch, name):
+    d = golden(name)
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Hubbard(4, 4, na, nb, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    prop = {'hubbard_stratonovich': 'discrete'}
+    if bool(d['charge']):
+        prop['charge_decomposition'] = True
+    options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
+                       'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
+                       'num_walkers': d['phi0'].shape[0]},
+               'propagator': prop,
+               'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
+    afqmc = AFQMC(options=options, system=s, trial=t)
+    close(afqmc.propagators.bt2, d['bt2'], 1e-12)
+    stream = iter(d['u'])
+    monkeypatch.setattr(numpy.random, 'random', lambda: next(stream))
+    rec = dict(weight=[], ot=[], pix=[])
+
+    def on_step(step, psi):
+        rec['weight'].append(psi._mirror('weight').copy())
+        rec['ot'].append(psi._mirror('ot').copy())
+        if step % afqmc.qmc.npop_control == 0:
+            rec['pix'].append(psi.last_parent_ix.copy())
+
+    afqmc.run(verbose=False, on_step=on_step)
+    assert next(stream, None) is None                      # consumed exactly the reference's uniforms
+    close(numpy.array(rec['weight']), d['weight'])
+    close(numpy.array(rec['ot']), d['ot'])
+    assert numpy.array_equal(numpy.array(rec['pix']), d['parent_ix'])
+    mixed = afqmc.estimators.estimators['mixed']
+    close(numpy.array(mixed.blocks)[:, 1:10], d['blocks'][:, 1:10])
+    close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'])
+    mixed.update(s, afqmc.qmc, t, afqmc.psi, 0, False)
+    close(mixed.estimates[:9], d['final_estimates'][:9])
+    est = mixed.estimates.copy()
+    release_context(s, t)
+    return est
+
+
+def test_traj_hubbard_hirsch(golden, monkeypatch):
+    """SURVEY 8f-4, qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS, single-site updates."""
+    est = run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch.npz')
+    assert est[2].real == pytest.approx(-152.68468568462666, rel=1e-8)
+
+
+def test_traj_hubbard_hirsch_charge(golden, monkeypatch):
+    run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch_charge.npz')
