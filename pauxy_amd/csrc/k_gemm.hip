@@ -78,6 +78,9 @@ int k_onebody(afq_handle *h) {
         if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
             // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
             AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
+            // large systems: 128 x 64 work-group tiles, 3M complex products
+            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else {
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
             DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
@@ -126,8 +129,11 @@ struct ForceBiasProb {
         return k < len[b] ? rre + (q0[b] + k) * ldr + col : (const double *)zero;
     }
     const cplx *zero;
+    int imag_pass;                   // second pass of a complex rchol on the real-B engine: out += i (A . Im B)
     __device__ void store(int b, int row, int col, double re, double im) const {
-        out[((long)b * rows + row) * K + col] = cmake(re, im);
+        cplx *o = out + ((long)b * rows + row) * K + col;
+        if (imag_pass) { const cplx t = *o; *o = cmake(t.x - im, t.y + re); }
+        else *o = cmake(re, im);
     }
 };
 
@@ -150,6 +156,7 @@ static void fill_force_bias(ForceBiasProb<RC> &p, afq_handle *h) {
     p.kdim = kmax;
     p.ghalf = h->ghalf; p.rre = h->rchol_re; p.rim = h->rchol_im; p.out = h->vbias;
     p.zero = (const cplx *)h->zero_page;
+    p.imag_pass = 0;
 }
 
 int k_force_bias_generic(afq_handle *h) {
@@ -170,6 +177,16 @@ int k_force_bias_generic(afq_handle *h) {
             else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         } else {
             DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
+        }
+    } else if (h->nw > 32 && !h->no_ring) {
+        // complex half-rotated Cholesky vectors (complex trial): rchol is stored planar, so the real-B ring
+        // engine runs twice, out = A . Re(rchol) then out += i A . Im(rchol)
+        ForceBiasProb<false> p;
+        fill_force_bias(p, h);
+        for (int pass = 0; pass < 2; ++pass) {
+            p.imag_pass = pass;
+            p.rre = pass ? h->rchol_im : h->rchol_re;
+            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         }
     } else {
         ForceBiasProb<true> p;
@@ -300,6 +317,11 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
             if (!h->no_ring && M > 64 && M <= 128 && p.cols > 32 && p.cols <= 64 && h->nw >= 64) {
                 // one work-group (8 waves, 128 x 64 tile) = one walker: VHS[w] and T[w] pass the LDS ring once
+                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                continue;
+            }
+            if (!h->no_ring && M > 128 && p.cols > 32 && h->nw >= 64) {
+                // large systems: 128 x 64 work-group tiles, 3M complex products
                 AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 continue;
             }

@@ -44,6 +44,20 @@ if __name__ == "__main__":
         s = systems.synthetic_generic(400, 2000, (50, 50), seed=7)
         run("C5 sizes, single determinant: generic M=400 K=2000 50+50, 256 walkers", s,
             trial_mod.rhf_trial_generic(s), 256, 0.005, 10, 5)
+    if "C5" in which:
+        # BASELINE configs[4]: generic M=400, K=2000, 50+50 electrons, 4-determinant NOMSD trial (mixed estimator;
+        # the reference cannot combine a multi-determinant trial with back-propagation)
+        s = systems.synthetic_generic(400, 2000, (50, 50), seed=7)
+        t0 = trial_mod.rhf_trial_generic(s)
+        rng = numpy.random.RandomState(3)
+        dets = numpy.array([t0.psi + (0.0 if d == 0 else 0.05) * (rng.rand(400, 100) + 1j * rng.rand(400, 100))
+                            for d in range(4)])
+        t = trial_mod.MultiDetTrial(s, (numpy.array([0.8, 0.3, 0.2, 0.1], dtype=complex), dets), init=t0.psi)
+        run("C5 generic M=400 K=2000 50+50, NOMSD ndet=4, 256 walkers (one GPU's shard)", s, t, 256, 0.005, 10, 5)
+    if "C1h" in which:
+        s = systems.Hubbard(4, 4, 8, 8, 4.0)
+        run("C1 Hubbard 4x4 U=4 8+8, 10 walkers, discrete Hirsch HS", s, trial_mod.uhf_trial_hubbard(s), 10, 0.01,
+            400, 50, prop={'hubbard_stratonovich': 'discrete'})
     if "C1" in which:
         s = systems.Hubbard(4, 4, 8, 8, 4.0)
         run("C1 Hubbard 4x4 U=4 8+8, 10 walkers", s, trial_mod.uhf_trial_hubbard(s), 10, 0.01, 400, 50)
