@@ -175,3 +175,61 @@ def test_large_n_reortho_breakdown_fallback():
 
 def test_c2_ueg_93_planewaves():
     run_fullsize(ueg_c2(), 64, [0, 63])
+
+
+def test_c5_sizes_multi_determinant_consistency():
+    """BASELINE configs[4] sizes (M=400, K=2000, 50+50 electrons).  Size-independent property of the
+    multi-determinant path: a trial made of three IDENTICAL determinants with coefficients c_d must
+    reproduce the single-determinant force bias, energy and propagated walkers, with overlap
+    sum_d conj(c_d) times the single-determinant overlap.  One walker is also checked directly against
+    the oracle (Green's function, force bias, half-rotated energy)."""
+    M, K, N, dt, nw = 400, 2000, 50, 0.005, 32
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=0.0)
+    rng = numpy.random.RandomState(5)
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, M, 2 * N) + 1j * rng.rand(nw, M, 2 * N))
+    xi = rng.normal(size=(nw, K))
+    # ---- single determinant
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    det = dev.greens()
+    xbar = dev.force_bias()
+    E = dev.local_energy()
+    d, gh, Gr = ref.greens_function(phis[3], model.psi, N, N)
+    close(det[3], d, 1e-10)
+    close(xbar[3], model.force_bias(gh, Gr), 1e-10)
+    close(E[3], numpy.array(model.local_energy(Gr, gh)), 1e-10)
+    dev.set(L.F_OT, det)
+    dev.propagate(xi, 0.0)
+    phi_sd, w_sd = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+    dev.close()
+    # ---- three copies of the same determinant
+    coeffs = numpy.array([0.7 + 0.1j, 0.2 - 0.3j, 0.4 + 0j])
+    per = M * 2 * N
+    dev = AfqDeviceForMsd(model, coeffs, t._rchol[:per], nw)
+    dev.set(L.F_PHI, phis)
+    det3 = dev.greens()
+    close(det3, det * numpy.sum(coeffs.conj()), 1e-10)
+    close(dev.det_weights(), det[:, None] * coeffs.conj()[None, :], 1e-10)
+    close(dev.force_bias(), xbar, 1e-10)
+    dev.greens()
+    close(dev.local_energy(), E, 1e-10)
+    dev.set(L.F_OT, det3)
+    dev.propagate(xi, 0.0)
+    close(dev.get(L.F_PHI), phi_sd, 1e-10)
+    close(dev.get(L.F_WEIGHT), w_sd, 1e-10)
+    dev.close()
+
+
+def AfqDeviceForMsd(model, coeffs, rchol0, nw):
+    from pauxy_amd.device import AfqDevice
+    dev = AfqDevice(0)
+    ndet = len(coeffs)
+    dev.set_system_generic(model.hs_pot, rchol0, model.H1, model.ecore, model.na, model.nb)
+    dev.set_trial_multi(numpy.array([model.psi] * ndet), coeffs, numpy.concatenate([rchol0] * ndet))
+    dev.set_propagator(model.BH1, model.mf_shift, model.dt)
+    dev.walkers_alloc(nw)
+    return dev
