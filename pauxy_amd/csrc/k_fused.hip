@@ -168,24 +168,25 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 if (j < ncs_w && t_ok(2 * wm + i, r)) v = *(const d2_t *)(Tf + t_addr(2 * wm + i, r, 2 * wn + j));
                 SR[i][j][r] = v[0]; SI[i][j][r] = v[1];
             }
+    // Software pipeline over the k-chunks of one product: the fragments of chunk c+1 travel LDS -> registers
+    // (second register set) while the MFMAs of chunk c run, so the LDS pipe (8 KB per wave and chunk) and the
+    // MFMA pipe overlap instead of alternating in lock step behind the per-chunk barrier.
+    auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2][2], d2_t (&bv)[2][2]) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i][ss] = lds_read_c(sl + ((2 * wm + i) * 2 + ss) * 1024 + lane * 16);
+                bv[i][ss] = lds_read_c(tf_l + ((c * 4 + 2 * wn + i) * 2 + ss) * 1024 + lane * 16);
+            }
+    };
     for (int n = 1; n <= a.order; ++n) {
         d4_t P1[2][2], P2[2][2], P3[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) { P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0}; }
-        for (int c = 0; c < NCH; ++c) {
-            const unsigned sl = next_chunk();
-            d2_t av[2][2], bv[2][2];
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    av[i][ss] = lds_read_c(sl + ((2 * wm + i) * 2 + ss) * 1024 + lane * 16);
-                    bv[i][ss] = lds_read_c(tf_l + ((c * 4 + 2 * wn + i) * 2 + ss) * 1024 + lane * 16);
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        auto mfmas = [&](d2_t (&av)[2][2], d2_t (&bv)[2][2]) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -197,6 +198,23 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                             P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
                             P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
                         }
+        };
+        d2_t avA[2][2], bvA[2][2], avB[2][2], bvB[2][2];
+        load_frags(next_chunk(), 0, avA, bvA);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int c = 0; c < NCH; c += 2) {
+            if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c + 1 < NCH) {
+                if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(avB, bvB);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
         __builtin_amdgcn_s_barrier();                            // everyone finished reading T_{n-1}
         const double inv_n = 1.0 / n;
