@@ -75,7 +75,7 @@ void free_system(afq_handle *h) {
     dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     dev_free(h->H1); dev_free(h->rH1);
-    dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val);
+    dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val); dev_free(h->ell_row); dev_free(h->ell_val);
     dev_free(h->iB_colptr); dev_free(h->iB_row); dev_free(h->iB_val);
     dev_free(h->iA_rowptr); dev_free(h->iA_col); dev_free(h->iA_rval);
     dev_free(h->iB_rowptr); dev_free(h->iB_col); dev_free(h->iB_rval);
@@ -354,6 +354,30 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
     if ((rc = dev_upload(h, &h->iB_val, iB_val, (size_t)h->nnzB))) return rc;
     if ((rc = csc_to_csr(h, M * M, nq, iA_colptr, iA_row, iA_val, &h->iA_rowptr, &h->iA_col, &h->iA_rval))) return rc;
     if ((rc = csc_to_csr(h, M * M, nq, iB_colptr, iB_row, iB_val, &h->iB_rowptr, &h->iB_col, &h->iB_rval))) return rc;
+    {   // column-ELL layout of [iA | iB]: adjacent columns (= adjacent threads) read adjacent entries
+        int L = 0;
+        for (int q = 0; q < nq; ++q) {
+            L = std::max(L, (int)(iA_colptr[q + 1] - iA_colptr[q]));
+            L = std::max(L, (int)(iB_colptr[q + 1] - iB_colptr[q]));
+        }
+        const size_t nc = (size_t)2 * nq;
+        std::vector<int> er(nc * L, 0);
+        std::vector<double> ev(2 * nc * L, 0.0);
+        for (int c = 0; c < 2 * nq; ++c) {
+            const bool isB = c >= nq;
+            const int q = isB ? c - nq : c;
+            const int64_t *cp = isB ? iB_colptr : iA_colptr, *rw = isB ? iB_row : iA_row;
+            const double *vl = isB ? iB_val : iA_val;
+            int k = 0;
+            for (int64_t z = cp[q]; z < cp[q + 1]; ++z, ++k) {
+                er[(size_t)k * nc + c] = (int)rw[z];
+                ev[2 * ((size_t)k * nc + c)] = vl[2 * z]; ev[2 * ((size_t)k * nc + c) + 1] = vl[2 * z + 1];
+            }
+        }
+        h->ell_len = L;
+        if ((rc = dev_upload(h, &h->ell_row, er.data(), nc * L))) return rc;
+        if ((rc = dev_upload(h, &h->ell_val, ev.data(), nc * L))) return rc;
+    }
     if ((rc = dev_upload(h, &h->kpq_off, kpq_off, (size_t)nq + 1))) return rc;
     if ((rc = dev_upload(h, &h->kpq_i, kpq_i, (size_t)kpq_off[nq]))) return rc;
     if ((rc = dev_upload(h, &h->kpq_kpq, kpq_kpq, (size_t)kpq_off[nq]))) return rc;

@@ -67,6 +67,8 @@ struct afq_handle {
     // row-major (CSR over M*M rows) copies for the VHS gather
     int64_t *iA_rowptr = nullptr, *iA_col = nullptr; cplx *iA_rval = nullptr;
     int64_t *iB_rowptr = nullptr, *iB_col = nullptr; cplx *iB_rval = nullptr;
+    // column-ELL copy of [iA | iB] for the LDS force-bias kernel: k-th non-zero of column c at [k * 2nq + c]
+    int ell_len = 0; int *ell_row = nullptr; cplx *ell_val = nullptr;
     int64_t *kpq_off = nullptr, *kpq_i = nullptr, *kpq_kpq = nullptr;
     int64_t *pmq_off = nullptr, *pmq_i = nullptr, *pmq_pmq = nullptr;
     double *vqvec = nullptr; double vol = 1.0; double *H1diag = nullptr;

@@ -135,7 +135,43 @@ __global__ void vbias_ueg_kernel(const cplx *G, cplx *vbias, int nw, int M, int 
     if (lane == 0) vbias[(long)w * 2 * nq + col] = cmake(sr, si);
 }
 
+// Same contraction with the walker's spin-summed Green's function staged in LDS (M^2 x 16 B, 138 KB at
+// C2): one work-group per walker, one thread per column in turn.  The gathers run along shifted diagonals
+// of G (one element per cache line), which makes the global-memory version L2-transaction bound.
+__global__ __launch_bounds__(512) void vbias_ueg_lds_kernel(const cplx *G, cplx *vbias, int M, int ncol, int L,
+                                                            const int *ell_row, const cplx *ell_val) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx *gs = (cplx *)smem;
+    const int w = blockIdx.x;
+    const cplx *Ga = G + (long)w * 2 * M * M, *Gb = Ga + (long)M * M;
+    for (int e = threadIdx.x; e < M * M; e += 512) gs[e] = cadd(Ga[e], Gb[e]);
+    __syncthreads();
+    for (int col = threadIdx.x; col < ncol; col += 512) {
+        double sr = 0, si = 0;
+#pragma unroll 4
+        for (int k = 0; k < L; ++k) {                          // padded entries carry a zero value
+            const cplx g = gs[ell_row[(long)k * ncol + col]], v = ell_val[(long)k * ncol + col];
+            sr += g.x * v.x - g.y * v.y;
+            si += g.x * v.y + g.y * v.x;
+        }
+        vbias[(long)w * ncol + col] = cmake(sr, si);
+    }
+}
+
 int k_vbias_ueg(afq_handle *h) {
+    const size_t lds = sizeof(cplx) * (size_t)h->M * h->M;
+    if (lds <= 160 * 1024) {
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            AFQ_HIP(h, hipFuncSetAttribute((const void *)vbias_ueg_lds_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(vbias_ueg_lds_kernel, dim3(h->nw), dim3(512), lds, h->stream, h->G, h->vbias, h->M, 2 * h->nq,
+                           h->ell_len, h->ell_row, h->ell_val);
+        AFQ_HIP(h, hipGetLastError());
+        return AFQ_OK;
+    }
     const long items = (long)h->nw * 2 * h->nq;
     hipLaunchKernelGGL(vbias_ueg_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, h->stream, h->G,
                        h->vbias, h->nw, h->M, h->nq, h->iA_colptr, h->iA_row, h->iA_val, h->iB_colptr,
