@@ -75,7 +75,7 @@ void free_system(afq_handle *h) {
     dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     dev_free(h->H1); dev_free(h->rH1);
-    dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val); dev_free(h->ell_row); dev_free(h->ell_val);
+    dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val); dev_free(h->ell_row); dev_free(h->ell_val); dev_free(h->ueg_rmap); dev_free(h->ueg_rows);
     dev_free(h->iB_colptr); dev_free(h->iB_row); dev_free(h->iB_val);
     dev_free(h->iA_rowptr); dev_free(h->iA_col); dev_free(h->iA_rval);
     dev_free(h->iB_rowptr); dev_free(h->iB_col); dev_free(h->iB_rval);
@@ -384,6 +384,15 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
     if ((rc = dev_upload(h, &h->pmq_off, pmq_off, (size_t)nq + 1))) return rc;
     if ((rc = dev_upload(h, &h->pmq_i, pmq_i, (size_t)pmq_off[nq]))) return rc;
     if ((rc = dev_upload(h, &h->pmq_pmq, pmq_pmq, (size_t)pmq_off[nq]))) return rc;
+    {   // rows of G referenced by the energy's index lists (estimators/ueg.py:27-88)
+        std::vector<int> rmap(M, -1), rows;
+        for (int64_t z = 0; z < kpq_off[nq]; ++z) if (rmap[kpq_i[z]] < 0) { rmap[kpq_i[z]] = 1; }
+        for (int64_t z = 0; z < pmq_off[nq]; ++z) if (rmap[pmq_i[z]] < 0) { rmap[pmq_i[z]] = 1; }
+        for (int i = 0; i < M; ++i) if (rmap[i] > 0) { rmap[i] = (int)rows.size(); rows.push_back(i); }
+        h->ueg_nrows = (int)rows.size();
+        if ((rc = dev_upload(h, &h->ueg_rmap, rmap.data(), (size_t)M))) return rc;
+        if ((rc = dev_upload(h, &h->ueg_rows, rows.data(), rows.size()))) return rc;
+    }
     if ((rc = dev_upload(h, &h->vqvec, vqvec, (size_t)nq))) return rc;
     if ((rc = dev_upload(h, &h->H1diag, H1diag, (size_t)2 * M))) return rc;
     cache_of(h)->H1.clear();

@@ -69,6 +69,8 @@ struct afq_handle {
     int64_t *iB_rowptr = nullptr, *iB_col = nullptr; cplx *iB_rval = nullptr;
     // column-ELL copy of [iA | iB] for the LDS force-bias kernel: k-th non-zero of column c at [k * 2nq + c]
     int ell_len = 0; int *ell_row = nullptr; cplx *ell_val = nullptr;
+    // rows of G the UEG energy gathers touch (the occupied orbitals of the trial): compact index per row or -1
+    int ueg_nrows = 0; int *ueg_rmap = nullptr; int *ueg_rows = nullptr;
     int64_t *kpq_off = nullptr, *kpq_i = nullptr, *kpq_kpq = nullptr;
     int64_t *pmq_off = nullptr, *pmq_i = nullptr, *pmq_pmq = nullptr;
     double *vqvec = nullptr; double vol = 1.0; double *H1diag = nullptr;

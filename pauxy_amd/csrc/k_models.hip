@@ -206,40 +206,56 @@ int k_vhs_ueg(afq_handle *h) {
 
 // Energy: one workgroup per walker; each wavefront takes q-vectors in turn and
 // gathers Gkpq, Gpmq and the exchange double sum for both spins.
-__global__ __launch_bounds__(256) void energy_ueg_kernel(const cplx *G, cplx *energy, int M, int nq,
+// STAGED: only the rows of G that the index lists touch (the trial's occupied orbitals, ueg_rows) are
+// copied to LDS for both spins and every gather goes there; otherwise the gathers read global memory.
+template <bool STAGED>
+__global__ __launch_bounds__(1024) void energy_ueg_kernel(const cplx *G, cplx *energy, int M, int nq,
                                                          const int64_t *kpq_off, const int64_t *kpq_i,
                                                          const int64_t *kpq_kpq, const int64_t *pmq_off,
                                                          const int64_t *pmq_i, const int64_t *pmq_pmq,
-                                                         const double *vqvec, double vol, const double *H1diag) {
-    __shared__ double red[8];
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const cplx *Gs[2] = {G + (long)w * 2 * M * M, G + (long)w * 2 * M * M + (long)M * M};
+                                                         const double *vqvec, double vol, const double *H1diag,
+                                                         const int *rmap, const int *rows, int nrows) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double red[16];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const cplx *Gg[2] = {G + (long)w * 2 * M * M, G + (long)w * 2 * M * M + (long)M * M};
+    const cplx *Gs[2] = {Gg[0], Gg[1]};
+    if (STAGED) {
+        cplx *st = (cplx *)smem;
+        for (int e = tid; e < 2 * nrows * M; e += (int)blockDim.x) {
+            const int s = e / (nrows * M), r = (e / M) % nrows, c = e % M;
+            st[e] = Gg[s][(long)rows[r] * M + c];
+        }
+        Gs[0] = st; Gs[1] = st + (long)nrows * M;
+    }
+    auto RI = [&](int64_t i) -> long { return STAGED ? (long)rmap[i] : (long)i; };
     double ker = 0, kei = 0;
-    for (int e = tid; e < 2 * M; e += 256) {
+    for (int e = tid; e < 2 * M; e += (int)blockDim.x) {
         const int s = e / M, i = e % M;
-        const cplx g = Gs[s][(long)i * M + i];
+        const cplx g = Gg[s][(long)i * M + i];
         ker += H1diag[e] * g.x; kei += H1diag[e] * g.y;
     }
+    if (STAGED) __syncthreads();
     double per = 0, pei = 0;
-    for (int q = wave; q < nq; q += 4) {
-        const int64_t k0 = kpq_off[q], nk = kpq_off[q + 1] - k0;
-        const int64_t p0 = pmq_off[q], np = pmq_off[q + 1] - p0;
+    for (int q = wave; q < nq; q += nwave) {
+        const int64_t k0 = kpq_off[q], p0 = pmq_off[q];
+        const int nk = (int)(kpq_off[q + 1] - k0), np = (int)(pmq_off[q + 1] - p0);   // <= N: 32-bit index math
         cplx gk[2], gp[2], gx[2];
         for (int s = 0; s < 2; ++s) {
             double ar = 0, ai = 0, br = 0, bi = 0, cr = 0, ci = 0;
-            for (int64_t z = lane; z < nk; z += 64) {
-                const cplx g = Gs[s][kpq_i[k0 + z] * M + kpq_kpq[k0 + z]];
+            for (int z = lane; z < nk; z += 64) {
+                const cplx g = Gs[s][RI(kpq_i[k0 + z]) * M + kpq_kpq[k0 + z]];
                 ar += g.x; ai += g.y;
             }
-            for (int64_t z = lane; z < np; z += 64) {
-                const cplx g = Gs[s][pmq_i[p0 + z] * M + pmq_pmq[p0 + z]];
+            for (int z = lane; z < np; z += 64) {
+                const cplx g = Gs[s][RI(pmq_i[p0 + z]) * M + pmq_pmq[p0 + z]];
                 br += g.x; bi += g.y;
             }
             // sum_{a,b} G[pmq_i[b], kpq[a]] * G[kpq_i[a], pmq[b]]
-            for (int64_t z = lane; z < nk * np; z += 64) {
-                const int64_t ia = z / np, ibb = z % np;
-                const cplx g1 = Gs[s][pmq_i[p0 + ibb] * M + kpq_kpq[k0 + ia]];
-                const cplx g2 = Gs[s][kpq_i[k0 + ia] * M + pmq_pmq[p0 + ibb]];
+            for (int z = lane; z < nk * np; z += 64) {
+                const int ia = z / np, ibb = z % np;
+                const cplx g1 = Gs[s][RI(pmq_i[p0 + ibb]) * M + kpq_kpq[k0 + ia]];
+                const cplx g2 = Gs[s][RI(kpq_i[k0 + ia]) * M + pmq_pmq[p0 + ibb]];
                 cr += g1.x * g2.x - g1.y * g2.y;
                 ci += g1.x * g2.y + g1.y * g2.x;
             }
@@ -267,7 +283,9 @@ __global__ __launch_bounds__(256) void energy_ueg_kernel(const cplx *G, cplx *en
         __syncthreads();
         if (lane == 0) red[wave] = x;
         __syncthreads();
-        v[k] = red[0] + red[1] + red[2] + red[3];
+        double t = 0.0;
+        for (int i = 0; i < nwave; ++i) t += red[i];
+        v[k] = t;
     }
     if (tid == 0) {
         energy[3 * w + 0] = cmake(v[0] + v[2], v[1] + v[3]);
@@ -277,9 +295,22 @@ __global__ __launch_bounds__(256) void energy_ueg_kernel(const cplx *G, cplx *en
 }
 
 int k_energy_ueg(afq_handle *h) {
-    hipLaunchKernelGGL(energy_ueg_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->G, h->energy, h->M, h->nq,
-                       h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
-                       h->H1diag);
+    const size_t lds = sizeof(cplx) * 2 * (size_t)h->ueg_nrows * h->M;
+    if (lds <= 120 * 1024) {
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            AFQ_HIP(h, hipFuncSetAttribute((const void *)energy_ueg_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(energy_ueg_kernel<true>, dim3(h->nw), dim3(1024), lds, h->stream, h->G, h->energy, h->M, h->nq,
+                           h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
+                           h->H1diag, h->ueg_rmap, h->ueg_rows, h->ueg_nrows);
+    } else {
+        hipLaunchKernelGGL(energy_ueg_kernel<false>, dim3(h->nw), dim3(1024), 0, h->stream, h->G, h->energy, h->M, h->nq,
+                           h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
+                           h->H1diag, h->ueg_rmap, h->ueg_rows, h->ueg_nrows);
+    }
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;
 }
