@@ -52,9 +52,14 @@ class FakeComm(object):
     def recv_tensor(self, t, source, tag=0):
         raise RuntimeError("recv on a size-1 communicator")
 
+    def exchange_tensors(self, send, recv):
+        if send or recv:
+            raise RuntimeError("exchange on a size-1 communicator")
+
 
 class TorchComm(object):
     """mpi4py-like facade over an initialised torch.distributed process group."""
+    reduce_is_allreduce = True      # Reduce() leaves the sum on every rank (see Mixed.print_step)
 
     def __init__(self, device=None, group=None):
         import torch
@@ -83,6 +88,13 @@ class TorchComm(object):
     Barrier = barrier
 
     def bcast(self, obj, root=0):
+        # numeric payloads (the energy shift pair of mixed.py:273, a float) travel as a tensor; anything else
+        # falls back to the pickling broadcast.  Every rank passes an object of the same type and shape.
+        if isinstance(obj, (float, numpy.floating)):
+            return float(self.Bcast(numpy.array([obj], dtype=numpy.float64), root)[0])
+        if isinstance(obj, numpy.ndarray) and obj.dtype.kind in 'fc' and obj.size > 0:
+            return self.Bcast(numpy.array(obj, dtype=numpy.complex128 if obj.dtype.kind == 'c' else numpy.float64),
+                              root)
         box = [obj]
         self._dist.broadcast_object_list(box, src=root, group=self.group, device=self.device)
         return box[0]
@@ -122,6 +134,15 @@ class TorchComm(object):
     def Reduce(self, send, recv, op=None, root=0):
         # every rank ends with the sum; only `root` is documented to hold it (mixed.py:261)
         self.Allreduce(send, recv)
+
+    def exchange_tensors(self, send, recv):
+        """Post every send ({peer: tensor}) and receive of this rank as one batch and wait for all of them."""
+        ops = [self._dist.P2POp(self._dist.isend, t, peer, self.group) for peer, t in sorted(send.items())]
+        ops += [self._dist.P2POp(self._dist.irecv, t, peer, self.group) for peer, t in sorted(recv.items())]
+        if not ops:
+            return
+        for req in self._dist.batch_isend_irecv(ops):
+            req.wait()
 
     def send_tensor(self, t, dest, tag=0):
         self._dist.send(t, dst=dest, group=self.group, tag=tag)

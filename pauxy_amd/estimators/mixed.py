@@ -80,7 +80,10 @@ class Mixed(object):
         es[ns.ehyb:ns.time + 1] /= nsteps
         comm.Reduce(es, self.global_estimates, op=None)
         gs = self.global_estimates
-        if comm.rank == 0:
+        # torch.distributed has no rooted reduce worth its latency: TorchComm.Reduce leaves the sums on every
+        # rank, so every rank derives the shift itself and the broadcast of mixed.py:273 is not needed
+        everywhere = getattr(comm, 'reduce_is_allreduce', False)
+        if comm.rank == 0 or everywhere:
             gs[ns.eproj] = gs[ns.enumer]
             gs[ns.eproj:ns.e2b + 1] = gs[ns.eproj:ns.e2b + 1] / gs[ns.edenom]
             gs[ns.ehyb] /= gs[ns.weight]
@@ -88,7 +91,8 @@ class Mixed(object):
             eshift = numpy.array([gs[ns.ehyb], gs[ns.eproj]])
         else:
             eshift = numpy.array([0, 0])
-        eshift = comm.bcast(eshift, root=0)
+        if not everywhere:
+            eshift = comm.bcast(eshift, root=0)
         self.eshift = eshift
         if comm.rank == 0:
             row = [step] + list(gs[:ns.time + 1])

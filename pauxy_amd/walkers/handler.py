@@ -32,22 +32,18 @@ _SCALARS = {
 
 
 def comb_parent_ix(weights, target, r):
-    """Comb teeth against cumulative weights (walkers/handler.py:269-286);
-    sequential on purpose: the decisions must not depend on summation order."""
+    """Comb teeth against cumulative weights (walkers/handler.py:269-286).  Tooth ic goes to the first
+    walker iw with (ic + r) * step < cumsum(weights)[iw]; the reference finds it with a sequential scan,
+    here every tooth is located by bisection of the SAME sequential numpy.cumsum (identical comparisons,
+    identical decisions); teeth beyond the last cumulative weight are dropped, as in the scan."""
+    weights = numpy.asarray(weights, dtype=numpy.float64)
     n = len(weights)
-    parent_ix = numpy.zeros(n, dtype='i')
-    total_weight = sum(weights)
     cprobs = numpy.cumsum(weights)
+    total_weight = cprobs[-1]                  # == sum(weights): same left-to-right additions
     step = total_weight / target
-    iw = 0
-    ic = 0
-    while ic < target and iw < n:
-        if (ic + r) * step < cprobs[iw]:
-            parent_ix[iw] += 1
-            ic += 1
-        else:
-            iw += 1
-    return parent_ix
+    teeth = (numpy.arange(int(target)) + r) * step
+    iw = numpy.searchsorted(cprobs, teeth, side='right')
+    return numpy.bincount(iw[iw < n], minlength=n).astype('i')
 
 
 def comb_pairs(parent_ix):
@@ -352,38 +348,47 @@ class Walkers(object):
 
 def pop_control_distributed(dev, comm, nw, target_weight):
     """walkers/handler.py:225-338 across ranks.  ``dev`` is the rank's AfqDevice
-    (anything with get/scale_weights/copy_walker/pack/unpack/reset_weights)."""
+    (anything with get/scale_weights/copy_walker/pack/unpack/reset_weights).
+
+    Two collectives per call: one all-gather carries every rank's |weights| plus rank 0's comb uniform
+    (the reference's Allgather :232 and bcast :291), then every rank decides the identical global comb and
+    the cloned walkers move in ONE batched exchange (all sends and receives of a rank posted together;
+    the reference's per-pair Isend/Recv loop :303-331)."""
     weights = numpy.abs(dev.get(L.F_WEIGHT))
-    global_weights = numpy.empty(nw * comm.size)
-    comm.Allgather(weights, global_weights)                # handler.py:232
-    total_weight = sum(global_weights)
+    r = numpy.random.random() if comm.rank == 0 else 0.0   # handler.py:276 (only rank 0 draws)
+    mine = numpy.concatenate([weights, [r]])
+    gathered = numpy.empty((nw + 1) * comm.size)
+    comm.Allgather(mine, gathered)                         # handler.py:232
+    gathered = gathered.reshape(comm.size, nw + 1)
+    global_weights = numpy.ascontiguousarray(gathered[:, :nw]).reshape(-1)
+    r = float(gathered[0, nw])
+    total_weight = float(numpy.cumsum(global_weights)[-1])  # sum(global_weights), sequential
     if total_weight < 1e-8:
         if comm.rank == 0:
             print("# Warning: total weight is {:13.8e}.  Something is seriously wrong.".format(total_weight))
         sys.exit()
     scale = total_weight / target_weight
     dev.scale_weights(scale)                               # handler.py:244-246
-    r = numpy.random.random() if comm.rank == 0 else None  # handler.py:276
-    r = comm.bcast(r, root=0)
     parent_ix = comb_parent_ix(global_weights / scale, target_weight, r)
-    transport = WalkerTransport(dev, comm)
-    for i, (c, k) in enumerate(comb_pairs(parent_ix)):
+    outgoing, incoming = {}, {}                            # peer rank -> local walker indices, in pair order
+    for c, k in comb_pairs(parent_ix):
         src_rank, dst_rank = c // nw, k // nw
         if src_rank == dst_rank:
             if src_rank == comm.rank:
                 dev.copy_walker(c % nw, k % nw)
         elif src_rank == comm.rank:
-            transport.send(c % nw, dst_rank, tag=i)
+            outgoing.setdefault(dst_rank, []).append(c % nw)
         elif dst_rank == comm.rank:
-            transport.recv(k % nw, src_rank, tag=i)
-    transport.finish()
+            incoming.setdefault(src_rank, []).append(k % nw)
+    WalkerTransport(dev, comm).exchange(outgoing, incoming)
     dev.reset_weights()                                    # handler.py:337-338
     return total_weight, parent_ix
 
 
 class WalkerTransport(object):
-    """Moves packed walkers (phi + scalars, ``afq_walker_pack``) between ranks
-    through device tensors: RCCL send/recv over xGMI on the GPU node."""
+    """Moves packed walkers (phi + scalars [+ back-propagation state], ``afq_walker_pack``) between ranks:
+    per peer one contiguous buffer of packed walkers, all transfers of a pop-control posted as one batch of
+    isend / irecv (RCCL send/recv over xGMI on the GPU node; host-staged for CPU backends)."""
 
     def __init__(self, dev, comm):
         import torch
@@ -397,28 +402,32 @@ class WalkerTransport(object):
         self.direct = self.gpu.type == 'cpu' or (getattr(comm, 'device', None) is not None and
                                                 comm.device.type == 'cuda')
 
-    def _buf(self):
-        return self.torch.empty(self.nbytes // 8, dtype=self.torch.float64, device=self.gpu)
+    def exchange(self, outgoing, incoming):
+        """outgoing / incoming: {peer rank: [local walker index, ...]} in the global pair order (both sides
+        enumerate the same comb, so the k-th packed walker sent to a peer is the k-th it expects)."""
+        torch = self.torch
+        per = self.nbytes // 8
+        sbuf, rbuf = {}, {}
+        for peer in sorted(outgoing):
+            buf = torch.empty(len(outgoing[peer]) * per, dtype=torch.float64, device=self.gpu)
+            for j, iw in enumerate(outgoing[peer]):
+                self.dev.pack(iw, buf.data_ptr() + j * self.nbytes)
+            sbuf[peer] = buf
+        if sbuf:
+            self.dev.sync()
+        for peer in sorted(incoming):
+            n = len(incoming[peer]) * per
+            rbuf[peer] = torch.empty(n, dtype=torch.float64, device=self.gpu if self.direct else 'cpu')
+        if not self.direct:
+            sbuf = {p: b.cpu() for p, b in sbuf.items()}
+        self.comm.exchange_tensors(sbuf, rbuf)
+        for peer in sorted(incoming):
+            buf = rbuf[peer] if self.direct else rbuf[peer].to(self.gpu)
+            if buf.is_cuda:
+                torch.cuda.current_stream(buf.device).synchronize()
+            for j, iw in enumerate(incoming[peer]):
+                self.dev.unpack(iw, buf.data_ptr() + j * self.nbytes)
+        if incoming:
+            self.dev.sync()
 
-    def send(self, iw, dest, tag):
-        buf = self._buf()
-        self.dev.pack(iw, buf.data_ptr())
-        self.dev.sync()
-        # RCCL moves the device buffer itself; a CPU backend (gloo: tests, debugging) gets a host copy
-        self.comm.send_tensor(buf if self.direct else buf.cpu(), dest, tag)
 
-    def recv(self, iw, source, tag):
-        buf = self._buf()
-        if self.direct:
-            self.comm.recv_tensor(buf, source, tag)
-        else:
-            host = self.torch.empty(self.nbytes // 8, dtype=self.torch.float64)
-            self.comm.recv_tensor(host, source, tag)
-            buf.copy_(host)
-        if buf.is_cuda:
-            self.torch.cuda.current_stream(buf.device).synchronize()
-        self.dev.unpack(iw, buf.data_ptr())
-        self.dev.sync()
-
-    def finish(self):
-        self.comm.barrier()
