@@ -762,11 +762,18 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
 }
 
 int afq_reortho(afq_handle *h, double *detR_out) {
-    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
-    if (rc) return rc;
+    if (rc) { h->greens_valid = false; return rc; }
+    // Ghalf = (phi^T psi*)^-1 phi^T does not change when phi -> phi R^-1, so a Green's function kept from
+    // the end of the last step stays valid across the QR; only the cached overlap picks up 1 / det R.
+    const bool keep = h->greens_valid && h->ndet == 1;
+    h->greens_valid = false;
     { PhaseTimer t(h, T_QR); if ((rc = k_reortho(h))) return rc; }
+    if (keep) {
+        if ((rc = k_scale_by_inverse(h, h->ovlp_new, h->detR))) return rc;
+        h->greens_valid = true;
+    }
     return copy_out(h, detR_out, h->detR, sizeof(double) * h->nw);
 }
 
@@ -908,12 +915,15 @@ int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
 
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *parent_ix,
                         double *total_weight_out) {
-    if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
-    if (rc) return rc;
+    if (rc) { h->greens_valid = false; return rc; }
     if (h->nw == 1) return AFQ_OK;                       // handler.py:226-227
-    if ((rc = k_comb(h, r, target_weight))) return rc;
+    // a kept Green's function travels with the cloned walkers (k_comb copies Ghalf and the cached overlap)
+    const bool keep = h->greens_valid && h->ndet == 1;
+    h->greens_valid = false;
+    if ((rc = k_comb(h, r, target_weight, keep))) return rc;
+    h->greens_valid = keep;
     if (!parent_ix && !total_weight_out) return AFQ_OK;  // asynchronous: nothing read back, no host sync
     double sc[2];
     if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;

@@ -274,7 +274,8 @@ int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -
 int k_update_weight(afq_handle *h, cplx eshift);
 int k_reortho(afq_handle *h);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);
-int k_comb(afq_handle *h, double r, double target);
+int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
+int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[w]
 int k_scale_weights(afq_handle *h, double scale);
 int k_reset_weights(afq_handle *h);
 int k_estimates(afq_handle *h, int have_energy);

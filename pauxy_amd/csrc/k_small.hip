@@ -1154,6 +1154,8 @@ struct CloneArgs {
     double *bp_cos;
     int *bp_n;
     long hist_per;
+    // a cached Green's function travels too; null when there is none
+    cplx *ghalf, *ovlp_new;
 };
 
 __global__ void clone_kernel(CloneArgs a) {
@@ -1162,6 +1164,11 @@ __global__ void clone_kernel(CloneArgs a) {
     const int src = a.pairs[2 * pr], dst = a.pairs[2 * pr + 1];
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
         a.phi[dst * a.per + i] = a.phi[src * a.per + i];
+    if (a.ghalf) {
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
+            a.ghalf[dst * a.per + i] = a.ghalf[src * a.per + i];
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.ovlp_new[dst] = a.ovlp_new[src];
+    }
     if (a.phi_old) {
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
             a.phi_old[dst * a.per + i] = a.phi_old[src * a.per + i];
@@ -1175,7 +1182,18 @@ __global__ void clone_kernel(CloneArgs a) {
     }
 }
 
-int k_comb(afq_handle *h, double r, double target) {
+__global__ void scale_by_inverse_kernel(cplx *x, const double *d, int nw) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) x[w] = cmake(x[w].x / d[w], x[w].y / d[w]);
+}
+
+int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
+    hipLaunchKernelGGL(scale_by_inverse_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, x, d, h->nw);
+    AFQ_HIP(h, hipGetLastError());
+    return AFQ_OK;
+}
+
+int k_comb(afq_handle *h, double r, double target, bool with_greens) {
     int *pairs = (int *)h->pack_tmp;
     hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + 3 * sizeof(int)) * (size_t)h->nw,
                        h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
@@ -1185,6 +1203,7 @@ int k_comb(afq_handle *h, double r, double target) {
     a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = pairs; a.scal = h->scal;
     a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
     a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
+    a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;
     // at most nw/2 pairs
     hipLaunchKernelGGL(clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
