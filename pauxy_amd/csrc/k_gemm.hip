@@ -168,9 +168,11 @@ int k_force_bias_generic(afq_handle *h) {
         if (h->nw > 32 && !h->no_ring) {
             // work-group tile 64 walkers x 64 fields, operands shared through the LDS ring
             static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 1;
+            static const int kc = getenv("AFQ_GEMM_KC") ? atoi(getenv("AFQ_GEMM_KC")) : 1;
             if (cfg == 1) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
-                AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                if (kc == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 2>(p, h->stream, h->zero_page)));
+                else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             }
             else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
@@ -251,8 +253,12 @@ int k_vhs_generic(afq_handle *h) {
         else if (cfg == 5) AFQ_HIP(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 6) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 1, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 7) {
+            static const int kc = getenv("AFQ_GEMM_KC") ? atoi(getenv("AFQ_GEMM_KC")) : 1;
             KernelTrace kt(h, AFQ_K_VHS);
-            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            static const int xmap = getenv("AFQ_VHS_XCD") ? atoi(getenv("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
+            if (kc == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
+            else if (xmap) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
+            else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         }
         else if (cfg == 8) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 9) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));

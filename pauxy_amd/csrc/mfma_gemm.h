@@ -55,7 +55,8 @@ struct FragSet {
 //   MAP_COLS_FAST  consecutive waves walk tile columns of one tile row (share the A panel)
 //   MAP_ROWS_FAST  consecutive waves walk tile rows of one tile column (share the B panel)
 //   MAP_BATCH_XCD  batch b runs on XCD b % 8: each batch's operand slices stay in one L2
-enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2 };
+//   MAP_COLPANEL_XCD  (work-group engine, batch == 1) column panel c and all its row tiles run on XCD c % 8
+enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3 };
 
 template <int TM, int TN, class P, int MAP = MAP_COLS_FAST>
 __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {

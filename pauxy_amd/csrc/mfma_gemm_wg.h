@@ -30,7 +30,9 @@
 template <class P, class = void> struct gemm_conj_a { static constexpr bool value = false; };
 template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static constexpr bool value = P::A_CONJ; };
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false>
+// KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
+// read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
     static_assert(P::A_CPLX, "A operand must be complex");
     static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
@@ -39,8 +41,9 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     constexpr int RT = WM * TM, CT = WN * TN;              // tile rows / cols of the work-group tile
     constexpr int NA = RT * 2;                             // A fragments per chunk (1 KB each)
     constexpr int NB = P::B_CPLX ? CT * 2 : CT;            // B fragments (1 KB each)
-    constexpr int LPA = (NA + NW - 1) / NW, LPB = (NB + NW - 1) / NW, LPW = LPA + LPB;
-    constexpr int CHUNK = (NA + NB) * 1024;
+    constexpr int LPA = (NA + NW - 1) / NW, LPB = (NB + NW - 1) / NW, LPW = KC * (LPA + LPB);
+    constexpr int SUB = (NA + NB) * 1024;                    // bytes of one 8-index sub-chunk
+    constexpr int CHUNK = KC * SUB;
     constexpr int NWAIT = (D - 2) * LPW;
     static_assert(NWAIT <= 63, "vmcnt field is 6 bits");
     const int lane = threadIdx.x & 63;
@@ -58,6 +61,13 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
         if (b >= p.batch) return;
         const int rem = (int)(t % per_batch);
         tm = rem / tiles_n; tn = rem % tiles_n;
+    } else if (MAP == MAP_COLPANEL_XCD) {
+        // single batch: work-groups are dealt round-robin to the 8 XCDs, so XCD x takes the column panels
+        // x, x+8, ... with ALL their row tiles: a B panel (and its slice of the output) stays in one L2
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = 0;
+        tn = (j / tiles_m) * 8 + x; tm = j % tiles_m;
+        if (tn >= tiles_n) return;
     } else {
         const long t = blockIdx.x;
         b = (int)(t / per_batch);
@@ -70,13 +80,15 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     const int lr = lane & 15, lk = lane >> 4;
     unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
     const unsigned ring_l = lds_addr(smem);
-    const int nchunks = (p.kdim + 7) >> 3;
+    const int nchunks = (p.kdim + 8 * KC - 1) / (8 * KC);
     const int b_half = lane >> 5, b_lp = lane & 31;
     const int b_kk = b_lp >> 3, b_cc = (b_lp & 7) * 2;
 
     auto issue = [&](int c, int slot) {
-        unsigned char *dst = smem + (size_t)slot * CHUNK;
-        const int k0 = c * 8;
+#pragma unroll
+        for (int sub = 0; sub < KC; ++sub) {
+        unsigned char *dst = smem + (size_t)slot * CHUNK + (size_t)sub * SUB;
+        const int k0 = (c * KC + sub) * 8;
 #pragma unroll
         for (int t = 0; t < LPA; ++t) {
             const int f = wave + t * NW;                   // A fragment index: tile row f>>1, sub-step f&1
@@ -98,6 +110,7 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
             glds16(src, f < NB ? dst + (NA + f) * 1024 : scratch);
         }
+        }
     };
 
     d4_t accR[TM][TN], accI[TM][TN], acc3[K3M ? TM : 1][K3M ? TN : 1];
@@ -116,49 +129,66 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(c + D - 1, (c + D - 1) & (D - 1));
-        const unsigned sl = ring_l + (c & (D - 1)) * CHUNK;
-        d2_t a[TM][2];
-        d2_t bc[TN][2];
-        double br[TN][2];
+        const unsigned sl0 = ring_l + (c & (D - 1)) * CHUNK;
+        d2_t a[KC][TM][2];
+        d2_t bc[KC][TN][2];
+        double br[KC][TN][2];
+        auto read_sub = [&](int sub) {
+            const unsigned sl = sl0 + sub * SUB;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) a[i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+                for (int s = 0; s < 2; ++s) a[sub][i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (P::B_CPLX) bc[j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
-                else br[j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
+                for (int s = 0; s < 2; ++s) {
+                    if (P::B_CPLX) bc[sub][j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
+                    else br[sub][j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
+                }
+        };
+        auto mfma_sub = [&](int sub) {
+            if (gemm_conj_a<P>::value) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) a[sub][i][s][1] = -a[sub][i][s][1];
             }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (P::B_CPLX && K3M) {
+                            accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);                          // P1
+                            accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][1], accI[i][j]);                          // P2
+                            acc3[i][j] = mfma16(a[sub][i][s][0] + a[sub][i][s][1], bc[sub][j][s][0] + bc[sub][j][s][1], acc3[i][j]);  // P3
+                        } else if (P::B_CPLX) {
+                            accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);
+                            accI[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][1], accI[i][j]);
+                            accR[i][j] = mfma16(-a[sub][i][s][1], bc[sub][j][s][1], accR[i][j]);
+                            accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][0], accI[i][j]);
+                        } else {
+                            accR[i][j] = mfma16(a[sub][i][s][0], br[sub][j][s], accR[i][j]);
+                            accI[i][j] = mfma16(a[sub][i][s][1], br[sub][j][s], accI[i][j]);
+                        }
+                    }
+        };
+        read_sub(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (gemm_conj_a<P>::value) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a[i][s][1] = -a[i][s][1];
+        if (KC == 2) {
+            read_sub(KC - 1);                              // in flight under the MFMAs of the first half
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (P::B_CPLX && K3M) {
-                        accR[i][j] = mfma16(a[i][s][0], bc[j][s][0], accR[i][j]);                          // P1
-                        accI[i][j] = mfma16(a[i][s][1], bc[j][s][1], accI[i][j]);                          // P2
-                        acc3[i][j] = mfma16(a[i][s][0] + a[i][s][1], bc[j][s][0] + bc[j][s][1], acc3[i][j]);  // P3
-                    } else if (P::B_CPLX) {
-                        accR[i][j] = mfma16(a[i][s][0], bc[j][s][0], accR[i][j]);
-                        accI[i][j] = mfma16(a[i][s][0], bc[j][s][1], accI[i][j]);
-                        accR[i][j] = mfma16(-a[i][s][1], bc[j][s][1], accR[i][j]);
-                        accI[i][j] = mfma16(a[i][s][1], bc[j][s][0], accI[i][j]);
-                    } else {
-                        accR[i][j] = mfma16(a[i][s][0], br[j][s], accR[i][j]);
-                        accI[i][j] = mfma16(a[i][s][1], br[j][s], accI[i][j]);
-                    }
-                }
+        mfma_sub(0);
+        if (KC == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(KC - 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (P::B_CPLX && K3M) {
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
 }
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;
     constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
@@ -197,8 +227,9 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
         const int nb8 = p.batch < 8 ? p.batch : 8;
         nblk = per_batch * ((p.batch + nb8 - 1) / nb8) * nb8;
     }
-    const size_t lds = (size_t)D * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
-    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M>;
+    if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
+    const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
+    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC>;
     static size_t lds_set = 0;              // one per template instantiation: set the cap once
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
