@@ -187,6 +187,10 @@ int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *by
 int afq_greens(afq_handle *h, int want_G, double *ovlp_out);
 /* walkers/single_det.py:170-199 for every walker -> ovlp_out c128[nw]         */
 int afq_calc_overlap(afq_handle *h, double *ovlp_out);
+/* O^-1 of every walker and spin, O = phi_s^T conj(psi_s) (so O^-1 = inv_O of estimators/greens_function.py:82-115
+ * and the transpose of SingleDetWalker.inv_ovlp, walkers/single_det.py:95-115): c128[nw, 2, nmax, nmax] row-major with
+ * leading dimension nmax = max(na, nb), zero padded; ovlp_out c128[nw] may be NULL.  N <= 45, M <= 128.              */
+int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out);
 /* propagation/continuous.py:232-262 (phaseless) or :175-200 (free projection)
  * for every live walker (|weight| > 1e-8, qmc/afqmc.py:232).
  * xi: host f64[nw, K] normal fields (row iw used only if walker iw is live),

@@ -637,6 +637,28 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
     return copy_out(h, ovlp_out, h->ovlp_old, sizeof(cplx) * h->nw);
 }
 
+int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
+    if (h) h->greens_valid = false;
+    if (!h || !oinv_out) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "inverse overlaps: single-determinant trials");
+    const size_t nmax = h->na > h->nb ? h->na : h->nb, n = (size_t)h->nw * 2 * nmax * nmax;
+    cplx *tmp = nullptr;
+    if ((rc = dev_alloc(h, &tmp, n))) return rc;
+    AFQ_HIP(h, hipMemsetAsync(tmp, 0, sizeof(cplx) * n, h->stream));
+    if ((rc = k_alive(h))) { dev_free(tmp); return rc; }
+    // every walker, dead or alive: flag them all for this call
+    std::vector<int> ones(h->nw, 1);
+    AFQ_HIP(h, hipMemcpyAsync(h->alive, ones.data(), sizeof(int) * h->nw, hipMemcpyHostToDevice, h->stream));
+    rc = k_inverse_overlap(h, tmp, h->ovlp_new);
+    if (!rc) rc = copy_out(h, oinv_out, tmp, sizeof(cplx) * n);
+    if (!rc && ovlp_out) rc = copy_out(h, ovlp_out, h->ovlp_new, sizeof(cplx) * h->nw);
+    dev_free(tmp);
+    if (!rc) rc = k_alive(h);
+    return rc;
+}
+
 int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
     if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;

@@ -112,6 +112,14 @@ class AfqDevice(object):
         psi = _c128(psi, (self.M, self.na + self.nb))
         self._ck(self.lib.afq_set_trial(self.h, _p(psi)))
 
+    def inverse_overlap(self):
+        """(O^-1 [nw, 2, nmax, nmax], overlap [nw]) with O = phi_s^T conj(psi_s)."""
+        nmax = max(self.na, self.nb)
+        out = numpy.zeros((self.nw, 2, nmax, nmax), dtype=numpy.complex128)
+        ov = numpy.zeros(self.nw, dtype=numpy.complex128)
+        self._ck(self.lib.afq_inverse_overlap(self.h, _p(out), _p(ov)))
+        return out, ov
+
     # ---- discrete Hirsch propagator
     def set_propagator_hirsch(self, bt2, dt, charge_decomposition=False):
         bt2 = _c128(bt2, (2, self.M, self.M))

@@ -272,3 +272,29 @@ def test_hirsch_single_step(golden, charge):
     live = numpy.nonzero(wt != 0)[0]
     close(dev.get(L.F_OT)[live], dev.calc_overlap()[live])
     dev.close()
+
+
+def test_greens_function_free_functions():
+    """pauxy/estimators/greens_function.py:5-160 by name, on the device, against the oracle's restatements."""
+    from pauxy_amd.estimators import greens_function as gf
+    rng = numpy.random.RandomState(2)
+    M, na, nb = 14, 5, 3
+    A = rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)
+    B = rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)
+    close(gf.gab(A[:, :na], B[:, :na]), ref.gab(A[:, :na], B[:, :na]))
+    G, Gh = gf.gab_mod(A[:, :na], B[:, :na])
+    Gr, Ghr = ref.gab_mod(A[:, :na], B[:, :na])
+    close(G, Gr)
+    close(Gh, Ghr)
+    Gs, Ghs = gf.gab_spin(A, B, na, nb)
+    close(Gs[0], Gr)
+    close(Gs[1], ref.gab_mod(A[:, na:], B[:, na:])[0])
+    close(Ghs[1], ref.gab_mod(A[:, na:], B[:, na:])[1])
+    G, Gh, inv = gf.gab_mod_ovlp(A[:, :na], B[:, :na])
+    close(inv, numpy.linalg.inv(numpy.dot(B[:, :na].T, A[:, :na].conj())))
+    As = numpy.array([A[:, :na], A[:, :na] + 0.1 * rng.rand(M, na), A[:, :na] + 0.2j * rng.rand(M, na)])
+    co = numpy.array([0.6 + 0.1j, 0.3, -0.2j])
+    Gi = numpy.array([ref.gab(a_, B[:, :na]).T for a_ in As])
+    ov = numpy.array([numpy.linalg.det(a_.conj().T.dot(B[:, :na])) for a_ in As])
+    close(gf.gab_multi_det(As, B[:, :na], co), numpy.einsum('i,ijk,i->jk', co, Gi, ov) / numpy.dot(co, ov))
+    gf.release()
