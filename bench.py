@@ -204,7 +204,7 @@ def main():
                          "flops_per_launch": dom["flops_per_launch"]},
             "roofline_all": rows,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(system, trial)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
