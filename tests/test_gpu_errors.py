@@ -1,0 +1,75 @@
+"""Error behaviour of the C ABI (status codes + afq_last_error text surfaced as AfqError): wrong call order,
+out-of-range arguments, unsupported configurations.  The reference raises Python exceptions / sys.exit at the
+same places ("conventions at this boundary")."""
+import numpy
+import pytest
+
+from pauxy_amd import _lib as L
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.device import AfqDevice
+from pauxy_amd.propagation import setup
+
+pytestmark = pytest.mark.gpu
+
+
+def small_generic():
+    s = systems.synthetic_generic(12, 10, (3, 3), seed=1)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, 0.01)
+    return s, t, BH1, mf
+
+
+def test_call_order_and_ranges():
+    s, t, BH1, mf = small_generic()
+    dev = AfqDevice(0)
+    with pytest.raises(L.AfqError) as e:                    # nothing set yet
+        dev.walkers_alloc(4)
+    assert e.value.code == -2
+    dev.set_system_generic(s.hs_pot, t._rchol, s.H1.astype(complex), 0.0, 3, 3)
+    dev.walkers_alloc(4)
+    with pytest.raises(L.AfqError) as e:                    # no trial, no propagator
+        dev.propagate(numpy.zeros((4, 10)), 0.0)
+    assert e.value.code == -2 and 'must be set' in str(e.value)
+    dev.set_trial(t.psi)
+    with pytest.raises(L.AfqError) as e:
+        dev.propagate(numpy.zeros((4, 10)), 0.0)
+    assert e.value.code == -2 and 'propagator' in str(e.value)
+    dev.set_propagator(BH1, mf, 0.01)
+    with pytest.raises(L.AfqError) as e:                    # walker range
+        dev.set(L.F_WEIGHT, numpy.ones(2), first=3)
+    assert e.value.code == -1
+    with pytest.raises(L.AfqError) as e:
+        dev.copy_walker(0, 9)
+    assert e.value.code == -1
+    with pytest.raises(L.AfqError) as e:                    # back-propagation not configured
+        dev.bp_update(t.psi, 5)
+    assert e.value.code == -2
+    with pytest.raises(L.AfqError) as e:                    # multi-determinant trial after the walkers exist
+        dev.set_trial_multi(numpy.array([t.psi, t.psi]), numpy.ones(2), numpy.concatenate([t._rchol, t._rchol]))
+    assert e.value.code == -2
+    with pytest.raises(L.AfqError) as e:                    # Hirsch transformation needs a Hubbard system
+        dev.set_propagator_hirsch(BH1, 0.01)
+    assert e.value.code == -2
+    # the handle is still usable after the errors
+    dev.set(L.F_PHI, numpy.array([t.psi] * 4))
+    dev.propagate(numpy.zeros((4, 10)), 0.0)
+    assert numpy.all(numpy.isfinite(dev.get(L.F_WEIGHT)))
+    dev.close()
+
+
+def test_unsupported_sizes():
+    s = systems.Hubbard(8, 8, 50, 50, 4.0)                  # N = 50 > 45
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    dev = AfqDevice(0)
+    dev.set_system_hubbard(s.T.astype(complex), 4.0, 50, 50)
+    dev.set_trial(t.psi)
+    dev.set_propagator_hirsch(numpy.array([numpy.eye(64), numpy.eye(64)], dtype=complex), 0.01)
+    dev.walkers_alloc(2)
+    dev.set(L.F_PHI, numpy.array([t.psi] * 2))
+    with pytest.raises(L.AfqError) as e:
+        dev.hirsch_kinetic()
+    assert e.value.code == -5 and 'N <= 45' in str(e.value)
+    with pytest.raises(L.AfqError) as e:                    # continuous step on a handle configured for Hirsch
+        dev.propagate(numpy.zeros((2, 64)), 0.0)
+    assert e.value.code == -2
+    dev.close()
