@@ -1262,7 +1262,8 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     double *s_detR = h->detR;
     const int s_flags = h->flags;
     cplx *tmp_ot = nullptr; double *tmp_detR = nullptr;
-    if ((rc = dev_alloc(h, &tmp_ot, n)) || (rc = dev_alloc(h, &tmp_detR, n))) return rc;
+    if ((rc = dev_alloc(h, &tmp_ot, n))) return rc;
+    if ((rc = dev_alloc(h, &tmp_detR, n))) { dev_free(tmp_ot); return rc; }
     h->phi = h->phi_bp; h->xs = h->bp_xs; h->BH1 = h->BH1dag; h->ot = tmp_ot; h->detR = tmp_detR;
     h->flags &= ~AFQ_PROP_FREE_PROJECTION;
     const bool fused = k_prop_fused_supported(h);

@@ -127,6 +127,15 @@ __global__ __launch_bounds__(256) void fullg_finish_kernel(const cplx *G, const 
     }
 }
 
+namespace {
+// scratch device buffer released on every exit path
+template <class T> struct Scratch {
+    T *p = nullptr;
+    ~Scratch() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, n * sizeof(T)); }
+};
+}  // namespace
+
 // G_dev [ng, 2, M, M] -> E_dev [ng, 3]
 int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
     const int M = h->M, K = h->K, Mp = (M + 1) & ~1;
@@ -141,11 +150,12 @@ int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
     // chunk of Cholesky vectors: T workspace <= ~1.5 GB
     const size_t per_n = (size_t)ng2 * M * M * sizeof(cplx);
     int nc = (int)std::max<size_t>(1, std::min<size_t>((size_t)K, ((size_t)3 << 29) / per_n));
-    cplx *T = nullptr, *part = nullptr, *X = nullptr, *exx = nullptr;
-    AFQ_HIP(h, hipMalloc(&T, per_n * nc));
-    AFQ_HIP(h, hipMalloc(&part, sizeof(cplx) * (size_t)ng2 * nc));
-    AFQ_HIP(h, hipMalloc(&X, sizeof(cplx) * (size_t)ng2 * K));
-    AFQ_HIP(h, hipMalloc(&exx, sizeof(cplx) * (size_t)ng2));
+    Scratch<cplx> sT, spart, sX, sexx;
+    AFQ_HIP(h, sT.alloc(per_n / sizeof(cplx) * nc));
+    AFQ_HIP(h, spart.alloc((size_t)ng2 * nc));
+    AFQ_HIP(h, sX.alloc((size_t)ng2 * K));
+    AFQ_HIP(h, sexx.alloc((size_t)ng2));
+    cplx *T = sT.p, *part = spart.p, *X = sX.p, *exx = sexx.p;
     AFQ_HIP(h, hipMemsetAsync(exx, 0, sizeof(cplx) * (size_t)ng2, h->stream));
     {
         const long nt = (long)ng2 * K;
@@ -170,7 +180,6 @@ int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
                            h->ecore);
         if (hipGetLastError() != hipSuccess) { h->err = "full-G energy launch failed"; rc = AFQ_EHIP; }
     }
-    hipStreamSynchronize(h->stream);
-    hipFree(T); hipFree(part); hipFree(X); hipFree(exx);
+    hipStreamSynchronize(h->stream);       // the scratch buffers are released on return
     return rc;
 }
