@@ -7,10 +7,10 @@ trials on a Generic system: same constructor signature and attributes (``tau_bp`
 FieldConfig), ``phi_old`` and the back-propagation itself live on the device
 (``afq_bp_configure`` / ``afq_bp_update``); one call handles the whole population.
 
-Output: instead of the reference's HDF5 groups (``back_propagated/one_rdm_<n>`` and
-``denominator_<n>``, estimators/utils.py:308-324) the per-window results are appended to
-``self.one_rdm`` / ``self.denominator`` / ``self.energies`` (lists; ``rdm()`` returns their ratio like
-pauxy.analysis.extraction.extract_rdm).
+Output: the per-window results are appended to ``self.one_rdm`` / ``self.denominator`` /
+``self.energies`` (lists; ``rdm()`` returns their ratio like pauxy.analysis.extraction.extract_rdm)
+and, when the container was given a file name, pushed by the root rank to the reference's
+groups ``back_propagated/{denominator,energies,one_rdm}_<n>/<block>`` (back_propagation.py:288-324).
 """
 import numpy
 
@@ -52,6 +52,10 @@ class BackPropagation(object):
         self.energies = []
         self.buff_ix = 0
         self._nsteps_seen = 0
+        self.flush_every = bp.get('flush_every', None)
+        self.output = None
+        if root and filename is not None:
+            self.setup_output(filename)
 
     def update(self, system, qmc, trial, psi, step, free_projection=False):
         """back_propagation.py:127-226 (update_uhf).  ``psi.walkers[0].field_configs.step`` of the
@@ -81,12 +85,21 @@ class BackPropagation(object):
         if comm.rank == 0:
             weight = self.global_estimates[self.nreg]
             self.denominator.append(numpy.array(weight))
+            out = self.output
+            if out is not None:
+                out.push(numpy.array([weight]), 'denominator_%d' % self.buff_ix)
             if self.eval_energy:                        # back_propagation.py:291-297
                 e = self.global_estimates[:self.nreg]
                 self.energies.append(e.copy() if free_projection else e / weight)
+                if out is not None:
+                    out.push(self.energies[-1], 'energies_%d' % self.buff_ix)
             if self.calc_one_rdm:
                 start = self.nreg + 1
                 self.one_rdm.append(self.global_estimates[start:start + self.G.size].reshape(self.G.shape).copy())
+                if out is not None:
+                    out.push(self.one_rdm[-1], 'one_rdm_%d' % self.buff_ix)
+            if out is not None and self.buff_ix == self.splits[-1]:
+                out.increment()
         self.accumulated = False
         self.zero()
 
@@ -99,4 +112,10 @@ class BackPropagation(object):
         self.global_estimates[:] = 0
 
     def setup_output(self, filename):
-        pass
+        """back_propagation.py:333-338."""
+        from pauxy_amd.estimators.utils import H5EstimatorHelper
+        from pauxy_amd.utils import io as _io
+        if self.eval_energy:
+            with _io.h5.File(filename, 'a') as fh5:
+                fh5['back_propagated/headers'] = numpy.array(self.header).astype('S')
+        self.output = H5EstimatorHelper(filename, 'back_propagated', flush_every=self.flush_every)

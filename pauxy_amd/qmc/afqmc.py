@@ -12,6 +12,7 @@ Two loops are provided:
                         replaced by one batched device call and no host round
                         trip inside a step except at population control.
 """
+import json
 import time
 
 import numpy
@@ -44,6 +45,36 @@ class AFQMC(object):
         self.psi = Walkers(system, trial, self.qmc, walker_opts=options.get('walkers', {}), comm=self.comm,
                            nprop_tot=self.estimators.nprop_tot, nbp=self.estimators.nbp)       # afqmc.py:177-182
         self.setup_timers()
+        if self.comm.rank == 0:                                                     # afqmc.py:192-195
+            self.estimators.json_string = self.to_json()
+            self.estimators.dump_metadata()
+
+    def to_json(self):
+        """Run description stored as ``metadata`` in the estimator file (utils/io.py:44-48 serialises
+        the whole driver object; here: the scalar options of every component)."""
+        def scalars(obj):
+            out = {}
+            for k, v in sorted(vars(obj).items()):
+                if k.startswith('_'):
+                    continue
+                if isinstance(v, (bool, int, float, str)) or v is None:
+                    out[k] = v
+                elif isinstance(v, (numpy.integer, numpy.floating)):
+                    out[k] = v.item()
+                elif isinstance(v, complex):
+                    out[k] = [v.real, v.imag]
+                elif isinstance(v, (tuple, list)) and all(isinstance(x, (int, float)) for x in v):
+                    out[k] = list(v)
+            return out
+        est = {'mixed': scalars(self.estimators.estimators['mixed'])}
+        if 'back_prop' in self.estimators.estimators:
+            est['back_prop'] = scalars(self.estimators.estimators['back_prop'])
+        doc = {'system': scalars(self.system), 'qmc': scalars(self.qmc), 'trial': scalars(self.trial),
+               'propagators': scalars(self.propagators),
+               'estimators': {'filename': self.estimators.filename, 'estimators': est,
+                              'nbp': self.estimators.nbp},
+               'nprocs': self.comm.size}
+        return json.dumps(doc, sort_keys=False, indent=4)
 
     def setup_timers(self):
         self.tortho = self.tprop = self.testim = self.tpopc = self.tstep = 0.0
@@ -84,6 +115,8 @@ class AFQMC(object):
             if on_step is not None:
                 on_step(step, self.psi)
             self.estimators.print_step(comm, comm.size, step)
+            if self.psi.write_restart and step % self.psi.write_freq == 0:       # afqmc.py:249-250
+                self.psi.write_walkers(comm)
             if step < self.qmc.neqlb:
                 eshift = mixed.get_shift(self.propagators.hybrid)
             else:
@@ -118,6 +151,8 @@ class AFQMC(object):
                 est = self.psi.dev.estimates_get(zero=True)
                 mixed.estimates[:ns.time] += est[:ns.time]
                 mixed.print_step(self.comm, self.comm.size, step)
+            if self.psi.write_restart and step % self.psi.write_freq == 0:
+                self.psi.write_walkers(self.comm)
             if step < self.qmc.neqlb:
                 eshift = mixed.get_shift(self.propagators.hybrid)
             else:
@@ -125,4 +160,5 @@ class AFQMC(object):
         return eshift
 
     def finalise(self, verbose=False):
-        pass
+        """afqmc.py:257-275 prints timings; here: write whatever estimator blocks are still queued."""
+        self.estimators.flush()

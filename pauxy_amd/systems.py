@@ -241,3 +241,38 @@ def synthetic_generic(M, K, nelec, seed=7):
     L = 0.5 * (A + A.transpose(0, 2, 1))
     chol = numpy.ascontiguousarray(L.reshape(K, M * M).T)
     return Generic(nelec, numpy.array([h1, h1]), chol, ecore=0.0)
+
+
+def get_generic_integrals(filename):
+    """-> (h1e [2,M,M], chol [M*M,K], h1e_mod [2,M,M], ecore) from a QMCPACK-style HDF5 Hamiltonian
+    (pauxy/systems/utils.py:62-124 without the MPI shared-memory window: every rank = one GPU keeps
+    its own copy on the device anyway)."""
+    from pauxy_amd.utils.io import read_integrals
+    hcore, chol, ecore = read_integrals(filename)
+    h1e = numpy.array([hcore, hcore])
+    M = hcore.shape[-1]
+    c3 = numpy.asarray(chol).reshape((M, M, -1))
+    v0 = 0.5 * numpy.einsum('ikn,jkn->ij', c3, c3, optimize=True)       # systems/generic.py:202-210
+    return h1e, chol, numpy.array([h1e[0] - v0, h1e[1] - v0]), ecore
+
+
+def get_system(sys_opts):
+    """Option-driven constructor (pauxy/systems/utils.py:9-60) for the three systems on the device path."""
+    name = sys_opts['name']
+    if name == 'Generic':
+        filename = sys_opts.get('integrals')
+        if filename is None:
+            raise ValueError("Generic system: 'integrals' file not specified")
+        nup, ndown = sys_opts.get('nup'), sys_opts.get('ndown')
+        if nup is None or ndown is None:
+            raise ValueError("Generic system: number of electrons not specified")
+        h1e, chol, h1e_mod, ecore = get_generic_integrals(filename)
+        if numpy.iscomplexobj(chol) and numpy.abs(numpy.imag(chol)).max() == 0.0:
+            chol = numpy.ascontiguousarray(numpy.real(chol))
+        return Generic((nup, ndown), h1e, chol, ecore, h1e_mod=h1e_mod)
+    if name == 'Hubbard':
+        return Hubbard(sys_opts['nx'], sys_opts['ny'], sys_opts['nup'], sys_opts['ndown'], sys_opts['U'],
+                       t=sys_opts.get('t', 1.0))
+    if name == 'UEG':
+        return UEG(sys_opts['rs'], sys_opts['nup'], sys_opts['ndown'], sys_opts['ecut'])
+    raise ValueError("unrecognized system name {}".format(name))

@@ -238,3 +238,33 @@ def uhf_trial_hubbard(system, ueff=0.4, nit_max=5000, alpha=0.5, deps=1e-8):
         niup = (1 - alpha) * nu + alpha * niup
         nidn = (1 - alpha) * nd + alpha * nidn
     return SingleDetTrial(system, psi, name="UHF")
+
+
+def get_trial_wavefunction(system, options=None, verbose=False):
+    """File-driven constructor for the ``MultiSlater`` family
+    (pauxy/trial_wavefunction/utils.py:33-82): ``options['filename']`` (alias
+    ``wavefunction_file``) names a QMCPACK-style HDF5 wavefunction (NOMSD or PHMSD,
+    pauxy_amd/utils/io.py); ``ndets`` keeps the leading determinants, ``threshold`` the
+    leading ones with |c| above it.  Without a file: the identity-orbital RHF guess of :63-73."""
+    from pauxy_amd.utils.io import read_qmcpack_wfn_hdf
+    options = options or {}
+    wfn_file = options.get('filename', options.get('wavefunction_file'))
+    na, nb, M = system.nup, system.ndown, system.nbasis
+    if wfn_file is None:
+        psi = numpy.zeros((M, na + nb), dtype=numpy.complex128)
+        eye = numpy.identity(M, dtype=numpy.complex128)
+        psi[:, :na] = eye[:, :na]
+        psi[:, na:] = eye[:, :nb]
+        return SingleDetTrial(system, psi)
+    read, psi0 = read_qmcpack_wfn_hdf(wfn_file)
+    thresh = options.get('threshold')
+    if thresh is not None:
+        ndets = int(numpy.sum(numpy.abs(read[0]) > thresh))
+    else:
+        ndets = options.get('ndets') or len(read[0])
+    wfn = tuple(x[:ndets] for x in read)
+    if verbose:
+        print("# Number of determinants in trial wavefunction: {}".format(ndets))
+    if ndets == 1 and len(wfn) == 2:
+        return SingleDetTrial(system, wfn[1][0], init=psi0)
+    return MultiDetTrial(system, wfn, init=psi0)

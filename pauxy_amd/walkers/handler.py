@@ -15,9 +15,12 @@ batched launch and flushed back before the next one if the driver wrote to it.
 """
 import sys
 
+import time
+
 import numpy
 
 from pauxy_amd import _lib as L
+from pauxy_amd.utils import io as _io
 from pauxy_amd.context import get_context, trial_psi
 
 _SCALARS = {
@@ -172,9 +175,8 @@ class Walkers(object):
         self.write_file = walker_opts.get('write_file', 'restart.h5')
         self.use_log_shift = walker_opts.get('use_log_shift', False)
         self.read_file = walker_opts.get('read_file', None)
-        self.write_restart = False
-        if self.write_freq > 0 or self.read_file is not None:
-            raise NotImplementedError("HDF5 walker restart files are outside the device hot path")
+        self.write_restart = self.write_freq > 0
+        self.comm = comm
         if self.use_log_shift:
             raise NotImplementedError("use_log_shift is not supported")
         if nbp is not None and nprop_tot is not None and nprop_tot != nbp:
@@ -225,6 +227,14 @@ class Walkers(object):
         # E_L of the initial walkers (single_det.py:86-92) is evaluated lazily on request
         self.buff_size = init.size + 7
         self.walker_buffer = numpy.zeros(self.buff_size, dtype=numpy.complex128)
+        # restart files (walkers/handler.py:146-161): one dataset walker_<global index> = [weight, phase, ot, phi]
+        rank = 0 if comm is None else comm.rank
+        if self.write_restart and rank == 0:
+            with _io.h5.File(self.write_file, 'w') as fh5:
+                for i in range(self.ntot_walkers):
+                    fh5.create_dataset('walker_%d' % i, (3 + init.size,), dtype=numpy.complex128)
+        if self.read_file is not None:
+            self.read_walkers(comm)
 
     # ------------------------------------------------------------ mirrors
     def _mirror(self, name):
@@ -302,8 +312,73 @@ class Walkers(object):
     def add_field_config(self, *a, **k):
         raise NotImplementedError("back propagation is not on the device path yet")
 
+    def get_write_buffers(self):
+        """[nw, 3 + M*(Na+Nb)] rows of (weight, phase, ot, phi) -- walkers/handler.py:432-435, batched."""
+        self._end_sweep()
+        self._flush()
+        phi = self.dev.get(L.F_PHI).reshape(self.nw, -1)
+        buf = numpy.empty((self.nw, 3 + phi.shape[1]), dtype=numpy.complex128)
+        buf[:, 0] = self.dev.get(L.F_WEIGHT)
+        buf[:, 1] = self.dev.get(L.F_PHASE)
+        buf[:, 2] = self.dev.get(L.F_OT)
+        buf[:, 3:] = phi
+        return buf
+
+    def get_write_buffer(self, i):
+        return self.get_write_buffers()[i]
+
     def write_walkers(self, comm):
-        raise NotImplementedError("HDF5 walker restart files are outside the device hot path")
+        """walkers/handler.py:444-455.  The reference writes through parallel HDF5 (driver='mpio'); here
+        the ranks' rows are all-gathered (a few MB, once per ``write_freq`` steps) and rank 0 writes."""
+        start = time.time()
+        mine = self.get_write_buffers()
+        size = 1 if comm is None else comm.size
+        rank = 0 if comm is None else comm.rank
+        if size > 1:
+            everything = numpy.zeros((size,) + mine.shape, dtype=numpy.complex128)
+            comm.Allgather(mine, everything)
+            everything = everything.reshape((-1, mine.shape[1]))
+        else:
+            everything = mine
+        if rank == 0:
+            with _io.h5.File(self.write_file, 'r+') as fh5:
+                for ix in range(everything.shape[0]):
+                    fh5['walker_%d' % ix][:] = everything[ix]
+            print(" # Writing walkers to file.")
+            print(" # Time to write restart: {:13.8e} s".format(time.time() - start))
+
+    def set_walkers_from_buffers(self, first, rows):
+        """Rows of (weight, phase, ot, phi) into walkers first.. -- walkers/handler.py:437-442, batched."""
+        rows = numpy.asarray(rows, dtype=numpy.complex128)
+        n = rows.shape[0]
+        if n == 0:
+            return
+        self._flush()
+        M, nt = self.dev.M, self.dev.na + self.dev.nb
+        self.dev.set(L.F_PHI, numpy.ascontiguousarray(rows[:, 3:]).reshape(n, M, nt), first)
+        self.dev.set(L.F_WEIGHT, numpy.ascontiguousarray(rows[:, 0].real), first)
+        self.dev.set(L.F_PHASE, numpy.ascontiguousarray(rows[:, 1]), first)
+        self.dev.set(L.F_OT, numpy.ascontiguousarray(rows[:, 2]), first)
+        self.phi_version += 1
+        self._invalidate()
+
+    def read_walkers(self, comm):
+        """walkers/handler.py:477-485: walker i of this rank is dataset walker_<i + nw*rank>; walkers the
+        file does not hold keep their initial state (the reference prints the same warning)."""
+        rank = 0 if comm is None else comm.rank
+        with _io.h5.File(self.read_file, 'r') as fh5:
+            run_first, run = 0, []
+            for i in range(self.nw):
+                name = 'walker_%d' % (i + self.nw * rank)
+                if name in fh5:
+                    if not run:
+                        run_first = i
+                    run.append(fh5[name][:])
+                else:
+                    print(" # Could not read walker data from: %s" % self.read_file)
+                    self.set_walkers_from_buffers(run_first, run)
+                    run = []
+            self.set_walkers_from_buffers(run_first, run)
 
     def recompute_greens_function(self, trial, time_slice=None):
         self._greens_version = -1

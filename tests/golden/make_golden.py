@@ -29,24 +29,53 @@ REF = "/root/reference/pauxy"
 H5PY_STUB = '''
 import numpy
 _STORE = {}
-class _Grp(dict):
+def _norm(p):
+    return '/'.join(x for x in p.split('/') if x)
+class Group(object):
+    # path-prefix view of one in-memory "file" (a flat dict: dataset path -> array, group path -> None)
+    def __init__(self, d, prefix):
+        self.d = d
+        self.prefix = prefix
+    def _key(self, k):
+        return _norm(self.prefix + '/' + k)
+    def __setitem__(self, k, v):
+        self.d[self._key(k)] = numpy.array(v)
+    def __getitem__(self, k):
+        key = self._key(k)
+        if self.d.get(key) is not None:
+            return self.d[key]
+        if key in self.d or any(x.startswith(key + '/') for x in self.d):
+            return Group(self.d, key)
+        raise KeyError(key)
+    def __contains__(self, k):
+        try:
+            self[k]
+            return True
+        except KeyError:
+            return False
+    def __delitem__(self, k):
+        key = self._key(k)
+        for x in [x for x in self.d if x == key or x.startswith(key + '/')]:
+            del self.d[x]
+    def create_group(self, k):
+        key = self._key(k)
+        if key in self.d or any(x.startswith(key + '/') for x in self.d):
+            raise ValueError('name already exists')
+        self.d[key] = None
+        return Group(self.d, key)
     def create_dataset(self, name, shape=None, dtype=None, data=None):
         if data is None:
             data = numpy.zeros(shape, dtype=dtype)
-        self[name] = numpy.array(data)
+        self[name] = data
         return self[name]
-class File(object):
+class File(Group):
     def __init__(self, name, mode='r', **kw):
-        self.name = name
         if mode == 'w':
-            _STORE[name] = _Grp()
-        self.d = _STORE.setdefault(name, _Grp())
+            _STORE[name] = {}
+        Group.__init__(self, _STORE.setdefault(name, {}), '')
+        self.name = name
     def __enter__(self): return self
     def __exit__(self, *a): return False
-    def __setitem__(self, k, v): self.d[k] = numpy.array(v)
-    def __getitem__(self, k): return self.d[k]
-    def __contains__(self, k): return k in self.d
-    def create_dataset(self, *a, **k): return self.d.create_dataset(*a, **k)
     def close(self): pass
 '''
 MPI_STUB = '''
@@ -774,7 +803,69 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     numpy.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def make_io():
+    """On-disk formats: what the reference's writers put under each dataset name (captured
+    through the in-memory h5py stand-in) and what its readers return, for small random inputs."""
+    from pauxy.utils import io as rio
+    out = {}
+    rng = numpy.random.RandomState(7)
+    M, K, nelec = 5, 7, (2, 2)
+    h = rng.rand(M, M)
+    h = 0.5 * (h + h.T)
+    L = rng.rand(K, M, M) - 0.5
+    L = 0.5 * (L + L.transpose(0, 2, 1))
+    L[abs(L) < 0.15] = 0.0
+    chol = L.reshape(K, M * M).T.copy()
+    a = rng.rand(M, M)
+    hc = h + 1j * 0.3 * (a - a.T)
+    cholc = chol * (1.0 + 0.0j) + 1j * 0.1 * chol[::-1]
+    X = rng.rand(M, M)
+    out.update(h=h, chol=chol, hc=hc, cholc=cholc, X=X, nelec=numpy.array(nelec), enuc=1.25)
+    rio.write_qmcpack_dense(h, chol, nelec, M, enuc=1.25, filename='dense_real.h5', real_chol=True)
+    rio.write_qmcpack_dense(hc, cholc, nelec, M, enuc=1.25, filename='dense_cplx.h5', real_chol=False, ortho=X)
+    rio.write_qmcpack_sparse(hc, cholc, nelec, M, enuc=1.25, filename='sparse_cplx.h5', real_chol=False)
+    rio.write_qmcpack_sparse(h, chol, nelec, M, enuc=1.25, filename='sparse_real.h5', real_chol=True)
+    for f in ('dense_real.h5', 'dense_cplx.h5'):
+        r = rio.from_qmcpack_dense(f)
+        out[f + '|read|hcore'], out[f + '|read|chol'] = numpy.array(r[0]), numpy.array(r[1])
+        out[f + '|read|scalars'] = numpy.array([r[2], r[3], r[4], r[5]], dtype=float)
+    for f in ('sparse_real.h5', 'sparse_cplx.h5'):
+        r = rio.from_qmcpack_sparse(f)
+        out[f + '|read|hcore'], out[f + '|read|chol'] = numpy.array(r[0]), r[1].toarray()
+        out[f + '|read|scalars'] = numpy.array([r[2], r[3], r[4], r[5]], dtype=float)
+    # wavefunctions
+    na, nb = nelec
+    coeffs = rng.rand(3) + 1j * rng.rand(3)
+    dets = rng.rand(3, M, na + nb) + 1j * rng.rand(3, M, na + nb)
+    dets[abs(dets.real) < 0.2] = 0.0
+    init = [rng.rand(M, na) + 1j * rng.rand(M, na), rng.rand(M, nb) + 1j * rng.rand(M, nb)]
+    occa = numpy.array([[0, 1], [0, 2], [1, 3]])
+    occb = numpy.array([[0, 1], [1, 2], [0, 4]])
+    out.update(coeffs=coeffs, dets=dets, init_a=init[0], init_b=init[1], occa=occa, occb=occb)
+    rio.write_qmcpack_wfn('nomsd_uhf.h5', (coeffs.copy(), dets.copy()), 'uhf', nelec, M)
+    rio.write_qmcpack_wfn('nomsd_rhf.h5', (coeffs.copy(), dets.copy()), 'rhf', nelec, M)
+    rio.write_qmcpack_wfn('nomsd_init.h5', (coeffs.copy(), dets.copy()), 'uhf', nelec, M, init=init)
+    rio.write_qmcpack_wfn('phmsd.h5', (coeffs.copy(), occa, occb), 'uhf', nelec, M)
+    rio.write_qmcpack_wfn('phmsd_init.h5', (coeffs.copy(), occa, occb), 'uhf', nelec, M, init=init)
+    for f in ('nomsd_uhf.h5', 'nomsd_rhf.h5', 'nomsd_init.h5', 'phmsd.h5', 'phmsd_init.h5'):
+        wfn, psi0 = rio.read_qmcpack_wfn_hdf(f)
+        for i, x in enumerate(wfn):
+            out[f + '|read|wfn%d' % i] = numpy.array(x)
+        out[f + '|read|psi0'] = psi0
+    for fname, store in h5py._STORE.items():
+        if not fname.endswith('.h5') or '|' in fname:
+            continue
+        for path, arr in store.items():
+            if arr is not None:
+                out[fname + '|' + path] = arr
+    numpy.savez_compressed(os.path.join(HERE, 'io_formats.npz'), **out)
+    print('io_formats.npz: %d arrays' % len(out))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'io':
+        make_io()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hirsch':
         make_traj_hirsch(pin=-152.68468568462666)
         make_traj_hirsch('traj_hubbard_hirsch_charge.npz', charge=True, blocks=4)
