@@ -9,18 +9,24 @@
 //   * the left operands (BH1[0], BH1[1], VHS[w] x order, BH1[0], BH1[1]) stream through a
 //     3-slot LDS ring as ONE continuous sequence of k-chunks filled by global_load_lds
 //     (A-fragment order), so the pipeline never drains between products
-//   * complex products use the 3-multiplication form (see mfma_gemm_wg.h)
+//   * complex products use the 3-multiplication form (see mfma_gemm_wg.h); when BH1 has no imaginary part
+//     (real trial and real Cholesky vectors: the usual case) the four one-body products need only the two
+//     real-by-complex multiplications
 // One raw s_barrier per k-chunk; two more per product to hand the result back into T.
 // Replaces 2 x 2 one-body launches + order Taylor launches + 3 copy kernels + the
 // phi ping-pong buffers of the unfused path; dead walkers (qmc/afqmc.py:232) are skipped
 // in place.
 // Limits: M <= 104 (13 chunks of T = 104 KB of LDS), na, nb <= 32, one VHS matrix per walker.
+#include <cstdlib>
+#include <type_traits>
+
 #include "mfma_gemm_wg.h"
 
 #define PF_D 3
 
 struct PropFusedArgs {
     int M, na, nb, nt, order;
+    int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
     const cplx *BH1;            // [2, M, M]
     const cplx *vhs;            // [nw, M, M]
     cplx *phi;                  // [nw, M, nt], updated in place
@@ -105,7 +111,8 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
 
     // ------------------------------------------------------------------ one-body product
     // wave v owns row tile v and the (up to) two column tiles of spin s
-    auto one_body = [&](int s, bool to_global) {
+    auto one_body = [&](int s, bool to_global, auto real_tag) {
+        constexpr bool BR = decltype(real_tag)::value;
         d4_t P1[2], P2[2], P3[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0}; }
@@ -128,9 +135,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     if (j < ncs) {
-                        P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
-                        P2[j] = mfma16(av[ss][1], bv[j][ss][1], P2[j]);
-                        P3[j] = mfma16(av[ss][0] + av[ss][1], bv[j][ss][0] + bv[j][ss][1], P3[j]);
+                        if (BR) {
+                            P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
+                            P2[j] = mfma16(av[ss][0], bv[j][ss][1], P2[j]);
+                        } else {
+                            P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
+                            P2[j] = mfma16(av[ss][1], bv[j][ss][1], P2[j]);
+                            P3[j] = mfma16(av[ss][0] + av[ss][1], bv[j][ss][0] + bv[j][ss][1], P3[j]);
+                        }
                     }
         }
         __builtin_amdgcn_s_barrier();                            // everyone finished reading T(spin s)
@@ -139,7 +151,8 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             if (j < ncs) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double re = P1[j][r] - P2[j][r], im = P3[j][r] - P1[j][r] - P2[j][r];
+                    const double re = BR ? P1[j][r] : P1[j][r] - P2[j][r];
+                    const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
                         const int row = wave * 16 + lk + 4 * r, col = j * 16 + lr;
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             }
     };
 
-    one_body(0, false);
-    one_body(1, false);
+    if (a.b_real) { one_body(0, false, std::true_type{}); one_body(1, false, std::true_type{}); }
+    else { one_body(0, false, std::false_type{}); one_body(1, false, std::false_type{}); }
     __syncthreads();                                             // T = B phi complete
 
     // ------------------------------------------------------------------ Taylor series
@@ -239,8 +252,8 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     }
     if (a.order == 0) __syncthreads();
 
-    one_body(0, true);
-    one_body(1, true);
+    if (a.b_real) { one_body(0, true, std::true_type{}); one_body(1, true, std::true_type{}); }
+    else { one_body(0, true, std::false_type{}); one_body(1, true, std::false_type{}); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -251,6 +264,7 @@ int k_prop_fused_supported(afq_handle *h) {
 int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
+    a.b_real = (h->bh1_real && !getenv("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
