@@ -65,6 +65,8 @@ class AFQMC(object):
                     out[k] = [v.real, v.imag]
                 elif isinstance(v, (tuple, list)) and all(isinstance(x, (int, float)) for x in v):
                     out[k] = list(v)
+                elif isinstance(v, numpy.ndarray) and v.size <= 64 and v.dtype.kind in 'iuf':
+                    out[k] = [v.tolist()]                       # utils/misc.py serialise() nests arrays this way
             return out
         est = {'mixed': scalars(self.estimators.estimators['mixed'])}
         if 'back_prop' in self.estimators.estimators:

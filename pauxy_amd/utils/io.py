@@ -325,3 +325,52 @@ def write_qmcpack_wfn(filename, wfn, walker_type, nelec, norb, init=None, mode='
             write_phmsd(group, occa, occb, nelec, norb, init=init)
         group['ci_coeffs'] = to_qmcpack_complex(coeffs)
         group['dims'] = numpy.array([norb, nelec[0], nelec[1], wtype, len(coeffs)], dtype=numpy.int32)
+
+
+# ------------------------------------------------------- estimator file readers
+def get_param(filename, path):
+    """Entry of the ``metadata`` JSON of an estimator file (pauxy/analysis/extraction.py:86-95)."""
+    import json
+    with h5.File(filename, 'r') as fh5:
+        doc = json.loads(fh5['metadata'][()])
+    for key in path:
+        doc = doc[key]
+    return doc
+
+
+def extract_data(filename, group, estimator, raw=False):
+    """Blocks of one estimator (pauxy/analysis/extraction.py:14-28) without pandas: ``raw`` or an ``*rdm*``
+    estimator -> array [nblocks, ...]; otherwise a dict {header name: column [nblocks]} with the real parts
+    (complex columns for a free-projection run, as in the reference)."""
+    try:
+        fp = bool(get_param(filename, ['propagators', 'free_projection']))
+    except KeyError:
+        fp = False
+    with h5.File(filename, 'r') as fh5:
+        names = sorted(fh5[group][estimator].keys())
+        data = numpy.array([fh5[group][estimator][d][:] for d in names])
+        if 'rdm' in estimator or raw:
+            return data
+        header = [x.decode('utf-8') for x in fh5[group]['headers'][:]]
+    if not fp:
+        data = numpy.real(data)
+    return {name: data[:, i] for i, name in enumerate(header)}
+
+
+def extract_mixed_estimates(filename, skip=0):
+    """analysis/extraction.py:30-31."""
+    return {k: v[skip:] for k, v in extract_data(filename, 'basic', 'energies').items()}
+
+
+def extract_bp_estimates(filename, skip=0):
+    """analysis/extraction.py:33-34."""
+    return {k: v[skip:] for k, v in extract_data(filename, 'back_propagated', 'energies').items()}
+
+
+def extract_rdm(filename, est_type='back_propagated', rdm_type='one_rdm', ix=None):
+    """Back-propagated density matrices divided by their denominators (analysis/extraction.py:36-62)."""
+    if ix is None:
+        ix = get_param(filename, ['estimators', 'estimators', 'back_prop', 'splits'])[0][-1]
+    one_rdm = extract_data(filename, est_type, '%s_%d' % (rdm_type, ix), raw=True)
+    denom = extract_data(filename, est_type, 'denominator_%d' % ix, raw=True)
+    return one_rdm / denom.reshape((-1,) + (1,) * (one_rdm.ndim - 1))

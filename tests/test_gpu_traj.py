@@ -11,6 +11,7 @@ import pytest
 from pauxy_amd import systems, trial as trial_mod
 from pauxy_amd.context import release_context
 from pauxy_amd.qmc.afqmc import AFQMC
+from pauxy_amd.utils.io import extract_mixed_estimates, extract_rdm
 from tests.helpers import ragged
 
 pytestmark = pytest.mark.gpu
@@ -87,28 +88,37 @@ def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None):
     assert afqmc.propagators.nfb_trig == int(d['nfb_trig'])
     assert afqmc.propagators.nhe_trig == int(d['nhe_trig'])
     est = mixed.estimates.copy()
+    afqmc.finalise()
     if out is not None:
         out['afqmc'] = afqmc
     release_context(system, trial)
     return est
 
 
-def test_traj_generic(golden, monkeypatch):
+def mean_etotal(filename):
+    """numpy.mean(extract_mixed_estimates('estimates.0.h5').ETotal.values[:-1]) of qmc/tests/test_afqmc.py."""
+    return numpy.mean(extract_mixed_estimates(filename)['ETotal'][:-1])
+
+
+def test_traj_generic(golden, monkeypatch, tmp_path):
     d = golden('traj_generic.npz')
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
     t = trial_mod.SingleDetTrial(s, d['psi'])
-    est = replay(d, s, t, {}, monkeypatch)
+    est = replay(d, s, t, {}, monkeypatch, est_extra={'basename': str(tmp_path / 'estimates')})
     assert est[2].real == pytest.approx(3.8763193646854273, rel=1e-8)        # qmc/tests/test_afqmc.py:227
+    assert mean_etotal(str(tmp_path / 'estimates.0.h5')) == pytest.approx(1.5485077038208, rel=1e-8)   # :229
 
 
-def test_traj_hubbard(golden, monkeypatch):
+def test_traj_hubbard(golden, monkeypatch, tmp_path):
     d = golden('traj_hubbard.npz')
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
     t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
-    est = replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch)
+    est = replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch,
+                 est_extra={'basename': str(tmp_path / 'estimates')})
     assert est[2].real == pytest.approx(-152.91937839611, rel=1e-8)          # qmc/tests/test_afqmc.py:186
+    assert mean_etotal(str(tmp_path / 'estimates.0.h5')) == pytest.approx(-15.14323385684513, rel=1e-8)   # :188
 
 
 def test_traj_hubbard_c1(golden, monkeypatch):
@@ -154,7 +164,7 @@ def test_traj_msd(golden, monkeypatch):
     replay(d, s, t, {}, monkeypatch)
 
 
-def run_bp(golden, monkeypatch, name, restore):
+def run_bp(golden, monkeypatch, name, restore, tmp_path=None):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
@@ -163,17 +173,23 @@ def run_bp(golden, monkeypatch, name, restore):
     if restore is not None:
         bp['restore_weights'] = restore
     out = {}
-    replay(d, s, t, {}, monkeypatch, est_extra={'back_propagated': bp}, out=out)
+    extra = {'back_propagated': bp}
+    if tmp_path is not None:
+        extra['basename'] = str(tmp_path / 'estimates')
+    replay(d, s, t, {}, monkeypatch, est_extra=extra, out=out)
     est = out['afqmc'].estimators.estimators['back_prop']
     close(numpy.array(est.denominator), d['bp_denominator'])
     close(numpy.array(est.one_rdm), d['bp_one_rdm'])
+    if tmp_path is not None:
+        # extract_rdm('estimates.0.h5') of qmc/tests/test_afqmc.py:276 reads the same numbers back from the file
+        assert numpy.array_equal(extract_rdm(str(tmp_path / 'estimates.0.h5')), est.rdm())
     return est.rdm()
 
 
-def test_traj_back_propagation(golden, monkeypatch):
+def test_traj_back_propagation(golden, monkeypatch, tmp_path):
     """SURVEY 8f-2, qmc/tests/test_afqmc.py:232-278: back-propagated one-body RDM (5-step window) next to the
     mixed estimator, comb every step; every window's RDM and the pinned element."""
-    rdm = run_bp(golden, monkeypatch, 'traj_bp.npz', None)
+    rdm = run_bp(golden, monkeypatch, 'traj_bp.npz', None, tmp_path)
     assert rdm[0, 0].trace() == pytest.approx(3.0, rel=1e-9)
     assert rdm[11, 0, 1, 3].real == pytest.approx(-0.121883381144845, rel=1e-7)
 
@@ -182,7 +198,7 @@ def test_traj_back_propagation_restored_weights(golden, monkeypatch):
     run_bp(golden, monkeypatch, 'traj_bp_full.npz', 'full')
 
 
-def run_hirsch(golden, monkeypatch, name):
+def run_hirsch(golden, monkeypatch, name, basename=None):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -195,6 +211,8 @@ def run_hirsch(golden, monkeypatch, name):
                        'num_walkers': d['phi0'].shape[0]},
                'propagator': prop,
                'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
+    if basename is not None:
+        options['estimators']['basename'] = basename
     afqmc = AFQMC(options=options, system=s, trial=t)
     close(afqmc.propagators.bt2, d['bt2'], 1e-12)
     stream = iter(d['u'])
@@ -218,14 +236,16 @@ def run_hirsch(golden, monkeypatch, name):
     mixed.update(s, afqmc.qmc, t, afqmc.psi, 0, False)
     close(mixed.estimates[:9], d['final_estimates'][:9])
     est = mixed.estimates.copy()
+    afqmc.finalise()
     release_context(s, t)
     return est
 
 
-def test_traj_hubbard_hirsch(golden, monkeypatch):
+def test_traj_hubbard_hirsch(golden, monkeypatch, tmp_path):
     """SURVEY 8f-4, qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS, single-site updates."""
-    est = run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch.npz')
+    est = run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch.npz', str(tmp_path / 'estimates'))
     assert est[2].real == pytest.approx(-152.68468568462666, rel=1e-8)
+    assert mean_etotal(str(tmp_path / 'estimates.0.h5')) == pytest.approx(-14.974806533852874, rel=1e-8)   # :143
 
 
 def test_traj_hubbard_hirsch_charge(golden, monkeypatch):

@@ -131,7 +131,7 @@ def run_traj(d, model, **kw):
     return walkers, rec, blocks
 
 
-def check_traj(d, model, tol=1e-8, **kw):
+def check_traj(d, model, tol=1e-8, mean_etotal=None, **kw):
     walkers, rec, blocks = run_traj(d, model, **kw)
     fp = kw.get('free_projection', False)
     if 'phase' in d:
@@ -147,6 +147,9 @@ def check_traj(d, model, tol=1e-8, **kw):
     B = numpy.array(blocks)
     gold = d['blocks']                      # [nblocks+1, 1 + 10]: step, estimates
     close(B[:, :9], gold[:, 1:10], tol)
+    if mean_etotal is not None:
+        # numpy.mean(extract_mixed_estimates('estimates.0.h5').ETotal.values[:-1]), qmc/tests/test_afqmc.py:188,229
+        assert numpy.mean(B[:-1, 4].real) == pytest.approx(mean_etotal, rel=1e-9)
     close(numpy.array([w['phi'] for w in walkers]), d['final_phi'], tol)
     # final estimator pass pinned by the reference's driver tests
     est = numpy.zeros(10, dtype=numpy.complex128)
@@ -157,14 +160,14 @@ def check_traj(d, model, tol=1e-8, **kw):
 
 def test_traj_generic(golden):
     d = golden('traj_generic.npz')
-    est = check_traj(d, generic_model(d, ''))
+    est = check_traj(d, generic_model(d, ''), mean_etotal=1.5485077038208)
     # qmc/tests/test_afqmc.py:227
     assert est[ref.EST['enumer']].real == pytest.approx(3.8763193646854273, rel=1e-9)
 
 
 def test_traj_hubbard(golden):
     d = golden('traj_hubbard.npz')
-    est = check_traj(d, hubbard_model(d, '', 'hubbard'))
+    est = check_traj(d, hubbard_model(d, '', 'hubbard'), mean_etotal=-15.14323385684513)
     # qmc/tests/test_afqmc.py:186
     assert est[ref.EST['enumer']].real == pytest.approx(-152.91937839611, rel=1e-9)
 

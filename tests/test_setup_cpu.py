@@ -106,3 +106,15 @@ def test_multi_determinant_mean_field_shift(golden):
     BH1, mf = setup.generic_propagator_arrays(s, t, 0.005)
     assert numpy.max(numpy.abs(mf - d['N_mf_shift'])) < 1e-13
     assert numpy.max(numpy.abs(BH1 - d['N_BH1'])) < 1e-13
+
+
+def test_uhf_trial_reaches_the_reference_minimum():
+    """trial_wavefunction/tests/test_uhf.py:8-19: the UHF energy (with U -> ueff) the reference's ten random
+    SCF starts settle on; the deterministic staggered start used here converges to the same minimum."""
+    s = systems.Hubbard(4, 4, 8, 8, 4.0)
+    for ueff, emin in ((0.4, -22.638405458100653), (4.0, -12.56655451978628)):
+        psi = trial_mod.uhf_trial_hubbard(s, ueff=ueff).psi
+        Ga = psi[:, :8] @ psi[:, :8].conj().T
+        Gb = psi[:, 8:] @ psi[:, 8:].conj().T
+        e = (s.T[0] * Ga.T).sum() + (s.T[1] * Gb.T).sum() + ueff * (numpy.diag(Ga) * numpy.diag(Gb)).sum()
+        assert e.real == pytest.approx(emin)              # pytest.approx default (1e-6), as in the reference
