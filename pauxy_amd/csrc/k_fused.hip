@@ -5,7 +5,7 @@
 // matrix never leaves the CU between the 2 + order + 2 matrix products:
 //   * T (the current right-hand operand, M x (na+nb) complex) lives in LDS in
 //     MFMA B-fragment order: [k-chunk of 8][column-tile slot a0 a1 b0 b1][sub-step][64 lanes x 16 B]
-//   * the running Taylor sum lives in registers (each wave owns 2 x 2 tiles)
+//   * the running Taylor sum lives in registers (waves 0-3 own 2 x 2 tiles, waves 4-7 own 3 x 1: 7 per SIMD)
 //   * the left operands (BH1[0], BH1[1], VHS[w] x order, BH1[0], BH1[1]) stream through a
 //     3-slot LDS ring as ONE continuous sequence of k-chunks filled by global_load_lds
 //     (A-fragment order), so the pipeline never drains between products
@@ -36,6 +36,14 @@ struct PropFusedArgs {
 
 __device__ inline d2_t lds_read_c(unsigned addr) { return lds_read_b128(addr); }
 
+// Work-group barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every
+// operand chunk still in flight in the DMA ring -- a full pipeline drain at each product boundary.
+__device__ inline void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = blockIdx.x;
@@ -44,6 +52,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     const int lr = lane & 15, lk = lane >> 4;
     const int M = a.M, nt = a.nt;
     const int NCH = (M + 7) >> 3;
+    const int nrt = (M + 15) >> 4;                               // row tiles that exist
     // ---- LDS carve
     unsigned char *Tf = smem;                                   // [NCH][4][2][1024]
     unsigned char *ring = smem + (size_t)NCH * 8192;            // [PF_D][8 row tiles][2][1024]
@@ -90,10 +99,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
 
     // accumulator-layout address of element (row tile ti, reg r) of column slot cs for this lane
     auto t_ok = [&](int ti, int r) -> bool { return 2 * ti + (r >> 1) < NCH; };   // rows past the last chunk do not exist
+    // = lane part + wave-uniform tile part + small immediates in r.  The lane part is laundered through an empty
+    // asm at every use: otherwise the compiler keeps one address register per tile alive across the whole MFMA
+    // loop, spills them, and the reload's s_waitcnt vmcnt(0) drains the operand DMA ring once per product.
+    const unsigned t_lane = (unsigned)((lk & 1) * 1024 + ((lk >> 1) * 16 + lr) * 16);
     auto t_addr = [&](int ti, int r, int cs) -> unsigned {
-        const int c = 2 * ti + (r >> 1);
-        const int g = (lk >> 1) + 2 * (r & 1), s = lk & 1;
-        return (unsigned)((((c * 4 + cs) * 2 + s) * 1024) + (g * 16 + lr) * 16);
+        unsigned base = t_lane;
+        asm volatile("" : "+v"(base));
+        return base + (unsigned)(((2 * ti * 4 + cs) * 2) * 1024) + (unsigned)((r >> 1) * 8192 + (r & 1) * 512);
     };
 
     int ring_slot = 0;                                           // slot of the chunk being consumed
@@ -118,9 +131,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         for (int j = 0; j < 2; ++j) { P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0}; }
         const int ns_ = s ? a.nb : a.na, off_ = s ? a.na : 0;
         const int ncs = (ns_ + 15) >> 4;
-        for (int c = 0; c < NCH; ++c) {
-            const unsigned sl = next_chunk();
-            d2_t av[2], bv[2][2];
+        auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[2][2]) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 av[ss] = lds_read_c(sl + (wave * 2 + ss) * 1024 + lane * 16);
@@ -128,13 +139,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 for (int j = 0; j < 2; ++j)
                     bv[j][ss] = lds_read_c(tf_l + ((c * 4 + 2 * s + j) * 2 + ss) * 1024 + lane * 16);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[2][2]) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (j < ncs) {
+                    if (j < ncs && wave < nrt) {
                         if (BR) {
                             P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
                             P2[j] = mfma16(av[ss][0], bv[j][ss][1], P2[j]);
@@ -144,6 +156,20 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                             P3[j] = mfma16(av[ss][0] + av[ss][1], bv[j][ss][0] + bv[j][ss][1], P3[j]);
                         }
                     }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // fragments of chunk c+1 are read while the MFMAs of chunk c run (two register sets)
+        d2_t avA[2], bvA[2][2], avB[2], bvB[2][2];
+        load_frags(next_chunk(), 0, avA, bvA);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int c = 0; c < NCH; c += 2) {
+            if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
+            mfmas(avA, bvA);
+            if (c + 1 < NCH) {
+                if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
+                mfmas(avB, bvB);
+            }
         }
         __builtin_amdgcn_s_barrier();                            // everyone finished reading T(spin s)
 #pragma unroll
@@ -165,92 +191,107 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
 
     if (a.b_real) { one_body(0, false, std::true_type{}); one_body(1, false, std::true_type{}); }
     else { one_body(0, false, std::false_type{}); one_body(1, false, std::false_type{}); }
-    __syncthreads();                                             // T = B phi complete
+    lds_barrier();                                               // T = B phi complete
 
     // ------------------------------------------------------------------ Taylor series
-    const int wm = wave >> 1, wn = wave & 1;                     // rows {2wm, 2wm+1}, spin wn's column tiles
-    const int ncs_w = ((wn ? a.nb : a.na) + 15) >> 4;
-    d4_t SR[2][2], SI[2][2];                                     // running sum, this wave's tiles
+    // Tile deal: the 7 x 4 grid of 16x16 output tiles (M <= 104 rows, two column tiles per spin) is split so that
+    // every SIMD carries the same MFMA load.  Waves 0-3 own a 2 x 2 block of the first four row tiles, waves 4-7
+    // a 3 x 1 block (row tiles 4-6 of one column tile); waves w and w+4 share a SIMD: 4 + 3 = 7 tiles each
+    // instead of the 8 (one of them pure padding) of an 8-row-tile deal.
+    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0) {
+        constexpr int NI = decltype(ni_tag)::value, NJ = decltype(nj_tag)::value;
+        bool cv[NJ], rv[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j) {
+            const int cs = c0 + j;
+            cv[j] = (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < NI; ++i) rv[i] = r0 + i < nrt;
+        d4_t SR[NI][NJ], SI[NI][NJ];                              // running sum, this wave's tiles
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d2_t v = (d2_t){0.0, 0.0};
-                if (j < ncs_w && t_ok(2 * wm + i, r)) v = *(const d2_t *)(Tf + t_addr(2 * wm + i, r, 2 * wn + j));
-                SR[i][j][r] = v[0]; SI[i][j][r] = v[1];
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d2_t v = (d2_t){0.0, 0.0};
+                    if (cv[j] && rv[i] && t_ok(r0 + i, r)) v = *(const d2_t *)(Tf + t_addr(r0 + i, r, c0 + j));
+                    SR[i][j][r] = v[0]; SI[i][j][r] = v[1];
+                }
+        // Software pipeline over the k-chunks of one product: the fragments of chunk c+1 travel LDS -> registers
+        // (second register set) while the MFMAs of chunk c run, so the LDS pipe and the MFMA pipe overlap instead
+        // of alternating in lock step behind the per-chunk barrier.
+        auto load_frags = [&](unsigned sl, int c, d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) av[i][ss] = lds_read_c(sl + ((r0 + i) * 2 + ss) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + c0 + j) * 2 + ss) * 1024 + lane * 16);
             }
-    // Software pipeline over the k-chunks of one product: the fragments of chunk c+1 travel LDS -> registers
-    // (second register set) while the MFMAs of chunk c run, so the LDS pipe (8 KB per wave and chunk) and the
-    // MFMA pipe overlap instead of alternating in lock step behind the per-chunk barrier.
-    auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2][2], d2_t (&bv)[2][2]) {
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                av[i][ss] = lds_read_c(sl + ((2 * wm + i) * 2 + ss) * 1024 + lane * 16);
-                bv[i][ss] = lds_read_c(tf_l + ((c * 4 + 2 * wn + i) * 2 + ss) * 1024 + lane * 16);
-            }
-    };
-    for (int n = 1; n <= a.order; ++n) {
-        d4_t P1[2][2], P2[2][2], P3[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0}; }
-        auto mfmas = [&](d2_t (&av)[2][2], d2_t (&bv)[2][2]) {
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (j < ncs_w) {
-                            P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
-                            P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
-                            P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
-                        }
         };
-        d2_t avA[2][2], bvA[2][2], avB[2][2], bvB[2][2];
-        load_frags(next_chunk(), 0, avA, bvA);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int c = 0; c < NCH; c += 2) {
-            if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(avA, bvA);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (c + 1 < NCH) {
-                if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
+        for (int n = 1; n <= a.order; ++n) {
+            d4_t P1[NI][NJ], P2[NI][NJ], P3[NI][NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0};
+                }
+            auto mfmas = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas(avB, bvB);
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            if (cv[j] && rv[i]) {
+                                P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
+                                P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
+                                P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
+                            }
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        __builtin_amdgcn_s_barrier();                            // everyone finished reading T_{n-1}
-        const double inv_n = 1.0 / n;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (j < ncs_w) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double re = (P1[i][j][r] - P2[i][j][r]) * inv_n;
-                        const double im = (P3[i][j][r] - P1[i][j][r] - P2[i][j][r]) * inv_n;
-                        SR[i][j][r] += re; SI[i][j][r] += im;
-                        // T_n (next right-hand operand); after the last term T holds the SUM instead
-                        const bool last = n == a.order;
-                        if (t_ok(2 * wm + i, r))
-                            *(d2_t *)(Tf + t_addr(2 * wm + i, r, 2 * wn + j)) =
-                                last ? (d2_t){SR[i][j][r], SI[i][j][r]} : (d2_t){re, im};
-                    }
+            };
+            d2_t avA[NI][2], bvA[NJ][2], avB[NI][2], bvB[NJ][2];
+            load_frags(next_chunk(), 0, avA, bvA);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int c = 0; c < NCH; c += 2) {
+                if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
+                mfmas(avA, bvA);
+                if (c + 1 < NCH) {
+                    if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
+                    mfmas(avB, bvB);
                 }
-        __syncthreads();                                         // T_n visible
-    }
-    if (a.order == 0) __syncthreads();
+            }
+            __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
+            const double inv_n = 1.0 / n;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (cv[j] && rv[i]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double re = (P1[i][j][r] - P2[i][j][r]) * inv_n;
+                            const double im = (P3[i][j][r] - P1[i][j][r] - P2[i][j][r]) * inv_n;
+                            SR[i][j][r] += re; SI[i][j][r] += im;
+                            // T_n (next right-hand operand); after the last term T holds the SUM instead
+                            const bool last = n == a.order;
+                            if (t_ok(r0 + i, r))
+                                *(d2_t *)(Tf + t_addr(r0 + i, r, c0 + j)) =
+                                    last ? (d2_t){SR[i][j][r], SI[i][j][r]} : (d2_t){re, im};
+                        }
+                    }
+            lds_barrier();                                       // T_n visible
+        }
+    };
+    if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, 2 * (wave >> 1), 2 * (wave & 1));
+    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 4, wave - 4);
+    if (a.order == 0) lds_barrier();
 
     if (a.b_real) { one_body(0, true, std::true_type{}); one_body(1, true, std::true_type{}); }
     else { one_body(0, true, std::false_type{}); one_body(1, true, std::false_type{}); }
