@@ -455,6 +455,7 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
     int rc;
     if ((rc = dev_upload(h, &h->BH1, BH1, (size_t)2 * h->M * h->M))) return rc;
     h->bh1_real = true;
+    h->bh1_same = memcmp(BH1, BH1 + (size_t)2 * h->M * h->M, sizeof(double) * 2 * h->M * h->M) == 0;
     for (size_t i = 0, n = (size_t)2 * h->M * h->M; i < n && h->bh1_real; ++i) h->bh1_real = BH1[2 * i + 1] == 0.0;
     if ((rc = dev_upload(h, &h->mf_shift, mf_shift, (size_t)h->K))) return rc;
     h->dt = dt; h->sqrt_dt = std::pow(dt, 0.5); h->exp_order = exp_order;
@@ -1131,6 +1132,7 @@ int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int c
     int rc;
     if ((rc = dev_upload(h, &h->BH1, bt2, (size_t)2 * h->M * h->M))) return rc;
     h->bh1_real = false;
+    h->bh1_same = false;
     // propagation/hubbard.py:66-82
     typedef std::complex<double> C;
     C gamma, auxf[2][2], wfac[2];

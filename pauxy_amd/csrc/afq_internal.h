@@ -123,6 +123,7 @@ struct afq_handle {
     // ---- propagator
     bool have_prop = false;
     cplx *BH1 = nullptr;            // [2, M, M]
+    bool bh1_same = false;          // BH1[0] and BH1[1] are bitwise equal
     bool bh1_real = false;          // every imaginary part of BH1 is exactly zero (real trial, real L_n)
     cplx *mf_shift = nullptr;       // [K]
     double dt = 0.0, sqrt_dt = 0.0;

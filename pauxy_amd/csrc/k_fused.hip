@@ -26,6 +26,7 @@
 
 struct PropFusedArgs {
     int M, na, nb, nt, order;
+    int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
     const cplx *BH1;            // [2, M, M]
     const cplx *vhs;            // [nw, M, M]
@@ -60,16 +61,19 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     cplx *phi = a.phi + (long)w * M * nt;
     const cplx *vhs = a.vhs + (long)w * M * M;
 
-    // ---- A stream: global chunk g = phase * NCH + c; phases: B0 B1 V..V B0 B1
-    const int nphase = 4 + a.order;
+    // ---- A stream: global chunk g = phase * NCH + c; phases: B0 B1 V..V B0 B1, or B V..V B when both spins
+    // share one propagator matrix (BH1[0] == BH1[1]: every closed-shell-type Hamiltonian) -- the one-body
+    // products of the two spins then run as ONE pass over the matrix with four column tiles per wave
+    const int nob = a.same_b ? 1 : 2;
+    const int nphase = 2 * nob + a.order;
     const int G = nphase * NCH;
     auto a_base = [&](int phase) -> const cplx * {
-        if (phase < 2) return a.BH1 + (long)phase * M * M;
-        if (phase < 2 + a.order) return vhs;
-        return a.BH1 + (long)(phase - 2 - a.order) * M * M;
+        if (phase < nob) return a.BH1 + (long)phase * M * M;
+        if (phase < nob + a.order) return vhs;
+        return a.BH1 + (long)(phase - nob - a.order) * M * M;
     };
     int gi = 0, gi_phase = 0, gi_c = 0, gi_slot = 0;            // next chunk to issue
-    auto issueA = [&]() {
+    auto issueA = [&]() __attribute__((always_inline)) {
         const cplx *A = a_base(gi_phase < nphase ? gi_phase : 0);
         unsigned char *dst = ring + (size_t)gi_slot * 16384;
 #pragma unroll
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     int ring_slot = 0;                                           // slot of the chunk being consumed
     int gcons = 0;                                               // chunks consumed so far
     // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
-    auto next_chunk = [&]() -> unsigned {
+    auto next_chunk = [&]() __attribute__((always_inline)) -> unsigned {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * 2) : "memory");
         __builtin_amdgcn_s_barrier();
         issueA();
@@ -123,30 +127,35 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     };
 
     // ------------------------------------------------------------------ one-body product
-    // wave v owns row tile v and the (up to) two column tiles of spin s
-    auto one_body = [&](int s, bool to_global, auto real_tag) {
+    // wave v owns row tile v and NSL column-tile slots starting at slot0: the (up to) two tiles of one spin, or
+    // all four when both spins share the matrix
+    auto one_body = [&](auto nsl_tag, int slot0, bool to_global, auto real_tag) __attribute__((always_inline)) {
+        constexpr int NSL = decltype(nsl_tag)::value;
         constexpr bool BR = decltype(real_tag)::value;
-        d4_t P1[2], P2[2], P3[2];
+        d4_t P1[NSL], P2[NSL], P3[NSL];
+        bool cv[NSL];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0}; }
-        const int ns_ = s ? a.nb : a.na, off_ = s ? a.na : 0;
-        const int ncs = (ns_ + 15) >> 4;
-        auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[2][2]) {
+        for (int j = 0; j < NSL; ++j) {
+            P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0};
+            const int cs = slot0 + j;
+            cv[j] = wave < nrt && (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
+        }
+        auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 av[ss] = lds_read_c(sl + (wave * 2 + ss) * 1024 + lane * 16);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + 2 * s + j) * 2 + ss) * 1024 + lane * 16);
+                for (int j = 0; j < NSL; ++j)
+                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + slot0 + j) * 2 + ss) * 1024 + lane * 16);
             }
         };
-        auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[2][2]) {
+        auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < ncs && wave < nrt) {
+                for (int j = 0; j < NSL; ++j)
+                    if (cv[j]) {
                         if (BR) {
                             P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
                             P2[j] = mfma16(av[ss][0], bv[j][ss][1], P2[j]);
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // fragments of chunk c+1 are read while the MFMAs of chunk c run (two register sets)
-        d2_t avA[2], bvA[2][2], avB[2], bvB[2][2];
+        d2_t avA[2], bvA[NSL][2], avB[2], bvB[NSL][2];
         load_frags(next_chunk(), 0, avA, bvA);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int c = 0; c < NCH; c += 2) {
@@ -171,26 +180,41 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 mfmas(avB, bvB);
             }
         }
-        __builtin_amdgcn_s_barrier();                            // everyone finished reading T(spin s)
+        __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
+        int lk_e = lk, lr_e = lr;                                // laundered: keeps the store addresses from being
+        asm volatile("" : "+v"(lk_e), "+v"(lr_e));               // computed (and kept alive) ahead of the MFMA loop
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < ncs) {
+        for (int j = 0; j < NSL; ++j)
+            if (cv[j]) {
+                const int cs = slot0 + j, sp = cs >> 1;
+                const int ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double re = BR ? P1[j][r] : P1[j][r] - P2[j][r];
                     const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
-                        const int row = wave * 16 + lk + 4 * r, col = j * 16 + lr;
+                        const int row = wave * 16 + lk_e + 4 * r, col = (cs & 1) * 16 + lr_e;
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
                     } else if (t_ok(wave, r)) {
-                        *(d2_t *)(Tf + t_addr(wave, r, 2 * s + j)) = (d2_t){re, im};
+                        *(d2_t *)(Tf + t_addr(wave, r, cs)) = (d2_t){re, im};
                     }
                 }
             }
     };
+    auto one_body_stage = [&](bool to_global) __attribute__((always_inline)) {
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+        if (a.same_b) {
+            if (a.b_real) one_body(I4{}, 0, to_global, std::true_type{});
+            else one_body(I4{}, 0, to_global, std::false_type{});
+        } else if (a.b_real) {
+            one_body(I2{}, 0, to_global, std::true_type{}); one_body(I2{}, 2, to_global, std::true_type{});
+        } else {
+            one_body(I2{}, 0, to_global, std::false_type{}); one_body(I2{}, 2, to_global, std::false_type{});
+        }
+    };
 
-    if (a.b_real) { one_body(0, false, std::true_type{}); one_body(1, false, std::true_type{}); }
-    else { one_body(0, false, std::false_type{}); one_body(1, false, std::false_type{}); }
+    one_body_stage(false);
     lds_barrier();                                               // T = B phi complete
 
     // ------------------------------------------------------------------ Taylor series
@@ -198,7 +222,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     // every SIMD carries the same MFMA load.  Waves 0-3 own a 2 x 2 block of the first four row tiles, waves 4-7
     // a 3 x 1 block (row tiles 4-6 of one column tile); waves w and w+4 share a SIMD: 4 + 3 = 7 tiles each
     // instead of the 8 (one of them pure padding) of an 8-row-tile deal.
-    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0) {
+    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0) __attribute__((always_inline)) {
         constexpr int NI = decltype(ni_tag)::value, NJ = decltype(nj_tag)::value;
         bool cv[NJ], rv[NI];
 #pragma unroll
@@ -293,8 +317,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 4, wave - 4);
     if (a.order == 0) lds_barrier();
 
-    if (a.b_real) { one_body(0, true, std::true_type{}); one_body(1, true, std::true_type{}); }
-    else { one_body(0, true, std::false_type{}); one_body(1, true, std::false_type{}); }
+    one_body_stage(true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -305,6 +328,7 @@ int k_prop_fused_supported(afq_handle *h) {
 int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
+    a.same_b = (h->bh1_same && !getenv("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !getenv("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
