@@ -20,6 +20,7 @@ from pauxy_amd.estimators.utils import H5EstimatorHelper
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = numpy.load(os.path.join(HERE, "golden", "io_formats.npz"), allow_pickle=False)
 REF_WFN = os.path.join(HERE, "golden", "ref_wfn_nomsd.h5")
+REF_EST = os.path.join(HERE, "golden", "ref_analysed_estimates.h5")     # docs/source/tutorials/calcs/hubbard/
 
 
 def flatten(group, prefix=''):
@@ -78,6 +79,28 @@ def test_reads_reference_hdf5_fixture():
         assert numpy.linalg.matrix_rank(wfn[d, :, :7]) == 7
     with pytest.raises(ValueError):
         aio.read_qmcpack_wfn_hdf(REF_WFN, nelec=(7, 6))
+
+
+def test_reads_reference_estimates_file():
+    """A second libhdf5-written file of the reference (its Hubbard tutorial's analysed estimates, written through
+    h5py/pandas in 2018): variable-length strings in a global heap collection (the ``metadata`` JSON and the header
+    arrays), 5-dimensional float datasets, modification-time and padding messages."""
+    with h5lite.File(REF_EST, 'r') as f:
+        assert f.keys() == ['back_propagated', 'metadata', 'mixed', 'real_itcf', 'real_itcf_err']
+        meta = json.loads(f['metadata'][:][0])
+        assert meta['system']['name'] == 'Hubbard' and meta['system']['nup'] == 3 and meta['qmc']['dt'] == 0.05
+        assert meta['estimators']['estimators']['back_prop']['nmax'] == 40
+        assert [x.decode() for x in f['mixed/headers'][:]][:4] == ['ndets', 'dt', 'E', 'E_error']
+        est = f['mixed/estimates'][:]
+        assert est.shape == (1, 8) and est[0, 1] == 0.05 and est[0, 2] == pytest.approx(-9.66736746, abs=1e-8)
+        bp = f['back_propagated/estimates'][:]
+        assert bp.shape == (1, 10) and bp[0, 0] == 40.0 and bp[0, 2] == pytest.approx(-10.17259488, abs=1e-8)
+        itcf = f['real_itcf']
+        assert itcf.shape == (41, 2, 2, 9, 9) and itcf.dtype == numpy.float64
+        g = itcf[:]
+        # equal-time Green's function of the 3x3 lattice: G(0)_ii = 1 - n_i, translation invariant
+        assert numpy.allclose(numpy.diag(g[0, 0, 0]), g[0, 0, 0, 0, 0], atol=0.1) and 0.0 < g[0, 0, 0, 0, 0] < 1.0
+        assert numpy.isfinite(g).all() and (f['real_itcf_err'][:] >= 0).all()
 
 
 def test_rewrites_reference_fixture_identically(tmp_path):
