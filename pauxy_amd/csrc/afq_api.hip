@@ -180,6 +180,7 @@ int afq_create(int device_id, afq_handle **out) {
     hipMemset(h->zero_page, 0, 256);
     h->no_ring = getenv("AFQ_NO_RING") != nullptr;
     h->no_fused = getenv("AFQ_NO_FUSED") != nullptr;
+    h->no_vhs_upper = getenv("AFQ_VHS_MIRROR") != nullptr;
     h->greens_cache = getenv("AFQ_NO_GREENS_CACHE") == nullptr;
     *out = h;
     return AFQ_OK;
@@ -760,10 +761,16 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         if ((rc = force_bias(h, false))) return rc;
         if ((rc = k_xbar_fields(h))) return rc;
     }
-    { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                // :161
+    // symmetric L_n and the fused propagator as the only consumer: the HS potential is stored as its upper
+    // triangle only (no scattered mirror writes) and the propagator fetches V[k][row] for k < row
+    h->vhs_upper = fused && h->hs_sym && !h->no_vhs_upper;
+    { PhaseTimer t(h, T_VHS); rc = build_vhs(h); }                                  // :161
+    if (rc) { h->vhs_upper = false; return rc; }
     if (fused) {
         PhaseTimer t(h, T_EXP);                                                     // :251, :162-171, :258
-        if ((rc = k_prop_fused(h))) return rc;
+        rc = k_prop_fused(h);
+        h->vhs_upper = false;
+        if (rc) return rc;
     } else {
         { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }    // :162-171
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }        // :258
@@ -1275,9 +1282,12 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     rc = AFQ_OK;
     for (int i = 0; i < h->nbp && !rc; ++i) {                       // propagation/generic.py:279-288
         if ((rc = k_bp_fields(h, i))) break;
-        if ((rc = build_vhs(h))) break;
-        if (fused) rc = k_prop_fused(h);
-        else {
+        h->vhs_upper = fused && h->hs_sym && !h->no_vhs_upper;
+        rc = build_vhs(h);
+        if (!rc && fused) rc = k_prop_fused(h);
+        h->vhs_upper = false;
+        if (rc) break;
+        if (!fused) {
             if ((rc = k_onebody(h))) break;
             if ((rc = apply_exp(h, h->vhs))) break;
             rc = k_onebody(h);

@@ -123,6 +123,7 @@ struct afq_handle {
     // ---- propagator
     bool have_prop = false;
     cplx *BH1 = nullptr;            // [2, M, M]
+    bool vhs_upper = false;         // set around build_vhs + k_prop_fused: VHS[w] holds only its upper triangle
     bool bh1_same = false;          // BH1[0] and BH1[1] are bitwise equal
     bool bh1_real = false;          // every imaginary part of BH1 is exactly zero (real trial, real L_n)
     cplx *mf_shift = nullptr;       // [K]
@@ -177,6 +178,7 @@ struct afq_handle {
     bool greens_valid = false;
     bool greens_cache = true;       // AFQ_NO_GREENS_CACHE=1 or a handed-out device pointer turns it off
     bool no_fused = false;          // AFQ_NO_FUSED=1: separate one-body / Taylor launches (A/B runs)
+    bool no_vhs_upper = false;      // AFQ_VHS_MIRROR=1: always store both triangles of the HS potential (A/B runs)
     bool no_ring = false;           // AFQ_NO_RING=1: register-prefetch GEMM engine only (A/B runs)
 
     // rng

@@ -26,6 +26,7 @@
 
 struct PropFusedArgs {
     int M, na, nb, nt, order;
+    int vhs_upper;              // vhs holds only the upper triangle of the (symmetric) HS potential
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
     const cplx *BH1;            // [2, M, M]
@@ -36,6 +37,26 @@ struct PropFusedArgs {
 };
 
 __device__ inline d2_t lds_read_c(unsigned addr) { return lds_read_b128(addr); }
+
+// ds_read_b128 of fragment `idx` (1 KB apart) behind one base register: the offset goes into the instruction,
+// so a set of fragment reads costs one address register instead of one per fragment.
+template <int OFF> __device__ inline d2_t lds_read_off(unsigned addr) {
+    d2_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __attribute__((always_inline)) inline d2_t lds_read_frag(unsigned base, int idx) {
+    switch (idx) {
+    case 0: return lds_read_off<0>(base);
+    case 1: return lds_read_off<1024>(base);
+    case 2: return lds_read_off<2048>(base);
+    case 3: return lds_read_off<3072>(base);
+    case 4: return lds_read_off<4096>(base);
+    case 5: return lds_read_off<5120>(base);
+    case 6: return lds_read_off<6144>(base);
+    default: return lds_read_off<7168>(base);
+    }
+}
 
 // Work-group barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every
 // operand chunk still in flight in the DMA ring -- a full pipeline drain at each product boundary.
@@ -73,21 +94,39 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         return a.BH1 + (long)(phase - nob - a.order) * M * M;
     };
     int gi = 0, gi_phase = 0, gi_c = 0, gi_slot = 0;            // next chunk to issue
-    auto issueA = [&]() __attribute__((always_inline)) {
+    // The source addresses of a refill are computed ahead of time (prepare), normally right behind an MFMA block
+    // where the integer arithmetic issues under running MFMAs; the refill itself (issueA), which sits in the
+    // barrier-aligned part of the chunk loop that all eight waves execute at once, is then two DMA instructions.
+    const void *nsrc[2];
+    bool prepared = false;
+    auto prepare = [&]() __attribute__((always_inline)) {
         const cplx *A = a_base(gi_phase < nphase ? gi_phase : 0);
-        unsigned char *dst = ring + (size_t)gi_slot * 16384;
+        const bool sym_phase = a.vhs_upper && gi_phase >= nob && gi_phase < nob + a.order;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int f = wave + t * 8;                          // fragment: row tile f>>1, sub-step f&1
             const int row = (f >> 1) * 16 + lr, k = gi_c * 8 + 2 * lk + (f & 1);
-            const void *src = (gi < G && row < M && k < M) ? (const void *)(A + (long)row * M + k) : a.zero16;
-            glds16(src, dst + f * 1024);
+            // upper-triangle storage of V: element (row, k < row) lives at (k, row); the 16 lanes of one k then
+            // read 256 contiguous bytes instead of 16 rows
+            // (branch-free on purpose: a global_load_lds inside a divergent region leaves the LDS slots of the
+            // masked-off lanes stale)
+            const int r2 = sym_phase ? min(row, k) : row, k2 = sym_phase ? max(row, k) : k;
+            nsrc[t] = (gi < G && row < M && k < M) ? (const void *)(A + (r2 * M + k2)) : a.zero16;
         }
         ++gi;
         if (++gi_c == NCH) { gi_c = 0; ++gi_phase; }
+        prepared = true;
+    };
+    auto issueA = [&]() __attribute__((always_inline)) {
+        if (!prepared) prepare();
+        unsigned char *dst = ring + (size_t)gi_slot * 16384;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) glds16(nsrc[t], dst + (wave + t * 8) * 1024);
         if (++gi_slot == PF_D) gi_slot = 0;
+        prepared = false;
     };
     issueA(); issueA();                                          // PF_D - 1 chunks in flight
+    prepare();
 
     // ---- phi[w] -> T (B-fragment order), padding zeroed
     for (int e = tid; e < NCH * 512; e += 512) ((d2_t *)Tf)[e] = (d2_t){0.0, 0.0};
@@ -141,12 +180,13 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             cv[j] = wave < nrt && (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
         }
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
+            const unsigned abase = sl + wave * 2048 + lane * 16;
+            const unsigned bbase = tf_l + (c * 4 + slot0) * 2048 + lane * 16;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                av[ss] = lds_read_c(sl + (wave * 2 + ss) * 1024 + lane * 16);
+                av[ss] = lds_read_frag(abase, ss);
 #pragma unroll
-                for (int j = 0; j < NSL; ++j)
-                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + slot0 + j) * 2 + ss) * 1024 + lane * 16);
+                for (int j = 0; j < NSL; ++j) bv[j][ss] = lds_read_frag(bbase, j * 2 + ss);
             }
         };
         auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
@@ -166,6 +206,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                         }
                     }
             __builtin_amdgcn_sched_barrier(0);
+            if (!prepared) prepare();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // fragments of chunk c+1 are read while the MFMAs of chunk c run (two register sets)
@@ -247,13 +288,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         // (second register set) while the MFMAs of chunk c run, so the LDS pipe and the MFMA pipe overlap instead
         // of alternating in lock step behind the per-chunk barrier.
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
+            const unsigned abase = sl + r0 * 2048 + lane * 16;
+            const unsigned bbase = tf_l + (c * 4 + c0) * 2048 + lane * 16;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i) av[i][ss] = lds_read_c(sl + ((r0 + i) * 2 + ss) * 1024 + lane * 16);
+                for (int i = 0; i < NI; ++i) av[i][ss] = lds_read_frag(abase, i * 2 + ss);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    bv[j][ss] = lds_read_c(tf_l + ((c * 4 + c0 + j) * 2 + ss) * 1024 + lane * 16);
+                for (int j = 0; j < NJ; ++j) bv[j][ss] = lds_read_frag(bbase, j * 2 + ss);
             }
         };
         for (int n = 1; n <= a.order; ++n) {
@@ -278,6 +320,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                                 P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
                             }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!prepared) prepare();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             d2_t avA[NI][2], bvA[NJ][2], avB[NI][2], bvB[NJ][2];
@@ -328,6 +371,7 @@ int k_prop_fused_supported(afq_handle *h) {
 int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
+    a.vhs_upper = h->vhs_upper ? 1 : 0;
     a.same_b = (h->bh1_same && !getenv("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !getenv("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;

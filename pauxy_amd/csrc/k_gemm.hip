@@ -216,6 +216,7 @@ struct VhsProb {
     const int2 *pair;
     int M;
     long mm;
+    bool mirror;                     // false: only (p,q), p <= q, is stored (consumer: prop_fused_kernel)
     __device__ bool active(int) const { return true; }
     __device__ cplx loadA(int, int row, int k) const { return xs[(long)row * kdim + k]; }
     __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * ldb + col], 0.0); }
@@ -228,7 +229,7 @@ struct VhsProb {
             const int2 pq = pair[col];
             cplx *o = out + (long)row * mm;
             o[pq.x * M + pq.y] = v;
-            if (pq.x != pq.y) o[pq.y * M + pq.x] = v;
+            if (mirror && pq.x != pq.y) o[pq.y * M + pq.x] = v;
         } else {
             out[(long)row * mm + col] = v;
         }
@@ -240,6 +241,7 @@ int k_vhs_generic(afq_handle *h) {
     p.batch = 1; p.rows = h->nw; p.cols = h->hs_sym ? h->M * (h->M + 1) / 2 : h->M * h->M; p.kdim = h->K;
     p.xs = h->xs; p.hsT = h->hs_pot; p.ldb = h->ld_hs; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
     p.pair = h->hs_sym ? h->hs_pair : nullptr; p.M = h->M; p.mm = (long)h->M * h->M;
+    p.mirror = !h->vhs_upper;
     if (h->nw > 32 && !h->no_ring) {
         // work-group tile 64 walkers x 160 (p,q) pairs; hs_pot^T panels shared through the LDS ring
         // measured at C3 (tools/sweep_vhs_cfg.sh): packed symmetric columns 75.8 us with the 32 x 160 tile
