@@ -101,32 +101,43 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
                     for (int x = 0; x < 2; ++x)
 #pragma unroll
                         for (int y = 0; y < 2; ++y) { Tr[x][y] = (d4_t){0, 0, 0, 0}; Ti[x][y] = (d4_t){0, 0, 0, 0}; }
-                    double cA[2], cAi[2], cBr[2], cBi[2], nA[2], nAi[2], nBr[2], nBi[2];
-#pragma unroll
-                    for (int x = 0; x < 2; ++x) {
-                        cA[x] = A0[oAi[x]]; cBr[x] = G0[oBi[x]]; cBi[x] = G0[oBi[x] + gstride_c];
-                        cAi[x] = RC ? A0i[oAi[x]] : 0.0;
-                    }
-                    for (int ks = 0; ks < a.nks; ++ks) {
-                        const int o = (ks + 1 < a.nks ? ks + 1 : ks) * 64;
+                    // Two fragment sets, loop unrolled by two with scheduling fences: written as cur/nxt with a copy
+                    // at the end of the iteration the compiler folds the copy away and ends up loading, waiting for and
+                    // consuming the fragments of one k-step inside the same iteration (no prefetch at all).
+                    struct DFr { double A[2], Ai[2], Br[2], Bi[2]; };
+                    DFr fA, fB;
+                    auto dload = [&](DFr &f, int o) __attribute__((always_inline)) {
 #pragma unroll
                         for (int x = 0; x < 2; ++x) {
-                            nA[x] = A0[oAi[x] + o]; nBr[x] = G0[oBi[x] + o]; nBi[x] = G0[oBi[x] + gstride_c + o];
-                            nAi[x] = RC ? A0i[oAi[x] + o] : 0.0;
+                            f.A[x] = A0[oAi[x] + o]; f.Br[x] = G0[oBi[x] + o]; f.Bi[x] = G0[oBi[x] + gstride_c + o];
+                            f.Ai[x] = RC ? A0i[oAi[x] + o] : 0.0;
                         }
+                    };
+                    auto dmfma = [&](const DFr &f) __attribute__((always_inline)) {
 #pragma unroll
                         for (int x = 0; x < 2; ++x)
 #pragma unroll
                             for (int y = 0; y < 2; ++y) {
-                                Tr[x][y] = mfma16(cA[x], cBr[y], Tr[x][y]);
-                                Ti[x][y] = mfma16(cA[x], cBi[y], Ti[x][y]);
+                                Tr[x][y] = mfma16(f.A[x], f.Br[y], Tr[x][y]);
+                                Ti[x][y] = mfma16(f.A[x], f.Bi[y], Ti[x][y]);
                                 if (RC) {
-                                    Tr[x][y] = mfma16(-cAi[x], cBi[y], Tr[x][y]);
-                                    Ti[x][y] = mfma16(cAi[x], cBr[y], Ti[x][y]);
+                                    Tr[x][y] = mfma16(-f.Ai[x], f.Bi[y], Tr[x][y]);
+                                    Ti[x][y] = mfma16(f.Ai[x], f.Br[y], Ti[x][y]);
                                 }
                             }
-#pragma unroll
-                        for (int x = 0; x < 2; ++x) { cA[x] = nA[x]; cAi[x] = nAi[x]; cBr[x] = nBr[x]; cBi[x] = nBi[x]; }
+                    };
+                    dload(fA, 0);
+                    for (int ks = 0; ks < a.nks; ks += 2) {
+                        dload(fB, (ks + 1 < a.nks ? ks + 1 : ks) * 64);
+                        __builtin_amdgcn_sched_barrier(0);
+                        dmfma(fA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + 1 < a.nks) {
+                            dload(fA, (ks + 2 < a.nks ? ks + 2 : ks + 1) * 64);
+                            __builtin_amdgcn_sched_barrier(0);
+                            dmfma(fB);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     cmul_acc(sr, si, Tr[0][0], Ti[0][0], Tr[0][0], Ti[0][0], 1.0);
                     if (ci == 2) {
@@ -143,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
                             Tr[x][y] = (d4_t){0, 0, 0, 0}; Ti[x][y] = (d4_t){0, 0, 0, 0};
                             Sr[x][y] = (d4_t){0, 0, 0, 0}; Si[x][y] = (d4_t){0, 0, 0, 0};
                         }
-                    ExxFrags<RC> cur, nxt;
-                    auto load = [&](ExxFrags<RC> &f, int o) {
+                    ExxFrags<RC> fA, fB;                   // two sets, unrolled by two: see the diagonal case
+                    auto load = [&](ExxFrags<RC> &f, int o) __attribute__((always_inline)) {
 #pragma unroll
                         for (int x = 0; x < 2; ++x) {
                             f.Air[x] = A0[oAi[x] + o]; f.Ajr[x] = A0[oAj[x] + o];
@@ -153,9 +164,7 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
                             if (RC) { f.Aii[x] = A0i[oAi[x] + o]; f.Aji[x] = A0i[oAj[x] + o]; }
                         }
                     };
-                    load(cur, 0);
-                    for (int ks = 0; ks < a.nks; ++ks) {
-                        load(nxt, (ks + 1 < a.nks ? ks + 1 : ks) * 64);
+                    auto mfmas = [&](const ExxFrags<RC> &cur) __attribute__((always_inline)) {
 #pragma unroll
                         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -171,7 +180,19 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
                                     Si[y][x] = mfma16(cur.Aji[y], cur.Bir[x], Si[y][x]);
                                 }
                             }
-                        cur = nxt;
+                    };
+                    load(fA, 0);
+                    for (int ks = 0; ks < a.nks; ks += 2) {
+                        load(fB, (ks + 1 < a.nks ? ks + 1 : ks) * 64);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(fA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks + 1 < a.nks) {
+                            load(fA, (ks + 2 < a.nks ? ks + 2 : ks + 1) * 64);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfmas(fB);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
 #pragma unroll
                     for (int x = 0; x < 2; ++x)
