@@ -271,15 +271,13 @@ int k_vhs_generic(afq_handle *h) {
         }
         return AFQ_OK;
     }
-    static const TileChoice cand[] = {{2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 2}};
-    const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, cand, 5);
+    static const TileChoice cand[] = {{2, 4}, {2, 2}, {1, 4}, {1, 2}};       // (2 x 5 does not fit two fragment sets)
+    const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, cand, 4);
     const int tiles_m = (p.rows + 16 * tc.tm - 1) / (16 * tc.tm);
     int wpb = tiles_m <= 8 ? (tiles_m < 1 ? 1 : tiles_m) : 8;
     const long ntask = mfma_gemm_tasks(p.batch, p.rows, p.cols, tc.tm, tc.tn);
     while (wpb > 1 && ntask / wpb < 200) wpb >>= 1;      // keep >= ~1 workgroup per CU
-    if (tc.tm == 2 && tc.tn == 5)
-        AFQ_HIP(h, (launch_mfma_gemm<2, 5, VhsProb, MAP_ROWS_FAST>(p, h->stream, wpb)));
-    else DISPATCH_TILES(h, p, tc, MAP_ROWS_FAST, wpb);
+    DISPATCH_TILES(h, p, tc, MAP_ROWS_FAST, wpb);
     return AFQ_OK;
 }
 

@@ -104,10 +104,12 @@ __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {
             accI[i][j] = (d4_t){0, 0, 0, 0};
         }
 
-    FragSet<TM, TN, P> cur, nxt;
-    cur.load(p, b, row0, col0, 0, lr, lk);
-    for (int k0 = 0; k0 < p.kdim; k0 += 8) {
-        if (k0 + 8 < p.kdim) nxt.load(p, b, row0, col0, k0 + 8, lr, lk);
+    // Register prefetch one k-chunk ahead with two explicit fragment sets and the loop unrolled by two.  (Written
+    // as cur/nxt with a copy at the end of the iteration, the compiler folds the copy away and loads, waits for and
+    // consumes a chunk's fragments inside one iteration.)
+    FragSet<TM, TN, P> fA, fB;
+    auto mfmas = [&](const FragSet<TM, TN, P> &cur) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -119,7 +121,16 @@ __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {
                     if (P::B_CPLX) accI[i][j] = mfma16(cur.a[i][s].x, cur.b[j][s].y, accI[i][j]);
                     if (P::A_CPLX) accI[i][j] = mfma16(cur.a[i][s].y, cur.b[j][s].x, accI[i][j]);
                 }
-        cur = nxt;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fA.load(p, b, row0, col0, 0, lr, lk);
+    for (int k0 = 0; k0 < p.kdim; k0 += 16) {
+        if (k0 + 8 < p.kdim) fB.load(p, b, row0, col0, k0 + 8, lr, lk);
+        mfmas(fA);
+        if (k0 + 8 < p.kdim) {
+            if (k0 + 16 < p.kdim) fA.load(p, b, row0, col0, k0 + 16, lr, lk);
+            mfmas(fB);
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
