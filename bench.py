@@ -139,9 +139,15 @@ def main():
         dev.sync()
     eshift = afqmc.run_batched(args.warmup, first_step=1, eshift=0.0)
     barrier()
-    dev.kernel_trace(True)          # event pairs around the hot kernels, read after the timed region
+    # Event pairs around the launches of the two kernels that can dominate the step (fused propagator, exchange
+    # energy), read after the timed region.  An event pair costs a few microseconds of pipeline bubble per launch:
+    # with every hot kernel traced the step is 4 % slower (553 vs 531 us), so the per-step GEMMs are timed in a
+    # separate, untimed pass below.
+    from pauxy_amd import _lib as L
+    in_region = [L.K_PROPAGATOR, L.K_EXCHANGE]
+    dev.kernel_trace(True, in_region)
     t0 = time.perf_counter()
-    afqmc.run_batched(args.steps, first_step=args.warmup + 1, eshift=eshift)
+    eshift = afqmc.run_batched(args.steps, first_step=args.warmup + 1, eshift=eshift)
     barrier()
     elapsed = time.perf_counter() - t0
     dev.kernel_trace(False)
@@ -151,9 +157,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Rooflines of the hot kernels from HIP events recorded on the library's stream around every
-    # launch INSIDE the timed region (afq_kernel_trace); algorithmic flops per launch as in DESIGN.md.
-    from pauxy_amd import _lib as L
+    # Rooflines of the hot kernels from HIP events recorded on the library's stream around every launch
+    # (afq_kernel_trace): the dominant candidates INSIDE the timed region, the per-step GEMMs in an extra pass of
+    # 2 blocks right after it; algorithmic flops per launch as in DESIGN.md.
+    traced = {kind: dev.kernel_trace_get(kind) for kind in in_region}
+    extra_steps = 2 * NSTEPS_BLOCK
+    dev.kernel_trace(True)
+    afqmc.run_batched(extra_steps, first_step=args.warmup + args.steps + 1, eshift=eshift)
+    dev.sync()
+    dev.kernel_trace(False)
     nt = 2 * N
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR,
@@ -166,17 +178,21 @@ def main():
     ]
     rows = []
     for name, kind, flops in kernels:
-        ms = dev.kernel_trace_get(kind)
+        live = kind in traced
+        ms = traced[kind] if live else dev.kernel_trace_get(kind)
         if len(ms) == 0:
             continue
         avg = float(numpy.mean(ms))
         rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg,
-                     "ms_per_step": float(numpy.sum(ms)) / args.steps, "flops_per_launch": flops,
+                     "measured": "timed region" if live else "extra pass of %d steps after the timed region" % extra_steps,
+                     "ms_per_step": float(numpy.sum(ms)) / (args.steps if live else extra_steps), "flops_per_launch": flops,
                      "achieved": flops / (avg * 1e-3) / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS})
     if not rows:
         raise RuntimeError("no traced kernel launches in the timed region")
     dom = max(rows, key=lambda r: r["ms_per_step"])
+    if dom["measured"] != "timed region":
+        raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile):
@@ -200,7 +216,7 @@ def main():
                        "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
-                         "kernel_ms": dom["avg_ms"], "launches": dom["launches"],
+                         "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
                          "flops_per_launch": dom["flops_per_launch"]},
             "roofline_all": rows,
         }

@@ -254,7 +254,9 @@ int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
 /* Per-launch durations of the hot kernels, HIP events recorded on the handle's
  * stream around the launch (no host synchronisation until _get): bench.py's
  * live roofline measurement over its timed region.  afq_kernel_trace(h, 1)
- * clears and starts recording (up to 4096 launches per kind), (h, 0) stops.   */
+ * clears and starts recording every kind (up to 4096 launches per kind),
+ * (h, 2 << kind | ...) only the selected kinds (an event pair costs a few
+ * microseconds of pipeline bubble per launch), (h, 0) stops.                   */
 #define AFQ_K_PROPAGATOR 0   /* fused B exp(V) B kernel (k_fused.hip)          */
 #define AFQ_K_EXCHANGE 1     /* Cholesky exchange-energy kernel (k_energy.hip) */
 #define AFQ_K_VHS 2          /* HS potential GEMM                              */

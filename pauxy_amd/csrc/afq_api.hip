@@ -497,8 +497,8 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
         const long tiles = (long)((nw + 31) / 32) * ((h->K + 31) / 32) * 2;
         int sp = (int)std::max(1L, std::min(8L, 1024 / std::max(1L, tiles)));
         if (nw > 32) {
-            // work-group-tiled kernel (64 walkers x 128 fields per work-group): aim at >= 512 work-groups
-            const long wgt = (long)((nw + 63) / 64) * ((h->K + 127) / 128) * 2;
+            // work-group-tiled kernel (64 walkers x 64 fields per work-group): aim at >= 512 work-groups
+            const long wgt = (long)((nw + 63) / 64) * ((h->K + 63) / 64) * 2;
             sp = (int)std::max(1L, std::min(16L, (512 + wgt - 1) / wgt));
         }
         if (getenv("AFQ_FB_SPLIT")) sp = atoi(getenv("AFQ_FB_SPLIT"));
@@ -1346,7 +1346,8 @@ int afq_walkers_det_weights(afq_handle *h, double *weights_out) {
 
 int afq_kernel_trace(afq_handle *h, int on) {
     if (!h) return AFQ_EINVAL;
-    h->ktrace_on = on != 0;
+    // on == 1: every kind; on > 1: bit (k + 1) selects kind k, e.g. 2 = AFQ_K_PROPAGATOR only; 0: off
+    h->ktrace_mask = on == 1 ? ~0u : on > 1 ? (unsigned)on >> 1 : 0u;
     if (on) for (int k = 0; k < AFQ_K_COUNT; ++k) h->ktrace_used[k] = 0;
     return AFQ_OK;
 }

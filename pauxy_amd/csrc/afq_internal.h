@@ -163,7 +163,7 @@ struct afq_handle {
     size_t gfrag_bytes = 0;
     hipEvent_t ev_e0 = nullptr, ev_e1 = nullptr;   // brackets the exchange kernel
     bool energy_ev_valid = false;
-    bool ktrace_on = false;
+    unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
     cplx *estimates = nullptr;      // [10]
@@ -222,7 +222,7 @@ struct PhaseTimer {
 struct KernelTrace {
     afq_handle *h; int kind, idx;
     KernelTrace(afq_handle *h_, int k) : h(h_), kind(k), idx(-1) {
-        if (!h->ktrace_on || h->ktrace_used[k] >= 4096) return;
+        if (!(h->ktrace_mask >> k & 1) || h->ktrace_used[k] >= 4096) return;
         idx = h->ktrace_used[k];
         std::vector<hipEvent_t> &ev = h->ktrace_ev[k];
         while ((int)ev.size() < 2 * idx + 2) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }

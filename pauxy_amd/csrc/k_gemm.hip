@@ -166,15 +166,20 @@ int k_force_bias_generic(afq_handle *h) {
         fill_force_bias(p, h);
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kMixedTiles, 5);
         if (h->nw > 32 && !h->no_ring) {
-            // work-group tile 64 walkers x 64 fields, operands shared through the LDS ring
-            static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 1;
+            // work-group tile 64 walkers x 64 fields (cfg 2), operands shared through the LDS ring.  Measured at C3
+            // together with the reduction of the split-K partial sums in fields_kernel (step time, us):
+            // 64x128 tile / 16 slices 553.7, 64x64 / 8 slices 545.4, 32x64 / 8 slices 545.3, 64x64 / 4 slices 553.6
+            static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 2;
             static const int kc = getenv("AFQ_GEMM_KC") ? atoi(getenv("AFQ_GEMM_KC")) : 1;
             if (cfg == 1) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
                 if (kc == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 2>(p, h->stream, h->zero_page)));
                 else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             }
-            else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else if (cfg == 2) {
+                KernelTrace kt(h, AFQ_K_FORCE_BIAS);
+                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            }
             else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         } else {

@@ -342,9 +342,12 @@ class AfqDevice(object):
         return dict(zip(['greens', 'one_body', 'force_bias', 'vhs', 'exponential', 'overlap_weight',
                          'reortho', 'energy'], out))
 
-    def kernel_trace(self, on=True):
-        """Start (and clear) / stop per-launch HIP-event timing of the hot kernels."""
-        self._ck(self.lib.afq_kernel_trace(self.h, int(on)))
+    def kernel_trace(self, on=True, kinds=None):
+        """Event pairs around the hot kernels' launches: every kind, or only ``kinds`` (list of K_* constants)."""
+        arg = int(bool(on))
+        if on and kinds is not None:
+            arg = sum(2 << int(k) for k in kinds)
+        self._ck(self.lib.afq_kernel_trace(self.h, arg))
 
     def kernel_trace_get(self, kind, max_n=4096):
         """Durations [ms] of the traced launches of kernel ``kind`` (_lib.K_*)."""
