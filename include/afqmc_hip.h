@@ -217,6 +217,9 @@ int afq_kinetic(afq_handle *h);                                      /* phi <- B
  * total_weight means "the total weight the last afq_popcontrol_comb measured" (kept on the
  * device; the population size before the first comb), which needs no host round trip.     */
 int afq_cap_weights(afq_handle *h, double frac, double total_weight);
+/* The same cap applied by afq_propagate itself, at the end of its weight-update kernel (one launch
+ * less per step).  frac <= 0 switches it off (the default); total_weight as in afq_cap_weights.   */
+int afq_set_weight_cap(afq_handle *h, double frac, double total_weight);
 /* walkers/handler.py:225-338 for a single rank: rescale, comb with the uniform
  * r, clone/kill, weights reset to 1.  parent_ix int32[nw] out (may be NULL);
  * total_weight_out f64 (may be NULL).  With BOTH outputs NULL the call only enqueues

@@ -50,6 +50,7 @@ SIGNATURES = {
     "afq_apply_exponential": [_h, _dp],
     "afq_kinetic": [_h],
     "afq_cap_weights": [_h, c_double, c_double],
+    "afq_set_weight_cap": [_h, c_double, c_double],
     "afq_popcontrol_comb": [_h, c_double, c_double, c_void_p, POINTER(c_double)],
     "afq_walkers_scale_weights": [_h, c_double],
     "afq_walkers_copy": [_h, c_int, c_int],

@@ -938,6 +938,13 @@ int afq_kinetic(afq_handle *h) {
 }
 
 // -------------------------------------------------------------- driver glue
+int afq_set_weight_cap(afq_handle *h, double frac, double total_weight) {
+    if (!h) return AFQ_EINVAL;
+    h->cap_frac = frac > 0.0 ? frac : 0.0;
+    h->cap_total = total_weight;
+    return AFQ_OK;
+}
+
 int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);

@@ -123,6 +123,7 @@ struct afq_handle {
     // ---- propagator
     bool have_prop = false;
     cplx *BH1 = nullptr;            // [2, M, M]
+    double cap_frac = 0.0, cap_total = -1.0;   // afq_set_weight_cap: cap applied inside the weight-update kernel
     bool vhs_upper = false;         // set around build_vhs + k_prop_fused: VHS[w] holds only its upper triangle
     bool bh1_same = false;          // BH1[0] and BH1[1] are bitwise equal
     bool bh1_real = false;          // every imaginary part of BH1 is exactly zero (real trial, real L_n)

@@ -706,6 +706,9 @@ struct WeightArgs {
     int *bp_flag;
     double *bp_cos;
     cplx *bp_ph;
+    // weight cap of the driver (qmc/afqmc.py:235-236) applied right behind the update; cap_frac <= 0: off
+    double cap_frac, cap_total;
+    const double *cap_total_dev;    // total weight of the last comb when cap_total < 0
 };
 
 __device__ inline void bp_record(const WeightArgs &a, int w, double magn, cplx wfac0, double cosine_fac) {
@@ -717,9 +720,7 @@ __device__ inline void bp_record(const WeightArgs &a, int w, double magn, cplx w
 }
 
 // propagation/continuous.py:264-292 (hybrid) and :194-200 (free projection)
-__global__ void weight_kernel(WeightArgs a) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.nw) return;
+__device__ static void weight_update(const WeightArgs &a, const int w) {
     if (a.bp_flag) a.bp_flag[w] = 0;
     if (!a.alive[w]) return;
     const cplx on = a.ovlp_new[w];
@@ -773,6 +774,17 @@ __global__ void weight_kernel(WeightArgs a) {
         bp_record(a, w, magn, cmake(imp.x / magn, imp.y / magn), cf);
     } else {
         a.weight[w] = 0.0;
+    }
+}
+
+__global__ void weight_kernel(WeightArgs a) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nw) return;
+    weight_update(a, w);
+    if (a.cap_frac > 0.0) {
+        // every walker, propagated or not, exactly like the driver's loop
+        const double cap = a.cap_frac * (a.cap_total < 0.0 ? a.cap_total_dev[0] : a.cap_total);
+        if (fabs(a.weight[w]) > cap) a.weight[w] = cap;
     }
 }
 
@@ -899,6 +911,7 @@ int k_update_weight(afq_handle *h, cplx eshift) {
     a.weight = h->weight; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase; a.counters = h->counters;
     a.eloc = h->eloc; a.energy = h->energy;
     a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
+    a.cap_frac = h->cap_frac; a.cap_total = h->cap_total; a.cap_total_dev = h->scal;
     hipLaunchKernelGGL(weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
     AFQ_HIP(h, hipGetLastError());
     return AFQ_OK;

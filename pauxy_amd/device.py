@@ -288,6 +288,10 @@ class AfqDevice(object):
     def cap_weights(self, frac, total_weight):
         self._ck(self.lib.afq_cap_weights(self.h, float(frac), float(total_weight)))
 
+    def set_weight_cap(self, frac, total_weight=-1.0):
+        """Cap applied by propagate() itself from now on (frac <= 0: off); see afq_set_weight_cap."""
+        self._ck(self.lib.afq_set_weight_cap(self.h, float(frac), float(total_weight)))
+
     def popcontrol_comb(self, r, target, fetch=True):
         if not fetch:        # asynchronous: the total weight stays on the device (cap_weights(frac, -1))
             self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), None, None))

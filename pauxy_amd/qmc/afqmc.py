@@ -131,10 +131,14 @@ class AFQMC(object):
         psi, dev = self.psi, self.psi.dev
         if step % self.qmc.nstblz == 0:
             dev.reortho(fetch=False)
-        self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
         single = self.comm is None or self.comm.size == 1
-        if step > 1:
-            # single rank: the total weight of the last comb is still on the device
+        hirsch = getattr(self.propagators, 'hs_type', '') == 'discrete'
+        if not hirsch:
+            # the weight cap of afqmc.py:235-236 rides on the weight-update kernel of the propagation
+            # (single rank: the total weight of the last comb is still on the device)
+            dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0 if single else psi.total_weight)
+        self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
+        if hirsch and step > 1:
             dev.cap_weights(0.10, -1.0 if single else psi.total_weight)
         if step % self.qmc.npop_control == 0:
             psi._invalidate()

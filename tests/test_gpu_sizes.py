@@ -147,3 +147,42 @@ def test_back_propagation_with_reortho(M, K, na, nb, restore):
     close(G, est[4:].reshape(2, M, M), 1e-8)
     assert numpy.all(energies == 0)
     dev.close()
+
+
+def test_weight_cap_inside_propagate_equals_separate_cap():
+    """afq_set_weight_cap (cap riding on the weight-update kernel) against afq_propagate + afq_cap_weights:
+    same weights bit for bit, dead walkers capped too, switched off again by frac = 0."""
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.context import get_context, release_context
+    from pauxy_amd.propagation import setup
+    s = systems.synthetic_generic(12, 20, (3, 3), seed=9)
+    t = trial_mod.rhf_trial_generic(s)
+    dev = get_context(s, t).dev
+    BH1, mf = setup.generic_propagator_arrays(s, t, 0.01)
+    dev.set_propagator(BH1, mf, 0.01)
+    nw = 9
+    dev.walkers_alloc(nw)
+    rng = numpy.random.RandomState(2)
+    phi = numpy.asarray(t.psi)[None] + 0.05 * (rng.rand(nw, 12, 6) + 1j * rng.rand(nw, 12, 6))
+    w0 = numpy.array([1.0, 3.0, 0.0, 0.2, 5.0, 1.0, 0.0, 2.5, 0.7])      # two dead walkers, several above the cap
+    xi = rng.normal(size=(nw, 20))
+
+    def run(fused):
+        dev.set(L.F_PHI, phi)
+        dev.set(L.F_WEIGHT, w0)
+        dev.set(L.F_OT, dev.calc_overlap())
+        dev.set(L.F_HYBRID_ENERGY, numpy.zeros(nw, dtype=complex))
+        dev.set_weight_cap(0.1 if fused else 0.0, 9.0)
+        dev.propagate(xi, 0.0)
+        if not fused:
+            dev.cap_weights(0.1, 9.0)
+        return dev.get(L.F_WEIGHT), dev.get(L.F_PHI)
+
+    wa, pa = run(False)
+    wb, pb = run(True)
+    assert numpy.array_equal(wa, wb) and numpy.array_equal(pa, pb)
+    assert wa.max() <= 0.9 + 1e-15 and (wa == 0.9).sum() >= 2 and (wa[[2, 6]] == 0.0).all()
+    dev.set_weight_cap(0.0)
+    wc, _ = run(False)
+    assert numpy.array_equal(wc, wa)
+    release_context(s, t)
