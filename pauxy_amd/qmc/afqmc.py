@@ -88,6 +88,7 @@ class AFQMC(object):
         if psi is not None:
             self.psi = psi
         self.setup_timers()
+        self.psi.dev.set_weight_cap(0.0)          # this loop caps on the host mirrors, like the reference driver
         mixed = self.estimators.estimators['mixed']
         eshift = 0
         mixed.update(self.system, self.qmc, self.trial, self.psi, 0, self.propagators.free_projection)
