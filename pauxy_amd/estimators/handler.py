@@ -14,47 +14,53 @@ from pauxy_amd.estimators.mixed import Mixed
 from pauxy_amd.utils import io as _io
 
 
+def _series_file(basename, index):
+    """Name of file number ``index`` of an output series: <basename>.<index>.h5 (handler.py:64,122-124)."""
+    return "%s.%s.h5" % (basename, index)
+
+
+def _touch(filename):
+    with _io.h5.File(filename, 'w'):
+        pass
+
+
 class Estimators(object):
     def __init__(self, estimates, root, qmc, system, trial, BT2, verbose=False):
-        self.index = estimates.get('index', 0)
-        self.filename = estimates.get('filename', None)
-        self.basename = estimates.get('basename', None)
-        self.flush_every = estimates.get('flush_every', None)
-        if not root:
-            self.filename = None
-        elif self.filename is None and self.basename is not None:
-            overwrite = estimates.get('overwrite', True)
-            self.filename = self.basename + '.%s.h5' % self.index
-            while os.path.isfile(self.filename) and not overwrite:
-                self.index = self.index + 1
-                self.filename = self.basename + '.%s.h5' % self.index
+        opts = estimates
+        self.index = opts.get('index', 0)
+        self.basename = opts.get('basename')
+        self.flush_every = opts.get('flush_every')
+        name = opts.get('filename') if root else None
+        if root and name is None and self.basename is not None:
+            # first free slot of the series unless overwriting is allowed (handler.py:63-69)
+            keep_existing = not opts.get('overwrite', True)
+            name = _series_file(self.basename, self.index)
+            while keep_existing and os.path.isfile(name):
+                self.index += 1
+                name = _series_file(self.basename, self.index)
+        self.filename = name
         if self.basename is None:
             self.basename = 'estimates'
-        if self.filename is not None:
-            with _io.h5.File(self.filename, 'w'):
-                pass
-        mixed = dict(estimates.get('mixed', {}))
-        mixed.setdefault('flush_every', self.flush_every)
+        if name is not None:
+            _touch(name)
         self.estimators = {}
-        self.estimators['mixed'] = Mixed(mixed, system, root, self.filename, qmc, trial, complex)
-        if estimates.get('itcf') is not None:
+        mixed_opts = dict(opts.get('mixed', {}), flush_every=opts.get('mixed', {}).get('flush_every', self.flush_every))
+        self.estimators['mixed'] = Mixed(mixed_opts, system, root, name, qmc, trial, complex)
+        if opts.get('itcf') is not None:
             raise NotImplementedError("itcf estimator is not on the device path yet")
-        bp = estimates.get('back_propagation', estimates.get('back_propagated'))     # handler.py:83-85
-        self.back_propagation = bp is not None
+        bp_opts = opts.get('back_propagation', opts.get('back_propagated'))              # handler.py:83-85
+        self.back_propagation = bp_opts is not None
+        self.nprop_tot = self.nbp = None
         if self.back_propagation:
-            bp = dict(bp)
-            bp.setdefault('flush_every', self.flush_every)
-            self.estimators['back_prop'] = BackPropagation(bp, root, self.filename, qmc, system, trial, complex, BT2)
-            self.nprop_tot = self.estimators['back_prop'].nmax                           # handler.py:91-92
-            self.nbp = self.estimators['back_prop'].nmax
-        else:
-            self.nprop_tot = None
-            self.nbp = None
+            bp_opts = dict(bp_opts, flush_every=bp_opts.get('flush_every', self.flush_every))
+            est = BackPropagation(bp_opts, root, name, qmc, system, trial, complex, BT2)
+            self.estimators['back_prop'] = est
+            self.nprop_tot = self.nbp = est.nmax                                         # handler.py:91-92
         self.calc_itcf = False
         self.json_string = ''
 
     def dump_metadata(self):
-        """handler.py:117-120."""
+        """handler.py:117-120: the run description as the ``metadata`` dataset (replaced if present)."""
         if self.filename is None:
             return
         with _io.h5.File(self.filename, 'a') as fh5:
@@ -63,29 +69,31 @@ class Estimators(object):
             fh5['metadata'] = self.json_string
 
     def increment_file_number(self):
-        self.index = self.index + 1
-        self.filename = self.basename + '.%s.h5' % self.index
+        self.index += 1
+        self.filename = _series_file(self.basename, self.index)
 
     def reset(self, root):
         """handler.py:110-115: start the next file of the series."""
-        if root and self.filename is not None:
-            self.flush()
-            self.increment_file_number()
-            with _io.h5.File(self.filename, 'w'):
-                pass
-            self.dump_metadata()
-            for k, e in self.estimators.items():
-                e.setup_output(self.filename)
+        if not root or self.filename is None:
+            return
+        self.flush()
+        self.increment_file_number()
+        _touch(self.filename)
+        self.dump_metadata()
+        for est in self.estimators.values():
+            est.setup_output(self.filename)
 
     def flush(self):
-        for k, e in self.estimators.items():
-            if getattr(e, 'output', None) is not None:
-                e.output.flush()
+        """Write the estimator blocks still queued (pauxy_amd/estimators/utils.py)."""
+        for est in self.estimators.values():
+            out = getattr(est, 'output', None)
+            if out is not None:
+                out.flush()
 
     def print_step(self, comm, nprocs, step, nsteps=None, free_projection=False):
-        for k, e in self.estimators.items():
-            e.print_step(comm, nprocs, step, nsteps=nsteps, free_projection=free_projection)
+        for est in self.estimators.values():
+            est.print_step(comm, nprocs, step, nsteps=nsteps, free_projection=free_projection)
 
     def update(self, system, qmc, trial, psi, step, free_projection=False):
-        for k, e in self.estimators.items():
-            e.update(system, qmc, trial, psi, step, free_projection)
+        for est in self.estimators.values():
+            est.update(system, qmc, trial, psi, step, free_projection)
