@@ -70,6 +70,10 @@ def cpu_baseline(system, trial, nw_cpu=16, nsteps=10):
 
 
 def main():
+    # a hang anywhere (driver, runtime, collective) ends the run with every thread's traceback instead of
+    # waiting for the caller's timeout
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("AFQ_BENCH_WATCHDOG_S", "900")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
