@@ -38,6 +38,8 @@ typedef struct afq_handle afq_handle;
 #define AFQ_ENOMEM       (-4)
 #define AFQ_EUNSUPPORTED (-5)
 #define AFQ_EWEIGHT      (-6)   /* total weight < 1e-8 (walkers/handler.py:236)  */
+#define AFQ_EOVERFLOW    (-7)   /* more walkers moved between two ranks in one population control than the
+                                   exchange slots of the communicator hold (afq_comm_set_capacity)   */
 
 /* system kinds */
 #define AFQ_SYS_GENERIC 1
@@ -226,6 +228,41 @@ int afq_set_weight_cap(afq_handle *h, double frac, double total_weight);
  * work (no host synchronisation, no AFQ_EWEIGHT check).                         */
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
                         int32_t *parent_ix, double *total_weight_out);
+
+/* ---- library-owned communicator ----------------------------------------------------
+ * walkers/handler.py:225-338 across ranks -- the Allgather of the weights (:232), rank 0's comb uniform
+ * (:276,291) and the point-to-point walker copies (:303-331) -- and the estimator reduction of
+ * estimators/mixed.py:261,273, on the device over RCCL (xGMI on one node), one process per GPU.
+ * After afq_comm_init, afq_popcontrol_comb is a collective: every rank calls it with the same
+ * target_weight (= total walkers) and rank 0's r; the weights are all-gathered on the device, every rank
+ * decides the identical global comb, cloned walkers that change rank travel through fixed-capacity slot
+ * buffers (one ncclSend / ncclRecv group), nothing is read back by the host unless outputs are requested
+ * (parent_ix is then the GLOBAL int32[nranks * nw] comb, total_weight_out the global weight).  The cap of
+ * afq_cap_weights / afq_set_weight_cap with total_weight < 0 uses the global weight of the last comb.
+ *   afq_comm_unique_id     128-byte ncclUniqueId, made by rank 0 and handed to every rank by the caller
+ *   afq_comm_init          ncclCommInitRank on the handle's GPU (librccl is loaded here, not before)
+ *   afq_comm_set_capacity  walkers one rank can send to one peer per event (default max(8, nw/8));
+ *                          exceeding it raises AFQ_EOVERFLOW at the next afq_estimates_get / fetching comb
+ *   afq_comm_stats         int64[6]: largest per-peer transfer seen, events, capacity, overflow flag, rank, size
+ *   afq_estimates_allreduce  sum over ranks of buf c128[nest] (in/out, host), or with buf == NULL of the
+ *                          device accumulators of afq_estimates_update in place (no host round trip; a
+ *                          following afq_estimates_get returns the global sums on every rank)
+ * In-process variant: afq_comm_init_local makes handles[0..n) (one host thread driving several GPUs, or
+ * several handles on one GPU) the ranks 0..n-1 of one communicator; the collectives are then the group calls
+ * afq_popcontrol_comb_local / afq_estimates_allreduce_local (same kernels, device-to-device copies ordered by
+ * events instead of RCCL).                                                                               */
+#define AFQ_COMM_ID_BYTES 128
+int afq_comm_unique_id(void *id_out);
+int afq_comm_init(afq_handle *h, const void *unique_id, int rank, int nranks);
+int afq_comm_destroy(afq_handle *h);
+int afq_comm_set_capacity(afq_handle *h, int max_walkers_per_peer);
+int afq_comm_stats(afq_handle *h, int64_t *out);
+int afq_comm_parent_ix(afq_handle *h, int32_t *parent_ix_global);
+int afq_estimates_allreduce(afq_handle *h, double *buf, int nest);
+int afq_comm_init_local(afq_handle **handles, int n);
+int afq_popcontrol_comb_local(afq_handle **handles, int n, double r, double target_weight,
+                              int32_t *parent_ix_global, double *total_weight_out);
+int afq_estimates_allreduce_local(afq_handle **handles, int n);
 /* multi-rank building blocks: scale weights by 1/scale saving unscaled_weight
  * (handler.py:244-246); copy walker src -> dst inside this GPU; pack / unpack
  * the minimal walker state (phi + scalars) to a device buffer for transport;
@@ -239,10 +276,29 @@ int afq_walkers_reset_weights(afq_handle *h);
 /* estimators/mixed.py:180-225: accumulate the 10 mixed estimators over all
  * walkers on the device; eval_energy != 0 runs afq_greens + afq_local_energy. */
 int afq_estimates_update(afq_handle *h, int eval_energy);
+/* Synchronises the stream; also the place where a population that collapsed in an asynchronous comb is
+ * reported (AFQ_EWEIGHT, walkers/handler.py:236-241) and an exchange overflow (AFQ_EOVERFLOW).           */
 int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
 
 /* ---- misc ------------------------------------------------------------------ */
+/* Device stream of auxiliary fields (used by afq_propagate with xi == NULL; replaces numpy.random.normal of
+ * propagation/continuous.py:133 when parity with the host stream is not required): Philox4x32-10 (Salmon et
+ * al., SC'11), counter = (element pair index, launch counter ^ stream hash), key = seed, Box-Muller on two
+ * 53-bit uniforms.  `stream` must differ between ranks (qmc/utils.py:14 seeds seed + rank).
+ *   afq_rng_normal      the next n normals of the stream (what the next afq_propagate would have used)
+ *   afq_rng_philox4x32  the bare block function for known-answer tests: ctr_key uint32[n][6] =
+ *                       (counter[4], key[2]) -> out uint32[n][4]                                          */
 int afq_rng_seed(afq_handle *h, uint64_t seed, uint64_t stream);
+int afq_rng_normal(afq_handle *h, double *out, int64_t n);
+int afq_rng_philox4x32(afq_handle *h, const uint32_t *ctr_key, uint32_t *out, int n);
+/* Diagnostics.  Every kernel launch leaves its name in a host-side ring of the handle; afq_last_launch formats
+ * "api=<entry point> queued=<n> [retired=<m> first-unretired=<kernel>] last: <names>" into buf and may be
+ * called from a watchdog thread while the owning thread is blocked in a synchronising call (host memory only).
+ * afq_debug(h, sync, markers): sync != 0 synchronises and checks after every launch (a failing kernel is named
+ * in afq_last_error); markers != 0 queues a one-thread marker behind every launch so that `retired` counts the
+ * launches that completed.  Environment: AFQ_DEBUG_SYNC=1, AFQ_DEBUG_MARKERS=1 set them at afq_create.     */
+int afq_debug(afq_handle *h, int sync_every_launch, int markers);
+int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_t *retired);
 /* counters: [0]=nfb_trig (continuous.py:150), [1]=nhe_trig (:210,213)          */
 int afq_counters(afq_handle *h, int64_t *out, int reset);
 /* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libafqmc_hip.so")
 
 AFQ_OK = 0
+AFQ_EWEIGHT, AFQ_EOVERFLOW = -6, -7
 AFQ_SYS_GENERIC, AFQ_SYS_HUBBARD, AFQ_SYS_UEG = 1, 2, 3
 AFQ_PROP_HYBRID, AFQ_PROP_FORCE_BIAS, AFQ_PROP_FREE_PROJECTION, AFQ_PROP_HUBBARD_SPIN = 1, 2, 4, 8
 (F_PHI, F_WEIGHT, F_UNSCALED_WEIGHT, F_OT, F_HYBRID_ENERGY, F_PHASE, F_DETR, F_ELOC, F_GHALF, F_G,
@@ -78,6 +79,20 @@ SIGNATURES = {
     "afq_local_energy_full_g": [_h, _dp, c_int, _dp],
     "afq_set_trial_multi": [_h, c_int, _dp, _dp, _dp],
     "afq_walkers_det_weights": [_h, _dp],
+    "afq_rng_normal": [_h, _dp, c_int64],
+    "afq_rng_philox4x32": [_h, c_void_p, c_void_p, c_int],
+    "afq_debug": [_h, c_int, c_int],
+    "afq_last_launch": [_h, c_void_p, c_int, POINTER(c_uint64), POINTER(c_uint64)],
+    "afq_comm_unique_id": [c_void_p],
+    "afq_comm_init": [_h, c_void_p, c_int, c_int],
+    "afq_comm_destroy": [_h],
+    "afq_comm_set_capacity": [_h, c_int],
+    "afq_comm_stats": [_h, c_void_p],
+    "afq_comm_parent_ix": [_h, c_void_p],
+    "afq_estimates_allreduce": [_h, _dp, c_int],
+    "afq_comm_init_local": [POINTER(_h), c_int],
+    "afq_popcontrol_comb_local": [POINTER(_h), c_int, c_double, c_double, c_void_p, POINTER(c_double)],
+    "afq_estimates_allreduce_local": [POINTER(_h), c_int],
     "afq_kernel_trace": [_h, c_int],
     "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],
 }

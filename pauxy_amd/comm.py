@@ -149,3 +149,43 @@ class TorchComm(object):
 
     def recv_tensor(self, t, source, tag=0):
         self._dist.recv(t, src=source, group=self.group, tag=tag)
+
+
+class ReducedComm(object):
+    """Stands in for the communicator in ``Mixed.print_step`` when the sums it is handed are already global
+    (``afq_estimates_allreduce`` on the device accumulators): Reduce copies, every rank holds the result."""
+    reduce_is_allreduce = True
+    already_reduced = True
+
+    def __init__(self, comm):
+        self.rank, self.size = comm.rank, comm.size
+
+    def Reduce(self, send, recv, op=None, root=0):
+        recv[...] = send
+
+    Allreduce = Reduce
+
+    def bcast(self, obj, root=0):
+        return obj
+
+
+class DeviceComm(object):
+    """Reductions of host arrays over the library-owned RCCL communicator of an AfqDevice
+    (``afq_estimates_allreduce`` with a host buffer): what estimators other than ``mixed`` use when the
+    population control already runs on that communicator, so that no second communicator is active
+    inside the step loop."""
+    reduce_is_allreduce = True
+
+    def __init__(self, dev, comm):
+        self.dev = dev
+        self.rank, self.size = comm.rank, comm.size
+
+    def Allreduce(self, send, recv, op=None):
+        out = self.dev.estimates_allreduce(numpy.asarray(send, dtype=numpy.complex128))
+        recv[...] = out.reshape(recv.shape) if numpy.iscomplexobj(recv) else out.real.reshape(recv.shape)
+
+    def Reduce(self, send, recv, op=None, root=0):
+        self.Allreduce(send, recv)
+
+    def bcast(self, obj, root=0):
+        return obj

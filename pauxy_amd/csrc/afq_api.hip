@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "afq_internal.h"
@@ -154,9 +155,25 @@ static int maybe_build_rH1(afq_handle *h) {
     return build_rH1(h, c->H1, c->psi);
 }
 
+__global__ void afq_marker_kernel(volatile unsigned long long *retired, unsigned long long n) { *retired = n; }
+
+hipError_t afq_post_launch(afq_handle *h) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (h->debug_markers) {
+        unsigned long long *dptr = nullptr;
+        if (hipHostGetDevicePointer((void **)&dptr, (void *)h->retired, 0) == hipSuccess)
+            hipLaunchKernelGGL(afq_marker_kernel, dim3(1), dim3(1), 0, h->stream, dptr, (unsigned long long)h->n_launch);
+    }
+    if (h->debug_sync) e = hipStreamSynchronize(h->stream);
+    return e;
+}
+
+#define AFQ_API(h, name) do { if (h) (h)->crumb_api = name; } while (0)
+
 extern "C" {
 
-int afq_version(void) { return 1; }
+int afq_version(void) { return 2; }
 
 int afq_create(int device_id, afq_handle **out) {
     if (!out) return AFQ_EINVAL;
@@ -178,10 +195,19 @@ int afq_create(int device_id, afq_handle **out) {
     hipMemset(h->scal, 0, sizeof(double) * 8);
     if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->zero_page, 0, 256);
-    h->no_ring = getenv("AFQ_NO_RING") != nullptr;
-    h->no_fused = getenv("AFQ_NO_FUSED") != nullptr;
-    h->no_vhs_upper = getenv("AFQ_VHS_MIRROR") != nullptr;
-    h->greens_cache = getenv("AFQ_NO_GREENS_CACHE") == nullptr;
+    // diagnostics (not tuning): AFQ_DEBUG_SYNC=1 synchronises and checks after every launch (a failing kernel is
+    // named in afq_last_error), AFQ_DEBUG_MARKERS=1 queues a marker behind every launch so that afq_last_launch
+    // can tell the last launch that RETIRED apart from the last one queued
+    if (hipHostMalloc((void **)&h->retired, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) {
+        delete h; return AFQ_ENOMEM;
+    }
+    *h->retired = 0;
+    h->debug_sync = getenv("AFQ_DEBUG_SYNC") != nullptr && atoi(getenv("AFQ_DEBUG_SYNC")) != 0;
+    h->debug_markers = getenv("AFQ_DEBUG_MARKERS") != nullptr && atoi(getenv("AFQ_DEBUG_MARKERS")) != 0;
+    h->no_ring = afq_knob("AFQ_NO_RING") != nullptr;
+    h->no_fused = afq_knob("AFQ_NO_FUSED") != nullptr;
+    h->no_vhs_upper = afq_knob("AFQ_VHS_MIRROR") != nullptr;
+    h->greens_cache = afq_knob("AFQ_NO_GREENS_CACHE") == nullptr;
     *out = h;
     return AFQ_OK;
 }
@@ -190,11 +216,13 @@ int afq_destroy(afq_handle *h) {
     if (!h) return AFQ_EINVAL;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    k_comm_destroy(h);
     free_walkers(h);
     free_system(h);
     dev_free(h->psi); dev_free(h->psic); dev_free(h->BH1); dev_free(h->mf_shift);
     dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
     if (h->zero_page) hipFree(h->zero_page);
+    if (h->retired) hipHostFree((void *)h->retired);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
     for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
@@ -268,7 +296,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
     {   // hs_pot^T : [K, ld_hs] so that a VHS B-fragment is contiguous (even, zero-padded rows: the
         // LDS-DMA path moves 16-byte pairs of doubles).  Cholesky matrices of real orbitals are
         // symmetric in (p, q); then only the columns p <= q are kept and the VHS GEMM does half the work.
-        bool sym = getenv("AFQ_VHS_FULL") == nullptr;
+        bool sym = afq_knob("AFQ_VHS_FULL") == nullptr;
         for (int p = 0; p < M && sym; ++p)
             for (int q = p + 1; q < M && sym; ++q) {
                 const double *a = hs_pot + ((size_t)p * M + q) * K, *b = hs_pot + ((size_t)q * M + p) * K;
@@ -501,7 +529,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
             const long wgt = (long)((nw + 63) / 64) * ((h->K + 63) / 64) * 2;
             sp = (int)std::max(1L, std::min(16L, (512 + wgt - 1) / wgt));
         }
-        if (getenv("AFQ_FB_SPLIT")) sp = atoi(getenv("AFQ_FB_SPLIT"));
+        if (afq_knob("AFQ_FB_SPLIT")) sp = atoi(afq_knob("AFQ_FB_SPLIT"));
         const int nmax = std::max(h->na, h->nb) * h->M;
         while (sp > 1 && nmax / sp < 64) --sp;
         h->fb_split = sp;
@@ -519,9 +547,12 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
 #undef A_
     AFQ_HIP(h, hipMalloc(&h->pack_tmp, std::max((size_t)nw * 2 * sizeof(int), (size_t)4096)));
     h->nw = nw;
-    {   // walker.total_weight starts as the population size (walkers/handler.py:164)
-        const double tw0 = (double)nw;
-        AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
+    h->cap_frac = 0.0; h->cap_total = -1.0;       // a cap armed for an earlier population does not carry over
+    {   // walker.total_weight starts as the population size (walkers/handler.py:164); with a communicator
+        // the population is nw walkers on every rank
+        double sc0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        sc0[0] = (double)nw * k_comm_size(h);
+        AFQ_HIP(h, hipMemcpy(h->scal, sc0, sizeof(sc0), hipMemcpyHostToDevice));
     }
     // defaults of walkers/walker.py:24-61
     std::vector<double> one(nw, 1.0), zero2(2 * (size_t)nw, 0.0), one2(2 * (size_t)nw, 0.0);
@@ -626,6 +657,7 @@ static int copy_out(afq_handle *h, void *host, const void *dev, size_t bytes) {
 }
 
 int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
+    AFQ_API(h, "afq_greens");
     if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
@@ -664,6 +696,7 @@ int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
 }
 
 int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
+    AFQ_API(h, "afq_calc_overlap");
     if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
@@ -721,6 +754,7 @@ static int apply_exp(afq_handle *h, const cplx *vhs) {
 }
 
 int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im) {
+    AFQ_API(h, "afq_propagate");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -794,6 +828,7 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
 }
 
 int afq_reortho(afq_handle *h, double *detR_out) {
+    AFQ_API(h, "afq_reortho");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) { h->greens_valid = false; return rc; }
@@ -837,6 +872,7 @@ static int local_energy(afq_handle *h) {
 }
 
 int afq_local_energy(afq_handle *h, double *E_out) {
+    AFQ_API(h, "afq_local_energy");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -954,21 +990,25 @@ int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
 
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *parent_ix,
                         double *total_weight_out) {
+    AFQ_API(h, "afq_popcontrol_comb");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) { h->greens_valid = false; return rc; }
-    if (h->nw == 1) return AFQ_OK;                       // handler.py:226-227
-    // a kept Green's function travels with the cloned walkers (k_comb copies Ghalf and the cached overlap)
+    const int nranks = k_comm_size(h);
+    if (h->nw * nranks == 1) return AFQ_OK;              // handler.py:226-227
+    // a kept Green's function travels with the cloned walkers (the clone / pack kernels copy Ghalf and the cached overlap)
     const bool keep = h->greens_valid && h->ndet == 1;
     h->greens_valid = false;
     if ((rc = k_comb(h, r, target_weight, keep))) return rc;
     h->greens_valid = keep;
     if (!parent_ix && !total_weight_out) return AFQ_OK;  // asynchronous: nothing read back, no host sync
-    double sc[2];
+    double sc[4];
     if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;
     if (total_weight_out) *total_weight_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8");
+    if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "more walkers moved between two ranks than the exchange slots hold");
     if (!parent_ix) return AFQ_OK;
+    if (h->comm) return afq_comm_parent_ix(h, parent_ix);   // the global comb, [nranks * nw]
     return copy_out(h, parent_ix, h->parent_ix, sizeof(int) * h->nw);
 }
 
@@ -1059,6 +1099,7 @@ int afq_walkers_copy(afq_handle *h, int src, int dst) {
 }
 
 int afq_estimates_update(afq_handle *h, int eval_energy) {
+    AFQ_API(h, "afq_estimates_update");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1078,11 +1119,19 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
 }
 
 int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
+    AFQ_API(h, "afq_estimates_get");
     if (!h || !est_out) return AFQ_EINVAL;
     hipSetDevice(h->device);
+    // the one host synchronisation of a block of steps also reports a population that collapsed in an
+    // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
+    double sc[4];
+    AFQ_HIP(h, hipMemcpyAsync(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
     int rc = copy_out(h, est_out, h->estimates, sizeof(cplx) * AFQ_EST_COUNT_);
     if (rc) return rc;
     if (zero) AFQ_HIP(h, hipMemsetAsync(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_, h->stream));
+    if (sc[2] != 0.0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8 in an earlier population control");
+    if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "population control: more walkers moved between two ranks than the "
+                                                 "exchange slots hold (afq_comm_init capacity)");
     return AFQ_OK;
 }
 
@@ -1090,6 +1139,56 @@ int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
 int afq_rng_seed(afq_handle *h, uint64_t seed, uint64_t stream) {
     if (!h) return AFQ_EINVAL;
     h->rng_seed = seed; h->rng_stream = stream; h->rng_counter = 0;
+    return AFQ_OK;
+}
+
+int afq_rng_normal(afq_handle *h, double *out, int64_t n) {
+    if (!h || !out || n < 1) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    double *tmp = nullptr;
+    int rc = dev_alloc(h, &tmp, (size_t)n);
+    if (rc) return rc;
+    rc = k_rng_normal_into(h, tmp, (long)n);
+    if (!rc) rc = copy_out(h, out, tmp, sizeof(double) * (size_t)n);
+    dev_free(tmp);
+    return rc;
+}
+
+int afq_rng_philox4x32(afq_handle *h, const uint32_t *ctr_key, uint32_t *out, int n) {
+    if (!h || !ctr_key || !out || n < 1) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    uint32_t *in_d = nullptr, *out_d = nullptr;
+    int rc = dev_upload(h, &in_d, ctr_key, (size_t)6 * n);
+    if (!rc) rc = dev_alloc(h, &out_d, (size_t)4 * n);
+    if (!rc) rc = k_philox_raw(h, in_d, out_d, n);
+    if (!rc) rc = copy_out(h, out, out_d, sizeof(uint32_t) * 4 * (size_t)n);
+    dev_free(in_d); dev_free(out_d);
+    return rc;
+}
+
+int afq_debug(afq_handle *h, int sync_every_launch, int markers) {
+    if (!h) return AFQ_EINVAL;
+    h->debug_sync = sync_every_launch != 0;
+    h->debug_markers = markers != 0;
+    return AFQ_OK;
+}
+
+// Readable from a watchdog thread while the owning thread is blocked inside a synchronising call: touches
+// host memory only (no HIP call, no lock).
+int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_t *retired) {
+    if (!h || !buf || len < 1) return AFQ_EINVAL;
+    const unsigned long long n = h->n_launch, r = h->retired ? *h->retired : 0ull;
+    if (queued) *queued = n;
+    if (retired) *retired = h->debug_markers ? r : 0ull;
+    std::string txt = std::string("api=") + (h->crumb_api ? h->crumb_api : "") + " queued=" + std::to_string(n);
+    if (h->debug_markers) {
+        txt += " retired=" + std::to_string(r);
+        if (r < n && h->crumb_name[r & 63] && n - r <= 64) txt += std::string(" first-unretired=") + h->crumb_name[r & 63];
+    }
+    txt += " last:";
+    for (unsigned long long i = n > 8 ? n - 8 : 0; i < n; ++i)
+        txt += std::string(" ") + (h->crumb_name[i & 63] ? h->crumb_name[i & 63] : "?");
+    snprintf(buf, (size_t)len, "%s", txt.c_str());
     return AFQ_OK;
 }
 
@@ -1214,6 +1313,7 @@ int afq_hirsch_finish(afq_handle *h, double eshift) {
 }
 
 int afq_propagate_hirsch(afq_handle *h, double eshift) {
+    AFQ_API(h, "afq_propagate_hirsch");
     if (h) h->greens_valid = false;
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
@@ -1266,6 +1366,7 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
 
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
                   double *est_out) {
+    AFQ_API(h, "afq_bp_update");
     if (h) h->greens_valid = false;
     if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
     int rc = need_ready(h, true);

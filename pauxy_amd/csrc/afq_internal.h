@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/afqmc_hip.h"
@@ -185,6 +186,17 @@ struct afq_handle {
     // rng
     uint64_t rng_seed = 0, rng_stream = 0, rng_counter = 0;
 
+    // diagnostics: host-side breadcrumbs of the launches queued on the stream (afq_last_launch)
+    const char *crumb_name[64] = {nullptr};     // ring of the last 64 kernel names (string literals)
+    const char *crumb_api = "";                 // C-ABI entry point that queued them
+    volatile unsigned long long n_launch = 0;   // launches queued so far
+    bool debug_sync = false;                    // AFQ_DEBUG_SYNC=1: synchronise + check after every launch
+    bool debug_markers = false;                 // AFQ_DEBUG_MARKERS=1: a 1-thread marker kernel behind every launch
+    volatile unsigned long long *retired = nullptr;   // pinned, device-mapped: index of the last RETIRED launch
+
+    // library-owned RCCL communicator (afq_comm_init; walkers/handler.py:232,291,313,322, mixed.py:261,273)
+    void *comm = nullptr;                       // afq_comm_state (k_comm.hip)
+
     // timers
     bool timers_on = false;
     double t_ms[T_COUNT] = {0};
@@ -200,6 +212,53 @@ struct afq_handle {
             return AFQ_EHIP;                                                    \
         }                                                                       \
     } while (0)
+
+// tuning / A-B switches read from the environment exist only in builds made with -DAFQ_TUNING
+// (make TUNING=1); the product library has none of them
+#ifdef AFQ_TUNING
+inline const char *afq_knob(const char *name) { return getenv(name); }
+#else
+inline const char *afq_knob(const char *) { return nullptr; }
+#endif
+
+// every kernel launch goes through AFQ_LAUNCH / AFQ_GEMM + AFQ_POST: the name of the kernel is left in the
+// handle's breadcrumb ring before the launch, and AFQ_POST checks the launch (and, in the debug modes,
+// queues a marker or synchronises so that a failing or hanging kernel is identified by name)
+inline void afq_note_launch(afq_handle *h, const char *name) {
+    h->crumb_name[h->n_launch & 63] = name;
+    h->n_launch = h->n_launch + 1;
+}
+hipError_t afq_post_launch(afq_handle *h);      // afq_api.hip
+#define AFQ_LAUNCH(h, kern, ...) do { afq_note_launch((h), #kern); hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
+#define AFQ_POST(h)                                                              \
+    do {                                                                        \
+        hipError_t e_ = afq_post_launch(h);                                     \
+        if (e_ != hipSuccess) {                                                 \
+            (h)->err = std::string("kernel ") + (h)->crumb_name[((h)->n_launch - 1) & 63] + ": " + hipGetErrorString(e_); \
+            return AFQ_EHIP;                                                    \
+        }                                                                       \
+    } while (0)
+#define AFQ_GEMM(h, call)                                                       \
+    do {                                                                        \
+        afq_note_launch((h), __func__);                                         \
+        hipError_t e_ = (call);                                                 \
+        if (e_ == hipSuccess) e_ = afq_post_launch(h);                          \
+        if (e_ != hipSuccess) {                                                 \
+            (h)->err = std::string("GEMM of ") + __func__ + ": " + hipGetErrorString(e_); \
+            return AFQ_EHIP;                                                    \
+        }                                                                       \
+    } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (kernel, device): raise it once per device
+#define AFQ_MAX_DEVICES 16
+inline hipError_t afq_raise_lds(const void *kern, size_t lds, size_t (&set)[AFQ_MAX_DEVICES]) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= AFQ_MAX_DEVICES) d = -1;
+    if (d >= 0 && lds <= set[d]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && d >= 0) set[d] = lds;
+    return e;
+}
 
 #define AFQ_FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
 
@@ -280,11 +339,18 @@ int k_update_weight(afq_handle *h, cplx eshift);
 int k_reortho(afq_handle *h);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);
 int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
+int k_clone_pairs(afq_handle *h, bool with_greens);
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[w]
 int k_scale_weights(afq_handle *h, double scale);
-int k_reset_weights(afq_handle *h);
+int k_reset_weights(afq_handle *h, bool after_comb = false);
 int k_estimates(afq_handle *h, int have_energy);
 int k_rng_normal(afq_handle *h);
+int k_rng_normal_into(afq_handle *h, double *out_d, long n);
+int k_philox_raw(afq_handle *h, const unsigned int *in_d, unsigned int *out_d, int n);
+// k_comm.hip
+int k_comm_size(afq_handle *h);                             // ranks of the library-owned communicator (1 without)
+void k_comm_destroy(afq_handle *h);
+int k_comm_popcontrol(afq_handle *h, double r, double target, bool with_greens);
 // k_energy.hip
 int k_energy_generic(afq_handle *h);
 int k_prepare_energy_operands(afq_handle *h, const double *rchol_host);

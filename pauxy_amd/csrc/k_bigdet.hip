@@ -289,24 +289,24 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
         p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
         p.phi = h->phi; p.psic = h->psic; p.psi_stride = h->psi_stride; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
-        AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OvlpProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OvlpProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     }
     {
         GjArgs a;
         a.na = h->na; a.nb = h->nb; a.ld = nmax; a.write_inverse = ghalf != nullptr;
         a.O = h->big_ws; a.detm = h->detm; a.dete = h->dete;
-        hipLaunchKernelGGL(gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
-        AFQ_HIP(h, hipGetLastError());
-        hipLaunchKernelGGL(det_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detm,
+        AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+        AFQ_POST(h);
+        AFQ_LAUNCH(h, det_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detm,
                            h->dete, det, h->nw);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
     }
     if (ghalf) {
         GhalfProb p;
         p.batch = nb2; p.rows = nmax; p.cols = h->M; p.kdim = nmax;
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
         p.Oinv = h->big_ws; p.phi = h->phi; p.ghalf = ghalf; p.zero = (const cplx *)h->zero_page;
-        AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GhalfProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GhalfProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     }
     return AFQ_OK;
 }
@@ -556,26 +556,26 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
-            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         }
         {
             CholArgs a;
             a.na = h->na; a.nb = h->nb; a.ld = nmax;
             a.S = h->big_ws; a.Tt = h->big_ws2; a.logd = h->qr_logd + (size_t)pass * nb2; a.fail = h->qr_fail;
-            if (nmax <= 32) hipLaunchKernelGGL(chol_small_kernel, dim3((nb2 + 3) / 4), dim3(256), 0, h->stream, a, nb2);
-            else hipLaunchKernelGGL(chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
-            AFQ_HIP(h, hipGetLastError());
+            if (nmax <= 32) AFQ_LAUNCH(h, chol_small_kernel, dim3((nb2 + 3) / 4), dim3(256), 0, h->stream, a, nb2);
+            else AFQ_LAUNCH(h, chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            AFQ_POST(h);
         }
         {
             QProb p;
             p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
-            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         }
     }
-    hipLaunchKernelGGL(qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,
+    AFQ_LAUNCH(h, qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,
                        h->qr_fail, h->detR, h->ot, h->weight, h->nw, (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }

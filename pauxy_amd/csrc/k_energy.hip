@@ -20,7 +20,7 @@
 //   afrag[s][i][xt][ks][lane] = rchol_s[(i, p = 4 ks + lane/16), x = 16 xt + lane%16]   (built once)
 //   gfrag[orb][c][wt][ks][lane] = (re|im) Ghalf[w = 16 wt + lane%16][orb][p = 4 ks + lane/16]
 #include <cstdlib>
-#include "mfma_gemm_ring.h"
+#include "lds_dma.h"
 
 #define EXX_CHUNKS 2      // wave-tasks per (spin, x-tile, walker-tile) cell
 
@@ -209,195 +209,6 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
     if (lane < 16) a.part[task * 16 + lane] = cmake(sr, si);
 }
 
-// --------------------------------------------------------------------------
-// exx2: same tile choice (16 Cholesky indices x 16 walkers per orbital pair),
-// reorganised around what can stay on chip.
-//   work-group  = (spin, x-tile, super-pair): 4 waves, super-pair = two blocks I, J of 4 orbitals
-//   streamed    : per k-step the 8 rchol fragments (4 KB) and the 16 Ghalf fragments (8 KB) of the 8
-//                 orbitals, walker tile after walker tile, through a 4-slot LDS ring filled by
-//                 global_load_lds (one raw s_barrier per k-step); 52 KB of LDS -> 3 work-groups per CU,
-//                 so barrier / LDS latency of one work-group hides under the MFMAs of the others
-//   wave (a, b) : tiles T[I_a x J_b] and their transposes S[J_b x I_a] (2x2 orbitals each), lane-local trace
-// Work-groups are numbered so that the 32 x-tiles of one (spin, super-pair) run side by side on the 32
-// CUs of one XCD: they stream the SAME Ghalf fragments, which therefore come from that XCD's L2.
-// Per MFMA the kernel moves 2.5x fewer bytes from L2 than exx_kernel (which reloads every fragment for
-// every orbital-pair block) and none of them on the critical path.
-#define EX2_D 4
-struct Exx2Args {
-    int nw, nt, nks, nxt, nwt, nwpad;
-    int ns[2], goff[2], nsb[2], nsp[2];       // orbitals, Ghalf row offset, super-blocks, super-pairs per spin
-    const double *afrag[2];
-    const double *gfrag;
-    cplx *part;                               // [ngroup * nxt, nwpad]
-    const void *zero16;
-};
-
-__global__ __launch_bounds__(256) void exx2_kernel(Exx2Args a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- which (spin, super-pair, x-tile)
-    const int xcd = blockIdx.x & 7;
-    const int r = blockIdx.x >> 3;
-    const int grp = (r / a.nxt) * 8 + xcd;
-    const int xt = r % a.nxt;
-    const int ngrp = a.nsp[0] + a.nsp[1];
-    if (grp >= ngrp) return;
-    const int s = grp < a.nsp[0] ? 0 : 1;
-    int sp = grp - (s ? a.nsp[0] : 0);
-    // heavy (off-diagonal) super-pairs first: sp enumerates (IB < JB) pairs, then the diagonal ones
-    const int nsb = a.nsb[s], noff = nsb * (nsb - 1) / 2;
-    int IB = 0, JB = 0;
-    if (sp < noff) {
-        int q = sp;
-        for (IB = 0; IB < nsb; ++IB) { const int cnt = nsb - 1 - IB; if (q < cnt) { JB = IB + 1 + q; break; } q -= cnt; }
-    } else { IB = JB = sp - noff; }
-    const bool diag = IB == JB;
-    const int ns = a.ns[s];
-    // orbital of LDS slot o (0..3 -> block I, 4..7 -> block J); -1 when past the last orbital
-    auto orb_of = [&](int o) { const int x = (o < 4 ? 4 * IB + o : 4 * JB + o - 4); return (x < ns && !(diag && o >= 4)) ? x : -1; };
-    // ---- LDS carve: ring[EX2_D] of { 8 rchol fragments (512 B each) | 8 x (re 512 | im 512) Ghalf fragments }
-    constexpr int SLOT = 4096 + 8192;
-    unsigned char *ring = smem;
-    unsigned char *scratch = ring + (size_t)EX2_D * SLOT + wave * 1024;
-    const unsigned ring_l = lds_addr(ring);
-    const int half = lane >> 5, lp = lane & 31;
-    const long astride_i = (long)a.nxt * a.nks * 64;
-    const long gstride_o = 2L * a.nwt * a.nks * 64, gstride_c = (long)a.nwt * a.nks * 64;
-    // ---- stream step q = (wt, ks).  Per step wave v issues 3 DMA instructions:
-    //   rchol fragments of slots (2v, 2v+1)   (lanes 0-31 -> slot 2v, lanes 32-63 -> slot 2v+1)
-    //   Ghalf fragments (re | im) of slot 2v and of slot 2v+1
-    const int Q = a.nwt * a.nks;
-    int orb_w[2];
-    orb_w[0] = orb_of(2 * wave); orb_w[1] = orb_of(2 * wave + 1);
-    int ks_i = 0, wt_i = 0;                  // (wt, ks) of the next step to issue
-    auto issueB = [&](int q, int slot) {
-        unsigned char *dst = ring + (size_t)slot * SLOT;
-        {
-            const int orb = orb_w[half];
-            const void *src = a.zero16;
-            if (q < Q && orb >= 0) src = a.afrag[s] + (long)orb * astride_i + ((long)xt * a.nks + ks_i) * 64 + lp * 2;
-            glds16(src, dst + (2 * wave) * 512);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const void *src = a.zero16;
-            if (q < Q && orb_w[u] >= 0)
-                src = a.gfrag + (long)(a.goff[s] + orb_w[u]) * gstride_o + half * gstride_c + (long)q * 64 + lp * 2;
-            glds16(src, orb_w[u] >= 0 ? dst + 4096 + (2 * wave + u) * 1024 : scratch);
-        }
-        if (++ks_i == a.nks) { ks_i = 0; ++wt_i; }
-    };
-#pragma unroll
-    for (int q = 0; q < EX2_D - 1; ++q) issueB(q, q);
-    // ---- this wave's tiles
-    int i_slot[2], j_slot[2], ci, cj;
-    bool self;
-    if (!diag) {
-        const int wa = wave >> 1, wb = wave & 1;
-        i_slot[0] = 2 * wa; i_slot[1] = 2 * wa + 1; j_slot[0] = 4 + 2 * wb; j_slot[1] = 5 + 2 * wb;
-        ci = (orb_of(i_slot[0]) >= 0) + (orb_of(i_slot[1]) >= 0);
-        cj = (orb_of(j_slot[0]) >= 0) + (orb_of(j_slot[1]) >= 0);
-        self = false;
-    } else if (wave == 0 || wave == 3) {
-        i_slot[0] = wave == 0 ? 0 : 2; i_slot[1] = i_slot[0] + 1; j_slot[0] = j_slot[1] = 0;
-        ci = (orb_of(i_slot[0]) >= 0) + (orb_of(i_slot[1]) >= 0); cj = 0;
-        self = true;
-    } else {
-        i_slot[0] = wave - 1; i_slot[1] = 0; j_slot[0] = 2; j_slot[1] = 3;
-        ci = orb_of(i_slot[0]) >= 0 ? 1 : 0;
-        cj = (orb_of(2) >= 0) + (orb_of(3) >= 0);
-        self = false;
-    }
-    const bool work = self ? ci > 0 : (ci > 0 && cj > 0);
-    d4_t Tr[2][2], Ti[2][2], Sr[2][2], Si[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            Tr[x][y] = (d4_t){0, 0, 0, 0}; Ti[x][y] = (d4_t){0, 0, 0, 0};
-            Sr[x][y] = (d4_t){0, 0, 0, 0}; Si[x][y] = (d4_t){0, 0, 0, 0};
-        }
-    int ks = 0, wt = 0;
-    for (int q = 0; q < Q; ++q) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((EX2_D - 2) * 3) : "memory");
-        __builtin_amdgcn_s_barrier();
-        issueB(q + EX2_D - 1, (q + EX2_D - 1) & (EX2_D - 1));
-        if (work) {
-            const unsigned al = ring_l + (q & (EX2_D - 1)) * SLOT + lane * 8;
-            const unsigned sl = al + 4096;
-            double Ai_[2], Aj_[2], Bir[2], Bii[2], Bjr[2], Bji[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                if (x < ci) {
-                    Ai_[x] = lds_read_b64(al + i_slot[x] * 512);
-                    Bir[x] = lds_read_b64(sl + i_slot[x] * 1024);
-                    Bii[x] = lds_read_b64(sl + i_slot[x] * 1024 + 512);
-                }
-                if (x < cj) {
-                    Aj_[x] = lds_read_b64(al + j_slot[x] * 512);
-                    Bjr[x] = lds_read_b64(sl + j_slot[x] * 1024);
-                    Bji[x] = lds_read_b64(sl + j_slot[x] * 1024 + 512);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (self) {
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-                        if (x < ci && y < ci) {
-                            Tr[x][y] = mfma16(Ai_[x], Bir[y], Tr[x][y]);
-                            Ti[x][y] = mfma16(Ai_[x], Bii[y], Ti[x][y]);
-                        }
-            } else {
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-                        if (x < ci && y < cj) {
-                            Tr[x][y] = mfma16(Ai_[x], Bjr[y], Tr[x][y]);
-                            Ti[x][y] = mfma16(Ai_[x], Bji[y], Ti[x][y]);
-                            Sr[y][x] = mfma16(Aj_[y], Bir[x], Sr[y][x]);
-                            Si[y][x] = mfma16(Aj_[y], Bii[x], Si[y][x]);
-                        }
-            }
-        }
-        if (++ks == a.nks) {
-            // walker tile finished: lane-local trace, then the 4 row groups of each walker column
-            double sr = 0.0, si = 0.0;
-            if (work) {
-                if (self) {
-                    cmul_acc(sr, si, Tr[0][0], Ti[0][0], Tr[0][0], Ti[0][0], 1.0);
-                    if (ci == 2) {
-                        cmul_acc(sr, si, Tr[1][1], Ti[1][1], Tr[1][1], Ti[1][1], 1.0);
-                        cmul_acc(sr, si, Tr[0][1], Ti[0][1], Tr[1][0], Ti[1][0], 2.0);
-                    }
-                } else {
-#pragma unroll
-                    for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int y = 0; y < 2; ++y)
-                            if (x < ci && y < cj) cmul_acc(sr, si, Tr[x][y], Ti[x][y], Sr[y][x], Si[y][x], 2.0);
-                }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        Tr[x][y] = (d4_t){0, 0, 0, 0}; Ti[x][y] = (d4_t){0, 0, 0, 0};
-                        Sr[x][y] = (d4_t){0, 0, 0, 0}; Si[x][y] = (d4_t){0, 0, 0, 0};
-                    }
-            }
-            sr += __shfl_xor(sr, 16); si += __shfl_xor(si, 16);
-            sr += __shfl_xor(sr, 32); si += __shfl_xor(si, 32);
-            // every wave owns its own row of partial sums (deterministic: no atomics)
-            if (lane < 16) a.part[(((long)grp * a.nxt + xt) * 4 + wave) * a.nwpad + wt * 16 + lane] = cmake(sr, si);
-            ks = 0; ++wt;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // Ghalf [nw, nt, M] -> fragment order (see header comment)
 __global__ void gfrag_kernel(const cplx *ghalf, double *gfrag, int nw, int nt, int M, int nwt, int nks) {
     const int lane = threadIdx.x & 63;
@@ -416,7 +227,6 @@ __global__ void gfrag_kernel(const cplx *ghalf, double *gfrag, int nw, int nt, i
 
 struct EFinArgs {
     int M, K, nw, nt, nsplit, nxt, nwt;
-    int nrows2, nwpad;          // exx2 partials: [nrows2, nwpad]; nrows2 == 0 -> exx_kernel layout
     double ecore;
     const cplx *rH1, *ghalf, *vbias, *part;
     cplx *energy;
@@ -445,13 +255,7 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
     // exchange partials of this walker
     double exr = 0, exi = 0;
     const int wt = w >> 4, wl = w & 15;
-    if (a.nrows2 > 0) {
-        for (int t = tid; t < a.nrows2; t += 256) {
-            const cplx v = a.part[(long)t * a.nwpad + w];
-            exr += v.x; exi += v.y;
-        }
-    }
-    const int np = a.nrows2 > 0 ? 0 : 2 * a.nxt * EXX_CHUNKS;
+    const int np = 2 * a.nxt * EXX_CHUNKS;
     for (int t = tid; t < np; t += 256) {
         const int chunk = t % EXX_CHUNKS;
         const int xt = (t / EXX_CHUNKS) % a.nxt;
@@ -524,49 +328,10 @@ int k_energy_generic(afq_handle *h) {
     }
     {
         const long nf = (long)h->nt * nwt * nks;
-        hipLaunchKernelGGL(gfrag_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, h->stream, h->ghalf,
+        AFQ_LAUNCH(h, gfrag_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, h->stream, h->ghalf,
                            h->gfrag, h->nw, h->nt, M, nwt, nks);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
     }
-    // exx2 (LDS-resident rchol fragments) when they fit; exx_kernel otherwise / for complex rchol
-    const size_t lds2 = (size_t)EX2_D * (4096 + 8192) + 4 * 1024;
-    // exx2 (work-group LDS ring) measured slower than the software-pipelined exx_kernel on MI355X
-    // (1.76 ms vs 1.28 ms at C3): kept selectable for A/B runs only
-    static const bool want_v2 = getenv("AFQ_EXX_V2") != nullptr;
-    const bool use2 = h->rchol_real && want_v2;
-    int nrows2 = 0;
-    const int nwpad = nwt * 16;
-    if (use2) {
-        Exx2Args a;
-        a.nw = h->nw; a.nt = h->nt; a.nks = nks; a.nxt = nxt; a.nwt = nwt; a.nwpad = nwpad;
-        a.ns[0] = h->na; a.ns[1] = h->nb; a.goff[0] = 0; a.goff[1] = h->na;
-        for (int s = 0; s < 2; ++s) {
-            a.nsb[s] = (a.ns[s] + 3) / 4;
-            a.nsp[s] = a.nsb[s] * (a.nsb[s] + 1) / 2;
-        }
-        a.afrag[0] = h->rchol_frag[0]; a.afrag[1] = h->rchol_frag[1];
-        a.gfrag = h->gfrag; a.zero16 = h->zero_page;
-        const int ngrp = a.nsp[0] + a.nsp[1];
-        nrows2 = ngrp * nxt * 4;
-        const long need = (long)nrows2 * nwpad;
-        if (h->exx_part_len < need) {
-            if (h->exx_part) hipFree(h->exx_part);
-            AFQ_HIP(h, hipMalloc(&h->exx_part, sizeof(cplx) * need));
-            h->exx_part_len = need;
-        }
-        a.part = h->exx_part;
-        static size_t lds_set = 0;
-        if (lds2 > lds_set) {
-            AFQ_HIP(h, hipFuncSetAttribute((const void *)exx2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            lds_set = lds2;
-        }
-        const unsigned nblk = (unsigned)(8 * ((ngrp + 7) / 8) * nxt);
-        AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
-        hipLaunchKernelGGL(exx2_kernel, dim3(nblk), dim3(256), lds2, h->stream, a);
-        AFQ_HIP(h, hipGetLastError());
-        AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
-        h->energy_ev_valid = true;
-    } else {
     const long ntask = 2L * nxt * nwt * EXX_CHUNKS;
     if (h->exx_part_len < ntask * 16) {
         if (h->exx_part) hipFree(h->exx_part);
@@ -581,23 +346,22 @@ int k_energy_generic(afq_handle *h) {
     a.gfrag = h->gfrag; a.part = h->exx_part;
     AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
     {
-    KernelTrace kt(h, AFQ_K_EXCHANGE);
-    const long per_xcd = 2L * nxt * ((nwt + 7) / 8) * EXX_CHUNKS;
-    const unsigned nblk = (unsigned)(8 * ((per_xcd + 3) / 4));
-    if (h->rchol_real)
-        hipLaunchKernelGGL(exx_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, a);
-    else
-        hipLaunchKernelGGL(exx_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, a);
+        KernelTrace kt(h, AFQ_K_EXCHANGE);
+        const long per_xcd = 2L * nxt * ((nwt + 7) / 8) * EXX_CHUNKS;
+        const unsigned nblk = (unsigned)(8 * ((per_xcd + 3) / 4));
+        if (h->rchol_real)
+            AFQ_LAUNCH(h, exx_kernel<false>, dim3(nblk), dim3(256), 0, h->stream, a);
+        else
+            AFQ_LAUNCH(h, exx_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, a);
     }
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
     h->energy_ev_valid = true;
-    }
     EFinArgs f;
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
-    f.energy = h->energy; f.nrows2 = nrows2; f.nwpad = nwpad;
-    hipLaunchKernelGGL(energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
-    AFQ_HIP(h, hipGetLastError());
+    f.energy = h->energy;
+    AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
+    AFQ_POST(h);
     return AFQ_OK;
 }

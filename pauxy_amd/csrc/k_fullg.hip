@@ -142,9 +142,9 @@ int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
     if (!h->L_full) {
         AFQ_HIP(h, hipMalloc(&h->L_full, sizeof(double) * (size_t)K * M * Mp));
         const long n = (long)K * M * Mp;
-        hipLaunchKernelGGL(fullg_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_pot,
+        AFQ_LAUNCH(h, fullg_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_pot,
                            h->ld_hs, h->hs_sym ? 1 : 0, M, Mp, K, h->L_full);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
     }
     const int ng2 = 2 * ng;
     // chunk of Cholesky vectors: T workspace <= ~1.5 GB
@@ -159,9 +159,9 @@ int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
     AFQ_HIP(h, hipMemsetAsync(exx, 0, sizeof(cplx) * (size_t)ng2, h->stream));
     {
         const long nt = (long)ng2 * K;
-        hipLaunchKernelGGL(fullg_coulomb_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->stream, G_dev,
+        AFQ_LAUNCH(h, fullg_coulomb_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->stream, G_dev,
                            h->L_full, X, ng2, M, Mp, K);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
     }
     int rc = AFQ_OK;
     for (int n0 = 0; n0 < K && !rc; n0 += nc) {
@@ -169,14 +169,16 @@ int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev) {
         FullGTProb p;
         p.batch = ng2 * cur; p.rows = M; p.cols = M; p.kdim = M; p.nc = cur; p.n0 = n0; p.M = M; p.Mp = Mp;
         p.G = G_dev; p.L = h->L_full; p.T = T;
+        afq_note_launch(h, "FullGTProb GEMM");
         hipError_t e = launch_mfma_gemm_wg<2, 2, 2, 2, 4, FullGTProb, MAP_COLS_FAST>(p, h->stream, h->zero_page);
+        if (e == hipSuccess) e = afq_post_launch(h);
         if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = AFQ_EHIP; break; }
-        hipLaunchKernelGGL(fullg_trace_kernel, dim3((unsigned)p.batch), dim3(256), 0, h->stream, T, part, M);
-        hipLaunchKernelGGL(fullg_exx_add_kernel, dim3((ng2 + 63) / 64), dim3(64), 0, h->stream, part, exx, ng2, cur);
+        AFQ_LAUNCH(h, fullg_trace_kernel, dim3((unsigned)p.batch), dim3(256), 0, h->stream, T, part, M);
+        AFQ_LAUNCH(h, fullg_exx_add_kernel, dim3((ng2 + 63) / 64), dim3(64), 0, h->stream, part, exx, ng2, cur);
         if (hipGetLastError() != hipSuccess) { h->err = "full-G energy launch failed"; rc = AFQ_EHIP; }
     }
     if (!rc) {
-        hipLaunchKernelGGL(fullg_finish_kernel, dim3(ng), dim3(256), 0, h->stream, G_dev, h->H1, X, exx, E_dev, M, K,
+        AFQ_LAUNCH(h, fullg_finish_kernel, dim3(ng), dim3(256), 0, h->stream, G_dev, h->H1, X, exx, E_dev, M, K,
                            h->ecore);
         if (hipGetLastError() != hipSuccess) { h->err = "full-G energy launch failed"; rc = AFQ_EHIP; }
     }

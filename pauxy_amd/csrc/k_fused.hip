@@ -372,19 +372,15 @@ int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
     a.vhs_upper = h->vhs_upper ? 1 : 0;
-    a.same_b = (h->bh1_same && !getenv("AFQ_NO_SAME_B")) ? 1 : 0;
-    a.b_real = (h->bh1_real && !getenv("AFQ_NO_REAL_B")) ? 1 : 0;
+    a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
+    a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        AFQ_HIP(h, hipFuncSetAttribute((const void *)prop_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        lds_set = lds;
-    }
+    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+    AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel, lds, lds_set));
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
-    hipLaunchKernelGGL(prop_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, prop_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }

@@ -25,6 +25,7 @@ static TileChoice pick_tiles(int batch, int rows, int cols, const TileChoice *ca
     do {                                                                                           \
         hipError_t e__;                                                                            \
         typedef decltype(p) P__;                                                                   \
+        afq_note_launch((h), __func__);                                                            \
         if (tc.tm == 1 && tc.tn == 1) e__ = launch_mfma_gemm<1, 1, P__, MAP>(p, (h)->stream, WPB);      \
         else if (tc.tm == 1 && tc.tn == 2) e__ = launch_mfma_gemm<1, 2, P__, MAP>(p, (h)->stream, WPB); \
         else if (tc.tm == 2 && tc.tn == 1) e__ = launch_mfma_gemm<2, 1, P__, MAP>(p, (h)->stream, WPB); \
@@ -32,6 +33,7 @@ static TileChoice pick_tiles(int batch, int rows, int cols, const TileChoice *ca
         else if (tc.tm == 1 && tc.tn == 4) e__ = launch_mfma_gemm<1, 4, P__, MAP>(p, (h)->stream, WPB); \
         else if (tc.tm == 2 && tc.tn == 4) e__ = launch_mfma_gemm<2, 4, P__, MAP>(p, (h)->stream, WPB); \
         else e__ = launch_mfma_gemm<2, 2, P__, MAP>(p, (h)->stream, WPB);                               \
+        if (e__ == hipSuccess) e__ = afq_post_launch(h);                                           \
         AFQ_HIP(h, e__);                                                                           \
     } while (0)
 static const TileChoice kCplxTiles[] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
@@ -77,19 +79,19 @@ int k_onebody(afq_handle *h) {
         p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
         if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
             // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
-            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
             // large systems: 128 x 64 work-group tiles, 3M complex products
-            AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else {
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
             DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
         }
     }
     // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
-    hipLaunchKernelGGL(copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
+    AFQ_LAUNCH(h, copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
                        h->alive, (long)M * h->nt);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     cplx *t = h->phi; h->phi = h->phi_t; h->phi_t = t;
     return AFQ_OK;
 }
@@ -169,19 +171,19 @@ int k_force_bias_generic(afq_handle *h) {
             // work-group tile 64 walkers x 64 fields (cfg 2), operands shared through the LDS ring.  Measured at C3
             // together with the reduction of the split-K partial sums in fields_kernel (step time, us):
             // 64x128 tile / 16 slices 553.7, 64x64 / 8 slices 545.4, 32x64 / 8 slices 545.3, 64x64 / 4 slices 553.6
-            static const int cfg = getenv("AFQ_FB_CFG") ? atoi(getenv("AFQ_FB_CFG")) : 2;
-            static const int kc = getenv("AFQ_GEMM_KC") ? atoi(getenv("AFQ_GEMM_KC")) : 1;
+            static const int cfg = afq_knob("AFQ_FB_CFG") ? atoi(afq_knob("AFQ_FB_CFG")) : 2;
+            static const int kc = afq_knob("AFQ_GEMM_KC") ? atoi(afq_knob("AFQ_GEMM_KC")) : 1;
             if (cfg == 1) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
-                if (kc == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 2>(p, h->stream, h->zero_page)));
-                else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 2>(p, h->stream, h->zero_page)));
+                else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             }
             else if (cfg == 2) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
-                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             }
-            else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
-            else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         } else {
             DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
         }
@@ -193,7 +195,7 @@ int k_force_bias_generic(afq_handle *h) {
         for (int pass = 0; pass < 2; ++pass) {
             p.imag_pass = pass;
             p.rre = pass ? h->rchol_im : h->rchol_re;
-            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         }
     } else {
         ForceBiasProb<true> p;
@@ -251,28 +253,28 @@ int k_vhs_generic(afq_handle *h) {
         // work-group tile 64 walkers x 160 (p,q) pairs; hs_pot^T panels shared through the LDS ring
         // measured at C3 (tools/sweep_vhs_cfg.sh): packed symmetric columns 75.8 us with the 32 x 160 tile
         // (cfg 7), 116 us with the 64 x 160 tile that is best for the full M^2 columns (100 us)
-        static const int cfg_env = getenv("AFQ_VHS_CFG") ? atoi(getenv("AFQ_VHS_CFG")) : -1;
+        static const int cfg_env = afq_knob("AFQ_VHS_CFG") ? atoi(afq_knob("AFQ_VHS_CFG")) : -1;
         const int cfg = cfg_env >= 0 ? cfg_env : (h->hs_sym ? 7 : 0);
-        if (cfg == 1) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 3) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 4) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 5) AFQ_HIP(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 6) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 1, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 1, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 7) {
-            static const int kc = getenv("AFQ_GEMM_KC") ? atoi(getenv("AFQ_GEMM_KC")) : 1;
+            static const int kc = afq_knob("AFQ_GEMM_KC") ? atoi(afq_knob("AFQ_GEMM_KC")) : 1;
             KernelTrace kt(h, AFQ_K_VHS);
-            static const int xmap = getenv("AFQ_VHS_XCD") ? atoi(getenv("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
-            if (kc == 2) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
-            else if (xmap) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
-            else AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
+            if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
+            else if (xmap) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         }
-        else if (cfg == 8) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 9) AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-        else if (cfg == 10) AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 1, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        else if (cfg == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else {
             KernelTrace kt(h, AFQ_K_VHS);
-            AFQ_HIP(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         }
         return AFQ_OK;
     }
@@ -328,12 +330,12 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
             if (!h->no_ring && M > 64 && M <= 128 && p.cols > 32 && p.cols <= 64 && h->nw >= 64) {
                 // one work-group (8 waves, 128 x 64 tile) = one walker: VHS[w] and T[w] pass the LDS ring once
-                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 continue;
             }
             if (!h->no_ring && M > 128 && p.cols > 32 && h->nw >= 64) {
                 // large systems: 128 x 64 work-group tiles, 3M complex products
-                AFQ_HIP(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 continue;
             }
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);

@@ -144,9 +144,9 @@ __global__ void hirsch_fill_kernel(int *fields, long n) {
 }
 
 int k_hirsch_alive(afq_handle *h, int mode) {
-    hipLaunchKernelGGL(hirsch_alive_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->alive,
+    AFQ_LAUNCH(h, hirsch_alive_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->alive,
                        h->hs_alive0, h->nw, mode);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -155,9 +155,9 @@ int k_hirsch_kinetic(afq_handle *h) {
     int rc;
     if ((rc = k_onebody(h))) return rc;
     if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;
-    hipLaunchKernelGGL(hirsch_kin_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
+    AFQ_LAUNCH(h, hirsch_kin_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
                        h->ovlp_new, h->alive, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -165,7 +165,7 @@ int k_hirsch_two_body(afq_handle *h) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
     {
         const long n = (long)h->nw * h->M;
-        hipLaunchKernelGGL(hirsch_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_fields, n);
+        AFQ_LAUNCH(h, hirsch_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_fields, n);
     }
     HirschArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.nmax = nmax;
@@ -173,20 +173,16 @@ int k_hirsch_two_body(afq_handle *h) {
     a.fields = h->hs_fields; a.used = h->hs_used; a.alive = h->alive;
     for (int x = 0; x < 2; ++x) { a.wfac[x] = h->hs_wfac[x]; for (int s = 0; s < 2; ++s) a.delta[x][s] = h->hs_delta[x][s]; }
     const size_t lds = sizeof(cplx) * 2 * (size_t)nmax * nmax;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        AFQ_HIP(h, hipFuncSetAttribute((const void *)hirsch_two_body_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        lds_set = lds;
-    }
-    hipLaunchKernelGGL(hirsch_two_body_kernel, dim3(h->nw), dim3(256), lds, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+    AFQ_HIP(h, afq_raise_lds((const void *)hirsch_two_body_kernel, lds, lds_set));
+    AFQ_LAUNCH(h, hirsch_two_body_kernel, dim3(h->nw), dim3(256), lds, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_hirsch_eshift(afq_handle *h, double fac) {
-    hipLaunchKernelGGL(hirsch_eshift_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->hs_alive0,
+    AFQ_LAUNCH(h, hirsch_eshift_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->hs_alive0,
                        h->nw, fac);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }

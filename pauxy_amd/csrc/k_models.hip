@@ -27,9 +27,9 @@ __global__ void vhs_hubbard_kernel(const cplx *xs, cplx *vd, int nw, int M, int 
 
 int k_vhs_hubbard(afq_handle *h) {
     const int spin = (h->flags & AFQ_PROP_HUBBARD_SPIN) ? 1 : 0;
-    hipLaunchKernelGGL(vhs_hubbard_kernel, dim3((h->M + 127) / 128, h->nw), dim3(128), 0, h->stream, h->xs,
+    AFQ_LAUNCH(h, vhs_hubbard_kernel, dim3((h->M + 127) / 128, h->nw), dim3(128), 0, h->stream, h->xs,
                        h->vhs, h->nw, h->M, h->nv, h->sqrt_dt, h->dt, h->U, spin);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -56,9 +56,9 @@ __global__ void exp_diag_kernel(cplx *phi, const cplx *vd, const int *alive, int
 
 int k_apply_exponential_diag(afq_handle *h, const cplx *vd) {
     const long per = (long)h->M * h->nt;
-    hipLaunchKernelGGL(exp_diag_kernel, dim3((unsigned)((per + 255) / 256), h->nw), dim3(256), 0, h->stream,
+    AFQ_LAUNCH(h, exp_diag_kernel, dim3((unsigned)((per + 255) / 256), h->nw), dim3(256), 0, h->stream,
                        h->phi, vd, h->alive, h->M, h->nt, h->na, h->nv, h->exp_order);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void energy_hubbard_kernel(const cplx *rH1, co
 }
 
 int k_energy_hubbard(afq_handle *h) {
-    hipLaunchKernelGGL(energy_hubbard_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->rH1, h->ghalf, h->psi,
+    AFQ_LAUNCH(h, energy_hubbard_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->rH1, h->ghalf, h->psi,
                        h->energy, h->M, h->na, h->nb, h->nt, h->U);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -161,22 +161,18 @@ __global__ __launch_bounds__(512) void vbias_ueg_lds_kernel(const cplx *G, cplx 
 int k_vbias_ueg(afq_handle *h) {
     const size_t lds = sizeof(cplx) * (size_t)h->M * h->M;
     if (lds <= 160 * 1024) {
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            AFQ_HIP(h, hipFuncSetAttribute((const void *)vbias_ueg_lds_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
-        }
-        hipLaunchKernelGGL(vbias_ueg_lds_kernel, dim3(h->nw), dim3(512), lds, h->stream, h->G, h->vbias, h->M, 2 * h->nq,
+        static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+        AFQ_HIP(h, afq_raise_lds((const void *)vbias_ueg_lds_kernel, lds, lds_set));
+        AFQ_LAUNCH(h, vbias_ueg_lds_kernel, dim3(h->nw), dim3(512), lds, h->stream, h->G, h->vbias, h->M, 2 * h->nq,
                            h->ell_len, h->ell_row, h->ell_val);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
         return AFQ_OK;
     }
     const long items = (long)h->nw * 2 * h->nq;
-    hipLaunchKernelGGL(vbias_ueg_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, h->stream, h->G,
+    AFQ_LAUNCH(h, vbias_ueg_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, h->stream, h->G,
                        h->vbias, h->nw, h->M, h->nq, h->iA_colptr, h->iA_row, h->iA_val, h->iB_colptr,
                        h->iB_row, h->iB_val);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -197,10 +193,10 @@ __global__ void vhs_ueg_kernel(const cplx *xs, cplx *vhs, int nw, int M, int nq,
 
 int k_vhs_ueg(afq_handle *h) {
     const long mm = (long)h->M * h->M;
-    hipLaunchKernelGGL(vhs_ueg_kernel, dim3((unsigned)((mm + 255) / 256), h->nw), dim3(256), 0, h->stream, h->xs,
+    AFQ_LAUNCH(h, vhs_ueg_kernel, dim3((unsigned)((mm + 255) / 256), h->nw), dim3(256), 0, h->stream, h->xs,
                        h->vhs, h->nw, h->M, h->nq, h->sqrt_dt, h->iA_rowptr, h->iA_col, h->iA_rval,
                        h->iB_rowptr, h->iB_col, h->iB_rval);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -297,20 +293,16 @@ __global__ __launch_bounds__(1024) void energy_ueg_kernel(const cplx *G, cplx *e
 int k_energy_ueg(afq_handle *h) {
     const size_t lds = sizeof(cplx) * 2 * (size_t)h->ueg_nrows * h->M;
     if (lds <= 120 * 1024) {
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            AFQ_HIP(h, hipFuncSetAttribute((const void *)energy_ueg_kernel<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
-        }
-        hipLaunchKernelGGL(energy_ueg_kernel<true>, dim3(h->nw), dim3(1024), lds, h->stream, h->G, h->energy, h->M, h->nq,
+        static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+        AFQ_HIP(h, afq_raise_lds((const void *)energy_ueg_kernel<true>, lds, lds_set));
+        AFQ_LAUNCH(h, energy_ueg_kernel<true>, dim3(h->nw), dim3(1024), lds, h->stream, h->G, h->energy, h->M, h->nq,
                            h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
                            h->H1diag, h->ueg_rmap, h->ueg_rows, h->ueg_nrows);
     } else {
-        hipLaunchKernelGGL(energy_ueg_kernel<false>, dim3(h->nw), dim3(1024), 0, h->stream, h->G, h->energy, h->M, h->nq,
+        AFQ_LAUNCH(h, energy_ueg_kernel<false>, dim3(h->nw), dim3(1024), 0, h->stream, h->G, h->energy, h->M, h->nq,
                            h->kpq_off, h->kpq_i, h->kpq_kpq, h->pmq_off, h->pmq_i, h->pmq_pmq, h->vqvec, h->vol,
                            h->H1diag, h->ueg_rmap, h->ueg_rows, h->ueg_nrows);
     }
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }

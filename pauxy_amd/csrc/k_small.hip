@@ -7,6 +7,7 @@
 #include "mfma_gemm.h"
 #include "gj_wave.h"
 
+#include "block_scan.h"
 #define NTHR 256
 
 // --------------------------------------------------------------------------
@@ -16,9 +17,9 @@ __global__ void alive_kernel(const double *weight, int *alive, int nw) {
 }
 
 int k_alive(afq_handle *h) {
-    hipLaunchKernelGGL(alive_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
+    AFQ_LAUNCH(h, alive_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
                        h->alive, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -420,29 +421,22 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     }
     if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
-        static const int dbg = getenv("AFQ_GREENS_DBG") ? atoi(getenv("AFQ_GREENS_DBG")) : 0;
+        static const int dbg = afq_knob("AFQ_GREENS_DBG") ? atoi(afq_knob("AFQ_GREENS_DBG")) : 0;
         a.dbg = dbg;
         if (h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "fast Green's kernel supports M <= 128");
         const size_t lds = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) +
                                            (size_t)h->M * h->nt);
-        static size_t lds_set[2] = {0, 0};      // raise the dynamic-LDS cap once per kernel, not per launch
+        // raise the dynamic-LDS cap once per kernel and device, not per launch
+        static size_t lds_set1[AFQ_MAX_DEVICES] = {0}, lds_set0[AFQ_MAX_DEVICES] = {0};
         if (ghalf || oinv) {
-            if (lds > lds_set[1]) {
-                AFQ_HIP(h, hipFuncSetAttribute((const void *)greens_small_kernel<true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_set[1] = lds;
-            }
+            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true>, lds, lds_set1));
             KernelTrace kt(h, AFQ_K_GREENS);
-            hipLaunchKernelGGL(greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
+            AFQ_LAUNCH(h, greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
         } else {
-            if (lds > lds_set[0]) {
-                AFQ_HIP(h, hipFuncSetAttribute((const void *)greens_small_kernel<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_set[0] = lds;
-            }
-            hipLaunchKernelGGL(greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false>, lds, lds_set0));
+            AFQ_LAUNCH(h, greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
         }
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
         return AFQ_OK;
     }
     const size_t need = sizeof(cplx) * (size_t)nmax * nmax;
@@ -452,8 +446,8 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     if (!a.o_in_lds && !h->lu_ws)
         AFQ_HIP(h, hipMalloc(&h->lu_ws, sizeof(cplx) * (size_t)h->nw * nmax * nmax));
     a.ws = h->lu_ws;
-    hipLaunchKernelGGL(greens_kernel, dim3(h->nw), dim3(NTHR), a.o_in_lds ? need : 0, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, greens_kernel, dim3(h->nw), dim3(NTHR), a.o_in_lds ? need : 0, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -562,8 +556,8 @@ static XbarArgs xbar_args(afq_handle *h) {
 
 int k_xbar(afq_handle *h) {
     const XbarArgs a = xbar_args(h);
-    hipLaunchKernelGGL(xbar_kernel, dim3((h->K + 127) / 128, h->nw), dim3(128), 0, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, xbar_kernel, dim3((h->K + 127) / 128, h->nw), dim3(128), 0, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -583,9 +577,9 @@ __global__ void msd_combine_kernel(const cplx *detd, const cplx *coeffs, cplx *d
 }
 
 int k_msd_combine(afq_handle *h, cplx *det_out) {
-    hipLaunchKernelGGL(msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd, h->coeffs,
+    AFQ_LAUNCH(h, msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd, h->coeffs,
                        h->detw, det_out, h->nw, h->ndet);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -604,9 +598,9 @@ __global__ void msd_energy_combine_kernel(const cplx *energy_all, const cplx *de
 }
 
 int k_msd_energy_combine(afq_handle *h) {
-    hipLaunchKernelGGL(msd_energy_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream,
+    AFQ_LAUNCH(h, msd_energy_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream,
                        h->energy_all, h->detw, h->energy, h->nw, h->ndet);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -661,26 +655,26 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
 }
 
 int k_fields(afq_handle *h) {
-    hipLaunchKernelGGL(fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
+    AFQ_LAUNCH(h, fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
                        h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, XbarArgs());
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 // force bias from the contraction output + clip + shift in one launch (the step's hot path)
 int k_xbar_fields(afq_handle *h) {
-    hipLaunchKernelGGL(fields_kernel<true>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
+    AFQ_LAUNCH(h, fields_kernel<true>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
                        h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xbar_args(h));
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cplx *xs_d, cplx *cmf_d,
                       cplx *cfb_d) {
-    hipLaunchKernelGGL(fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
+    AFQ_LAUNCH(h, fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
                        (cplx *)xbar_d, h->mf_shift, xs_d, cmf_d, cfb_d, (unsigned long long *)nullptr,
                        (const int *)nullptr, XbarArgs());
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -854,53 +848,53 @@ __global__ void bp_reset_kernel(int *bp_n, double *bp_cos, cplx *bp_ph, int nw) 
 }
 
 int k_bp_push(afq_handle *h) {
-    hipLaunchKernelGGL(bp_push_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->xs, h->bp_hist, h->bp_n, h->bp_flag,
+    AFQ_LAUNCH(h, bp_push_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->xs, h->bp_hist, h->bp_n, h->bp_flag,
                        h->K, h->nbp);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_bp_fields(afq_handle *h, int i) {
-    hipLaunchKernelGGL(bp_fields_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->bp_hist, h->bp_n, h->xs, h->alive,
+    AFQ_LAUNCH(h, bp_fields_kernel, dim3(h->nw), dim3(128), 0, h->stream, h->bp_hist, h->bp_n, h->xs, h->alive,
                        h->K, h->nbp, i);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_bp_init(afq_handle *h, const cplx *phi0_dev) {
     const long per = (long)h->M * h->nt, n = per * h->nw;
-    hipLaunchKernelGGL(bp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, phi0_dev, h->phi_bp,
+    AFQ_LAUNCH(h, bp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, phi0_dev, h->phi_bp,
                        per, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_conj_copy(afq_handle *h, const cplx *src, cplx *dst, long n) {
-    hipLaunchKernelGGL(conj_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, n);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, conj_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, n);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At) {
-    hipLaunchKernelGGL(conj_transpose_kernel, dim3((h->M * h->M + 255) / 256, 2), dim3(256), 0, h->stream, A, At,
+    AFQ_LAUNCH(h, conj_transpose_kernel, dim3((h->M * h->M + 255) / 256, 2), dim3(256), 0, h->stream, A, At,
                        h->M);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_bp_accumulate(afq_handle *h, int restore, int with_energy) {
     const long gsz = 2L * h->M * h->M;
-    hipLaunchKernelGGL(bp_accumulate_kernel, dim3((unsigned)((gsz + 4 + 127) / 128)), dim3(128), 0, h->stream, h->G,
+    AFQ_LAUNCH(h, bp_accumulate_kernel, dim3((unsigned)((gsz + 4 + 127) / 128)), dim3(128), 0, h->stream, h->G,
                        h->weight, h->bp_cos, h->bp_ph, h->bp_est, h->nw, gsz, restore,
                        with_energy ? h->energy : (const cplx *)nullptr);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_bp_reset(afq_handle *h) {
-    hipLaunchKernelGGL(bp_reset_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->bp_n, h->bp_cos,
+    AFQ_LAUNCH(h, bp_reset_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->bp_n, h->bp_cos,
                        h->bp_ph, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -912,8 +906,8 @@ int k_update_weight(afq_handle *h, cplx eshift) {
     a.eloc = h->eloc; a.energy = h->energy;
     a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
     a.cap_frac = h->cap_frac; a.cap_total = h->cap_total; a.cap_total_dev = h->scal;
-    hipLaunchKernelGGL(weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -1004,7 +998,7 @@ int k_reortho(afq_handle *h) {
     a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot;
     a.only = nullptr;
     const int nmax = h->na > h->nb ? h->na : h->nb;
-    static const bool no_cholqr = getenv("AFQ_NO_CHOLQR") != nullptr;
+    static const bool no_cholqr = afq_knob("AFQ_NO_CHOLQR") != nullptr;
     // Cholesky-QR2 on the GEMM engines: always for 45 < N <= 128; for smaller N once the population is
     // large enough that seven launches beat the one latency-bound Gram-Schmidt work-group per walker
     const bool small_ok = nmax <= 45 && h->nb > 0 && !h->no_ring && h->nw >= 64 && h->M >= 32;
@@ -1016,8 +1010,8 @@ int k_reortho(afq_handle *h) {
     const size_t need = sizeof(cplx) * (size_t)nmax * h->M;
     a.in_lds = need <= 64 * 1024;
     a.ws = h->phi_t2;       // scratch panel (nmax*M <= M*nt elements per walker)
-    hipLaunchKernelGGL(reortho_kernel, dim3(h->nw), dim3(NTHR), a.in_lds ? need : 0, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, reortho_kernel, dim3(h->nw), dim3(NTHR), a.in_lds ? need : 0, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -1035,14 +1029,14 @@ __global__ void cap_dev_kernel(double *weight, int nw, double frac, const double
 
 int k_cap_weights(afq_handle *h, double frac, double total_weight) {
     if (total_weight < 0.0) {
-        hipLaunchKernelGGL(cap_dev_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
+        AFQ_LAUNCH(h, cap_dev_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
                            frac, h->scal);
-        AFQ_HIP(h, hipGetLastError());
+        AFQ_POST(h);
         return AFQ_OK;
     }
-    hipLaunchKernelGGL(cap_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
+    AFQ_LAUNCH(h, cap_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
                        frac * total_weight);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -1052,20 +1046,22 @@ __global__ void scale_kernel(double *weight, double *unscaled, int nw, double sc
 }
 
 int k_scale_weights(afq_handle *h, double scale) {
-    hipLaunchKernelGGL(scale_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
+    AFQ_LAUNCH(h, scale_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight,
                        h->unscaled, h->nw, scale);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
-__global__ void reset_kernel(double *weight, int nw) {
+__global__ void reset_kernel(double *weight, int nw, const double *scal) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (scal && scal[1] < 0.0) return;                             // collapsed population: see comb_plan_kernel
     if (w < nw) weight[w] = 1.0;                                   // handler.py:337-338
 }
 
-int k_reset_weights(afq_handle *h) {
-    hipLaunchKernelGGL(reset_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+int k_reset_weights(afq_handle *h, bool after_comb) {
+    AFQ_LAUNCH(h, reset_kernel, dim3((h->nw + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw,
+               after_comb ? (const double *)h->scal : (const double *)nullptr);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -1073,25 +1069,6 @@ int k_reset_weights(afq_handle *h) {
 // walk over the comb teeth are inherently sequential and must reproduce the
 // reference's left-to-right double additions, so one thread does them (nw adds).
 // scal[0] = total weight (before scaling), scal[1] = number of (clone, kill) pairs.
-// exclusive prefix sum of one value per thread over a 256-thread work-group (wave shuffles + 4 wave
-// totals through LDS); *total receives the sum of all 256 values
-template <class T> __device__ inline T block_excl_scan256(T v, T *wtot, T *total) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    T inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const T t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    __syncthreads();                 // wtot may still be read from a previous call
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    T base = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) { if (w < wave) base += wtot[w]; tot += wtot[w]; }
-    *total = tot;
-    return base + inc - v;
-}
-
 // Comb population control, walkers/handler.py:225-338, decided by one work-group: every thread owns a
 // contiguous chunk of walkers (sequential sums inside the chunk, prefix scans across chunks), every
 // comb tooth is located in the cumulative weights by bisection, and the clone / kill lists are
@@ -1114,7 +1091,10 @@ __global__ __launch_bounds__(256) void comb_plan_kernel(double *weight, double *
     double total;
     (void)block_excl_scan256(loc, wtot_d, &total);            // sum(global_weights), handler.py:233
     if (tid == 0) scal[0] = total;
-    if (total < 1e-8) { if (tid == 0) scal[1] = -1.0; return; }
+    // handler.py:236-241: the reference stops here.  Nothing is cloned, the weights are left alone, and the sticky
+    // flag scal[2] makes the next synchronising call (afq_popcontrol_comb with outputs, afq_estimates_get)
+    // return AFQ_EWEIGHT
+    if (total < 1e-8) { if (tid == 0) { scal[1] = -1.0; scal[2] = 1.0; } return; }
     const double scale = total / target;
     loc = 0.0;
     for (int i = i0; i < i1; ++i) {
@@ -1201,26 +1181,33 @@ __global__ void scale_by_inverse_kernel(cplx *x, const double *d, int nw) {
 }
 
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
-    hipLaunchKernelGGL(scale_by_inverse_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, x, d, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_LAUNCH(h, scale_by_inverse_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, x, d, h->nw);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
+// clone_kernel over the (src, dst) pairs in h->pack_tmp, count in scal[1]; at most nw / 2 pairs
+int k_clone_pairs(afq_handle *h, bool with_greens) {
+    CloneArgs a;
+    a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
+    a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = (const int *)h->pack_tmp; a.scal = h->scal;
+    a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
+    a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
+    a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;
+    AFQ_LAUNCH(h, clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_comb(afq_handle *h, double r, double target, bool with_greens) {
+    if (k_comm_size(h) > 1 || h->comm) return k_comm_popcontrol(h, r, target, with_greens);
     int *pairs = (int *)h->pack_tmp;
-    hipLaunchKernelGGL(comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + 3 * sizeof(int)) * (size_t)h->nw,
-                       h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
-    AFQ_HIP(h, hipGetLastError());
-    CloneArgs a;
-    a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
-    a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = pairs; a.scal = h->scal;
-    a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
-    a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
-    a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;
-    // at most nw/2 pairs
-    hipLaunchKernelGGL(clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
-    AFQ_HIP(h, hipGetLastError());
-    return k_reset_weights(h);
+    AFQ_LAUNCH(h, comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + 3 * sizeof(int)) * (size_t)h->nw,
+               h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
+    AFQ_POST(h);
+    int rc = k_clone_pairs(h, with_greens);
+    if (rc) return rc;
+    return k_reset_weights(h, true);
 }
 
 // --------------------------------------------------------------------------
@@ -1270,9 +1257,9 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
 
 int k_estimates(afq_handle *h, int have_energy) {
     const int fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
-    hipLaunchKernelGGL(estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, fp, h->weight,
+    AFQ_LAUNCH(h, estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, fp, h->weight,
                        h->unscaled, h->ot, h->ehyb, h->phase, h->energy, h->estimates);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
@@ -1334,21 +1321,51 @@ __global__ void rng_uniform_kernel(double *u, long n, unsigned long long seed, u
 
 int k_rng_uniform(afq_handle *h, double *u, long n) {
     const long pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(rng_uniform_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, u, n,
+    AFQ_LAUNCH(h, rng_uniform_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, u, n,
                        (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
                        (unsigned long long)h->rng_counter);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     h->rng_counter += 1;
+    return AFQ_OK;
+}
+
+// test hooks (afq_rng_normal / afq_rng_philox4x32): the same stream into a caller-provided device buffer, and
+// the bare Philox4x32-10 block function for the Random123 known-answer vectors
+int k_rng_normal_into(afq_handle *h, double *out_d, long n) {
+    const long pairs = (n + 1) / 2;
+    AFQ_LAUNCH(h, rng_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, out_d, n,
+               (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
+               (unsigned long long)h->rng_counter, (const double *)nullptr, (int *)nullptr, 0);
+    AFQ_POST(h);
+    h->rng_counter += 1;
+    return AFQ_OK;
+}
+
+__global__ void philox_raw_kernel(const unsigned int *in, unsigned int *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned int c0 = in[6 * i], c1 = in[6 * i + 1], c2 = in[6 * i + 2], c3 = in[6 * i + 3];
+    unsigned int k0 = in[6 * i + 4], k1 = in[6 * i + 5];
+    for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[4 * i] = c0; out[4 * i + 1] = c1; out[4 * i + 2] = c2; out[4 * i + 3] = c3;
+}
+
+int k_philox_raw(afq_handle *h, const unsigned int *in_d, unsigned int *out_d, int n) {
+    AFQ_LAUNCH(h, philox_raw_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, in_d, out_d, n);
+    AFQ_POST(h);
     return AFQ_OK;
 }
 
 int k_rng_normal(afq_handle *h) {
     const long n = (long)h->nw * h->K;
     const long pairs = std::max((n + 1) / 2, (long)h->nw);
-    hipLaunchKernelGGL(rng_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, h->xi, n,
+    AFQ_LAUNCH(h, rng_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, h->xi, n,
                        (unsigned long long)h->rng_seed, (unsigned long long)h->rng_stream,
                        (unsigned long long)h->rng_counter, h->weight, h->alive, h->nw);
-    AFQ_HIP(h, hipGetLastError());
+    AFQ_POST(h);
     h->rng_counter += 1;
     return AFQ_OK;
 }

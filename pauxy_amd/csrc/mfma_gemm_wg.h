@@ -3,7 +3,7 @@
 // WM x WN waves form one work-group; wave (wm, wn) owns TM x TN 16x16 tiles, so
 // the work-group tile is (16 TM WM) x (16 TN WN).  Per chunk of 8 contraction
 // indices every operand fragment of the work-group tile is brought into LDS
-// ONCE (global_load_lds_dwordx4, fragment order, see mfma_gemm_ring.h) and read
+// ONCE (global_load_lds_dwordx4, fragment order, see lds_dma.h) and read
 // by all the waves that need it: an A fragment by the WN waves of its tile row,
 // a B fragment by the WM waves of its tile column.  That multiplies the flops
 // per byte fetched from L2 by ~WM (resp. WN) over the one-wave-one-block
@@ -21,7 +21,7 @@
 // fragments, padded with zero-page loads into a scratch KB) so the counted
 // vmcnt is a compile-time constant.
 #pragma once
-#include "mfma_gemm_ring.h"
+#include "lds_dma.h"
 
 // K3M: complex x complex products by the 3-multiplication (Karatsuba) form
 //   P1 = Ar Br, P2 = Ai Bi, P3 = (Ar+Ai)(Br+Bi);  Cr = P1 - P2, Ci = P3 - P1 - P2
@@ -230,11 +230,10 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
     const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
     auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC>;
-    static size_t lds_set = 0;              // one per template instantiation: set the cap once
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set[AFQ_MAX_DEVICES] = {0};   // one per template instantiation and device: set the cap once
+    {
+        hipError_t e = afq_raise_lds((const void *)kern, lds, lds_set);
         if (e != hipSuccess) return e;
-        lds_set = lds;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, p, zero16);
     return hipGetLastError();

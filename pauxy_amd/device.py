@@ -293,10 +293,11 @@ class AfqDevice(object):
         self._ck(self.lib.afq_set_weight_cap(self.h, float(frac), float(total_weight)))
 
     def popcontrol_comb(self, r, target, fetch=True):
+        """Single rank, or a collective over the ranks of comm_init (parent_ix is then the global comb)."""
         if not fetch:        # asynchronous: the total weight stays on the device (cap_weights(frac, -1))
             self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), None, None))
             return None, None
-        pix = numpy.zeros(self.nw, dtype=numpy.int32)
+        pix = numpy.zeros(self.nw * getattr(self, 'comm_size', 1), dtype=numpy.int32)
         tw = ctypes.c_double(0.0)
         self._ck(self.lib.afq_popcontrol_comb(self.h, float(r), float(target), _p(pix), ctypes.byref(tw)))
         return pix, tw.value
@@ -328,6 +329,61 @@ class AfqDevice(object):
         out = numpy.empty(10, dtype=numpy.complex128)
         self._ck(self.lib.afq_estimates_get(self.h, _p(out), int(bool(zero))))
         return out
+
+    # -- library-owned communicator -----------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.afq_comm_unique_id(buf)
+        if rc != 0:
+            raise L.AfqError(rc, "afq_comm_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        assert len(unique_id) == 128
+        self._ck(self.lib.afq_comm_init(self.h, ctypes.c_char_p(unique_id), int(rank), int(nranks)))
+        self.comm_rank, self.comm_size = int(rank), int(nranks)
+
+    def comm_destroy(self):
+        self._ck(self.lib.afq_comm_destroy(self.h))
+        self.comm_rank, self.comm_size = 0, 1
+
+    def comm_set_capacity(self, cap):
+        self._ck(self.lib.afq_comm_set_capacity(self.h, int(cap)))
+
+    def comm_stats(self):
+        out = numpy.zeros(6, dtype=numpy.int64)
+        self._ck(self.lib.afq_comm_stats(self.h, _p(out)))
+        return dict(zip(['max_transfer', 'events', 'capacity', 'overflow', 'rank', 'size'], out.tolist()))
+
+    def estimates_allreduce(self, buf=None):
+        """Sum over the ranks of the communicator: the device accumulators in place (buf None) or a host array."""
+        if buf is None:
+            self._ck(self.lib.afq_estimates_allreduce(self.h, None, 0))
+            return None
+        a = numpy.ascontiguousarray(buf, dtype=numpy.complex128)
+        self._ck(self.lib.afq_estimates_allreduce(self.h, _p(a), a.size))
+        return a
+
+    def rng_normal(self, n):
+        out = numpy.empty(int(n), dtype=numpy.float64)
+        self._ck(self.lib.afq_rng_normal(self.h, _p(out), int(n)))
+        return out
+
+    def philox4x32(self, ctr_key):
+        ck = numpy.ascontiguousarray(ctr_key, dtype=numpy.uint32).reshape(-1, 6)
+        out = numpy.zeros((ck.shape[0], 4), dtype=numpy.uint32)
+        self._ck(self.lib.afq_rng_philox4x32(self.h, _p(ck), _p(out), ck.shape[0]))
+        return out
+
+    def debug(self, sync_every_launch=False, markers=False):
+        self._ck(self.lib.afq_debug(self.h, int(bool(sync_every_launch)), int(bool(markers))))
+
+    def last_launch(self):
+        """(text, queued, retired): safe to call from a watchdog thread while another thread is blocked in a sync."""
+        buf = ctypes.create_string_buffer(1024)
+        q, r = ctypes.c_uint64(), ctypes.c_uint64()
+        self.lib.afq_last_launch(self.h, buf, 1024, ctypes.byref(q), ctypes.byref(r))
+        return buf.value.decode(errors='replace'), q.value, r.value
 
     def rng_seed(self, seed, stream=0):
         self._ck(self.lib.afq_rng_seed(self.h, int(seed), int(stream)))
@@ -364,3 +420,42 @@ class AfqDevice(object):
         ms = ctypes.c_double()
         self._ck(self.lib.afq_last_energy_kernel_ms(self.h, ctypes.byref(ms)))
         return ms.value
+
+
+# -- in-process communicator: several AfqDevice objects driven by one host thread -----------------------------
+def _handle_array(devs):
+    return (ctypes.c_void_p * len(devs))(*[d.h.value for d in devs])
+
+
+def comm_init_local(devs):
+    """devs[i] becomes rank i of one communicator (afq_comm_init_local)."""
+    lib = devs[0].lib
+    rc = lib.afq_comm_init_local(_handle_array(devs), len(devs))
+    if rc != 0:
+        raise L.AfqError(rc, lib.afq_last_error(devs[0].h).decode())
+    for i, d in enumerate(devs):
+        d.comm_rank, d.comm_size = i, len(devs)
+
+
+def popcontrol_comb_local(devs, r, target, fetch=True):
+    """walkers/handler.py:225-338 over the ranks of comm_init_local -> (global parent_ix, total weight)."""
+    lib = devs[0].lib
+    n = len(devs)
+    if not fetch:
+        rc = lib.afq_popcontrol_comb_local(_handle_array(devs), n, float(r), float(target), None, None)
+        pix = tw = None
+    else:
+        pix = numpy.zeros(n * devs[0].nw, dtype=numpy.int32)
+        tw = ctypes.c_double(0.0)
+        rc = lib.afq_popcontrol_comb_local(_handle_array(devs), n, float(r), float(target), _p(pix), ctypes.byref(tw))
+        tw = tw.value
+    if rc != 0:
+        raise L.AfqError(rc, lib.afq_last_error(devs[0].h).decode())
+    return pix, tw
+
+
+def estimates_allreduce_local(devs):
+    lib = devs[0].lib
+    rc = lib.afq_estimates_allreduce_local(_handle_array(devs), len(devs))
+    if rc != 0:
+        raise L.AfqError(rc, lib.afq_last_error(devs[0].h).decode())

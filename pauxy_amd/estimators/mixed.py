@@ -80,7 +80,7 @@ class Mixed(object):
             nsteps = self.nsteps
         es = self.estimates
         ns = self.names
-        es[ns.time] = (time.time() - es[ns.time]) / nprocs
+        es[ns.time] = (time.time() - es[ns.time]) / (1 if getattr(comm, 'already_reduced', False) else nprocs)
         es[ns.uweight:ns.weight + 1] /= nsteps
         es[ns.ehyb:ns.time + 1] /= nsteps
         comm.Reduce(es, self.global_estimates, op=None)

@@ -13,10 +13,12 @@ Two loops are provided:
                         trip inside a step except at population control.
 """
 import json
+import sys
 import time
 
 import numpy
 
+from pauxy_amd import _lib
 from pauxy_amd.comm import FakeComm
 from pauxy_amd.estimators.handler import Estimators
 from pauxy_amd.propagation.continuous import get_propagator_driver
@@ -36,6 +38,9 @@ class AFQMC(object):
             numpy.random.seed(self.qmc.rng_seed + self.comm.rank)
         prop_opt = dict(options.get('propagator', {}))
         prop_opt.setdefault('hubbard_stratonovich', 'continuous')
+        # device Philox stream = GLOBAL rank (the host path seeds seed + rank, qmc/utils.py:14): two ranks
+        # must never draw the same auxiliary fields
+        prop_opt.setdefault('rng_stream', self.comm.rank)
         self.propagators = get_propagator_driver(system, trial, self.qmc, options=prop_opt, verbose=verbose)
         est_opts = options.get('estimators', options.get('estimates', options.get('estimator', {})))
         self.estimators = Estimators(est_opts, self.comm.rank == 0, self.qmc, system, trial,
@@ -127,43 +132,90 @@ class AFQMC(object):
             self.tstep += time.time() - start_step
 
     # ------------------------------------------------------------ batched loop
-    def step_batched(self, step, eshift):
-        """One step of run() with batched device calls only."""
+    def step_batched(self, step, eshift, fetch_popcontrol=False):
+        """One step of run() with batched device calls only (qmc/afqmc.py:223-246)."""
         psi, dev = self.psi, self.psi.dev
         if step % self.qmc.nstblz == 0:
             dev.reortho(fetch=False)
+            psi.phi_version += 1
+            psi._invalidate('ot', 'detR', 'weight')
         single = self.comm is None or self.comm.size == 1
         hirsch = getattr(self.propagators, 'hs_type', '') == 'discrete'
+        # the total weight of the last comb stays on the device whenever the comb itself ran there
+        # (single rank, or the library-owned communicator of afq_comm_init)
+        on_device = single or getattr(psi, 'device_comm', False)
         if not hirsch:
             # the weight cap of afqmc.py:235-236 rides on the weight-update kernel of the propagation
-            # (single rank: the total weight of the last comb is still on the device)
-            dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0 if single else psi.total_weight)
+            dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0 if on_device else psi.total_weight)
         self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
         if hirsch and step > 1:
-            dev.cap_weights(0.10, -1.0 if single else psi.total_weight)
+            dev.cap_weights(0.10, -1.0 if on_device else psi.total_weight)
+            psi._invalidate('weight')
         if step % self.qmc.npop_control == 0:
             psi._invalidate()
-            psi.pop_control(self.comm, fetch=not single)
+            psi.pop_control(self.comm, fetch=fetch_popcontrol or not on_device)
         do_energy = step % self.estimators.estimators['mixed'].energy_eval_freq == 0
-        dev.estimates_update(do_energy)
-
-    def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0):
-        """Steps first_step .. first_step+nsteps_total-1; returns the final eshift."""
         mixed = self.estimators.estimators['mixed']
+        if do_energy and not mixed.eval_energy:
+            mixed.update(self.system, self.qmc, self.trial, psi, step, self.propagators.free_projection)
+        else:
+            dev.estimates_update(do_energy)
+
+    def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0, on_step=None, fetch_popcontrol=False):
+        """Steps first_step .. first_step+nsteps_total-1 of run() with no host round trip inside a step
+        (the estimator sums stay on the device until the end of a block); returns the final eshift.
+        ``first_step == 1`` starts with the step-0 estimator pass of qmc/afqmc.py:214-221, like run().
+        ``on_step(step, psi)`` (tests) is called after every step; ``fetch_popcontrol`` reads the comb
+        decisions back (``psi.last_parent_ix``)."""
+        mixed = self.estimators.estimators['mixed']
+        others = [e for k, e in self.estimators.estimators.items() if k != 'mixed']
         n = self.qmc.total_steps if nsteps_total is None else nsteps_total
         ns = mixed.names
-        for step in range(first_step, first_step + n):
-            self.step_batched(step, eshift)
-            if step % self.qmc.nsteps == 0:
-                est = self.psi.dev.estimates_get(zero=True)
-                mixed.estimates[:ns.time] += est[:ns.time]
-                mixed.print_step(self.comm, self.comm.size, step)
-            if self.psi.write_restart and step % self.psi.write_freq == 0:
-                self.psi.write_walkers(self.comm)
-            if step < self.qmc.neqlb:
-                eshift = mixed.get_shift(self.propagators.hybrid)
+        dev = self.psi.dev
+        fp = self.propagators.free_projection
+        dcomm = getattr(self.psi, 'device_comm', False)
+        if dcomm and not mixed.eval_energy:
+            raise NotImplementedError("evaluate_energy: False with the device communicator")
+        if dcomm:
+            from pauxy_amd.comm import DeviceComm, ReducedComm
+            block_comm, other_comm = ReducedComm(self.comm), DeviceComm(dev, self.comm)
+        else:
+            block_comm = other_comm = self.comm
+        if first_step == 1:
+            if dcomm:       # stays in the device accumulators and is reduced with the first block
+                self.psi._end_sweep()
+                self.psi._flush()
+                dev.estimates_update(True)
             else:
-                eshift += (mixed.get_shift() - eshift)
+                mixed.update(self.system, self.qmc, self.trial, self.psi, 0, fp)
+        try:
+            for step in range(first_step, first_step + n):
+                self.step_batched(step, eshift, fetch_popcontrol)
+                for est in others:                      # back-propagation: estimators/handler.py:156-162
+                    est.update(self.system, self.qmc, self.trial, self.psi, step, fp)
+                if on_step is not None:
+                    on_step(step, self.psi)
+                if step % self.qmc.nsteps == 0:
+                    if dcomm:
+                        dev.estimates_allreduce()       # mixed.py:261 on the device, 20 doubles over RCCL
+                    est = dev.estimates_get(zero=True)  # also reports a collapsed population (AFQ_EWEIGHT)
+                    mixed.estimates[:ns.time] += est[:ns.time]
+                    mixed.print_step(block_comm, self.comm.size, step)
+                for est in others:
+                    est.print_step(other_comm, self.comm.size, step)
+                if self.psi.write_restart and step % self.psi.write_freq == 0:
+                    self.psi.write_walkers(self.comm)
+                if step < self.qmc.neqlb:
+                    eshift = mixed.get_shift(self.propagators.hybrid)
+                else:
+                    eshift += (mixed.get_shift() - eshift)
+        except _lib.AfqError as e:
+            if e.code == _lib.AFQ_EWEIGHT:              # walkers/handler.py:236-241
+                print("# Warning: total weight is below 1e-8.  Something is seriously wrong.")
+                sys.exit()
+            raise
+        finally:
+            dev.set_weight_cap(0.0)                     # the cap must not stay armed on the shared handle
         return eshift
 
     def finalise(self, verbose=False):

@@ -13,6 +13,7 @@ unchanged PAUXY driver can read ``w.weight`` inside its per-walker loop without
 one device round trip per walker: the mirror is refreshed once after each
 batched launch and flushed back before the next one if the driver wrote to it.
 """
+import os
 import sys
 
 import time
@@ -195,6 +196,17 @@ class Walkers(object):
         self.system, self.trial = system, trial
         self.dev.walkers_alloc(self.nwalkers)
         self.nw = self.nwalkers
+        # Population control on the device over the library-owned RCCL communicator (afq_comm_init) whenever the
+        # ranks sit on GPUs: rank 0's ncclUniqueId travels over the communicator the driver was given.  The
+        # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo).
+        self.device_comm = False
+        want = walker_opts.get('device_comm', os.environ.get('AFQ_DEVICE_COMM', '1') != '0')
+        if (comm is not None and comm.size > 1 and want and getattr(comm, 'device', None) is not None
+                and comm.device.type == 'cuda'):
+            uid = self.dev.comm_unique_id() if comm.rank == 0 else bytes(128)
+            uid = comm.bcast(uid, root=0)
+            self.dev.comm_init(uid, comm.rank, comm.size)
+            self.device_comm = True
         self.target_weight = qmc.ntot_walkers
         # host mirrors of the per-walker scalars
         self._host = {}
@@ -395,8 +407,9 @@ class Walkers(object):
             return
         self._flush()
         size = 1 if comm is None else comm.size
-        if size == 1:
-            r = numpy.random.random()                      # handler.py:276
+        if size == 1 or self.device_comm:
+            # single rank, or the collective of afq_comm_init: only rank 0 draws the comb uniform (handler.py:276)
+            r = numpy.random.random() if (size == 1 or comm.rank == 0) else 0.0
             if not fetch:
                 self.dev.popcontrol_comb(r, self.target_weight, fetch=False)
                 self.phi_version += 1
@@ -409,7 +422,7 @@ class Walkers(object):
                     print("# Warning: total weight is below 1e-8.  Something is seriously wrong.")
                     sys.exit()
                 raise
-            self.last_parent_ix = parent_ix
+            self.last_parent_ix = parent_ix                # the global comb when several ranks took part
         else:
             total = self._pop_control_distributed(comm)
         self.set_total_weight(total)

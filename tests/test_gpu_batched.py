@@ -1,0 +1,145 @@
+"""The benchmarked loop is the tested loop: ``AFQMC.run_batched`` (what ``bench.py`` times -- batched device
+calls only, in-kernel weight cap, comb without read-back, estimator sums kept on the device for a whole block)
+replays the golden trajectories of the genuine reference with the same tolerances as the per-walker loop of
+``tests/test_gpu_traj.py`` (1e-8 relative, comb decisions exact, block rows), and at the BASELINE configs[2]
+size it is compared with ``AFQMC.run`` on identical host-drawn fields.  Reference loop: qmc/afqmc.py:223-255."""
+import numpy
+import pytest
+
+from pauxy_amd import _lib as L
+from pauxy_amd import systems, trial as trial_mod
+from pauxy_amd.context import release_context
+from pauxy_amd.qmc.afqmc import AFQMC
+from tests.test_gpu_traj import close, replay, run_bp, run_hirsch
+
+pytestmark = pytest.mark.gpu
+
+
+def generic_from(d):
+    na, nb = [int(x) for x in d['nelec']]
+    return systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+
+
+def test_batched_traj_generic(golden, monkeypatch):
+    d = golden('traj_generic.npz')
+    s = generic_from(d)
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    est = replay(d, s, t, {}, monkeypatch, batched=True)
+    assert est[2].real == pytest.approx(3.8763193646854273, rel=1e-8)        # qmc/tests/test_afqmc.py:227
+
+
+def test_batched_traj_hubbard_c1(golden, monkeypatch):
+    d = golden('traj_hubbard_c1.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch, batched=True)
+
+
+def test_batched_traj_hubbard(golden, monkeypatch):
+    d = golden('traj_hubbard.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Hubbard(4, 4, na, nb, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    est = replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch, batched=True)
+    assert est[2].real == pytest.approx(-152.91937839611, rel=1e-8)          # qmc/tests/test_afqmc.py:186
+
+
+def test_batched_traj_ueg(golden, monkeypatch):
+    d = golden('traj_ueg.npz')
+    s = systems.UEG(float(d['sys_rs']), 7, 7, float(d['sys_ecut']))
+    t = trial_mod.hartree_fock_ueg(s)
+    est = replay(d, s, t, {}, monkeypatch, batched=True)
+    assert est[2].real == pytest.approx(16.33039729324558, rel=1e-8)         # qmc/tests/test_afqmc.py:87
+
+
+def test_batched_traj_msd(golden, monkeypatch):
+    d = golden('traj_msd.npz')
+    s = generic_from(d)
+    t = trial_mod.MultiDetTrial(s, (d['coeffs'], d['psi']), init=d['phi0'][0])
+    replay(d, s, t, {}, monkeypatch, batched=True)
+
+
+def test_batched_traj_free_projection_and_local_energy(golden, monkeypatch):
+    for name, opts in (('traj_hubbard_fp.npz', {'free_projection': True}), ('traj_hubbard_le.npz', {'hybrid': False})):
+        d = golden(name)
+        s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+        t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+        replay(d, s, t, dict(opts, hubbard_stratonovich='continuous'), monkeypatch, batched=True)
+
+
+def test_batched_traj_back_propagation(golden, monkeypatch):
+    """run_batched drives the back-propagation estimator at the reference cadence (estimators/handler.py:156-162)."""
+    rdm = run_bp(golden, monkeypatch, 'traj_bp.npz', None, batched=True)
+    assert rdm[11, 0, 1, 3].real == pytest.approx(-0.121883381144845, rel=1e-7)   # qmc/tests/test_afqmc.py:276
+
+
+def test_batched_traj_hirsch(golden, monkeypatch):
+    est = run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch.npz', batched=True)
+    assert est[2].real == pytest.approx(-152.68468568462666, rel=1e-8)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[2] size
+C3 = dict(M=100, K=500, N=25, nw=256)
+
+
+def c3_afqmc(device_rng=False):
+    s = systems.synthetic_generic(C3['M'], C3['K'], (C3['N'], C3['N']), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    options = {'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': 2, 'stabilise_freq': 10, 'pop_control_freq': 5,
+                       'num_walkers': C3['nw'], 'rng_seed': 7},
+               'propagator': {'device_rng': device_rng, 'rng_seed': 7},
+               'estimators': {'mixed': {'verbose': False}}}
+    return AFQMC(options=options, system=s, trial=t), s, t
+
+
+def run_c3(batched, fetch):
+    afqmc, s, t = c3_afqmc()
+    numpy.random.seed(1234)
+    rec = dict(weight=[], ot=[], ehyb=[], pix=[])
+
+    def on_step(step, psi):
+        rec['weight'].append(psi._mirror('weight').copy())
+        rec['ot'].append(psi._mirror('ot').copy())
+        rec['ehyb'].append(psi._mirror('hybrid_energy').copy())
+        if fetch and step % afqmc.qmc.npop_control == 0:
+            rec['pix'].append(psi.last_parent_ix.copy())
+
+    if batched:
+        afqmc.run_batched(on_step=on_step, fetch_popcontrol=fetch)
+    else:
+        afqmc.run(on_step=on_step)
+    blocks = numpy.array(afqmc.estimators.estimators['mixed'].blocks)
+    phi = afqmc.psi.dev.get(L.F_PHI)
+    release_context(s, t)
+    return {k: numpy.array(v) for k, v in rec.items()}, blocks, phi
+
+
+def test_c3_run_batched_equals_run():
+    """20 steps at Nbasis=100, Nchol=500, 256 walkers with host-drawn fields: the batched loop (weight cap inside the
+    weight-update kernel, comb with and without read-back, per-block estimator fetch) against the per-walker
+    loop.  The two loops queue the same kernels on the same data, so everything the walkers carry is bit-equal;
+    the block rows differ only in where the step-0 row is added (1e-13)."""
+    a, blocks_a, phi_a = run_c3(False, True)
+    b, blocks_b, phi_b = run_c3(True, True)
+    c, blocks_c, phi_c = run_c3(True, False)         # nothing read back at the comb (bench.py's mode)
+    for other, blocks, phi in ((b, blocks_b, phi_b), (c, blocks_c, phi_c)):
+        for key in ('weight', 'ot', 'ehyb'):
+            assert numpy.array_equal(a[key], other[key]), key
+        assert numpy.array_equal(phi_a, phi)
+        close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-12)
+    assert numpy.array_equal(a['pix'], b['pix'])
+    assert a['pix'].shape == (4, C3['nw']) and a['pix'].max() >= 2         # the comb did clone walkers
+
+
+def test_collapsed_population_is_reported():
+    """walkers/handler.py:236-241: total weight < 1e-8 stops the run; on the asynchronous comb the flag surfaces at
+    the next afq_estimates_get (AFQ_EWEIGHT) and nothing was cloned or reset."""
+    afqmc, s, t = c3_afqmc()
+    dev = afqmc.psi.dev
+    dev.set(L.F_WEIGHT, numpy.full(dev.nw, 1e-12))
+    dev.popcontrol_comb(0.3, dev.nw, fetch=False)
+    with pytest.raises(L.AfqError) as e:
+        dev.estimates_get(zero=True)
+    assert e.value.code == L.AFQ_EWEIGHT
+    assert numpy.all(dev.get(L.F_WEIGHT) == 1e-12)
+    release_context(s, t)

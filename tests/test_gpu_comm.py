@@ -1,0 +1,208 @@
+"""SURVEY 8e parity definition on the device path: N ranks with the same host-drawn streams equal the ONE-rank
+run with N x nw walkers (walkers/handler.py:225-338; the reference's own multi-rank run differs only in its
+per-rank seeds, qmc/utils.py:14).
+
+The box has one GPU and RCCL refuses two ranks on one device, so the ranks here are the handles of the
+in-process communicator (afq_comm_init_local): the same prep / global-plan / pack / unpack kernels and slot
+buffers the RCCL transport uses, with device-to-device copies in place of ncclAllGather / ncclSend / ncclRecv.
+The RCCL calls themselves are exercised on a communicator of size 1."""
+import numpy
+import pytest
+
+from oracle import afqmc_ref as ref
+from pauxy_amd import _lib as L
+from pauxy_amd import device as devmod
+from tests.helpers import generic_model, make_device
+
+pytestmark = pytest.mark.gpu
+FIELDS = (L.F_PHI, L.F_WEIGHT, L.F_UNSCALED_WEIGHT, L.F_OT, L.F_HYBRID_ENERGY, L.F_PHASE, L.F_DETR, L.F_ELOC)
+
+
+def start(golden, nranks, nw, seed=5, spread=1.0):
+    d = golden('generic_ops.npz')
+    model = generic_model(d, 'A_')
+    rng = numpy.random.RandomState(seed)
+    M, nt = model.M, model.na + model.nb
+    ntot = nranks * nw
+    phis = numpy.array([model.psi + 0.05 * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for _ in range(ntot)])
+    ots = numpy.array([ref.calc_overlap(p, model.psi, model.na, model.nb) for p in phis])
+    weights = numpy.exp(spread * rng.normal(size=ntot))
+    one = make_device(model, ntot)
+    ranks = [make_device(model, nw) for _ in range(nranks)]
+    for dev, sl in [(one, slice(0, ntot))] + [(ranks[i], slice(i * nw, (i + 1) * nw)) for i in range(nranks)]:
+        dev.set(L.F_PHI, phis[sl]); dev.set(L.F_OT, ots[sl]); dev.set(L.F_WEIGHT, weights[sl])
+    devmod.comm_init_local(ranks)
+    return model, one, ranks, rng
+
+
+def gather(ranks, field):
+    return numpy.concatenate([r.get(field) for r in ranks])
+
+
+def same_population(one, ranks, exact=True):
+    for f in FIELDS:
+        a, b = one.get(f), gather(ranks, f)
+        if exact:
+            assert numpy.array_equal(a, b), f
+        else:
+            assert numpy.max(numpy.abs(a - b)) <= 1e-12 * max(1.0, numpy.max(numpy.abs(a))), f
+
+
+def close_all(devs):
+    for dv in devs:
+        dv.close()
+
+
+@pytest.mark.parametrize("nranks,nw", [(2, 6), (3, 4), (4, 16)])
+def test_comb_across_ranks_equals_one_rank(golden, nranks, nw):
+    model, one, ranks, rng = start(golden, nranks, nw)
+    ntot = nranks * nw
+    xi = rng.normal(size=(ntot, one.K))
+    for step in range(3):
+        # one step with a cached Green's function at its end (the cache has to travel with the clones),
+        # then the comb; the next step consumes the cache
+        one.propagate(xi, 0.1)
+        for i, rk in enumerate(ranks):
+            rk.propagate(xi[i * nw:(i + 1) * nw], 0.1)
+        r = rng.rand()
+        pix_one, tw_one = one.popcontrol_comb(r, ntot)
+        pix, tw = devmod.popcontrol_comb_local(ranks, r, ntot)
+        assert numpy.array_equal(pix, pix_one)
+        assert tw == pytest.approx(tw_one, rel=1e-14)
+        same_population(one, ranks, exact=(step == 0))     # later steps: the total weight differs in the last bit
+        st = ranks[0].comm_stats()
+        assert st['overflow'] == 0 and st['size'] == nranks and st['events'] == step + 1
+    pairs_cross = sum(1 for c, k in zip(numpy.where(pix > 1)[0], numpy.where(pix == 0)[0]) if c // nw != k // nw)
+    assert ranks[0].comm_stats()['max_transfer'] >= (1 if pairs_cross else 0)
+    close_all([one] + ranks)
+
+
+def test_walkers_did_change_rank(golden):
+    """The case the transport exists for: every heavy walker on rank 0, every dead one on rank 1."""
+    nranks, nw = 2, 8
+    model, one, ranks, rng = start(golden, nranks, nw)
+    w = numpy.concatenate([numpy.full(nw, 3.0), numpy.full(nw, 1e-3)])
+    one.set(L.F_WEIGHT, w); ranks[0].set(L.F_WEIGHT, w[:nw]); ranks[1].set(L.F_WEIGHT, w[nw:])
+    for rk in ranks:
+        rk.comm_set_capacity(nw)
+    pix_one, _ = one.popcontrol_comb(0.37, nranks * nw)
+    pix, _ = devmod.popcontrol_comb_local(ranks, 0.37, nranks * nw)
+    assert numpy.array_equal(pix, pix_one)
+    assert numpy.all(pix[nw:] == 0) and numpy.all(pix[:nw] == 2)
+    same_population(one, ranks)
+    assert ranks[0].comm_stats()['max_transfer'] == nw
+    # the walkers of rank 1 now ARE those of rank 0
+    assert numpy.array_equal(ranks[1].get(L.F_PHI), ranks[0].get(L.F_PHI))
+    close_all([one] + ranks)
+
+
+def test_exchange_overflow_is_an_error(golden):
+    nranks, nw = 2, 8
+    model, one, ranks, rng = start(golden, nranks, nw)
+    w = numpy.concatenate([numpy.full(nw, 3.0), numpy.full(nw, 1e-3)])
+    ranks[0].set(L.F_WEIGHT, w[:nw]); ranks[1].set(L.F_WEIGHT, w[nw:])
+    for rk in ranks:
+        rk.comm_set_capacity(3)
+    with pytest.raises(L.AfqError) as e:
+        devmod.popcontrol_comb_local(ranks, 0.37, nranks * nw)
+    assert e.value.code == L.AFQ_EOVERFLOW
+    # asynchronous comb: the flag is sticky and surfaces at the next estimator fetch of every rank
+    for rk in ranks:
+        with pytest.raises(L.AfqError) as e:
+            rk.estimates_get()
+        assert e.value.code == L.AFQ_EOVERFLOW
+    close_all([one] + ranks)
+
+
+def test_multi_rank_loop_equals_one_rank(golden):
+    """30 steps of the batched driver sequence (qmc/afqmc.py:223-255: reortho / 5, propagate with the in-kernel
+    weight cap on the GLOBAL total weight, comb / 2 without read-back, estimators with energy / 5, all-reduce per
+    block) on 3 ranks x 5 walkers against one rank x 15 walkers, same fields and comb uniforms."""
+    nranks, nw = 3, 5
+    model, one, ranks, rng = start(golden, nranks, nw, spread=0.3)
+    ntot = nranks * nw
+    eshift = 0.0
+    for step in range(1, 31):
+        xi = rng.normal(size=(ntot, one.K))
+        r = rng.rand()
+        groups = [(one, xi)] + [(ranks[i], xi[i * nw:(i + 1) * nw]) for i in range(nranks)]
+        for dev, x in groups:
+            if step % 5 == 0:
+                dev.reortho(fetch=False)
+            dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0)
+            dev.propagate(x, eshift)
+        if step % 2 == 0:
+            one.popcontrol_comb(r, ntot, fetch=False)
+            devmod.popcontrol_comb_local(ranks, r, ntot, fetch=False)
+        for dev, _ in groups:
+            dev.estimates_update(step % 5 == 0)
+        if step % 10 == 0:
+            devmod.estimates_allreduce_local(ranks)
+            e_one = one.estimates_get(zero=True)
+            for rk in ranks:
+                e = rk.estimates_get(zero=True)
+                assert numpy.max(numpy.abs(e - e_one)) <= 1e-10 * numpy.max(numpy.abs(e_one))
+            eshift = (e_one[7] / e_one[1]).real                     # ehyb / weight, estimators/mixed.py:268-271
+        same_population(one, ranks, exact=False)
+    assert ranks[0].comm_stats()['events'] == 15
+    close_all([one] + ranks)
+
+
+def test_back_propagation_state_travels(golden):
+    nranks, nw, nbp = 2, 6, 4
+    model, one, ranks, rng = start(golden, nranks, nw, spread=0.8)
+    ntot = nranks * nw
+    for dev in [one] + ranks:
+        dev.bp_configure(nbp)
+    for step in range(nbp):
+        xi = rng.normal(size=(ntot, one.K))
+        one.propagate(xi, 0.0)
+        for i, rk in enumerate(ranks):
+            rk.propagate(xi[i * nw:(i + 1) * nw], 0.0)
+        r = rng.rand()
+        pix_one, _ = one.popcontrol_comb(r, ntot)
+        pix, _ = devmod.popcontrol_comb_local(ranks, r, ntot)
+        assert numpy.array_equal(pix, pix_one)
+    assert numpy.array_equal(one.bp_steps(), numpy.concatenate([rk.bp_steps() for rk in ranks]))
+    _, den_one, G_one = one.bp_update(model.psi, 10, 'full')
+    den, G = 0.0, 0.0
+    for rk in ranks:
+        _, dn, g = rk.bp_update(model.psi, 10, 'full')
+        den, G = den + dn, G + g
+    assert abs(den - den_one) <= 1e-11 * abs(den_one)
+    assert numpy.max(numpy.abs(G - G_one)) <= 1e-10 * numpy.max(numpy.abs(G_one))
+    close_all([one] + ranks)
+
+
+def test_rccl_communicator_of_one_rank(golden):
+    """afq_comm_init / the RCCL calls (ncclCommInitRank, ncclAllGather of the weights, ncclAllReduce of the
+    estimators) on the one GPU of the box: must reproduce the plain single-rank path."""
+    d = golden('generic_ops.npz')
+    model = generic_model(d, 'A_')
+    nw = 8
+    rng = numpy.random.RandomState(11)
+    M, nt = model.M, model.na + model.nb
+    phis = numpy.array([model.psi + 0.05 * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for _ in range(nw)])
+    w = numpy.exp(rng.normal(size=nw))
+    plain, withcomm = make_device(model, nw), make_device(model, nw)
+    withcomm.comm_init(withcomm.comm_unique_id(), 0, 1)
+    xi = rng.normal(size=(nw, plain.K))
+    for dev in (plain, withcomm):
+        dev.set(L.F_PHI, phis); dev.set(L.F_WEIGHT, w)
+        dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, model.na, model.nb) for p in phis]))
+        dev.propagate(xi, 0.0)
+    pa, ta = plain.popcontrol_comb(0.61, nw)
+    pb, tb = withcomm.popcontrol_comb(0.61, nw)
+    assert numpy.array_equal(pa, pb) and ta == tb
+    for f in FIELDS:
+        assert numpy.array_equal(plain.get(f), withcomm.get(f)), f
+    for dev in (plain, withcomm):
+        dev.estimates_update(True)
+    withcomm.estimates_allreduce()
+    assert numpy.array_equal(plain.estimates_get(), withcomm.estimates_get())
+    buf = rng.rand(7) + 1j * rng.rand(7)
+    assert numpy.array_equal(withcomm.estimates_allreduce(buf.copy()), buf)
+    st = withcomm.comm_stats()
+    assert (st['rank'], st['size'], st['events']) == (0, 1, 1)
+    withcomm.comm_destroy()
+    close_all([plain, withcomm])

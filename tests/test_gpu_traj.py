@@ -44,7 +44,7 @@ class Replay(object):
         return next(self.r)
 
 
-def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None):
+def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None, batched=False):
     options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
                        'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
                        'num_walkers': d['phi0'].shape[0]},
@@ -69,7 +69,10 @@ def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None):
         if step % afqmc.qmc.npop_control == 0:
             rec['pix'].append(psi.last_parent_ix.copy())
 
-    afqmc.run(verbose=False, on_step=on_step)
+    if batched:     # the loop bench.py times: batched device calls, estimator sums kept on the device per block
+        afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
+    else:
+        afqmc.run(verbose=False, on_step=on_step)
     close(numpy.array(rec['weight']), d['weight'])
     close(numpy.array(rec['unscaled']), d['unscaled_weight'])
     close(numpy.array(rec['ot']), d['ot'])
@@ -164,7 +167,7 @@ def test_traj_msd(golden, monkeypatch):
     replay(d, s, t, {}, monkeypatch)
 
 
-def run_bp(golden, monkeypatch, name, restore, tmp_path=None):
+def run_bp(golden, monkeypatch, name, restore, tmp_path=None, batched=False):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
@@ -176,7 +179,7 @@ def run_bp(golden, monkeypatch, name, restore, tmp_path=None):
     extra = {'back_propagated': bp}
     if tmp_path is not None:
         extra['basename'] = str(tmp_path / 'estimates')
-    replay(d, s, t, {}, monkeypatch, est_extra=extra, out=out)
+    replay(d, s, t, {}, monkeypatch, est_extra=extra, out=out, batched=batched)
     est = out['afqmc'].estimators.estimators['back_prop']
     close(numpy.array(est.denominator), d['bp_denominator'])
     close(numpy.array(est.one_rdm), d['bp_one_rdm'])
@@ -198,7 +201,7 @@ def test_traj_back_propagation_restored_weights(golden, monkeypatch):
     run_bp(golden, monkeypatch, 'traj_bp_full.npz', 'full')
 
 
-def run_hirsch(golden, monkeypatch, name, basename=None):
+def run_hirsch(golden, monkeypatch, name, basename=None, batched=False):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -225,7 +228,10 @@ def run_hirsch(golden, monkeypatch, name, basename=None):
         if step % afqmc.qmc.npop_control == 0:
             rec['pix'].append(psi.last_parent_ix.copy())
 
-    afqmc.run(verbose=False, on_step=on_step)
+    if batched:
+        afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
+    else:
+        afqmc.run(verbose=False, on_step=on_step)
     assert next(stream, None) is None                      # consumed exactly the reference's uniforms
     close(numpy.array(rec['weight']), d['weight'])
     close(numpy.array(rec['ot']), d['ot'])
