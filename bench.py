@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 M, K, N = 100, 500, 25
 NW_PER_GPU = 256
+STRONG_TOTAL = 2048                  # strong scaling at 2048 walkers in total
 DT = 0.005
 NSTBLZ, NPOP, NSTEPS_BLOCK = 10, 5, 10
 PEAK_F64_MFMA_TFLOPS = 78.6          # MI355X fp64 matrix peak
@@ -45,40 +46,111 @@ def build_inputs():
     return system, trial
 
 
-def cpu_baseline(system, trial, nw_cpu=16, nsteps=10):
-    """Oracle ("port") timed on the host cores over a bounded sample of the same
-    workload: nw_cpu walkers x nsteps steps in the same cadence."""
+def host_cpu():
+    """(model name, physical cores of one socket, sockets) from /proc/cpuinfo."""
+    model, cores, sockets = "unknown", None, set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("cpu cores") and cores is None:
+                    cores = int(line.split(":", 1)[1])
+                elif line.startswith("physical id"):
+                    sockets.add(line.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return model, cores or (os.cpu_count() or 1), max(1, len(sockets))
+
+
+def cpu_baseline(system, trial):
+    """the oracle ("port": per-walker numpy/scipy loop of oracle/afqmc_ref.py, the
+    reference's algorithm and call sequence) timed on this host over bounded samples of the same workload and
+    cadence (reortho / 10, comb / 5, energy / 10; one warm-up block first):
+      * socket-novcopy : BLAS threads = physical cores of ONE socket, hs_pot pre-cast to complex128 once (the
+                         reference promotes the real 40 MB matrix to complex on every construct_VHS call,
+                         propagation/generic.py:177; this variant removes that accident) -- 32 walkers x 20 steps
+      * socket-faithful: same threads, the reference's behaviour                     -- 16 walkers x 10 steps
+      * one-thread     : 1 BLAS thread, faithful                                     --  4 walkers x 10 steps
+    The value reported is the FASTEST variant, so the speed-up is not won on the promotion copy."""
     from oracle import afqmc_ref as ref
     from pauxy_amd.propagation.setup import generic_propagator_arrays
-    BH1, mf = generic_propagator_arrays(system, trial, DT)
-    model = ref.RefModel('generic', M, N, N, trial.psi, BH1, mf, DT, hs_pot=system.hs_pot,
-                         rchol=trial._rchol, H1=system.H1.astype(complex), ecore=system.ecore)
-    walkers = [ref.new_walker(model, trial.psi) for _ in range(nw_cpu)]
-    rng = numpy.random.RandomState(11)
-    t0 = time.time()
-    ref.run_afqmc(model, walkers, lambda s, w: rng.normal(size=K), lambda s: rng.random_sample(),
-                  nsteps, 1, nstblz=NSTBLZ, npop_control=NPOP, energy_eval_freq=NSTEPS_BLOCK)
-    dt = time.time() - t0
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
     except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": nw_cpu * nsteps / dt, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d walkers x %d steps (1 block incl. step-0 and step-%d energy evaluations), numpy/scipy "
-                      "per-walker loop of oracle/afqmc_ref.py, %.1f s" % (nw_cpu, nsteps, nsteps, dt)}
+        threadpool_limits = None
+    BH1, mf = generic_propagator_arrays(system, trial, DT)
+    cpu_model, socket_cores, sockets = host_cpu()
+
+    def timed(hs_pot, nthreads, nw_cpu, nsteps):
+        model = ref.RefModel('generic', M, N, N, trial.psi, BH1, mf, DT, hs_pot=hs_pot,
+                             rchol=trial._rchol, H1=system.H1.astype(complex), ecore=system.ecore)
+        rng = numpy.random.RandomState(11)
+
+        def go(steps, nw_):
+            walkers = [ref.new_walker(model, trial.psi) for _ in range(nw_)]
+            t0 = time.time()
+            ref.run_afqmc(model, walkers, lambda s, w: rng.normal(size=K), lambda s: rng.random_sample(),
+                          NSTEPS_BLOCK, steps // NSTEPS_BLOCK, nstblz=NSTBLZ, npop_control=NPOP,
+                          energy_eval_freq=NSTEPS_BLOCK)
+            return time.time() - t0
+
+        def both():
+            go(NSTEPS_BLOCK, 2)                              # warm-up: one block of two walkers
+            return go(nsteps, nw_cpu)
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=nthreads):
+                dt = both()
+        else:
+            dt = both()
+        return nw_cpu * nsteps / dt, dt
+
+    variants = []
+    for name, hs, thr, nwc, nst in (
+            ("socket-novcopy", system.hs_pot.astype(numpy.complex128), socket_cores, 32, 20),
+            ("socket-faithful", system.hs_pot, socket_cores, 16, 10),
+            ("one-thread", system.hs_pot, 1, 4, 10)):
+        v, dt = timed(hs, thr, nwc, nst)
+        variants.append({"variant": name, "value": v, "threads": thr, "walkers": nwc, "steps": nst, "seconds": dt})
+    best = max(variants, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "walker-steps/s", "cores": int(best["threads"]), "kind": "port",
+            "cpu": "%s, %d cores/socket x %d sockets" % (cpu_model, socket_cores, sockets),
+            "sample": "%s: %d walkers x %d steps in the bench cadence (incl. step-0 and per-block energy evaluations), "
+                      "numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s; BLAS threads = cores of one socket"
+                      % (best["variant"], best["walkers"], best["steps"], best["seconds"]),
+            "variants": variants}
 
 
 def main():
     # a hang anywhere (driver, runtime, collective) ends the run with every thread's traceback instead of
     # waiting for the caller's timeout
     import faulthandler
-    faulthandler.dump_traceback_later(float(os.environ.get("AFQ_BENCH_WATCHDOG_S", "900")), exit=True)
+    import threading
+    limit = float(os.environ.get("AFQ_BENCH_WATCHDOG_S", "900"))
+    faulthandler.dump_traceback_later(limit + 10.0, exit=True)          # backstop if the thread below cannot run
+    state = {"dev": None, "phase": "start-up"}
+
+    def watchdog():
+        time.sleep(limit)
+        dev = state["dev"]
+        where = "no device yet"
+        if dev is not None:
+            try:
+                where = dev.last_launch()[0]          # host memory only: safe while the main thread is stuck in a sync
+            except Exception as e:                    # noqa: BLE001
+                where = "afq_last_launch failed: %r" % (e,)
+        sys.stderr.write("bench.py WATCHDOG after %.0f s in phase %r; library: %s\n" % (limit, state["phase"], where))
+        sys.stderr.flush()
+        faulthandler.dump_traceback(all_threads=True)
+        os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--walkers-per-gpu", type=int, default=NW_PER_GPU)
+    ap.add_argument("--walkers-per-gpu", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 256 walkers per GPU (BASELINE configs[2]); strong: 2048 walkers in total (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
     args = ap.parse_args()
@@ -114,15 +186,27 @@ def main():
 
     from pauxy_amd.qmc.afqmc import AFQMC
     system, trial = build_inputs()
-    nw = args.walkers_per_gpu
+    if args.steps < 100 and rank == 0:
+        sys.stderr.write("bench.py: --steps %d times a region of only ~%d ms with %d energy evaluations; use >= 100 steps "
+                         "for a stable number\n" % (args.steps, args.steps // 2, args.steps // NSTEPS_BLOCK))
+    if args.walkers_per_gpu is not None:
+        nw = args.walkers_per_gpu
+    elif args.scaling == "strong":
+        if STRONG_TOTAL % world:
+            raise SystemExit("strong scaling: %d walkers do not divide over %d GPUs" % (STRONG_TOTAL, world))
+        nw = STRONG_TOTAL // world
+    else:
+        nw = NW_PER_GPU
     options = {
         'qmc': {'timestep': DT, 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
                 'pop_control_freq': NPOP, 'num_walkers': nw * world, 'rng_seed': 7},
         'propagator': {'device_rng': not args.host_rng, 'rng_seed': 7, 'rng_stream': rank},
         'estimators': {'mixed': {'verbose': False}},
     }
+    state["phase"] = "set-up"
     afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
+    state["dev"] = dev
 
     def barrier():
         dev.sync()
@@ -141,8 +225,10 @@ def main():
         for _ in range(8):
             dev.local_energy(fetch=False)
         dev.sync()
+    state["phase"] = "warm-up"
     eshift = afqmc.run_batched(args.warmup, first_step=1, eshift=0.0)
     barrier()
+    state["phase"] = "timed region"
     # Event pairs around the launches of the two kernels that can dominate the step (fused propagator, exchange
     # energy), read after the timed region.  An event pair costs a few microseconds of pipeline bubble per launch:
     # with every hot kernel traced the step is 4 % slower (553 vs 531 us), so the per-step GEMMs are timed in a
@@ -155,6 +241,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev.kernel_trace(False)
+    state["phase"] = "after the timed region"
     if comm is not None:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -198,8 +285,11 @@ def main():
     if dom["measured"] != "timed region":
         raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tfile):
+    traffic_source = None
+    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                  if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
+    if tfile:
+        traffic_source = "%s: rocprofv3 --pmc passes of this command (not collected in this run)" % os.path.relpath(tfile, ROOT)
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
         with open(tfile) as f:
             traffic = json.load(f).get(dom["kernel"].split(" ")[0], {}).get("traffic_bytes_per_launch")
@@ -212,14 +302,19 @@ def main():
             "unit": "walker-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if args.walkers_per_gpu is None else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "generic Cholesky AFQMC: Nbasis=100, Nchol=500, RHF trial 25+25 electrons, "
                                    "%d walkers/GPU, dt=0.005, reortho/10, comb/5, energy/10 "
                                    "(BASELINE configs[2])" % nw,
-                       "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox"},
+                       "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox",
+                       "population_control": ("device comb over the library's RCCL communicator" if
+                                              getattr(afqmc.psi, 'device_comm', False) else
+                                              "device comb (one rank)" if world == 1 else "host-mediated (torch.distributed)")},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
                          "flops_per_launch": dom["flops_per_launch"]},
             "roofline_all": rows,
