@@ -63,6 +63,53 @@ def host_cpu():
     return model, cores or (os.cpu_count() or 1), max(1, len(sockets))
 
 
+def cpu_worker(variant, window):
+    """One single-threaded process of the 'socket-processes' CPU variant: oracle blocks of 2 walkers x 20 steps
+    in the bench cadence until `window` seconds have passed; prints {"walker_steps": n, "seconds": t}."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd.propagation.setup import generic_propagator_arrays
+    system, trial = build_inputs()
+    BH1, mf = generic_propagator_arrays(system, trial, DT)
+    hs = system.hs_pot.astype(numpy.complex128) if variant == "novcopy" else system.hs_pot
+    model = ref.RefModel('generic', M, N, N, trial.psi, BH1, mf, DT, hs_pot=hs, rchol=trial._rchol,
+                         H1=system.H1.astype(complex), ecore=system.ecore)
+    rng = numpy.random.RandomState(11 + os.getpid() % 1000)
+
+    def block(nw_, nblocks):
+        walkers = [ref.new_walker(model, trial.psi) for _ in range(nw_)]
+        ref.run_afqmc(model, walkers, lambda s, w: rng.normal(size=K), lambda s: rng.random_sample(), NSTEPS_BLOCK,
+                      nblocks, nstblz=NSTBLZ, npop_control=NPOP, energy_eval_freq=NSTEPS_BLOCK)
+        return nw_ * nblocks * NSTEPS_BLOCK
+    block(1, 1)                                             # warm-up
+    t0 = time.time()
+    done = 0
+    while time.time() - t0 < window:
+        done += block(2, 2)
+    print(json.dumps({"walker_steps": done, "seconds": time.time() - t0}))
+
+
+def cpu_socket_processes(variant, nproc, window=8.0):
+    """`nproc` concurrent single-threaded oracle processes (the reference's own parallelism is MPI over walkers,
+    qmc/afqmc.py:167-176): aggregate walker-steps/s = sum over processes of steps / own window."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", variant, "--cpu-window", str(window)]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(nproc)]
+    rate, steps, ok = 0.0, 0, 0
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            r = json.loads(out.strip().splitlines()[-1])
+            rate += r["walker_steps"] / r["seconds"]
+            steps += r["walker_steps"]
+            ok += 1
+        except Exception:                                   # noqa: BLE001
+            pass
+    return rate, steps, ok, time.time() - t0
+
+
 def cpu_baseline(system, trial):
     """the oracle ("port": per-walker numpy/scipy loop of oracle/afqmc_ref.py, the
     reference's algorithm and call sequence) timed on this host over bounded samples of the same workload and
@@ -72,7 +119,11 @@ def cpu_baseline(system, trial):
                          propagation/generic.py:177; this variant removes that accident) -- 32 walkers x 20 steps
       * socket-faithful: same threads, the reference's behaviour                     -- 16 walkers x 10 steps
       * one-thread     : 1 BLAS thread, faithful                                     --  4 walkers x 10 steps
-    The value reported is the FASTEST variant, so the speed-up is not won on the promotion copy."""
+      * socket-processes(-novcopy): one single-threaded oracle process per physical core of one socket, all running
+                         at once (the reference parallelises over walkers with MPI ranks, not with BLAS threads:
+                         qmc/afqmc.py:167-176), each timing its own 8 s window of 2-walker blocks
+    The value reported is the FASTEST variant, so the speed-up is neither won on the promotion copy nor on BLAS
+    threads that small per-walker matrices cannot use."""
     from oracle import afqmc_ref as ref
     from pauxy_amd.propagation.setup import generic_propagator_arrays
     try:
@@ -112,12 +163,16 @@ def cpu_baseline(system, trial):
             ("one-thread", system.hs_pot, 1, 4, 10)):
         v, dt = timed(hs, thr, nwc, nst)
         variants.append({"variant": name, "value": v, "threads": thr, "walkers": nwc, "steps": nst, "seconds": dt})
+    for name, var in (("socket-processes-novcopy", "novcopy"), ("socket-processes", "faithful")):
+        rate, steps, okp, wall = cpu_socket_processes(var, socket_cores)
+        variants.append({"variant": name, "value": rate, "threads": okp, "walkers": 2 * okp, "steps": steps // max(1, 2 * okp),
+                         "seconds": wall, "processes": okp})
     best = max(variants, key=lambda r: r["value"])
     return {"value": best["value"], "unit": "walker-steps/s", "cores": int(best["threads"]), "kind": "port",
             "cpu": "%s, %d cores/socket x %d sockets" % (cpu_model, socket_cores, sockets),
             "sample": "%s: %d walkers x %d steps in the bench cadence (incl. step-0 and per-block energy evaluations), "
-                      "numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s; BLAS threads = cores of one socket"
-                      % (best["variant"], best["walkers"], best["steps"], best["seconds"]),
+                      "numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s wall, %d thread(s) or process(es) on one socket"
+                      % (best["variant"], best["walkers"], best["steps"], best["seconds"], best["threads"]),
             "variants": variants}
 
 
@@ -153,7 +208,12 @@ def main():
                     help="weak: 256 walkers per GPU (BASELINE configs[2]); strong: 2048 walkers in total (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-window", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:                 # child of cpu_socket_processes: numpy only, never touches the GPU
+        cpu_worker(args.cpu_worker, args.cpu_window)
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

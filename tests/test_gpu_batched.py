@@ -95,6 +95,10 @@ def c3_afqmc(device_rng=False):
 def run_c3(batched, fetch):
     afqmc, s, t = c3_afqmc()
     numpy.random.seed(1234)
+    # walkers that all start on the trial keep weights within a few per cent of each other for the first blocks and
+    # the comb would clone nobody: start from a spread population
+    afqmc.psi.dev.set(L.F_WEIGHT, numpy.exp(0.6 * numpy.random.RandomState(5).normal(size=C3['nw'])))
+    afqmc.psi._invalidate()
     rec = dict(weight=[], ot=[], ehyb=[], pix=[])
 
     def on_step(step, psi):
