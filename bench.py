@@ -321,7 +321,12 @@ def main():
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR,
          8.0 * M * M * nt * (6 + 2) * nw),
-        ("exx_kernel (Cholesky exchange energy)", L.K_EXCHANGE, exchange_flops_per_walker(M, K, N, N) * nw),
+        # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
+        # GEMM per spin) executes 4 (N M)^2 flops per spin and walker -- K / M = 5 times fewer than the
+        # T-intermediate formulation of the reference (4 K M N^2); both counts are reported
+        (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g)", L.K_EXCHANGE,
+          4.0 * 2 * (N * M) ** 2 * nw) if dev.exchange_algorithm() == 2 else
+         ("exx_kernel (Cholesky exchange energy, T intermediate)", L.K_EXCHANGE, exchange_flops_per_walker(M, K, N, N) * nw)),
         # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted
         ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS,
          4.0 * (M * (M + 1) // 2) * K * nw),
@@ -334,7 +339,12 @@ def main():
         if len(ms) == 0:
             continue
         avg = float(numpy.mean(ms))
-        rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg,
+        extra = {}
+        if kind == L.K_EXCHANGE and dev.exchange_algorithm() == 2:
+            ref_flops = exchange_flops_per_walker(M, K, N, N) * nw
+            extra = {"reference_formulation_flops_per_launch": ref_flops,
+                     "effective_vs_reference_formulation": ref_flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg, **extra,
                      "measured": "timed region" if live else "extra pass of %d steps after the timed region" % extra_steps,
                      "ms_per_step": float(numpy.sum(ms)) / (args.steps if live else extra_steps), "flops_per_launch": flops,
                      "achieved": flops / (avg * 1e-3) / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -204,6 +204,16 @@ int afq_reortho(afq_handle *h, double *detR_out);
  * Ghalf/G (call afq_greens first): E c128[nw,3] = (E, E1, E2); may be NULL.   */
 int afq_local_energy(afq_handle *h, double *E_out);
 
+/* The exchange part of estimators/generic.py:198-216 has two device algorithms with the same result:
+ *   1  T-intermediate: T[x,i,j] = sum_p rchol[(i,p),x] Ghalf[j,p] on MFMA tiles, traced in registers
+ *      (4 K M N^2 flops per spin and walker)
+ *   2  quadratic form: exx = g^T Atil g with Atil[(j,p),(i,q)] = sum_x rchol[(i,p),x] rchol[(j,q),x] built once per
+ *      trial ((N M)^2 entries per spin in HBM) -- one [nw x NM] x [NM x NM] GEMM per evaluation, K / M times
+ *      fewer flops
+ * mode 0 (default) picks 2 when K >= M and the operands of all determinants fit 72 GB, else 1.            */
+int afq_set_exchange_algorithm(afq_handle *h, int mode);
+int afq_exchange_algorithm(afq_handle *h, int *mode_out);
+
 /* unit-test hooks (reference: <system propagator>.construct_force_bias /
  * construct_VHS, Continuous.apply_exponential, operations.kinetic_real)       */
 int afq_force_bias(afq_handle *h, double *xbar_out);                 /* c128[nw,K] */

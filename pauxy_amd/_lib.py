@@ -93,6 +93,8 @@ SIGNATURES = {
     "afq_comm_init_local": [POINTER(_h), c_int],
     "afq_popcontrol_comb_local": [POINTER(_h), c_int, c_double, c_double, c_void_p, POINTER(c_double)],
     "afq_estimates_allreduce_local": [POINTER(_h), c_int],
+    "afq_set_exchange_algorithm": [_h, c_int],
+    "afq_exchange_algorithm": [_h, POINTER(c_int)],
     "afq_kernel_trace": [_h, c_int],
     "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],
 }

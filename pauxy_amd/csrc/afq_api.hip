@@ -33,7 +33,8 @@ void stash_det(afq_handle *h) {
     if (h->ndet <= 1) return;
     afq_handle::DetOps &o = h->dets[h->cur_det];
     o.psi = h->psi; o.psic = h->psic; o.rH1 = h->rH1; o.rchol_re = h->rchol_re; o.rchol_im = h->rchol_im;
-    for (int s = 0; s < 2; ++s) { o.rchol_frag[s] = h->rchol_frag[s]; o.rchol_frag_im[s] = h->rchol_frag_im[s]; }
+    for (int s = 0; s < 2; ++s) { o.rchol_frag[s] = h->rchol_frag[s]; o.rchol_frag_im[s] = h->rchol_frag_im[s]; o.atil[s] = h->atil[s]; }
+    o.rchol_same = h->rchol_same;
 }
 
 void select_det(afq_handle *h, int d) {
@@ -41,7 +42,8 @@ void select_det(afq_handle *h, int d) {
     stash_det(h);
     const afq_handle::DetOps &o = h->dets[d];
     h->psi = o.psi; h->psic = o.psic; h->rH1 = o.rH1; h->rchol_re = o.rchol_re; h->rchol_im = o.rchol_im;
-    for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = o.rchol_frag[s]; h->rchol_frag_im[s] = o.rchol_frag_im[s]; }
+    for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = o.rchol_frag[s]; h->rchol_frag_im[s] = o.rchol_frag_im[s]; h->atil[s] = o.atil[s]; }
+    h->rchol_same = o.rchol_same;
     h->cur_det = d;
     if (h->nw) {
         h->ghalf = h->ghalf_all + (size_t)d * h->nw * h->M * h->nt;
@@ -62,9 +64,10 @@ void free_dets(afq_handle *h) {
                 if (o.rchol_frag[s]) hipFree(o.rchol_frag[s]);
                 if (o.rchol_frag_im[s]) hipFree(o.rchol_frag_im[s]);
             }
+            k_free_atil(o.atil);
         }
         h->psi = nullptr; h->psic = nullptr; h->rH1 = nullptr; h->rchol_re = nullptr; h->rchol_im = nullptr;
-        for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; }
+        for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; h->atil[s] = nullptr; }
     }
     h->dets.clear();
     h->ndet = 1; h->cur_det = 0;
@@ -75,6 +78,7 @@ void free_system(afq_handle *h) {
     free_dets(h);
     dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
+    k_free_atil(h->atil);
     dev_free(h->H1); dev_free(h->rH1);
     dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val); dev_free(h->ell_row); dev_free(h->ell_val); dev_free(h->ueg_rmap); dev_free(h->ueg_rows);
     dev_free(h->iB_colptr); dev_free(h->iB_row); dev_free(h->iB_val);
@@ -99,7 +103,7 @@ void free_walkers(afq_handle *h) {
     h->nbp = 0; dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
     dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
-    dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag);
+    dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag); dev_free(h->exq_y); h->exq_y_len = 0;
     dev_free(h->alive); dev_free(h->parent_ix);
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }
     h->exx_part_len = 0; h->gfrag_bytes = 0; h->nw = 0;
@@ -271,6 +275,8 @@ static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
     for (size_t q = 0; q < nq; ++q)
         for (int n = 0; n < K; ++n) re[q * h->ld_rc + n] = rchol[2 * (q * K + n)];
     h->rchol_real = real;
+    h->rchol_same = h->na == h->nb && memcmp(rchol, rchol + 2 * (size_t)h->na * h->M * K, sizeof(double) * 2 * (size_t)h->na * h->M * K) == 0;
+    k_free_atil(h->atil);                  // the quadratic-form operand belongs to the old vectors
     if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
     if (!real) {
         std::vector<double> im(nq * h->ld_rc, 0.0);
@@ -450,6 +456,7 @@ int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double
     free_dets(h);
     dev_free(h->psi); dev_free(h->psic); dev_free(h->rH1); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
+    k_free_atil(h->atil);
     const size_t npsi = (size_t)h->M * h->nt, nrc = npsi * h->K;
     const bool real = rchol_is_real(rchol, nrc * ndet);
     h->ndet = ndet; h->cur_det = 0;
@@ -461,7 +468,7 @@ int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double
             if (d > 0) {
                 stash_det(h);
                 h->psi = nullptr; h->psic = nullptr; h->rH1 = nullptr; h->rchol_re = nullptr; h->rchol_im = nullptr;
-                for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; }
+                for (int s = 0; s < 2; ++s) { h->rchol_frag[s] = nullptr; h->rchol_frag_im[s] = nullptr; h->atil[s] = nullptr; }
                 h->cur_det = d;
             }
         }
@@ -762,6 +769,12 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     if (xi) {
         if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
+    } else if (k_prop_fused_supported(h)) {
+        // nothing ahead of fields_kernel reads the fields or the alive flags on this path (the Green's function is
+        // evaluated for every walker, the one-body product sits inside the fused propagator): fields_kernel draws
+        // the same Philox stream itself and sets the flags
+        h->rng_inline = true;
+        h->rng_inline_counter = h->rng_counter++;
     } else {
         if ((rc = k_rng_normal(h))) return rc;           // draws the fields and sets the alive flags
     }
@@ -814,10 +827,20 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         // The overlap of the propagated walker is the determinant of the matrix whose inverse the next
         // step's Green's function needs (continuous.py:245 of step n+1), so factorise once: this call
         // leaves Ghalf of the NEW phi behind and the next afq_propagate / afq_estimates_update reuses it.
+        const bool le_msd = h->ndet > 1 && !fp && !(h->flags & AFQ_PROP_HYBRID);
+        h->fuse_weight_done = false;
+        h->fuse_weight_req = h->ndet == 1 && !le_msd;       // single determinant: k_greens may take the weight update along
+        h->fuse_eshift = cmake(eshift_re, eshift_im);
         if (h->greens_cache && !fp) {
-            if ((rc = greens_any(h, h->ovlp_new, true))) return rc;
+            rc = greens_any(h, h->ovlp_new, true);
+            h->fuse_weight_req = false;
+            if (rc) return rc;
             h->greens_valid = true;
-        } else if ((rc = greens_any(h, h->ovlp_new, false))) return rc;
+        } else {
+            rc = greens_any(h, h->ovlp_new, false);
+            h->fuse_weight_req = false;
+            if (rc) return rc;
+        }
         if (h->ndet > 1 && !fp && !(h->flags & AFQ_PROP_HYBRID)) {
             if ((rc = k_msd_energy_combine(h))) return rc;
         }
@@ -879,6 +902,19 @@ int afq_local_energy(afq_handle *h, double *E_out) {
     if (!h->rH1 && h->kind != AFQ_SYS_UEG) AFQ_FAIL(h, AFQ_ESTATE, "half-rotated H1 missing (set trial)");
     { PhaseTimer t(h, T_ENERGY); if ((rc = local_energy(h))) return rc; }
     return copy_out(h, E_out, h->energy, sizeof(cplx) * 3 * h->nw);
+}
+
+int afq_set_exchange_algorithm(afq_handle *h, int mode) {
+    if (!h || mode < 0 || mode > 2) return AFQ_EINVAL;
+    h->exx_mode = mode;
+    return AFQ_OK;
+}
+
+int afq_exchange_algorithm(afq_handle *h, int *mode) {
+    if (!h || !mode) return AFQ_EINVAL;
+    if (h->kind != AFQ_SYS_GENERIC || !h->have_trial) AFQ_FAIL(h, AFQ_ESTATE, "generic system and trial must be set");
+    *mode = k_exchange_uses_quadratic(h) ? 2 : 1;
+    return AFQ_OK;
 }
 
 int afq_last_energy_kernel_ms(afq_handle *h, double *ms) {

@@ -56,6 +56,13 @@ struct afq_handle {
     double *rchol_im = nullptr;     // f64 [nt*M, ld_rc] or null when real
     double *rchol_frag[2] = {nullptr, nullptr};   // energy-kernel A operand, fragment order, per spin
     double *rchol_frag_im[2] = {nullptr, nullptr};
+    // quadratic-form exchange (k_energy.hip): Atil_s [(N_s M), ldq] f64 (c128 when rchol is complex), built on first
+    // use; atil[1] == atil[0] when both spins have the same half-rotated vectors (closed-shell trial)
+    void *atil[2] = {nullptr, nullptr};
+    bool rchol_same = false;        // alpha and beta blocks of rchol are bitwise equal
+    int exx_mode = 0;               // afq_set_exchange_algorithm: 0 auto, 1 T-intermediate (exx_kernel), 2 quadratic form
+    cplx *exq_y = nullptr;          // [2 * slices, nw, ldy] partial products of the quadratic form
+    size_t exq_y_len = 0;
     cplx *H1 = nullptr;             // [2, M, M]
     cplx *rH1 = nullptr;            // half-rotated H1: [nt, M]; rH1[i][q] = sum_p conj(psi[p,i]) H1_s[p,q]
     // hubbard
@@ -88,6 +95,8 @@ struct afq_handle {
         cplx *psi = nullptr, *psic = nullptr, *rH1 = nullptr;
         double *rchol_re = nullptr, *rchol_im = nullptr;
         double *rchol_frag[2] = {nullptr, nullptr}, *rchol_frag_im[2] = {nullptr, nullptr};
+        void *atil[2] = {nullptr, nullptr};
+        bool rchol_same = false;
     };
     int ndet = 1, cur_det = 0;
     std::vector<DetOps> dets;       // size ndet when ndet > 1
@@ -183,8 +192,14 @@ struct afq_handle {
     bool no_vhs_upper = false;      // AFQ_VHS_MIRROR=1: always store both triangles of the HS potential (A/B runs)
     bool no_ring = false;           // AFQ_NO_RING=1: register-prefetch GEMM engine only (A/B runs)
 
+    // afq_propagate -> k_greens: run the step's weight update behind the determinant (greens_small_kernel)
+    bool fuse_weight_req = false, fuse_weight_done = false;
+    cplx fuse_eshift;
+
     // rng
     uint64_t rng_seed = 0, rng_stream = 0, rng_counter = 0;
+    bool rng_inline = false;            // this step's fields are drawn inside fields_kernel (no rng launch)
+    uint64_t rng_inline_counter = 0;
 
     // diagnostics: host-side breadcrumbs of the launches queued on the stream (afq_last_launch)
     const char *crumb_name[64] = {nullptr};     // ring of the last 64 kernel names (string literals)
@@ -354,6 +369,8 @@ int k_comm_popcontrol(afq_handle *h, double r, double target, bool with_greens);
 // k_energy.hip
 int k_energy_generic(afq_handle *h);
 int k_prepare_energy_operands(afq_handle *h, const double *rchol_host);
+int k_exchange_uses_quadratic(afq_handle *h);            // which algorithm k_energy_generic takes for the current trial
+void k_free_atil(void *(&atil)[2]);
 // k_models.hip (Hubbard / UEG)
 int k_vhs_hubbard(afq_handle *h);
 int k_apply_exponential_diag(afq_handle *h, const cplx *vhs_diag);

@@ -20,7 +20,7 @@
 //   afrag[s][i][xt][ks][lane] = rchol_s[(i, p = 4 ks + lane/16), x = 16 xt + lane%16]   (built once)
 //   gfrag[orb][c][wt][ks][lane] = (re|im) Ghalf[w = 16 wt + lane%16][orb][p = 4 ks + lane/16]
 #include <cstdlib>
-#include "lds_dma.h"
+#include "mfma_gemm_wg.h"
 
 #define EXX_CHUNKS 2      // wave-tasks per (spin, x-tile, walker-tile) cell
 
@@ -209,6 +209,104 @@ __global__ __launch_bounds__(256, 2) void exx_kernel(ExxArgs a) {
     if (lane < 16) a.part[task * 16 + lane] = cmake(sr, si);
 }
 
+// --------------------------------------------------------------------------
+// Exchange energy as a quadratic form (estimators/generic.py:198-216, re-associated):
+//   exx_s = sum_x sum_ij T[x,i,j] T[x,j,i],   T[x,i,j] = sum_p R[(i,p),x] G[j,p]            (R = rchol_s, G = Ghalf_s)
+//         = sum_{(j,p),(i,q)} G[j,p] Atil[(j,p),(i,q)] G[i,q],   Atil[(j,p),(i,q)] = sum_x R[(i,p),x] R[(j,q),x]
+// Atil_s is a property of the trial: (N_s M)^2 entries (50 MB per spin at M=100, N=25; 3.2 GB at M=400, N=50 -- this
+// is what 288 GB of HBM are for), built once on the device.  Per evaluation the exchange energy of every walker is
+// then ONE real-by-complex GEMM  Y[w, :] = g_w^T Atil  ([nw x NM] x [NM x NM], 4 nw (NM)^2 flops per spin) followed
+// by the dot products Y[w] . g_w in energy_finish_kernel: K / M times fewer flops than forming T (5x at K = 5 M),
+// and no Cholesky-index loop at all.  Same number to rounding (different summation order, ~1e-15 relative).
+// Used when K >= M and the matrices fit the memory budget; exx_kernel above otherwise.
+#define EXQ_MAX_BATCH 32
+template <bool RC>
+struct ExxQProb {
+    static constexpr bool A_CPLX = true, B_CPLX = RC;
+    int batch, rows, cols, kdim;      // 2 spins x slices, nw, max N_s M, longest slice
+    long astride;                     // elements between walkers in ghalf
+    long goff[EXQ_MAX_BATCH];         // first contraction element of the batch inside a walker's ghalf
+    int len[EXQ_MAX_BATCH];           // slice length
+    int ncol[EXQ_MAX_BATCH];          // N_s M of the batch's spin
+    const void *B[EXQ_MAX_BATCH];     // Atil_s + (slice start) * ldq
+    long ldq[EXQ_MAX_BATCH];
+    const cplx *ghalf;
+    cplx *Y;                          // [batch, nw, ldy] partial products
+    long ldy;
+    const cplx *zero;
+    __device__ bool active(int) const { return true; }
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        return k < len[b] ? ghalf + row * astride + goff[b] + k : zero;
+    }
+    __device__ const void *ptrB(int b, int k, int col) const {
+        if (k >= len[b] || col >= ncol[b]) return (const void *)zero;
+        return RC ? (const void *)((const cplx *)B[b] + k * ldq[b] + col) : (const void *)((const double *)B[b] + k * ldq[b] + col);
+    }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        if (col < ncol[b]) Y[((long)b * rows + row) * ldy + col] = cmake(re, im);
+    }
+};
+
+// A = R R^T (unconjugated) for one spin, stored permuted: out[(j,p),(i,q)] = A[(i,p),(j,q)].  One-time set-up
+// kernel: 64 x 64 tiles, 16 contraction indices per LDS stage, 4 x 4 outputs per thread on the fp64 vector ALU.
+template <bool RC>
+__global__ __launch_bounds__(256) void atilde_build_kernel(const double *Rre, const double *Rim, long ld, int K, int ns,
+                                                           int M, long row0, void *out_v, long ldo) {
+    __shared__ double As[RC ? 2 : 1][16][68], Bs[RC ? 2 : 1][16][68];
+    const int NM = ns * M;
+    const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double ar[4][4], ai[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { ar[u][v] = 0.0; ai[u][v] = 0.0; }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int t = threadIdx.x; t < 64 * 16; t += 256) {
+            const int r = t >> 4, kk = t & 15;
+            const bool kok = k0 + kk < K;
+            const bool aok = kok && tr + r < NM, bok = kok && tc + r < NM;
+            const long ia = (row0 + tr + r) * ld + k0 + kk, ib = (row0 + tc + r) * ld + k0 + kk;
+            As[0][kk][r] = aok ? Rre[ia] : 0.0;
+            Bs[0][kk][r] = bok ? Rre[ib] : 0.0;
+            if (RC) { As[1][kk][r] = aok ? Rim[ia] : 0.0; Bs[1][kk][r] = bok ? Rim[ib] : 0.0; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4], a2[4], b2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = As[0][kk][ty * 4 + u]; b[u] = Bs[0][kk][tx * 4 + u];
+                if (RC) { a2[u] = As[1][kk][ty * 4 + u]; b2[u] = Bs[1][kk][tx * 4 + u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    ar[u][v] = fma(a[u], b[v], ar[u][v]);
+                    if (RC) {
+                        ar[u][v] = fma(-a2[u], b2[v], ar[u][v]);
+                        ai[u][v] = fma(a[u], b2[v], ai[u][v]);
+                        ai[u][v] = fma(a2[u], b[v], ai[u][v]);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = tr + ty * 4 + u, c = tc + tx * 4 + v;
+            if (r >= NM || c >= NM) continue;
+            const int i = r / M, p = r % M, j = c / M, q = c % M;
+            const long dst = ((long)j * M + p) * ldo + (long)i * M + q;
+            if (RC) ((cplx *)out_v)[dst] = cmake(ar[u][v], ai[u][v]);
+            else ((double *)out_v)[dst] = ar[u][v];
+        }
+}
+
 // Ghalf [nw, nt, M] -> fragment order (see header comment)
 __global__ void gfrag_kernel(const cplx *ghalf, double *gfrag, int nw, int nt, int M, int nwt, int nks) {
     const int lane = threadIdx.x & 63;
@@ -230,6 +328,10 @@ struct EFinArgs {
     double ecore;
     const cplx *rH1, *ghalf, *vbias, *part;
     cplx *energy;
+    // quadratic-form exchange: Y[2 * qsplit, nw, ldy] (null: exx_kernel partials in `part`)
+    const cplx *Yq;
+    int qsplit, na;
+    long ldy;
 };
 
 __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
@@ -239,10 +341,20 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
     double e1r = 0, e1i = 0;
     const long nq = (long)a.nt * a.M;
     const cplx *gh = a.ghalf + (long)w * nq;
+    double exr = 0, exi = 0;
+    const long nqa = (long)a.na * a.M;
     for (long q = tid; q < nq; q += 256) {
         const cplx h = a.rH1[q], g = gh[q];
         e1r += h.x * g.x - h.y * g.y;
         e1i += h.x * g.y + h.y * g.x;
+        if (a.Yq) {      // exx += (g^T Atil)[q] g[q], slices summed in a fixed order
+            const int s = q < nqa ? 0 : 1;
+            const long c = q - (s ? nqa : 0);
+            cplx y = cmake(0.0, 0.0);
+            for (int sl = 0; sl < a.qsplit; ++sl) y = cadd(y, a.Yq[((long)(s * a.qsplit + sl) * a.nw + w) * a.ldy + c]);
+            exr += y.x * g.x - y.y * g.y;
+            exi += y.x * g.y + y.y * g.x;
+        }
     }
     // Coulomb
     double ecr = 0, eci = 0;
@@ -252,10 +364,9 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
         ecr += x.x * x.x - x.y * x.y;
         eci += 2.0 * x.x * x.y;
     }
-    // exchange partials of this walker
-    double exr = 0, exi = 0;
+    // exchange partials of this walker (exx_kernel path)
     const int wt = w >> 4, wl = w & 15;
-    const int np = 2 * a.nxt * EXX_CHUNKS;
+    const int np = a.Yq ? 0 : 2 * a.nxt * EXX_CHUNKS;
     for (int t = tid; t < np; t += 256) {
         const int chunk = t % EXX_CHUNKS;
         const int xt = (t / EXX_CHUNKS) % a.nxt;
@@ -314,12 +425,120 @@ int k_prepare_energy_operands(afq_handle *h, const double *rchol_host) {
     return AFQ_OK;
 }
 
+void k_free_atil(void *(&atil)[2]) {
+    if (atil[0]) hipFree(atil[0]);
+    if (atil[1] && atil[1] != atil[0]) hipFree(atil[1]);
+    atil[0] = atil[1] = nullptr;
+}
+
+// bytes of the quadratic-form operands of ONE determinant
+static double atil_bytes(afq_handle *h) {
+    const double e = h->rchol_real ? 8.0 : 16.0;
+    const double a = (double)h->na * h->M, b = (double)h->nb * h->M;
+    return e * (a * a + (h->rchol_same ? 0.0 : b * b));
+}
+
+int k_exchange_uses_quadratic(afq_handle *h) {
+    if (h->exx_mode == 1) return 0;
+    if (h->exx_mode == 2) return 1;
+    // K / M times fewer flops; the operands of every determinant must fit a quarter of the 288 GB
+    return h->K >= h->M && atil_bytes(h) * h->ndet <= 72e9;
+}
+
+static int ensure_atil(afq_handle *h) {
+    if (h->atil[0]) return AFQ_OK;
+    const int M = h->M;
+    for (int s = 0; s < 2; ++s) {
+        const int ns = s == 0 ? h->na : h->nb;
+        if (ns == 0) continue;
+        if (s == 1 && h->rchol_same) { h->atil[1] = h->atil[0]; break; }
+        const long NM = (long)ns * M, ldq = (NM + 1) & ~1L;
+        const size_t bytes = (size_t)NM * ldq * (h->rchol_real ? sizeof(double) : sizeof(cplx));
+        if (hipMalloc(&h->atil[s], bytes) != hipSuccess) AFQ_FAIL(h, AFQ_ENOMEM, "quadratic-form exchange operand does not fit");
+        AFQ_HIP(h, hipMemsetAsync(h->atil[s], 0, bytes, h->stream));
+        const dim3 grid((unsigned)((NM + 63) / 64), (unsigned)((NM + 63) / 64));
+        const long row0 = s == 0 ? 0 : (long)h->na * M;
+        if (h->rchol_real)
+            AFQ_LAUNCH(h, atilde_build_kernel<false>, grid, dim3(256), 0, h->stream, h->rchol_re, h->rchol_im, h->ld_rc, h->K, ns, M, row0, h->atil[s], ldq);
+        else
+            AFQ_LAUNCH(h, atilde_build_kernel<true>, grid, dim3(256), 0, h->stream, h->rchol_re, h->rchol_im, h->ld_rc, h->K, ns, M, row0, h->atil[s], ldq);
+        AFQ_POST(h);
+    }
+    return AFQ_OK;
+}
+
+template <bool RC>
+static int launch_exx_quadratic(afq_handle *h) {
+    const int M = h->M;
+    const long nma = (long)h->na * M, nmb = (long)h->nb * M, nmax = nma > nmb ? nma : nmb;
+    // contraction slices: enough 64 x 64 work-group tiles to fill the chip about twice
+    const long tiles = (long)((h->nw + 63) / 64) * ((nmax + 63) / 64) * (h->nb > 0 ? 2 : 1);
+    int S = (int)((1000 + tiles - 1) / tiles);
+    if (S < 1) S = 1;
+    if (S > EXQ_MAX_BATCH / 2) S = EXQ_MAX_BATCH / 2;
+    while (S > 1 && nmax / S < 64) --S;
+    if (afq_knob("AFQ_EXQ_SPLIT")) S = atoi(afq_knob("AFQ_EXQ_SPLIT"));
+    ExxQProb<RC> p;
+    p.batch = 2 * S; p.rows = h->nw; p.cols = (int)nmax; p.astride = (long)h->nt * M;
+    p.ghalf = h->ghalf; p.zero = (const cplx *)h->zero_page;
+    int kmax = 0;
+    for (int b = 0; b < 2 * S; ++b) {
+        const int s = b / S, sl = b % S;
+        const long tot = s == 0 ? nma : nmb;
+        if (tot == 0) { p.goff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; continue; }
+        const long ldq = (tot + 1) & ~1L;
+        long per = (tot + S - 1) / S;
+        per = (per + 7) & ~7L;                              // whole k-chunks per slice
+        long k0 = sl * per, l = tot - k0;
+        if (l > per) l = per;
+        if (l < 0) { l = 0; k0 = 0; }
+        p.goff[b] = (s ? nma : 0) + k0;
+        p.len[b] = (int)l; p.ncol[b] = (int)tot;
+        p.B[b] = h->rchol_real ? (const void *)((const double *)h->atil[s] + k0 * ldq) : (const void *)((const cplx *)h->atil[s] + k0 * ldq);
+        p.ldq[b] = ldq;
+        if (l > kmax) kmax = (int)l;
+    }
+    p.kdim = kmax;
+    const size_t need = (size_t)2 * S * h->nw * nmax;
+    if (h->exq_y_len < need) {
+        if (h->exq_y) hipFree(h->exq_y);
+        AFQ_HIP(h, hipMalloc(&h->exq_y, sizeof(cplx) * need));
+        h->exq_y_len = need;
+    }
+    p.Y = h->exq_y; p.ldy = nmax;
+    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : 0;
+    AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
+    {
+        KernelTrace kt(h, AFQ_K_EXCHANGE);
+        if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD, RC>(p, h->stream, h->zero_page)));
+        else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+    }
+    AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
+    h->energy_ev_valid = true;
+    return S;
+}
+
 int k_energy_generic(afq_handle *h) {
     const int M = h->M, K = h->K;
     const int nks = (M + 3) / 4, nxt = (K + 15) / 16, nwt = (h->nw + 15) / 16;
     // Coulomb vectors: the force-bias contraction on the current Ghalf
     int rc = k_force_bias_generic(h);
     if (rc) return rc;
+    if (k_exchange_uses_quadratic(h)) {
+        if ((rc = ensure_atil(h))) return rc;
+        const int S = h->rchol_real ? launch_exx_quadratic<false>(h) : launch_exx_quadratic<true>(h);
+        if (S < 0) return S;
+        EFinArgs f;
+        f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
+        f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = nullptr;
+        f.energy = h->energy; f.Yq = h->exq_y; f.qsplit = S; f.na = h->na;
+        f.ldy = (long)(h->na > h->nb ? h->na : h->nb) * M;
+        AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
+        AFQ_POST(h);
+        return AFQ_OK;
+    }
     const size_t gbytes = sizeof(double) * (size_t)h->nt * 2 * nwt * nks * 64;
     if (!h->gfrag || h->gfrag_bytes < gbytes) {
         if (h->gfrag) hipFree(h->gfrag);
@@ -360,7 +579,7 @@ int k_energy_generic(afq_handle *h) {
     EFinArgs f;
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
-    f.energy = h->energy;
+    f.energy = h->energy; f.Yq = nullptr; f.qsplit = 0; f.na = h->na; f.ldy = 0;
     AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
     AFQ_POST(h);
     return AFQ_OK;

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     // every SIMD carries the same MFMA load.  Waves 0-3 own a 2 x 2 block of the first four row tiles, waves 4-7
     // a 3 x 1 block (row tiles 4-6 of one column tile); waves w and w+4 share a SIMD: 4 + 3 = 7 tiles each
     // instead of the 8 (one of them pure padding) of an 8-row-tile deal.
-    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0) __attribute__((always_inline)) {
+    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0, const int rcount) __attribute__((always_inline)) {
         constexpr int NI = decltype(ni_tag)::value, NJ = decltype(nj_tag)::value;
         bool cv[NJ], rv[NI];
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             cv[j] = (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) rv[i] = r0 + i < nrt;
+        for (int i = 0; i < NI; ++i) rv[i] = i < rcount && r0 + i < nrt;
         d4_t SR[NI][NJ], SI[NI][NJ];                              // running sum, this wave's tiles
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -356,8 +356,18 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             lds_barrier();                                       // T_n visible
         }
     };
-    if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, 2 * (wave >> 1), 2 * (wave & 1));
-    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 4, wave - 4);
+    if (a.na <= 16 && a.nb <= 16) {
+        // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
+        // waves 4-7 the row tiles from 4 on: singly when there are six (3 tiles on every SIMD), as a pair + a single
+        // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (wave < 4) taylor(I2{}, I1{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
+        else if (nrt <= 6) taylor(I2{}, I1{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
+        else taylor(I2{}, I1{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2);
+    }
+    else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
+    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 4, wave - 4, 3);
     if (a.order == 0) lds_barrier();
 
     one_body_stage(true);

@@ -4,6 +4,7 @@
 // the mixed-estimator accumulation.  One workgroup per walker; panels live in
 // LDS when they fit and in a global workspace otherwise.
 #include <cstdlib>
+#include <cstring>
 #include "mfma_gemm.h"
 #include "gj_wave.h"
 
@@ -166,6 +167,121 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
 
 
 // --------------------------------------------------------------------------
+__device__ inline cplx clog_(cplx z) { return cmake(log(hypot(z.x, z.y)), atan2(z.y, z.x)); }
+__device__ inline cplx cexp_(cplx z) {
+    const double e = exp(z.x);
+    double s, c; sincos(z.y, &s, &c);
+    return cmake(e * c, e * s);
+}
+
+struct WeightArgs {
+    int nw, flags;
+    double dt;
+    cplx eshift;
+    const int *alive;
+    const cplx *ovlp_old, *ovlp_new, *cmf, *cfb;
+    double *weight;
+    cplx *ot, *ehyb, *phase, *eloc;
+    const cplx *energy;         // [nw, 3] local energy of the walker before the step (hybrid == false)
+    unsigned long long *counters;
+    // back-propagation bookkeeping (continuous.py:284-289,310-315, walkers/stack.py:51-76); null = off
+    int *bp_flag;
+    double *bp_cos;
+    cplx *bp_ph;
+    // weight cap of the driver (qmc/afqmc.py:235-236) applied right behind the update; cap_frac <= 0: off
+    double cap_frac, cap_total;
+    const double *cap_total_dev;    // total weight of the last comb when cap_total < 0
+};
+
+static WeightArgs weight_args(afq_handle *h, cplx eshift);
+static WeightArgs no_weight_args() {
+    WeightArgs a;
+    memset(&a, 0, sizeof(a));
+    return a;
+}
+
+__device__ inline void bp_record(const WeightArgs &a, int w, double magn, cplx wfac0, double cosine_fac) {
+    if (!a.bp_flag) return;
+    if (!(magn > 1e-16)) { wfac0 = cmake(0.0, 0.0); cosine_fac = 0.0; }
+    a.bp_flag[w] = 1;
+    a.bp_cos[w] *= cosine_fac;
+    a.bp_ph[w] = cmul(a.bp_ph[w], wfac0);
+}
+
+// propagation/continuous.py:264-292 (hybrid) and :194-200 (free projection)
+__device__ static void weight_update(const WeightArgs &a, const int w) {
+    if (a.bp_flag) a.bp_flag[w] = 0;
+    if (!a.alive[w]) return;
+    const cplx on = a.ovlp_new[w];
+    if (a.flags & AFQ_PROP_FREE_PROJECTION) {
+        const cplx e = cexp_(cmake(a.cmf[w].x + a.dt * a.eshift.x, a.cmf[w].y + a.dt * a.eshift.y));
+        const double magn = hypot(e.x, e.y), dth = atan2(e.y, e.x);
+        a.weight[w] *= magn;
+        double s, c; sincos(dth, &s, &c);
+        a.phase[w] = cmul(a.phase[w], cmake(c, s));
+        a.ot[w] = on;
+        return;
+    }
+    const cplx ratio = cdiv(on, a.ovlp_old[w]);
+    if (!(a.flags & AFQ_PROP_HYBRID)) {
+        // local-energy weight update, propagation/continuous.py:294-318 (+ :216-230)
+        const cplx el = a.energy[3 * w];
+        double re = el.x;
+        const double ebound = sqrt(2.0 / a.dt);
+        if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {
+            if (re > a.eshift.x + ebound) { re = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
+            else if (re < a.eshift.x - ebound) { re = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
+        }
+        const double magn = exp(-0.5 * a.dt * (re + a.eloc[w].x - a.eshift.x));
+        const double wfac_imag = exp(-0.5 * a.dt * (el.y + a.eloc[w].y - a.eshift.y));   // continuous.py:299
+        a.eloc[w] = el;
+        a.ot[w] = on;
+        if (!isinf(magn)) {
+            const double cf = fmax(0.0, cos(atan2(ratio.y, ratio.x)));
+            a.weight[w] *= magn * cf;
+            bp_record(a, w, magn, cmake(wfac_imag, 0.0), cf);
+        } else a.weight[w] = 0.0;
+        return;
+    }
+    const cplx lg = clog_(ratio);
+    cplx eh = cmake(-(lg.x + a.cfb[w].x + a.cmf[w].x) / a.dt, -(lg.y + a.cfb[w].y + a.cmf[w].y) / a.dt);
+    const double ebound = sqrt(2.0 / a.dt);
+    if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {       // continuous.py:206
+        if (eh.x > a.eshift.x + ebound) { eh.x = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
+        else if (eh.x < a.eshift.x - ebound) { eh.x = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
+    }
+    const cplx old = a.ehyb[w];
+    const cplx arg = cmake(-a.dt * (0.5 * (eh.x + old.x) - a.eshift.x), -a.dt * (0.5 * (eh.y + old.y) - a.eshift.y));
+    const cplx imp = cexp_(arg);
+    const double magn = hypot(imp.x, imp.y);
+    a.ehyb[w] = eh;
+    a.ot[w] = on;
+    if (!isinf(magn)) {
+        const double dtheta = -a.dt * eh.y - a.cfb[w].y;
+        const double cf = fmax(0.0, cos(dtheta));
+        a.weight[w] *= magn * cf;
+        bp_record(a, w, magn, cmake(imp.x / magn, imp.y / magn), cf);
+    } else {
+        a.weight[w] = 0.0;
+    }
+}
+
+__device__ static void weight_update_and_cap(const WeightArgs &a, const int w) {
+    weight_update(a, w);
+    if (a.cap_frac > 0.0) {
+        // every walker, propagated or not, exactly like the driver's loop
+        const double cap = a.cap_frac * (a.cap_total < 0.0 ? a.cap_total_dev[0] : a.cap_total);
+        if (fabs(a.weight[w]) > cap) a.weight[w] = cap;
+    }
+}
+
+__global__ void weight_kernel(WeightArgs a) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nw) return;
+    weight_update_and_cap(a, w);
+}
+
+// --------------------------------------------------------------------------
 // Fast path for N <= 45 electrons per spin (the overlap matrix and its inverse
 // fit LDS twice over).  One 512-thread workgroup per walker: waves 0-3 work on
 // spin up, waves 4-7 on spin down, in lock step.
@@ -175,8 +291,11 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
 //   phase 3  Ghalf_s = O^-1 phi_s^T             fp64 MFMA, A fragment from LDS
 // (reference: scipy.linalg.inv + numpy.dot + slogdet, walkers/single_det.py:310-320)
 #define GS_KSMAX 32       // k-steps of 4 supported by the fast Green's kernel (M <= 128)
+// wa.weight != null: the hybrid / free-projection weight update of this walker (propagation/continuous.py:264-292,
+// :194-200) and the driver's weight cap run right behind its determinant (a.det IS wa.ovlp_new then), which
+// saves the separate weight_kernel launch of the step.
 template <bool INVERSE>
-__global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
+__global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cplx ph_s[2];
     __shared__ double la_s[2];
@@ -374,6 +493,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a) {
         const cplx p2 = (a.dbg & 1) ? cmake(1.0, 0.0) : cmul(ph_s[0], ph_s[1]);
         const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
+        if (wa.weight) weight_update_and_cap(wa, w);
     }
     if (INVERSE && a.oinv) {
         cplx *oo = a.oinv + ((long)w * 2 + g) * nmax * nmax;
@@ -421,6 +541,14 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     }
     if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
+        // the step's weight update rides on this launch when afq_propagate asked for it and this IS the
+        // overlap of the propagated walkers
+        WeightArgs wa = no_weight_args();
+        if (h->fuse_weight_req && det == h->ovlp_new && !only_alive && !oinv) {
+            wa = weight_args(h, h->fuse_eshift);
+            h->fuse_weight_done = true;
+        }
+        h->fuse_weight_req = false;
         static const int dbg = afq_knob("AFQ_GREENS_DBG") ? atoi(afq_knob("AFQ_GREENS_DBG")) : 0;
         a.dbg = dbg;
         if (h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "fast Green's kernel supports M <= 128");
@@ -431,10 +559,10 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         if (ghalf || oinv) {
             AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true>, lds, lds_set1));
             KernelTrace kt(h, AFQ_K_GREENS);
-            AFQ_LAUNCH(h, greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
+            AFQ_LAUNCH(h, greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
         } else {
             AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false>, lds, lds_set0));
-            AFQ_LAUNCH(h, greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+            AFQ_LAUNCH(h, greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
         }
         AFQ_POST(h);
         return AFQ_OK;
@@ -605,6 +733,39 @@ int k_msd_energy_combine(afq_handle *h) {
 }
 
 // --------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller: the device stream of
+// auxiliary fields used when the host passes xi == NULL (performance mode; the
+// parity mode uploads numpy's legacy MT19937 normals instead).
+__device__ inline void philox_round(unsigned int &c0, unsigned int &c1, unsigned int &c2, unsigned int &c3,
+                                    unsigned int k0, unsigned int k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned int h0 = (unsigned int)(p0 >> 32), l0 = (unsigned int)p0;
+    const unsigned int h1 = (unsigned int)(p1 >> 32), l1 = (unsigned int)p1;
+    const unsigned int n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+}
+
+// the two normals of element pair `pair` of launch `counter` of the stream (seed, stream)
+__device__ inline void philox_normal_pair(long pair, unsigned long long seed, unsigned long long stream,
+                                          unsigned long long counter, double &x0, double &x1) {
+    unsigned int c0 = (unsigned int)pair, c1 = (unsigned int)(pair >> 32);
+    unsigned int c2 = (unsigned int)counter, c3 = (unsigned int)(counter >> 32) ^ (unsigned int)(stream * 0x9E3779B9u);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    // two 53-bit uniforms: u1 in (0, 1], u2 in (0, 1)
+    const unsigned long long a = (((unsigned long long)c0 << 32) | c1) >> 11;
+    const unsigned long long b = (((unsigned long long)c2 << 32) | c3) >> 11;
+    const double u1 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)b + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c; sincospi(2.0 * u2, &s, &c);
+    x0 = rad * c; x1 = rad * s;
+}
+
+// --------------------------------------------------------------------------
 __device__ inline double block_sum(double v, double *red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -619,20 +780,41 @@ __device__ inline double block_sum(double v, double *red) {
 // propagation/continuous.py:140-158: clip, shift, constant factors
 // FUSED: the force bias of (w, n) is evaluated here from the contraction output (xbar_value) instead
 // of being read back from a separate xbar_kernel launch
+// rng.on: the auxiliary fields are drawn here from the device stream instead of being read from xi (the same
+// numbers rng_normal_kernel writes: element e = w K + n is member e & 1 of Philox pair e >> 1), and the alive
+// flag of the step (qmc/afqmc.py:232) is set here too -- one launch less per step.
+struct FieldRng {
+    int on;
+    unsigned long long seed, stream, counter;
+    const double *weight;
+    int *alive_out;
+};
+
 template <bool FUSED>
 __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, const double *xi, cplx *xbar,
                                                       const cplx *mf, cplx *xs, cplx *cmf, cplx *cfb,
-                                                      unsigned long long *counters, const int *alive, XbarArgs xa) {
+                                                      unsigned long long *counters, const int *alive, XbarArgs xa,
+                                                      FieldRng rng) {
     __shared__ double red[8];
     const int w = blockIdx.x;
-    if (alive && !alive[w]) return;
+    if (rng.on) {
+        const bool live = fabs(rng.weight[w]) > 1e-8;
+        if (threadIdx.x == 0) rng.alive_out[w] = live ? 1 : 0;
+        if (!live) return;
+    } else if (alive && !alive[w]) return;
     double s_mf_r = 0, s_mf_i = 0, s_xx_r = 0, s_xx_i = 0, s_bb_r = 0, s_bb_i = 0;
     unsigned int ntrig = 0;
     for (int n = threadIdx.x; n < K; n += NTHR) {
         cplx b = FUSED ? xbar_value(xa, w, n) : xbar[(long)w * K + n];
         const double ab = hypot(b.x, b.y);
         if (ab > 1.0) { b.x /= ab; b.y /= ab; ++ntrig; }
-        const double x = xi[(long)w * K + n];
+        double x;
+        if (rng.on) {
+            const long e = (long)w * K + n;
+            double x0, x1;
+            philox_normal_pair(e >> 1, rng.seed, rng.stream, rng.counter, x0, x1);
+            x = (e & 1) ? x1 : x0;
+        } else x = xi[(long)w * K + n];
         const cplx sft = cmake(x - b.x, -b.y);
         xbar[(long)w * K + n] = b;
         xs[(long)w * K + n] = sft;
@@ -656,15 +838,21 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
 
 int k_fields(afq_handle *h) {
     AFQ_LAUNCH(h, fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
-                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, XbarArgs());
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, XbarArgs(), FieldRng());
     AFQ_POST(h);
     return AFQ_OK;
 }
 
 // force bias from the contraction output + clip + shift in one launch (the step's hot path)
 int k_xbar_fields(afq_handle *h) {
+    FieldRng rng = FieldRng();
+    if (h->rng_inline) {
+        rng.on = 1; rng.seed = h->rng_seed; rng.stream = h->rng_stream; rng.counter = h->rng_inline_counter;
+        rng.weight = h->weight; rng.alive_out = h->alive;
+        h->rng_inline = false;
+    }
     AFQ_LAUNCH(h, fields_kernel<true>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
-                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xbar_args(h));
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xbar_args(h), rng);
     AFQ_POST(h);
     return AFQ_OK;
 }
@@ -673,113 +861,9 @@ int k_fields_explicit(afq_handle *h, const double *xi_d, const cplx *xbar_d, cpl
                       cplx *cfb_d) {
     AFQ_LAUNCH(h, fields_kernel<false>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, xi_d,
                        (cplx *)xbar_d, h->mf_shift, xs_d, cmf_d, cfb_d, (unsigned long long *)nullptr,
-                       (const int *)nullptr, XbarArgs());
+                       (const int *)nullptr, XbarArgs(), FieldRng());
     AFQ_POST(h);
     return AFQ_OK;
-}
-
-// --------------------------------------------------------------------------
-__device__ inline cplx clog_(cplx z) { return cmake(log(hypot(z.x, z.y)), atan2(z.y, z.x)); }
-__device__ inline cplx cexp_(cplx z) {
-    const double e = exp(z.x);
-    double s, c; sincos(z.y, &s, &c);
-    return cmake(e * c, e * s);
-}
-
-struct WeightArgs {
-    int nw, flags;
-    double dt;
-    cplx eshift;
-    const int *alive;
-    const cplx *ovlp_old, *ovlp_new, *cmf, *cfb;
-    double *weight;
-    cplx *ot, *ehyb, *phase, *eloc;
-    const cplx *energy;         // [nw, 3] local energy of the walker before the step (hybrid == false)
-    unsigned long long *counters;
-    // back-propagation bookkeeping (continuous.py:284-289,310-315, walkers/stack.py:51-76); null = off
-    int *bp_flag;
-    double *bp_cos;
-    cplx *bp_ph;
-    // weight cap of the driver (qmc/afqmc.py:235-236) applied right behind the update; cap_frac <= 0: off
-    double cap_frac, cap_total;
-    const double *cap_total_dev;    // total weight of the last comb when cap_total < 0
-};
-
-__device__ inline void bp_record(const WeightArgs &a, int w, double magn, cplx wfac0, double cosine_fac) {
-    if (!a.bp_flag) return;
-    if (!(magn > 1e-16)) { wfac0 = cmake(0.0, 0.0); cosine_fac = 0.0; }
-    a.bp_flag[w] = 1;
-    a.bp_cos[w] *= cosine_fac;
-    a.bp_ph[w] = cmul(a.bp_ph[w], wfac0);
-}
-
-// propagation/continuous.py:264-292 (hybrid) and :194-200 (free projection)
-__device__ static void weight_update(const WeightArgs &a, const int w) {
-    if (a.bp_flag) a.bp_flag[w] = 0;
-    if (!a.alive[w]) return;
-    const cplx on = a.ovlp_new[w];
-    if (a.flags & AFQ_PROP_FREE_PROJECTION) {
-        const cplx e = cexp_(cmake(a.cmf[w].x + a.dt * a.eshift.x, a.cmf[w].y + a.dt * a.eshift.y));
-        const double magn = hypot(e.x, e.y), dth = atan2(e.y, e.x);
-        a.weight[w] *= magn;
-        double s, c; sincos(dth, &s, &c);
-        a.phase[w] = cmul(a.phase[w], cmake(c, s));
-        a.ot[w] = on;
-        return;
-    }
-    const cplx ratio = cdiv(on, a.ovlp_old[w]);
-    if (!(a.flags & AFQ_PROP_HYBRID)) {
-        // local-energy weight update, propagation/continuous.py:294-318 (+ :216-230)
-        const cplx el = a.energy[3 * w];
-        double re = el.x;
-        const double ebound = sqrt(2.0 / a.dt);
-        if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {
-            if (re > a.eshift.x + ebound) { re = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
-            else if (re < a.eshift.x - ebound) { re = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
-        }
-        const double magn = exp(-0.5 * a.dt * (re + a.eloc[w].x - a.eshift.x));
-        const double wfac_imag = exp(-0.5 * a.dt * (el.y + a.eloc[w].y - a.eshift.y));   // continuous.py:299
-        a.eloc[w] = el;
-        a.ot[w] = on;
-        if (!isinf(magn)) {
-            const double cf = fmax(0.0, cos(atan2(ratio.y, ratio.x)));
-            a.weight[w] *= magn * cf;
-            bp_record(a, w, magn, cmake(wfac_imag, 0.0), cf);
-        } else a.weight[w] = 0.0;
-        return;
-    }
-    const cplx lg = clog_(ratio);
-    cplx eh = cmake(-(lg.x + a.cfb[w].x + a.cmf[w].x) / a.dt, -(lg.y + a.cfb[w].y + a.cmf[w].y) / a.dt);
-    const double ebound = sqrt(2.0 / a.dt);
-    if (hypot(a.eshift.x, a.eshift.y) >= 1e-10) {       // continuous.py:206
-        if (eh.x > a.eshift.x + ebound) { eh.x = a.eshift.x + ebound; atomicAdd(&a.counters[1], 1ull); }
-        else if (eh.x < a.eshift.x - ebound) { eh.x = a.eshift.x - ebound; atomicAdd(&a.counters[1], 1ull); }
-    }
-    const cplx old = a.ehyb[w];
-    const cplx arg = cmake(-a.dt * (0.5 * (eh.x + old.x) - a.eshift.x), -a.dt * (0.5 * (eh.y + old.y) - a.eshift.y));
-    const cplx imp = cexp_(arg);
-    const double magn = hypot(imp.x, imp.y);
-    a.ehyb[w] = eh;
-    a.ot[w] = on;
-    if (!isinf(magn)) {
-        const double dtheta = -a.dt * eh.y - a.cfb[w].y;
-        const double cf = fmax(0.0, cos(dtheta));
-        a.weight[w] *= magn * cf;
-        bp_record(a, w, magn, cmake(imp.x / magn, imp.y / magn), cf);
-    } else {
-        a.weight[w] = 0.0;
-    }
-}
-
-__global__ void weight_kernel(WeightArgs a) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.nw) return;
-    weight_update(a, w);
-    if (a.cap_frac > 0.0) {
-        // every walker, propagated or not, exactly like the driver's loop
-        const double cap = a.cap_frac * (a.cap_total < 0.0 ? a.cap_total_dev[0] : a.cap_total);
-        if (fabs(a.weight[w]) > cap) a.weight[w] = cap;
-    }
 }
 
 // FieldConfig.update: append this step's shifted fields to the walker's history
@@ -898,7 +982,16 @@ int k_bp_reset(afq_handle *h) {
     return AFQ_OK;
 }
 
+
 int k_update_weight(afq_handle *h, cplx eshift) {
+    if (h->fuse_weight_done) { h->fuse_weight_done = false; return AFQ_OK; }   // rode on the Green's function kernel
+    const WeightArgs a = weight_args(h, eshift);
+    AFQ_LAUNCH(h, weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
+static WeightArgs weight_args(afq_handle *h, cplx eshift) {
     WeightArgs a;
     a.nw = h->nw; a.flags = h->flags; a.dt = h->dt; a.eshift = eshift; a.alive = h->alive;
     a.ovlp_old = h->ovlp_old; a.ovlp_new = h->ovlp_new; a.cmf = h->cmf; a.cfb = h->cfb;
@@ -906,9 +999,7 @@ int k_update_weight(afq_handle *h, cplx eshift) {
     a.eloc = h->eloc; a.energy = h->energy;
     a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
     a.cap_frac = h->cap_frac; a.cap_total = h->cap_total; a.cap_total_dev = h->scal;
-    AFQ_LAUNCH(h, weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, a);
-    AFQ_POST(h);
-    return AFQ_OK;
+    return a;
 }
 
 // --------------------------------------------------------------------------
@@ -1263,19 +1354,6 @@ int k_estimates(afq_handle *h, int have_energy) {
     return AFQ_OK;
 }
 
-// --------------------------------------------------------------------------
-// Philox4x32-10 counter-based generator + Box-Muller: the device stream of
-// auxiliary fields used when the host passes xi == NULL (performance mode; the
-// parity mode uploads numpy's legacy MT19937 normals instead).
-__device__ inline void philox_round(unsigned int &c0, unsigned int &c1, unsigned int &c2, unsigned int &c3,
-                                    unsigned int k0, unsigned int k1) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned int h0 = (unsigned int)(p0 >> 32), l0 = (unsigned int)p0;
-    const unsigned int h1 = (unsigned int)(p1 >> 32), l1 = (unsigned int)p1;
-    const unsigned int n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-}
-
 // also refreshes the alive flags of the step (qmc/afqmc.py:232) so that the device-RNG path needs no
 // separate alive_kernel launch
 __global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, unsigned long long stream,
@@ -1283,22 +1361,10 @@ __global__ void rng_normal_kernel(double *xi, long n, unsigned long long seed, u
     const long pair = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (pair < nw) alive[pair] = fabs(weight[pair]) > 1e-8 ? 1 : 0;
     if (2 * pair >= n) return;
-    unsigned int c0 = (unsigned int)pair, c1 = (unsigned int)(pair >> 32);
-    unsigned int c2 = (unsigned int)counter, c3 = (unsigned int)(counter >> 32) ^ (unsigned int)(stream * 0x9E3779B9u);
-    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
-    for (int rd = 0; rd < 10; ++rd) {
-        philox_round(c0, c1, c2, c3, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    // two 53-bit uniforms in (0, 1]
-    const unsigned long long a = (((unsigned long long)c0 << 32) | c1) >> 11;
-    const unsigned long long b = (((unsigned long long)c2 << 32) | c3) >> 11;
-    const double u1 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
-    const double u2 = ((double)b + 0.5) * (1.0 / 9007199254740992.0);
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c; sincospi(2.0 * u2, &s, &c);
-    xi[2 * pair] = rad * c;
-    if (2 * pair + 1 < n) xi[2 * pair + 1] = rad * s;
+    double x0, x1;
+    philox_normal_pair(pair, seed, stream, counter, x0, x1);
+    xi[2 * pair] = x0;
+    if (2 * pair + 1 < n) xi[2 * pair + 1] = x1;
 }
 
 // uniforms in [0, 1) (53 bits), same counter-based stream

@@ -56,7 +56,9 @@ struct FragSet {
 //   MAP_ROWS_FAST  consecutive waves walk tile rows of one tile column (share the B panel)
 //   MAP_BATCH_XCD  batch b runs on XCD b % 8: each batch's operand slices stay in one L2
 //   MAP_COLPANEL_XCD  (work-group engine, batch == 1) column panel c and all its row tiles run on XCD c % 8
-enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3 };
+//   MAP_BATCH_XCD_ROWS  (work-group engine) as MAP_BATCH_XCD, tile rows fastest inside a batch: the row tiles of one
+//                       B column panel run back to back on one XCD
+enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3, MAP_BATCH_XCD_ROWS = 4 };
 
 template <int TM, int TN, class P, int MAP = MAP_COLS_FAST>
 __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {

@@ -53,14 +53,15 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     const int tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
     const long per_batch = (long)tiles_m * tiles_n;
     int b, tm, tn;
-    if (MAP == MAP_BATCH_XCD) {
+    if (MAP == MAP_BATCH_XCD || MAP == MAP_BATCH_XCD_ROWS) {
         const int nb8 = p.batch < 8 ? p.batch : 8;
         const int grp = blockIdx.x % nb8;
         const long t = blockIdx.x / nb8;
         b = grp + (int)(t / per_batch) * nb8;
         if (b >= p.batch) return;
         const int rem = (int)(t % per_batch);
-        tm = rem / tiles_n; tn = rem % tiles_n;
+        if (MAP == MAP_BATCH_XCD_ROWS) { tn = rem / tiles_m; tm = rem % tiles_m; }
+        else { tm = rem / tiles_n; tn = rem % tiles_n; }
     } else if (MAP == MAP_COLPANEL_XCD) {
         // single batch: work-groups are dealt round-robin to the 8 XCDs, so XCD x takes the column panels
         // x, x+8, ... with ALL their row tiles: a B panel (and its slice of the output) stays in one L2
@@ -223,7 +224,7 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     const long per_batch = tiles_m * tiles_n;
     long nblk = (long)p.batch * per_batch;
     if (nblk == 0) return hipSuccess;
-    if (MAP == MAP_BATCH_XCD) {
+    if (MAP == MAP_BATCH_XCD || MAP == MAP_BATCH_XCD_ROWS) {
         const int nb8 = p.batch < 8 ? p.batch : 8;
         nblk = per_batch * ((p.batch + nb8 - 1) / nb8) * nb8;
     }

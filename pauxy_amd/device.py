@@ -416,6 +416,15 @@ class AfqDevice(object):
         self._ck(self.lib.afq_kernel_trace_get(self.h, int(kind), _p(out), max_n, ctypes.byref(n)))
         return out[:min(n.value, max_n)]
 
+    def set_exchange_algorithm(self, mode):
+        """0 automatic, 1 T-intermediate (exx_kernel), 2 quadratic form (see afq_set_exchange_algorithm)."""
+        self._ck(self.lib.afq_set_exchange_algorithm(self.h, int(mode)))
+
+    def exchange_algorithm(self):
+        m = ctypes.c_int()
+        self._ck(self.lib.afq_exchange_algorithm(self.h, ctypes.byref(m)))
+        return m.value
+
     def last_energy_kernel_ms(self):
         ms = ctypes.c_double()
         self._ck(self.lib.afq_last_energy_kernel_ms(self.h, ctypes.byref(ms)))

@@ -127,6 +127,32 @@ def test_c3_generic_256_walkers():
     run_fullsize(generic_c3(256), 256, [0, 100, 255])
 
 
+def test_c3_exchange_algorithms_agree():
+    """BASELINE configs[2] size, 256 walkers: quadratic-form exchange energy (the default there, K = 5 M) against the
+    T-intermediate kernel for every walker, and a sample against the oracle."""
+    model = generic_c3(256)
+    rng = numpy.random.RandomState(9)
+    nw, M, nt = 256, model.M, model.na + model.nb
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, M, nt) + 1j * rng.rand(nw, M, nt))
+    E = {}
+    for mode in (1, 2):
+        dev = make_device(model, nw)
+        dev.set_exchange_algorithm(mode)
+        dev.set(L.F_PHI, phis)
+        dev.greens()
+        E[mode] = dev.local_energy()
+        if mode == 2:
+            assert dev.exchange_algorithm() == 2
+        dev.close()
+    close(E[1], E[2], 1e-12)
+    dev = make_device(model, nw)
+    assert dev.exchange_algorithm() == 2                            # what bench.py runs
+    dev.close()
+    for w in (0, 17, 255):
+        _, gh, Gr = ref.greens_function(phis[w], model.psi, model.na, model.nb)
+        close(E[2][w], numpy.array(model.local_energy(Gr, gh)), 1e-10)
+
+
 def test_c4_hubbard_16x16():
     run_fullsize(hubbard_c4(), 32, [0, 31])
 

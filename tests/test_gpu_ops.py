@@ -153,6 +153,30 @@ def test_generic_energy_known_answer(golden):
     dev.close()
 
 
+def test_exchange_energy_algorithms_agree(golden):
+    """estimators/generic.py:198-216 by the two device algorithms (afq_set_exchange_algorithm): the T-intermediate
+    MFMA kernel and the quadratic form g^T Atil g -- real trial with n_alpha != n_beta, complex trial, odd walker
+    counts; both against the oracle and against each other."""
+    d = golden('generic_ops.npz')
+    for tag, nw in (('A_', 5), ('B_', 19)):
+        m = generic_model(d, tag)
+        phis = perturbed(d[tag + 'phi'], nw)
+        E = {}
+        for mode in (1, 2):
+            dev = make_device(m, nw)
+            dev.set_exchange_algorithm(mode)
+            assert dev.exchange_algorithm() == mode
+            dev.set(L.F_PHI, phis)
+            dev.greens(want_G=False)
+            E[mode] = dev.local_energy()
+            dev.local_energy()                                   # second evaluation reuses the operands
+            dev.close()
+        close(E[1], E[2], 1e-12)
+        for w in range(nw):
+            _, gh, G = ref.greens_function(phis[w], m.psi, m.na, m.nb)
+            close(E[2][w], numpy.array(m.local_energy(G, gh)), 1e-10)
+
+
 def test_hubbard_ops(golden):
     d = golden('hubbard_ops.npz')
     check_ops(d, 'C_', hubbard_model(d, 'C_', 'hubbard'))
