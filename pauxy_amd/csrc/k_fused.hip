@@ -26,6 +26,7 @@
 
 struct PropFusedArgs {
     int M, na, nb, nt, order;
+    int t4;                     // Taylor products on v_mfma_f64_4x4x4 (see taylor4 below)
     int vhs_upper;              // vhs holds only the upper triangle of the (symmetric) HS potential
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
@@ -356,7 +357,141 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             lds_barrier();                                       // T_n visible
         }
     };
-    if (a.na <= 16 && a.nb <= 16) {
+
+    // ------------------------------------------------------------------ Taylor series on v_mfma_f64_4x4x4_4b_f64
+    // The 16x16x4 tile grid pads M = 100 rows to 112 and 25 columns per spin to 32: 30 % of the MFMA cycles of a
+    // Taylor product multiply zeros.  The 4x4x4 instruction runs four independent 4x4x4 products (lane layouts,
+    // decoded on gfx950 with tools/mfma4x4_probe: A lane = 16 k + 4 blk + i, B lane = 16 k + 4 blk + j,
+    // D lane = 16 i + 4 blk + j) at the same flop rate, which allows two finer shapes on the SAME operand data:
+    //   * 16 rows x 4 columns: blk = 4-row group of a 16-row tile, so the A operand IS the 16x16x4 A fragment of
+    //     the DMA ring; the B operand is one 4-column group of T broadcast to the four blk (a permuted
+    //     ds_read_b128 of the T fragment).  A spin needs ceil(N / 4) column groups: 7 for N = 25 instead of 8.
+    //   * 4 rows x 16 columns for the rows 96 .. M-1 (M <= 100): blk = 4-column group, the B operand IS the T
+    //     fragment, the A operand the first four rows of the ring fragment of row tile 6 broadcast to the four blk.
+    // Per 4 contraction indices that is 6 x 14 + 4 = 88 instructions of 16 cycles against 28 x 64: 79 % of the
+    // MFMA cycles (the one-body products and the spin-padded column slots of T keep their 16x16x4 form).
+    // Deal: wave (trip = wave >> 2, q) owns row tiles 3 trip .. 3 trip + 2 and a quarter q of the column groups
+    // (4 or 3 of 14); waves w and w + 4 share a SIMD and get a long and a short quarter; waves 4-7 also take the
+    // 4-row remainder of column slot wave - 4.  Products by the 3-multiplication form as above.
+    auto taylor4 = [&]() __attribute__((always_inline)) {
+        const int trip = wave >> 2;
+        const int q = ((wave & 3) + 2 * trip) & 3;
+        const int nga = (a.na + 3) >> 2, ngb = (a.nb + 3) >> 2, G = nga + ngb;
+        const int gbase = G >> 2, gext = G & 3;
+        const int g0 = q * gbase + (q < gext ? q : gext), gcnt = gbase + (q < gext ? 1 : 0);
+        const bool rem4 = M > 96;                                 // rows 96 .. M-1 (M <= 100)
+        const int nfull = rem4 ? 6 : nrt;
+        bool rv[3], gv[4];
+        unsigned boff[4];                                        // byte offset of group u inside a T chunk (ss = 0)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = 3 * trip + i < nfull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gv[u] = u < gcnt;
+            const int Gi = g0 + (u < gcnt ? u : 0);
+            const int sp = Gi >= nga ? 1 : 0, g = Gi - (sp ? nga : 0);
+            boff[u] = (unsigned)((2 * sp + (g >> 2)) * 2048 + (g & 3) * 64);
+        }
+        const int rslot = wave - 4;                              // remainder unit of waves 4-7: column slot
+        const bool remv = rem4 && wave >= 4 && (rslot & 1) < ((((rslot >> 1) ? a.nb : a.na) + 15) >> 4);
+        // lane parts of the addresses
+        const int l_i = lane >> 4, l_blk = (lane >> 2) & 3, l_j = lane & 3;
+        const unsigned bc_lane = (unsigned)((16 * (lane >> 4) + (lane & 3)) * 16);      // 4-wide group broadcast to the 4 blk
+        // D element of a 16 x 4 unit: row 16 R + 4 blk + i, column 4 g + j
+        const unsigned d_lane = (unsigned)((l_blk >> 1) * 8192 + (l_i & 1) * 1024 + ((2 * (l_blk & 1) + (l_i >> 1)) * 16 + l_j) * 16);
+        // D element of the 4 x 16 remainder unit: row 96 + i, column 16 slot + 4 blk + j
+        const unsigned r_lane = (unsigned)((l_i & 1) * 1024 + ((l_i >> 1) * 16 + 4 * l_blk + l_j) * 16);
+        auto d_addr = [&](int i, int u) -> unsigned {
+            unsigned base = d_lane;
+            asm volatile("" : "+v"(base));
+            return base + (unsigned)(2 * (3 * trip + i) * 8192) + boff[u];
+        };
+        auto d_ok = [&](int i) -> bool { return 2 * (3 * trip + i) + (l_blk >> 1) < NCH; };
+        const unsigned r_addr = (unsigned)((12 * 4 + (rslot & 3)) * 2048) + r_lane;
+        double SR[3][4], SI[3][4], RR = 0.0, RI = 0.0;           // running sums
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d2_t v = (d2_t){0.0, 0.0};
+                if (rv[i] && gv[u] && d_ok(i)) v = *(const d2_t *)(Tf + d_addr(i, u));
+                SR[i][u] = v[0]; SI[i][u] = v[1];
+            }
+        if (remv) { const d2_t v = *(const d2_t *)(Tf + r_addr); RR = v[0]; RI = v[1]; }
+        for (int n = 1; n <= a.order; ++n) {
+            double P1[3][4], P2[3][4], P3[3][4], Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { P1[i][u] = 0.0; P2[i][u] = 0.0; P3[i][u] = 0.0; }
+            for (int c = 0; c < NCH; ++c) {
+                const unsigned sl = next_chunk();
+                const unsigned abase = sl + (3 * trip) * 2048 + lane * 16;
+                const unsigned bbase = tf_l + c * 8192 + bc_lane;
+                d2_t av[3][2], bv[4][2], a4[2], b4[2];
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) av[i][ss] = lds_read_frag(abase, i * 2 + ss);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bv[u][ss] = lds_read_c(bbase + boff[u] + ss * 1024);
+                    if (rem4 && wave >= 4) {
+                        a4[ss] = lds_read_c(sl + 6 * 2048 + ss * 1024 + bc_lane);
+                        b4[ss] = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + ss * 1024 + lane * 16);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    double bs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bs[u] = bv[u][ss][0] + bv[u][ss][1];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (!rv[i]) continue;
+                        const double as = av[i][ss][0] + av[i][ss][1];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (gv[u]) {
+                                P1[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i][ss][0], bv[u][ss][0], P1[i][u], 0, 0, 0);
+                                P2[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i][ss][1], bv[u][ss][1], P2[i][u], 0, 0, 0);
+                                P3[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, bs[u], P3[i][u], 0, 0, 0);
+                            }
+                    }
+                    if (remv) {
+                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][0], b4[ss][0], Q1, 0, 0, 0);
+                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][1], b4[ss][1], Q2, 0, 0, 0);
+                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][0] + a4[ss][1], b4[ss][0] + b4[ss][1], Q3, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!prepared) prepare();
+            }
+            __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
+            const double inv_n = 1.0 / n;
+            const bool last = n == a.order;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rv[i] && gv[u]) {
+                        const double re = (P1[i][u] - P2[i][u]) * inv_n;
+                        const double im = (P3[i][u] - P1[i][u] - P2[i][u]) * inv_n;
+                        SR[i][u] += re; SI[i][u] += im;
+                        if (d_ok(i))
+                            *(d2_t *)(Tf + d_addr(i, u)) = last ? (d2_t){SR[i][u], SI[i][u]} : (d2_t){re, im};
+                    }
+            if (remv) {
+                const double re = (Q1 - Q2) * inv_n, im = (Q3 - Q1 - Q2) * inv_n;
+                RR += re; RI += im;
+                *(d2_t *)(Tf + r_addr) = last ? (d2_t){RR, RI} : (d2_t){re, im};
+            }
+            lds_barrier();                                       // T_n visible
+        }
+    };
+    if (a.t4) taylor4();
+    else if (a.na <= 16 && a.nb <= 16) {
         // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
         // waves 4-7 the row tiles from 4 on: singly when there are six (3 tiles on every SIMD), as a pair + a single
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
@@ -382,6 +517,8 @@ int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
     a.vhs_upper = h->vhs_upper ? 1 : 0;
+    // 4x4x4 Taylor products: M <= 100 (six full row tiles + at most four remainder rows)
+    a.t4 = (h->M <= 100 && !afq_knob("AFQ_NO_T4")) ? 1 : 0;
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
