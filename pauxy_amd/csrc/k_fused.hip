@@ -358,6 +358,13 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         }
     };
 
+    // Measured negative result (round 2, profiles/r02_pmc_prop_fused_t4_vs_t16.txt): the same products on
+    // v_mfma_f64_4x4x4 (16 x 4 and 4 x 16 units, 79 % of the MFMA cycles of the padded 16x16x4 grid) are CORRECT but
+    // not faster -- 183 us against 177 us: MFMA-busy cycles drop 18 %, wave-parked cycles (s_waitcnt / barrier) rise
+    // from 23 % to 35 % of the wave cycles, 1.6 x the instructions, and the broadcast read of a 4-column group of T
+    // is a 2-way bank conflict in the spin-padded fragment layout.  The kernel is bound by the per-chunk
+    // synchronisation skeleton, not by MFMA issue.  The variant is compiled only into tuning builds (AFQ_T4=1).
+#ifdef AFQ_TUNING
     // ------------------------------------------------------------------ Taylor series on v_mfma_f64_4x4x4_4b_f64
     // The 16x16x4 tile grid pads M = 100 rows to 112 and 25 columns per spin to 32: 30 % of the MFMA cycles of a
     // Taylor product multiply zeros.  The 4x4x4 instruction runs four independent 4x4x4 products (lane layouts,
@@ -424,49 +431,70 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { P1[i][u] = 0.0; P2[i][u] = 0.0; P3[i][u] = 0.0; }
-            for (int c = 0; c < NCH; ++c) {
-                const unsigned sl = next_chunk();
+            // Two operand sets at sub-step granularity: while the MFMAs of (chunk c, sub-step 0) issue, the fragments of
+            // sub-step 1 travel LDS -> registers, and while those of sub-step 1 issue, the ring has already been
+            // advanced (barrier in the MIDDLE of the chunk) and the fragments of (c + 1, 0) are on their way: every
+            // s_waitcnt lgkmcnt(0) sits behind a burst of ~40 MFMAs.
+            d2_t av[2][3], bv[2][4];
+            unsigned sl = 0;
+            auto rd = [&](int set, int c, int ss) __attribute__((always_inline)) {
                 const unsigned abase = sl + (3 * trip) * 2048 + lane * 16;
-                const unsigned bbase = tf_l + c * 8192 + bc_lane;
-                d2_t av[3][2], bv[4][2], a4[2], b4[2];
+                const unsigned bbase = tf_l + c * 8192 + bc_lane + ss * 1024;
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
+                for (int i = 0; i < 3; ++i) av[set][i] = lds_read_frag(abase, i * 2 + ss);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) av[i][ss] = lds_read_frag(abase, i * 2 + ss);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) bv[u][ss] = lds_read_c(bbase + boff[u] + ss * 1024);
-                    if (rem4 && wave >= 4) {
-                        a4[ss] = lds_read_c(sl + 6 * 2048 + ss * 1024 + bc_lane);
-                        b4[ss] = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + ss * 1024 + lane * 16);
-                    }
+                for (int u = 0; u < 4; ++u) bv[set][u] = lds_read_c(bbase + boff[u]);
+            };
+            // REM: the remainder unit of this chunk (both sub-steps) rides on the first burst -- its fragments must be
+            // read before the ring advances in the middle of the chunk, because that refills this chunk's slot
+            auto mm = [&](int set, auto rem_tag, unsigned sl_cur, int c) __attribute__((always_inline)) {
+                constexpr bool REM = decltype(rem_tag)::value;
+                d2_t a4 = (d2_t){0.0, 0.0}, b4 = (d2_t){0.0, 0.0};
+                if (REM && rem4 && wave >= 4) {
+                    a4 = lds_read_c(sl_cur + 6 * 2048 + bc_lane);
+                    b4 = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + lane * 16);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    double bs[4];
+                for (int u = 0; u < 4; ++u) {
+                    if (!gv[u]) continue;
+                    const double bs = bv[set][u][0] + bv[set][u][1];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) bs[u] = bv[u][ss][0] + bv[u][ss][1];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (!rv[i]) continue;
-                        const double as = av[i][ss][0] + av[i][ss][1];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (gv[u]) {
-                                P1[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i][ss][0], bv[u][ss][0], P1[i][u], 0, 0, 0);
-                                P2[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i][ss][1], bv[u][ss][1], P2[i][u], 0, 0, 0);
-                                P3[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, bs[u], P3[i][u], 0, 0, 0);
-                            }
-                    }
-                    if (remv) {
-                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][0], b4[ss][0], Q1, 0, 0, 0);
-                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][1], b4[ss][1], Q2, 0, 0, 0);
-                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[ss][0] + a4[ss][1], b4[ss][0] + b4[ss][1], Q3, 0, 0, 0);
-                    }
+                    for (int i = 0; i < 3; ++i)
+                        if (rv[i]) {
+                            P1[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][0], bv[set][u][0], P1[i][u], 0, 0, 0);
+                            P2[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][1], bv[set][u][1], P2[i][u], 0, 0, 0);
+                            P3[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][0] + av[set][i][1], bs, P3[i][u], 0, 0, 0);
+                        }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!prepared) prepare();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the other set and the remainder fragments have landed
+                if (REM && rem4 && wave >= 4) {
+                    // sub-step 1 fragments of the remainder unit: one exposed LDS round trip per chunk (waves 4-7)
+                    const d2_t a5 = lds_read_c(sl_cur + 6 * 2048 + 1024 + bc_lane);
+                    const d2_t b5 = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + 1024 + lane * 16);
+                    if (remv) {
+                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0], b4[0], Q1, 0, 0, 0);
+                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[1], b4[1], Q2, 0, 0, 0);
+                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0] + a4[1], b4[0] + b4[1], Q3, 0, 0, 0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (remv) {
+                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[0], b5[0], Q1, 0, 0, 0);
+                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[1], b5[1], Q2, 0, 0, 0);
+                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[0] + a5[1], b5[0] + b5[1], Q3, 0, 0, 0);
+                    }
+                }
+            };
+            sl = next_chunk();
+            rd(0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int c = 0; c < NCH; ++c) {
+                rd(1, c, 1);
+                mm(0, std::true_type{}, sl, c);
+                if (c + 1 < NCH) { sl = next_chunk(); rd(0, c + 1, 0); }
+                mm(1, std::false_type{}, sl, c);
             }
             __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
             const double inv_n = 1.0 / n;
@@ -490,8 +518,12 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             lds_barrier();                                       // T_n visible
         }
     };
+#endif
+#ifdef AFQ_TUNING
     if (a.t4) taylor4();
-    else if (a.na <= 16 && a.nb <= 16) {
+    else
+#endif
+    if (a.na <= 16 && a.nb <= 16) {
         // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
         // waves 4-7 the row tiles from 4 on: singly when there are six (3 tiles on every SIMD), as a pair + a single
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
@@ -517,8 +549,8 @@ int k_prop_fused(afq_handle *h) {
     PropFusedArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
     a.vhs_upper = h->vhs_upper ? 1 : 0;
-    // 4x4x4 Taylor products: M <= 100 (six full row tiles + at most four remainder rows)
-    a.t4 = (h->M <= 100 && !afq_knob("AFQ_NO_T4")) ? 1 : 0;
+    // 4x4x4 Taylor products (tuning builds only): M <= 100 (six full row tiles + at most four remainder rows)
+    a.t4 = (h->M <= 100 && afq_knob("AFQ_T4")) ? 1 : 0;
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
