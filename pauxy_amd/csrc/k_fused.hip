@@ -264,8 +264,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     // every SIMD carries the same MFMA load.  Waves 0-3 own a 2 x 2 block of the first four row tiles, waves 4-7
     // a 3 x 1 block (row tiles 4-6 of one column tile); waves w and w+4 share a SIMD: 4 + 3 = 7 tiles each
     // instead of the 8 (one of them pure padding) of an 8-row-tile deal.
-    auto taylor = [&](auto ni_tag, auto nj_tag, const int r0, const int c0, const int rcount) __attribute__((always_inline)) {
+    // STAG (waves 4-7): the wave crosses the chunk barrier in the MIDDLE of a chunk's MFMAs -- sub-step 1 of chunk c is
+    // multiplied right behind barrier c + 1 from fragments that are already in registers, then the fragments of chunk
+    // c + 1 are read and its sub-step 0 multiplied.  Its SIMD partner (wave - 4) reads its fragments right behind the
+    // same barrier and multiplies afterwards, so the partner's LDS reads / ring refill run under this wave's MFMAs and
+    // vice versa, instead of both waves doing the same thing at the same time.
+    auto taylor = [&](auto ni_tag, auto nj_tag, auto stag_tag, const int r0, const int c0, const int rcount) __attribute__((always_inline)) {
         constexpr int NI = decltype(ni_tag)::value, NJ = decltype(nj_tag)::value;
+        constexpr bool STAG = decltype(stag_tag)::value;
         bool cv[NJ], rv[NI];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -307,32 +313,63 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 for (int j = 0; j < NJ; ++j) {
                     P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0};
                 }
+            auto mfma_ss = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2], const int ss) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (cv[j] && rv[i]) {
+                            P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
+                            P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
+                            P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
+                        }
+            };
             auto mfmas = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            if (cv[j] && rv[i]) {
-                                P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
-                                P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
-                                P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
-                            }
+                mfma_ss(av, bv, 0);
+                mfma_ss(av, bv, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!prepared) prepare();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             d2_t avA[NI][2], bvA[NJ][2], avB[NI][2], bvB[NJ][2];
-            load_frags(next_chunk(), 0, avA, bvA);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int c = 0; c < NCH; c += 2) {
-                if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
-                mfmas(avA, bvA);
-                if (c + 1 < NCH) {
-                    if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
-                    mfmas(avB, bvB);
+            if (STAG) {
+                // X = fragments of the chunk whose sub-step 1 is still owed, Y = the set being filled
+                auto half = [&](d2_t (&ax)[NI][2], d2_t (&bx)[NJ][2], d2_t (&ay)[NI][2], d2_t (&by)[NJ][2], const int c)
+                    __attribute__((always_inline)) {
+                    unsigned sl = 0;
+                    if (c + 1 < NCH) sl = next_chunk();                     // barrier c + 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_ss(ax, bx, 1);                                      // (c, sub-step 1): operands in registers
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!prepared) prepare();
+                    if (c + 1 < NCH) {
+                        load_frags(sl, c + 1, ay, by);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_ss(ay, by, 0);                                  // (c + 1, sub-step 0)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                load_frags(next_chunk(), 0, avA, bvA);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_ss(avA, bvA, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < NCH; c += 2) {
+                    half(avA, bvA, avB, bvB, c);
+                    if (c + 1 < NCH) half(avB, bvB, avA, bvA, c + 1);
+                }
+            } else {
+                load_frags(next_chunk(), 0, avA, bvA);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int c = 0; c < NCH; c += 2) {
+                    if (c + 1 < NCH) load_frags(next_chunk(), c + 1, avB, bvB);
+                    mfmas(avA, bvA);
+                    if (c + 1 < NCH) {
+                        if (c + 2 < NCH) load_frags(next_chunk(), c + 2, avA, bvA);
+                        mfmas(avB, bvB);
+                    }
                 }
             }
             __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
@@ -529,12 +566,12 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (wave < 4) taylor(I2{}, I1{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
-        else if (nrt <= 6) taylor(I2{}, I1{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
-        else taylor(I2{}, I1{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2);
+        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
+        else if (nrt <= 6) taylor(I2{}, I1{}, std::true_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
+        else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2);
     }
-    else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
-    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 4, wave - 4, 3);
+    else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
+    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3);
     if (a.order == 0) lds_barrier();
 
     one_body_stage(true);
