@@ -151,10 +151,12 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out);
  * G_bp[w] = gab(phi_bp, phi_old)^T and returns est_out c128[4 + 2 M M] =
  * [0, 0, 0, sum_w wt_w, sum_w wt_w G_bp[w]] with wt = weight (restore_weights 0),
  * weight * prod(I/|I|) (1, "partial") or weight * prod(I/|I|) / prod(cos) (2, "full");
- * then resets the histories and copies phi -> phi_old.  With eval_energy the entries 0-2 are
+ * then, when `reset` is set (the last of the nsplit path lengths, back_propagation.py:68-69,219-222), resets the
+ * histories and copies phi -> phi_old.  Generic systems (propagation/generic.py:253-290) and the UEG
+ * (propagation/planewave.py:114-178; B(x)^H = B(-conj x) for both).  With eval_energy the entries 0-2 are
  * sum_w wt_w (E, E1b, E2b)[G_bp[w]] from the full-G Cholesky energy (generic systems).          */
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
-                  double *est_out);
+                  int reset, double *est_out);
 
 /* Multi-determinant (NOMSD / PHMSD) trial |psi_T> = sum_d c_d |D_d> for a generic system, replacing
  * the single-determinant operands of afq_set_system_generic / afq_set_trial.  Call after the
@@ -286,6 +288,13 @@ int afq_walkers_reset_weights(afq_handle *h);
 /* estimators/mixed.py:180-225: accumulate the 10 mixed estimators over all
  * walkers on the device; eval_energy != 0 runs afq_greens + afq_local_energy. */
 int afq_estimates_update(afq_handle *h, int eval_energy);
+/* Mixed estimator with one_rdm: True (estimators/mixed.py:226-233,279-283): after afq_estimates_rdm(h, 1) every
+ * afq_estimates_update also adds sum_w weight_w Re(G_w) to a device accumulator f64[2, M, M], where G_w is
+ * walker.G as the reference leaves it: the Green's function evaluated before the step's propagation
+ * (propagation/continuous.py:245), refreshed on energy steps, cloned with the walker by the comb.
+ * afq_estimates_rdm_get returns (and optionally zeroes) the accumulator.  One rank, single determinant.      */
+int afq_estimates_rdm(afq_handle *h, int on);
+int afq_estimates_rdm_get(afq_handle *h, double *rdm_out /* f64[2, M, M] */, int zero);
 /* Synchronises the stream; also the place where a population that collapsed in an asynchronous comb is
  * reported (AFQ_EWEIGHT, walkers/handler.py:236-241) and an exchange overflow (AFQ_EOVERFLOW).           */
 int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);

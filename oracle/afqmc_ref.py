@@ -570,11 +570,12 @@ def reortho_qr(A):
     return Q.dot(signs), scipy.linalg.det(signs.dot(R))
 
 
-def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt):
-    """propagation/generic.py:253-290 with :181-211: apply B(x_n)^H ... B(x_1)^H to the trial,
-    most recent field configuration first, re-orthogonalising every nstblz steps (not at i == 0)."""
+def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt, vhs=None):
+    """propagation/generic.py:253-290 with :181-211 (and, with ``vhs`` = the plane-wave HS potential,
+    propagation/planewave.py:114-178): apply B(x_n)^H ... B(x_1)^H to the trial, most recent field
+    configuration first, re-orthogonalising every nstblz steps (not at i == 0)."""
     for (i, c) in enumerate(configs[::-1]):
-        VHS = 1j * dt ** 0.5 * hs_pot.dot(c).reshape(M, M)
+        VHS = vhs(c) if vhs is not None else 1j * dt ** 0.5 * hs_pot.dot(c).reshape(M, M)
         EXP_VHS = exponentiate_matrix(VHS)
         Bup = BT2[0].dot(EXP_VHS).dot(BT2[0])
         Bdn = BT2[1].dot(EXP_VHS).dot(BT2[1])
@@ -586,15 +587,19 @@ def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt):
     return phi
 
 
-def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval_energy=False):
+def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval_energy=False, reset=True):
     """estimators/back_propagation.py:127-226 (update_uhf, one_rdm only).  ``est`` is
-    [3 energies, denominator, G.flatten()]; called when the field buffers are full; resets them
-    and copies phi -> phi_old (walkers/handler.py:200-203)."""
+    [3 energies, denominator, G.flatten()]; called when the field buffers hold one of the split lengths; at the last
+    split (``reset``) it resets them and copies phi -> phi_old (walkers/handler.py:200-203)."""
     M, na = model.M, model.na
+    vhs = None
+    if model.kind == 'ueg':
+        vhs = lambda c: vhs_ueg(model.iA, model.iB, c, M, model.sqrt_dt)       # noqa: E731  planewave.py:94-112
     for w in walkers:
         fc = w['bp']
         phi_bp = numpy.array(model.psi if init is None else init, dtype=numpy.complex128, copy=True)
-        back_propagate_generic(phi_bp, fc['configs'][:fc['step']], model.hs_pot, M, na, nstblz, model.BH1, model.dt)
+        back_propagate_generic(phi_bp, fc['configs'][:fc['step']], getattr(model, 'hs_pot', None), M, na, nstblz,
+                               model.BH1, model.dt, vhs=vhs)
         G = numpy.array([gab(phi_bp[:, :na], w['phi_old'][:, :na]).T,
                          gab(phi_bp[:, na:], w['phi_old'][:, na:]).T])
         if restore_weights is not None:
@@ -608,9 +613,11 @@ def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval
             est[:3] += weight * numpy.array(local_energy_generic_cholesky(model.H1, model.ecore, G, model.hs_pot))
         est[3] += weight
         est[4:] += weight * G.flatten()
-        fc['step'] = 0                                      # FieldConfig.reset (stack.py:124-127)
-    for w in walkers:
-        w['phi_old'] = w['phi'].copy()
+        if reset:
+            fc['step'] = 0                                  # FieldConfig.reset (stack.py:124-127)
+    if reset:
+        for w in walkers:
+            w['phi_old'] = w['phi'].copy()
 
 
 # --------------------------------------------------------------------------
@@ -748,8 +755,11 @@ def new_walker(model, phi0, weight=1.0):
     """walkers/walker.py:24-61 + single_det.py:64-67 (the state the loop touches)."""
     phi = numpy.array(phi0, dtype=numpy.complex128, copy=True)
     ot = model.overlap(phi)
-    return dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
-                hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0)
+    w = dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
+             hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0)
+    if getattr(model, 'track_G', False):
+        w['G'] = model.greens(phi)[2]              # walker.G as left by the constructor (single_det.py:81)
+    return w
 
 
 def propagate_walker_free(model, w, xi, eshift):
@@ -781,6 +791,8 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
     Returns (nfb_trig, nhe_trig)."""
     na, nb = model.na, model.nb
     ovlp, Ghalf, G = model.greens(w['phi'])
+    if 'G' in w:
+        w['G'] = G                                 # walker.G: the Green's function BEFORE this step (continuous.py:245)
     kinetic_real(w['phi'], model.BH1, na)
     xbar = model.force_bias(Ghalf, G)
     xs, cmf, cfb, ntrig = shift_fields(xi, xbar, model.mf_shift, model.sqrt_dt)
@@ -841,9 +853,10 @@ def pop_control(model, walkers, target, r):
     return parent_ix
 
 
-def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=False):
+def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=False, rdm=None):
     """estimators/mixed.py:180-225 (importance-sampling branch, le_oratio == 1) and
-    :151-175 (free projection: wfac = weight * ot * phase)."""
+    :151-175 (free projection: wfac = weight * ot * phase).  ``rdm`` [2, M, M] (one_rdm: True, :226-229):
+    += weight * walker.G.real with whatever walker.G currently holds."""
     if free_projection:
         for w in walkers:
             wfac = w['weight'] * w['ot'] * w['phase']
@@ -862,6 +875,8 @@ def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=Fa
     for w in walkers:
         if step % energy_eval_freq == 0:
             _, Ghalf, G = model.greens(w['phi'])
+            if 'G' in w:
+                w['G'] = G
             E, T, V = model.local_energy(G, Ghalf)
             est[EST['enumer']] += w['weight'] * complex(E).real
             est[EST['e1b']] += w['weight'] * complex(T).real
@@ -871,6 +886,8 @@ def mixed_update(model, est, walkers, step, energy_eval_freq, free_projection=Fa
         est[EST['weight']] += w['weight']
         est[EST['ovlp']] += w['weight'] * abs(w['ot'])
         est[EST['ehyb']] += w['weight'] * w['hybrid_energy']
+        if rdm is not None:
+            rdm += w['weight'] * w['G'].real
 
 
 def block_reduce(est, nsteps):
@@ -889,7 +906,7 @@ def block_reduce(est, nsteps):
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
               record=None, verbose=False, free_projection=False, nbp=None, bp_out=None,
-              restore_weights=None, bp_energy=False, uniform_source=None):
+              restore_weights=None, bp_energy=False, uniform_source=None, bp_nsplit=1, rdm_out=None):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -921,8 +938,11 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
     blocks = []
     eshift_pair = numpy.array([0, 0], dtype=numpy.complex128)
     eshift = 0
+    rdm = None
+    if rdm_out is not None:                       # mixed estimator with one_rdm: True (walkers carry w['G'])
+        rdm = numpy.zeros((2, model.M, model.M))
     # step-0 estimator pass (qmc/afqmc.py:214-221)
-    mixed_update(model, est, walkers, 0, energy_eval_freq, free_projection)
+    mixed_update(model, est, walkers, 0, energy_eval_freq, free_projection, rdm)
     if verbose:
         gs, eshift_pair = block_reduce(est, 1)
         blocks.append(gs)
@@ -952,11 +972,14 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
         parent_ix = None
         if step % npop_control == 0:
             parent_ix = pop_control(model, walkers, ntot, uni() if uni is not None else r_source(step))
-        mixed_update(model, est, walkers, step, energy_eval_freq, free_projection)
-        if nbp is not None and walkers[0]['bp']['step'] == nbp:     # back_propagation.py:145-147
-            bpe = numpy.zeros(4 + 2 * model.M * model.M, dtype=numpy.complex128)
-            bp_update(model, walkers, nstblz, bpe, restore_weights, eval_energy=bp_energy)
-            bp_out.append(bpe)                                       # print_step: one Reduce per window
+        mixed_update(model, est, walkers, step, energy_eval_freq, free_projection, rdm)
+        if nbp is not None:                                          # back_propagation.py:68-69,145-147
+            splits = [(i + 1) * (nbp // bp_nsplit) for i in range(bp_nsplit)]
+            cur = walkers[0]['bp']['step']
+            if cur in splits:
+                bpe = numpy.zeros(4 + 2 * model.M * model.M, dtype=numpy.complex128)
+                bp_update(model, walkers, nstblz, bpe, restore_weights, eval_energy=bp_energy, reset=cur == splits[-1])
+                bp_out.append(bpe if bp_nsplit == 1 else (cur, bpe))   # print_step: one Reduce per window
         if record is not None:
             record.append(dict(
                 weight=numpy.array([w['weight'] for w in walkers]),
@@ -970,6 +993,9 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
             gs, eshift_pair = block_reduce(est, nsteps)
             blocks.append(gs)
             est[:] = 0
+            if rdm is not None:                    # mixed.py:279-283
+                rdm_out.append(rdm / nsteps / gs[EST['weight']])
+                rdm[:] = 0
         if step < neqlb:
             eshift = eshift_pair[0].real if hybrid else eshift_pair[1].real
         else:

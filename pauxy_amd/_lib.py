@@ -61,6 +61,8 @@ SIGNATURES = {
     "afq_walkers_reset_weights": [_h],
     "afq_estimates_update": [_h, c_int],
     "afq_estimates_get": [_h, _dp, c_int],
+    "afq_estimates_rdm": [_h, c_int],
+    "afq_estimates_rdm_get": [_h, _dp, c_int],
     "afq_rng_seed": [_h, c_uint64, c_uint64],
     "afq_counters": [_h, c_void_p, c_int],
     "afq_timers": [_h, _dp, c_int],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "afq_hirsch_finish": [_h, c_double],
     "afq_bp_configure": [_h, c_int],
     "afq_bp_steps": [_h, _dp],
-    "afq_bp_update": [_h, _dp, c_int, c_int, c_int, _dp],
+    "afq_bp_update": [_h, _dp, c_int, c_int, c_int, c_int, _dp],
     "afq_local_energy_full_g": [_h, _dp, c_int, _dp],
     "afq_set_trial_multi": [_h, c_int, _dp, _dp, _dp],
     "afq_walkers_det_weights": [_h, _dp],

@@ -104,7 +104,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
     dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag); dev_free(h->exq_y); h->exq_y_len = 0;
-    dev_free(h->alive); dev_free(h->parent_ix);
+    dev_free(h->alive); dev_free(h->parent_ix); dev_free(h->rdm_acc); h->rdm_on = false;
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }
     h->exx_part_len = 0; h->gfrag_bytes = 0; h->nw = 0;
 }
@@ -785,7 +785,8 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         else if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
         h->greens_valid = false;
         const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
-        if (h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) {
+        if ((h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) || (h->rdm_on && h->ndet == 1)) {
+            // (one_rdm: walker.G = the Green's function of the walker before this step, continuous.py:245)
             if ((rc = ensure_G(h))) return rc;
             if ((rc = k_full_G(h))) return rc;
         }
@@ -1143,7 +1144,7 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
         {
             PhaseTimer t(h, T_GREENS);
             if (!h->greens_valid && (rc = greens_any(h, h->ovlp_old, true))) return rc;
-            if (h->kind == AFQ_SYS_UEG) {
+            if (h->kind == AFQ_SYS_UEG || h->rdm_on) {       // (one_rdm: w.greens_function(trial) refreshes walker.G, mixed.py:212)
                 if ((rc = ensure_G(h))) return rc;
                 if ((rc = k_full_G(h))) return rc;
             }
@@ -1151,7 +1152,38 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
         PhaseTimer t(h, T_ENERGY);
         if ((rc = local_energy(h))) return rc;
     }
-    return k_estimates(h, eval_energy);
+    if ((rc = k_estimates(h, eval_energy))) return rc;
+    if (h->rdm_on && !(h->flags & AFQ_PROP_FREE_PROJECTION)) {   // the free-projection branch has no RDM (mixed.py:151-175)
+        if (!h->G) AFQ_FAIL(h, AFQ_ESTATE, "one_rdm: no Green's function evaluated yet");
+        return k_rdm_accumulate(h);
+    }
+    return AFQ_OK;
+}
+
+int afq_estimates_rdm(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    if (h->ndet > 1 || h->hirsch) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "mixed one_rdm: single-determinant trial, continuous propagator");
+    if (k_comm_size(h) > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "mixed one_rdm: walker.G does not travel between ranks");
+    h->rdm_on = on != 0;
+    if (h->rdm_on && !h->rdm_acc) {
+        const size_t n = (size_t)2 * h->M * h->M;
+        if ((rc = dev_alloc(h, &h->rdm_acc, n))) return rc;
+        AFQ_HIP(h, hipMemsetAsync(h->rdm_acc, 0, sizeof(double) * n, h->stream));
+    }
+    return AFQ_OK;
+}
+
+int afq_estimates_rdm_get(afq_handle *h, double *rdm_out, int zero) {
+    if (!h || !rdm_out) return AFQ_EINVAL;
+    if (!h->rdm_acc) AFQ_FAIL(h, AFQ_ESTATE, "mixed one_rdm accumulation is not switched on");
+    hipSetDevice(h->device);
+    const size_t n = (size_t)2 * h->M * h->M;
+    int rc = copy_out(h, rdm_out, h->rdm_acc, sizeof(double) * n);
+    if (rc) return rc;
+    if (zero) AFQ_HIP(h, hipMemsetAsync(h->rdm_acc, 0, sizeof(double) * n, h->stream));
+    return AFQ_OK;
 }
 
 int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
@@ -1371,6 +1403,8 @@ int afq_bp_configure(afq_handle *h, int nbp) {
     int rc = need_ready(h, true);
     if (rc) return rc;
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation needs a single-determinant trial");
+    if (h->hirsch || h->kind == AFQ_SYS_HUBBARD)
+        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation: generic and UEG systems (the reference's Hubbard variant is for the discrete fields)");
     if (h->flags & AFQ_PROP_FREE_PROJECTION) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "no field history in free projection");
     const size_t per = (size_t)h->M * h->nt, n = h->nw;
     if ((rc = dev_alloc(h, &h->bp_hist, n * nbp * h->K))) return rc;
@@ -1401,7 +1435,7 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
 }
 
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
-                  double *est_out) {
+                  int reset, double *est_out) {
     AFQ_API(h, "afq_bp_update");
     if (h) h->greens_valid = false;
     if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
@@ -1458,9 +1492,11 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
         if ((rc = k_energy_full_g(h, h->G, h->nw, h->energy))) return rc;
     }
     if ((rc = k_bp_accumulate(h, restore_weights, eval_energy))) return rc;
-    // FieldConfig.reset + Walkers.copy_historic_wfn (walkers/stack.py:124-127, handler.py:200-203)
-    if ((rc = k_bp_reset(h))) return rc;
-    AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
+    if (reset) {
+        // FieldConfig.reset + Walkers.copy_historic_wfn (walkers/stack.py:124-127, handler.py:200-203)
+        if ((rc = k_bp_reset(h))) return rc;
+        AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
+    }
     if ((rc = k_alive(h))) return rc;
     return copy_out(h, est_out, h->bp_est, sizeof(cplx) * ((size_t)4 + 2 * h->M * h->M));
 }

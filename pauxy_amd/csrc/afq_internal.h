@@ -178,6 +178,11 @@ struct afq_handle {
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
     cplx *estimates = nullptr;      // [10]
+    // Mixed estimator with one_rdm: True (estimators/mixed.py:226-229): G then is per-walker STATE (walker.G: the
+    // Green's function the walker last evaluated -- before the step's propagation, or at an energy evaluation),
+    // cloned by the comb, and rdm_acc += sum_w weight_w Re G_w with every afq_estimates_update
+    bool rdm_on = false;
+    double *rdm_acc = nullptr;      // [2, M, M]
     unsigned long long *counters = nullptr;   // [4]
     int *alive = nullptr;           // [nw]
     int *parent_ix = nullptr;       // [nw]
@@ -359,6 +364,7 @@ int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[
 int k_scale_weights(afq_handle *h, double scale);
 int k_reset_weights(afq_handle *h, bool after_comb = false);
 int k_estimates(afq_handle *h, int have_energy);
+int k_rdm_accumulate(afq_handle *h);
 int k_rng_normal(afq_handle *h);
 int k_rng_normal_into(afq_handle *h, double *out_d, long n);
 int k_philox_raw(afq_handle *h, const unsigned int *in_d, unsigned int *out_d, int n);

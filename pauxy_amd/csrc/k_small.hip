@@ -1240,6 +1240,8 @@ struct CloneArgs {
     long hist_per;
     // a cached Green's function travels too; null when there is none
     cplx *ghalf, *ovlp_new;
+    cplx *G;             // walker.G as walker state (mixed one_rdm); null otherwise
+    long gsz;
 };
 
 __global__ void clone_kernel(CloneArgs a) {
@@ -1253,6 +1255,9 @@ __global__ void clone_kernel(CloneArgs a) {
             a.ghalf[dst * a.per + i] = a.ghalf[src * a.per + i];
         if (blockIdx.x == 0 && threadIdx.x == 0) a.ovlp_new[dst] = a.ovlp_new[src];
     }
+    if (a.G)
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gsz; i += (long)gridDim.x * blockDim.x)
+            a.G[dst * a.gsz + i] = a.G[src * a.gsz + i];
     if (a.phi_old) {
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
             a.phi_old[dst * a.per + i] = a.phi_old[src * a.per + i];
@@ -1285,6 +1290,7 @@ int k_clone_pairs(afq_handle *h, bool with_greens) {
     a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
     a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
     a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;
+    a.G = (h->rdm_on && h->G) ? h->G : nullptr; a.gsz = 2L * h->M * h->M;
     AFQ_LAUNCH(h, clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
     AFQ_POST(h);
     return AFQ_OK;
@@ -1344,6 +1350,23 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
             est[AFQ_EST_EDENOM].x += v[1]; est[AFQ_EST_EDENOM].y += v[2];
         }
     }
+}
+
+// estimators/mixed.py:226-229: estimates[one_rdm] += weight * walker.G.real, summed over walkers in a fixed order
+__global__ void rdm_accumulate_kernel(const cplx *G, const double *weight, double *acc, int nw, long gsz) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= gsz) return;
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s = fma(weight[w], G[(long)w * gsz + e].x, s);
+    acc[e] += s;
+}
+
+int k_rdm_accumulate(afq_handle *h) {
+    const long gsz = 2L * h->M * h->M;
+    AFQ_LAUNCH(h, rdm_accumulate_kernel, dim3((unsigned)((gsz + 127) / 128)), dim3(128), 0, h->stream, h->G, h->weight,
+               h->rdm_acc, h->nw, gsz);
+    AFQ_POST(h);
+    return AFQ_OK;
 }
 
 int k_estimates(afq_handle *h, int have_energy) {

@@ -161,12 +161,13 @@ class AfqDevice(object):
         self._ck(self.lib.afq_local_energy_full_g(self.h, _p(G), n, _p(out)))
         return out
 
-    def bp_update(self, phi_bp0, nstblz, restore_weights=None, eval_energy=False):
+    def bp_update(self, phi_bp0, nstblz, restore_weights=None, eval_energy=False, reset=True):
         """-> (energies_sum[3], denominator, G_bp_sum[2, M, M]); restore_weights in (None, 'partial', 'full')."""
         mode = {None: 0, 'partial': 1, 'full': 2}.get(restore_weights, 1)
         phi0 = _c128(phi_bp0, (self.M, self.na + self.nb))
         out = numpy.zeros(4 + 2 * self.M * self.M, dtype=numpy.complex128)
-        self._ck(self.lib.afq_bp_update(self.h, _p(phi0), int(nstblz), mode, int(bool(eval_energy)), _p(out)))
+        self._ck(self.lib.afq_bp_update(self.h, _p(phi0), int(nstblz), mode, int(bool(eval_energy)), int(bool(reset)),
+                                        _p(out)))
         return out[:3], out[3], out[4:].reshape(2, self.M, self.M)
 
     def set_trial_multi(self, psi, coeffs, rchol):
@@ -324,6 +325,14 @@ class AfqDevice(object):
 
     def estimates_update(self, eval_energy):
         self._ck(self.lib.afq_estimates_update(self.h, int(bool(eval_energy))))
+
+    def estimates_rdm(self, on=True):
+        self._ck(self.lib.afq_estimates_rdm(self.h, int(bool(on))))
+
+    def estimates_rdm_get(self, zero=False):
+        out = numpy.empty((2, self.M, self.M), dtype=numpy.float64)
+        self._ck(self.lib.afq_estimates_rdm_get(self.h, _p(out), int(bool(zero))))
+        return out
 
     def estimates_get(self, zero=False):
         out = numpy.empty(10, dtype=numpy.complex128)

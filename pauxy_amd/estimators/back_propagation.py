@@ -30,11 +30,13 @@ class BackPropagation(object):
         self.eval_energy = bp.get('evaluate_energy', False)
         self.eval_ekt = bp.get('evaluate_ekt', False)
         self.restore_weights = bp.get('restore_weights', None)
-        if system.name != "Generic" or getattr(trial, 'ndets', 1) != 1:
-            raise NotImplementedError("device back-propagation: Generic system, single-determinant trial")
-        if self.nsplit != 1 or self.calc_two_rdm is not None or self.eval_ekt:
-            raise NotImplementedError("device back-propagation covers the full window (nsplit=1): one-body RDM "
-                                      "and energies; no two_rdm / EKT")
+        if system.name not in ("Generic", "UEG") or getattr(trial, 'ndets', 1) != 1:
+            # back_propagation.py:117-124: the reference's Hubbard variant back-propagates the DISCRETE fields
+            raise NotImplementedError("device back-propagation: Generic or UEG system, single-determinant trial")
+        if self.calc_two_rdm is not None or self.eval_ekt:
+            raise NotImplementedError("device back-propagation: one-body RDM and energies; no two_rdm / EKT")
+        if self.eval_energy and system.name != "Generic":
+            raise NotImplementedError("back-propagated energies: Generic systems")
         if self.nmax < 1:
             raise ValueError("tau_bp shorter than one time step")
         M = system.nbasis
@@ -50,6 +52,7 @@ class BackPropagation(object):
         self.one_rdm = []
         self.denominator = []
         self.energies = []
+        self.split_of = []                     # path length (buff_ix) of every stored window
         self.buff_ix = 0
         self._nsteps_seen = 0
         self.flush_every = bp.get('flush_every', None)
@@ -69,7 +72,8 @@ class BackPropagation(object):
         phi0 = numpy.asarray(trial.init if self.init_walker else trial.psi, dtype=numpy.complex128)
         if phi0.ndim == 3:
             phi0 = phi0[0]
-        energies, denom, G = dev.bp_update(phi0, self.nstblz, self.restore_weights, self.eval_energy)
+        energies, denom, G = dev.bp_update(phi0, self.nstblz, self.restore_weights, self.eval_energy,
+                                           reset=bool(buff_ix == self.splits[-1]))     # back_propagation.py:219-222
         self.estimates[:self.nreg] += energies
         self.estimates[self.nreg] += denom
         self.estimates[self.nreg + 1:] += G.ravel()
@@ -85,6 +89,7 @@ class BackPropagation(object):
         if comm.rank == 0:
             weight = self.global_estimates[self.nreg]
             self.denominator.append(numpy.array(weight))
+            self.split_of.append(int(self.buff_ix))
             out = self.output
             if out is not None:
                 out.push(numpy.array([weight]), 'denominator_%d' % self.buff_ix)

@@ -29,8 +29,12 @@ class Mixed(object):
     def __init__(self, mixed, system, root, filename, qmc, trial, dtype=complex):
         self.eval_energy = mixed.get('evaluate_energy', True)
         self.calc_one_rdm = mixed.get('one_rdm', False)
-        if self.calc_one_rdm or mixed.get('two_rdm', None) is not None:
-            raise NotImplementedError("RDM accumulation is outside the device hot path")
+        if mixed.get('two_rdm', None) is not None:
+            raise NotImplementedError("two_rdm accumulation is outside the device hot path")
+        self.G = numpy.zeros((2, system.nbasis, system.nbasis))          # mixed.py:99
+        self.rdm_acc = numpy.zeros_like(self.G)
+        self.one_rdm = []                                               # per block, as pushed to 'one_rdm'
+        self._rdm_armed = False
         self.energy_eval_freq = mixed.get('energy_eval_freq', None)
         if self.energy_eval_freq is None:
             self.energy_eval_freq = qmc.nsteps                      # mixed.py:78-80
@@ -59,6 +63,7 @@ class Mixed(object):
         psi._end_sweep()
         psi._flush()
         dev = psi.dev
+        self.arm_rdm(dev)
         do_energy = (step % self.energy_eval_freq == 0)
         if do_energy and not self.eval_energy:
             # E, T, V = 0 but the denominator still accumulates (mixed.py:215-221)
@@ -69,8 +74,16 @@ class Mixed(object):
             dev.estimates_update(do_energy)
             est = dev.estimates_get(zero=True)
         self.estimates[:self.names.time] += est[:self.names.time]
+        if self.calc_one_rdm:
+            self.rdm_acc += dev.estimates_rdm_get(zero=True)            # mixed.py:226-229
         if do_energy:
             psi._greens_version = psi.phi_version           # the launch refreshed Ghalf
+
+    def arm_rdm(self, dev):
+        """one_rdm: True -> the device accumulates weight * walker.G.real with every estimator update."""
+        if self.calc_one_rdm and not self._rdm_armed:
+            dev.estimates_rdm(True)
+            self._rdm_armed = True
 
     def print_step(self, comm, nprocs, step, nsteps=None, free_projection=False):
         """mixed.py:235-289."""
@@ -102,8 +115,13 @@ class Mixed(object):
         if comm.rank == 0:
             row = [step] + list(gs[:ns.time + 1])
             self.blocks.append(numpy.array(row))
+            if self.calc_one_rdm:                               # mixed.py:279-283
+                rdm = self.rdm_acc / nsteps / gs[ns.weight].real
+                self.one_rdm.append(rdm)
             if self.output is not None:
                 self.output.push(row, 'energies')               # mixed.py:278
+                if self.calc_one_rdm:
+                    self.output.push(self.one_rdm[-1], 'one_rdm')
                 self.output.increment()
             if self.verbose:
                 print(" ".join("{: .10e}".format(x) for x in numpy.array(row).real))
@@ -117,6 +135,7 @@ class Mixed(object):
         return (self.estimates[self.names.enumer] / self.estimates[self.names.edenom]).real
 
     def zero(self):
+        self.rdm_acc[:] = 0
         self.estimates[:] = 0
         self.global_estimates[:] = 0
         self.estimates[self.names.time] = time.time()

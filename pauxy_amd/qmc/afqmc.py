@@ -181,6 +181,9 @@ class AFQMC(object):
             block_comm, other_comm = ReducedComm(self.comm), DeviceComm(dev, self.comm)
         else:
             block_comm = other_comm = self.comm
+        if dcomm and mixed.calc_one_rdm:
+            raise NotImplementedError("mixed one_rdm with the device communicator")
+        mixed.arm_rdm(dev)
         if first_step == 1:
             if dcomm:       # stays in the device accumulators and is reduced with the first block
                 self.psi._end_sweep()
@@ -200,6 +203,8 @@ class AFQMC(object):
                         dev.estimates_allreduce()       # mixed.py:261 on the device, 20 doubles over RCCL
                     est = dev.estimates_get(zero=True)  # also reports a collapsed population (AFQ_EWEIGHT)
                     mixed.estimates[:ns.time] += est[:ns.time]
+                    if mixed.calc_one_rdm:
+                        mixed.rdm_acc += dev.estimates_rdm_get(zero=True)
                     mixed.print_step(block_comm, self.comm.size, step)
                 for est in others:
                     est.print_step(other_comm, self.comm.size, step)

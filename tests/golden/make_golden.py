@@ -553,6 +553,77 @@ def make_traj_ueg():
 
 
 
+def make_traj_bp_ueg(name='traj_bp_ueg.npz'):
+    """Back-propagated one-body RDM for the UEG (estimators/back_propagation.py:127-226 with
+    propagation/planewave.py:141-178), same model as traj_ueg.npz, tau_bp = 4 steps."""
+    out = {}
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 4, 'rng_seed': 8},
+               'model': {'name': "UEG", 'rs': 2.44, 'ecut': 2, 'nup': 7, 'ndown': 7},
+               'estimates': {'mixed': {'energy_eval_freq': 1}, 'back_propagated': {'tau_bp': 0.04, 'one_rdm': True}},
+               'trial': {'name': 'hartree_fock'}}
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, options=options)
+    assert afqmc.estimators.back_propagation and afqmc.estimators.nbp == 4
+    ueg_arrays(afqmc.system, out, 'sys_')
+    out['nbp'] = afqmc.estimators.nbp
+    record_trajectory(afqmc, comm, out)
+    store = h5py._STORE[afqmc.estimators.filename]
+    dk = sorted((k for k in store if k.startswith('back_propagated/denominator_4/')), key=lambda k: int(k.rsplit('/', 1)[1]))
+    rk = sorted((k for k in store if k.startswith('back_propagated/one_rdm_4/')), key=lambda k: int(k.rsplit('/', 1)[1]))
+    assert len(dk) == len(rk) and len(dk) > 0
+    out['bp_denominator'] = numpy.array([store[k] for k in dk]).reshape(len(dk))
+    out['bp_one_rdm'] = numpy.array([store[k] for k in rk])
+    numpy.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def make_traj_mixed_rdm(name='traj_hubbard_rdm.npz'):
+    """Mixed estimator with one_rdm: True (estimators/mixed.py:226-233,279-283): 4x4 U=4 Hubbard, continuous HS,
+    10 walkers, comb every 5 steps, energy every 5 steps (so that the accumulated w.G is stale on the steps between:
+    it is the Green's function of the walker BEFORE that step's propagation, continuous.py:245)."""
+    out = {}
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 4, 'rng_seed': 8,
+                       'num_walkers': 10, 'pop_control_freq': 5},
+               'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 8, "U": 4, 'ndown': 8},
+               'trial': {'name': 'UHF'},
+               'estimates': {'mixed': {'energy_eval_freq': 5, 'one_rdm': True}},
+               'propagator': {'hubbard_stratonovich': 'continuous'}}
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, options=options)
+    out['T'] = afqmc.system.T
+    out['U'] = afqmc.system.U
+    record_trajectory(afqmc, comm, out)
+    store = h5py._STORE[afqmc.estimators.filename]
+    rk = sorted((k for k in store if k.startswith('basic/one_rdm/')), key=lambda k: int(k.rsplit('/', 1)[1]))
+    assert len(rk) > 0
+    out['mixed_one_rdm'] = numpy.array([store[k] for k in rk])
+    numpy.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def make_traj_log_shift(name='traj_hubbard_logshift.npz'):
+    """walkers/handler.py:228,456-475 (use_log_shift: True): running-average shifts of log|ot|, log detR applied in
+    walkers/single_det.py:159,192,250,320; same 4x4 model, comb every 5 steps, reortho every 5."""
+    out = {}
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 4, 'rng_seed': 8,
+                       'num_walkers': 10, 'pop_control_freq': 5, 'stabilise_freq': 5},
+               'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 8, "U": 4, 'ndown': 8},
+               'trial': {'name': 'UHF'},
+               'walkers': {'use_log_shift': True},
+               'estimates': {'mixed': {'energy_eval_freq': 1}},
+               'propagator': {'hubbard_stratonovich': 'continuous'}}
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, options=options)
+    assert afqmc.psi.use_log_shift
+    out['T'] = afqmc.system.T
+    out['U'] = afqmc.system.U
+    record_trajectory(afqmc, comm, out)
+    out['final_log_shift'] = numpy.array([w.log_shift for w in afqmc.psi.walkers])
+    out['final_detR_shift'] = numpy.array([w.detR_shift for w in afqmc.psi.walkers])
+    numpy.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def msd_system(out, tag=''):
     """propagation/tests/test_generic.py:52-62: 10 orbitals, 5+5 electrons, seed 7."""
     numpy.random.seed(7)
@@ -676,12 +747,14 @@ def make_traj_msd():
 
 
 
-def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=False):
+def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=False, nsplit=1, tau_bp=0.025):
     """qmc/tests/test_afqmc.py:232-278: single-determinant generic run with the back-propagated
     one-body RDM (tau_bp = 5 steps); pinned rdm[11,0,1,3].real == -0.121883381144845."""
     out = {}
     nmo, nelec = 11, (3, 3)
-    bp = {'tau_bp': 0.025, 'one_rdm': True}
+    bp = {'tau_bp': tau_bp, 'one_rdm': True}
+    if nsplit != 1:
+        bp['nsplit'] = nsplit
     if restore_weights is not None:
         bp['restore_weights'] = restore_weights
     if energy:
@@ -696,7 +769,7 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
                      chol=chol.reshape((-1, nmo * nmo)).T.copy(), ecore=enuc)
     comm = MPI.COMM_WORLD
     afqmc = AFQMC(comm=comm, system=system, options=options)
-    assert afqmc.estimators.back_propagation and afqmc.estimators.nbp == 5
+    assert afqmc.estimators.back_propagation and afqmc.estimators.nbp == int(round(tau_bp / 0.005))
     out['h1e'] = h1e
     out['chol'] = system.chol_vecs
     out['ecore'] = enuc
@@ -705,12 +778,25 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
     out['restore_weights'] = '' if restore_weights is None else restore_weights
     record_trajectory(afqmc, comm, out)
     store = h5py._STORE[afqmc.estimators.filename]
-    dk = sorted(k for k in store if k.startswith('back_propagated/denominator_5/'))
-    rk = sorted(k for k in store if k.startswith('back_propagated/one_rdm_5/'))
+    nbp = afqmc.estimators.nbp
+    if nsplit != 1:
+        # one output group per split length (back_propagation.py:288-324)
+        splits = [int(x) for x in afqmc.estimators.estimators['back_prop'].splits]
+        out['splits'] = numpy.array(splits)
+        for sp in splits:
+            dk = sorted((k for k in store if k.startswith('back_propagated/denominator_%d/' % sp)), key=lambda k: int(k.rsplit('/', 1)[1]))
+            rk = sorted((k for k in store if k.startswith('back_propagated/one_rdm_%d/' % sp)), key=lambda k: int(k.rsplit('/', 1)[1]))
+            assert len(dk) == len(rk) and len(dk) > 0, sp
+            out['bp_denominator_%d' % sp] = numpy.array([store[k] for k in dk]).reshape(len(dk))
+            out['bp_one_rdm_%d' % sp] = numpy.array([store[k] for k in rk])
+        numpy.savez_compressed(os.path.join(HERE, name), **out)
+        return
+    dk = sorted(k for k in store if k.startswith('back_propagated/denominator_%d/' % nbp))
+    rk = sorted(k for k in store if k.startswith('back_propagated/one_rdm_%d/' % nbp))
     assert len(dk) == len(rk) and len(dk) > 0
     out['bp_denominator'] = numpy.array([store[k] for k in dk]).reshape(len(dk))
     out['bp_one_rdm'] = numpy.array([store[k] for k in rk])
-    ek = sorted(k for k in store if k.startswith('back_propagated/energies_5/'))
+    ek = sorted(k for k in store if k.startswith('back_propagated/energies_%d/' % nbp))
     if ek:
         out['bp_energies'] = numpy.array([store[k] for k in ek])
     rdm = out['bp_one_rdm'] / out['bp_denominator'][:, None, None, None]
@@ -874,6 +960,13 @@ if __name__ == '__main__':
         make_traj_bp()
         make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r2':
+        # round-2 additions
+        make_traj_bp('traj_bp_split.npz', blocks=4, nsplit=2, tau_bp=0.03)
+        make_traj_bp_ueg()
+        make_traj_mixed_rdm()
+        make_traj_log_shift()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'msd':
         make_msd_ops()
         make_traj_msd()
@@ -898,6 +991,10 @@ if __name__ == '__main__':
     make_traj_bp('traj_bp_full.npz', restore_weights='full', blocks=4)
     make_traj_hirsch(pin=-152.68468568462666)
     make_traj_hirsch('traj_hubbard_hirsch_charge.npz', charge=True, blocks=4)
+    make_traj_bp('traj_bp_split.npz', blocks=4, nsplit=2, tau_bp=0.03)
+    make_traj_bp_ueg()
+    make_traj_mixed_rdm()
+    make_traj_log_shift()
     # (evaluate_energy: the reference raises TypeError at back_propagation.py:160 -- local_energy() has no
     #  'opt' keyword -- so there is no reference output to record for back-propagated energies)
     for f in sorted(os.listdir(HERE)):

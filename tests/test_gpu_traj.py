@@ -201,6 +201,50 @@ def test_traj_back_propagation_restored_weights(golden, monkeypatch):
     run_bp(golden, monkeypatch, 'traj_bp_full.npz', 'full')
 
 
+def test_traj_back_propagation_two_path_lengths(golden, monkeypatch):
+    """estimators/back_propagation.py:68-69,219-222 (nsplit = 2): windows of 3 and 6 steps from one field history."""
+    d = golden('traj_bp_split.npz')
+    na, nb = [int(x) for x in d['nelec']]
+    s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    for batched in (False, True):
+        out = {}
+        replay(d, s, t, {}, monkeypatch, est_extra={'back_propagated': {'tau_bp': 0.03, 'one_rdm': True, 'nsplit': 2}},
+               out=out, batched=batched)
+        est = out['afqmc'].estimators.estimators['back_prop']
+        sp = numpy.array(est.split_of)
+        for k in (3, 6):
+            close(numpy.array(est.denominator)[sp == k], d['bp_denominator_%d' % k])
+            close(numpy.array(est.one_rdm)[sp == k], d['bp_one_rdm_%d' % k])
+
+
+def test_traj_back_propagation_ueg(golden, monkeypatch):
+    """Back-propagated one-body RDM of the UEG (propagation/planewave.py:114-178), per-walker and batched loops."""
+    d = golden('traj_bp_ueg.npz')
+    s = systems.UEG(float(d['sys_rs']), 7, 7, float(d['sys_ecut']))
+    t = trial_mod.hartree_fock_ueg(s)
+    for batched in (False, True):
+        out = {}
+        replay(d, s, t, {}, monkeypatch, est_extra={'back_propagated': {'tau_bp': 0.04, 'one_rdm': True}}, out=out,
+               batched=batched)
+        est = out['afqmc'].estimators.estimators['back_prop']
+        close(numpy.array(est.denominator), d['bp_denominator'])
+        close(numpy.array(est.one_rdm), d['bp_one_rdm'])
+
+
+def test_traj_mixed_one_rdm(golden, monkeypatch):
+    """estimators/mixed.py:226-233,279-283 (one_rdm: True): per-block mixed one-body RDM, energy every 5 steps so that
+    the accumulated walker.G is stale (before the step's propagation) in between; both driver loops."""
+    d = golden('traj_hubbard_rdm.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    for batched in (False, True):
+        out = {}
+        replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch, out=out, batched=batched,
+               est_extra={'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'one_rdm': True, 'verbose': False}})
+        close(numpy.array(out['afqmc'].estimators.estimators['mixed'].one_rdm), d['mixed_one_rdm'])
+
+
 def run_hirsch(golden, monkeypatch, name, basename=None, batched=False):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]

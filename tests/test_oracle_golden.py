@@ -278,6 +278,57 @@ def test_back_propagated_rdm_restored_weights(golden):
     run_bp(d, 'full')
 
 
+def test_back_propagated_rdm_two_path_lengths(golden):
+    """estimators/back_propagation.py:68-69,145-147,219-222 with nsplit = 2: windows of 3 and 6 steps from one field
+    history, reset only at the longer one."""
+    d = golden('traj_bp_split.npz')
+    m = generic_model(d, '')
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+    bp = []
+    ref.run_afqmc(m, walkers, lambda s, w: xi[s - 1, w], lambda s: r[s - 1], int(d['nsteps']), int(d['nblocks']),
+                  nstblz=int(d['nstblz']), npop_control=int(d['npop_control']),
+                  energy_eval_freq=int(d['energy_eval_freq']), nbp=int(d['nbp']), bp_out=bp, bp_nsplit=2)
+    assert [int(x) for x in d['splits']] == [3, 6]
+    for sp in (3, 6):
+        mine = numpy.array([e for (k, e) in bp if k == sp])
+        close(mine[:, 3], d['bp_denominator_%d' % sp], 1e-9)
+        close(mine[:, 4:].reshape(d['bp_one_rdm_%d' % sp].shape), d['bp_one_rdm_%d' % sp], 1e-9)
+
+
+def test_back_propagated_rdm_ueg(golden):
+    """estimators/back_propagation.py:127-226 with propagation/planewave.py:114-178 (tau_bp = 4 steps)."""
+    d = golden('traj_bp_ueg.npz')
+    m = ueg_model(d, '', 'sys_')
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+    bp = []
+    ref.run_afqmc(m, walkers, lambda s, w: xi[s - 1, w], lambda s: r[s - 1], int(d['nsteps']), int(d['nblocks']),
+                  nstblz=int(d['nstblz']), npop_control=int(d['npop_control']),
+                  energy_eval_freq=int(d['energy_eval_freq']), nbp=int(d['nbp']), bp_out=bp)
+    bp = numpy.array(bp)
+    close(bp[:, 3], d['bp_denominator'], 1e-9)
+    close(bp[:, 4:].reshape(d['bp_one_rdm'].shape), d['bp_one_rdm'], 1e-9)
+
+
+def test_mixed_one_rdm(golden):
+    """estimators/mixed.py:226-233,279-283 (one_rdm: True, energy every 5 steps: the accumulated walker.G is the
+    Green's function before the step's propagation on the steps in between)."""
+    d = golden('traj_hubbard_rdm.npz')
+    m = hubbard_model(d, '', 'hubbard')
+    m.track_G = True
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+    rdm = []
+    ref.run_afqmc(m, walkers, lambda s, w: xi[s - 1, w], lambda s: r[s - 1], int(d['nsteps']), int(d['nblocks']),
+                  nstblz=int(d['nstblz']), npop_control=int(d['npop_control']),
+                  energy_eval_freq=int(d['energy_eval_freq']), rdm_out=rdm)
+    close(numpy.array(rdm), d['mixed_one_rdm'], 1e-9)
+
+
 def run_hirsch(d):
     na, nb = [int(x) for x in d['nelec']]
     m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
