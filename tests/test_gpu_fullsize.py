@@ -259,3 +259,87 @@ def AfqDeviceForMsd(model, coeffs, rchol0, nw):
     dev.set_propagator(model.BH1, model.mf_shift, model.dt)
     dev.walkers_alloc(nw)
     return dev
+
+
+def test_c5_sizes_distinct_complex_determinants():
+    """BASELINE configs[4] sizes (M=400, K=2000, 50+50) with a NOMSD trial of three DISTINCT complex determinants
+    (complex half-rotated Cholesky vectors: the complex exchange path).  Per walker: determinant weights
+    conj(c_d) <D_d|phi>, the weighted force bias (propagation/generic.py:154-157) and the energy
+    sum_d w_d E[G_d] / sum_d w_d (estimators/mixed.py:439-448) with every E[G_d] evaluated by the oracle's
+    half-rotated form (estimators/generic.py:156-221, equal to the reference's full-G form; the full-G intermediate
+    would need 5 GB per walker here); both exchange algorithms of the device against each other for all walkers."""
+    M, K, N, dt, nw = 400, 2000, 50, 0.005, 8
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t0 = trial_mod.rhf_trial_generic(s)
+    rng = numpy.random.RandomState(3)
+    dets = numpy.array([t0.psi + (0.0 if d == 0 else 0.05) * (rng.rand(M, 2 * N) + 1j * rng.rand(M, 2 * N)) for d in range(3)])
+    coeffs = numpy.array([0.8 + 0.1j, 0.3 - 0.2j, 0.2 + 0.05j])
+    t = trial_mod.MultiDetTrial(s, (coeffs, dets), init=t0.psi)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    phis = t0.psi[None] + 0.05 * (rng.rand(nw, M, 2 * N) + 1j * rng.rand(nw, M, 2 * N))
+    per = M * 2 * N
+    E = {}
+    for mode in (1, 2):
+        from pauxy_amd.device import AfqDevice
+        dev = AfqDevice(0)
+        dev.set_exchange_algorithm(mode)
+        dev.set_system_generic(s.hs_pot, t._rchol[:per], s.H1.astype(complex), s.ecore, N, N)
+        dev.set_trial_multi(dets, coeffs, t._rchol)
+        dev.set_propagator(BH1, mf, dt)
+        dev.walkers_alloc(nw)
+        dev.set(L.F_PHI, phis)
+        tot = dev.greens()
+        wts = dev.det_weights()
+        xbar = dev.force_bias()
+        dev.greens()
+        E[mode] = dev.local_energy()
+        assert dev.exchange_algorithm() == mode
+        dev.close()
+    close(E[1], E[2], 1e-11)
+    H1 = s.H1.astype(complex)
+    for w in (0, 5):
+        ws, Es, Gsum = [], [], 0.0
+        for d in range(3):
+            ov, gh, G = ref.greens_function(phis[w], dets[d], N, N)
+            ws.append(numpy.conj(coeffs[d]) * ov)
+            Es.append(numpy.array(ref.local_energy_generic_cholesky_opt(H1, s.ecore, G, gh, t._rchol[d * per:(d + 1) * per], N, N)))
+            Gsum = Gsum + ws[-1] * (G[0] + G[1])
+        ws = numpy.array(ws)
+        close(wts[w], ws, 1e-10)
+        close(tot[w], ws.sum(), 1e-10)
+        close(E[2][w], (ws[:, None] * numpy.array(Es)).sum(0) / ws.sum(), 1e-10)
+        vbias = s.hs_pot.T.dot((Gsum / ws.sum()).ravel())                      # propagation/generic.py:154-157
+        close(xbar[w], -dt ** 0.5 * (1j * vbias - mf), 1e-10)
+
+
+def test_c5_sizes_back_propagation_window():
+    """A back-propagation window at M=400, K=2000 (single-determinant trial, as the reference requires for it):
+    three recorded steps through the unfused propagator path (M > 104), afq_bp_update against the oracle."""
+    M, K, N, dt, nw, nbp = 400, 2000, 50, 0.005, 4, 3
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=0.0)
+    rng = numpy.random.RandomState(11)
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, M, 2 * N) + 1j * rng.rand(nw, M, 2 * N))
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_OT, dev.calc_overlap())
+    dev.bp_configure(nbp)
+    walkers = [ref.new_walker(model, p) for p in phis]
+    for w in walkers:
+        w['bp'] = ref.bp_new(K, nbp)
+        w['phi_old'] = w['phi'].copy()
+    for step in range(nbp):
+        xi = rng.normal(size=(nw, K))
+        dev.propagate(xi, 0.1)
+        for w, x in zip(walkers, xi):
+            ref.propagate_walker_phaseless(model, w, x, 0.1)
+    close(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]), 1e-9)
+    est = numpy.zeros(4 + 2 * M * M, dtype=complex)
+    ref.bp_update(model, walkers, 2, est, 'partial')
+    _, denom, G = dev.bp_update(model.psi, 2, 'partial')
+    close(denom, est[3], 1e-9)
+    close(G, est[4:].reshape(2, M, M), 1e-8)
+    dev.close()
