@@ -111,7 +111,8 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb,
 int afq_set_trial(afq_handle *h, const double *psi);
 /* ---- discrete Hirsch Hubbard-Stratonovich propagator -----------
  * propagation/hubbard.py:12-343 (Hirsch, single-site updates, constrained path) for a Hubbard system and a
- * single-determinant trial with N <= 45, M <= 128.  bt2 c128[2, M, M] = expm(-dt/2 T) (:36-37);
+ * single-determinant trial with N <= 128 electrons per spin (the inverse overlaps live in LDS up to N = 68 and are
+ * updated in place in global memory beyond).  bt2 c128[2, M, M] = expm(-dt/2 T) (:36-37);
  * charge_decomposition selects the charge (complex gamma) or spin HS (:66-82).
  *   afq_propagate_hirsch   one step for every walker with |weight| > 1e-8, site uniforms from the device
  *                          Philox stream: kinetic + importance sampling (:148-172), M single-site
@@ -193,7 +194,7 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out);
 int afq_calc_overlap(afq_handle *h, double *ovlp_out);
 /* O^-1 of every walker and spin, O = phi_s^T conj(psi_s) (so O^-1 = inv_O of estimators/greens_function.py:82-115
  * and the transpose of SingleDetWalker.inv_ovlp, walkers/single_det.py:95-115): c128[nw, 2, nmax, nmax] row-major with
- * leading dimension nmax = max(na, nb), zero padded; ovlp_out c128[nw] may be NULL.  N <= 45, M <= 128.              */
+ * leading dimension nmax = max(na, nb), zero padded; ovlp_out c128[nw] may be NULL.  N <= 128.                         */
 int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out);
 /* propagation/continuous.py:232-262 (phaseless) or :175-200 (free projection)
  * for every live walker (|weight| > 1e-8, qmc/afqmc.py:232).

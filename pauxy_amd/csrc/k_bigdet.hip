@@ -275,7 +275,7 @@ int k_greens_big_supported(afq_handle *h) {
     return nmax > 45 && nmax <= GJ_N && h->nb > 0 && !h->no_ring;
 }
 
-int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
+int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
     const int nb2 = 2 * h->nw;
     const size_t wsn = (size_t)nb2 * nmax * nmax;
@@ -293,7 +293,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
     }
     {
         GjArgs a;
-        a.na = h->na; a.nb = h->nb; a.ld = nmax; a.write_inverse = ghalf != nullptr;
+        a.na = h->na; a.nb = h->nb; a.ld = nmax; a.write_inverse = ghalf != nullptr || oinv != nullptr;
         a.O = h->big_ws; a.detm = h->detm; a.dete = h->dete;
         AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
         AFQ_POST(h);
@@ -301,6 +301,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det) {
                            h->dete, det, h->nw);
         AFQ_POST(h);
     }
+    if (oinv)    // [nw, 2, nmax, nmax]: the layout of the workspace (batch = 2 w + spin)
+        AFQ_HIP(h, hipMemcpyAsync(oinv, h->big_ws, sizeof(cplx) * wsn, hipMemcpyDeviceToDevice, h->stream));
     if (ghalf) {
         GhalfProb p;
         p.batch = nb2; p.rows = nmax; p.cols = h->M; p.kdim = nmax;

@@ -19,46 +19,57 @@ struct HirschArgs {
     const double *u;                 // [nw, M]
     int *fields, *used;
     const int *alive;
+    int inv_in_lds;
     cplx delta[2][2], wfac[2];
 };
 
 __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ cplx q_s[2][48], a_s[2][48], gii_s[2], den_s[2];
+    __shared__ cplx q_s[2][128], a_s[2][128], gii_s[2], den_s[2];
     __shared__ int xi_s, stop_s;
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!a.alive[w]) { if (tid == 0) a.used[w] = 0; return; }
     const int M = a.M, nt = a.nt, nmax = a.nmax;
-    cplx *inv = (cplx *)smem;                                  // [2][nmax][nmax] : O^-1
     cplx *phi = a.phi + (long)w * M * nt;
-    const cplx *og = a.oinv + (long)w * 2 * nmax * nmax;
-    for (int e = tid; e < 2 * nmax * nmax; e += 256) inv[e] = og[e];
+    cplx *og = a.oinv + (long)w * 2 * nmax * nmax;
+    // O^-1 of both spins: in LDS when it fits (N <= 68), else updated in place in global memory (L2 / MALL resident)
+    cplx *inv = a.inv_in_lds ? (cplx *)smem : og;               // [2][nmax][nmax]
+    if (a.inv_in_lds) for (int e = tid; e < 2 * nmax * nmax; e += 256) inv[e] = og[e];
     double weight = a.weight[w];
     cplx ot = a.ot[w];
     int used = 0;
     __syncthreads();
     for (int i = 0; i < M; ++i) {
-        // q_k = sum_l O^-1[k][l] phi[i,l];  a_l = sum_k O^-1[k][l] conj(psi[i,k])   (both spins)
-        for (int t = tid; t < 2 * 2 * nmax; t += 256) {
-            const int s = t / (2 * nmax), r = t % (2 * nmax), which = r / nmax, k = r % nmax;
+        // q_k = sum_l O^-1[k][l] phi[i,l]: one wave per row k, lanes over l;
+        // a_l = sum_k O^-1[k][l] conj(psi[i,k]): one thread per column l, rows read coalesced   (both spins)
+        for (int s = 0; s < 2; ++s) {
             const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
-            if (k >= ns) continue;
             const cplx *iv = inv + (long)s * nmax * nmax;
-            cplx acc = cmake(0.0, 0.0);
-            if (which == 0) {
-                for (int l = 0; l < ns; ++l) cfma(acc, iv[k * nmax + l], phi[(long)i * nt + off + l]);
-                q_s[s][k] = acc;
-            } else {
-                for (int l = 0; l < ns; ++l) cfma(acc, iv[l * nmax + k], cconj(a.psi[(long)i * nt + off + l]));
-                a_s[s][k] = acc;
+            for (int k = wave; k < ns; k += 4) {
+                cplx acc = cmake(0.0, 0.0);
+                for (int l = lane; l < ns; l += 64) cfma(acc, iv[k * nmax + l], phi[(long)i * nt + off + l]);
+                for (int o = 32; o > 0; o >>= 1) { acc.x += __shfl_down(acc.x, o); acc.y += __shfl_down(acc.y, o); }
+                if (lane == 0) q_s[s][k] = acc;
+            }
+            for (int l = tid; l < ns; l += 256) {
+                cplx acc = cmake(0.0, 0.0);
+                for (int k = 0; k < ns; ++k) cfma(acc, iv[k * nmax + l], cconj(a.psi[(long)i * nt + off + k]));
+                a_s[s][l] = acc;
             }
         }
         __syncthreads();
-        if (tid < 2) {                                        // G_ii of spin tid (hubbard.py:110-122)
-            const int s = tid, ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
-            cplx g = cmake(0.0, 0.0);
-            for (int k = 0; k < ns; ++k) cfma(g, cconj(a.psi[(long)i * nt + off + k]), q_s[s][k]);
-            gii_s[s] = g;
+        if (wave < 2) {                                       // G_ii of spin `wave` (hubbard.py:110-122)
+            const int s = wave, ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+            cplx g = cmake(0.0, 0.0), d = cmake(0.0, 0.0);
+            for (int k = lane; k < ns; k += 64) {
+                cfma(g, cconj(a.psi[(long)i * nt + off + k]), q_s[s][k]);
+                cfma(d, phi[(long)i * nt + off + k], a_s[s][k]);      // vt . (inv u) of the Sherman-Morrison denominator
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                g.x += __shfl_down(g.x, o); g.y += __shfl_down(g.y, o);
+                d.x += __shfl_down(d.x, o); d.y += __shfl_down(d.y, o);
+            }
+            if (lane == 0) { gii_s[s] = g; den_s[s] = d; }
         }
         __syncthreads();
         if (tid == 0) {
@@ -80,12 +91,7 @@ __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
                 xi_s = xi; stop_s = 0;
                 a.fields[(long)w * M + i] = xi;
                 // Sherman-Morrison denominators 1 + vt . (inv u) with vt = phi[i,:] delta
-                for (int s = 0; s < 2; ++s) {
-                    const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
-                    cplx d = cmake(0.0, 0.0);
-                    for (int l = 0; l < ns; ++l) cfma(d, phi[(long)i * nt + off + l], a_s[s][l]);
-                    den_s[s] = cadd(cmake(1.0, 0.0), cmul(a.delta[xi][s], d));
-                }
+                for (int s = 0; s < 2; ++s) den_s[s] = cadd(cmake(1.0, 0.0), cmul(a.delta[xi][s], den_s[s]));
             } else {
                 weight = 0.0; stop_s = 1;
             }
@@ -172,7 +178,10 @@ int k_hirsch_two_body(afq_handle *h) {
     a.phi = h->phi; a.psi = h->psi; a.oinv = h->hs_oinv; a.weight = h->weight; a.ot = h->ot; a.u = h->hs_u;
     a.fields = h->hs_fields; a.used = h->hs_used; a.alive = h->alive;
     for (int x = 0; x < 2; ++x) { a.wfac[x] = h->hs_wfac[x]; for (int s = 0; s < 2; ++s) a.delta[x][s] = h->hs_delta[x][s]; }
-    const size_t lds = sizeof(cplx) * 2 * (size_t)nmax * nmax;
+    if (nmax > 128) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: N <= 128 per spin");
+    size_t lds = sizeof(cplx) * 2 * (size_t)nmax * nmax;
+    a.inv_in_lds = lds <= 150 * 1024;
+    if (!a.inv_in_lds) lds = 0;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)hirsch_two_body_kernel, lds, lds_set));
     AFQ_LAUNCH(h, hirsch_two_body_kernel, dim3(h->nw), dim3(256), lds, h->stream, a);

@@ -536,8 +536,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
     if (k_greens_big_supported(h)) {
-        if (oinv) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "O^-1 output: N <= 45 only");
-        return k_greens_big(h, ghalf, det);
+        return k_greens_big(h, ghalf, det, oinv);
     }
     if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
@@ -586,7 +585,8 @@ int k_overlap(afq_handle *h, cplx *det_out) { return launch_greens(h, nullptr, d
 // O^-1 of every walker and spin (+ determinant), no Ghalf: the discrete Hirsch propagator's inverse overlap
 int k_inverse_overlap(afq_handle *h, cplx *oinv, cplx *det_out) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
-    if (nmax > 45 || h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: N <= 45, M <= 128");
+    if (!k_greens_big_supported(h) && (nmax > 45 || h->M > 4 * GS_KSMAX))
+        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "inverse overlaps: N <= 128 per spin (N <= 45: M <= 128)");
     return launch_greens(h, nullptr, det_out, 1, oinv);
 }
 

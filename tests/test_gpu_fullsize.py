@@ -343,3 +343,46 @@ def test_c5_sizes_back_propagation_window():
     close(denom, est[3], 1e-9)
     close(G, est[4:].reshape(2, M, M), 1e-8)
     dev.close()
+
+
+@pytest.mark.parametrize("nx,ny,ne", [(8, 8, 30), (16, 16, 128)])
+def test_hirsch_large_lattices(nx, ny, ne):
+    """The discrete Hirsch step (propagation/hubbard.py:148-225,285-312) beyond N = 45: 8x8 with 30+30 electrons
+    (inverse overlaps still in LDS) and the BASELINE configs[3] lattice 16x16 with 128+128 (inverse overlaps from
+    the register-resident Gauss-Jordan kernel, updated in place in global memory).  Kinetic importance sampling,
+    site loop (chosen fields exact), second kinetic step, against the oracle."""
+    from pauxy_amd.device import AfqDevice
+    s = systems.Hubbard(nx, ny, ne, ne, 4.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    m = ref.HirschModel(s.T.astype(complex), 4.0, t.psi, ne, ne, 0.01, False)
+    nw, M = 4, m.M
+    rng = numpy.random.RandomState(9)
+    dev = AfqDevice(0)
+    dev.set_system_hubbard(m.H1, m.U, ne, ne)
+    dev.set_trial(m.psi)
+    dev.set_propagator_hirsch(m.bt2, 0.01, False)
+    dev.walkers_alloc(nw)
+    phis = numpy.array([m.psi + 0.02 * (rng.rand(M, 2 * ne) + 1j * rng.rand(M, 2 * ne)) for _ in range(nw)])
+    w0 = numpy.array([1.0, 0.7, 0.0, 1.3])
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, dev.calc_overlap())
+    walkers = [ref.new_walker(m, p, weight=w) for p, w in zip(phis, w0)]
+    u = rng.rand(nw, M)
+    dev.hirsch_kinetic()
+    for wk in walkers:
+        if abs(wk['weight']) > 1e-8:
+            ref.hirsch_kinetic_importance_sampling(m, wk)
+    close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]), 1e-9)
+    fields, used = dev.hirsch_two_body(u)
+    for iw, wk in enumerate(walkers):
+        if abs(w0[iw]) > 1e-8 and abs(wk['weight']) > 0:
+            it = iter(u[iw])
+            f = ref.hirsch_two_body_single_site(m, wk, lambda: next(it))
+            assert list(fields[iw]) == f and used[iw] == M
+        else:
+            assert used[iw] == 0
+    close(dev.get(L.F_PHI), numpy.array([wk['phi'] for wk in walkers]), 1e-9)
+    close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]), 1e-8)
+    close(dev.get(L.F_OT), numpy.array([wk['ot'] for wk in walkers]), 1e-8)
+    dev.close()
