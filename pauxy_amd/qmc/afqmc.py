@@ -206,6 +206,7 @@ class AFQMC(object):
                     if mixed.calc_one_rdm:
                         mixed.rdm_acc += dev.estimates_rdm_get(zero=True)
                     mixed.print_step(block_comm, self.comm.size, step)
+                    self.psi.tune_exchange_capacity()
                 for est in others:
                     est.print_step(other_comm, self.comm.size, step)
                 if self.psi.write_restart and step % self.psi.write_freq == 0:

@@ -429,6 +429,17 @@ class Walkers(object):
         self.phi_version += 1
         self._invalidate()
 
+    def tune_exchange_capacity(self):
+        """Device communicator: size the per-peer exchange slots from the largest transfer seen so far (twice that + 4,
+        at least 4, at most nw).  Called at block boundaries, right behind the block's host sync; every rank computes the
+        same global comb, hence the same statistic and the same new capacity (send and receive sizes must agree)."""
+        if not self.device_comm:
+            return
+        st = self.dev.comm_stats()
+        want = min(self.nw, max(4, 2 * st['max_transfer'] + 4))
+        if want > st['capacity'] or want < 0.6 * st['capacity']:
+            self.dev.comm_set_capacity(want)
+
     def _pop_control_distributed(self, comm):
         total, self.last_parent_ix = pop_control_distributed(self.dev, comm, self.nw, self.target_weight)
         return total
