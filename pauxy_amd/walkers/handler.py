@@ -430,14 +430,16 @@ class Walkers(object):
         self._invalidate()
 
     def tune_exchange_capacity(self):
-        """Device communicator: size the per-peer exchange slots from the largest transfer seen so far (twice that + 4,
-        at least 4, at most nw).  Called at block boundaries, right behind the block's host sync; every rank computes the
-        same global comb, hence the same statistic and the same new capacity (send and receive sizes must agree)."""
+        """Device communicator: size the per-peer exchange slots from the largest transfer seen so far (four times that
+        + 8, at least 8, at most nw; an overflow aborts the run, spare slots only cost link time).  Called at block
+        boundaries, right behind the block's host sync; every rank computes the same global comb, hence the same
+        statistic and the same new capacity (send and receive sizes must agree).  Growing is immediate, shrinking waits
+        for 20 events of history."""
         if not self.device_comm:
             return
         st = self.dev.comm_stats()
-        want = min(self.nw, max(4, 2 * st['max_transfer'] + 4))
-        if want > st['capacity'] or want < 0.6 * st['capacity']:
+        want = min(self.nw, max(8, 4 * st['max_transfer'] + 8))
+        if want > st['capacity'] or (st['events'] >= 20 and want < 0.6 * st['capacity']):
             self.dev.comm_set_capacity(want)
 
     def _pop_control_distributed(self, comm):
