@@ -67,6 +67,9 @@ __device__ inline void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// NARROW: at most one column tile per spin (na, nb <= 16); a separate instantiation so that each carries only the
+// Taylor tile deals it uses (register allocation and code size of one variant do not tax the other)
+template <bool NARROW>
 __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = blockIdx.x;
@@ -154,7 +157,6 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     };
 
     int ring_slot = 0;                                           // slot of the chunk being consumed
-    int gcons = 0;                                               // chunks consumed so far
     // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
     auto next_chunk = [&]() __attribute__((always_inline)) -> unsigned {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * 2) : "memory");
@@ -162,7 +164,6 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         issueA();
         const unsigned sl = ring_l + ring_slot * 16384;
         if (++ring_slot == PF_D) ring_slot = 0;
-        ++gcons;
         return sl;
     };
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     if (a.t4) taylor4();
     else
 #endif
-    if (a.na <= 16 && a.nb <= 16) {
+    if (NARROW) {
         // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
         // waves 4-7 the row tiles from 4 on: singly when there are six (3 tiles on every SIMD), as a pair + a single
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
@@ -593,10 +594,16 @@ int k_prop_fused(afq_handle *h) {
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
-    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
-    AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel, lds, lds_set));
+    static size_t lds_set[2][AFQ_MAX_DEVICES] = {{0}, {0}};
+    const bool narrow = h->na <= 16 && h->nb <= 16;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
-    AFQ_LAUNCH(h, prop_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
+    if (narrow) {
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true>, lds, lds_set[1]));
+        AFQ_LAUNCH(h, prop_fused_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
+    } else {
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false>, lds, lds_set[0]));
+        AFQ_LAUNCH(h, prop_fused_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+    }
     AFQ_POST(h);
     return AFQ_OK;
 }

@@ -180,7 +180,11 @@ int k_force_bias_generic(afq_handle *h) {
             }
             else if (cfg == 2) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
-                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+#ifdef AFQ_TUNING
+                if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                else
+#endif
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, true>(p, h->stream, h->zero_page)));
             }
             else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));

@@ -32,7 +32,7 @@ template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static con
 
 // KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, bool STAG = false>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
     static_assert(P::A_CPLX, "A operand must be complex");
     static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
@@ -124,63 +124,104 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             if (K3M) acc3[i][j] = (d4_t){0, 0, 0, 0};
         }
 
+    // operand fragments of ONE chunk (declared outside the chunk loop: the staggered waves carry them across a barrier)
+    d2_t a[KC][TM][2];
+    d2_t bc[KC][TN][2];
+    double br[KC][TN][2];
+    auto read_sub = [&](unsigned sl0, int sub) __attribute__((always_inline)) {
+        const unsigned sl = sl0 + sub * SUB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a[sub][i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (P::B_CPLX) bc[sub][j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
+                else br[sub][j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
+            }
+    };
+    auto conj_sub = [&](int sub) __attribute__((always_inline)) {
+        if (gemm_conj_a<P>::value) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[sub][i][s][1] = -a[sub][i][s][1];
+        }
+    };
+    // the MFMAs of sub-step s (4 of the 8 contraction indices of a chunk)
+    auto mfma_step = [&](int sub, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (P::B_CPLX && K3M) {
+                    accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);                          // P1
+                    accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][1], accI[i][j]);                          // P2
+                    acc3[i][j] = mfma16(a[sub][i][s][0] + a[sub][i][s][1], bc[sub][j][s][0] + bc[sub][j][s][1], acc3[i][j]);  // P3
+                } else if (P::B_CPLX) {
+                    accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);
+                    accI[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][1], accI[i][j]);
+                    accR[i][j] = mfma16(-a[sub][i][s][1], bc[sub][j][s][1], accR[i][j]);
+                    accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][0], accI[i][j]);
+                } else {
+                    accR[i][j] = mfma16(a[sub][i][s][0], br[sub][j][s], accR[i][j]);
+                    accI[i][j] = mfma16(a[sub][i][s][1], br[sub][j][s], accI[i][j]);
+                }
+            }
+    };
+    auto mfma_sub = [&](int sub) __attribute__((always_inline)) {
+        conj_sub(sub);
+        mfma_step(sub, 0);
+        mfma_step(sub, 1);
+    };
+
 #pragma unroll
     for (int c = 0; c < D - 1; ++c) issue(c, c);
+    // STAG: the second half of the waves (the SIMD partners of the first half when the work-group has 8 waves) cross
+    // the chunk barrier in the MIDDLE of a chunk's MFMAs -- sub-step 1 of chunk c is multiplied right behind barrier
+    // c + 1 from fragments already in registers, then the fragments of chunk c + 1 are read and its sub-step 0
+    // multiplied -- so that the partner's LDS reads and ring refill run under this wave's MFMAs and vice versa.
+    if (STAG && KC == 1 && wave >= NW / 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(D - 1, (D - 1) & (D - 1));
+        read_sub(ring_l, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        conj_sub(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(c + D, (c + D) & (D - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunks) {
+                read_sub(ring_l + ((c + 1) & (D - 1)) * CHUNK, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                conj_sub(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(c + D - 1, (c + D - 1) & (D - 1));
         const unsigned sl0 = ring_l + (c & (D - 1)) * CHUNK;
-        d2_t a[KC][TM][2];
-        d2_t bc[KC][TN][2];
-        double br[KC][TN][2];
-        auto read_sub = [&](int sub) {
-            const unsigned sl = sl0 + sub * SUB;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a[sub][i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (P::B_CPLX) bc[sub][j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
-                    else br[sub][j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
-                }
-        };
-        auto mfma_sub = [&](int sub) {
-            if (gemm_conj_a<P>::value) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) a[sub][i][s][1] = -a[sub][i][s][1];
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (P::B_CPLX && K3M) {
-                            accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);                          // P1
-                            accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][1], accI[i][j]);                          // P2
-                            acc3[i][j] = mfma16(a[sub][i][s][0] + a[sub][i][s][1], bc[sub][j][s][0] + bc[sub][j][s][1], acc3[i][j]);  // P3
-                        } else if (P::B_CPLX) {
-                            accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);
-                            accI[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][1], accI[i][j]);
-                            accR[i][j] = mfma16(-a[sub][i][s][1], bc[sub][j][s][1], accR[i][j]);
-                            accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][0], accI[i][j]);
-                        } else {
-                            accR[i][j] = mfma16(a[sub][i][s][0], br[sub][j][s], accR[i][j]);
-                            accI[i][j] = mfma16(a[sub][i][s][1], br[sub][j][s], accI[i][j]);
-                        }
-                    }
-        };
-        read_sub(0);
+        read_sub(sl0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (KC == 2) {
-            read_sub(KC - 1);                              // in flight under the MFMAs of the first half
+            read_sub(sl0, KC - 1);                         // in flight under the MFMAs of the first half
             __builtin_amdgcn_sched_barrier(0);
         }
         mfma_sub(0);
@@ -215,7 +256,7 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
 }
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, bool STAG = false>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;
     constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
@@ -230,7 +271,7 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     }
     if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
     const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
-    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC>;
+    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC, STAG>;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};   // one per template instantiation and device: set the cap once
     {
         hipError_t e = afq_raise_lds((const void *)kern, lds, lds_set);
