@@ -150,6 +150,16 @@ static int upload_psi(afq_handle *h, const double *psi) {
     cache_of(h)->psi.assign(psi, psi + 2 * n);
     std::vector<double> pc(psi, psi + 2 * n);
     for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
+    if (h->ndet <= 1) {     // transposed copy (Hubbard force bias: diag of G from rows of conj(psi)^T and Ghalf)
+        std::vector<double> pt(2 * n);
+        for (int p_ = 0; p_ < h->M; ++p_)
+            for (int i = 0; i < h->nt; ++i) {
+                pt[2 * ((size_t)i * h->M + p_)] = pc[2 * ((size_t)p_ * h->nt + i)];
+                pt[2 * ((size_t)i * h->M + p_) + 1] = pc[2 * ((size_t)p_ * h->nt + i) + 1];
+            }
+        int rc2 = dev_upload(h, &h->psicT, pt.data(), n);
+        if (rc2) return rc2;
+    }
     return dev_upload(h, &h->psic, pc.data(), n);
 }
 
@@ -223,7 +233,7 @@ int afq_destroy(afq_handle *h) {
     k_comm_destroy(h);
     free_walkers(h);
     free_system(h);
-    dev_free(h->psi); dev_free(h->psic); dev_free(h->BH1); dev_free(h->mf_shift);
+    dev_free(h->psi); dev_free(h->psic); dev_free(h->psicT); dev_free(h->BH1); dev_free(h->mf_shift);
     dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
     if (h->zero_page) hipFree(h->zero_page);
     if (h->retired) hipHostFree((void *)h->retired);

@@ -87,6 +87,7 @@ struct afq_handle {
     bool have_trial = false;
     cplx *psi = nullptr;            // [M, nt]
     cplx *psic = nullptr;           // conj(psi) [M, nt] (B operand of the overlap GEMM)
+    cplx *psicT = nullptr;          // conj(psi)^T [nt, M]: coalesced reads of the Hubbard force bias (single-determinant upload only)
     long psi_stride = 0;            // elements between per-walker 'trials' (back-propagation only; 0 = shared psi)
 
     // multi-determinant trial: the trial-dependent operands of every determinant;

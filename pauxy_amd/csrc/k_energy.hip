@@ -334,8 +334,11 @@ struct EFinArgs {
     long ldy;
 };
 
-__global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
-    __shared__ double red[8];
+// EF_THR threads per walker: the kernel streams Ghalf, rH1, the Coulomb partials and (quadratic-form exchange) the
+// Y partials of its walker once; 16 waves per CU keep enough loads in flight
+#define EF_THR 1024
+__global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
+    __shared__ double red[EF_THR / 64];
     const int w = blockIdx.x, tid = threadIdx.x;
     // one-body
     double e1r = 0, e1i = 0;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
     const cplx *gh = a.ghalf + (long)w * nq;
     double exr = 0, exi = 0;
     const long nqa = (long)a.na * a.M;
-    for (long q = tid; q < nq; q += 256) {
+    for (long q = tid; q < nq; q += EF_THR) {
         const cplx h = a.rH1[q], g = gh[q];
         e1r += h.x * g.x - h.y * g.y;
         e1i += h.x * g.y + h.y * g.x;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
     }
     // Coulomb
     double ecr = 0, eci = 0;
-    for (int n = tid; n < a.K; n += 256) {
+    for (int n = tid; n < a.K; n += EF_THR) {
         cplx x = cmake(0.0, 0.0);
         for (int b = 0; b < 2 * a.nsplit; ++b) x = cadd(x, a.vbias[((long)b * a.nw + w) * a.K + n]);
         ecr += x.x * x.x - x.y * x.y;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
     // exchange partials of this walker (exx_kernel path)
     const int wt = w >> 4, wl = w & 15;
     const int np = a.Yq ? 0 : 2 * a.nxt * EXX_CHUNKS;
-    for (int t = tid; t < np; t += 256) {
+    for (int t = tid; t < np; t += EF_THR) {
         const int chunk = t % EXX_CHUNKS;
         const int xt = (t / EXX_CHUNKS) % a.nxt;
         const int s = t / (EXX_CHUNKS * a.nxt);
@@ -383,7 +386,9 @@ __global__ __launch_bounds__(256) void energy_finish_kernel(EFinArgs a) {
         __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = x;
         __syncthreads();
-        v[k] = red[0] + red[1] + red[2] + red[3];
+        double tot = 0.0;
+        for (int i = 0; i < EF_THR / 64; ++i) tot += red[i];
+        v[k] = tot;
     }
     if (tid == 0) {
         const double e2r = 0.5 * (v[2] - v[4]), e2i = 0.5 * (v[3] - v[5]);
@@ -535,7 +540,7 @@ int k_energy_generic(afq_handle *h) {
         f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = nullptr;
         f.energy = h->energy; f.Yq = h->exq_y; f.qsplit = S; f.na = h->na;
         f.ldy = (long)(h->na > h->nb ? h->na : h->nb) * M;
-        AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
+        AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
         AFQ_POST(h);
         return AFQ_OK;
     }
@@ -580,7 +585,7 @@ int k_energy_generic(afq_handle *h) {
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
     f.energy = h->energy; f.Yq = nullptr; f.qsplit = 0; f.na = h->na; f.ldy = 0;
-    AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(256), 0, h->stream, f);
+    AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
     AFQ_POST(h);
     return AFQ_OK;
 }

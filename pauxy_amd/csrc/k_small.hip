@@ -596,6 +596,7 @@ struct XbarArgs {
     int kind, flags, M, K, na, nb, nt, nw, nsplit, nq;
     double sqrt_dt, U;
     const cplx *vbias, *mf, *ghalf, *psi;
+    const cplx *psicT;      // conj(psi)^T [nt, M] or null
     cplx *xbar;
     int ndet;               // > 1: vbias holds ndet slices of det_stride elements, combined with detw
     long det_stride;
@@ -641,7 +642,8 @@ __device__ inline cplx xbar_value(const XbarArgs &a, int w, int n) {
             for (int s = 0; s < 2; ++s) {
                 const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
                 for (int i = 0; i < ns; ++i) {
-                    const cplx c = cconj(a.psi[(long)n * a.nt + off + i]);
+                    // adjacent threads = adjacent sites n: both operands read along n
+                    const cplx c = a.psicT ? a.psicT[(long)(off + i) * a.M + n] : cconj(a.psi[(long)n * a.nt + off + i]);
                     cfma(g[s], c, a.ghalf[((long)w * a.nt + off + i) * a.M + n]);
                 }
             }
@@ -677,6 +679,7 @@ static XbarArgs xbar_args(afq_handle *h) {
     a.nt = h->nt; a.nw = h->nw; a.nsplit = h->fb_split; a.nq = h->nq;
     a.sqrt_dt = h->sqrt_dt; a.U = h->U;
     a.vbias = h->vbias; a.mf = h->mf_shift; a.ghalf = h->ghalf; a.psi = h->psi; a.xbar = h->xbar;
+    a.psicT = (h->ndet <= 1 && h->psi_stride == 0) ? h->psicT : nullptr;
     a.ndet = h->ndet; a.detw = h->detw; a.det_stride = (long)2 * h->fb_split * h->nw * h->K;
     if (h->ndet > 1) a.vbias = h->vbias_all;
     return a;

@@ -58,18 +58,20 @@ def test_call_order_and_ranges():
 
 
 def test_unsupported_sizes():
-    s = systems.Hubbard(8, 8, 50, 50, 4.0)                  # N = 50 > 45
-    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    s = systems.Hubbard(12, 12, 130, 130, 4.0)              # N = 130 > 128: beyond the discrete Hirsch propagator
+    M = 144
+    q = numpy.linalg.qr(numpy.random.RandomState(1).rand(M, 130))[0]
+    psi = numpy.hstack([q, q]).astype(complex)
     dev = AfqDevice(0)
-    dev.set_system_hubbard(s.T.astype(complex), 4.0, 50, 50)
-    dev.set_trial(t.psi)
-    dev.set_propagator_hirsch(numpy.array([numpy.eye(64), numpy.eye(64)], dtype=complex), 0.01)
+    dev.set_system_hubbard(s.T.astype(complex), 4.0, 130, 130)
+    dev.set_trial(psi)
+    dev.set_propagator_hirsch(numpy.array([numpy.eye(M), numpy.eye(M)], dtype=complex), 0.01)
     dev.walkers_alloc(2)
-    dev.set(L.F_PHI, numpy.array([t.psi] * 2))
+    dev.set(L.F_PHI, numpy.array([psi] * 2))
     with pytest.raises(L.AfqError) as e:
         dev.hirsch_kinetic()
-    assert e.value.code == -5 and 'N <= 45' in str(e.value)
+    assert e.value.code == -5 and 'N <= 128' in str(e.value)
     with pytest.raises(L.AfqError) as e:                    # continuous step on a handle configured for Hirsch
-        dev.propagate(numpy.zeros((2, 64)), 0.0)
+        dev.propagate(numpy.zeros((2, M)), 0.0)
     assert e.value.code == -2
     dev.close()
