@@ -186,3 +186,23 @@ def test_weight_cap_inside_propagate_equals_separate_cap():
     wc, _ = run(False)
     assert numpy.array_equal(wc, wa)
     release_context(s, t)
+
+
+@pytest.mark.parametrize("M,K,na,nb,nw,cplx", [(40, 24, 6, 6, 20, False), (12, 30, 3, 0, 9, False), (19, 33, 4, 1, 33, True)])
+def test_exchange_algorithms_odd_sizes(M, K, na, nb, nw, cplx):
+    """Both exchange-energy algorithms (estimators/generic.py:198-216) at awkward sizes: K < M (the automatic choice is
+    the T-intermediate kernel there), a fully polarised system (no beta electrons), one beta electron with a complex
+    trial; each against the oracle."""
+    model, rng = build(M, K, na, nb, cplx)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    refs = [ref.greens_function(p, model.psi, na, nb) for p in phis]
+    want = numpy.array([model.local_energy(r[2], r[1]) for r in refs])
+    for mode in (0, 1, 2):
+        dev = make_device(model, nw)
+        dev.set_exchange_algorithm(mode)
+        if mode == 0:
+            assert dev.exchange_algorithm() == (2 if K >= M else 1)
+        dev.set(L.F_PHI, phis)
+        dev.greens()
+        close(dev.local_energy(), want)
+        dev.close()
