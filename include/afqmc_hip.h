@@ -55,7 +55,7 @@ typedef struct afq_handle afq_handle;
 /* walker fields for afq_walkers_set / afq_walkers_get.
  * per-walker shapes: PHI c128[M, na+nb]; WEIGHT, UNSCALED_WEIGHT, DETR f64;
  * OT, HYBRID_ENERGY, PHASE, ELOC c128; GHALF c128[na+nb, M] (alpha rows first);
- * G c128[2, M, M]; XBAR, XSHIFTED c128[K]; ENERGY c128[3]                       */
+ * G c128[2, M, M]; XBAR, XSHIFTED c128[K]; ENERGY c128[3]; LOG_DETR f64         */
 enum afq_field {
     AFQ_F_PHI = 0,
     AFQ_F_WEIGHT = 1,
@@ -70,6 +70,7 @@ enum afq_field {
     AFQ_F_XBAR = 10,
     AFQ_F_XSHIFTED = 11,
     AFQ_F_ENERGY = 12,
+    AFQ_F_LOG_DETR = 13,
     AFQ_F_COUNT_
 };
 
@@ -203,6 +204,15 @@ int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out);
 int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im);
 /* walkers/handler.py:166-181 -> walkers/single_det.py:215-255; detR f64[nw] out (may be NULL) */
 int afq_reortho(afq_handle *h, double *detR_out);
+/* walkers: {use_log_shift: true} (walkers/handler.py:45,228,456-475, walkers/single_det.py:159,192,250-253,320).
+ * Every walker carries the same log_shift / detR_shift (walker.py:49-52, handler.py:471-474), so they are handle
+ * state: walker.ot = overlap * exp(-log_shift) on the continuous path (exp(+log_shift) behind calc_otrial on the
+ * discrete path, :159), detR = exp(log det R - detR_shift), and AFQ_F_LOG_DETR accumulates log(detR) per walker.
+ * on == 0 switches the option off.  afq_calc_overlap / afq_greens keep returning the unshifted determinant.
+ * afq_log_ovlp_sums: f64[3] = sums over this rank's walkers of |ot|, |detR|, |log_detR| (handler.py:457-462);
+ * the caller reduces them over ranks and feeds the running averages back through afq_set_log_shift.          */
+int afq_set_log_shift(afq_handle *h, int on, double log_shift, double detR_shift);
+int afq_log_ovlp_sums(afq_handle *h, double *sums3);
 /* estimators/mixed.py:383-437 dispatch for every walker, from the current
  * Ghalf/G (call afq_greens first): E c128[nw,3] = (E, E1, E2); may be NULL.   */
 int afq_local_energy(afq_handle *h, double *E_out);

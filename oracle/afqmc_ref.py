@@ -442,10 +442,10 @@ class HirschModel(object):
         self.nfields = self.M
 
     def greens(self, phi):
-        return greens_function(phi, self.psi, self.na, self.nb)
+        return greens_function(phi, self.psi, self.na, self.nb, getattr(self, 'log_shift', 0.0))
 
     def overlap(self, phi):
-        return calc_overlap(phi, self.psi, self.na, self.nb)
+        return calc_overlap(phi, self.psi, self.na, self.nb, getattr(self, 'log_shift', 0.0))
 
     def local_energy(self, G, Ghalf):
         return local_energy_hubbard(self.H1, self.U, G)
@@ -458,18 +458,19 @@ def hirsch_inverse_overlap(model, w):
                      scipy.linalg.inv((model.psi[:, na:].conj()).T.dot(w['phi'][:, na:]))]
 
 
-def hirsch_calc_otrial(w):
-    """walkers/single_det.py:141-168: 1 / (det inv_ovlp_a det inv_ovlp_b)."""
+def hirsch_calc_otrial(w, log_shift=0.0):
+    """walkers/single_det.py:141-168: 1 / (det inv_ovlp_a det inv_ovlp_b exp(-log_shift)) -- the shift enters the
+    determinant of the INVERSE here (:159), i.e. with the opposite sign of calc_overlap (:192)."""
     sa, la = numpy.linalg.slogdet(w['inv_ovlp'][0])
     sb, lb = numpy.linalg.slogdet(w['inv_ovlp'][1])
-    return 1.0 / (sa * sb * numpy.exp(la + lb))
+    return 1.0 / (sa * sb * numpy.exp(la + lb - log_shift))
 
 
 def hirsch_kinetic_importance_sampling(model, w):
     """propagation/hubbard.py:148-172."""
     kinetic_real(w['phi'], model.bt2, model.na)
     hirsch_inverse_overlap(model, w)
-    ot_new = hirsch_calc_otrial(w)
+    ot_new = hirsch_calc_otrial(w, getattr(model, 'log_shift', 0.0))
     ratio = ot_new / w['ot']
     if abs(cmath.phase(ratio)) < 0.5 * math.pi:
         w['weight'] = w['weight'] * ratio.real
@@ -703,12 +704,12 @@ class RefModel(object):
     def greens(self, phi):
         if self.kind == 'generic_msd':
             return msd_greens_function(phi, self.psi, self.coeffs, self.na, self.nb)
-        return greens_function(phi, self.psi, self.na, self.nb)
+        return greens_function(phi, self.psi, self.na, self.nb, getattr(self, 'log_shift', 0.0))
 
     def overlap(self, phi):
         if self.kind == 'generic_msd':
             return msd_calc_overlap(phi, self.psi, self.coeffs, self.na, self.nb)
-        return calc_overlap(phi, self.psi, self.na, self.nb)
+        return calc_overlap(phi, self.psi, self.na, self.nb, getattr(self, 'log_shift', 0.0))
 
     # -- system dispatch ------------------------------------------------
     def force_bias(self, Ghalf, G):
@@ -756,7 +757,7 @@ def new_walker(model, phi0, weight=1.0):
     phi = numpy.array(phi0, dtype=numpy.complex128, copy=True)
     ot = model.overlap(phi)
     w = dict(phi=phi, weight=weight, unscaled_weight=weight, ot=ot, ovlp=ot,
-             hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0)
+             hybrid_energy=0.0, total_weight=0.0, detR=1.0, phase=1.0 + 0j, eloc=0.0, log_detR=0.0)
     if getattr(model, 'track_G', False):
         w['G'] = model.greens(phi)[2]              # walker.G as left by the constructor (single_det.py:81)
     return w
@@ -825,11 +826,27 @@ def propagate_walker_phaseless(model, w, xi, eshift, hybrid=True):
     return ntrig, htrig
 
 
-def pop_control(model, walkers, target, r):
+def update_log_ovlp(model, walkers):
+    """walkers/handler.py:456-475 (use_log_shift: True) for one rank: running averages of log <|ot|>, log <|detR|>
+    and <|log_detR|>, kept on the model since every walker carries the same values (walker.py:49-52)."""
+    n = getattr(model, 'shift_counter', 1)
+    nw = len(walkers)
+    log_shift = numpy.log(sum(abs(w['ot']) for w in walkers) / nw)
+    detR_shift = numpy.log(sum(abs(w['detR']) for w in walkers) / nw)
+    log_detR_shift = sum(abs(w['log_detR']) for w in walkers) / nw
+    model.log_shift = (getattr(model, 'log_shift', 0.0) * (n - 1) + log_shift) / n
+    model.log_detR_shift = (getattr(model, 'log_detR_shift', 0.0) * (n - 1) + log_detR_shift) / n
+    model.detR_shift = (getattr(model, 'detR_shift', 0.0) * (n - 1) + detR_shift) / n
+    model.shift_counter = n + 1
+
+
+def pop_control(model, walkers, target, r, use_log_shift=False):
     """walkers/handler.py:225-338 for one rank.  ``r`` is the uniform the
     reference draws at :276.  Returns parent_ix."""
     if len(walkers) == 1:
         return None
+    if use_log_shift:
+        update_log_ovlp(model, walkers)
     weights = numpy.array([abs(w['weight']) for w in walkers])
     total_weight = sum(weights)
     scale = total_weight / target
@@ -906,7 +923,8 @@ def block_reduce(est, nsteps):
 def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
               npop_control=1, energy_eval_freq=None, eqlb_time=2.0, hybrid=True,
               record=None, verbose=False, free_projection=False, nbp=None, bp_out=None,
-              restore_weights=None, bp_energy=False, uniform_source=None, bp_nsplit=1, rdm_out=None):
+              restore_weights=None, bp_energy=False, uniform_source=None, bp_nsplit=1, rdm_out=None,
+              use_log_shift=False):
     """qmc/afqmc.py:200-255 for one rank.
 
     xi_source(step, iw) -> real [nfields] normal field for walker iw (called
@@ -950,8 +968,9 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
     for step in range(1, nsteps * nblocks + 1):
         if step % nstblz == 0:
             for w in walkers:
-                detR = reortho(w['phi'], model.na, model.nb)
+                detR = reortho(w['phi'], model.na, model.nb, getattr(model, 'detR_shift', 0.0))
                 w['detR'] = detR
+                w['log_detR'] += numpy.log(detR)         # single_det.py:251
                 w['ot'] = w['ot'] / detR
                 w['ovlp'] = w['ot']
                 if free_projection:                    # walkers/handler.py:178-181
@@ -971,7 +990,8 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
                 w['weight'] = w['total_weight'] * 0.10
         parent_ix = None
         if step % npop_control == 0:
-            parent_ix = pop_control(model, walkers, ntot, uni() if uni is not None else r_source(step))
+            parent_ix = pop_control(model, walkers, ntot, uni() if uni is not None else r_source(step),
+                                    use_log_shift)
         mixed_update(model, est, walkers, step, energy_eval_freq, free_projection, rdm)
         if nbp is not None:                                          # back_propagation.py:68-69,145-147
             splits = [(i + 1) * (nbp // bp_nsplit) for i in range(bp_nsplit)]

@@ -16,7 +16,7 @@ AFQ_EWEIGHT, AFQ_EOVERFLOW = -6, -7
 AFQ_SYS_GENERIC, AFQ_SYS_HUBBARD, AFQ_SYS_UEG = 1, 2, 3
 AFQ_PROP_HYBRID, AFQ_PROP_FORCE_BIAS, AFQ_PROP_FREE_PROJECTION, AFQ_PROP_HUBBARD_SPIN = 1, 2, 4, 8
 (F_PHI, F_WEIGHT, F_UNSCALED_WEIGHT, F_OT, F_HYBRID_ENERGY, F_PHASE, F_DETR, F_ELOC, F_GHALF, F_G,
- F_XBAR, F_XSHIFTED, F_ENERGY) = range(13)
+ F_XBAR, F_XSHIFTED, F_ENERGY, F_LOG_DETR) = range(14)
 
 _h = c_void_p
 _dp = c_void_p        # const double* / void* passed as raw addresses
@@ -43,6 +43,8 @@ SIGNATURES = {
     "afq_calc_overlap": [_h, _dp],
     "afq_propagate": [_h, _dp, c_double, c_double],
     "afq_reortho": [_h, _dp],
+    "afq_set_log_shift": [_h, c_int, c_double, c_double],
+    "afq_log_ovlp_sums": [_h, _dp],
     "afq_local_energy": [_h, _dp],
     "afq_force_bias": [_h, _dp],
     "afq_shift_fields": [_h, _dp, _dp, _dp, _dp, _dp],

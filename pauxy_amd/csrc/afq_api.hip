@@ -92,7 +92,7 @@ void free_system(afq_handle *h) {
 
 void free_walkers(afq_handle *h) {
     dev_free(h->phi); dev_free(h->phi_t); dev_free(h->phi_t2);
-    dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR);
+    dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR); dev_free(h->log_detR);
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr;
@@ -529,7 +529,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     int rc;
 #define A_(ptr, cnt) if ((rc = dev_alloc(h, &(ptr), (cnt)))) return rc;
     A_(h->phi, per * n) A_(h->phi_t, per * n) A_(h->phi_t2, per * n)
-    A_(h->weight, n) A_(h->unscaled, n) A_(h->detR, n)
+    A_(h->weight, n) A_(h->unscaled, n) A_(h->detR, n) A_(h->log_detR, n)
     A_(h->ot, n) A_(h->ehyb, n) A_(h->phase, n) A_(h->eloc, n)
     A_(h->ghalf_all, per * n * h->ndet) A_(h->ovlp_old, n) A_(h->ovlp_new, n)
     h->ghalf = h->ghalf_all + (size_t)h->cur_det * n * per;
@@ -577,6 +577,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     AFQ_HIP(h, hipMemcpy(h->weight, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
     AFQ_HIP(h, hipMemcpy(h->unscaled, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
     AFQ_HIP(h, hipMemcpy(h->detR, one.data(), sizeof(double) * nw, hipMemcpyHostToDevice));
+    AFQ_HIP(h, hipMemset(h->log_detR, 0, sizeof(double) * nw));
     AFQ_HIP(h, hipMemcpy(h->ot, one2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
     AFQ_HIP(h, hipMemcpy(h->phase, one2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
     AFQ_HIP(h, hipMemcpy(h->ehyb, zero2.data(), sizeof(cplx) * nw, hipMemcpyHostToDevice));
@@ -604,6 +605,7 @@ static int field_info(afq_handle *h, int field, void **base, size_t *bytes) {
     case AFQ_F_XBAR: *base = h->xbar; *bytes = (size_t)h->K * sizeof(cplx); break;
     case AFQ_F_XSHIFTED: *base = h->xs; *bytes = (size_t)h->K * sizeof(cplx); break;
     case AFQ_F_ENERGY: *base = h->energy; *bytes = 3 * sizeof(cplx); break;
+    case AFQ_F_LOG_DETR: *base = h->log_detR; *bytes = sizeof(double); break;
     default: AFQ_FAIL(h, AFQ_EINVAL, "unknown walker field");
     }
     if (!*base) AFQ_FAIL(h, AFQ_ESTATE, "walker field not allocated (afq_walkers_alloc / afq_greens first)");
@@ -861,6 +863,26 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
     return AFQ_OK;
 }
 
+// use_log_shift (walkers/handler.py:45,228,456-475).  The shifts are the same for every walker (walker.py:49-52 and
+// the update at handler.py:471-474), so they live on the handle; log_detR is walker state.
+int afq_set_log_shift(afq_handle *h, int on, double log_shift, double detR_shift) {
+    AFQ_API(h, "afq_set_log_shift");
+    if (!h) return AFQ_EINVAL;
+    if (on && h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "use_log_shift: single-determinant walkers only");
+    h->log_shift_on = on != 0;
+    h->log_shift = on ? log_shift : 0.0;
+    h->detR_shift = on ? detR_shift : 0.0;
+    return AFQ_OK;
+}
+
+int afq_log_ovlp_sums(afq_handle *h, double *sums3) {
+    AFQ_API(h, "afq_log_ovlp_sums");
+    if (!h || !sums3) return AFQ_EINVAL;
+    int rc = need_ready(h, false);
+    if (rc) return rc;
+    return k_log_ovlp_sums(h, sums3);
+}
+
 int afq_reortho(afq_handle *h, double *detR_out) {
     AFQ_API(h, "afq_reortho");
     if (!h) return AFQ_EINVAL;
@@ -875,6 +897,8 @@ int afq_reortho(afq_handle *h, double *detR_out) {
         if ((rc = k_scale_by_inverse(h, h->ovlp_new, h->detR))) return rc;
         h->greens_valid = true;
     }
+    // the cached overlap above needs det R itself; walker.detR / walker.ot / log_detR take the shifted one
+    if (h->log_shift_on && (rc = k_log_shift_reortho(h))) return rc;
     return copy_out(h, detR_out, h->detR, sizeof(double) * h->nw);
 }
 
@@ -1073,7 +1097,7 @@ int afq_walkers_reset_weights(afq_handle *h) {
     return k_reset_weights(h);
 }
 
-// packed walker: phi | ot, ehyb, phase, eloc (c128) | unscaled_weight, detR, weight, pad (f64)
+// packed walker: phi | ot, ehyb, phase, eloc (c128) | unscaled_weight, detR, weight, log_detR (f64)
 int afq_walker_pack_bytes(afq_handle *h, int64_t *bytes) {
     if (!h || !bytes) return AFQ_EINVAL;
     size_t b = sizeof(cplx) * ((size_t)h->M * h->nt + 4) + sizeof(double) * 4;
@@ -1089,7 +1113,8 @@ static int pack_io(afq_handle *h, int iw, char *buf, bool pack) {
     const Item items[] = {{h->phi + per * iw, per * sizeof(cplx)}, {h->ot + iw, sizeof(cplx)},
                           {h->ehyb + iw, sizeof(cplx)}, {h->phase + iw, sizeof(cplx)},
                           {h->eloc + iw, sizeof(cplx)}, {h->unscaled + iw, sizeof(double)},
-                          {h->detR + iw, sizeof(double)}, {h->weight + iw, sizeof(double)}};
+                          {h->detR + iw, sizeof(double)}, {h->weight + iw, sizeof(double)},
+                          {h->log_detR + iw, sizeof(double)}};
     size_t off = 0;
     for (const Item &it : items) {
         if (pack) AFQ_HIP(h, hipMemcpyAsync(buf + off, it.p, it.b, hipMemcpyDeviceToDevice, h->stream));
@@ -1137,7 +1162,7 @@ int afq_walkers_copy(afq_handle *h, int src, int dst) {
     const size_t per = (size_t)h->M * h->nt;
 #define C_(ptr, n) AFQ_HIP(h, hipMemcpyAsync((ptr) + (size_t)dst * (n), (ptr) + (size_t)src * (n), sizeof(*(ptr)) * (n), hipMemcpyDeviceToDevice, h->stream));
     C_(h->phi, per) C_(h->ot, 1) C_(h->ehyb, 1) C_(h->phase, 1) C_(h->eloc, 1)
-    C_(h->unscaled, 1) C_(h->detR, 1) C_(h->weight, 1)
+    C_(h->unscaled, 1) C_(h->detR, 1) C_(h->weight, 1) C_(h->log_detR, 1)
     if (h->nbp > 0) {
         C_(h->phi_old, per) C_(h->bp_hist, (size_t)h->nbp * h->K) C_(h->bp_ph, 1) C_(h->bp_cos, 1) C_(h->bp_n, 1)
     }

@@ -151,6 +151,10 @@ struct afq_handle {
     cplx *phi_t = nullptr;          // scratch [nw, M, nt] (Taylor term ping)
     cplx *phi_t2 = nullptr;         // scratch [nw, M, nt] (Taylor term pong)
     double *weight = nullptr, *unscaled = nullptr, *detR = nullptr;
+    // use_log_shift (walkers/handler.py:45,456-475): the shifts are the same for every walker, log_detR is per walker
+    double *log_detR = nullptr;     // [nw]
+    bool log_shift_on = false;
+    double log_shift = 0.0, detR_shift = 0.0;
     cplx *ot = nullptr, *ehyb = nullptr, *phase = nullptr, *eloc = nullptr;
     cplx *ghalf = nullptr;          // [nw, nt, M]
     cplx *G = nullptr;              // [nw, 2, M, M] (allocated on demand)
@@ -362,6 +366,8 @@ int k_cap_weights(afq_handle *h, double frac, double total_weight);
 int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
 int k_clone_pairs(afq_handle *h, bool with_greens);
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[w]
+int k_log_shift_reortho(afq_handle *h);                            // detR -> exp(log det R - detR_shift), log_detR += log
+int k_log_ovlp_sums(afq_handle *h, double *out3);                  // sums of |ot|, |detR|, |log_detR| (device -> host)
 int k_scale_weights(afq_handle *h, double scale);
 int k_reset_weights(afq_handle *h, bool after_comb = false);
 int k_estimates(afq_handle *h, int have_energy);

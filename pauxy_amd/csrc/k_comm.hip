@@ -101,12 +101,12 @@ afq_comm_state *cs_of(afq_handle *h) { return (afq_comm_state *)h->comm; }
     } while (0)
 
 // ---- slot layout: the walker state that has to travel, in 16-byte units ------------------------------------
-// phi | ot ehyb phase eloc | (unscaled, detR) | [ghalf | ovlp_new] | [phi_old | hist | bp_ph | (bp_cos, bp_n)]
+// phi | ot ehyb phase eloc | (unscaled, detR) (log_detR, 0) | [ghalf | ovlp_new] | [phi_old | hist | bp_ph | (bp_cos, bp_n)]
 struct SlotLayout {
     long per, hist_per;
     int with_greens, with_bp;
     __host__ __device__ long size() const {
-        long n = per + 5;
+        long n = per + 6;
         if (with_greens) n += per + 1;
         if (with_bp) n += per + hist_per + 2;
         return n;
@@ -121,7 +121,7 @@ struct PackArgs {
     cplx *buf;               // sbuf / rbuf [R][cap][slot]
     long slot;               // elements per slot (>= L.size(), fixed for the buffers)
     cplx *phi, *ot, *ehyb, *phase, *eloc, *ghalf, *ovlp_new, *phi_old, *bp_hist, *bp_ph;
-    double *unscaled, *detR, *bp_cos;
+    double *unscaled, *detR, *log_detR, *bp_cos;
     int *bp_n;
 };
 
@@ -147,13 +147,15 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
         if (PACK) {
             s[off] = a.ot[w]; s[off + 1] = a.ehyb[w]; s[off + 2] = a.phase[w]; s[off + 3] = a.eloc[w];
             s[off + 4] = cmake(a.unscaled[w], a.detR[w]);
-            long o = off + 5;
+            s[off + 5] = cmake(a.log_detR[w], 0.0);
+            long o = off + 6;
             if (a.L.with_greens) s[o++] = a.ovlp_new[w];
             if (a.L.with_bp) { s[o++] = a.bp_ph[w]; s[o++] = cmake(a.bp_cos[w], (double)a.bp_n[w]); }
         } else {
             a.ot[w] = s[off]; a.ehyb[w] = s[off + 1]; a.phase[w] = s[off + 2]; a.eloc[w] = s[off + 3];
             a.unscaled[w] = s[off + 4].x; a.detR[w] = s[off + 4].y;
-            long o = off + 5;
+            a.log_detR[w] = s[off + 5].x;
+            long o = off + 6;
             if (a.L.with_greens) a.ovlp_new[w] = s[o++];
             if (a.L.with_bp) { a.bp_ph[w] = s[o++]; a.bp_cos[w] = s[o].x; a.bp_n[w] = (int)s[o].y; ++o; }
         }
@@ -325,7 +327,7 @@ void fill_pack(afq_handle *h, PackArgs &p, bool with_greens, bool send) {
     p.buf = send ? c->sbuf : c->rbuf; p.slot = (long)c->slot;
     p.phi = h->phi; p.ot = h->ot; p.ehyb = h->ehyb; p.phase = h->phase; p.eloc = h->eloc; p.ghalf = h->ghalf;
     p.ovlp_new = h->ovlp_new; p.phi_old = h->phi_old; p.bp_hist = h->bp_hist; p.bp_ph = h->bp_ph;
-    p.unscaled = h->unscaled; p.detR = h->detR; p.bp_cos = h->bp_cos; p.bp_n = h->bp_n;
+    p.unscaled = h->unscaled; p.detR = h->detR; p.log_detR = h->log_detR; p.bp_cos = h->bp_cos; p.bp_n = h->bp_n;
 }
 
 int stage_plan_pack(afq_handle *h, double target, bool with_greens) {

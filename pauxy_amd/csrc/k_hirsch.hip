@@ -119,13 +119,17 @@ __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
 }
 
 // kinetic importance sampling (hubbard.py:163-172) after phi <- bt2 phi and the new overlap
-__global__ void hirsch_kin_weight_kernel(double *weight, cplx *ot, const cplx *ot_new, const int *alive, int nw) {
+// use_log_shift: calc_otrial applies the shift to the determinant of the INVERSE overlap (single_det.py:159), so the
+// overlap it returns is det * exp(+log_shift); `scale` carries that factor (1 when the option is off)
+__global__ void hirsch_kin_weight_kernel(double *weight, cplx *ot, const cplx *ot_new, const int *alive, int nw,
+                                         double scale) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw || !alive[w]) return;
-    const cplx ratio = cdiv(ot_new[w], ot[w]);
+    const cplx on = cscale(ot_new[w], scale);
+    const cplx ratio = cdiv(on, ot[w]);
     if (fabs(atan2(ratio.y, ratio.x)) < 0.5 * 3.14159265358979323846) {
         weight[w] *= ratio.x;
-        ot[w] = ot_new[w];
+        ot[w] = on;
     } else {
         weight[w] = 0.0;
     }
@@ -162,7 +166,7 @@ int k_hirsch_kinetic(afq_handle *h) {
     if ((rc = k_onebody(h))) return rc;
     if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;
     AFQ_LAUNCH(h, hirsch_kin_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
-                       h->ovlp_new, h->alive, h->nw);
+                       h->ovlp_new, h->alive, h->nw, h->log_shift_on ? exp(h->log_shift) : 1.0);
     AFQ_POST(h);
     return AFQ_OK;
 }

@@ -191,6 +191,9 @@ struct WeightArgs {
     // weight cap of the driver (qmc/afqmc.py:235-236) applied right behind the update; cap_frac <= 0: off
     double cap_frac, cap_total;
     const double *cap_total_dev;    // total weight of the last comb when cap_total < 0
+    // use_log_shift (walkers/single_det.py:192): walker.ot = overlap * exp(-log_shift); the ratios of a step do not
+    // see it, both of its overlaps carry the same shift.  1 when the option is off.
+    double ot_scale;
 };
 
 static WeightArgs weight_args(afq_handle *h, cplx eshift);
@@ -219,7 +222,7 @@ __device__ static void weight_update(const WeightArgs &a, const int w) {
         a.weight[w] *= magn;
         double s, c; sincos(dth, &s, &c);
         a.phase[w] = cmul(a.phase[w], cmake(c, s));
-        a.ot[w] = on;
+        a.ot[w] = cscale(on, a.ot_scale);
         return;
     }
     const cplx ratio = cdiv(on, a.ovlp_old[w]);
@@ -235,7 +238,7 @@ __device__ static void weight_update(const WeightArgs &a, const int w) {
         const double magn = exp(-0.5 * a.dt * (re + a.eloc[w].x - a.eshift.x));
         const double wfac_imag = exp(-0.5 * a.dt * (el.y + a.eloc[w].y - a.eshift.y));   // continuous.py:299
         a.eloc[w] = el;
-        a.ot[w] = on;
+        a.ot[w] = cscale(on, a.ot_scale);
         if (!isinf(magn)) {
             const double cf = fmax(0.0, cos(atan2(ratio.y, ratio.x)));
             a.weight[w] *= magn * cf;
@@ -255,7 +258,7 @@ __device__ static void weight_update(const WeightArgs &a, const int w) {
     const cplx imp = cexp_(arg);
     const double magn = hypot(imp.x, imp.y);
     a.ehyb[w] = eh;
-    a.ot[w] = on;
+    a.ot[w] = cscale(on, a.ot_scale);
     if (!isinf(magn)) {
         const double dtheta = -a.dt * eh.y - a.cfb[w].y;
         const double cf = fmax(0.0, cos(dtheta));
@@ -1002,6 +1005,7 @@ static WeightArgs weight_args(afq_handle *h, cplx eshift) {
     a.eloc = h->eloc; a.energy = h->energy;
     a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
     a.cap_frac = h->cap_frac; a.cap_total = h->cap_total; a.cap_total_dev = h->scal;
+    a.ot_scale = h->log_shift_on ? exp(-h->log_shift) : 1.0;
     return a;
 }
 
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(256) void comb_plan_kernel(double *weight, double *
 struct CloneArgs {
     long per;
     cplx *phi, *ot, *ehyb, *phase, *eloc;
-    double *unscaled, *detR;
+    double *unscaled, *detR, *log_detR;
     const int *pairs;
     const double *scal;
     // back-propagation state travels with the walker (walkers/walker.py:89-90); null when off
@@ -1270,6 +1274,7 @@ __global__ void clone_kernel(CloneArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.ot[dst] = a.ot[src]; a.ehyb[dst] = a.ehyb[src]; a.phase[dst] = a.phase[src];
         a.eloc[dst] = a.eloc[src]; a.unscaled[dst] = a.unscaled[src]; a.detR[dst] = a.detR[src];
+        a.log_detR[dst] = a.log_detR[src];
         if (a.phi_old) { a.bp_ph[dst] = a.bp_ph[src]; a.bp_cos[dst] = a.bp_cos[src]; a.bp_n[dst] = a.bp_n[src]; }
     }
 }
@@ -1277,6 +1282,54 @@ __global__ void clone_kernel(CloneArgs a) {
 __global__ void scale_by_inverse_kernel(cplx *x, const double *d, int nw) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < nw) x[w] = cmake(x[w].x / d[w], x[w].y / d[w]);
+}
+
+// use_log_shift, walkers/single_det.py:250-253 on top of the plain QR bookkeeping the re-orthogonalisation kernels
+// leave behind (detR = det R, ot /= det R, free projection: weight *= det R):
+// detR -> exp(log det R - detR_shift), ot and the free-projection weight follow, log_detR += log(detR).
+__global__ void log_shift_reortho_kernel(cplx *ot, double *detR, double *weight, double *log_detR, int nw,
+                                         double detR_shift, int fp) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const double raw = detR[w], d = exp(log(raw) - detR_shift), f = raw / d;
+    detR[w] = d;
+    ot[w] = cscale(ot[w], f);
+    if (fp) weight[w] /= f;
+    log_detR[w] += log(d);
+}
+
+int k_log_shift_reortho(afq_handle *h) {
+    AFQ_LAUNCH(h, log_shift_reortho_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->ot, h->detR,
+               h->weight, h->log_detR, h->nw, h->detR_shift, (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
+// walkers/handler.py:457-462: sums of |ot|, |detR|, |log_detR| over this rank's walkers, one work-group
+__global__ __launch_bounds__(256) void log_ovlp_sums_kernel(const cplx *ot, const double *detR, const double *log_detR,
+                                                            int nw, double *out) {
+    __shared__ double red[3][256];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int w = threadIdx.x; w < nw; w += 256) {
+        s0 += hypot(ot[w].x, ot[w].y); s1 += fabs(detR[w]); s2 += fabs(log_detR[w]);
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+int k_log_ovlp_sums(afq_handle *h, double *out3) {
+    double *tmp = (double *)h->pack_tmp;
+    AFQ_LAUNCH(h, log_ovlp_sums_kernel, dim3(1), dim3(256), 0, h->stream, h->ot, h->detR, h->log_detR, h->nw, tmp);
+    AFQ_POST(h);
+    AFQ_HIP(h, hipMemcpyAsync(out3, tmp, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    return AFQ_OK;
 }
 
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
@@ -1289,7 +1342,8 @@ int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
 int k_clone_pairs(afq_handle *h, bool with_greens) {
     CloneArgs a;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
-    a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.pairs = (const int *)h->pack_tmp; a.scal = h->scal;
+    a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.log_detR = h->log_detR;
+    a.pairs = (const int *)h->pack_tmp; a.scal = h->scal;
     a.phi_old = h->nbp > 0 ? h->phi_old : nullptr; a.bp_hist = h->bp_hist; a.bp_ph = h->bp_ph; a.bp_cos = h->bp_cos;
     a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
     a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;

@@ -213,7 +213,7 @@ class AfqDevice(object):
             L.F_DETR: ((), numpy.float64), L.F_ELOC: ((), numpy.complex128),
             L.F_GHALF: ((nt, M), numpy.complex128), L.F_G: ((2, M, M), numpy.complex128),
             L.F_XBAR: ((K,), numpy.complex128), L.F_XSHIFTED: ((K,), numpy.complex128),
-            L.F_ENERGY: ((3,), numpy.complex128),
+            L.F_ENERGY: ((3,), numpy.complex128), L.F_LOG_DETR: ((), numpy.float64),
         }[field]
 
     def set(self, field, values, first=0):
@@ -251,6 +251,16 @@ class AfqDevice(object):
     def reortho(self, fetch=True):
         out = numpy.empty(self.nw, dtype=numpy.float64) if fetch else None
         self._ck(self.lib.afq_reortho(self.h, _p(out)))
+        return out
+
+    def set_log_shift(self, on, log_shift=0.0, detR_shift=0.0):
+        """use_log_shift (walkers/handler.py:45): walker.log_shift / walker.detR_shift of every walker."""
+        self._ck(self.lib.afq_set_log_shift(self.h, int(bool(on)), float(log_shift), float(detR_shift)))
+
+    def log_ovlp_sums(self):
+        """sums of |ot|, |detR|, |log_detR| over this rank's walkers (walkers/handler.py:457-462)."""
+        out = numpy.empty(3, dtype=numpy.float64)
+        self._ck(self.lib.afq_log_ovlp_sums(self.h, _p(out)))
         return out
 
     def local_energy(self, fetch=True):

@@ -32,6 +32,7 @@ _SCALARS = {
     'phase': (L.F_PHASE, numpy.complex128),
     'detR': (L.F_DETR, numpy.float64),
     'eloc': (L.F_ELOC, numpy.complex128),
+    'log_detR': (L.F_LOG_DETR, numpy.float64),
 }
 
 
@@ -72,10 +73,6 @@ class WalkerView(object):
         object.__setattr__(self, 'field_configs', None)
         object.__setattr__(self, 'stack', None)
         object.__setattr__(self, 'alive', 1)
-        object.__setattr__(self, 'log_shift', 0.0)
-        object.__setattr__(self, 'detR_shift', 0.0)
-        object.__setattr__(self, 'log_detR', 0.0)
-        object.__setattr__(self, 'log_detR_shift', 0.0)
 
     # -- scalar attributes through the host mirror
     def __getattr__(self, name):
@@ -95,6 +92,19 @@ class WalkerView(object):
             self._h._dirty.add('ot')
         else:
             object.__setattr__(self, name, value)
+
+    # use_log_shift: the same values for every walker (walkers/walker.py:49-52, handler.py:471-474)
+    @property
+    def log_shift(self):
+        return self._h.log_shift
+
+    @property
+    def detR_shift(self):
+        return self._h.detR_shift
+
+    @property
+    def log_detR_shift(self):
+        return self._h.log_detR_shift
 
     @property
     def nup(self):
@@ -134,12 +144,12 @@ class WalkerView(object):
     # -- methods (walkers/single_det.py)
     def greens_function(self, trial):
         """single_det.py:295-321: batched for the whole population, returns this walker's det."""
-        return complex(self._h._ensure_greens()[self._i])
+        return complex(self._h._ensure_greens()[self._i] * numpy.exp(-self._h.log_shift))     # :320
 
     def calc_overlap(self, trial):
         """single_det.py:170-199."""
         self._h._flush()
-        return complex(self._h.dev.calc_overlap()[self._i])
+        return complex(self._h.dev.calc_overlap()[self._i] * numpy.exp(-self._h.log_shift))   # :192
 
     def local_energy(self, system, two_rdm=None, rchol=None, eri=None, UVT=None):
         """single_det.py:340-364 -> estimators/mixed.py:383-437."""
@@ -178,8 +188,8 @@ class Walkers(object):
         self.read_file = walker_opts.get('read_file', None)
         self.write_restart = self.write_freq > 0
         self.comm = comm
-        if self.use_log_shift:
-            raise NotImplementedError("use_log_shift is not supported")
+        self.shift_counter = 1
+        self.log_shift = self.detR_shift = self.log_detR_shift = 0.0
         if nbp is not None and nprop_tot is not None and nprop_tot != nbp:
             raise NotImplementedError("ITCF field history (nprop_tot != nbp) is not on the device path")
         self.walker_type = 'SD' if getattr(trial, 'ndets', 1) == 1 else 'MSD'     # walkers/handler.py:53-68
@@ -196,6 +206,10 @@ class Walkers(object):
         self.system, self.trial = system, trial
         self.dev.walkers_alloc(self.nwalkers)
         self.nw = self.nwalkers
+        if self.use_log_shift and self.walker_type != 'SD':
+            raise NotImplementedError("use_log_shift: single-determinant walkers only (as in the reference, "
+                                      "walkers/multi_det.py has no shifts)")
+        self.dev.set_log_shift(self.use_log_shift)
         # Population control on the device over the library-owned RCCL communicator (afq_comm_init) whenever the
         # ranks sit on GPUs: rank 0's ncclUniqueId travels over the communicator the driver was given.  The
         # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo).
@@ -406,6 +420,8 @@ class Walkers(object):
         if self.ntot_walkers == 1:
             return
         self._flush()
+        if self.use_log_shift:
+            self.update_log_ovlp(comm)
         size = 1 if comm is None else comm.size
         if size == 1 or self.device_comm:
             # single rank, or the collective of afq_comm_init: only rank 0 draws the comb uniform (handler.py:276)
@@ -428,6 +444,26 @@ class Walkers(object):
         self.set_total_weight(total)
         self.phi_version += 1
         self._invalidate()
+
+    def update_log_ovlp(self, comm):
+        """walkers/handler.py:456-475: running averages of log <|ot|>, log <|detR|>, <|log_detR|> over the global
+        population.  Three sums come back from the device (one small synchronising copy per population control,
+        which this option therefore costs), the averages go back as handle state."""
+        send = self.dev.log_ovlp_sums()
+        if comm is not None and comm.size > 1:
+            global_av = numpy.zeros(3, dtype=numpy.float64)
+            comm.Allreduce(send, global_av)
+        else:
+            global_av = send
+        log_shift = numpy.log(global_av[0] / self.ntot_walkers)
+        detR_shift = numpy.log(global_av[1] / self.ntot_walkers)
+        log_detR_shift = global_av[2] / self.ntot_walkers
+        n, nm1 = self.shift_counter, self.shift_counter - 1
+        self.log_shift = float((self.log_shift * nm1 + log_shift) / n)
+        self.log_detR_shift = float((self.log_detR_shift * nm1 + log_detR_shift) / n)
+        self.detR_shift = float((self.detR_shift * nm1 + detR_shift) / n)
+        self.shift_counter += 1
+        self.dev.set_log_shift(True, self.log_shift, self.detR_shift)
 
     def tune_exchange_capacity(self):
         """Device communicator: size the per-peer exchange slots from the largest transfer seen so far (four times that

@@ -809,7 +809,7 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
 
 
 
-def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None):
+def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None, walkers=None):
     """qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS (single-site updates, propagation/hubbard.py:12-343),
     4x4 U=4 with 7+7 electrons, UHF trial.  Every uniform the run draws (one per site per live walker, then the
     comb's) is recorded per step."""
@@ -823,6 +823,8 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
                'trial': {'name': 'UHF'},
                'estimates': {'mixed': {'energy_eval_freq': 1}},
                'propagator': prop}
+    if walkers:
+        options['walkers'] = walkers
     comm = MPI.COMM_WORLD
     afqmc = AFQMC(comm=comm, options=options)
     psi = afqmc.psi
@@ -881,6 +883,8 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     mixed.update(afqmc.system, afqmc.qmc, afqmc.trial, afqmc.psi, 0, afqmc.propagators.free_projection)
     out['final_estimates'] = mixed.estimates.copy()
     out['final_phi'] = numpy.array([w.phi for w in psi.walkers])
+    out['final_log_shift'] = numpy.array([w.log_shift for w in psi.walkers])
+    out['final_detR_shift'] = numpy.array([w.detR_shift for w in psi.walkers])
     if pin is not None:
         assert abs(out['final_estimates'][2].real - pin) < 1e-8, out['final_estimates'][2]
     if mean_pin is not None:
@@ -966,6 +970,11 @@ if __name__ == '__main__':
         make_traj_bp_ueg()
         make_traj_mixed_rdm()
         make_traj_log_shift()
+        # discrete fields + use_log_shift: calc_otrial shifts the determinant of the inverse overlap (single_det.py:159)
+        make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_logshift':
+        make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'msd':
         make_msd_ops()
@@ -995,6 +1004,7 @@ if __name__ == '__main__':
     make_traj_bp_ueg()
     make_traj_mixed_rdm()
     make_traj_log_shift()
+    make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})
     # (evaluate_energy: the reference raises TypeError at back_propagation.py:160 -- local_energy() has no
     #  'opt' keyword -- so there is no reference output to record for back-propagated energies)
     for f in sorted(os.listdir(HERE)):

@@ -44,13 +44,15 @@ class Replay(object):
         return next(self.r)
 
 
-def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None, batched=False):
+def replay(d, system, trial, prop_opts, monkeypatch, est_extra=None, out=None, batched=False, walker_opts=None):
     options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
                        'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
                        'num_walkers': d['phi0'].shape[0]},
                'propagator': prop_opts,
                'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
     options['estimators'].update(est_extra or {})
+    if walker_opts:
+        options['walkers'] = walker_opts
     afqmc = AFQMC(options=options, system=system, trial=trial)
     close(afqmc.propagators.propagator.BH1, d['BH1'], 1e-12)
     close(afqmc.propagators.propagator.mf_shift, d['mf_shift'], 1e-12)
@@ -245,7 +247,23 @@ def test_traj_mixed_one_rdm(golden, monkeypatch):
         close(numpy.array(out['afqmc'].estimators.estimators['mixed'].one_rdm), d['mixed_one_rdm'])
 
 
-def run_hirsch(golden, monkeypatch, name, basename=None, batched=False):
+def test_traj_use_log_shift(golden, monkeypatch):
+    """walkers: {use_log_shift: true} (walkers/handler.py:228,456-475): shifted walker.ot / detR, running averages
+    across population controls; per-walker and batched loops."""
+    d = golden('traj_hubbard_logshift.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    for batched in (False, True):
+        out = {}
+        replay(d, s, t, {'hubbard_stratonovich': 'continuous'}, monkeypatch, out=out, batched=batched,
+               walker_opts={'use_log_shift': True})
+        psi = out['afqmc'].psi
+        assert psi.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-9)
+        assert psi.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-9)
+        assert psi.walkers[3].log_shift == psi.log_shift
+
+
+def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -260,6 +278,8 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False):
                'estimators': {'mixed': {'energy_eval_freq': int(d['energy_eval_freq']), 'verbose': False}}}
     if basename is not None:
         options['estimators']['basename'] = basename
+    if walker_opts:
+        options['walkers'] = walker_opts
     afqmc = AFQMC(options=options, system=s, trial=t)
     close(afqmc.propagators.bt2, d['bt2'], 1e-12)
     stream = iter(d['u'])
@@ -283,6 +303,9 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False):
     mixed = afqmc.estimators.estimators['mixed']
     close(numpy.array(mixed.blocks)[:, 1:10], d['blocks'][:, 1:10])
     close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'])
+    if walker_opts and walker_opts.get('use_log_shift'):
+        assert afqmc.psi.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-9)
+        assert afqmc.psi.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-9)
     mixed.update(s, afqmc.qmc, t, afqmc.psi, 0, False)
     close(mixed.estimates[:9], d['final_estimates'][:9])
     est = mixed.estimates.copy()
@@ -296,6 +319,14 @@ def test_traj_hubbard_hirsch(golden, monkeypatch, tmp_path):
     est = run_hirsch(golden, monkeypatch, 'traj_hubbard_hirsch.npz', str(tmp_path / 'estimates'))
     assert est[2].real == pytest.approx(-152.68468568462666, rel=1e-8)
     assert mean_etotal(str(tmp_path / 'estimates.0.h5')) == pytest.approx(-14.974806533852874, rel=1e-8)   # :143
+
+
+def test_traj_hirsch_use_log_shift(golden, monkeypatch):
+    """Discrete fields with use_log_shift (the shift enters calc_otrial with the opposite sign, single_det.py:159,
+    and a change of it shows in the next kinetic importance-sampling ratio); per-walker and batched loops."""
+    for batched in (False, True):
+        run_hirsch(golden, monkeypatch, 'traj_hirsch_logshift.npz', batched=batched,
+                   walker_opts={'use_log_shift': True})
 
 
 def test_traj_hubbard_hirsch_charge(golden, monkeypatch):

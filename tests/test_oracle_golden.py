@@ -329,7 +329,29 @@ def test_mixed_one_rdm(golden):
     close(numpy.array(rdm), d['mixed_one_rdm'], 1e-9)
 
 
-def run_hirsch(d):
+def test_use_log_shift(golden):
+    """walkers/handler.py:228,456-475 + single_det.py:159,192,250-253,320 (use_log_shift: True): the weights do not
+    see the shift on the continuous path (both overlaps of a step carry the same one), walker.ot and the
+    overlap column of the estimates do."""
+    d = golden('traj_hubbard_logshift.npz')
+    m = hubbard_model(d, '', 'hubbard')
+    nw = d['phi0'].shape[0]
+    walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
+    xi, r = d['xi'], d['r']
+    rec = []
+    blocks = ref.run_afqmc(m, walkers, lambda s, w: xi[s - 1, w], lambda s: r[s - 1], int(d['nsteps']),
+                           int(d['nblocks']), nstblz=int(d['nstblz']), npop_control=int(d['npop_control']),
+                           energy_eval_freq=int(d['energy_eval_freq']), record=rec, use_log_shift=True)
+    close(numpy.array([x['weight'] for x in rec]), d['weight'], 1e-9)
+    close(numpy.array([x['ot'] for x in rec]), d['ot'], 1e-9)
+    close(numpy.array(blocks)[:, :9], d['blocks'][:, 1:10], 1e-9)
+    assert m.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-10)
+    assert m.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-10)
+    assert abs(m.log_shift) > 0.5          # the option does something in this run
+    assert numpy.all(d['final_log_shift'] == d['final_log_shift'][0])
+
+
+def run_hirsch(d, use_log_shift=False):
     na, nb = [int(x) for x in d['nelec']]
     m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
     close(m.bt2, d['bt2'])
@@ -344,7 +366,10 @@ def run_hirsch(d):
     rec = []
     blocks = ref.run_afqmc(m, walkers, None, None, int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
                            npop_control=int(d['npop_control']), energy_eval_freq=int(d['energy_eval_freq']),
-                           record=rec, uniform_source=usrc, hybrid=False)
+                           record=rec, uniform_source=usrc, hybrid=False, use_log_shift=use_log_shift)
+    if use_log_shift:
+        assert m.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-10)
+        assert m.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-10)
     close(numpy.array([x['weight'] for x in rec]), d['weight'], 1e-9)
     close(numpy.array([x['ot'] for x in rec]), d['ot'], 1e-9)
     pix = numpy.array([x['parent_ix'] for x in rec if x['parent_ix'] is not None])
@@ -355,6 +380,17 @@ def run_hirsch(d):
     ref.mixed_update(m, est, walkers, 0, 1)
     close(est[:9], d['final_estimates'][:9], 1e-9)
     return est, numpy.array(blocks)
+
+
+def test_traj_hirsch_use_log_shift(golden):
+    """Discrete fields with use_log_shift: calc_otrial shifts the determinant of the INVERSE overlap
+    (single_det.py:159), so a change of the shift at a population control shows in the next kinetic
+    importance-sampling ratio (hubbard.py:163-164) and therefore in the weights."""
+    d = golden('traj_hirsch_logshift.npz')
+    run_hirsch(d, use_log_shift=True)
+    plain = golden('traj_hubbard_hirsch.npz')
+    n = d['weight'].shape[0]
+    assert numpy.max(numpy.abs(d['unscaled_weight'] - plain['unscaled_weight'][:n])) > 1e-3   # the option changes the weights
 
 
 def test_traj_hubbard_hirsch(golden):

@@ -18,7 +18,7 @@ import torch.multiprocessing as mp
 from oracle import afqmc_ref as ref
 from pauxy_amd import _lib as L
 from pauxy_amd.comm import TorchComm, FakeComm
-from pauxy_amd.walkers.handler import pop_control_distributed, comb_parent_ix, comb_pairs
+from pauxy_amd.walkers.handler import pop_control_distributed, comb_parent_ix, comb_pairs, Walkers
 
 NW, M, NE = 4, 3, 2
 
@@ -73,6 +73,26 @@ class NumpyDevice(object):
     def sync(self):
         pass
 
+    # use_log_shift surface (afq_log_ovlp_sums / afq_set_log_shift)
+    def log_ovlp_sums(self):
+        return numpy.array([numpy.abs(self.ot).sum(), numpy.abs(self.detR).sum(), numpy.abs(self.log_detR).sum()])
+
+    def set_log_shift(self, on, log_shift=0.0, detR_shift=0.0):
+        self.shifts = (bool(on), log_shift, detR_shift)
+
+
+class ShiftHost(object):
+    """The attributes Walkers.update_log_ovlp touches."""
+
+    def __init__(self, dev, ntot):
+        self.dev, self.ntot_walkers, self.shift_counter = dev, ntot, 1
+        self.log_shift = self.detR_shift = self.log_detR_shift = 0.0
+
+
+def shift_population(k):
+    rng = numpy.random.RandomState(40 + k)
+    return (rng.rand(2 * NW) * numpy.exp(1j * rng.rand(2 * NW)) * 1e-3, rng.rand(2 * NW) * 5.0, rng.randn(2 * NW))
+
 
 def population(seed=5):
     rng = numpy.random.RandomState(seed)
@@ -103,7 +123,16 @@ def _work(rank, out):
     est = numpy.array([dev.unscaled.sum(), 0.0], dtype=numpy.complex128)
     red = numpy.zeros_like(est)
     comm.Reduce(est, red, root=0)
-    out.put((rank, dev.phi, dev.weight, dev.unscaled, total, pix, red))
+    # walkers/handler.py:456-475 over two ranks: two population controls' worth of running averages
+    host = ShiftHost(dev, 2 * NW)
+    for k in range(2):
+        ot, detR, log_detR = shift_population(k)
+        sl = slice(rank * NW, (rank + 1) * NW)
+        dev.ot, dev.detR, dev.log_detR = ot[sl], detR[sl], log_detR[sl]
+        Walkers.update_log_ovlp(host, comm)
+    assert dev.shifts == (True, host.log_shift, host.detR_shift)
+    out.put((rank, dev.phi, dev.weight, dev.unscaled, total, pix, red,
+             (host.log_shift, host.detR_shift, host.log_detR_shift, host.shift_counter)))
 
 
 def free_port():
@@ -123,7 +152,7 @@ def test_two_rank_comb_matches_single_rank_oracle():
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
     for rr in res:
-        assert len(rr) == 7, rr
+        assert len(rr) == 8, rr
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -144,6 +173,18 @@ def test_two_rank_comb_matches_single_rank_oracle():
         assert rr[4] == pytest.approx(w.sum(), rel=1e-15)
         assert numpy.array_equal(rr[5], pix)
         assert rr[6][0].real == pytest.approx(sum(x['unscaled_weight'] for x in walkers), rel=1e-14)
+    # use_log_shift: both ranks hold the single-rank oracle's running averages of the combined population
+    class Model(object):
+        pass
+    m = Model()
+    for k in range(2):
+        ot, detR, log_detR = shift_population(k)
+        ref.update_log_ovlp(m, [dict(ot=ot[i], detR=detR[i], log_detR=log_detR[i]) for i in range(2 * NW)])
+    for rr in res:
+        assert rr[7][0] == pytest.approx(m.log_shift, rel=1e-13)
+        assert rr[7][1] == pytest.approx(m.detR_shift, rel=1e-13)
+        assert rr[7][2] == pytest.approx(m.log_detR_shift, rel=1e-13)
+        assert rr[7][3] == 3
     # cross-rank clone really happened in this case
     assert any(c // NW != k // NW for c, k in comb_pairs(pix))
 
