@@ -143,7 +143,12 @@ int afq_local_energy_full_g(afq_handle *h, const double *G, int n, double *E_out
  * the phase / cosine factors of the weight update (up to nbp steps; the history,
  * phi_old and the factors travel with the walker through the comb, afq_walkers_copy
  * and afq_walker_pack / unpack).  Call after afq_walkers_alloc and afq_set_propagator;
- * phi_old starts as the current phi.                                            */
+ * phi_old starts as the current phi.
+ * Hubbard systems: with the discrete Hirsch propagator the kernel of afq_hirsch_two_body / afq_propagate_hirsch
+ * records the chosen field of every site as it goes (FieldConfig.push, walkers/stack.py:35-49, called at
+ * propagation/hubbard.py:215-216; no weight factors on this path), and afq_bp_update applies
+ * B(x)^H = (BT2 diag(auxf[x, spin]) BT2)^H of propagation/hubbard.py:568-600,634-672; the continuous Hubbard
+ * propagator is refused (the reference would read its fields as 0 / 1 indices, estimators/back_propagation.py:125). */
 int afq_bp_configure(afq_handle *h, int nbp);
 /* FieldConfig.step of every walker: int32[nw]                                   */
 int afq_bp_steps(afq_handle *h, int32_t *steps_out);

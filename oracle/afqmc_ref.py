@@ -509,6 +509,8 @@ def hirsch_two_body_single_site(model, w, uniform):
             w['phi'][i, na:] = w['phi'][i, na:] + vtdown
             w['ot'] = 2 * w['ot'] * probs[xi]                                      # single_det.py:213
             fields.append(xi)
+            if 'bp' in w:
+                bp_push_field(w['bp'], xi)                                        # hubbard.py:215-216
             w['inv_ovlp'][0] = sherman_morrison(w['inv_ovlp'][0], model.psi[i, :na].conj(), vtup)
             w['inv_ovlp'][1] = sherman_morrison(w['inv_ovlp'][1], model.psi[i, na:].conj(), vtdown)
         else:
@@ -538,7 +540,16 @@ def bp_new(nfields, nbp):
     """walkers/stack.py:19-32 (FieldConfig with nprop_tot == nbp)."""
     return dict(configs=numpy.zeros((nbp, nfields), dtype=numpy.complex128),
                 cos_fac=numpy.zeros(nbp), weight_fac=numpy.zeros(nbp, dtype=numpy.complex128),
-                step=0, nbp=nbp)
+                step=0, nbp=nbp, ib=0)
+
+
+def bp_push_field(fc, xi):
+    """walkers/stack.py:35-49 (FieldConfig.push, the discrete propagator's one-field-at-a-time variant): neither the
+    weight nor the cosine factors are recorded on this path."""
+    fc['configs'][fc['step'], fc['ib']] = xi
+    fc['ib'] = (fc['ib'] + 1) % fc['configs'].shape[1]
+    if fc['ib'] == 0:
+        fc['step'] += 1
 
 
 def bp_push(fc, config, wfac):
@@ -551,7 +562,7 @@ def bp_push(fc, config, wfac):
 
 def bp_copy(fc):
     return dict(configs=fc['configs'].copy(), cos_fac=fc['cos_fac'].copy(), weight_fac=fc['weight_fac'].copy(),
-                step=fc['step'], nbp=fc['nbp'])
+                step=fc['step'], nbp=fc['nbp'], ib=fc.get('ib', 0))
 
 
 def exponentiate_matrix(Mx, order=6):
@@ -588,6 +599,24 @@ def back_propagate_generic(phi, configs, hs_pot, M, na, nstblz, BT2, dt, vhs=Non
     return phi
 
 
+def back_propagate_hirsch(phi, configs, U, na, nstblz, BT2, dt):
+    """propagation/hubbard.py:568-600,634-672: B(x)^H = (BT2 diag(auxf[x, spin]) BT2)^H per recorded configuration, most
+    recent first, with the SPIN decomposition's auxf whatever the propagator used (:589-591)."""
+    gamma = numpy.arccosh(numpy.exp(0.5 * dt * U))
+    auxf = numpy.array([[numpy.exp(gamma), numpy.exp(-gamma)], [numpy.exp(-gamma), numpy.exp(gamma)]])
+    for (i, c) in enumerate(configs[::-1]):
+        bv_up = numpy.array([auxf[int(xi.real), 0] for xi in c])
+        bv_down = numpy.array([auxf[int(xi.real), 1] for xi in c])
+        Bup = BT2[0].dot(numpy.einsum('i,ij->ij', bv_up, BT2[0]))
+        Bdown = BT2[1].dot(numpy.einsum('i,ij->ij', bv_down, BT2[1]))
+        phi[:, :na] = Bup.conj().T.dot(phi[:, :na])
+        phi[:, na:] = Bdown.conj().T.dot(phi[:, na:])
+        if i != 0 and i % nstblz == 0:
+            phi[:, :na], _ = reortho_qr(phi[:, :na])
+            phi[:, na:], _ = reortho_qr(phi[:, na:])
+    return phi
+
+
 def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval_energy=False, reset=True):
     """estimators/back_propagation.py:127-226 (update_uhf, one_rdm only).  ``est`` is
     [3 energies, denominator, G.flatten()]; called when the field buffers hold one of the split lengths; at the last
@@ -599,8 +628,11 @@ def bp_update(model, walkers, nstblz, est, restore_weights=None, init=None, eval
     for w in walkers:
         fc = w['bp']
         phi_bp = numpy.array(model.psi if init is None else init, dtype=numpy.complex128, copy=True)
-        back_propagate_generic(phi_bp, fc['configs'][:fc['step']], getattr(model, 'hs_pot', None), M, na, nstblz,
-                               model.BH1, model.dt, vhs=vhs)
+        if model.kind == 'hubbard_hirsch':
+            back_propagate_hirsch(phi_bp, fc['configs'][:fc['step']], model.U, na, nstblz, model.bt2, model.dt)
+        else:
+            back_propagate_generic(phi_bp, fc['configs'][:fc['step']], getattr(model, 'hs_pot', None), M, na, nstblz,
+                                   model.BH1, model.dt, vhs=vhs)
         G = numpy.array([gab(phi_bp[:, :na], w['phi_old'][:, :na]).T,
                          gab(phi_bp[:, na:], w['phi_old'][:, na:]).T])
         if restore_weights is not None:

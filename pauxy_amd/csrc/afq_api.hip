@@ -1438,8 +1438,9 @@ int afq_bp_configure(afq_handle *h, int nbp) {
     int rc = need_ready(h, true);
     if (rc) return rc;
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation needs a single-determinant trial");
-    if (h->hirsch || h->kind == AFQ_SYS_HUBBARD)
-        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation: generic and UEG systems (the reference's Hubbard variant is for the discrete fields)");
+    if (h->kind == AFQ_SYS_HUBBARD && !h->hirsch)
+        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "back-propagation of a Hubbard system: discrete fields only (the reference's propagation/hubbard.py:568-672 reads the history as 0 / 1 fields)");
+    if (h->hirsch && h->K != h->M) AFQ_FAIL(h, AFQ_ESTATE, "discrete fields: one per site expected");
     if (h->flags & AFQ_PROP_FREE_PROJECTION) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "no field history in free projection");
     const size_t per = (size_t)h->M * h->nt, n = h->nw;
     if ((rc = dev_alloc(h, &h->bp_hist, n * nbp * h->K))) return rc;
@@ -1455,7 +1456,7 @@ int afq_bp_configure(afq_handle *h, int nbp) {
     h->nbp = nbp;
     AFQ_HIP(h, hipMemsetAsync(h->bp_hist, 0, sizeof(cplx) * n * nbp * h->K, h->stream));
     AFQ_HIP(h, hipMemsetAsync(h->bp_flag, 0, sizeof(int) * n, h->stream));
-    if ((rc = k_bp_reset(h))) return rc;
+    if ((rc = k_bp_reset(h, true))) return rc;
     if ((rc = k_conj_transpose(h, h->BH1, h->BH1dag))) return rc;
     // walkers/walker.py:43: phi_old starts as the walker itself
     AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
@@ -1466,7 +1467,10 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
     if (!h || !steps_out) return AFQ_EINVAL;
     if (!h->nbp) AFQ_FAIL(h, AFQ_ESTATE, "back-propagation is not configured");
     hipSetDevice(h->device);
-    return copy_out(h, steps_out, h->bp_n, sizeof(int) * h->nw);
+    int rc = copy_out(h, steps_out, h->bp_n, sizeof(int) * h->nw);
+    // discrete fields are recorded one at a time: FieldConfig.step counts completed configurations
+    if (!rc && h->hirsch) for (int i = 0; i < h->nw; ++i) steps_out[i] /= h->M;
+    return rc;
 }
 
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
@@ -1477,6 +1481,8 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     int rc = need_ready(h, true);
     if (rc) return rc;
     if (!h->nbp) AFQ_FAIL(h, AFQ_ESTATE, "back-propagation is not configured");
+    if (h->hirsch && restore_weights)
+        AFQ_FAIL(h, AFQ_EUNSUPPORTED, "restore_weights with discrete fields: FieldConfig.push records no weight factors (walkers/stack.py:35-49)");
     const size_t per = (size_t)h->M * h->nt, n = h->nw;
     // trial (or initial) determinant for every walker; the second half of phi_bp is upload scratch first
     AFQ_HIP(h, hipMemcpyAsync(h->phi_bp + per * n, phi_bp0, sizeof(cplx) * per, hipMemcpyHostToDevice, h->stream));
@@ -1494,6 +1500,11 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     const bool fused = k_prop_fused_supported(h);
     rc = AFQ_OK;
     for (int i = 0; i < h->nbp && !rc; ++i) {                       // propagation/generic.py:279-288
+        if (h->hirsch) {                                            // propagation/hubbard.py:661-671
+            rc = k_bp_hirsch_step(h, i);
+            if (!rc && i != 0 && i % nstblz == 0) rc = k_reortho(h);
+            continue;
+        }
         if ((rc = k_bp_fields(h, i))) break;
         h->vhs_upper = fused && h->hs_sym && !h->no_vhs_upper;
         rc = build_vhs(h);
@@ -1529,7 +1540,7 @@ int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_
     if ((rc = k_bp_accumulate(h, restore_weights, eval_energy))) return rc;
     if (reset) {
         // FieldConfig.reset + Walkers.copy_historic_wfn (walkers/stack.py:124-127, handler.py:200-203)
-        if ((rc = k_bp_reset(h))) return rc;
+        if ((rc = k_bp_reset(h, false))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->phi_old, h->phi, sizeof(cplx) * per * n, hipMemcpyDeviceToDevice, h->stream));
     }
     if ((rc = k_alive(h))) return rc;

@@ -356,7 +356,8 @@ int k_bp_init(afq_handle *h, const cplx *phi0_dev);
 int k_conj_copy(afq_handle *h, const cplx *src, cplx *dst, long n);
 int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At);
 int k_bp_accumulate(afq_handle *h, int restore, int with_energy);
-int k_bp_reset(afq_handle *h);
+int k_bp_reset(afq_handle *h, bool first);
+int k_bp_hirsch_step(afq_handle *h, int i);                 // B(x)^H of the i-th most recent discrete configuration
 int k_xbar_fields(afq_handle *h);                           // xbar + clip + shift in one launch
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch

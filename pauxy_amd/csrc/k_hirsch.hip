@@ -21,6 +21,11 @@ struct HirschArgs {
     const int *alive;
     int inv_in_lds;
     cplx delta[2][2], wfac[2];
+    // back-propagation history (FieldConfig.push, walkers/stack.py:35-49): one field at a time, bp_n = fields
+    // recorded so far = step * M + ib; null when off
+    cplx *bp_hist;
+    int *bp_n;
+    long hist_cap;                   // nbp * M
 };
 
 __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
@@ -38,6 +43,7 @@ __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
     double weight = a.weight[w];
     cplx ot = a.ot[w];
     int used = 0;
+    long pos = a.bp_hist ? a.bp_n[w] : 0;
     __syncthreads();
     for (int i = 0; i < M; ++i) {
         // q_k = sum_l O^-1[k][l] phi[i,l]: one wave per row k, lanes over l;
@@ -90,6 +96,10 @@ __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
                 ot = cmul(cmake(2.0 * ot.x, 2.0 * ot.y), probs[xi]);                 // single_det.py:213
                 xi_s = xi; stop_s = 0;
                 a.fields[(long)w * M + i] = xi;
+                if (a.bp_hist) {                                                      // hubbard.py:215-216
+                    if (pos < a.hist_cap) a.bp_hist[(long)w * a.hist_cap + pos] = cmake((double)xi, 0.0);
+                    ++pos;
+                }
                 // Sherman-Morrison denominators 1 + vt . (inv u) with vt = phi[i,:] delta
                 for (int s = 0; s < 2; ++s) den_s[s] = cadd(cmake(1.0, 0.0), cmul(a.delta[xi][s], den_s[s]));
             } else {
@@ -115,7 +125,10 @@ __global__ __launch_bounds__(256) void hirsch_two_body_kernel(HirschArgs a) {
         }
         __syncthreads();
     }
-    if (tid == 0) { a.weight[w] = weight; a.ot[w] = ot; a.used[w] = used; }
+    if (tid == 0) {
+        a.weight[w] = weight; a.ot[w] = ot; a.used[w] = used;
+        if (a.bp_hist) a.bp_n[w] = (int)(pos < a.hist_cap ? pos : a.hist_cap);
+    }
 }
 
 // kinetic importance sampling (hubbard.py:163-172) after phi <- bt2 phi and the new overlap
@@ -182,6 +195,7 @@ int k_hirsch_two_body(afq_handle *h) {
     a.phi = h->phi; a.psi = h->psi; a.oinv = h->hs_oinv; a.weight = h->weight; a.ot = h->ot; a.u = h->hs_u;
     a.fields = h->hs_fields; a.used = h->hs_used; a.alive = h->alive;
     for (int x = 0; x < 2; ++x) { a.wfac[x] = h->hs_wfac[x]; for (int s = 0; s < 2; ++s) a.delta[x][s] = h->hs_delta[x][s]; }
+    a.bp_hist = h->nbp > 0 ? h->bp_hist : nullptr; a.bp_n = h->bp_n; a.hist_cap = (long)h->nbp * h->M;
     if (nmax > 128) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: N <= 128 per spin");
     size_t lds = sizeof(cplx) * 2 * (size_t)nmax * nmax;
     a.inv_in_lds = lds <= 150 * 1024;
@@ -198,4 +212,41 @@ int k_hirsch_eshift(afq_handle *h, double fac) {
                        h->nw, fac);
     AFQ_POST(h);
     return AFQ_OK;
+}
+
+// ---- back-propagation of the discrete fields (propagation/hubbard.py:568-600,634-672) -------------------------
+// B(x)^H = BT2^H diag(auxf[x_j, spin]) BT2^H with the SPIN decomposition's real auxf = exp(+-gamma),
+// gamma = arccosh(exp(dt U / 2)), whatever decomposition the propagator used (:589-591).
+__global__ void bp_hirsch_alive_kernel(const int *bp_n, int *alive, int nw, int K, int i) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) alive[w] = i < bp_n[w] / K ? 1 : 0;
+}
+
+__global__ void bp_hirsch_scale_kernel(const cplx *hist, const int *bp_n, cplx *phi, int M, int nt, int na, int nbp,
+                                       int i, double eg, double emg) {
+    const int w = blockIdx.x;
+    const int n = bp_n[w] / M;
+    if (i >= n) return;
+    const cplx *row = hist + ((long)w * nbp + (n - 1 - i)) * M;
+    cplx *p = phi + (long)w * M * nt;
+    for (int e = threadIdx.x; e < M * nt; e += blockDim.x) {
+        const int j = e / nt, c = e % nt;
+        const int x = (int)row[j].x;                             // int(xi.real), :590
+        const bool up = c < na;
+        const double f = (x == 0) == up ? eg : emg;             // auxf[0] = (e^g, e^-g), auxf[1] = (e^-g, e^g)
+        p[e] = cscale(p[e], f);
+    }
+}
+
+int k_bp_hirsch_step(afq_handle *h, int i) {
+    AFQ_LAUNCH(h, bp_hirsch_alive_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->bp_n, h->alive,
+               h->nw, h->M, i);
+    AFQ_POST(h);
+    int rc = k_onebody(h);                                       // BT2^H (h->BH1 points at the adjoint here)
+    if (rc) return rc;
+    const double g = acosh(exp(0.5 * h->dt * h->U));
+    AFQ_LAUNCH(h, bp_hirsch_scale_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->bp_hist, h->bp_n, h->phi, h->M,
+               h->nt, h->na, h->nbp, i, exp(g), exp(-g));
+    AFQ_POST(h);
+    return k_onebody(h);
 }

@@ -932,9 +932,11 @@ __global__ void bp_accumulate_kernel(const cplx *G, const double *weight, const 
     else est[4 + e] = cadd(est[4 + e], acc);
 }
 
-__global__ void bp_reset_kernel(int *bp_n, double *bp_cos, cplx *bp_ph, int nw) {
+// keep_mod > 0 (discrete fields, bp_n counts single fields): FieldConfig.reset zeroes `step` but not the position
+// `ib` inside an unfinished configuration (walkers/stack.py:124-127)
+__global__ void bp_reset_kernel(int *bp_n, double *bp_cos, cplx *bp_ph, int nw, int keep_mod) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nw) { bp_n[w] = 0; bp_cos[w] = 1.0; bp_ph[w] = cmake(1.0, 0.0); }
+    if (w < nw) { bp_n[w] = keep_mod > 0 ? bp_n[w] % keep_mod : 0; bp_cos[w] = 1.0; bp_ph[w] = cmake(1.0, 0.0); }
 }
 
 int k_bp_push(afq_handle *h) {
@@ -981,9 +983,9 @@ int k_bp_accumulate(afq_handle *h, int restore, int with_energy) {
     return AFQ_OK;
 }
 
-int k_bp_reset(afq_handle *h) {
+int k_bp_reset(afq_handle *h, bool first) {
     AFQ_LAUNCH(h, bp_reset_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->bp_n, h->bp_cos,
-                       h->bp_ph, h->nw);
+                       h->bp_ph, h->nw, (h->hirsch && !first) ? h->K : 0);
     AFQ_POST(h);
     return AFQ_OK;
 }

@@ -1,7 +1,7 @@
 """Back-propagated estimator on the device, behind PAUXY's ``BackPropagation`` surface.
 
 Mirrors pauxy/estimators/back_propagation.py:63-326 for RHF/UHF-type single-determinant
-trials on a Generic system: same constructor signature and attributes (``tau_bp``,
+trials on a Generic, UEG or (discrete-field) Hubbard system: same constructor signature and attributes (``tau_bp``,
 ``nmax``, ``splits``, ``calc_one_rdm``, ``restore_weights``, ``init_walker``), same
 ``update`` / ``print_step`` / ``zero`` methods.  The field history (walkers/stack.py
 FieldConfig), ``phi_old`` and the back-propagation itself live on the device
@@ -30,9 +30,13 @@ class BackPropagation(object):
         self.eval_energy = bp.get('evaluate_energy', False)
         self.eval_ekt = bp.get('evaluate_ekt', False)
         self.restore_weights = bp.get('restore_weights', None)
-        if system.name not in ("Generic", "UEG") or getattr(trial, 'ndets', 1) != 1:
-            # back_propagation.py:117-124: the reference's Hubbard variant back-propagates the DISCRETE fields
-            raise NotImplementedError("device back-propagation: Generic or UEG system, single-determinant trial")
+        if system.name not in ("Generic", "UEG", "Hubbard") or getattr(trial, 'ndets', 1) != 1:
+            raise NotImplementedError("device back-propagation: Generic, UEG or Hubbard system, single-determinant trial")
+        if system.name == "Hubbard" and self.restore_weights is not None:
+            # back_propagation.py:117-125: the Hubbard variant back-propagates the DISCRETE fields, which are recorded
+            # without weight factors (hubbard.py:215-216, walkers/stack.py:35-49); afq_bp_configure refuses the
+            # continuous Hubbard propagator
+            raise NotImplementedError("restore_weights with the discrete Hubbard fields")
         if self.calc_two_rdm is not None or self.eval_ekt:
             raise NotImplementedError("device back-propagation: one-body RDM and energies; no two_rdm / EKT")
         if self.eval_energy and system.name != "Generic":

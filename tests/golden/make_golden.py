@@ -809,7 +809,8 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
 
 
 
-def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None, walkers=None):
+def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None, walkers=None,
+                     bp=None):
     """qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS (single-site updates, propagation/hubbard.py:12-343),
     4x4 U=4 with 7+7 electrons, UHF trial.  Every uniform the run draws (one per site per live walker, then the
     comb's) is recorded per step."""
@@ -825,6 +826,8 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
                'propagator': prop}
     if walkers:
         options['walkers'] = walkers
+    if bp:
+        options['estimates']['back_propagated'] = bp
     comm = MPI.COMM_WORLD
     afqmc = AFQMC(comm=comm, options=options)
     psi = afqmc.psi
@@ -883,6 +886,14 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     mixed.update(afqmc.system, afqmc.qmc, afqmc.trial, afqmc.psi, 0, afqmc.propagators.free_projection)
     out['final_estimates'] = mixed.estimates.copy()
     out['final_phi'] = numpy.array([w.phi for w in psi.walkers])
+    if bp:
+        nbp = afqmc.estimators.nbp
+        out['nbp'] = nbp
+        dk = sorted((k for k in store if k.startswith('back_propagated/denominator_%d/' % nbp)), key=lambda k: int(k.rsplit('/', 1)[1]))
+        rk = sorted((k for k in store if k.startswith('back_propagated/one_rdm_%d/' % nbp)), key=lambda k: int(k.rsplit('/', 1)[1]))
+        assert len(dk) == len(rk) and len(dk) > 0
+        out['bp_denominator'] = numpy.array([store[k] for k in dk]).reshape(len(dk))
+        out['bp_one_rdm'] = numpy.array([store[k] for k in rk])
     out['final_log_shift'] = numpy.array([w.log_shift for w in psi.walkers])
     out['final_detR_shift'] = numpy.array([w.detR_shift for w in psi.walkers])
     if pin is not None:
@@ -972,6 +983,9 @@ if __name__ == '__main__':
         make_traj_log_shift()
         # discrete fields + use_log_shift: calc_otrial shifts the determinant of the inverse overlap (single_det.py:159)
         make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_bp':
+        make_traj_hirsch('traj_hirsch_bp.npz', blocks=4, bp={'tau_bp': 0.04, 'one_rdm': True})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_logshift':
         make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})

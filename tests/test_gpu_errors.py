@@ -75,3 +75,32 @@ def test_unsupported_sizes():
         dev.propagate(numpy.zeros((2, M)), 0.0)
     assert e.value.code == -2
     dev.close()
+
+
+def test_back_propagation_hubbard_needs_the_discrete_fields():
+    """estimators/back_propagation.py:117-125: for a Hubbard system the reference back-propagates with
+    propagation/hubbard.py:568-672, which reads the history as 0 / 1 fields; a continuous propagator is refused, and
+    so are restored weights with the discrete one (FieldConfig.push records no factors, walkers/stack.py:35-49)."""
+    s = systems.Hubbard(4, 4, 7, 7, 4.0)
+    M = 16
+    q = numpy.linalg.qr(numpy.random.RandomState(2).rand(M, 7))[0]
+    psi = numpy.hstack([q, q]).astype(complex)
+    dev = AfqDevice(0)
+    dev.set_system_hubbard(s.T.astype(complex), 4.0, 7, 7)
+    dev.set_trial(psi)
+    dev.walkers_alloc(4)
+    dev.set(L.F_PHI, numpy.array([psi] * 4))
+    eye = numpy.array([numpy.eye(M), numpy.eye(M)], dtype=complex)
+    dev.set_propagator(eye, numpy.zeros(M), 0.01)
+    with pytest.raises(L.AfqError) as e:
+        dev.bp_configure(4)
+    assert e.value.code == -5 and 'discrete' in str(e.value)
+    dev.set_propagator_hirsch(eye, 0.01)
+    dev.bp_configure(4)
+    with pytest.raises(L.AfqError) as e:
+        dev.bp_update(psi, 5, restore_weights='full')
+    assert e.value.code == -5 and 'restore_weights' in str(e.value)
+    assert numpy.array_equal(dev.bp_steps(), numpy.zeros(4, dtype=numpy.int32))
+    dev.propagate_hirsch(0.0)
+    assert numpy.array_equal(dev.bp_steps(), numpy.ones(4, dtype=numpy.int32))
+    dev.close()

@@ -263,7 +263,7 @@ def test_traj_use_log_shift(golden, monkeypatch):
         assert psi.walkers[3].log_shift == psi.log_shift
 
 
-def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None):
+def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None, bp=None):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -280,6 +280,8 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
         options['estimators']['basename'] = basename
     if walker_opts:
         options['walkers'] = walker_opts
+    if bp:
+        options['estimators']['back_propagated'] = bp
     afqmc = AFQMC(options=options, system=s, trial=t)
     close(afqmc.propagators.bt2, d['bt2'], 1e-12)
     stream = iter(d['u'])
@@ -303,6 +305,10 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     mixed = afqmc.estimators.estimators['mixed']
     close(numpy.array(mixed.blocks)[:, 1:10], d['blocks'][:, 1:10])
     close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'])
+    if bp:
+        est = afqmc.estimators.estimators['back_prop']
+        close(numpy.array(est.denominator), d['bp_denominator'])
+        close(numpy.array(est.one_rdm), d['bp_one_rdm'])
     if walker_opts and walker_opts.get('use_log_shift'):
         assert afqmc.psi.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-9)
         assert afqmc.psi.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-9)
@@ -327,6 +333,13 @@ def test_traj_hirsch_use_log_shift(golden, monkeypatch):
     for batched in (False, True):
         run_hirsch(golden, monkeypatch, 'traj_hirsch_logshift.npz', batched=batched,
                    walker_opts={'use_log_shift': True})
+
+
+def test_traj_back_propagation_hirsch(golden, monkeypatch):
+    """Back-propagated one-body RDM from the discrete fields (propagation/hubbard.py:568-600,634-672; fields recorded
+    one site at a time, hubbard.py:215-216); per-walker and batched loops."""
+    for batched in (False, True):
+        run_hirsch(golden, monkeypatch, 'traj_hirsch_bp.npz', batched=batched, bp={'tau_bp': 0.04, 'one_rdm': True})
 
 
 def test_traj_hubbard_hirsch_charge(golden, monkeypatch):

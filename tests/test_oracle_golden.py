@@ -351,7 +351,7 @@ def test_use_log_shift(golden):
     assert numpy.all(d['final_log_shift'] == d['final_log_shift'][0])
 
 
-def run_hirsch(d, use_log_shift=False):
+def run_hirsch(d, use_log_shift=False, bp_out=None):
     na, nb = [int(x) for x in d['nelec']]
     m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
     close(m.bt2, d['bt2'])
@@ -366,7 +366,8 @@ def run_hirsch(d, use_log_shift=False):
     rec = []
     blocks = ref.run_afqmc(m, walkers, None, None, int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
                            npop_control=int(d['npop_control']), energy_eval_freq=int(d['energy_eval_freq']),
-                           record=rec, uniform_source=usrc, hybrid=False, use_log_shift=use_log_shift)
+                           record=rec, uniform_source=usrc, hybrid=False, use_log_shift=use_log_shift,
+                           nbp=int(d['nbp']) if bp_out is not None else None, bp_out=bp_out)
     if use_log_shift:
         assert m.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-10)
         assert m.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-10)
@@ -391,6 +392,19 @@ def test_traj_hirsch_use_log_shift(golden):
     plain = golden('traj_hubbard_hirsch.npz')
     n = d['weight'].shape[0]
     assert numpy.max(numpy.abs(d['unscaled_weight'] - plain['unscaled_weight'][:n])) > 1e-3   # the option changes the weights
+
+
+def test_back_propagated_rdm_hirsch(golden):
+    """estimators/back_propagation.py:127-226 with propagation/hubbard.py:568-600,634-672: fields recorded one site
+    at a time (hubbard.py:215-216), tau_bp = 4 steps."""
+    d = golden('traj_hirsch_bp.npz')
+    bp = []
+    run_hirsch(d, bp_out=bp)
+    bp = numpy.array(bp)
+    close(bp[:, 3], d['bp_denominator'], 1e-9)
+    close(bp[:, 4:].reshape(d['bp_one_rdm'].shape), d['bp_one_rdm'], 1e-9)
+    rdm = bp[:, 4:].reshape(d['bp_one_rdm'].shape) / bp[:, 3][:, None, None, None]
+    assert rdm[0, 0].trace() == pytest.approx(7.0, rel=1e-10)
 
 
 def test_traj_hubbard_hirsch(golden):
