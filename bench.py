@@ -381,7 +381,10 @@ def main():
                        "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox",
                        "population_control": ("device comb over the library's RCCL communicator" if
                                               getattr(afqmc.psi, 'device_comm', False) else
-                                              "device comb (one rank)" if world == 1 else "host-mediated (torch.distributed)")},
+                                              "device comb (one rank)" if world == 1 else
+                                              "host-mediated (torch.distributed)" +
+                                              (": " + afqmc.psi.device_comm_error
+                                               if getattr(afqmc.psi, 'device_comm_error', '') else ""))},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -213,14 +213,12 @@ class Walkers(object):
         # Population control on the device over the library-owned RCCL communicator (afq_comm_init) whenever the
         # ranks sit on GPUs: rank 0's ncclUniqueId travels over the communicator the driver was given.  The
         # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo).
-        self.device_comm = False
+        self.device_comm, self.device_comm_error = False, ''
         want = walker_opts.get('device_comm', os.environ.get('AFQ_DEVICE_COMM', '1') != '0')
-        if (comm is not None and comm.size > 1 and want and getattr(comm, 'device', None) is not None
-                and comm.device.type == 'cuda'):
-            uid = self.dev.comm_unique_id() if comm.rank == 0 else bytes(128)
-            uid = comm.bcast(uid, root=0)
-            self.dev.comm_init(uid, comm.rank, comm.size)
-            self.device_comm = True
+        forced = walker_opts.get('device_comm', None) is True        # tried whatever the driver's communicator sits on
+        if (comm is not None and comm.size > 1 and want and
+                (forced or (getattr(comm, 'device', None) is not None and comm.device.type == 'cuda'))):
+            self.device_comm, self.device_comm_error = self._init_device_comm(comm)
         self.target_weight = qmc.ntot_walkers
         # host mirrors of the per-walker scalars
         self._host = {}
@@ -444,6 +442,40 @@ class Walkers(object):
         self.set_total_weight(total)
         self.phi_version += 1
         self._invalidate()
+
+    def _init_device_comm(self, comm):
+        """afq_comm_init on every rank plus a probe reduction whose answer is known; all ranks agree (one Allreduce of
+        the outcome flags over the communicator the driver was given) on whether the device communicator is used.
+        A rank that cannot bring it up must not leave the others waiting inside the first population control, so any
+        failure sends every rank to the host-mediated path, with the reason kept in ``device_comm_error``."""
+        err = ''
+        try:
+            uid = self.dev.comm_unique_id() if comm.rank == 0 else bytes(128)
+        except L.AfqError as e:
+            uid, err = bytes(128), str(e)
+        uid = comm.bcast(uid, root=0)
+        if uid == bytes(128):
+            return False, err or 'rank 0 could not create the communicator id'
+        try:
+            self.dev.comm_init(uid, comm.rank, comm.size)
+            probe = self.dev.estimates_allreduce(numpy.arange(1.0, 5.0) * (comm.rank + 1))
+            want = numpy.arange(1.0, 5.0) * (comm.size * (comm.size + 1) // 2)
+            if not numpy.allclose(probe, want, rtol=0, atol=1e-12):
+                err = 'probe all-reduce returned %r, expected %r' % (probe.real.tolist(), want.tolist())
+        except L.AfqError as e:
+            err = str(e)
+        flags = numpy.zeros(1)
+        comm.Allreduce(numpy.array([0.0 if err else 1.0]), flags)
+        if int(round(flags[0])) == comm.size:
+            return True, ''
+        try:
+            self.dev.comm_destroy()
+        except L.AfqError:
+            pass
+        if comm.rank == 0:
+            print("# Warning: device communicator not used (%s); population control goes through the host."
+                  % (err or 'another rank failed'))
+        return False, err or 'another rank failed'
 
     def update_log_ovlp(self, comm):
         """walkers/handler.py:456-475: running averages of log <|ot|>, log <|detR|>, <|log_detR|> over the global

@@ -1,0 +1,167 @@
+"""Two ranks of the real driver on ONE GPU (two processes, gloo process group, both on cuda:0): the batched loop over
+several ranks must reproduce the single-rank run with the same total population when both consume the same
+auxiliary fields (N ranks == 1 rank with N * nw walkers).
+
+What runs here is everything of the multi-rank path that a 1-GPU box allows: AFQMC.run_batched per rank on real device
+handles, the global comb with walkers cloned across ranks (packed on the device, moved through the process group), the
+block reductions, the energy-shift broadcast.  The second case asks for the library-owned RCCL communicator, which
+RCCL refuses for two ranks on one GPU: every rank must then agree on the host-mediated path and give the same numbers."""
+import os
+import socket
+
+import numpy
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+NW, NSTEPS, NBLOCKS = 6, 10, 2          # per rank; two ranks
+
+
+def build():
+    from pauxy_amd import systems, trial as trial_mod
+    s = systems.synthetic_generic(12, 10, (3, 3), seed=3)
+    t = trial_mod.rhf_trial_generic(s)
+    return s, t
+
+
+def options(nw_total, walkers=None):
+    o = {'qmc': {'timestep': 0.01, 'num_steps': NSTEPS, 'blocks': NBLOCKS, 'stabilise_freq': 5, 'pop_control_freq': 5,
+                 'num_walkers': nw_total},
+         'propagator': {'device_rng': False},
+         'estimators': {'mixed': {'energy_eval_freq': 2, 'verbose': False}}}
+    if walkers:
+        o['walkers'] = walkers
+    return o
+
+
+def tables():
+    rng = numpy.random.RandomState(77)
+    return rng.normal(size=(NSTEPS * NBLOCKS, 2 * NW, 10)), rng.rand(NSTEPS * NBLOCKS)
+
+
+class Feed(object):
+    """numpy.random.{normal, random} stand-ins handing out the table rows of this rank's walkers in order."""
+
+    def __init__(self, first, count):
+        xi, r = tables()
+        self.rows = iter(xi[:, first:first + count].reshape(-1, 10))
+        self.r = iter(r[4::5])                 # one comb uniform per population control (every 5th step)
+
+    def normal(self, loc, scale, size):
+        return next(self.rows)
+
+    def random(self):
+        return next(self.r)
+
+
+def drive(comm, nw_total, first, count, walkers=None):
+    from pauxy_amd.qmc.afqmc import AFQMC
+    s, t = build()
+    feed = Feed(first, count)
+    numpy.random.normal, numpy.random.random = feed.normal, feed.random
+    afqmc = AFQMC(comm=comm, options=options(nw_total, walkers), system=s, trial=t)
+    # weights spread over a decade so that the comb clones and kills, also across the two ranks
+    w0 = numpy.exp(0.9 * numpy.random.RandomState(5).normal(size=2 * NW))[first:first + count]
+    for i, w in enumerate(afqmc.psi.walkers):
+        w.weight = w0[i]
+    rec = dict(weight=[], ot=[], pix=[])
+
+    def on_step(step, psi):
+        rec['weight'].append(psi._mirror('weight').copy())
+        rec['ot'].append(psi._mirror('ot').copy())
+        if step % 5 == 0:
+            rec['pix'].append(numpy.array(psi.last_parent_ix).copy())
+
+    afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
+    blocks = numpy.array(afqmc.estimators.estimators['mixed'].blocks) if comm is None or comm.rank == 0 else None
+    phi = numpy.array([w.phi for w in afqmc.psi.walkers])
+    return dict(weight=numpy.array(rec['weight']), ot=numpy.array(rec['ot']), pix=numpy.array(rec['pix']),
+                blocks=blocks, phi=phi, device_comm=bool(getattr(afqmc.psi, 'device_comm', False)),
+                device_comm_error=getattr(afqmc.psi, 'device_comm_error', ''))
+
+
+def _worker(rank, port, walkers, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                          LOCAL_RANK='0')
+        import torch
+        import torch.distributed as dist
+        from pauxy_amd.comm import TorchComm
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        comm = TorchComm(device=torch.device('cpu'))
+        out = drive(comm, 2 * NW, rank * NW, NW, walkers)
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:          # surface the failure instead of leaving the parent waiting
+        q.put((rank, repr(e)))
+        raise
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def two_ranks(walkers=None):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, walkers, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    for rank, out in res:
+        assert isinstance(out, dict), (rank, out)
+    return res[0][1], res[1][1]
+
+
+def single_rank():
+    import numpy.random as nr
+    keep = nr.normal, nr.random
+    try:
+        return drive(None, 2 * NW, 0, 2 * NW)
+    finally:
+        nr.normal, nr.random = keep
+
+
+def compare(one, a, b):
+    assert one['pix'].shape[0] == 4 and (one['pix'] > 1).any() and (one['pix'] == 0).any()
+    assert numpy.array_equal(a['pix'], one['pix']) and numpy.array_equal(b['pix'], one['pix'])
+    # walkers really crossed the rank boundary
+    from pauxy_amd.walkers.handler import comb_pairs
+    assert any(c // NW != k // NW for pix in one['pix'] for c, k in comb_pairs(pix))
+    for key in ('weight', 'ot'):
+        got = numpy.concatenate([a[key], b[key]], axis=1)
+        assert got.shape == one[key].shape
+        assert numpy.max(numpy.abs(got - one[key])) <= 1e-9 * max(1.0, numpy.max(numpy.abs(one[key]))), key
+    got_phi = numpy.concatenate([a['phi'], b['phi']])
+    assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
+    assert a['blocks'].shape == one['blocks'].shape
+    assert numpy.max(numpy.abs(a['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
+
+
+def test_two_ranks_equal_one_rank_with_twice_the_walkers():
+    one = single_rank()
+    a, b = two_ranks()
+    assert not a['device_comm'] and not b['device_comm']
+    compare(one, a, b)
+
+
+def test_device_communicator_refused_then_host_path():
+    """walkers: {device_comm: True} on a gloo group: afq_comm_init is attempted, RCCL refuses two ranks on one GPU
+    (or the probe fails); both ranks must fall back together and still match the single-rank run."""
+    one = single_rank()
+    a, b = two_ranks({'device_comm': True})
+    assert not a['device_comm'] and not b['device_comm']
+    assert a['device_comm_error'] and b['device_comm_error']
+    compare(one, a, b)
