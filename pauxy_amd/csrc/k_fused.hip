@@ -23,10 +23,17 @@
 #include "mfma_gemm_wg.h"
 
 #define PF_D 3
+// waves per work-group: 8 (product) or 16 (experiment: -DPF_NW=16; four waves per SIMD, 2 x 1 tile deals)
+#ifndef PF_NW
+#define PF_NW 8
+#endif
+#define PF_NT (64 * PF_NW)
+#define PF_FPW (16 / PF_NW)      // operand fragments each wave moves per chunk
 
 struct PropFusedArgs {
     int M, na, nb, nt, order;
     int t4;                     // Taylor products on v_mfma_f64_4x4x4 (see taylor4 below)
+    int dbg;                    // tuning builds: bit 0 = no per-chunk barrier (WRONG results; timing ceiling only)
     int vhs_upper;              // vhs holds only the upper triangle of the (symmetric) HS potential
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
@@ -69,8 +76,10 @@ __device__ inline void lds_barrier() {
 
 // NARROW: at most one column tile per spin (na, nb <= 16); a separate instantiation so that each carries only the
 // Taylor tile deals it uses (register allocation and code size of one variant do not tax the other)
-template <bool NARROW>
-__global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
+// FULL: every tile of the wide deal exists (M > 96, na, nb > 16; host-checked): the per-tile validity tests, which
+// cost a branch per tile and k-step inside the MFMA blocks, are compiled out.
+template <bool NARROW, bool FULL>
+__global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = blockIdx.x;
     if (!a.alive[w]) return;
@@ -92,40 +101,56 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     const int nob = a.same_b ? 1 : 2;
     const int nphase = 2 * nob + a.order;
     const int G = nphase * NCH;
-    auto a_base = [&](int phase) -> const cplx * {
-        if (phase < nob) return a.BH1 + (long)phase * M * M;
-        if (phase < nob + a.order) return vhs;
-        return a.BH1 + (long)(phase - nob - a.order) * M * M;
-    };
+    const long MM = (long)M * M;
     int gi = 0, gi_phase = 0, gi_c = 0, gi_slot = 0;            // next chunk to issue
     // The source addresses of a refill are computed ahead of time (prepare), normally right behind an MFMA block
     // where the integer arithmetic issues under running MFMAs; the refill itself (issueA), which sits in the
     // barrier-aligned part of the chunk loop that all eight waves execute at once, is then two DMA instructions.
-    const void *nsrc[2];
+    // prepare() is straight-line code (selects, no branches): a taken branch costs a wave far more than the handful
+    // of integer instructions it would skip, and one basic block lets the scheduler place them between MFMAs.
+    const void *nsrc[PF_FPW];
     bool prepared = false;
+    const int p_row0 = (wave >> 1) * 16 + lr;                    // fragment f = wave + t * PF_NW: row tile f>>1,
+    const int p_kl = 2 * lk + (wave & 1);                        // sub-step f&1 (the same for every t: PF_NW is even)
     auto prepare = [&]() __attribute__((always_inline)) {
-        const cplx *A = a_base(gi_phase < nphase ? gi_phase : 0);
-        const bool sym_phase = a.vhs_upper && gi_phase >= nob && gi_phase < nob + a.order;
+#ifdef AFQ_TUNING
+        if ((a.dbg & 1024) && gi > 2) { prepared = true; return; }       // stale addresses (timing only)
+#endif
+        const bool in_v = gi_phase >= nob && gi_phase < nob + a.order;
+        const int spin = gi_phase < nob ? gi_phase : gi_phase - nob - a.order;      // 0 or 1 on live chunks
+        const cplx *A = in_v ? vhs : a.BH1 + (spin == 1 ? MM : 0L);
+        const bool sym_phase = a.vhs_upper && in_v;
+        const bool live = gi < G;
+        const int k = gi_c * 8 + p_kl;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int f = wave + t * 8;                          // fragment: row tile f>>1, sub-step f&1
-            const int row = (f >> 1) * 16 + lr, k = gi_c * 8 + 2 * lk + (f & 1);
+        for (int t = 0; t < PF_FPW; ++t) {
+            const int row = p_row0 + t * (PF_NW / 2) * 16;
             // upper-triangle storage of V: element (row, k < row) lives at (k, row); the 16 lanes of one k then
             // read 256 contiguous bytes instead of 16 rows
             // (branch-free on purpose: a global_load_lds inside a divergent region leaves the LDS slots of the
             // masked-off lanes stale)
-            const int r2 = sym_phase ? min(row, k) : row, k2 = sym_phase ? max(row, k) : k;
-            nsrc[t] = (gi < G && row < M && k < M) ? (const void *)(A + (r2 * M + k2)) : a.zero16;
+            const int off = (sym_phase && k < row) ? k * M + row : row * M + k;
+            nsrc[t] = (live && row < M && k < M) ? (const void *)(A + off) : a.zero16;
+            // materialise here: without a use at this point the optimiser sinks the whole computation down to the
+            // refill that consumes it, i.e. out of the MFMA shadow it was placed in and into the barrier-aligned part
+            asm volatile("" : "+v"(nsrc[t]));
         }
         ++gi;
-        if (++gi_c == NCH) { gi_c = 0; ++gi_phase; }
+        const bool wrap = gi_c + 1 == NCH;
+        gi_c = wrap ? 0 : gi_c + 1;
+        gi_phase += wrap ? 1 : 0;
         prepared = true;
     };
     auto issueA = [&]() __attribute__((always_inline)) {
         if (!prepared) prepare();
         unsigned char *dst = ring + (size_t)gi_slot * 16384;
+#ifdef AFQ_TUNING
+        if (a.dbg & 512) {                                   // addresses computed, DMA not issued
+            for (int t = 0; t < PF_FPW; ++t) asm volatile("" ::"v"(nsrc[t]), "s"(dst));
+        } else
+#endif
 #pragma unroll
-        for (int t = 0; t < 2; ++t) glds16(nsrc[t], dst + (wave + t * 8) * 1024);
+        for (int t = 0; t < PF_FPW; ++t) glds16(nsrc[t], dst + (wave + t * PF_NW) * 1024);
         if (++gi_slot == PF_D) gi_slot = 0;
         prepared = false;
     };
@@ -133,9 +158,15 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     prepare();
 
     // ---- phi[w] -> T (B-fragment order), padding zeroed
-    for (int e = tid; e < NCH * 512; e += 512) ((d2_t *)Tf)[e] = (d2_t){0.0, 0.0};
+#ifdef AFQ_TUNING
+    if (!(a.dbg & 32))
+#endif
+    for (int e = tid; e < NCH * 512; e += PF_NT) ((d2_t *)Tf)[e] = (d2_t){0.0, 0.0};
     __syncthreads();
-    for (int e = tid; e < M * nt; e += 512) {
+#ifdef AFQ_TUNING
+    if (!(a.dbg & 128))
+#endif
+    for (int e = tid; e < M * nt; e += PF_NT) {
         const int p = e / nt, col = e % nt;
         const int s = col >= a.na ? 1 : 0, j = col - (s ? a.na : 0);
         const int slot = 2 * s + (j >> 4);
@@ -159,18 +190,35 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     int ring_slot = 0;                                           // slot of the chunk being consumed
     // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
     auto next_chunk = [&]() __attribute__((always_inline)) -> unsigned {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * 2) : "memory");
+#ifdef AFQ_TUNING
+        if (!(a.dbg & 18))
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * PF_FPW) : "memory");
+#ifdef AFQ_TUNING
+        if (!(a.dbg & 1))
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef AFQ_TUNING
+        if (!(a.dbg & 2))
+#endif
         issueA();
         const unsigned sl = ring_l + ring_slot * 16384;
         if (++ring_slot == PF_D) ring_slot = 0;
+        return sl;
+    };
+    // the same without the refill: the caller issues issueA() itself, behind its first MFMAs of the chunk
+    auto next_chunk_sync = [&]() __attribute__((always_inline)) -> unsigned {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * PF_FPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned sl = ring_l + ring_slot * 16384;
+        ring_slot = ring_slot + 1 == PF_D ? 0 : ring_slot + 1;
         return sl;
     };
 
     // ------------------------------------------------------------------ one-body product
     // wave v owns row tile v and NSL column-tile slots starting at slot0: the (up to) two tiles of one spin, or
     // all four when both spins share the matrix
-    auto one_body = [&](auto nsl_tag, int slot0, bool to_global, auto real_tag) __attribute__((always_inline)) {
+    auto one_body = [&](auto nsl_tag, int slot0, bool to_global, auto real_tag, const int rt) __attribute__((always_inline)) {
         constexpr int NSL = decltype(nsl_tag)::value;
         constexpr bool BR = decltype(real_tag)::value;
         d4_t P1[NSL], P2[NSL], P3[NSL];
@@ -179,10 +227,10 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         for (int j = 0; j < NSL; ++j) {
             P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0};
             const int cs = slot0 + j;
-            cv[j] = wave < nrt && (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
+            cv[j] = rt < nrt && (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
         }
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
-            const unsigned abase = sl + wave * 2048 + lane * 16;
+            const unsigned abase = sl + rt * 2048 + lane * 16;
             const unsigned bbase = tf_l + (c * 4 + slot0) * 2048 + lane * 16;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -193,11 +241,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         };
         auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
             __builtin_amdgcn_sched_barrier(0);
+#ifdef AFQ_TUNING
+            if (!(a.dbg & 64))
+#endif
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
-                    if (cv[j]) {
+                    if (FULL || cv[j]) {        // FULL: a wave without a row tile multiplies the zero fragments the DMA put there
                         if (BR) {
                             P1[j] = mfma16(av[ss][0], bv[j][ss][0], P1[j]);
                             P2[j] = mfma16(av[ss][0], bv[j][ss][1], P2[j]);
@@ -211,6 +262,15 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
             if (!prepared) prepare();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
+#if PF_NW == 16
+        // four waves per SIMD: the other waves' MFMAs cover this wave's LDS reads, one register set is enough
+        d2_t avA[2], bvA[NSL][2];
+        for (int c = 0; c < NCH; ++c) {
+            load_frags(next_chunk(), c, avA, bvA);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfmas(avA, bvA);
+        }
+#else
         // fragments of chunk c+1 are read while the MFMAs of chunk c run (two register sets)
         d2_t avA[2], bvA[NSL][2], avB[2], bvB[NSL][2];
         load_frags(next_chunk(), 0, avA, bvA);
@@ -223,6 +283,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 mfmas(avB, bvB);
             }
         }
+#endif
         __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
         int lk_e = lk, lr_e = lr;                                // laundered: keeps the store addresses from being
         asm volatile("" : "+v"(lk_e), "+v"(lr_e));               // computed (and kept alive) ahead of the MFMA loop
@@ -236,25 +297,42 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                     const double re = BR ? P1[j][r] : P1[j][r] - P2[j][r];
                     const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
-                        const int row = wave * 16 + lk_e + 4 * r, col = (cs & 1) * 16 + lr_e;
+                        const int row = rt * 16 + lk_e + 4 * r, col = (cs & 1) * 16 + lr_e;
+#ifdef AFQ_TUNING
+                        if (!(a.dbg & 256))
+#endif
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
-                    } else if (t_ok(wave, r)) {
-                        *(d2_t *)(Tf + t_addr(wave, r, cs)) = (d2_t){re, im};
+                    } else if (t_ok(rt, r)) {
+                        *(d2_t *)(Tf + t_addr(rt, r, cs)) = (d2_t){re, im};
                     }
                 }
             }
     };
     auto one_body_stage = [&](bool to_global) __attribute__((always_inline)) {
         using I2 = std::integral_constant<int, 2>;
+#if PF_NW == 16
+        // two waves per row tile: each takes half of the column slots
+        using I1 = std::integral_constant<int, 1>;
+        const int rt = wave >> 1, h2 = wave & 1;
+        if (a.same_b) {
+            if (a.b_real) one_body(I2{}, 2 * h2, to_global, std::true_type{}, rt);
+            else one_body(I2{}, 2 * h2, to_global, std::false_type{}, rt);
+        } else if (a.b_real) {
+            one_body(I1{}, h2, to_global, std::true_type{}, rt); one_body(I1{}, 2 + h2, to_global, std::true_type{}, rt);
+        } else {
+            one_body(I1{}, h2, to_global, std::false_type{}, rt); one_body(I1{}, 2 + h2, to_global, std::false_type{}, rt);
+        }
+#else
         using I4 = std::integral_constant<int, 4>;
         if (a.same_b) {
-            if (a.b_real) one_body(I4{}, 0, to_global, std::true_type{});
-            else one_body(I4{}, 0, to_global, std::false_type{});
+            if (a.b_real) one_body(I4{}, 0, to_global, std::true_type{}, wave);
+            else one_body(I4{}, 0, to_global, std::false_type{}, wave);
         } else if (a.b_real) {
-            one_body(I2{}, 0, to_global, std::true_type{}); one_body(I2{}, 2, to_global, std::true_type{});
+            one_body(I2{}, 0, to_global, std::true_type{}, wave); one_body(I2{}, 2, to_global, std::true_type{}, wave);
         } else {
-            one_body(I2{}, 0, to_global, std::false_type{}); one_body(I2{}, 2, to_global, std::false_type{});
+            one_body(I2{}, 0, to_global, std::false_type{}, wave); one_body(I2{}, 2, to_global, std::false_type{}, wave);
         }
+#endif
     };
 
     one_body_stage(false);
@@ -296,6 +374,9 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         // (second register set) while the MFMAs of chunk c run, so the LDS pipe and the MFMA pipe overlap instead
         // of alternating in lock step behind the per-chunk barrier.
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
+#ifdef AFQ_TUNING
+            if (a.dbg & 4) return;
+#endif
             const unsigned abase = sl + r0 * 2048 + lane * 16;
             const unsigned bbase = tf_l + (c * 4 + c0) * 2048 + lane * 16;
 #pragma unroll
@@ -315,11 +396,14 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                     P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0};
                 }
             auto mfma_ss = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2], const int ss) __attribute__((always_inline)) {
+#ifdef AFQ_TUNING
+                if (a.dbg & 8) return;
+#endif
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        if (cv[j] && rv[i]) {
+                        if (FULL || (cv[j] && rv[i])) {
                             P1[i][j] = mfma16(av[i][ss][0], bv[j][ss][0], P1[i][j]);
                             P2[i][j] = mfma16(av[i][ss][1], bv[j][ss][1], P2[i][j]);
                             P3[i][j] = mfma16(av[i][ss][0] + av[i][ss][1], bv[j][ss][0] + bv[j][ss][1], P3[i][j]);
@@ -333,6 +417,77 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                 if (!prepared) prepare();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
+#if PF_NW == 8
+            if (FULL) {
+                // Every instruction that is not an MFMA sits BETWEEN two MFMA groups of the same wave (program order is
+                // pinned with sched_barrier), in the 64-cycle shadows of the MFMAs: the refill of the operand ring, the
+                // LDS reads of the fragments needed next, the address arithmetic of the next refill.  Measured before:
+                // with that work placed before / behind the MFMA block of a chunk it ran while the matrix pipe of the
+                // SIMD idled (the partner wave already waiting at the chunk barrier) -- the kernel took the SUM of its
+                // MFMA time (107 us) and its bookkeeping (70 us).
+                // The pipeline is half a chunk deep: the sub-step 0 MFMAs of chunk c run while the sub-step 1 fragments of
+                // chunk c are read, the wave crosses the barrier of chunk c + 1, and the sub-step 1 MFMAs run while the
+                // ring is refilled and the sub-step 0 fragments of chunk c + 1 are read -- one register set per sub-step
+                // instead of two per chunk (the 2 x 2 deal needs every register it can get: 96 product + 64 sum).
+                constexpr int NG = NI * NJ;                       // MFMA groups (one tile: 3 MFMAs) per sub-step
+                constexpr int NR = NI + NJ;                       // fragment reads per sub-step
+                constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;   // reads behind each group but the last
+                d2_t a0[NI], b0[NJ], a1[NI], b1[NJ];              // sub-step 0 / sub-step 1 fragments
+                auto half = [&](d2_t (&ax)[NI], d2_t (&bx)[NJ], d2_t (&ay)[NI], d2_t (&by)[NJ], const unsigned abase,
+                                const unsigned bbase, const int ys, const bool fetch, const bool refill)
+                    __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const int i = g / NJ, j = g % NJ;
+                        P1[i][j] = mfma16(ax[i][0], bx[j][0], P1[i][j]);
+                        P2[i][j] = mfma16(ax[i][1], bx[j][1], P2[i][j]);
+                        P3[i][j] = mfma16(ax[i][0] + ax[i][1], bx[j][0] + bx[j][1], P3[i][j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g == 0 && refill) issueA();
+                        if (g == 0 && !refill && !prepared) prepare();
+                        if (fetch && (g < NG - 1 || NG == 1)) {
+#pragma unroll
+                            for (int q = 0; q < RPG; ++q) {
+                                const int r = g * RPG + q;        // read r: the A tiles, then the B tiles
+                                if (r < NR) {
+                                    if (r < NI) ay[r] = lds_read_frag(abase, r * 2 + ys);
+                                    else by[r - NI] = lds_read_frag(bbase, (r - NI) * 2 + ys);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                };
+                unsigned sl = next_chunk();
+                {
+                    const unsigned abase = sl + r0 * 2048 + lane * 16, bbase = tf_l + c0 * 2048 + lane * 16;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) a0[i] = lds_read_frag(abase, i * 2);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b0[j] = lds_read_frag(bbase, j * 2);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                for (int c = 0; c < NCH; ++c) {
+                    const bool more = c + 1 < NCH;
+                    // sub-step 0 of chunk c; fetch its sub-step 1 fragments
+                    half(a0, b0, a1, b1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, 1, true, false);
+                    if (more) sl = next_chunk_sync();             // chunk c + 1 has landed
+                    // sub-step 1 of chunk c; refill the ring, fetch the sub-step 0 fragments of chunk c + 1
+                    half(a1, b1, a0, b0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, 0, more, more);
+                }
+            } else
+#endif
+            {
+#if PF_NW == 16
+            d2_t avA[NI][2], bvA[NJ][2];
+            for (int c = 0; c < NCH; ++c) {
+                load_frags(next_chunk(), c, avA, bvA);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                mfmas(avA, bvA);
+            }
+#else
             d2_t avA[NI][2], bvA[NJ][2], avB[NI][2], bvB[NJ][2];
             if (STAG) {
                 // X = fragments of the chunk whose sub-step 1 is still owed, Y = the set being filled
@@ -372,6 +527,8 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
                         mfmas(avB, bvB);
                     }
                 }
+            }
+#endif
             }
             __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
             const double inv_n = 1.0 / n;
@@ -557,6 +714,16 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
         }
     };
 #endif
+#if PF_NW == 16
+    {
+        // SIMD s (waves s, s + 4, s + 8, s + 12) owns column tile s: row tiles (0,1) (2,3) (4,5) (6); 7 tiles per SIMD
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        const int g = wave >> 2;
+        if (g & 1) taylor(I2{}, I1{}, std::true_type{}, 2 * g, wave & 3, g == 3 ? 1 : 2);
+        else taylor(I2{}, I1{}, std::false_type{}, 2 * g, wave & 3, 2);
+    }
+#else
 #ifdef AFQ_TUNING
     if (a.t4) taylor4();
     else
@@ -573,6 +740,7 @@ __global__ __launch_bounds__(512) void prop_fused_kernel(PropFusedArgs a) {
     }
     else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
     else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3);
+#endif
     if (a.order == 0) lds_barrier();
 
     one_body_stage(true);
@@ -589,20 +757,26 @@ int k_prop_fused(afq_handle *h) {
     a.vhs_upper = h->vhs_upper ? 1 : 0;
     // 4x4x4 Taylor products (tuning builds only): M <= 100 (six full row tiles + at most four remainder rows)
     a.t4 = (h->M <= 100 && afq_knob("AFQ_T4")) ? 1 : 0;
+    a.dbg = afq_knob("AFQ_PF_DBG") ? atoi(afq_knob("AFQ_PF_DBG")) : 0;
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
-    static size_t lds_set[2][AFQ_MAX_DEVICES] = {{0}, {0}};
+    static size_t lds_set[3][AFQ_MAX_DEVICES] = {{0}, {0}, {0}};
     const bool narrow = h->na <= 16 && h->nb <= 16;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
+    // every tile of the wide deal present: row tiles 0-6 (waves 4-7 own tiles 4, 5, 6) and two column tiles per spin
+    const bool full = !narrow && h->M > 96 && h->na > 16 && h->nb > 16 && PF_NW == 8 && !afq_knob("AFQ_PF_NOFULL");
     if (narrow) {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true>, lds, lds_set[1]));
-        AFQ_LAUNCH(h, prop_fused_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a);
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true, false>, lds, lds_set[1]));
+        AFQ_LAUNCH(h, (prop_fused_kernel<true, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
+    } else if (full) {
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false, true>, lds, lds_set[2]));
+        AFQ_LAUNCH(h, (prop_fused_kernel<false, true>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
     } else {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false>, lds, lds_set[0]));
-        AFQ_LAUNCH(h, prop_fused_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a);
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false, false>, lds, lds_set[0]));
+        AFQ_LAUNCH(h, (prop_fused_kernel<false, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
     }
     AFQ_POST(h);
     return AFQ_OK;
