@@ -34,6 +34,7 @@ struct PropFusedArgs {
     int M, na, nb, nt, order;
     int t4;                     // Taylor products on v_mfma_f64_4x4x4 (see taylor4 below)
     int dbg;                    // tuning builds: bit 0 = no per-chunk barrier (WRONG results; timing ceiling only)
+    unsigned long long *ts;     // tuning builds (AFQ_PF_TS=1): s_memtime stamps of work-group 0, waves 0 and 4
     int vhs_upper;              // vhs holds only the upper triangle of the (symmetric) HS potential
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
@@ -262,6 +263,60 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             if (!prepared) prepare();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
+#if PF_NW == 8
+        if (FULL) {
+            // the half-chunk pipeline of the Taylor products below (see there): refill, fragment reads and address
+            // arithmetic between the MFMA groups of the sub-step in flight
+            constexpr int NR = 1 + NSL;
+            constexpr int RPG = NSL > 1 ? (NR + NSL - 2) / (NSL - 1) : NR;
+            d2_t a0, a1, b0[NSL], b1[NSL];
+            auto half = [&](d2_t &ax, d2_t (&bx)[NSL], d2_t &ay, d2_t (&by)[NSL], const unsigned abase, const unsigned bbase,
+                            const int ys, const bool fetch, const bool refill) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NSL; ++j) {
+                    if (BR) {
+                        P1[j] = mfma16(ax[0], bx[j][0], P1[j]);
+                        P2[j] = mfma16(ax[0], bx[j][1], P2[j]);
+                    } else {
+                        P1[j] = mfma16(ax[0], bx[j][0], P1[j]);
+                        P2[j] = mfma16(ax[1], bx[j][1], P2[j]);
+                        P3[j] = mfma16(ax[0] + ax[1], bx[j][0] + bx[j][1], P3[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j == 0 && refill) issueA();
+                    if (j == 0 && !refill && !prepared) prepare();
+                    if (fetch && (j < NSL - 1 || NSL == 1)) {
+#pragma unroll
+                        for (int q = 0; q < RPG; ++q) {
+                            const int r = j * RPG + q;
+                            if (r < NR) {
+                                if (r == 0) ay = lds_read_frag(abase, ys);
+                                else by[r - 1] = lds_read_frag(bbase, (r - 1) * 2 + ys);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            unsigned sl = next_chunk();
+            {
+                const unsigned abase = sl + rt * 2048 + lane * 16, bbase = tf_l + slot0 * 2048 + lane * 16;
+                a0 = lds_read_frag(abase, 0);
+#pragma unroll
+                for (int j = 0; j < NSL; ++j) b0[j] = lds_read_frag(bbase, j * 2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            for (int c = 0; c < NCH; ++c) {
+                const bool more = c + 1 < NCH;
+                half(a0, b0, a1, b1, sl + rt * 2048 + lane * 16, tf_l + (c * 4 + slot0) * 2048 + lane * 16, 1, true, false);
+                if (more) sl = next_chunk_sync();
+                half(a1, b1, a0, b0, sl + rt * 2048 + lane * 16, tf_l + ((c + 1) * 4 + slot0) * 2048 + lane * 16, 0, more, more);
+            }
+        } else
+#endif
+        {
 #if PF_NW == 16
         // four waves per SIMD: the other waves' MFMAs cover this wave's LDS reads, one register set is enough
         d2_t avA[2], bvA[NSL][2];
@@ -284,6 +339,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             }
         }
 #endif
+        }
         __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
         int lk_e = lk, lr_e = lr;                                // laundered: keeps the store addresses from being
         asm volatile("" : "+v"(lk_e), "+v"(lr_e));               // computed (and kept alive) ahead of the MFMA loop
@@ -335,6 +391,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #endif
     };
 
+    // (s_setprio for either half of the waves only moves the barrier wait from one SIMD partner to the other:
+    //  measured, same chunk time)
     one_body_stage(false);
     lds_barrier();                                               // T = B phi complete
 
@@ -471,11 +529,29 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 }
                 for (int c = 0; c < NCH; ++c) {
                     const bool more = c + 1 < NCH;
+#ifdef AFQ_TUNING
+                    // s_memtime lands in SGPRs; the values are read behind the lgkmcnt(0) wait that closes a half
+                    unsigned long long t0, t1, t2, t3;
+                    asm volatile("s_memtime %0" : "=s"(t0));
+#endif
                     // sub-step 0 of chunk c; fetch its sub-step 1 fragments
                     half(a0, b0, a1, b1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, 1, true, false);
+#ifdef AFQ_TUNING
+                    asm volatile("s_memtime %0" : "=s"(t1));
+#endif
                     if (more) sl = next_chunk_sync();             // chunk c + 1 has landed
+#ifdef AFQ_TUNING
+                    asm volatile("s_memtime %0" : "=s"(t2));
+#endif
                     // sub-step 1 of chunk c; refill the ring, fetch the sub-step 0 fragments of chunk c + 1
                     half(a1, b1, a0, b0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, 0, more, more);
+#ifdef AFQ_TUNING
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3));
+                    if (a.ts && w == 0 && n == 3 && (wave & 3) == 0 && lane == 0) {
+                        unsigned long long *o = a.ts + ((wave >> 2) * 16 + c) * 4;
+                        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+                    }
+#endif
                 }
             } else
 #endif
@@ -758,6 +834,15 @@ int k_prop_fused(afq_handle *h) {
     // 4x4x4 Taylor products (tuning builds only): M <= 100 (six full row tiles + at most four remainder rows)
     a.t4 = (h->M <= 100 && afq_knob("AFQ_T4")) ? 1 : 0;
     a.dbg = afq_knob("AFQ_PF_DBG") ? atoi(afq_knob("AFQ_PF_DBG")) : 0;
+    a.ts = nullptr;
+#ifdef AFQ_TUNING
+    static unsigned long long *ts_dev = nullptr;
+    static int ts_launch = 0;
+    if (afq_knob("AFQ_PF_TS")) {
+        if (!ts_dev) { hipMalloc(&ts_dev, 2 * 16 * 4 * 8); hipMemset(ts_dev, 0, 2 * 16 * 4 * 8); }
+        a.ts = ts_dev;
+    }
+#endif
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
@@ -779,5 +864,19 @@ int k_prop_fused(afq_handle *h) {
         AFQ_LAUNCH(h, (prop_fused_kernel<false, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
     }
     AFQ_POST(h);
+#ifdef AFQ_TUNING
+    if (a.ts && ++ts_launch == 30) {
+        unsigned long long t[2 * 16 * 4];
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(t, a.ts, sizeof(t), hipMemcpyDeviceToHost);
+        for (int wv = 0; wv < 2; ++wv)
+            for (int c = 0; c < (h->M + 7) / 8; ++c) {
+                const unsigned long long *o = t + (wv * 16 + c) * 4;
+                fprintf(stderr, "PF_TS wave %d chunk %2d: halfA %5lld  sync %5lld  halfB %5lld  | since chunk start of wave 0: %lld\n",
+                        wv * 4, c, (long long)(o[1] - o[0]), (long long)(o[2] - o[1]), (long long)(o[3] - o[2]),
+                        (long long)(o[0] - t[c * 4]));
+            }
+    }
+#endif
     return AFQ_OK;
 }
