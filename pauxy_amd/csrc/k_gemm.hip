@@ -182,6 +182,7 @@ int k_force_bias_generic(afq_handle *h) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
 #ifdef AFQ_TUNING
                 if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                else if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
                 else
 #endif
                 AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, true>(p, h->stream, h->zero_page)));
@@ -269,6 +270,10 @@ int k_vhs_generic(afq_handle *h) {
             static const int kc = afq_knob("AFQ_GEMM_KC") ? atoi(afq_knob("AFQ_GEMM_KC")) : 1;
             KernelTrace kt(h, AFQ_K_VHS);
             static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
+#ifdef AFQ_TUNING
+            if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else
+#endif
             if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
             else if (xmap) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));

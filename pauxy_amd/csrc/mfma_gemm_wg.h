@@ -32,7 +32,7 @@ template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static con
 
 // KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, bool STAG = false>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
     static_assert(P::A_CPLX, "A operand must be complex");
     static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
@@ -183,7 +183,78 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     // the chunk barrier in the MIDDLE of a chunk's MFMAs -- sub-step 1 of chunk c is multiplied right behind barrier
     // c + 1 from fragments already in registers, then the fragments of chunk c + 1 are read and its sub-step 0
     // multiplied -- so that the partner's LDS reads and ring refill run under this wave's MFMAs and vice versa.
-    if (STAG && KC == 1 && wave >= NW / 2) {
+    // STAG == 2: half-chunk pipeline with every non-MFMA instruction BETWEEN two MFMA groups of the wave (program order
+    // pinned with sched_barrier), in the 64-cycle shadows of the MFMAs: the sub-step 0 MFMAs of chunk c run while the
+    // sub-step 1 fragments of chunk c are read; the wave crosses barrier c + 1; the sub-step 1 MFMAs run while the ring is
+    // refilled (address arithmetic included) and the sub-step 0 fragments of chunk c + 1 are read.  The plain loop below
+    // does refill, reads and the wait for them in a block behind the barrier with the matrix pipe idle, which only
+    // works out when several waves share a SIMD; the small-output contractions of this library run one wave per SIMD.
+    if (STAG == 2 && KC == 1) {
+        constexpr int NG = TM * TN, NR = TM + TN;
+        constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;
+        auto mfma_tile = [&](int i, int j, int s) __attribute__((always_inline)) {
+            if (P::B_CPLX && K3M) {
+                accR[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][0], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][1], bc[0][j][s][1], accI[i][j]);
+                acc3[i][j] = mfma16(a[0][i][s][0] + a[0][i][s][1], bc[0][j][s][0] + bc[0][j][s][1], acc3[i][j]);
+            } else if (P::B_CPLX) {
+                accR[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][0], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][1], accI[i][j]);
+                accR[i][j] = mfma16(-a[0][i][s][1], bc[0][j][s][1], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][1], bc[0][j][s][0], accI[i][j]);
+            } else {
+                accR[i][j] = mfma16(a[0][i][s][0], br[0][j][s], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][1], br[0][j][s], accI[i][j]);
+            }
+        };
+        auto read_one = [&](unsigned sl, int r, int s) __attribute__((always_inline)) {      // fragment r of sub-step s
+            if (r < TM) a[0][r][s] = lds_read_b128(sl + ((wm * TM + r) * 2 + s) * 1024 + lane * 16);
+            else if (P::B_CPLX) bc[0][r - TM][s] = lds_read_b128(sl + (NA + (wn * TN + r - TM) * 2 + s) * 1024 + lane * 16);
+            else br[0][r - TM][s] = lds_read_b64(sl + (NA + wn * TN + r - TM) * 1024 + s * 512 + lane * 8);
+        };
+        auto conj_set = [&](int s) __attribute__((always_inline)) {
+            if (gemm_conj_a<P>::value) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[0][i][s][1] = -a[0][i][s][1];
+            }
+        };
+        // MFMA groups of sub-step s; the reads of sub-step rs from slot `sl` (and the ring refill) in between
+        auto half = [&](const int s, const unsigned sl, const int rs, const bool fetch, const int refill_c)
+            __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                mfma_tile(g / TN, g % TN, s);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 0 && refill_c >= 0) issue(refill_c, refill_c & (D - 1));
+                if (fetch && (g < NG - 1 || NG == 1)) {
+#pragma unroll
+                    for (int q = 0; q < RPG; ++q)
+                        if (g * RPG + q < NR) read_one(sl, g * RPG + q, rs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (fetch) conj_set(rs);
+        };
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(D - 1, (D - 1) & (D - 1));
+#pragma unroll
+        for (int r = 0; r < NR; ++r) read_one(ring_l, r, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        conj_set(0);
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            half(0, ring_l + (c & (D - 1)) * CHUNK, 1, true, -1);
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            half(1, ring_l + ((c + 1) & (D - 1)) * CHUNK, 0, more, more ? c + D : -1);
+        }
+    } else
+    if (STAG == 1 && KC == 1 && wave >= NW / 2) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(D - 1, (D - 1) & (D - 1));
@@ -256,7 +327,7 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             }
 }
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, bool STAG = false>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;
     constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
