@@ -37,6 +37,14 @@ struct OvlpProb {
         const int s = b & 1, ns = s ? nb : na;
         return col < ns ? psic + (b >> 1) * psi_stride + (long)k * nt + (s ? na : 0) + col : zero;
     }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int b, int row) const { return phi + (long)(b >> 1) * kdim * nt + ((b & 1) ? na : 0) + row; }
+    __device__ const cplx *baseB(int b, int col) const { return psic + (b >> 1) * psi_stride + ((b & 1) ? na : 0) + col; }
+    __device__ long kstepA() const { return nt; }
+    __device__ long kstepB(int) const { return nt; }
+    __device__ bool rowok(int b, int row) const { return row < ((b & 1) ? nb : na); }
+    __device__ bool colok(int b, int col) const { return col < ((b & 1) ? nb : na); }
     __device__ void store(int b, int row, int col, double re, double im) const {
         O[(long)b * ld * ld + (long)row * ld + col] = cmake(re, im);
     }
@@ -62,6 +70,14 @@ struct GhalfProb {
         const int s = b & 1, ns = s ? nb : na;
         return k < ns ? phi + ((long)(b >> 1) * M + col) * nt + (s ? na : 0) + k : zero;
     }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int b) const { return (b & 1) ? nb : na; }
+    __device__ const cplx *baseA(int b, int row) const { return Oinv + (long)b * ld * ld + (long)row * ld; }
+    __device__ const cplx *baseB(int b, int col) const { return phi + ((long)(b >> 1) * M + col) * nt + ((b & 1) ? na : 0); }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return 1; }
+    __device__ bool rowok(int b, int row) const { return row < ((b & 1) ? nb : na); }
+    __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         const int s = b & 1, ns = s ? nb : na;
         if (row < ns) ghalf[((long)(b >> 1) * nt + (s ? na : 0) + row) * M + col] = cmake(re, im);
@@ -339,6 +355,14 @@ struct GramProb {
         const int s = b & 1, ns = s ? nb : na;
         return col < ns ? x + ((long)(b >> 1) * kdim + k) * nt + (s ? na : 0) + col : zero;
     }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int b, int row) const { return x + (long)(b >> 1) * kdim * nt + ((b & 1) ? na : 0) + row; }
+    __device__ const cplx *baseB(int b, int col) const { return x + (long)(b >> 1) * kdim * nt + ((b & 1) ? na : 0) + col; }
+    __device__ long kstepA() const { return nt; }
+    __device__ long kstepB(int) const { return nt; }
+    __device__ bool rowok(int b, int row) const { return row < ((b & 1) ? nb : na); }
+    __device__ bool colok(int b, int col) const { return col < ((b & 1) ? nb : na); }
     __device__ void store(int b, int row, int col, double re, double im) const {
         S[(long)b * ld * ld + (long)row * ld + col] = cmake(re, im);
     }
@@ -364,6 +388,14 @@ struct QProb {
         const int ns = (b & 1) ? nb : na;
         return (k < ns && col < ns) ? Tt + (long)b * ld * ld + (long)col * ld + k : zero;
     }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int b) const { return (b & 1) ? nb : na; }
+    __device__ const cplx *baseA(int b, int row) const { return x + ((long)(b >> 1) * rows + row) * nt + ((b & 1) ? na : 0); }
+    __device__ const cplx *baseB(int b, int col) const { return Tt + (long)b * ld * ld + (long)col * ld; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return 1; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int b, int col) const { return col < ((b & 1) ? nb : na); }
     __device__ void store(int b, int row, int col, double re, double im) const {
         const int s = b & 1, ns = s ? nb : na;
         if (col < ns) out[((long)(b >> 1) * rows + row) * nt + (s ? na : 0) + col] = cmake(re, im);

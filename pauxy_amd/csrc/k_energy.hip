@@ -242,6 +242,16 @@ struct ExxQProb {
         if (k >= len[b] || col >= ncol[b]) return (const void *)zero;
         return RC ? (const void *)((const cplx *)B[b] + k * ldq[b] + col) : (const void *)((const double *)B[b] + k * ldq[b] + col);
     }
+    // incremental refill of the ring engine
+    static constexpr bool INCR = true;
+    using elemB = typename std::conditional<RC, cplx, double>::type;
+    __device__ int klimit(int b) const { return len[b]; }
+    __device__ const cplx *baseA(int b, int row) const { return ghalf + row * astride + goff[b]; }
+    __device__ const elemB *baseB(int b, int col) const { return (const elemB *)B[b] + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int b) const { return ldq[b]; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int b, int col) const { return col < ncol[b]; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         if (col < ncol[b]) Y[((long)b * rows + row) * ldy + col] = cmake(re, im);
     }
@@ -518,6 +528,9 @@ static int launch_exx_quadratic(afq_handle *h) {
         if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD, RC>(p, h->stream, h->zero_page)));
+#ifdef AFQ_TUNING
+        else if (afq_knob("AFQ_EXQ_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+#endif
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
     }
     AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));

@@ -27,6 +27,14 @@ struct FullGTProb {
     __device__ const double *ptrB(int b, int k, int col) const {
         return L + ((long)(n0 + b % nc) * M + k) * Mp + col;
     }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int b, int row) const { return G + (long)(b / nc) * M * M + row; }
+    __device__ const double *baseB(int b, int col) const { return L + (long)(n0 + b % nc) * M * Mp + col; }
+    __device__ long kstepA() const { return M; }
+    __device__ long kstepB(int) const { return Mp; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         T[((long)b * M + row) * M + col] = cmake(re, im);
     }

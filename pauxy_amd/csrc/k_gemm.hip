@@ -55,6 +55,14 @@ struct OneBodyProb {
     }
     __device__ const cplx *ptrA(int, int row, int k) const { return B1 + (long)row * kdim + k; }
     __device__ const cplx *ptrB(int b, int k, int col) const { return src + ((long)b * kdim + k) * nt + off + col; }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int, int row) const { return B1 + (long)row * kdim; }
+    __device__ const cplx *baseB(int b, int col) const { return src + (long)b * kdim * nt + off + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return nt; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         dst[((long)b * rows + row) * nt + off + col] = cmake(re, im);
     }
@@ -130,6 +138,15 @@ struct ForceBiasProb {
     __device__ const double *ptrB(int b, int k, int col) const {
         return k < len[b] ? rre + (q0[b] + k) * ldr + col : (const double *)zero;
     }
+    // incremental refill of the ring engine (real rchol)
+    static constexpr bool INCR = !RC;
+    __device__ int klimit(int b) const { return len[b]; }
+    __device__ const cplx *baseA(int b, int row) const { return ghalf + row * astride + q0[b]; }
+    __device__ const double *baseB(int b, int col) const { return rre + q0[b] * ldr + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return ldr; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
     const cplx *zero;
     int imag_pass;                   // second pass of a complex rchol on the real-B engine: out += i (A . Im B)
     __device__ void store(int b, int row, int col, double re, double im) const {
@@ -180,12 +197,13 @@ int k_force_bias_generic(afq_handle *h) {
             }
             else if (cfg == 2) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
+                // half-chunk pipelined loop (STAG = 2): 56 us at C3 against 58 (staggered halves) / 61 (plain loop)
 #ifdef AFQ_TUNING
                 if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
-                else if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
+                else if (afq_knob("AFQ_GEMM_STAG1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 1>(p, h->stream, h->zero_page)));
                 else
 #endif
-                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, true>(p, h->stream, h->zero_page)));
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
             }
             else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
@@ -234,6 +252,15 @@ struct VhsProb {
     __device__ cplx loadB(int, int k, int col) const { return cmake(hsT[(long)k * ldb + col], 0.0); }
     __device__ const cplx *ptrA(int, int row, int k) const { return xs + (long)row * kdim + k; }
     __device__ const double *ptrB(int, int k, int col) const { return hsT + (long)k * ldb + col; }
+    // incremental refill of the ring engine
+    static constexpr bool INCR = true;
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int, int row) const { return xs + (long)row * kdim; }
+    __device__ const double *baseB(int, int col) const { return hsT + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return ldb; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
     __device__ void store(int, int row, int col, double re, double im) const {
         // i*sqrt(dt)*(re + i im)
         const cplx v = cmake(-sqrt_dt * im, sqrt_dt * re);
@@ -313,6 +340,14 @@ struct TaylorProb {
     __device__ cplx loadB(int b, int k, int col) const { return tin[((long)b * kdim + k) * nt + off + col]; }
     __device__ const cplx *ptrA(int b, int row, int k) const { return vhs + b * vstride + (long)row * kdim + k; }
     __device__ const cplx *ptrB(int b, int k, int col) const { return tin + ((long)b * kdim + k) * nt + off + col; }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int) const { return kdim; }
+    __device__ const cplx *baseA(int b, int row) const { return vhs + b * vstride + (long)row * kdim; }
+    __device__ const cplx *baseB(int b, int col) const { return tin + (long)b * kdim * nt + off + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return nt; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         const long idx = ((long)b * rows + row) * nt + off + col;
         const cplx t = cmake(re * inv_n, im * inv_n);

@@ -23,12 +23,25 @@
 #pragma once
 #include "lds_dma.h"
 
+
 // K3M: complex x complex products by the 3-multiplication (Karatsuba) form
 //   P1 = Ar Br, P2 = Ai Bi, P3 = (Ar+Ai)(Br+Bi);  Cr = P1 - P2, Ci = P3 - P1 - P2
 // (3 real MFMAs per fragment pair instead of 4; error is bounded normwise, ~1e-16 |A||B|).
 // optional problem trait: static constexpr bool A_CONJ = true contracts with conj(A)
 template <class P, class = void> struct gemm_conj_a { static constexpr bool value = false; };
 template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static constexpr bool value = P::A_CONJ; };
+
+// optional problem trait: static constexpr bool INCR = true -- both operands are affine in the contraction index
+// (baseA(b,row) + k kstepA(), baseB(b,col) + k kstepB(b), valid for k < klimit(b), rowok(b,row), colok(b,col)): the refill then
+// advances one pointer per fragment instead of re-deriving address and bounds from (b, row, k) every chunk
+template <class P, class = void> struct gemm_incr { static constexpr bool value = false; };
+template <class P> struct gemm_incr<P, decltype((void)P::INCR)> { static constexpr bool value = P::INCR; };
+
+template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
+template <class P> struct gemm_incr_types<P, true> {
+    using A = decltype(((const P *)nullptr)->baseA(0, 0));
+    using B = decltype(((const P *)nullptr)->baseB(0, 0));
+};
 
 // KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
@@ -85,7 +98,56 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     const int b_half = lane >> 5, b_lp = lane & 31;
     const int b_kk = b_lp >> 3, b_cc = (b_lp & 7) * 2;
 
+    // incremental refill state (INCR problems): current source of every fragment this wave moves, its static validity
+    // and the contraction index the next refill starts at
+    using ptrA_t = typename gemm_incr_types<P, gemm_incr<P>::value>::A;
+    using ptrB_t = typename gemm_incr_types<P, gemm_incr<P>::value>::B;
+    ptrA_t curA[LPA];
+    ptrB_t curB[LPB];
+    bool okA[LPA], okB[LPB];
+    int kcur = 0, klim = 0;
+    if constexpr (gemm_incr<P>::value) {
+        klim = p.klimit(b);
+#pragma unroll
+        for (int t = 0; t < LPA; ++t) {
+            const int f = wave + t * NW, row = row0 + (f >> 1) * 16 + lr;
+            okA[t] = f < NA && row < p.rows && p.rowok(b, row);
+            curA[t] = p.baseA(b, okA[t] ? row : row0) + (long)(2 * lk + (f & 1)) * p.kstepA();
+        }
+#pragma unroll
+        for (int t = 0; t < LPB; ++t) {
+            const int f = wave + t * NW;
+            const int col = P::B_CPLX ? col0 + (f >> 1) * 16 + lr : col0 + f * 16 + b_cc;
+            const int kl = P::B_CPLX ? 2 * lk + (f & 1) : 2 * b_kk + b_half;
+            okB[t] = f < NB && col < p.cols && p.colok(b, col);
+            curB[t] = p.baseB(b, okB[t] ? col : col0) + (long)kl * p.kstepB(b);
+        }
+    }
     auto issue = [&](int c, int slot) {
+        if constexpr (gemm_incr<P>::value) {
+            // refills come strictly in chunk order (the call sites below), so `c` is implied by kcur
+#pragma unroll
+            for (int sub = 0; sub < KC; ++sub) {
+                unsigned char *dst = smem + (size_t)slot * CHUNK + (size_t)sub * SUB;
+#pragma unroll
+                for (int t = 0; t < LPA; ++t) {
+                    const int f = wave + t * NW;
+                    const bool ok = okA[t] && kcur + 2 * lk + (f & 1) < klim;
+                    glds16(ok ? (const void *)curA[t] : zero16, f < NA ? dst + f * 1024 : scratch);
+                    curA[t] += 8 * p.kstepA();
+                }
+#pragma unroll
+                for (int t = 0; t < LPB; ++t) {
+                    const int f = wave + t * NW;
+                    const int kl = P::B_CPLX ? 2 * lk + (f & 1) : 2 * b_kk + b_half;
+                    const bool ok = okB[t] && kcur + kl < klim;
+                    glds16(ok ? (const void *)curB[t] : zero16, f < NB ? dst + (NA + f) * 1024 : scratch);
+                    curB[t] += 8 * p.kstepB(b);
+                }
+                kcur += 8;
+            }
+            return;
+        }
 #pragma unroll
         for (int sub = 0; sub < KC; ++sub) {
         unsigned char *dst = smem + (size_t)slot * CHUNK + (size_t)sub * SUB;

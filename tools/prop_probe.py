@@ -21,7 +21,7 @@ dev.set_propagator(BH1, mf, 0.005)
 rng = numpy.random.RandomState(1)
 phi0 = t.psi[None] + 0.05 * (rng.rand(nw, 100, 50) + 1j * rng.rand(nw, 100, 50))
 xi = rng.normal(size=(nw, 500))
-dev.kernel_trace(True, [L.K_PROPAGATOR])
+dev.kernel_trace(True, [L.K_PROPAGATOR, L.K_VHS, L.K_FORCE_BIAS])
 for it in range(40):
     dev.set(L.F_PHI, phi0)
     dev.set(L.F_WEIGHT, numpy.ones(nw))
@@ -30,4 +30,9 @@ dev.sync()
 ms = numpy.array(dev.kernel_trace_get(L.K_PROPAGATOR))[10:]
 print("AFQ_PF_DBG=%s: %d launches, mean %.1f us, min %.1f us" % (os.environ.get("AFQ_PF_DBG", "0"), len(ms),
                                                                 float(numpy.mean(ms)) * 1e3, float(numpy.min(ms)) * 1e3))
+for name, kind in (('VHS GEMM', L.K_VHS), ('force-bias GEMM', L.K_FORCE_BIAS)):
+    x = numpy.array(dev.kernel_trace_get(kind))[10:]
+    if len(x):
+        print("  %s (AFQ_GEMM_DBG=%s): mean %.1f us, min %.1f us" % (name, os.environ.get("AFQ_GEMM_DBG", "0"),
+                                                                    float(numpy.mean(x)) * 1e3, float(numpy.min(x)) * 1e3))
 release_context(s, t)
