@@ -275,7 +275,31 @@ struct VhsProb {
     }
 };
 
+#ifdef AFQ_TUNING
+static void gemm_ts_dump(afq_handle *h, const char *what) {
+    static unsigned long long *buf = nullptr;
+    static int n = 0;
+    if (!afq_knob("AFQ_GEMM_TS")) return;
+    if (!buf) {
+        hipMalloc(&buf, 64 * 4 * 8);
+        hipMemset(buf, 0, 64 * 4 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(afq_gemm_ts), &buf, sizeof(buf));
+    }
+    if (++n != 40) return;
+    unsigned long long t[64 * 4];
+    hipStreamSynchronize(h->stream);
+    hipMemcpy(t, buf, sizeof(t), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 64; w += 9)
+        fprintf(stderr, "GEMM_TS %s wg %2d: loop %llu ticks = %.2f us of the 100 MHz clock (tick %.2f GHz; %llu chunks, %.0f ticks per chunk)  stores %llu\n",
+                what, w, t[4 * w + 1], t[4 * w] * 0.01, t[4 * w] ? t[4 * w + 1] / (t[4 * w] * 10.0) : 0.0, t[4 * w + 3],
+                t[4 * w + 3] ? (double)t[4 * w + 1] / t[4 * w + 3] : 0.0, t[4 * w + 2]);
+}
+#endif
+
 int k_vhs_generic(afq_handle *h) {
+#ifdef AFQ_TUNING
+    struct Dump { afq_handle *h; ~Dump() { gemm_ts_dump(h, "after VHS"); } } dump_{h};
+#endif
     VhsProb p;
     p.batch = 1; p.rows = h->nw; p.cols = h->hs_sym ? h->M * (h->M + 1) / 2 : h->M * h->M; p.kdim = h->K;
     p.xs = h->xs; p.hsT = h->hs_pot; p.ldb = h->ld_hs; p.out = h->vhs; p.sqrt_dt = h->sqrt_dt; p.alive = h->alive;
@@ -299,6 +323,9 @@ int k_vhs_generic(afq_handle *h) {
             static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
 #ifdef AFQ_TUNING
             if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_D8X")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
             else
 #endif
             if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));

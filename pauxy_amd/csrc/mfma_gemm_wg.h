@@ -37,6 +37,10 @@ template <class P> struct gemm_conj_a<P, decltype((void)P::A_CONJ)> { static con
 template <class P, class = void> struct gemm_incr { static constexpr bool value = false; };
 template <class P> struct gemm_incr<P, decltype((void)P::INCR)> { static constexpr bool value = P::INCR; };
 
+#ifdef AFQ_TUNING
+// tuning builds: when set (hipMemcpyToSymbol), work-groups 0-63 of every ring GEMM leave their s_memtime phases here
+__device__ unsigned long long *afq_gemm_ts = nullptr;
+#endif
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -47,8 +51,11 @@ template <class P> struct gemm_incr_types<P, true> {
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
 __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
+#ifdef AFQ_TUNING
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
     static_assert(P::A_CPLX, "A operand must be complex");
-    static_assert(D == 2 || D == 4, "ring depth must be 2 or 4");
+    static_assert(D == 2 || D == 4 || D == 8, "ring depth must be 2, 4 or 8");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = WM * WN;
     constexpr int RT = WM * TM, CT = WN * TN;              // tile rows / cols of the work-group tile
@@ -239,6 +246,9 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
         mfma_step(sub, 1);
     };
 
+#ifdef AFQ_TUNING
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int c = 0; c < D - 1; ++c) issue(c, c);
     // STAG: the second half of the waves (the SIMD partners of the first half when the work-group has 8 waves) cross
@@ -365,6 +375,9 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             mfma_sub(KC - 1);
         }
     }
+#ifdef AFQ_TUNING
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime(), tr2 = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (P::B_CPLX && K3M) {
 #pragma unroll
@@ -387,6 +400,14 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
                 const int col = wcol0 + j * 16 + lr;
                 if (row < p.rows && col < p.cols) p.store(b, row, col, accR[i][j][r], accI[i][j][r]);
             }
+#ifdef AFQ_TUNING
+    if (afq_gemm_ts && threadIdx.x == 0 && blockIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = afq_gemm_ts + blockIdx.x * 4;
+        o[0] = tr2 - tr1; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = (unsigned long long)nchunks;
+    }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
