@@ -81,6 +81,7 @@ void free_system(afq_handle *h) {
     k_free_atil(h->atil);
     dev_free(h->H1); dev_free(h->rH1);
     dev_free(h->iA_colptr); dev_free(h->iA_row); dev_free(h->iA_val); dev_free(h->ell_row); dev_free(h->ell_val); dev_free(h->ueg_rmap); dev_free(h->ueg_rows);
+    dev_free(h->ueg_kp); dev_free(h->ueg_pm); dev_free(h->ueg_koff); dev_free(h->ueg_poff);
     dev_free(h->iB_colptr); dev_free(h->iB_row); dev_free(h->iB_val);
     dev_free(h->iA_rowptr); dev_free(h->iA_col); dev_free(h->iA_rval);
     dev_free(h->iB_rowptr); dev_free(h->iB_col); dev_free(h->iB_rval);
@@ -437,6 +438,18 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
         h->ueg_nrows = (int)rows.size();
         if ((rc = dev_upload(h, &h->ueg_rmap, rmap.data(), (size_t)M))) return rc;
         if ((rc = dev_upload(h, &h->ueg_rows, rows.data(), rows.size()))) return rc;
+        // packed copies for energy_ueg_q_kernel (M and the staged row count fit 16 bits, the list lengths 31)
+        dev_free(h->ueg_kp); dev_free(h->ueg_pm); dev_free(h->ueg_koff); dev_free(h->ueg_poff);
+        if (M < 65536 && kpq_off[nq] < (1LL << 31) && pmq_off[nq] < (1LL << 31)) {
+            std::vector<int> kp((size_t)kpq_off[nq]), pm((size_t)pmq_off[nq]), ko((size_t)nq + 1), po((size_t)nq + 1);
+            for (int64_t z = 0; z < kpq_off[nq]; ++z) kp[z] = (rmap[kpq_i[z]] << 16) | (int)kpq_kpq[z];
+            for (int64_t z = 0; z < pmq_off[nq]; ++z) pm[z] = (rmap[pmq_i[z]] << 16) | (int)pmq_pmq[z];
+            for (int q = 0; q <= nq; ++q) { ko[q] = (int)kpq_off[q]; po[q] = (int)pmq_off[q]; }
+            if ((rc = dev_upload(h, &h->ueg_kp, kp.data(), kp.size() ? kp.size() : 1))) return rc;
+            if ((rc = dev_upload(h, &h->ueg_pm, pm.data(), pm.size() ? pm.size() : 1))) return rc;
+            if ((rc = dev_upload(h, &h->ueg_koff, ko.data(), ko.size()))) return rc;
+            if ((rc = dev_upload(h, &h->ueg_poff, po.data(), po.size()))) return rc;
+        }
     }
     if ((rc = dev_upload(h, &h->vqvec, vqvec, (size_t)nq))) return rc;
     if ((rc = dev_upload(h, &h->H1diag, H1diag, (size_t)2 * M))) return rc;

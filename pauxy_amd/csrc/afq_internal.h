@@ -79,6 +79,8 @@ struct afq_handle {
     int ell_len = 0; int *ell_row = nullptr; cplx *ell_val = nullptr;
     // rows of G the UEG energy gathers touch (the occupied orbitals of the trial): compact index per row or -1
     int ueg_nrows = 0; int *ueg_rmap = nullptr; int *ueg_rows = nullptr;
+    // the energy's index lists packed for the thread-per-q kernel: (row of the staged G << 16) | column, int32 offsets
+    int *ueg_kp = nullptr, *ueg_pm = nullptr, *ueg_koff = nullptr, *ueg_poff = nullptr;
     int64_t *kpq_off = nullptr, *kpq_i = nullptr, *kpq_kpq = nullptr;
     int64_t *pmq_off = nullptr, *pmq_i = nullptr, *pmq_pmq = nullptr;
     double *vqvec = nullptr; double vol = 1.0; double *H1diag = nullptr;

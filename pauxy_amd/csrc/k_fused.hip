@@ -77,8 +77,8 @@ __device__ inline void lds_barrier() {
 
 // NARROW: at most one column tile per spin (na, nb <= 16); a separate instantiation so that each carries only the
 // Taylor tile deals it uses (register allocation and code size of one variant do not tax the other)
-// FULL: every tile of the wide deal exists (M > 96, na, nb > 16; host-checked): the per-tile validity tests, which
-// cost a branch per tile and k-step inside the MFMA blocks, are compiled out.
+// FULL: every tile of the deal exists (wide: M > 96, na, nb > 16; narrow: 80 < M <= 96; host-checked): the per-tile
+// validity tests, which cost a branch per tile and k-step inside the MFMA blocks, are compiled out.
 template <bool NARROW, bool FULL>
 __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -222,12 +222,13 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     auto one_body = [&](auto nsl_tag, int slot0, bool to_global, auto real_tag, const int rt) __attribute__((always_inline)) {
         constexpr int NSL = decltype(nsl_tag)::value;
         constexpr bool BR = decltype(real_tag)::value;
+        constexpr int SS = (NARROW && FULL) ? 2 : 1;             // narrow + full: only the first column slot of a spin exists
         d4_t P1[NSL], P2[NSL], P3[NSL];
         bool cv[NSL];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
             P1[j] = (d4_t){0, 0, 0, 0}; P2[j] = (d4_t){0, 0, 0, 0}; P3[j] = (d4_t){0, 0, 0, 0};
-            const int cs = slot0 + j;
+            const int cs = slot0 + j * SS;
             cv[j] = rt < nrt && (cs & 1) < ((((cs >> 1) ? a.nb : a.na) + 15) >> 4);
         }
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             for (int ss = 0; ss < 2; ++ss) {
                 av[ss] = lds_read_frag(abase, ss);
 #pragma unroll
-                for (int j = 0; j < NSL; ++j) bv[j][ss] = lds_read_frag(bbase, j * 2 + ss);
+                for (int j = 0; j < NSL; ++j) bv[j][ss] = lds_read_frag(bbase, j * SS * 2 + ss);
             }
         };
         auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                             const int r = j * RPG + q;
                             if (r < NR) {
                                 if (r == 0) ay = lds_read_frag(abase, ys);
-                                else by[r - 1] = lds_read_frag(bbase, (r - 1) * 2 + ys);
+                                else by[r - 1] = lds_read_frag(bbase, (r - 1) * SS * 2 + ys);
                             }
                         }
                     }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 const unsigned abase = sl + rt * 2048 + lane * 16, bbase = tf_l + slot0 * 2048 + lane * 16;
                 a0 = lds_read_frag(abase, 0);
 #pragma unroll
-                for (int j = 0; j < NSL; ++j) b0[j] = lds_read_frag(bbase, j * 2);
+                for (int j = 0; j < NSL; ++j) b0[j] = lds_read_frag(bbase, j * SS * 2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             for (int c = 0; c < NCH; ++c) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NSL; ++j)
             if (cv[j]) {
-                const int cs = slot0 + j, sp = cs >> 1;
+                const int cs = slot0 + j * SS, sp = cs >> 1;
                 const int ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -379,6 +380,18 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             one_body(I1{}, h2, to_global, std::false_type{}, rt); one_body(I1{}, 2 + h2, to_global, std::false_type{}, rt);
         }
 #else
+        if (NARROW && FULL) {                // column slots 0 and 2 only (see SS in one_body)
+            using I1 = std::integral_constant<int, 1>;
+            if (a.same_b) {
+                if (a.b_real) one_body(I2{}, 0, to_global, std::true_type{}, wave);
+                else one_body(I2{}, 0, to_global, std::false_type{}, wave);
+            } else if (a.b_real) {
+                one_body(I1{}, 0, to_global, std::true_type{}, wave); one_body(I1{}, 2, to_global, std::true_type{}, wave);
+            } else {
+                one_body(I1{}, 0, to_global, std::false_type{}, wave); one_body(I1{}, 2, to_global, std::false_type{}, wave);
+            }
+            return;
+        }
         using I4 = std::integral_constant<int, 4>;
         if (a.same_b) {
             if (a.b_real) one_body(I4{}, 0, to_global, std::true_type{}, wave);
@@ -804,7 +817,14 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     if (a.t4) taylor4();
     else
 #endif
-    if (NARROW) {
+    if (NARROW && FULL) {
+        // six row tiles, one column tile per spin: waves 0-3 a pair of the row tiles 0-3, waves 4-7 one of the tiles 4, 5
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
+        else taylor(I1{}, I1{}, std::false_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
+    }
+    else if (NARROW) {
         // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
         // waves 4-7 the row tiles from 4 on: singly when there are six (3 tiles on every SIMD), as a pair + a single
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
@@ -848,12 +868,16 @@ int k_prop_fused(afq_handle *h) {
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
-    static size_t lds_set[3][AFQ_MAX_DEVICES] = {{0}, {0}, {0}};
+    static size_t lds_set[4][AFQ_MAX_DEVICES] = {{0}, {0}, {0}, {0}};
     const bool narrow = h->na <= 16 && h->nb <= 16;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
     // every tile of the wide deal present: row tiles 0-6 (waves 4-7 own tiles 4, 5, 6) and two column tiles per spin
     const bool full = !narrow && h->M > 96 && h->na > 16 && h->nb > 16 && PF_NW == 8 && !afq_knob("AFQ_PF_NOFULL");
-    if (narrow) {
+    const bool full_narrow = narrow && h->M > 80 && h->M <= 96 && PF_NW == 8 && !afq_knob("AFQ_PF_NOFULL");
+    if (full_narrow) {
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true, true>, lds, lds_set[3]));
+        AFQ_LAUNCH(h, (prop_fused_kernel<true, true>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
+    } else if (narrow) {
         AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true, false>, lds, lds_set[1]));
         AFQ_LAUNCH(h, (prop_fused_kernel<true, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
     } else if (full) {

@@ -290,8 +290,98 @@ __global__ __launch_bounds__(1024) void energy_ueg_kernel(const cplx *G, cplx *e
     }
 }
 
+// Thread-per-q variant of the staged kernel: the index lists are short (at most N entries per q-vector), so a wave per
+// q spends its time on dependent index loads and cross-lane reductions of mostly idle lanes (296 us at the C2 sizes:
+// 47 q-vectors per wave, one after the other).  Here every thread owns one q-vector: the packed lists (row of the staged
+// G, column) are read straight from the cached global arrays, all gathers go to LDS, nothing is reduced until the end.
+__global__ __launch_bounds__(1024) void energy_ueg_q_kernel(const cplx *G, cplx *energy, int M, int nq, const int *koff,
+                                                            const int *kp, const int *poff, const int *pm,
+                                                            const double *vqvec, double vol, const double *H1diag,
+                                                            const int *rows, int nrows) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double red[16];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const cplx *Gg[2] = {G + (long)w * 2 * M * M, G + (long)w * 2 * M * M + (long)M * M};
+    cplx *st = (cplx *)smem;                                     // [2][nrows][M]
+    for (int e = tid; e < 2 * nrows * M; e += (int)blockDim.x) {
+        const int s = e / (nrows * M), r = (e / M) % nrows, c = e % M;
+        st[e] = Gg[s][(long)rows[r] * M + c];
+    }
+    double ker = 0, kei = 0;
+    for (int e = tid; e < 2 * M; e += (int)blockDim.x) {
+        const int s = e / M, i = e % M;
+        const cplx g = Gg[s][(long)i * M + i];
+        ker += H1diag[e] * g.x; kei += H1diag[e] * g.y;
+    }
+    __syncthreads();
+    double per = 0, pei = 0;
+    for (int q = tid; q < nq; q += (int)blockDim.x) {
+        const int k0 = koff[q], nk = koff[q + 1] - k0, p0 = poff[q], np = poff[q + 1] - p0;
+        cplx gk[2], gp[2], gx[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const cplx *Gs = st + (long)s * nrows * M;
+            double ar = 0, ai = 0, br = 0, bi = 0, cr = 0, ci = 0;
+            for (int z = 0; z < nk; ++z) {
+                const int e = kp[k0 + z];
+                const cplx g = Gs[(e >> 16) * M + (e & 0xffff)];
+                ar += g.x; ai += g.y;
+            }
+            for (int z = 0; z < np; ++z) {
+                const int e = pm[p0 + z];
+                const cplx g = Gs[(e >> 16) * M + (e & 0xffff)];
+                br += g.x; bi += g.y;
+            }
+            // sum_{a,b} G[pmq_i[b], kpq[a]] * G[kpq_i[a], pmq[b]]
+            for (int ia = 0; ia < nk; ++ia) {
+                const int ea = kp[k0 + ia];
+                const int ra = (ea >> 16) * M, ca = ea & 0xffff;
+                for (int ib = 0; ib < np; ++ib) {
+                    const int eb = pm[p0 + ib];
+                    const cplx g1 = Gs[(eb >> 16) * M + ca];
+                    const cplx g2 = Gs[ra + (eb & 0xffff)];
+                    cr += g1.x * g2.x - g1.y * g2.y;
+                    ci += g1.x * g2.y + g1.y * g2.x;
+                }
+            }
+            gk[s] = cmake(ar, ai); gp[s] = cmake(br, bi); gx[s] = cmake(cr, ci);
+        }
+        // (Gkpq Gpmq - Gprod)_aa + (..)_bb + Gkpq_a Gpmq_b + Gkpq_b Gpmq_a
+        cplx t = csub(cmul(gk[0], gp[0]), gx[0]);
+        t = cadd(t, csub(cmul(gk[1], gp[1]), gx[1]));
+        t = cadd(t, cmul(gk[0], gp[1]));
+        t = cadd(t, cmul(gk[1], gp[0]));
+        const double f = vqvec[q] / (2.0 * vol);
+        per += f * t.x; pei += f * t.y;
+    }
+    double v[4] = {ker, kei, per, pei};
+    for (int k = 0; k < 4; ++k) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        double t = 0.0;
+        for (int i = 0; i < nwave; ++i) t += red[i];
+        v[k] = t;
+    }
+    if (tid == 0) {
+        energy[3 * w + 0] = cmake(v[0] + v[2], v[1] + v[3]);
+        energy[3 * w + 1] = cmake(v[0], v[1]);
+        energy[3 * w + 2] = cmake(v[2], v[3]);
+    }
+}
+
 int k_energy_ueg(afq_handle *h) {
     const size_t lds = sizeof(cplx) * 2 * (size_t)h->ueg_nrows * h->M;
+    if (lds <= 120 * 1024 && h->ueg_kp && !afq_knob("AFQ_UEG_WAVE_Q")) {
+        static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+        AFQ_HIP(h, afq_raise_lds((const void *)energy_ueg_q_kernel, lds, lds_set));
+        AFQ_LAUNCH(h, energy_ueg_q_kernel, dim3(h->nw), dim3(1024), lds, h->stream, h->G, h->energy, h->M, h->nq,
+                   h->ueg_koff, h->ueg_kp, h->ueg_poff, h->ueg_pm, h->vqvec, h->vol, h->H1diag, h->ueg_rows, h->ueg_nrows);
+        AFQ_POST(h);
+        return AFQ_OK;
+    }
     if (lds <= 120 * 1024) {
         static size_t lds_set[AFQ_MAX_DEVICES] = {0};
         AFQ_HIP(h, afq_raise_lds((const void *)energy_ueg_kernel<true>, lds, lds_set));

@@ -206,3 +206,44 @@ def test_exchange_algorithms_odd_sizes(M, K, na, nb, nw, cplx):
         dev.greens()
         close(dev.local_energy(), want)
         dev.close()
+
+
+@pytest.mark.parametrize("M,na,nb,onebody", [
+    (100, 25, 25, 'same-real'),      # wide deal, every tile present (prop_fused_kernel<false, true>)
+    (97, 17, 32, 'spin-complex'),    # the same with spin-dependent complex one-body matrices
+    (104, 30, 18, 'same-real'),
+    (93, 7, 7, 'same-real'),         # one column tile per spin, six row tiles (prop_fused_kernel<true, true>)
+    (81, 16, 3, 'spin-complex'),
+    (96, 9, 16, 'same-real'),
+    (70, 7, 5, 'same-real'),         # narrow, generic tile tests (prop_fused_kernel<true, false>)
+    (90, 20, 18, 'spin-complex'),    # wide, generic tile tests (prop_fused_kernel<false, false>)
+    (104, 16, 17, 'same-real'),      # wide with a one-column second tile
+])
+def test_fused_propagator_shape_classes(M, na, nb, onebody):
+    """One full step through every instantiation of the fused B exp(V) B kernel (tile-deal variants are chosen from
+    M, na, nb on the host) against the oracle, with dead walkers in between."""
+    K, nw = 24, 19
+    model, rng = build(M, K, na, nb, False, seed=11)
+    if onebody == 'spin-complex':
+        # any pair of matrices is a valid one-body propagator for the kernel and for the oracle alike
+        pert = 1e-3 * (rng.rand(2, M, M) + 1j * rng.rand(2, M, M))
+        model.BH1 = model.BH1 + pert
+    dev = make_device(model, nw)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    dev.set(L.F_PHI, phis)
+    w0 = numpy.ones(nw)
+    w0[2::5] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, na, nb) for p in phis]))
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, 0.3)
+    out_phi, out_w = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+    for i in range(nw):
+        if w0[i] == 0.0:
+            assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+            continue
+        w = ref.new_walker(model, phis[i])
+        ref.propagate_walker_phaseless(model, w, xi[i], 0.3)
+        close(out_phi[i], w['phi'])
+        close(out_w[i], w['weight'])
+    dev.close()
