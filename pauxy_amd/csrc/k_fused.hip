@@ -77,9 +77,10 @@ __device__ inline void lds_barrier() {
 
 // NARROW: at most one column tile per spin (na, nb <= 16); a separate instantiation so that each carries only the
 // Taylor tile deals it uses (register allocation and code size of one variant do not tax the other)
-// FULL: every tile of the deal exists (wide: M > 96, na, nb > 16; narrow: 80 < M <= 96; host-checked): the per-tile
-// validity tests, which cost a branch per tile and k-step inside the MFMA blocks, are compiled out.
-template <bool NARROW, bool FULL>
+// FULL = number of row tiles when every tile of the deal exists (wide: 5-7 row tiles, i.e. 64 < M <= 112 capped by the
+// M <= 104 of the kernel, and na, nb > 16; narrow: 6 row tiles; host-checked), else 0: the per-tile validity tests,
+// which cost a branch per tile and k-step inside the MFMA blocks, are compiled out.
+template <bool NARROW, int FULL>
 __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = blockIdx.x;
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2);
     }
     else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
+    else if (FULL >= 5) taylor(std::integral_constant<int, FULL >= 5 ? FULL - 4 : 1>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, FULL - 4);
     else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3);
 #endif
     if (a.order == 0) lds_barrier();
@@ -868,25 +870,26 @@ int k_prop_fused(afq_handle *h) {
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
-    static size_t lds_set[4][AFQ_MAX_DEVICES] = {{0}, {0}, {0}, {0}};
+    static size_t lds_set[6][AFQ_MAX_DEVICES] = {{0}, {0}, {0}, {0}, {0}, {0}};
     const bool narrow = h->na <= 16 && h->nb <= 16;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
-    // every tile of the wide deal present: row tiles 0-6 (waves 4-7 own tiles 4, 5, 6) and two column tiles per spin
-    const bool full = !narrow && h->M > 96 && h->na > 16 && h->nb > 16 && PF_NW == 8 && !afq_knob("AFQ_PF_NOFULL");
-    const bool full_narrow = narrow && h->M > 80 && h->M <= 96 && PF_NW == 8 && !afq_knob("AFQ_PF_NOFULL");
-    if (full_narrow) {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true, true>, lds, lds_set[3]));
-        AFQ_LAUNCH(h, (prop_fused_kernel<true, true>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
-    } else if (narrow) {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<true, false>, lds, lds_set[1]));
-        AFQ_LAUNCH(h, (prop_fused_kernel<true, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
-    } else if (full) {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false, true>, lds, lds_set[2]));
-        AFQ_LAUNCH(h, (prop_fused_kernel<false, true>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
-    } else {
-        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<false, false>, lds, lds_set[0]));
-        AFQ_LAUNCH(h, (prop_fused_kernel<false, false>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);
-    }
+    // every tile of the deal present: wide with 5-7 row tiles (waves 4-7 own the tiles from 4 on) and two column tiles
+    // per spin, or narrow with six row tiles
+    const int nrt = (h->M + 15) / 16;
+    const bool nofull = PF_NW != 8 || afq_knob("AFQ_PF_NOFULL");
+    const int full = nofull ? 0 : narrow ? (nrt == 6 ? 6 : 0) : (nrt >= 5 && h->na > 16 && h->nb > 16 ? nrt : 0);
+#define PF_LAUNCH_(NARROW_, FULL_, SLOT_)                                                                     \
+    do {                                                                                                      \
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<NARROW_, FULL_>, lds, lds_set[SLOT_]));      \
+        AFQ_LAUNCH(h, (prop_fused_kernel<NARROW_, FULL_>), dim3(h->nw), dim3(PF_NT), lds, h->stream, a);      \
+    } while (0)
+    if (narrow && full) PF_LAUNCH_(true, 6, 0);
+    else if (narrow) PF_LAUNCH_(true, 0, 1);
+    else if (full == 7) PF_LAUNCH_(false, 7, 2);
+    else if (full == 6) PF_LAUNCH_(false, 6, 3);
+    else if (full == 5) PF_LAUNCH_(false, 5, 4);
+    else PF_LAUNCH_(false, 0, 5);
+#undef PF_LAUNCH_
     AFQ_POST(h);
 #ifdef AFQ_TUNING
     if (a.ts && ++ts_launch == 30) {

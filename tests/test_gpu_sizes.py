@@ -209,15 +209,17 @@ def test_exchange_algorithms_odd_sizes(M, K, na, nb, nw, cplx):
 
 
 @pytest.mark.parametrize("M,na,nb,onebody", [
-    (100, 25, 25, 'same-real'),      # wide deal, every tile present (prop_fused_kernel<false, true>)
+    (100, 25, 25, 'same-real'),      # wide deal, every tile present (prop_fused_kernel<false, 7>)
     (97, 17, 32, 'spin-complex'),    # the same with spin-dependent complex one-body matrices
     (104, 30, 18, 'same-real'),
-    (93, 7, 7, 'same-real'),         # one column tile per spin, six row tiles (prop_fused_kernel<true, true>)
+    (93, 7, 7, 'same-real'),         # one column tile per spin, six row tiles (prop_fused_kernel<true, 6>)
     (81, 16, 3, 'spin-complex'),
     (96, 9, 16, 'same-real'),
-    (70, 7, 5, 'same-real'),         # narrow, generic tile tests (prop_fused_kernel<true, false>)
-    (90, 20, 18, 'spin-complex'),    # wide, generic tile tests (prop_fused_kernel<false, false>)
-    (104, 16, 17, 'same-real'),      # wide with a one-column second tile
+    (70, 7, 5, 'same-real'),         # narrow, generic tile tests (prop_fused_kernel<true, 0>)
+    (90, 20, 18, 'spin-complex'),    # wide, six row tiles (prop_fused_kernel<false, 6>)
+    (70, 30, 17, 'same-real'),       # wide, five row tiles (prop_fused_kernel<false, 5>)
+    (60, 20, 18, 'spin-complex'),    # wide, generic tile tests (prop_fused_kernel<false, 0>)
+    (104, 16, 17, 'same-real'),      # wide with a one-column second tile of one spin only: generic
 ])
 def test_fused_propagator_shape_classes(M, na, nb, onebody):
     """One full step through every instantiation of the fused B exp(V) B kernel (tile-deal variants are chosen from
