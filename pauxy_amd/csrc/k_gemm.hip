@@ -90,6 +90,10 @@ int k_onebody(afq_handle *h) {
             AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
             // large systems: 128 x 64 work-group tiles, 3M complex products
+#ifdef AFQ_TUNING
+            if (afq_knob("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            else
+#endif
             AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         } else {
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
@@ -406,6 +410,10 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             }
             if (!h->no_ring && M > 128 && p.cols > 32 && h->nw >= 64) {
                 // large systems: 128 x 64 work-group tiles, 3M complex products
+#ifdef AFQ_TUNING
+                if (afq_knob("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                else
+#endif
                 AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 continue;
             }
