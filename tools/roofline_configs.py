@@ -31,7 +31,7 @@ def work(name, c):
     M, na, nb, K, nw = c['M'], c['na'], c['nb'], c['K'], c['nw']
     nt = na + nb
     cx = 2.0 if c.get('cplx') else 1.0
-    if name.startswith('prop_fused_kernel'):
+    if 'prop_fused_kernel' in name:
         return 'mfma', 8.0 * M * M * nt * 8 * nw, 'flop', 'B exp(V) B: 2 + 6 products of M x M by M x (na+nb), 8 flops per complex MAC'
     if 'VhsProb' in name:
         cols = M * (M + 1) // 2 if c['kind'] == 'generic' else M * M
@@ -61,7 +61,7 @@ def work(name, c):
         return 'hbm', (2.0 * M * M * 16 + K * 16) * nw, 'B', 'reads G [2, M, M], writes vbias [K] per walker'
     if name.startswith('vhs_ueg'):
         return 'hbm', (K * 16 + M * M * 16) * nw, 'B', 'reads xs [K], writes VHS [M, M] per walker'
-    if name.startswith('void energy_ueg') or name.startswith('energy_ueg'):
+    if 'energy_ueg' in name:
         return 'hbm', (2.0 * M * M * 16) * nw, 'B', 'reads G [2, M, M] per walker'
     if 'greens_small_kernel<true>' in name:
         return 'hbm', (2.0 * M * nt * 16) * nw, 'B', 'reads phi, writes Ghalf per walker (latency bound: Gauss-Jordan)'
