@@ -285,12 +285,12 @@ static void gemm_ts_dump(afq_handle *h, const char *what) {
     static int n = 0;
     if (!afq_knob("AFQ_GEMM_TS")) return;
     if (!buf) {
-        hipMalloc(&buf, 64 * 4 * 8);
-        hipMemset(buf, 0, 64 * 4 * 8);
+        hipMalloc(&buf, (64 * 4 + 64) * 8);
+        hipMemset(buf, 0, (64 * 4 + 64) * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(afq_gemm_ts), &buf, sizeof(buf));
     }
     if (++n != 40) return;
-    unsigned long long t[64 * 4];
+    unsigned long long t[64 * 4 + 64];
     hipStreamSynchronize(h->stream);
     hipMemcpy(t, buf, sizeof(t), hipMemcpyDeviceToHost);
     for (int w = 0; w < 64; w += 9)
@@ -327,6 +327,7 @@ int k_vhs_generic(afq_handle *h) {
             static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
 #ifdef AFQ_TUNING
             if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8X")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 2>(p, h->stream, h->zero_page)));

@@ -50,7 +50,7 @@ template <class P> struct gemm_incr_types<P, true> {
 // KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
-__global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const void *zero16) {
+__global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_wg_kernel(P p, const void *zero16) {
 #ifdef AFQ_TUNING
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -67,7 +67,13 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     constexpr int NWAIT = (D - 2) * LPW;
     static_assert(NWAIT <= 63, "vmcnt field is 6 bits");
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // STAG == 3: the work-group carries NW extra LOADER waves (one per compute wave, i.e. one per SIMD partner slot) that
+    // do nothing but the ring refill; the compute waves run the pipelined loop without it.  An LDS-DMA instruction keeps
+    // its wave's instruction issue busy for 100+ cycles and only two or three MFMAs queue up ahead of it, so a compute
+    // wave that refills the ring itself idles the matrix pipe of its SIMD for most of that time when it is alone there.
+    const int wave_all = threadIdx.x >> 6;
+    const bool loader = STAG == 3 && wave_all >= WM * WN;
+    const int wave = loader ? wave_all - WM * WN : wave_all;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
     const int tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
@@ -249,8 +255,22 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
 #ifdef AFQ_TUNING
     const unsigned long long ts1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (STAG != 3 || loader) {
 #pragma unroll
-    for (int c = 0; c < D - 1; ++c) issue(c, c);
+        for (int c = 0; c < D - 1; ++c) issue(c, c);
+    }
+    if (STAG == 3 && loader) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(D - 1, (D - 1) & (D - 1));
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(c + D, (c + D) & (D - 1));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     // STAG: the second half of the waves (the SIMD partners of the first half when the work-group has 8 waves) cross
     // the chunk barrier in the MIDDLE of a chunk's MFMAs -- sub-step 1 of chunk c is multiplied right behind barrier
     // c + 1 from fragments already in registers, then the fragments of chunk c + 1 are read and its sub-step 0
@@ -261,7 +281,8 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
     // refilled (address arithmetic included) and the sub-step 0 fragments of chunk c + 1 are read.  The plain loop below
     // does refill, reads and the wait for them in a block behind the barrier with the matrix pipe idle, which only
     // works out when several waves share a SIMD; the small-output contractions of this library run one wave per SIMD.
-    if (STAG == 2 && KC == 1) {
+    if ((STAG == 2 || STAG == 3) && KC == 1) {
+        constexpr bool own_refill = STAG == 2;
         constexpr int NG = TM * TN, NR = TM + TN;
         constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;
         auto mfma_tile = [&](int i, int j, int s) __attribute__((always_inline)) {
@@ -298,6 +319,8 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             for (int g = 0; g < NG; ++g) {
                 mfma_tile(g / TN, g % TN, s);
                 __builtin_amdgcn_sched_barrier(0);
+                // (dealing the refill's DMA instructions over the group boundaries instead was measured 2 x SLOWER:
+                //  an LDS-DMA instruction issued between MFMAs stalls the wave for 300-900 cycles)
                 if (g == 0 && refill_c >= 0) issue(refill_c, refill_c & (D - 1));
                 if (fetch && (g < NG - 1 || NG == 1)) {
 #pragma unroll
@@ -309,9 +332,9 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (fetch) conj_set(rs);
         };
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        if (own_refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
-        issue(D - 1, (D - 1) & (D - 1));
+        if (own_refill) issue(D - 1, (D - 1) & (D - 1));
 #pragma unroll
         for (int r = 0; r < NR; ++r) read_one(ring_l, r, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -320,10 +343,10 @@ __global__ __launch_bounds__(WM *WN * 64) void mfma_gemm_wg_kernel(P p, const vo
             const bool more = c + 1 < nchunks;
             half(0, ring_l + (c & (D - 1)) * CHUNK, 1, true, -1);
             if (more) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+                if (own_refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            half(1, ring_l + ((c + 1) & (D - 1)) * CHUNK, 0, more, more ? c + D : -1);
+            half(1, ring_l + ((c + 1) & (D - 1)) * CHUNK, 0, more, (own_refill && more) ? c + D : -1);
         }
     } else
     if (STAG == 1 && KC == 1 && wave >= NW / 2) {
@@ -425,12 +448,13 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     }
     if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
     const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
+    static_assert(STAG != 3 || WM * WN <= 8, "compute + loader waves must fit one work-group");
     auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC, STAG>;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};   // one per template instantiation and device: set the cap once
     {
         hipError_t e = afq_raise_lds((const void *)kern, lds, lds_set);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, p, zero16);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN * (STAG == 3 ? 2 : 1)), lds, stream, p, zero16);
     return hipGetLastError();
 }
