@@ -38,6 +38,7 @@ struct PropFusedArgs {
     int vhs_upper;              // vhs holds only the upper triangle of the (symmetric) HS potential
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
+    int rem4;                   // M <= 100 in the full 7-row-tile deal: rows 96.. as one 4x4x4 unit (see taylor)
     const cplx *BH1;            // [2, M, M]
     const cplx *vhs;            // [nw, M, M]
     cplx *phi;                  // [nw, M, nt], updated in place
@@ -420,9 +421,22 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     // c + 1 are read and its sub-step 0 multiplied.  Its SIMD partner (wave - 4) reads its fragments right behind the
     // same barrier and multiplies afterwards, so the partner's LDS reads / ring refill run under this wave's MFMAs and
     // vice versa, instead of both waves doing the same thing at the same time.
-    auto taylor = [&](auto ni_tag, auto nj_tag, auto stag_tag, const int r0, const int c0, const int rcount) __attribute__((always_inline)) {
+    // REM (full 7-row-tile deal, M <= 100, waves 4-7): the rows 96 .. M-1 of the wave's column slot are not a padded
+    // seventh 16x16x4 tile but ONE v_mfma_f64_4x4x4 unit of 4 rows x 16 columns (16 cycles instead of 64 per MFMA):
+    // blk = 4-column group, so the B operand IS the T fragment the full tiles use and the A operand is the first four
+    // rows of the ring fragment of row tile 6, every 4-lane group reading the same 4 rows (lane layouts decoded with
+    // tools/mfma4x4_probe: A lane = 16 k + 4 blk + i, B lane = 16 k + 4 blk + j, D lane = 16 i + 4 blk + j).
+    auto taylor = [&](auto ni_tag, auto nj_tag, auto stag_tag, const int r0, const int c0, const int rcount,
+                      auto rem_tag) __attribute__((always_inline)) {
         constexpr int NI = decltype(ni_tag)::value, NJ = decltype(nj_tag)::value;
         constexpr bool STAG = decltype(stag_tag)::value;
+        constexpr bool REM = decltype(rem_tag)::value;
+        static_assert(!REM || (FULL == 7 && NJ == 1), "row-remainder unit: waves 4-7 of the full wide deal");
+        // D lane (i, blk, j) of the remainder unit = element (row 96 + i, column 4 blk + j = lane & 15) of slot c0
+        const unsigned rem_t = (unsigned)((((12 * 4 + c0) * 2 + ((lane >> 4) & 1)) * 1024) + (((lane >> 5) * 16) + (lane & 15)) * 16);
+        const unsigned rem_a = (unsigned)(6 * 2048 + ((lane >> 4) * 16 + (lane & 3)) * 16);   // A(96 + i, k) for every blk
+        double RR = 0.0, RI = 0.0;
+        if (REM) { const d2_t v = *(const d2_t *)(Tf + rem_t); RR = v[0]; RI = v[1]; }
         bool cv[NJ], rv[NI];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -467,6 +481,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 for (int j = 0; j < NJ; ++j) {
                     P1[i][j] = (d4_t){0, 0, 0, 0}; P2[i][j] = (d4_t){0, 0, 0, 0}; P3[i][j] = (d4_t){0, 0, 0, 0};
                 }
+            double Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;                   // remainder unit (REM)
             auto mfma_ss = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2], const int ss) __attribute__((always_inline)) {
 #ifdef AFQ_TUNING
                 if (a.dbg & 8) return;
@@ -501,30 +516,45 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 // chunk c are read, the wave crosses the barrier of chunk c + 1, and the sub-step 1 MFMAs run while the
                 // ring is refilled and the sub-step 0 fragments of chunk c + 1 are read -- one register set per sub-step
                 // instead of two per chunk (the 2 x 2 deal needs every register it can get: 96 product + 64 sum).
-                constexpr int NG = NI * NJ;                       // MFMA groups (one tile: 3 MFMAs) per sub-step
-                constexpr int NR = NI + NJ;                       // fragment reads per sub-step
+                constexpr int NG = NI * NJ + (REM ? 1 : 0);       // MFMA groups (one tile or unit: 3 MFMAs) per sub-step
+                constexpr int NR = NI + NJ + (REM ? 1 : 0);       // fragment reads per sub-step
                 constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;   // reads behind each group but the last
                 d2_t a0[NI], b0[NJ], a1[NI], b1[NJ];              // sub-step 0 / sub-step 1 fragments
-                auto half = [&](d2_t (&ax)[NI], d2_t (&bx)[NJ], d2_t (&ay)[NI], d2_t (&by)[NJ], const unsigned abase,
-                                const unsigned bbase, const int ys, const bool fetch, const bool refill)
-                    __attribute__((always_inline)) {
+                d2_t q0 = (d2_t){0.0, 0.0}, q1 = (d2_t){0.0, 0.0};   // remainder rows of the A operand, sub-step 0 / 1
+                auto half = [&](d2_t (&ax)[NI], d2_t (&bx)[NJ], d2_t &qx, d2_t (&ay)[NI], d2_t (&by)[NJ], d2_t &qy,
+                                const unsigned abase, const unsigned bbase, const unsigned qbase, const int ys,
+                                const bool fetch, const bool refill) __attribute__((always_inline)) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
+                    for (int gt = 0; gt < NG; ++gt) {
+                        if (REM && gt == 0) {                     // the short unit first: the long groups cover the reads
+                            Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0], bx[0][0], Q1, 0, 0, 0);
+                            Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[1], bx[0][1], Q2, 0, 0, 0);
+                            Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0] + qx[1], bx[0][0] + bx[0][1], Q3, 0, 0, 0);
+                        }
+                        const int g = REM ? (gt == 0 ? 0 : gt - 1) : gt;
                         const int i = g / NJ, j = g % NJ;
+                        if (!(REM && gt == 0))
+#ifdef AFQ_TUNING
+                        // timing ablation (wrong results): the MFMA load a hybrid 16x16x4 / 4x4x4 tiling would leave at most
+                        if (!((a.dbg & 4096) && ((NI == 2 && NJ == 2 && g == 3) || (NI == 3 && i == 2))))
+#endif
+                        {
                         P1[i][j] = mfma16(ax[i][0], bx[j][0], P1[i][j]);
                         P2[i][j] = mfma16(ax[i][1], bx[j][1], P2[i][j]);
                         P3[i][j] = mfma16(ax[i][0] + ax[i][1], bx[j][0] + bx[j][1], P3[i][j]);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (g == 0 && refill) issueA();
-                        if (g == 0 && !refill && !prepared) prepare();
-                        if (fetch && (g < NG - 1 || NG == 1)) {
+                        if (gt == 0 && refill) issueA();
+                        if (gt == 0 && !refill && !prepared) prepare();
+                        if (fetch && (gt < NG - 1 || NG == 1)) {
 #pragma unroll
                             for (int q = 0; q < RPG; ++q) {
-                                const int r = g * RPG + q;        // read r: the A tiles, then the B tiles
+                                const int r = gt * RPG + q;       // read r: the A tiles, the B tiles, the remainder rows
                                 if (r < NR) {
                                     if (r < NI) ay[r] = lds_read_frag(abase, r * 2 + ys);
-                                    else by[r - NI] = lds_read_frag(bbase, (r - NI) * 2 + ys);
+                                    else if (r < NI + NJ) by[r - NI] = lds_read_frag(bbase, (r - NI) * 2 + ys);
+                                    else qy = lds_read_frag(qbase, ys);
                                 }
                             }
                         }
@@ -539,6 +569,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     for (int i = 0; i < NI; ++i) a0[i] = lds_read_frag(abase, i * 2);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) b0[j] = lds_read_frag(bbase, j * 2);
+                    if (REM) q0 = lds_read_frag(sl + rem_a, 0);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 for (int c = 0; c < NCH; ++c) {
@@ -549,7 +580,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     asm volatile("s_memtime %0" : "=s"(t0));
 #endif
                     // sub-step 0 of chunk c; fetch its sub-step 1 fragments
-                    half(a0, b0, a1, b1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, 1, true, false);
+                    half(a0, b0, q0, a1, b1, q1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, sl + rem_a, 1, true, false);
 #ifdef AFQ_TUNING
                     asm volatile("s_memtime %0" : "=s"(t1));
 #endif
@@ -558,7 +589,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     asm volatile("s_memtime %0" : "=s"(t2));
 #endif
                     // sub-step 1 of chunk c; refill the ring, fetch the sub-step 0 fragments of chunk c + 1
-                    half(a1, b1, a0, b0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, 0, more, more);
+                    half(a1, b1, q1, a0, b0, q0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, sl + rem_a, 0, more, more);
 #ifdef AFQ_TUNING
                     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3));
                     if (a.ts && w == 0 && n == 3 && (wave & 3) == 0 && lane == 0) {
@@ -639,6 +670,11 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                                     last ? (d2_t){SR[i][j][r], SI[i][j][r]} : (d2_t){re, im};
                         }
                     }
+            if (REM) {
+                const double re = (Q1 - Q2) * inv_n, im = (Q3 - Q1 - Q2) * inv_n;
+                RR += re; RI += im;
+                *(d2_t *)(Tf + rem_t) = n == a.order ? (d2_t){RR, RI} : (d2_t){re, im};
+            }
             lds_barrier();                                       // T_n visible
         }
     };
@@ -810,8 +846,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         const int g = wave >> 2;
-        if (g & 1) taylor(I2{}, I1{}, std::true_type{}, 2 * g, wave & 3, g == 3 ? 1 : 2);
-        else taylor(I2{}, I1{}, std::false_type{}, 2 * g, wave & 3, 2);
+        if (g & 1) taylor(I2{}, I1{}, std::true_type{}, 2 * g, wave & 3, g == 3 ? 1 : 2, std::false_type{});
+        else taylor(I2{}, I1{}, std::false_type{}, 2 * g, wave & 3, 2, std::false_type{});
     }
 #else
 #ifdef AFQ_TUNING
@@ -822,8 +858,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // six row tiles, one column tile per spin: waves 0-3 a pair of the row tiles 0-3, waves 4-7 one of the tiles 4, 5
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
-        else taylor(I1{}, I1{}, std::false_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
+        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2, std::false_type{});
+        else taylor(I1{}, I1{}, std::false_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1, std::false_type{});
     }
     else if (NARROW) {
         // one column tile per spin (slots 0 and 2): nrt x 2 tiles.  Waves 0-3 take a pair of row tiles of rows 0-3,
@@ -831,13 +867,18 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // per spin when there are seven (4, 3, 4, 3) -- instead of the 5, 2, 5, 2 the wide deal below would give
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2);
-        else if (nrt <= 6) taylor(I2{}, I1{}, std::true_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1);
-        else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2);
+        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2, std::false_type{});
+        else if (nrt <= 6) taylor(I2{}, I1{}, std::true_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1, std::false_type{});
+        else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2, std::false_type{});
     }
-    else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2);
-    else if (FULL >= 5) taylor(std::integral_constant<int, FULL >= 5 ? FULL - 4 : 1>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, FULL - 4);
-    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3);
+    else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2, std::false_type{});
+    else if constexpr (FULL == 7) {
+        // rows 96 .. M-1 as one 4x4x4 unit when there are at most four of them (see REM in taylor)
+        if (a.rem4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 2, std::true_type{});
+        else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3, std::false_type{});
+    }
+    else if (FULL >= 5) taylor(std::integral_constant<int, FULL >= 5 ? FULL - 4 : 1>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, FULL - 4, std::false_type{});
+    else taylor(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, 4, wave - 4, 3, std::false_type{});
 #endif
     if (a.order == 0) lds_barrier();
 
@@ -867,6 +908,7 @@ int k_prop_fused(afq_handle *h) {
 #endif
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
+    a.rem4 = (h->M > 96 && h->M <= 100 && !afq_knob("AFQ_PF_NOREM")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
