@@ -1116,6 +1116,7 @@ int afq_walker_pack_bytes(afq_handle *h, int64_t *bytes) {
     size_t b = sizeof(cplx) * ((size_t)h->M * h->nt + 4) + sizeof(double) * 4;
     if (h->nbp > 0)   // phi_old + field history + FieldConfig.step + the two running weight factors
         b += sizeof(cplx) * ((size_t)h->M * h->nt + (size_t)h->nbp * h->K + 1) + sizeof(double) * 2;
+    if (h->rdm_on && h->G) b += sizeof(cplx) * (size_t)2 * h->M * h->M;     // walker.G (mixed one_rdm)
     *bytes = (int64_t)b;
     return AFQ_OK;
 }
@@ -1144,6 +1145,13 @@ static int pack_io(afq_handle *h, int iw, char *buf, bool pack) {
             else AFQ_HIP(h, hipMemcpyAsync(it.p, buf + off, it.b, hipMemcpyDeviceToDevice, h->stream));
             off += it.b;
         }
+    }
+    if (h->rdm_on && h->G) {
+        const size_t gb = sizeof(cplx) * (size_t)2 * h->M * h->M;
+        cplx *g = h->G + (size_t)iw * 2 * h->M * h->M;
+        if (pack) AFQ_HIP(h, hipMemcpyAsync(buf + off, g, gb, hipMemcpyDeviceToDevice, h->stream));
+        else AFQ_HIP(h, hipMemcpyAsync(g, buf + off, gb, hipMemcpyDeviceToDevice, h->stream));
+        off += gb;
     }
     return AFQ_OK;
 }
@@ -1179,6 +1187,7 @@ int afq_walkers_copy(afq_handle *h, int src, int dst) {
     if (h->nbp > 0) {
         C_(h->phi_old, per) C_(h->bp_hist, (size_t)h->nbp * h->K) C_(h->bp_ph, 1) C_(h->bp_cos, 1) C_(h->bp_n, 1)
     }
+    if (h->rdm_on && h->G) { C_(h->G, (size_t)2 * h->M * h->M) }      // walker.G is walker state for the mixed one_rdm
 #undef C_
     return AFQ_OK;
 }
@@ -1213,7 +1222,6 @@ int afq_estimates_rdm(afq_handle *h, int on) {
     int rc = need_ready(h, false);
     if (rc) return rc;
     if (h->ndet > 1 || h->hirsch) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "mixed one_rdm: single-determinant trial, continuous propagator");
-    if (k_comm_size(h) > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "mixed one_rdm: walker.G does not travel between ranks");
     h->rdm_on = on != 0;
     if (h->rdm_on && !h->rdm_acc) {
         const size_t n = (size_t)2 * h->M * h->M;

@@ -101,14 +101,16 @@ afq_comm_state *cs_of(afq_handle *h) { return (afq_comm_state *)h->comm; }
     } while (0)
 
 // ---- slot layout: the walker state that has to travel, in 16-byte units ------------------------------------
-// phi | ot ehyb phase eloc | (unscaled, detR) (log_detR, 0) | [ghalf | ovlp_new] | [phi_old | hist | bp_ph | (bp_cos, bp_n)]
+// phi | [ghalf] | [phi_old | hist] | [G] | ot ehyb phase eloc | (unscaled, detR) (log_detR, 0) | [ovlp_new] | [bp_ph | (bp_cos, bp_n)]
 struct SlotLayout {
-    long per, hist_per;
-    int with_greens, with_bp;
+    long per, hist_per, gsz;
+    int with_greens, with_bp, with_rdm;     // with_rdm: walker.G travels (mixed estimator with one_rdm: the accumulated
+                                            // G is whatever the walker carries, estimators/mixed.py:226-229)
     __host__ __device__ long size() const {
         long n = per + 6;
         if (with_greens) n += per + 1;
         if (with_bp) n += per + hist_per + 2;
+        if (with_rdm) n += gsz;
         return n;
     }
 };
@@ -120,7 +122,7 @@ struct PackArgs {
     const int *idx;          // send_idx / recv_idx [R][cap]
     cplx *buf;               // sbuf / rbuf [R][cap][slot]
     long slot;               // elements per slot (>= L.size(), fixed for the buffers)
-    cplx *phi, *ot, *ehyb, *phase, *eloc, *ghalf, *ovlp_new, *phi_old, *bp_hist, *bp_ph;
+    cplx *phi, *ot, *ehyb, *phase, *eloc, *ghalf, *ovlp_new, *phi_old, *bp_hist, *bp_ph, *G;
     double *unscaled, *detR, *log_detR, *bp_cos;
     int *bp_n;
 };
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
     mv(a.phi, per, off); off += per;
     if (a.L.with_greens) { mv(a.ghalf, per, off); off += per; }
     if (a.L.with_bp) { mv(a.phi_old, per, off); off += per; mv(a.bp_hist, a.L.hist_per, off); off += a.L.hist_per; }
+    if (a.L.with_rdm) { mv(a.G, a.L.gsz, off); off += a.L.gsz; }
     if (t0 == 0) {
         if (PACK) {
             s[off] = a.ot[w]; s[off + 1] = a.ehyb[w]; s[off + 2] = a.phase[w]; s[off + 3] = a.eloc[w];
@@ -284,8 +287,8 @@ void free_buffers(afq_comm_state *c) {
 
 SlotLayout max_layout(afq_handle *h) {
     SlotLayout L;
-    L.per = (long)h->M * h->nt; L.hist_per = (long)h->nbp * h->K;
-    L.with_greens = 1; L.with_bp = h->nbp > 0;
+    L.per = (long)h->M * h->nt; L.hist_per = (long)h->nbp * h->K; L.gsz = 2L * h->M * h->M;
+    L.with_greens = 1; L.with_bp = h->nbp > 0; L.with_rdm = (h->rdm_on && h->G) ? 1 : 0;
     return L;
 }
 
@@ -326,7 +329,7 @@ void fill_pack(afq_handle *h, PackArgs &p, bool with_greens, bool send) {
     p.idx = c->lists + 2 * c->nranks + (send ? 0 : c->nranks * c->cap);
     p.buf = send ? c->sbuf : c->rbuf; p.slot = (long)c->slot;
     p.phi = h->phi; p.ot = h->ot; p.ehyb = h->ehyb; p.phase = h->phase; p.eloc = h->eloc; p.ghalf = h->ghalf;
-    p.ovlp_new = h->ovlp_new; p.phi_old = h->phi_old; p.bp_hist = h->bp_hist; p.bp_ph = h->bp_ph;
+    p.ovlp_new = h->ovlp_new; p.phi_old = h->phi_old; p.bp_hist = h->bp_hist; p.bp_ph = h->bp_ph; p.G = h->G;
     p.unscaled = h->unscaled; p.detR = h->detR; p.log_detR = h->log_detR; p.bp_cos = h->bp_cos; p.bp_n = h->bp_n;
 }
 
@@ -605,6 +608,8 @@ int afq_estimates_allreduce(afq_handle *h, double *buf, int nest) {
     if (!buf) {     // the device accumulators of afq_estimates_update, in place: no host round trip
         afq_note_launch(h, "ncclAllReduce(estimates)");
         AFQ_NCCL(h, api, api->AllReduce(h->estimates, h->estimates, 2 * AFQ_EST_COUNT_, ncclDouble, ncclSum, c->nccl, h->stream));
+        if (h->rdm_on && h->rdm_acc)    // the one-body RDM sums are part of the same reduction in the reference (mixed.py:261)
+            AFQ_NCCL(h, api, api->AllReduce(h->rdm_acc, h->rdm_acc, (size_t)2 * h->M * h->M, ncclDouble, ncclSum, c->nccl, h->stream));
         return AFQ_OK;
     }
     double *tmp = nullptr;
@@ -636,6 +641,20 @@ int afq_estimates_allreduce_local(afq_handle **hs, int n) {
         hipSetDevice(hs[i]->device);
         AFQ_HIP(hs[i], hipMemcpyAsync(hs[i]->estimates, sum.data(), sizeof(double) * sum.size(), hipMemcpyHostToDevice, hs[i]->stream));
         AFQ_HIP(hs[i], hipStreamSynchronize(hs[i]->stream));
+    }
+    if (hs[0]->rdm_on && hs[0]->rdm_acc) {
+        const size_t m = (size_t)2 * hs[0]->M * hs[0]->M;
+        std::vector<double> rs(m, 0.0), ro(m);
+        for (int i = 0; i < n; ++i) {
+            if (!hs[i]->rdm_acc) AFQ_FAIL(hs[0], AFQ_ESTATE, "one_rdm switched on for some ranks only");
+            hipSetDevice(hs[i]->device);
+            AFQ_HIP(hs[i], hipMemcpy(ro.data(), hs[i]->rdm_acc, sizeof(double) * m, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < m; ++k) rs[k] += ro[k];
+        }
+        for (int i = 0; i < n; ++i) {
+            hipSetDevice(hs[i]->device);
+            AFQ_HIP(hs[i], hipMemcpy(hs[i]->rdm_acc, rs.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+        }
     }
     return AFQ_OK;
 }

@@ -112,6 +112,11 @@ class Mixed(object):
         if not everywhere:
             eshift = comm.bcast(eshift, root=0)
         self.eshift = eshift
+        if self.calc_one_rdm and comm.size > 1 and not getattr(comm, 'already_reduced', False):
+            # the RDM sums are part of the reference's one estimates vector (mixed.py:261); here they are a second buffer
+            red = numpy.zeros_like(self.rdm_acc)
+            comm.Reduce(self.rdm_acc, red, op=None, root=0)
+            self.rdm_acc[...] = red
         if comm.rank == 0:
             row = [step] + list(gs[:ns.time + 1])
             self.blocks.append(numpy.array(row))

@@ -181,8 +181,6 @@ class AFQMC(object):
             block_comm, other_comm = ReducedComm(self.comm), DeviceComm(dev, self.comm)
         else:
             block_comm = other_comm = self.comm
-        if dcomm and mixed.calc_one_rdm:
-            raise NotImplementedError("mixed one_rdm with the device communicator")
         mixed.arm_rdm(dev)
         if first_step == 1:
             if dcomm:       # stays in the device accumulators and is reduced with the first block

@@ -148,6 +148,44 @@ def test_multi_rank_loop_equals_one_rank(golden):
     close_all([one] + ranks)
 
 
+def test_mixed_one_rdm_travels_and_reduces(golden):
+    """estimators/mixed.py:226-229 across ranks: walker.G is walker state (it is accumulated stale between energy
+    evaluations), so it travels with a cloned walker, and the RDM sums are part of the block reduction (:261).
+    3 ranks x 5 walkers against one rank x 15 walkers."""
+    nranks, nw = 3, 5
+    model, one, ranks, rng = start(golden, nranks, nw, spread=0.8)
+    ntot = nranks * nw
+    for dev in [one] + ranks:
+        dev.estimates_rdm(True)
+    crossed = False
+    for step in range(1, 21):
+        xi = rng.normal(size=(ntot, one.K))
+        r = rng.rand()
+        one.propagate(xi, 0.0)
+        for i, rk in enumerate(ranks):
+            rk.propagate(xi[i * nw:(i + 1) * nw], 0.0)
+        if step % 2 == 0:
+            pix_one, _ = one.popcontrol_comb(r, ntot)
+            pix, _ = devmod.popcontrol_comb_local(ranks, r, ntot)
+            assert numpy.array_equal(pix, pix_one)
+            kill, clone = numpy.where(pix == 0)[0], numpy.where(pix > 1)[0]
+            crossed = crossed or any(c // nw != k // nw for c, k in zip(clone, kill))
+        for dev in [one] + ranks:
+            dev.estimates_update(step % 5 == 0)         # energy (and a fresh walker.G) every 5th step only
+        a, b = one.get(L.F_G), gather(ranks, L.F_G)
+        assert numpy.max(numpy.abs(a - b)) <= 1e-12 * numpy.max(numpy.abs(a))
+        if step % 10 == 0:
+            devmod.estimates_allreduce_local(ranks)
+            want = one.estimates_rdm_get(zero=True)
+            for rk in ranks:
+                got = rk.estimates_rdm_get(zero=True)
+                assert numpy.max(numpy.abs(got - want)) <= 1e-10 * numpy.max(numpy.abs(want))
+            for dev in [one] + ranks:
+                dev.estimates_get(zero=True)
+    assert crossed
+    close_all([one] + ranks)
+
+
 def test_back_propagation_state_travels(golden):
     nranks, nw, nbp = 2, 6, 4
     model, one, ranks, rng = start(golden, nranks, nw, spread=0.8)

@@ -28,7 +28,7 @@ def options(nw_total, walkers=None):
     o = {'qmc': {'timestep': 0.01, 'num_steps': NSTEPS, 'blocks': NBLOCKS, 'stabilise_freq': 5, 'pop_control_freq': 5,
                  'num_walkers': nw_total},
          'propagator': {'device_rng': False},
-         'estimators': {'mixed': {'energy_eval_freq': 2, 'verbose': False}}}
+         'estimators': {'mixed': {'energy_eval_freq': 2, 'verbose': False, 'one_rdm': True}}}
     if walkers:
         o['walkers'] = walkers
     return o
@@ -73,10 +73,12 @@ def drive(comm, nw_total, first, count, walkers=None):
             rec['pix'].append(numpy.array(psi.last_parent_ix).copy())
 
     afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
-    blocks = numpy.array(afqmc.estimators.estimators['mixed'].blocks) if comm is None or comm.rank == 0 else None
+    mixed = afqmc.estimators.estimators['mixed']
+    blocks = numpy.array(mixed.blocks) if comm is None or comm.rank == 0 else None
+    rdm = numpy.array(mixed.one_rdm) if comm is None or comm.rank == 0 else None
     phi = numpy.array([w.phi for w in afqmc.psi.walkers])
     return dict(weight=numpy.array(rec['weight']), ot=numpy.array(rec['ot']), pix=numpy.array(rec['pix']),
-                blocks=blocks, phi=phi, device_comm=bool(getattr(afqmc.psi, 'device_comm', False)),
+                blocks=blocks, rdm=rdm, phi=phi, device_comm=bool(getattr(afqmc.psi, 'device_comm', False)),
                 device_comm_error=getattr(afqmc.psi, 'device_comm_error', ''))
 
 
@@ -146,6 +148,9 @@ def compare(one, a, b):
         assert numpy.max(numpy.abs(got - one[key])) <= 1e-9 * max(1.0, numpy.max(numpy.abs(one[key]))), key
     got_phi = numpy.concatenate([a['phi'], b['phi']])
     assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
+    # mixed one-body RDM (estimators/mixed.py:226-229,279-283): walker.G travelled with the clones, the sums were reduced
+    assert a['rdm'].shape == one['rdm'].shape and a['rdm'].shape[0] == NBLOCKS
+    assert numpy.max(numpy.abs(a['rdm'] - one['rdm'])) <= 1e-9 * numpy.max(numpy.abs(one['rdm']))
     assert a['blocks'].shape == one['blocks'].shape
     assert numpy.max(numpy.abs(a['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
 
