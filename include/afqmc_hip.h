@@ -308,7 +308,9 @@ int afq_estimates_update(afq_handle *h, int eval_energy);
  * afq_estimates_update also adds sum_w weight_w Re(G_w) to a device accumulator f64[2, M, M], where G_w is
  * walker.G as the reference leaves it: the Green's function evaluated before the step's propagation
  * (propagation/continuous.py:245), refreshed on energy steps, cloned with the walker by the comb.
- * afq_estimates_rdm_get returns (and optionally zeroes) the accumulator.  One rank, single determinant.      */
+ * afq_estimates_rdm_get returns (and optionally zeroes) the accumulator.  Single determinant.  With a communicator
+ * walker.G travels with a walker cloned to another rank (exchange slot, afq_walker_pack) and afq_estimates_allreduce
+ * reduces the accumulator along with the ten estimators (the reference keeps them in one vector, mixed.py:261).  */
 int afq_estimates_rdm(afq_handle *h, int on);
 int afq_estimates_rdm_get(afq_handle *h, double *rdm_out /* f64[2, M, M] */, int zero);
 /* Synchronises the stream; also the place where a population that collapsed in an asynchronous comb is
