@@ -318,6 +318,8 @@ def main():
     dev.sync()
     dev.kernel_trace(False)
     nt = 2 * N
+    rc = numpy.asarray(trial._rchol)
+    fb_same_spin_block = bool(numpy.array_equal(rc[:N * M], rc[N * M:2 * N * M]))
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR,
          8.0 * M * M * nt * (6 + 2) * nw),
@@ -330,7 +332,11 @@ def main():
         # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted
         ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS,
          4.0 * (M * (M + 1) // 2) * K * nw),
-        ("mfma_gemm_wg_kernel<ForceBiasProb> (force bias)", L.K_FORCE_BIAS, 4.0 * K * nt * M * nw),
+        # force bias: both spins of an RHF-type trial contract with the same half-rotated Cholesky block, so the library
+        # contracts Ghalf_a + Ghalf_b once (distributivity: half the flops of the two-spin contraction the reference
+        # does, SURVEY 8d: 4 K (Na + Nb) M); the executed count is reported
+        ("mfma_gemm_wg_kernel<ForceBiasProb> (force bias)", L.K_FORCE_BIAS,
+         4.0 * K * (N if fb_same_spin_block else nt) * M * nw),
     ]
     rows = []
     for name, kind, flops in kernels:
@@ -342,6 +348,10 @@ def main():
         extra = {}
         if kind == L.K_EXCHANGE and dev.exchange_algorithm() == 2:
             ref_flops = exchange_flops_per_walker(M, K, N, N) * nw
+            extra = {"reference_formulation_flops_per_launch": ref_flops,
+                     "effective_vs_reference_formulation": ref_flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        if kind == L.K_FORCE_BIAS and fb_same_spin_block:
+            ref_flops = 4.0 * K * nt * M * nw
             extra = {"reference_formulation_flops_per_launch": ref_flops,
                      "effective_vs_reference_formulation": ref_flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
         rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg, **extra,

@@ -164,6 +164,7 @@ struct afq_handle {
     double *xi = nullptr;           // [nw, K]
     int fb_split = 1;               // contraction slices of the force-bias GEMM
     cplx *vbias = nullptr;          // [fb_split*2, nw, K] partial per-spin Coulomb vectors X_a, X_b
+    cplx *ghalf_sum = nullptr;      // [nw, na*M] Ghalf_a + Ghalf_b when both spins share rchol (force bias on half the contraction)
     cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
     cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
     cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag

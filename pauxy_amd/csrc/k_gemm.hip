@@ -182,11 +182,43 @@ static void fill_force_bias(ForceBiasProb<RC> &p, afq_handle *h) {
     p.imag_pass = 0;
 }
 
+__global__ void ghalf_sum_kernel(const cplx *ghalf, cplx *out, long half, long n) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const long w = e / half, q = e % half;
+    const cplx a = ghalf[w * 2 * half + q], b = ghalf[w * 2 * half + half + q];
+    out[e] = cmake(a.x + b.x, a.y + b.y);
+}
+
+// Both spins contract with the SAME half-rotated Cholesky block (RHF-type trial: rchol_same, checked bitwise at upload):
+// sum_q R[q,k] Ga[q] + sum_q R[q,k] Gb[q] = sum_q R[q,k] (Ga + Gb)[q] -- half the contraction.  The 2 * nsplit output
+// partials keep their layout (every consumer sums all of them): they become 2 * nsplit slices of the one contraction.
+static bool fb_use_sum(afq_handle *h) {
+    return h->rchol_same && h->rchol_real && h->ndet == 1 && h->na == h->nb && h->nw > 32 && !h->no_ring &&
+           !afq_knob("AFQ_FB_NOSUM");
+}
+
 int k_force_bias_generic(afq_handle *h) {
     if (2 * h->fb_split > FB_MAX_BATCH) AFQ_FAIL(h, AFQ_EINVAL, "force-bias split too large");
     if (h->rchol_real) {
         ForceBiasProb<false> p;
         fill_force_bias(p, h);
+        if (fb_use_sum(h)) {
+            const long half = (long)h->na * h->M, n = half * h->nw;
+            if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)n));
+            AFQ_LAUNCH(h, ghalf_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ghalf,
+                       h->ghalf_sum, half, n);
+            AFQ_POST(h);
+            const int ns2 = 2 * h->fb_split;
+            const long per = (half + ns2 - 1) / ns2;
+            int kmax = 0;
+            for (int b = 0; b < ns2; ++b) {
+                long l = half - b * per; if (l > per) l = per; if (l < 0) l = 0;
+                p.q0[b] = b * per; p.len[b] = (int)l;
+                if (l > kmax) kmax = (int)l;
+            }
+            p.kdim = kmax; p.ghalf = h->ghalf_sum; p.astride = half;
+        }
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kMixedTiles, 5);
         if (h->nw > 32 && !h->no_ring) {
             // work-group tile 64 walkers x 64 fields (cfg 2), operands shared through the LDS ring.  Measured at C3

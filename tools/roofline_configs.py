@@ -37,8 +37,10 @@ def work(name, c):
         cols = M * (M + 1) // 2 if c['kind'] == 'generic' else M * M
         return 'mfma', 4.0 * cols * K * nw, 'flop', 'HS potential, packed symmetric columns'
     if 'ForceBiasProb<false>' in name:
-        # real-B engine: a complex rchol runs it twice (Re, Im), each launch a real-by-complex product
-        return 'mfma', 4.0 * K * nt * M * nw, 'flop', 'force bias / Coulomb vectors (one real-B pass)'
+        # real-B engine: a complex rchol runs it twice (Re, Im), each launch a real-by-complex product; a single
+        # real RHF-type determinant contracts Ghalf_a + Ghalf_b once (both spins share the rchol block)
+        rows = na if (c.get('ndet', 1) == 1 and not c.get('cplx') and na == nb) else nt
+        return 'mfma', 4.0 * K * rows * M * nw, 'flop', 'force bias / Coulomb vectors (one real-B pass; spin-summed Ghalf when both spins share rchol)'
     if 'ForceBiasProb' in name:
         return 'mfma', 4.0 * cx * K * nt * M * nw, 'flop', 'force bias / Coulomb vectors'
     if 'ExxQProb' in name:
