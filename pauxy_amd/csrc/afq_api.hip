@@ -559,6 +559,9 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
             const long wgt = (long)((nw + 63) / 64) * ((h->K + 63) / 64) * 2;
             sp = (int)std::max(1L, std::min(16L, (512 + wgt - 1) / wgt));
         }
+        // both spins share the Cholesky block: the contraction runs once over Ghalf_a + Ghalf_b (k_force_bias_generic),
+        // half as long -- measured at C3: 4 slices (8 partials for fields_kernel to add) beat 8 by 1 % of the step
+        if (h->rchol_same && h->rchol_real && h->ndet == 1 && h->na == h->nb && nw > 32 && sp > 1) sp = (sp + 1) / 2;
         if (afq_knob("AFQ_FB_SPLIT")) sp = atoi(afq_knob("AFQ_FB_SPLIT"));
         const int nmax = std::max(h->na, h->nb) * h->M;
         while (sp > 1 && nmax / sp < 64) --sp;
