@@ -326,8 +326,9 @@ def main():
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
         # GEMM per spin) executes 4 (N M)^2 flops per spin and walker -- K / M = 5 times fewer than the
         # T-intermediate formulation of the reference (4 K M N^2); both counts are reported
-        (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g)", L.K_EXCHANGE,
-          4.0 * 2 * (N * M) ** 2 * nw) if dev.exchange_algorithm() == 2 else
+        # (Atil is symmetric: the library stores its upper triangle and contracts only that -- NM (NM + 1) / 2 pairs)
+        (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g, upper triangle)",
+          L.K_EXCHANGE, 4.0 * 2 * (N * M) * (N * M + 1) / 2 * nw) if dev.exchange_algorithm() == 2 else
          ("exx_kernel (Cholesky exchange energy, T intermediate)", L.K_EXCHANGE, exchange_flops_per_walker(M, K, N, N) * nw)),
         # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted
         ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS,

@@ -242,6 +242,13 @@ struct ExxQProb {
         if (k >= len[b] || col >= ncol[b]) return (const void *)zero;
         return RC ? (const void *)((const cplx *)B[b] + k * ldq[b] + col) : (const void *)((const double *)B[b] + k * ldq[b] + col);
     }
+    // Atil is stored as its upper triangle times two (diagonal once): rows beyond the last column of a tile are zero
+    static constexpr bool KCUT = true;
+    long k0[EXQ_MAX_BATCH];           // first row of Atil_s the slice contracts
+    __device__ int kcut(int b, int col0, int ncols) const {
+        const long need = (long)col0 + ncols - k0[b];
+        return need <= 0 ? 0 : (need < len[b] ? (int)need : len[b]);
+    }
     // incremental refill of the ring engine
     static constexpr bool INCR = true;
     using elemB = typename std::conditional<RC, cplx, double>::type;
@@ -311,9 +318,15 @@ __global__ __launch_bounds__(256) void atilde_build_kernel(const double *Rre, co
             const int r = tr + ty * 4 + u, c = tc + tx * 4 + v;
             if (r >= NM || c >= NM) continue;
             const int i = r / M, p = r % M, j = c / M, q = c % M;
-            const long dst = ((long)j * M + p) * ldo + (long)i * M + q;
-            if (RC) ((cplx *)out_v)[dst] = cmake(ar[u][v], ai[u][v]);
-            else ((double *)out_v)[dst] = ar[u][v];
+            // the permuted matrix Q[(j,p),(i,q)] = A[(i,p),(j,q)] is symmetric (A = R R^T is), so g^T Q g needs the upper
+            // triangle only: stored as 2 Q above the diagonal, Q on it, zero (the memset) below -- the GEMM then skips
+            // the rows below the diagonal block of a column tile (KCUT): half the flops of the evaluation
+            const long qa = (long)j * M + p, qb = (long)i * M + q;
+            if (qa > qb) continue;
+            const double f = qa < qb ? 2.0 : 1.0;
+            const long dst = qa * ldo + qb;
+            if (RC) ((cplx *)out_v)[dst] = cmake(f * ar[u][v], f * ai[u][v]);
+            else ((double *)out_v)[dst] = f * ar[u][v];
         }
 }
 
@@ -500,17 +513,23 @@ static int launch_exx_quadratic(afq_handle *h) {
     for (int b = 0; b < 2 * S; ++b) {
         const int s = b / S, sl = b % S;
         const long tot = s == 0 ? nma : nmb;
-        if (tot == 0) { p.goff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; continue; }
+        if (tot == 0) { p.goff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; p.k0[b] = 0; continue; }
         const long ldq = (tot + 1) & ~1L;
-        long per = (tot + S - 1) / S;
-        per = (per + 7) & ~7L;                              // whole k-chunks per slice
-        long k0 = sl * per, l = tot - k0;
-        if (l > per) l = per;
+        // slices of EQUAL WORK on the triangular operand: row a meets tot - a columns, so the boundaries sit at
+        // tot (1 - sqrt(1 - s / S)) (rounded to whole k-chunks); every slice is one batch = one XCD's share
+        auto bound = [&](int x) -> long {
+            if (x <= 0) return 0;
+            if (x >= S) return tot;
+            long r = (long)((double)tot * (1.0 - std::sqrt(1.0 - (double)x / S)));
+            r = (r + 7) & ~7L;
+            return r > tot ? tot : r;
+        };
+        long k0 = bound(sl), l = bound(sl + 1) - k0;
         if (l < 0) { l = 0; k0 = 0; }
         p.goff[b] = (s ? nma : 0) + k0;
         p.len[b] = (int)l; p.ncol[b] = (int)tot;
         p.B[b] = h->rchol_real ? (const void *)((const double *)h->atil[s] + k0 * ldq) : (const void *)((const cplx *)h->atil[s] + k0 * ldq);
-        p.ldq[b] = ldq;
+        p.ldq[b] = ldq; p.k0[b] = k0;
         if (l > kmax) kmax = (int)l;
     }
     p.kdim = kmax;

@@ -41,6 +41,10 @@ template <class P> struct gemm_incr<P, decltype((void)P::INCR)> { static constex
 // tuning builds: when set (hipMemcpyToSymbol), work-groups 0-63 of every ring GEMM leave their s_memtime phases here
 __device__ unsigned long long *afq_gemm_ts = nullptr;
 #endif
+// optional problem trait: static constexpr bool KCUT = true -- kcut(b, col0, ncols) is the contraction length the work-group
+// tile at columns [col0, col0 + ncols) of batch b needs (<= kdim; B is zero beyond it for these columns: triangular B)
+template <class P, class = void> struct gemm_kcut { static constexpr bool value = false; };
+template <class P> struct gemm_kcut<P, decltype((void)P::KCUT)> { static constexpr bool value = P::KCUT; };
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -88,6 +92,8 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
         const int rem = (int)(t % per_batch);
         if (MAP == MAP_BATCH_XCD_ROWS) { tn = rem / tiles_m; tm = rem % tiles_m; }
         else { tm = rem / tiles_n; tn = rem % tiles_n; }
+        // triangular B: the contraction grows with the column tile -- longest work-groups first, the short ones fill the tail
+        if (gemm_kcut<P>::value) tn = tiles_n - 1 - tn;
     } else if (MAP == MAP_COLPANEL_XCD) {
         // single batch: work-groups are dealt round-robin to the 8 XCDs, so XCD x takes the column panels
         // x, x+8, ... with ALL their row tiles: a B panel (and its slice of the output) stays in one L2
@@ -107,7 +113,9 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     const int lr = lane & 15, lk = lane >> 4;
     unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
     const unsigned ring_l = lds_addr(smem);
-    const int nchunks = (p.kdim + 8 * KC - 1) / (8 * KC);
+    int kdim_wg = p.kdim;
+    if constexpr (gemm_kcut<P>::value) kdim_wg = p.kcut(b, col0, 16 * CT);
+    const int nchunks = (kdim_wg + 8 * KC - 1) / (8 * KC);
     const int b_half = lane >> 5, b_lp = lane & 31;
     const int b_kk = b_lp >> 3, b_cc = (b_lp & 7) * 2;
 

@@ -44,7 +44,8 @@ def work(name, c):
     if 'ForceBiasProb' in name:
         return 'mfma', 4.0 * cx * K * nt * M * nw, 'flop', 'force bias / Coulomb vectors'
     if 'ExxQProb' in name:
-        return 'mfma', 4.0 * cx * ((na * M) ** 2 + (nb * M) ** 2) * nw, 'flop', 'exchange energy, quadratic form (per determinant)'
+        tri = lambda n: n * (n + 1) / 2.0
+        return 'mfma', 4.0 * cx * (tri(na * M) + tri(nb * M)) * nw, 'flop', 'exchange energy, quadratic form on the upper triangle of Atil (per determinant)'
     if name.startswith('void exx_kernel'):
         return 'mfma', 4.0 * cx * K * M * (na * na + nb * nb) * nw, 'flop', 'exchange energy, T intermediate (per determinant)'
     if 'TaylorProb' in name:
