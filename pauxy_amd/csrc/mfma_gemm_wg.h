@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     // do nothing but the ring refill; the compute waves run the pipelined loop without it.  An LDS-DMA instruction keeps
     // its wave's instruction issue busy for 100+ cycles and only two or three MFMAs queue up ahead of it, so a compute
     // wave that refills the ring itself idles the matrix pipe of its SIMD for most of that time when it is alone there.
-    const int wave_all = threadIdx.x >> 6;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS-DMA targets (M0) stay in SGPRs
     const bool loader = STAG == 3 && wave_all >= WM * WN;
     const int wave = loader ? wave_all - WM * WN : wave_all;
     const int wm = wave / WN, wn = wave % WN;
