@@ -352,7 +352,9 @@ int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
  * live roofline measurement over its timed region.  afq_kernel_trace(h, 1)
  * clears and starts recording every kind (up to 4096 launches per kind),
  * (h, 2 << kind | ...) only the selected kinds (an event pair costs a few
- * microseconds of pipeline bubble per launch), (h, 0) stops.                   */
+ * microseconds of pipeline bubble per launch), (h, 0) stops.
+ * afq_kernel_trace_stride(h, kind, n): only every n-th launch of that kind is timed (n >= 1, default 1), so that
+ * sampling inside a timed region costs 1 / n of those bubbles.                                                  */
 #define AFQ_K_PROPAGATOR 0   /* fused B exp(V) B kernel (k_fused.hip)          */
 #define AFQ_K_EXCHANGE 1     /* Cholesky exchange-energy kernel (k_energy.hip) */
 #define AFQ_K_VHS 2          /* HS potential GEMM                              */
@@ -360,6 +362,7 @@ int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
 #define AFQ_K_GREENS 4       /* Green's function kernel (N <= 45 path)         */
 #define AFQ_K_COUNT 5
 int afq_kernel_trace(afq_handle *h, int on);
+int afq_kernel_trace_stride(afq_handle *h, int kind, int stride);
 int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int *n_out);
 
 #ifdef __cplusplus

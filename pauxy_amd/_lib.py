@@ -100,6 +100,7 @@ SIGNATURES = {
     "afq_set_exchange_algorithm": [_h, c_int],
     "afq_exchange_algorithm": [_h, POINTER(c_int)],
     "afq_kernel_trace": [_h, c_int],
+    "afq_kernel_trace_stride": [_h, c_int, c_int],
     "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],
 }
 

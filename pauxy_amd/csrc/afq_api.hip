@@ -1598,7 +1598,13 @@ int afq_kernel_trace(afq_handle *h, int on) {
     if (!h) return AFQ_EINVAL;
     // on == 1: every kind; on > 1: bit (k + 1) selects kind k, e.g. 2 = AFQ_K_PROPAGATOR only; 0: off
     h->ktrace_mask = on == 1 ? ~0u : on > 1 ? (unsigned)on >> 1 : 0u;
-    if (on) for (int k = 0; k < AFQ_K_COUNT; ++k) h->ktrace_used[k] = 0;
+    if (on) for (int k = 0; k < AFQ_K_COUNT; ++k) { h->ktrace_used[k] = 0; h->ktrace_seen[k] = 0; }
+    return AFQ_OK;
+}
+
+int afq_kernel_trace_stride(afq_handle *h, int kind, int stride) {
+    if (!h || stride < 1 || kind < 0 || kind >= AFQ_K_COUNT) return AFQ_EINVAL;
+    h->ktrace_stride[kind] = stride;
     return AFQ_OK;
 }
 

@@ -185,6 +185,7 @@ struct afq_handle {
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
+    int ktrace_stride[AFQ_K_COUNT] = {1, 1, 1, 1, 1}, ktrace_seen[AFQ_K_COUNT] = {0, 0, 0, 0, 0};   // every n-th launch of a kind is timed
     cplx *estimates = nullptr;      // [10]
     // Mixed estimator with one_rdm: True (estimators/mixed.py:226-229): G then is per-walker STATE (walker.G: the
     // Green's function the walker last evaluated -- before the step's propagation, or at an energy evaluation),
@@ -311,6 +312,7 @@ struct KernelTrace {
     afq_handle *h; int kind, idx;
     KernelTrace(afq_handle *h_, int k) : h(h_), kind(k), idx(-1) {
         if (!(h->ktrace_mask >> k & 1) || h->ktrace_used[k] >= 4096) return;
+        if (h->ktrace_seen[k]++ % h->ktrace_stride[k]) return;
         idx = h->ktrace_used[k];
         std::vector<hipEvent_t> &ev = h->ktrace_ev[k];
         while ((int)ev.size() < 2 * idx + 2) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }

@@ -428,6 +428,10 @@ class AfqDevice(object):
             arg = sum(2 << int(k) for k in kinds)
         self._ck(self.lib.afq_kernel_trace(self.h, arg))
 
+    def kernel_trace_stride(self, kind, stride):
+        """Time only every ``stride``-th launch of ``kind`` (an event pair costs a few microseconds of pipeline bubble)."""
+        self._ck(self.lib.afq_kernel_trace_stride(self.h, int(kind), int(stride)))
+
     def kernel_trace_get(self, kind, max_n=4096):
         """Durations [ms] of the traced launches of kernel ``kind`` (_lib.K_*)."""
         out = numpy.zeros(max_n, dtype=numpy.float64)
