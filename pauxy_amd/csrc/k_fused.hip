@@ -5,13 +5,17 @@
 // matrix never leaves the CU between the 2 + order + 2 matrix products:
 //   * T (the current right-hand operand, M x (na+nb) complex) lives in LDS in
 //     MFMA B-fragment order: [k-chunk of 8][column-tile slot a0 a1 b0 b1][sub-step][64 lanes x 16 B]
-//   * the running Taylor sum lives in registers (waves 0-3 own 2 x 2 tiles, waves 4-7 own 3 x 1: 7 per SIMD)
+//   * the running Taylor sum lives in registers (waves 0-3 own 2 x 2 tiles, waves 4-7 own 3 x 1: 7 per SIMD;
+//     for M <= 100 the third tile of waves 4-7 is one v_mfma_f64_4x4x4 unit of 4 rows x 16 columns instead)
 //   * the left operands (BH1[0], BH1[1], VHS[w] x order, BH1[0], BH1[1]) stream through a
 //     3-slot LDS ring as ONE continuous sequence of k-chunks filled by global_load_lds
 //     (A-fragment order), so the pipeline never drains between products
 //   * complex products use the 3-multiplication form (see mfma_gemm_wg.h); when BH1 has no imaginary part
 //     (real trial and real Cholesky vectors: the usual case) the four one-body products need only the two
 //     real-by-complex multiplications
+//   * shapes whose tile deal has no holes (template FULL) run a half-chunk pipeline in which every non-MFMA
+//     instruction -- ring refill, fragment reads, address arithmetic -- sits between two MFMA groups of the
+//     same wave; the other shapes run a generic loop with per-tile validity tests
 // One raw s_barrier per k-chunk; two more per product to hand the result back into T.
 // Replaces 2 x 2 one-body launches + order Taylor launches + 3 copy kernels + the
 // phi ping-pong buffers of the unfused path; dead walkers (qmc/afqmc.py:232) are skipped

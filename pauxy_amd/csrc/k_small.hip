@@ -1396,7 +1396,8 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
             }
         }
     }
-    for (int k = 0; k < 12; ++k) v[k] = block_sum(v[k], red);
+    const int nk = have_energy ? 12 : 6;                     // the energy sums stay zero (and unused) on the other steps
+    for (int k = 0; k < nk; ++k) v[k] = block_sum(v[k], red);
     if (threadIdx.x == 0) {
         est[AFQ_EST_UWEIGHT].x += v[0];
         est[AFQ_EST_WEIGHT].x += v[1]; est[AFQ_EST_WEIGHT].y += v[2];
