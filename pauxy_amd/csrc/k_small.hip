@@ -305,7 +305,10 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     __shared__ unsigned long long pmax_s[2][48];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (a.only_alive && !a.alive[w]) return;
-    const int g = tid >> 8, wave = (tid >> 6) & 3, lane = tid & 63;
+    // wave-uniform on purpose (readfirstlane): the spin's electron count n and column offset derive from g, and every
+    // test on them is then a scalar branch instead of an exec-mask region
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const int lane = tid & 63;
     unsigned long long *pmax = pmax_s[g];
     if ((tid & 255) < 48) pmax[tid & 255] = 0ull;
     const int M = a.M, nt = a.nt;
@@ -502,30 +505,53 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
         cplx *oo = a.oinv + ((long)w * 2 + g) * nmax * nmax;
         for (int e = tid & 255; e < n * n; e += 256) oo[(e / n) * nmax + (e % n)] = O[e];
     }
-    // ---- phase 3
+    // ---- phase 3: Ghalf = O^-1 phi^T.  Work item = (row tile of O^-1, PAIR of column tiles): the O^-1 fragments of the
+    // row tile are read from LDS once per item and kept in registers, the two column tiles give six independent
+    // accumulators (3-multiplication complex product: P1 = xr yr, P2 = xi yi, P3 = (xr + xi)(yr + yi)), and every LDS
+    // read is unconditional (clamped index, zero by select) -- the previous loop re-read O^-1 for every column tile,
+    // ran four dependent MFMAs per contraction step on two accumulators and branched around its operand reads.
     if (INVERSE && a.ghalf && n > 0 && !(a.dbg & 2)) {
         cplx *gh = a.ghalf + ((long)w * nt + off) * M;
-        const int mt16 = (M + 15) >> 4;
-        for (int t = wave; t < nt16 * mt16; t += 4) {
-            const int ti = t / mt16, tc = t % mt16;
-            d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
-            const int ia = ti * 16 + lr, c = tc * 16 + lr;
-            for (int j0 = 0; j0 < n; j0 += 4) {
-                const int j = j0 + lk;
-                cplx x = cmake(0.0, 0.0), y = cmake(0.0, 0.0);
-                if (j < n) {
-                    if (ia < n) x = O[ia * n + j];
-                    if (c < M) y = phi_l[c * nt + off + j];
+        const int mt16 = (M + 15) >> 4, npair = (mt16 + 1) >> 1, nks3 = (n + 3) >> 2;   // n <= 45: nks3 <= 12
+        for (int it = wave; it < nt16 * npair; it += 4) {
+            const int ti = it % nt16, tc0 = 2 * (it / nt16), tc1 = tc0 + 1;
+            const bool two = tc1 < mt16;
+            const int ia = ti * 16 + lr, iac = ia < n ? ia : n - 1;
+            const int c0 = tc0 * 16 + lr, c1 = tc1 * 16 + lr;
+            const int c0c = c0 < M ? c0 : M - 1, c1c = c1 < M ? c1 : M - 1;
+            cplx xf[12];
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const int j = ks * 4 + lk, jc = j < n ? j : n - 1;
+                const cplx x = O[iac * n + jc];
+                xf[ks] = (ks < nks3 && j < n && ia < n) ? x : cmake(0.0, 0.0);
+            }
+            d4_t p1a = {0, 0, 0, 0}, p2a = {0, 0, 0, 0}, p3a = {0, 0, 0, 0};
+            d4_t p1b = {0, 0, 0, 0}, p2b = {0, 0, 0, 0}, p3b = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                if (ks < nks3) {
+                    const int j = ks * 4 + lk, jc = j < n ? j : n - 1;
+                    cplx y0 = phi_l[c0c * nt + off + jc], y1 = phi_l[c1c * nt + off + jc];
+                    if (!(j < n && c0 < M)) y0 = cmake(0.0, 0.0);
+                    if (!(j < n && c1 < M && two)) y1 = cmake(0.0, 0.0);
+                    const cplx x = xf[ks];
+                    const double xs = x.x + x.y;
+                    p1a = mfma16(x.x, y0.x, p1a);
+                    p2a = mfma16(x.y, y0.y, p2a);
+                    p3a = mfma16(xs, y0.x + y0.y, p3a);
+                    if (two) {
+                        p1b = mfma16(x.x, y1.x, p1b);
+                        p2b = mfma16(x.y, y1.y, p2b);
+                        p3b = mfma16(xs, y1.x + y1.y, p3b);
+                    }
                 }
-                accR = mfma16(x.x, y.x, accR);
-                accR = mfma16(-x.y, y.y, accR);
-                accI = mfma16(x.x, y.y, accI);
-                accI = mfma16(x.y, y.x, accI);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + lk + 4 * r, cc = tc * 16 + lr;
-                if (i < n && cc < M) gh[(long)i * M + cc] = cmake(accR[r], accI[r]);
+                const int i = ti * 16 + lk + 4 * r;
+                if (i < n && c0 < M) gh[(long)i * M + c0] = cmake(p1a[r] - p2a[r], p3a[r] - p1a[r] - p2a[r]);
+                if (two && i < n && c1 < M) gh[(long)i * M + c1] = cmake(p1b[r] - p2b[r], p3b[r] - p1b[r] - p2b[r]);
             }
         }
     }
