@@ -96,7 +96,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR); dev_free(h->log_detR);
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
-    dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum);
+    dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
@@ -629,7 +629,7 @@ static int field_info(afq_handle *h, int field, void **base, size_t *bytes) {
 }
 
 int afq_walkers_set(afq_handle *h, int field, const void *host, int first, int count) {
-    if (h && (field == AFQ_F_PHI || field == AFQ_F_GHALF)) h->greens_valid = false;
+    if (h && (field == AFQ_F_PHI || field == AFQ_F_GHALF)) { h->greens_valid = false; ++h->ghalf_version; }
     if (!h || !host) return AFQ_EINVAL;
     if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
     if (first < 0 || count < 0 || first + count > h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker range out of bounds");

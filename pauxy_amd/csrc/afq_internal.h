@@ -165,6 +165,9 @@ struct afq_handle {
     int fb_split = 1;               // contraction slices of the force-bias GEMM
     cplx *vbias = nullptr;          // [fb_split*2, nw, K] partial per-spin Coulomb vectors X_a, X_b
     cplx *ghalf_sum = nullptr;      // [nw, na*M] Ghalf_a + Ghalf_b when both spins share rchol (force bias on half the contraction)
+    // every writer of ghalf bumps ghalf_version; ghalf_sum is current when gsum_version equals it (the small Green's
+    // function kernel writes the sum itself, otherwise k_force_bias_generic runs ghalf_sum_kernel first)
+    unsigned long long ghalf_version = 1, gsum_version = 0;
     cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
     cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
     cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag
@@ -329,6 +332,7 @@ struct KernelTrace {
 // k_gemm.hip
 int k_onebody(afq_handle *h);                               // phi <- BH1 phi (all live walkers)
 int k_force_bias_generic(afq_handle *h);                    // ghalf -> vbias[2,nw,K]
+bool k_fb_use_sum(afq_handle *h);                           // force bias runs once over Ghalf_a + Ghalf_b
 int k_vhs_generic(afq_handle *h);                           // xs -> vhs
 int k_apply_exponential(afq_handle *h, const cplx *vhs);    // phi <- sum_n vhs^n/n! phi
 int k_full_G(afq_handle *h);                                // G = conj(psi) ghalf

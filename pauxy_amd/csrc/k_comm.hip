@@ -358,6 +358,7 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
 }
 
 int stage_unpack(afq_handle *h, bool with_greens) {
+    ++h->ghalf_version;                 // cloned / received walkers bring their Ghalf along
     afq_comm_state *c = cs_of(h);
     if (c->nranks > 1) {
         PackArgs p;

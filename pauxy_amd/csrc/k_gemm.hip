@@ -193,7 +193,7 @@ __global__ void ghalf_sum_kernel(const cplx *ghalf, cplx *out, long half, long n
 // Both spins contract with the SAME half-rotated Cholesky block (RHF-type trial: rchol_same, checked bitwise at upload):
 // sum_q R[q,k] Ga[q] + sum_q R[q,k] Gb[q] = sum_q R[q,k] (Ga + Gb)[q] -- half the contraction.  The 2 * nsplit output
 // partials keep their layout (every consumer sums all of them): they become 2 * nsplit slices of the one contraction.
-static bool fb_use_sum(afq_handle *h) {
+bool k_fb_use_sum(afq_handle *h) {
     return h->rchol_same && h->rchol_real && h->ndet == 1 && h->na == h->nb && h->nw > 32 && !h->no_ring &&
            !afq_knob("AFQ_FB_NOSUM");
 }
@@ -203,12 +203,15 @@ int k_force_bias_generic(afq_handle *h) {
     if (h->rchol_real) {
         ForceBiasProb<false> p;
         fill_force_bias(p, h);
-        if (fb_use_sum(h)) {
+        if (k_fb_use_sum(h)) {
             const long half = (long)h->na * h->M, n = half * h->nw;
-            if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)n));
-            AFQ_LAUNCH(h, ghalf_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ghalf,
-                       h->ghalf_sum, half, n);
-            AFQ_POST(h);
+            if (!h->ghalf_sum) { AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)n)); h->gsum_version = 0; }
+            if (h->gsum_version != h->ghalf_version) {      // not written by the Green's function kernel itself
+                AFQ_LAUNCH(h, ghalf_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ghalf,
+                           h->ghalf_sum, half, n);
+                AFQ_POST(h);
+                h->gsum_version = h->ghalf_version;
+            }
             const int ns2 = 2 * h->fb_split;
             const long per = (half + ns2 - 1) / ns2;
             int kmax = 0;

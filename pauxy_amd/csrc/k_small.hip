@@ -89,6 +89,7 @@ struct GreensArgs {
     const cplx *phi, *psi;
     long psi_stride;    // 0: one trial for all walkers; M*nt: walker w uses psi + w*psi_stride
     cplx *ghalf;        // may be null (determinant only)
+    cplx *gsum;         // optional [nw, na*M]: Ghalf_a + Ghalf_b (na == nb), see k_force_bias_generic
     cplx *oinv;         // optional [nw, 2, nmax, nmax]: O^-1 (O = phi^T conj(psi)), row-major, leading dim nmax
     cplx *det;          // [nw]
     cplx *ws;           // global workspace [nw, nmax*nmax] when O does not fit LDS
@@ -510,48 +511,73 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     // accumulators (3-multiplication complex product: P1 = xr yr, P2 = xi yi, P3 = (xr + xi)(yr + yi)), and every LDS
     // read is unconditional (clamped index, zero by select) -- the previous loop re-read O^-1 for every column tile,
     // ran four dependent MFMAs per contraction step on two accumulators and branched around its operand reads.
-    if (INVERSE && a.ghalf && n > 0 && !(a.dbg & 2)) {
-        cplx *gh = a.ghalf + ((long)w * nt + off) * M;
-        const int mt16 = (M + 15) >> 4, npair = (mt16 + 1) >> 1, nks3 = (n + 3) >> 2;   // n <= 45: nks3 <= 12
-        for (int it = wave; it < nt16 * npair; it += 4) {
-            const int ti = it % nt16, tc0 = 2 * (it / nt16), tc1 = tc0 + 1;
+    // With a.gsum (na == nb, host-checked) every wave of the work-group takes items of BOTH spins, so that the two Green's
+    // functions of an element meet in one lane and their sum (what the force bias contracts when both spins share the
+    // Cholesky block) is stored along.
+    if (INVERSE && a.ghalf && !(a.dbg & 2)) {
+        const bool both = a.gsum != nullptr;
+        const int mt16 = (M + 15) >> 4, npair = (mt16 + 1) >> 1;
+        const int first = both ? __builtin_amdgcn_readfirstlane(tid >> 6) : wave, stride = both ? 8 : 4;
+        const int s_lo = both ? 0 : g, s_hi = both ? 2 : g + 1;
+        const int nn = both ? a.na : n, nt16x = (nn + 15) >> 4;
+        for (int it = first; nn > 0 && it < nt16x * npair; it += stride) {
+            const int ti = it % nt16x, tc0 = 2 * (it / nt16x), tc1 = tc0 + 1;
             const bool two = tc1 < mt16;
-            const int ia = ti * 16 + lr, iac = ia < n ? ia : n - 1;
             const int c0 = tc0 * 16 + lr, c1 = tc1 * 16 + lr;
             const int c0c = c0 < M ? c0 : M - 1, c1c = c1 < M ? c1 : M - 1;
-            cplx xf[12];
+            d4_t sra = {0, 0, 0, 0}, sia = {0, 0, 0, 0}, srb = {0, 0, 0, 0}, sib = {0, 0, 0, 0};
+            for (int s = s_lo; s < s_hi; ++s) {
+                const int ns = s ? a.nb : a.na, offs = s ? a.na : 0;
+                const cplx *Os = (const cplx *)smem + (long)s * (nmax * nmax + 2 * nmax);
+                cplx *gh = a.ghalf + ((long)w * nt + offs) * M;
+                const int nks3 = (ns + 3) >> 2;                      // ns <= 45: nks3 <= 12
+                const int ia = ti * 16 + lr, iac = ia < ns ? ia : ns - 1;
+                cplx xf[12];
 #pragma unroll
-            for (int ks = 0; ks < 12; ++ks) {
-                const int j = ks * 4 + lk, jc = j < n ? j : n - 1;
-                const cplx x = O[iac * n + jc];
-                xf[ks] = (ks < nks3 && j < n && ia < n) ? x : cmake(0.0, 0.0);
-            }
-            d4_t p1a = {0, 0, 0, 0}, p2a = {0, 0, 0, 0}, p3a = {0, 0, 0, 0};
-            d4_t p1b = {0, 0, 0, 0}, p2b = {0, 0, 0, 0}, p3b = {0, 0, 0, 0};
+                for (int ks = 0; ks < 12; ++ks) {
+                    const int j = ks * 4 + lk, jc = j < ns ? j : ns - 1;
+                    const cplx x = Os[iac * ns + jc];
+                    xf[ks] = (ks < nks3 && j < ns && ia < ns) ? x : cmake(0.0, 0.0);
+                }
+                d4_t p1a = {0, 0, 0, 0}, p2a = {0, 0, 0, 0}, p3a = {0, 0, 0, 0};
+                d4_t p1b = {0, 0, 0, 0}, p2b = {0, 0, 0, 0}, p3b = {0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < 12; ++ks) {
-                if (ks < nks3) {
-                    const int j = ks * 4 + lk, jc = j < n ? j : n - 1;
-                    cplx y0 = phi_l[c0c * nt + off + jc], y1 = phi_l[c1c * nt + off + jc];
-                    if (!(j < n && c0 < M)) y0 = cmake(0.0, 0.0);
-                    if (!(j < n && c1 < M && two)) y1 = cmake(0.0, 0.0);
-                    const cplx x = xf[ks];
-                    const double xs = x.x + x.y;
-                    p1a = mfma16(x.x, y0.x, p1a);
-                    p2a = mfma16(x.y, y0.y, p2a);
-                    p3a = mfma16(xs, y0.x + y0.y, p3a);
-                    if (two) {
-                        p1b = mfma16(x.x, y1.x, p1b);
-                        p2b = mfma16(x.y, y1.y, p2b);
-                        p3b = mfma16(xs, y1.x + y1.y, p3b);
+                for (int ks = 0; ks < 12; ++ks) {
+                    if (ks < nks3) {
+                        const int j = ks * 4 + lk, jc = j < ns ? j : ns - 1;
+                        cplx y0 = phi_l[c0c * nt + offs + jc], y1 = phi_l[c1c * nt + offs + jc];
+                        if (!(j < ns && c0 < M)) y0 = cmake(0.0, 0.0);
+                        if (!(j < ns && c1 < M && two)) y1 = cmake(0.0, 0.0);
+                        const cplx x = xf[ks];
+                        const double xs = x.x + x.y;
+                        p1a = mfma16(x.x, y0.x, p1a);
+                        p2a = mfma16(x.y, y0.y, p2a);
+                        p3a = mfma16(xs, y0.x + y0.y, p3a);
+                        if (two) {
+                            p1b = mfma16(x.x, y1.x, p1b);
+                            p2b = mfma16(x.y, y1.y, p2b);
+                            p3b = mfma16(xs, y1.x + y1.y, p3b);
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + lk + 4 * r;
-                if (i < n && c0 < M) gh[(long)i * M + c0] = cmake(p1a[r] - p2a[r], p3a[r] - p1a[r] - p2a[r]);
-                if (two && i < n && c1 < M) gh[(long)i * M + c1] = cmake(p1b[r] - p2b[r], p3b[r] - p1b[r] - p2b[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + lk + 4 * r;
+                    const double ra = p1a[r] - p2a[r], ima = p3a[r] - p1a[r] - p2a[r];
+                    const double rb = p1b[r] - p2b[r], imb = p3b[r] - p1b[r] - p2b[r];
+                    if (i < ns && c0 < M) gh[(long)i * M + c0] = cmake(ra, ima);
+                    if (two && i < ns && c1 < M) gh[(long)i * M + c1] = cmake(rb, imb);
+                    sra[r] += ra; sia[r] += ima; srb[r] += rb; sib[r] += imb;
+                }
+            }
+            if (both) {
+                cplx *gs = a.gsum + (long)w * a.na * M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + lk + 4 * r;
+                    if (i < a.na && c0 < M) gs[(long)i * M + c0] = cmake(sra[r], sia[r]);
+                    if (two && i < a.na && c1 < M) gs[(long)i * M + c1] = cmake(srb[r], sib[r]);
+                }
             }
         }
     }
@@ -559,7 +585,8 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
 
 static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, cplx *oinv = nullptr) {
     GreensArgs a;
-    a.oinv = oinv;
+    a.oinv = oinv; a.gsum = nullptr;
+    if (ghalf) ++h->ghalf_version;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     const int nmax = h->na > h->nb ? h->na : h->nb;
@@ -585,9 +612,16 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         // raise the dynamic-LDS cap once per kernel and device, not per launch
         static size_t lds_set1[AFQ_MAX_DEVICES] = {0}, lds_set0[AFQ_MAX_DEVICES] = {0};
         if (ghalf || oinv) {
+            // the spin sum the force bias contracts (every walker written: not on the only_alive path)
+            const bool want_sum = ghalf && ghalf == h->ghalf && !only_alive && k_fb_use_sum(h) && h->psi_stride == 0;
+            if (want_sum) {
+                if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)h->na * h->M * h->nw));
+                a.gsum = h->ghalf_sum;
+            }
             AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true>, lds, lds_set1));
             KernelTrace kt(h, AFQ_K_GREENS);
             AFQ_LAUNCH(h, greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
+            if (want_sum) h->gsum_version = h->ghalf_version;
         } else {
             AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false>, lds, lds_set0));
             AFQ_LAUNCH(h, greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
@@ -1368,6 +1402,7 @@ int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
 
 // clone_kernel over the (src, dst) pairs in h->pack_tmp, count in scal[1]; at most nw / 2 pairs
 int k_clone_pairs(afq_handle *h, bool with_greens) {
+    ++h->ghalf_version;                 // cloned walkers bring their Ghalf along (ghalf_sum goes stale)
     CloneArgs a;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
     a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.log_detR = h->log_detR;

@@ -244,3 +244,37 @@ def test_rccl_communicator_of_one_rank(golden):
     assert (st['rank'], st['size'], st['events']) == (0, 1, 1)
     withcomm.comm_destroy()
     close_all([plain, withcomm])
+
+
+def test_spin_summed_force_bias_after_an_exchange():
+    """More than 32 walkers per rank and an RHF-type trial: the force bias contracts the spin-summed Ghalf, which the
+    Green's-function kernel writes -- walkers received from another rank bring their Ghalf, so the sum has to be
+    redone.  2 ranks x 36 walkers against one rank x 72 (whose path tests/test_gpu_sizes.py checks against the oracle)."""
+    from tests.test_gpu_sizes import build
+    nranks, nw = 2, 36
+    model, rng = build(20, 30, 4, 4, False, seed=23)
+    ntot = nranks * nw
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(20, 8) + 1j * rng.rand(20, 8)) for _ in range(ntot)])
+    ots = numpy.array([ref.calc_overlap(p, model.psi, 4, 4) for p in phis])
+    weights = numpy.exp(0.8 * rng.normal(size=ntot))
+    one = make_device(model, ntot)
+    ranks = [make_device(model, nw) for _ in range(nranks)]
+    for dev, sl in [(one, slice(0, ntot))] + [(ranks[i], slice(i * nw, (i + 1) * nw)) for i in range(nranks)]:
+        dev.set(L.F_PHI, phis[sl]); dev.set(L.F_OT, ots[sl]); dev.set(L.F_WEIGHT, weights[sl])
+    devmod.comm_init_local(ranks)
+    crossed = False
+    for step in range(1, 5):
+        xi = rng.normal(size=(ntot, one.K))
+        one.propagate(xi, 0.1)
+        for i, rk in enumerate(ranks):
+            rk.propagate(xi[i * nw:(i + 1) * nw], 0.1)
+        if step < 4:
+            r = rng.rand()
+            pix_one, _ = one.popcontrol_comb(r, ntot)
+            pix, _ = devmod.popcontrol_comb_local(ranks, r, ntot)
+            assert numpy.array_equal(pix, pix_one)
+            kill, clone = numpy.where(pix == 0)[0], numpy.where(pix > 1)[0]
+            crossed = crossed or any(c // nw != k // nw for c, k in zip(clone, kill))
+        same_population(one, ranks, exact=False)
+    assert crossed
+    close_all([one] + ranks)

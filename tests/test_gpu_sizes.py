@@ -249,3 +249,44 @@ def test_fused_propagator_shape_classes(M, na, nb, onebody):
         close(out_phi[i], w['phi'])
         close(out_w[i], w['weight'])
     dev.close()
+
+
+def test_spin_summed_force_bias_follows_clones_and_reorthos():
+    """RHF-type trial, more than 32 walkers: the force bias contracts Ghalf_a + Ghalf_b once (both spins share the
+    half-rotated Cholesky block).  The sum is written by the Green's-function kernel and must be redone after a comb
+    cloned walkers (their cached Ghalf travels) -- four steps with a comb and a re-orthogonalisation in between,
+    every walker against the oracle."""
+    M, K, na, nb, nw = 20, 30, 4, 4, 40
+    model, rng = build(M, K, na, nb, False, seed=21)
+    assert numpy.array_equal(model.rchol[:na * M], model.rchol[na * M:])          # the spins do share the block
+    dev = make_device(model, nw)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    w0 = numpy.exp(0.8 * rng.normal(size=nw))
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, na, nb) for p in phis]))
+    walkers = [ref.new_walker(model, phis[i], weight=w0[i]) for i in range(nw)]
+    for w in walkers:
+        w['total_weight'] = nw
+    cloned = False
+    for step in range(1, 5):
+        xi = rng.normal(size=(nw, K))
+        if step == 3:
+            dev.reortho(fetch=False)
+            for w in walkers:
+                d = ref.reortho(w['phi'], na, nb)
+                w['ot'] = w['ot'] / d
+        dev.propagate(xi, 0.1)
+        for i, w in enumerate(walkers):
+            ref.propagate_walker_phaseless(model, w, xi[i], 0.1)
+        if step in (1, 2):
+            r = rng.rand()
+            pix, _ = dev.popcontrol_comb(r, nw)
+            pix_ref = ref.pop_control(model, walkers, nw, r)
+            assert numpy.array_equal(pix, pix_ref)
+            cloned = cloned or (pix > 1).any()
+        close(dev.get(L.F_PHI), numpy.array([w['phi'] for w in walkers]), 1e-9)
+        close(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]), 1e-9)
+        close(dev.get(L.F_HYBRID_ENERGY), numpy.array([w['hybrid_energy'] for w in walkers]), 1e-9)
+    assert cloned
+    dev.close()
