@@ -96,7 +96,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR); dev_free(h->log_detR);
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
-    dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0;
+    dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0; h->vbias_version = 0;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
@@ -286,6 +286,7 @@ static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
     for (size_t q = 0; q < nq; ++q)
         for (int n = 0; n < K; ++n) re[q * h->ld_rc + n] = rchol[2 * (q * K + n)];
     h->rchol_real = real;
+    ++h->ghalf_version;                 // force-bias partials contracted with the old vectors are stale
     h->rchol_same = h->na == h->nb && memcmp(rchol, rchol + 2 * (size_t)h->na * h->M * K, sizeof(double) * 2 * (size_t)h->na * h->M * K) == 0;
     k_free_atil(h->atil);                  // the quadratic-form operand belongs to the old vectors
     if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;

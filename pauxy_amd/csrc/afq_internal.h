@@ -168,6 +168,7 @@ struct afq_handle {
     // every writer of ghalf bumps ghalf_version; ghalf_sum is current when gsum_version equals it (the small Green's
     // function kernel writes the sum itself, otherwise k_force_bias_generic runs ghalf_sum_kernel first)
     unsigned long long ghalf_version = 1, gsum_version = 0;
+    unsigned long long vbias_version = 0;       // ghalf_version the force-bias partials in vbias were contracted from
     cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
     cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
     cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag

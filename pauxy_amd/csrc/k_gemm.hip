@@ -198,7 +198,18 @@ bool k_fb_use_sum(afq_handle *h) {
            !afq_knob("AFQ_FB_NOSUM");
 }
 
+static int force_bias_generic_impl(afq_handle *h);
+
+// The Coulomb vectors of the energy evaluation at the end of step n and the force bias at the start of step n + 1 are
+// the same contraction of the same (cached) Ghalf: the second call is skipped while ghalf_version has not moved.
 int k_force_bias_generic(afq_handle *h) {
+    if (h->ndet == 1 && h->vbias_version == h->ghalf_version && !afq_knob("AFQ_FB_NOREUSE")) return AFQ_OK;
+    const int rc = force_bias_generic_impl(h);
+    h->vbias_version = rc == AFQ_OK && h->ndet == 1 ? h->ghalf_version : 0;
+    return rc;
+}
+
+static int force_bias_generic_impl(afq_handle *h) {
     if (2 * h->fb_split > FB_MAX_BATCH) AFQ_FAIL(h, AFQ_EINVAL, "force-bias split too large");
     if (h->rchol_real) {
         ForceBiasProb<false> p;
