@@ -540,11 +540,18 @@ static int launch_exx_quadratic(afq_handle *h) {
         h->exq_y_len = need;
     }
     p.Y = h->exq_y; p.ldy = nmax;
-    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : 0;
+    // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
+    // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
+    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : (S > 1 ? 1 : 0);
     AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
     {
         KernelTrace kt(h, AFQ_K_EXCHANGE);
         if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+#ifdef AFQ_TUNING
+        else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+        else if (cfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+#endif
         else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD, RC>(p, h->stream, h->zero_page)));
 #ifdef AFQ_TUNING
