@@ -72,6 +72,27 @@ __device__ __attribute__((always_inline)) inline d2_t lds_read_frag(unsigned bas
     }
 }
 
+// Real part only (ds_read_b64) of fragment `idx`: the operand of a real matrix.  Reading the full 16 bytes and dropping the
+// upper half is not equivalent: the register allocator then lets that dead upper half overlap registers an MFMA issued
+// shortly before still has to read (measured: wrong rows in the column-deal one-body pass, varying from run to run).
+template <int OFF> __device__ inline double lds_read_re_off(unsigned addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __attribute__((always_inline)) inline double lds_read_frag_re(unsigned base, int idx) {
+    switch (idx) {
+    case 0: return lds_read_re_off<0>(base);
+    case 1: return lds_read_re_off<1024>(base);
+    case 2: return lds_read_re_off<2048>(base);
+    case 3: return lds_read_re_off<3072>(base);
+    case 4: return lds_read_re_off<4096>(base);
+    case 5: return lds_read_re_off<5120>(base);
+    case 6: return lds_read_re_off<6144>(base);
+    default: return lds_read_re_off<7168>(base);
+    }
+}
+
 // Work-group barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every
 // operand chunk still in flight in the DMA ring -- a full pipeline drain at each product boundary.
 __device__ inline void lds_barrier() {
@@ -242,7 +263,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             const unsigned bbase = tf_l + (c * 4 + slot0) * 2048 + lane * 16;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                av[ss] = lds_read_frag(abase, ss);
+                if (BR) av[ss][0] = lds_read_frag_re(abase, ss);
+                else av[ss] = lds_read_frag(abase, ss);
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) bv[j][ss] = lds_read_frag(bbase, j * SS * 2 + ss);
             }
@@ -298,7 +320,10 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                         for (int q = 0; q < RPG; ++q) {
                             const int r = j * RPG + q;
                             if (r < NR) {
-                                if (r == 0) ay = lds_read_frag(abase, ys);
+                                if (r == 0) {
+                                    if (BR) ay[0] = lds_read_frag_re(abase, ys);
+                                    else ay = lds_read_frag(abase, ys);
+                                }
                                 else by[r - 1] = lds_read_frag(bbase, (r - 1) * SS * 2 + ys);
                             }
                         }
@@ -310,7 +335,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             unsigned sl = next_chunk();
             {
                 const unsigned abase = sl + rt * 2048 + lane * 16, bbase = tf_l + slot0 * 2048 + lane * 16;
-                a0 = lds_read_frag(abase, 0);
+                if (BR) a0[0] = lds_read_frag_re(abase, 0);
+                else a0 = lds_read_frag(abase, 0);
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) b0[j] = lds_read_frag(bbase, j * SS * 2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -371,8 +397,141 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 }
             }
     };
+    // Column deal of a one-body product for the full 7-row-tile shape with M <= 100 and one matrix for both spins
+    // (FULL == 7, rem4, same_b): SIMD s = waves s, s + 4 owns column slot s; wave s the row tiles 0-2, wave s + 4 the row
+    // tiles 3-5 plus the rows 96 .. M-1 as one 4x4x4 unit (see REM in taylor) -- 6.25 tile equivalents per SIMD instead of
+    // the 8 of the row deal above (row tile 6 padded to 16 rows, wave 7 multiplying zeros).  Same half-chunk pipeline.
+    auto one_body_col = [&](bool to_global, auto real_tag, auto rem_tag) __attribute__((always_inline)) {
+        constexpr bool BR = decltype(real_tag)::value;
+        constexpr bool REM = decltype(rem_tag)::value;
+        constexpr int NI = 3;
+        constexpr int NG = NI + (REM ? 1 : 0), NR = NI + 1 + (REM ? 1 : 0), RPG = (NR + NG - 2) / (NG - 1);
+        const int c0 = wave & 3, r0 = (wave >> 2) * 3;
+        const unsigned rem_t = (unsigned)((((12 * 4 + c0) * 2 + ((lane >> 4) & 1)) * 1024) + (((lane >> 5) * 16) + (lane & 15)) * 16);
+        const unsigned rem_a = (unsigned)(6 * 2048 + ((lane >> 4) * 16 + (lane & 3)) * 16);
+        d4_t P1[NI], P2[NI], P3[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { P1[i] = (d4_t){0, 0, 0, 0}; P2[i] = (d4_t){0, 0, 0, 0}; P3[i] = (d4_t){0, 0, 0, 0}; }
+        double Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;
+        d2_t a0[NI], a1[NI], b0, b1, q0 = (d2_t){0.0, 0.0}, q1 = (d2_t){0.0, 0.0};
+        auto half = [&](d2_t (&ax)[NI], d2_t &bx, d2_t &qx, d2_t (&ay)[NI], d2_t &by, d2_t &qy, const unsigned abase,
+                        const unsigned bbase, const unsigned qbase, const int ys, const bool fetch, const bool refill)
+            __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gt = 0; gt < NG; ++gt) {
+                if (REM && gt == 0) {
+                    if (BR) {
+                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0], bx[0], Q1, 0, 0, 0);
+                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0], bx[1], Q2, 0, 0, 0);
+                    } else {
+                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0], bx[0], Q1, 0, 0, 0);
+                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[1], bx[1], Q2, 0, 0, 0);
+                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(qx[0] + qx[1], bx[0] + bx[1], Q3, 0, 0, 0);
+                    }
+                } else {
+                    const int i = REM ? gt - 1 : gt;
+                    if (BR) {
+                        P1[i] = mfma16(ax[i][0], bx[0], P1[i]);
+                        P2[i] = mfma16(ax[i][0], bx[1], P2[i]);
+                    } else {
+                        P1[i] = mfma16(ax[i][0], bx[0], P1[i]);
+                        P2[i] = mfma16(ax[i][1], bx[1], P2[i]);
+                        P3[i] = mfma16(ax[i][0] + ax[i][1], bx[0] + bx[1], P3[i]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (gt == 0 && refill) issueA();
+                if (gt == 0 && !refill && !prepared) prepare();
+                if (fetch && gt < NG - 1) {
+#pragma unroll
+                    for (int q = 0; q < RPG; ++q) {
+                        const int r = gt * RPG + q;
+                        if (r < NR) {
+                            if (r < NI) {
+                                if (BR) ay[r][0] = lds_read_frag_re(abase, r * 2 + ys);
+                                else ay[r] = lds_read_frag(abase, r * 2 + ys);
+                            } else if (r == NI) {
+                                by = lds_read_frag(bbase, ys);
+                            } else {
+                                if (BR) qy[0] = lds_read_frag_re(qbase, ys);
+                                else qy = lds_read_frag(qbase, ys);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        unsigned sl = next_chunk();
+        {
+            const unsigned abase = sl + r0 * 2048 + lane * 16, bbase = tf_l + c0 * 2048 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (BR) a0[i][0] = lds_read_frag_re(abase, i * 2);
+                else a0[i] = lds_read_frag(abase, i * 2);
+            }
+            b0 = lds_read_frag(bbase, 0);
+            if (REM) {
+                if (BR) q0[0] = lds_read_frag_re(sl + rem_a, 0);
+                else q0 = lds_read_frag(sl + rem_a, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        for (int c = 0; c < NCH; ++c) {
+            const bool more = c + 1 < NCH;
+            half(a0, b0, q0, a1, b1, q1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, sl + rem_a, 1, true, false);
+            if (more) sl = next_chunk_sync();
+            half(a1, b1, q1, a0, b0, q0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, sl + rem_a, 0, more, more);
+        }
+        __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
+        int lk_e = lk, lr_e = lr, ln_e = lane;                   // laundered (see one_body)
+        asm volatile("" : "+v"(lk_e), "+v"(lr_e), "+v"(ln_e));
+        const int sp = c0 >> 1, ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double re = BR ? P1[i][r] : P1[i][r] - P2[i][r];
+                const double im = BR ? P2[i][r] : P3[i][r] - P1[i][r] - P2[i][r];
+                if (to_global) {
+                    const int row = (r0 + i) * 16 + lk_e + 4 * r, col = (c0 & 1) * 16 + lr_e;
+                    if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+                } else if (t_ok(r0 + i, r)) {
+                    *(d2_t *)(Tf + t_addr(r0 + i, r, c0)) = (d2_t){re, im};
+                }
+            }
+        if (REM) {
+            const double re = BR ? Q1 : Q1 - Q2, im = BR ? Q2 : Q3 - Q1 - Q2;
+            if (to_global) {
+                const int row = 96 + (ln_e >> 4), col = (c0 & 1) * 16 + (ln_e & 15);
+                if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+            } else {
+                *(d2_t *)(Tf + rem_t) = (d2_t){re, im};
+            }
+        }
+    };
     auto one_body_stage = [&](bool to_global) __attribute__((always_inline)) {
         using I2 = std::integral_constant<int, 2>;
+#if PF_NW == 8
+        if constexpr (FULL == 7) {
+            bool col_deal = a.rem4 && a.same_b;
+#ifdef AFQ_TUNING
+            if (a.dbg & (to_global ? 16384 : 8192)) col_deal = false;
+#endif
+            if (col_deal) {
+                if (a.b_real) {
+                    if (wave < 4) one_body_col(to_global, std::true_type{}, std::false_type{});
+                    else one_body_col(to_global, std::true_type{}, std::true_type{});
+                } else {
+                    if (wave < 4) one_body_col(to_global, std::false_type{}, std::false_type{});
+                    else one_body_col(to_global, std::false_type{}, std::true_type{});
+                }
+                return;
+            }
+        }
+#endif
 #if PF_NW == 16
         // two waves per row tile: each takes half of the column slots
         using I1 = std::integral_constant<int, 1>;
