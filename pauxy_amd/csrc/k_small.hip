@@ -352,9 +352,9 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                         cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];
                         if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
                         const cplx y = yb[u];
-                        accR = mfma16(x.x, y.x, accR);             // x * conj(y)
-                        accR = mfma16(x.y, y.y, accR);
+                        accR = mfma16(x.x, y.x, accR);             // x * conj(y); the two chains alternate
                         accI = mfma16(x.y, y.x, accI);
+                        accR = mfma16(x.y, y.y, accR);
                         accI = mfma16(-x.x, y.y, accI);
                     }
                 }
@@ -861,44 +861,61 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
                                                       const cplx *mf, cplx *xs, cplx *cmf, cplx *cfb,
                                                       unsigned long long *counters, const int *alive, XbarArgs xa,
                                                       FieldRng rng) {
-    __shared__ double red[8];
+    __shared__ double red[NTHR / 64][8];
     const int w = blockIdx.x;
     if (rng.on) {
         const bool live = fabs(rng.weight[w]) > 1e-8;
         if (threadIdx.x == 0) rng.alive_out[w] = live ? 1 : 0;
         if (!live) return;
     } else if (alive && !alive[w]) return;
-    double s_mf_r = 0, s_mf_i = 0, s_xx_r = 0, s_xx_i = 0, s_bb_r = 0, s_bb_i = 0;
-    unsigned int ntrig = 0;
-    for (int n = threadIdx.x; n < K; n += NTHR) {
-        cplx b = FUSED ? xbar_value(xa, w, n) : xbar[(long)w * K + n];
-        const double ab = hypot(b.x, b.y);
-        if (ab > 1.0) { b.x /= ab; b.y /= ab; ++ntrig; }
-        double x;
-        if (rng.on) {
-            const long e = (long)w * K + n;
-            double x0, x1;
-            philox_normal_pair(e >> 1, rng.seed, rng.stream, rng.counter, x0, x1);
-            x = (e & 1) ? x1 : x0;
-        } else x = xi[(long)w * K + n];
-        const cplx sft = cmake(x - b.x, -b.y);
-        xbar[(long)w * K + n] = b;
-        xs[(long)w * K + n] = sft;
-        const cplx m = mf[n];
-        s_mf_r += sft.x * m.x - sft.y * m.y;
-        s_mf_i += sft.x * m.y + sft.y * m.x;
-        s_xx_r += x * b.x; s_xx_i += x * b.y;
-        s_bb_r += b.x * b.x - b.y * b.y;
-        s_bb_i += 2.0 * b.x * b.y;
+    // sums: mean-field shift (re, im), xi . xbar (re, im), xbar . xbar (re, im), clipped count
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    // a thread takes the two members of one Philox pair (elements 2 p, 2 p + 1 of the stream: consecutive fields of this
+    // walker, or its first / last field alone when the walker's K fields start or end inside a pair), so that a pair is
+    // generated once -- with a thread per field every pair was generated twice and one normal of each thrown away
+    const long e0 = (long)w * K;
+    for (long pr = (e0 >> 1) + threadIdx.x; pr <= ((e0 + K - 1) >> 1); pr += NTHR) {
+        double xn[2] = {0.0, 0.0};
+        if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long e = 2 * pr + m;
+            const int n = (int)(e - e0);
+            if (n < 0 || n >= K) continue;
+            cplx b = FUSED ? xbar_value(xa, w, n) : xbar[e];
+            const double ab = hypot(b.x, b.y);
+            if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
+            const double x = rng.on ? xn[m] : xi[e];
+            const cplx sft = cmake(x - b.x, -b.y);
+            xbar[e] = b;
+            xs[e] = sft;
+            const cplx mm = mf[n];
+            acc[0] += sft.x * mm.x - sft.y * mm.y;
+            acc[1] += sft.x * mm.y + sft.y * mm.x;
+            acc[2] += x * b.x; acc[3] += x * b.y;
+            acc[4] += b.x * b.x - b.y * b.y;
+            acc[5] += 2.0 * b.x * b.y;
+        }
     }
-    s_mf_r = block_sum(s_mf_r, red); s_mf_i = block_sum(s_mf_i, red);
-    s_xx_r = block_sum(s_xx_r, red); s_xx_i = block_sum(s_xx_i, red);
-    s_bb_r = block_sum(s_bb_r, red); s_bb_i = block_sum(s_bb_i, red);
-    const double nt = block_sum((double)ntrig, red);
+    // one reduction for all seven sums: wave shuffles, one barrier
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+        for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[threadIdx.x >> 6][q] = acc[q];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        cmf[w] = cmake(-sqrt_dt * s_mf_r, -sqrt_dt * s_mf_i);
-        cfb[w] = cmake(s_xx_r - 0.5 * s_bb_r, s_xx_i - 0.5 * s_bb_i);
-        if (nt > 0 && counters) atomicAdd(&counters[0], (unsigned long long)nt);
+        double t[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            t[q] = 0.0;
+            for (int i = 0; i < NTHR / 64; ++i) t[q] += red[i][q];
+        }
+        cmf[w] = cmake(-sqrt_dt * t[0], -sqrt_dt * t[1]);
+        cfb[w] = cmake(t[2] - 0.5 * t[4], t[3] - 0.5 * t[5]);
+        if (t[6] > 0 && counters) atomicAdd(&counters[0], (unsigned long long)t[6]);
     }
 }
 
@@ -1434,7 +1451,7 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
                                                          const double *unscaled, const cplx *ot,
                                                          const cplx *ehyb, const cplx *phase, const cplx *energy,
                                                          cplx *est) {
-    __shared__ double red[8];
+    __shared__ double red[NTHR / 64][12];
     // v[0]=uweight  v[1..2]=weight  v[3]=ovlp  v[4..5]=ehyb  v[6..7]=enumer  v[8..9]=e1b  v[10..11]=e2b
     double v[12];
     for (int k = 0; k < 12; ++k) v[k] = 0.0;
@@ -1457,9 +1474,23 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
             }
         }
     }
+    // all sums in one pass: wave shuffles, one barrier, thread 0 adds the per-wave partials in wave order
     const int nk = have_energy ? 12 : 6;                     // the energy sums stay zero (and unused) on the other steps
-    for (int k = 0; k < nk; ++k) v[k] = block_sum(v[k], red);
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        if (k < nk)
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) red[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            v[k] = 0.0;
+            for (int i = 0; i < NTHR / 64; ++i) v[k] += red[i][k];
+        }
         est[AFQ_EST_UWEIGHT].x += v[0];
         est[AFQ_EST_WEIGHT].x += v[1]; est[AFQ_EST_WEIGHT].y += v[2];
         est[AFQ_EST_OVLP].x += v[3];
