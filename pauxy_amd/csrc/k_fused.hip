@@ -123,6 +123,29 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     cplx *phi = a.phi + (long)w * M * nt;
     const cplx *vhs = a.vhs + (long)w * M * M;
 
+#ifdef AFQ_TUNING
+    // coarse stage stamps (AFQ_PF_TS=1): work-group 0, wave 0 -> a.ts[128 + i]
+    auto stage_stamp = [&](int i) {
+        if (a.ts && w == 0 && wave == 0) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+            if (lane == 0) a.ts[128 + i] = t;
+        }
+    };
+    auto bnd_stamp = [&](int n, int i) {
+        if (a.ts && w == 0 && (wave & 3) == 0 && (n == 3 || n == 4)) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+            if (lane == 0) a.ts[144 + (wave >> 2) * 8 + (n == 4 ? 4 : 0) + i] = t;
+        }
+    };
+#define PF_BND(n, i) bnd_stamp(n, i)
+#define PF_STAGE(i) stage_stamp(i)
+#else
+#define PF_STAGE(i)
+#define PF_BND(n, i)
+#endif
+    PF_STAGE(0);
     // ---- A stream: global chunk g = phase * NCH + c; phases: B0 B1 V..V B0 B1, or B V..V B when both spins
     // share one propagator matrix (BH1[0] == BH1[1]: every closed-shell-type Hamiltonian) -- the one-body
     // products of the two spins then run as ONE pass over the matrix with four column tiles per wave
@@ -185,21 +208,20 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     issueA(); issueA();                                          // PF_D - 1 chunks in flight
     prepare();
 
-    // ---- phi[w] -> T (B-fragment order), padding zeroed
+    // ---- phi[w] -> T (B-fragment order), padding zeroed: one sweep over the ENTRIES of T (16 bytes each; entry index =
+    // ((chunk * 4 + slot) * 2 + (p & 1)) * 64 + ((p & 7) >> 1) * 16 + column in the slot, i.e. shifts and masks only), each
+    // either a walker element or a zero -- instead of a zero fill, a barrier and a sweep over the walker with a division
+    // by the column count per element
 #ifdef AFQ_TUNING
-    if (!(a.dbg & 32))
+    if (!(a.dbg & (32 | 128)))
 #endif
-    for (int e = tid; e < NCH * 512; e += PF_NT) ((d2_t *)Tf)[e] = (d2_t){0.0, 0.0};
-    __syncthreads();
-#ifdef AFQ_TUNING
-    if (!(a.dbg & 128))
-#endif
-    for (int e = tid; e < M * nt; e += PF_NT) {
-        const int p = e / nt, col = e % nt;
-        const int s = col >= a.na ? 1 : 0, j = col - (s ? a.na : 0);
-        const int slot = 2 * s + (j >> 4);
-        const unsigned off = (((p >> 3) * 4 + slot) * 2 + (p & 1)) * 1024 + ((((p & 7) >> 1) * 16) + (j & 15)) * 16;
-        *(cplx *)(Tf + off) = phi[e];
+    for (int e = tid; e < NCH * 512; e += PF_NT) {
+        const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
+        const int p = ch * 8 + 2 * kk + pb, sp = slot >> 1, col = (slot & 1) * 16 + j;
+        const int ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const bool ok = p < M && col < ns_;
+        const cplx v = phi[ok ? p * nt + off_ + col : 0];
+        ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
     }
     __syncthreads();
 
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         return base + (unsigned)(((2 * ti * 4 + cs) * 2) * 1024) + (unsigned)((r >> 1) * 8192 + (r & 1) * 512);
     };
 
+    PF_STAGE(1);
     int ring_slot = 0;                                           // slot of the chunk being consumed
     // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
     auto next_chunk = [&]() __attribute__((always_inline)) -> unsigned {
@@ -332,13 +355,15 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
-            unsigned sl = next_chunk();
+            unsigned sl = next_chunk_sync();                     // reads first, the refill issues under their latency
             {
                 const unsigned abase = sl + rt * 2048 + lane * 16, bbase = tf_l + slot0 * 2048 + lane * 16;
                 if (BR) a0[0] = lds_read_frag_re(abase, 0);
                 else a0 = lds_read_frag(abase, 0);
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) b0[j] = lds_read_frag(bbase, j * SS * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                issueA();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             for (int c = 0; c < NCH; ++c) {
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         }
 #endif
         }
-        __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
+        if (!to_global) __builtin_amdgcn_s_barrier();            // everyone finished reading these T columns
         int lk_e = lk, lr_e = lr;                                // laundered: keeps the store addresses from being
         asm volatile("" : "+v"(lk_e), "+v"(lr_e));               // computed (and kept alive) ahead of the MFMA loop
 #pragma unroll
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-        unsigned sl = next_chunk();
+        unsigned sl = next_chunk_sync();                         // reads first, the refill issues under their latency
         {
             const unsigned abase = sl + r0 * 2048 + lane * 16, bbase = tf_l + c0 * 2048 + lane * 16;
 #pragma unroll
@@ -477,6 +502,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 if (BR) q0[0] = lds_read_frag_re(sl + rem_a, 0);
                 else q0 = lds_read_frag(sl + rem_a, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            issueA();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         for (int c = 0; c < NCH; ++c) {
@@ -485,7 +512,9 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             if (more) sl = next_chunk_sync();
             half(a1, b1, q1, a0, b0, q0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, sl + rem_a, 0, more, more);
         }
-        __builtin_amdgcn_s_barrier();                            // everyone finished reading these T columns
+        // everyone finished reading these T columns -- see the Taylor epilogue: the full tiles (rows below the last chunk)
+        // are stored first, the barrier sits ahead of the remainder unit's store; the pass that writes phi does not touch T
+        // and needs no barrier at all
         int lk_e = lk, lr_e = lr, ln_e = lane;                   // laundered (see one_body)
         asm volatile("" : "+v"(lk_e), "+v"(lr_e), "+v"(ln_e));
         const int sp = c0 >> 1, ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
@@ -502,6 +531,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     *(d2_t *)(Tf + t_addr(r0 + i, r, c0)) = (d2_t){re, im};
                 }
             }
+        if (!to_global) __builtin_amdgcn_s_barrier();
         if (REM) {
             const double re = BR ? Q1 : Q1 - Q2, im = BR ? Q2 : Q3 - Q1 - Q2;
             if (to_global) {
@@ -573,6 +603,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     //  measured, same chunk time)
     one_body_stage(false);
     lds_barrier();                                               // T = B phi complete
+    PF_STAGE(2);
 
     // ------------------------------------------------------------------ Taylor series
     // Tile deal: the 7 x 4 grid of 16x16 output tiles (M <= 104 rows, two column tiles per spin) is split so that
@@ -637,6 +668,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             }
         };
         for (int n = 1; n <= a.order; ++n) {
+            double inv_n = 1.0 / n;                              // here, not in the epilogue: the division runs under the first MFMAs
+            asm volatile("" : "+v"(inv_n));
             d4_t P1[NI][NJ], P2[NI][NJ], P3[NI][NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -725,7 +758,9 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 };
-                unsigned sl = next_chunk();
+                // first chunk of the product: the fragment reads go out first, the ring refill issues under their latency
+                unsigned sl = next_chunk_sync();
+                if (n == 4) PF_BND(4, 0);
                 {
                     const unsigned abase = sl + r0 * 2048 + lane * 16, bbase = tf_l + c0 * 2048 + lane * 16;
 #pragma unroll
@@ -733,8 +768,11 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) b0[j] = lds_read_frag(bbase, j * 2);
                     if (REM) q0 = lds_read_frag(sl + rem_a, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issueA();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (n == 4) PF_BND(4, 1);
                 for (int c = 0; c < NCH; ++c) {
                     const bool more = c + 1 < NCH;
 #ifdef AFQ_TUNING
@@ -814,31 +852,55 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             }
 #endif
             }
-            __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
-            const double inv_n = 1.0 / n;
+            if (n == 3) PF_BND(3, 0);
+            // Everyone has to be through with T_{n-1} before it is overwritten -- but behind the last chunk barrier of the
+            // half-chunk pipeline only the LAST chunk of T is still being read.  A wave whose tiles end below that chunk
+            // (every wave of the full M <= 100 deal: the last chunk belongs to the remainder unit) stores first and takes the
+            // barrier afterwards, just ahead of the remainder unit's store: the epilogue arithmetic of a wave then runs
+            // while its SIMD partner still multiplies, instead of behind it.
+            const bool store_first = PF_NW == 8 && FULL != 0 && 2 * (r0 + NI) <= NCH - 1;
+            if (!store_first) __builtin_amdgcn_s_barrier();
+            if (n == 3) PF_BND(3, 1);
+            // T_n = product / n goes back to T as the next right-hand operand; after the last term T receives the SUM instead
+            // (wave-uniform branch: two straight-line store sequences rather than a select per element)
+            const bool last = n == a.order;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    if (cv[j] && rv[i]) {
+                    if (FULL || (cv[j] && rv[i])) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double re = (P1[i][j][r] - P2[i][j][r]) * inv_n;
                             const double im = (P3[i][j][r] - P1[i][j][r] - P2[i][j][r]) * inv_n;
                             SR[i][j][r] += re; SI[i][j][r] += im;
-                            // T_n (next right-hand operand); after the last term T holds the SUM instead
-                            const bool last = n == a.order;
-                            if (t_ok(r0 + i, r))
-                                *(d2_t *)(Tf + t_addr(r0 + i, r, c0 + j)) =
-                                    last ? (d2_t){SR[i][j][r], SI[i][j][r]} : (d2_t){re, im};
+                            if (!last && t_ok(r0 + i, r)) *(d2_t *)(Tf + t_addr(r0 + i, r, c0 + j)) = (d2_t){re, im};
                         }
                     }
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (FULL || (cv[j] && rv[i])) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (t_ok(r0 + i, r))
+                                    *(d2_t *)(Tf + t_addr(r0 + i, r, c0 + j)) = (d2_t){SR[i][j][r], SI[i][j][r]};
+                        }
+            }
+            if (store_first) __builtin_amdgcn_s_barrier();
             if (REM) {
                 const double re = (Q1 - Q2) * inv_n, im = (Q3 - Q1 - Q2) * inv_n;
                 RR += re; RI += im;
-                *(d2_t *)(Tf + rem_t) = n == a.order ? (d2_t){RR, RI} : (d2_t){re, im};
+                *(d2_t *)(Tf + rem_t) = last ? (d2_t){RR, RI} : (d2_t){re, im};
             }
-            lds_barrier();                                       // T_n visible
+            if (n == 3) PF_BND(3, 2);
+            // T_n visible: the barrier is the one the first chunk of the next product (or of the closing one-body pass)
+            // starts with -- only the wave's own LDS writes have to be done before it gets there
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (n == 3) PF_BND(3, 3);
+            PF_STAGE(2 + n);
         }
     };
 
@@ -1047,6 +1109,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 
     one_body_stage(true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PF_STAGE(9);
 }
 
 int k_prop_fused_supported(afq_handle *h) {
@@ -1065,7 +1128,7 @@ int k_prop_fused(afq_handle *h) {
     static unsigned long long *ts_dev = nullptr;
     static int ts_launch = 0;
     if (afq_knob("AFQ_PF_TS")) {
-        if (!ts_dev) { hipMalloc(&ts_dev, 2 * 16 * 4 * 8); hipMemset(ts_dev, 0, 2 * 16 * 4 * 8); }
+        if (!ts_dev) { hipMalloc(&ts_dev, (128 + 32) * 8); hipMemset(ts_dev, 0, (128 + 32) * 8); }
         a.ts = ts_dev;
     }
 #endif
@@ -1098,9 +1161,18 @@ int k_prop_fused(afq_handle *h) {
     AFQ_POST(h);
 #ifdef AFQ_TUNING
     if (a.ts && ++ts_launch == 30) {
-        unsigned long long t[2 * 16 * 4];
+        unsigned long long t[128 + 32];
         hipStreamSynchronize(h->stream);
         hipMemcpy(t, a.ts, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "PF_STAGE ticks: phi->T %lld | one-body %lld | Taylor", (long long)(t[129] - t[128]), (long long)(t[130] - t[129]));
+        for (int n = 1; n <= h->exp_order && n <= 6; ++n) fprintf(stderr, " %lld", (long long)(t[130 + n] - t[129 + n]));
+        for (int wv = 0; wv < 2; ++wv) {
+            const unsigned long long *o = t + 144 + wv * 8;
+            fprintf(stderr, "\nPF_BND wave %d: loop end -> barrier %lld | epilogue + T writes %lld | barrier %lld | next_chunk %lld | fragment reads %lld",
+                    wv * 4, (long long)(o[1] - o[0]), (long long)(o[2] - o[1]), (long long)(o[3] - o[2]), (long long)(o[4] - o[3]), (long long)(o[5] - o[4]));
+        }
+        fprintf(stderr, "\n");
+        fprintf(stderr, " | one-body + store %lld | total %lld\n", (long long)(t[137] - t[130 + h->exp_order]), (long long)(t[137] - t[128]));
         for (int wv = 0; wv < 2; ++wv)
             for (int c = 0; c < (h->M + 7) / 8; ++c) {
                 const unsigned long long *o = t + (wv * 16 + c) * 4;
