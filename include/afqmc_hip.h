@@ -207,6 +207,16 @@ int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out);
  * xi: host f64[nw, K] normal fields (row iw used only if walker iw is live),
  * or NULL to draw them on the device (afq_rng_seed).                         */
 int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im);
+/* The same step in two calls.  Only the weight update at the very end of a step reads the energy shift
+ * (propagation/continuous.py:194-200, :206-230): afq_propagate_begin enqueues everything up to and including the
+ * propagation of the Slater matrices, afq_propagate_finish the overlap / Green's function of the propagated walkers and
+ * the weight update.  A driver that derives the shift of the next block from the estimators of the block just ended
+ * (qmc/afqmc.py:247-250 after estimators/mixed.py:261-273) can therefore enqueue the first part of the next step BEFORE
+ * it waits for those estimators (afq_estimates_get_begin / _end below) and keep the device busy across the block
+ * boundary.  afq_propagate(h, xi, e) == afq_propagate_begin(h, xi) + afq_propagate_finish(h, e); between the two calls
+ * only afq_estimates_get_end, afq_set_weight_cap and afq_last_error may be called (AFQ_ESTATE otherwise).           */
+int afq_propagate_begin(afq_handle *h, const double *xi);
+int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im);
 /* walkers/handler.py:166-181 -> walkers/single_det.py:215-255; detR f64[nw] out (may be NULL) */
 int afq_reortho(afq_handle *h, double *detR_out);
 /* walkers: {use_log_shift: true} (walkers/handler.py:45,228,456-475, walkers/single_det.py:159,192,250-253,320).
@@ -316,6 +326,11 @@ int afq_estimates_rdm_get(afq_handle *h, double *rdm_out /* f64[2, M, M] */, int
 /* Synchronises the stream; also the place where a population that collapsed in an asynchronous comb is
  * reported (AFQ_EWEIGHT, walkers/handler.py:236-241) and an exchange overflow (AFQ_EOVERFLOW).           */
 int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
+/* The same without blocking at enqueue time: _begin enqueues the copy of the sums (and their zeroing) behind the work
+ * already in the stream, _end waits for that copy only -- work enqueued after _begin keeps running.  One fetch in flight
+ * at a time (AFQ_ESTATE).                                                                                            */
+int afq_estimates_get_begin(afq_handle *h, int zero);
+int afq_estimates_get_end(afq_handle *h, double *est_out /* c128[10] */);
 
 /* ---- misc ------------------------------------------------------------------ */
 /* Device stream of auxiliary fields (used by afq_propagate with xi == NULL; replaces numpy.random.normal of

@@ -42,6 +42,8 @@ SIGNATURES = {
     "afq_greens": [_h, c_int, _dp],
     "afq_calc_overlap": [_h, _dp],
     "afq_propagate": [_h, _dp, c_double, c_double],
+    "afq_propagate_begin": [_h, _dp],
+    "afq_propagate_finish": [_h, c_double, c_double],
     "afq_reortho": [_h, _dp],
     "afq_set_log_shift": [_h, c_int, c_double, c_double],
     "afq_log_ovlp_sums": [_h, _dp],
@@ -63,6 +65,8 @@ SIGNATURES = {
     "afq_walkers_reset_weights": [_h],
     "afq_estimates_update": [_h, c_int],
     "afq_estimates_get": [_h, _dp, c_int],
+    "afq_estimates_get_begin": [_h, c_int],
+    "afq_estimates_get_end": [_h, _dp],
     "afq_estimates_rdm": [_h, c_int],
     "afq_estimates_rdm_get": [_h, _dp, c_int],
     "afq_rng_seed": [_h, c_uint64, c_uint64],

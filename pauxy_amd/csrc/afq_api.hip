@@ -240,6 +240,8 @@ int afq_destroy(afq_handle *h) {
     if (h->retired) hipHostFree((void *)h->retired);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
+    if (h->est_event) hipEventDestroy(h->est_event);
+    if (h->est_stage) hipHostFree(h->est_stage);
     for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
     hipStreamDestroy(h->stream);
     delete static_cast<afq_handle_full *>(h);
@@ -673,6 +675,7 @@ static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf);
 static int need_ready(afq_handle *h, bool prop) {
     if (!h->kind || !h->have_trial || !h->nw) AFQ_FAIL(h, AFQ_ESTATE, "system, trial and walkers must be set");
     if (prop && !h->have_prop) AFQ_FAIL(h, AFQ_ESTATE, "propagator not set");
+    if (h->prop_pending) AFQ_FAIL(h, AFQ_ESTATE, "a step is half done: afq_propagate_finish first");
     hipSetDevice(h->device);
     return AFQ_OK;
 }
@@ -790,6 +793,11 @@ static int apply_exp(afq_handle *h, const cplx *vhs) {
 }
 
 int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshift_im) {
+    const int rc = afq_propagate_begin(h, xi);
+    return rc ? rc : afq_propagate_finish(h, eshift_re, eshift_im);
+}
+
+int afq_propagate_begin(afq_handle *h, const double *xi) {
     AFQ_API(h, "afq_propagate");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
@@ -852,6 +860,18 @@ int afq_propagate(afq_handle *h, const double *xi, double eshift_re, double eshi
         { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }    // :162-171
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }        // :258
     }
+    h->prop_pending = true;
+    return AFQ_OK;
+}
+
+int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im) {
+    AFQ_API(h, "afq_propagate");
+    if (!h) return AFQ_EINVAL;
+    if (!h->prop_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_propagate_finish without afq_propagate_begin");
+    hipSetDevice(h->device);
+    h->prop_pending = false;
+    int rc;
+    const bool fp = (h->flags & AFQ_PROP_FREE_PROJECTION) != 0;
     {
         PhaseTimer t(h, T_OVLP);                                                    // :261-262
         // The overlap of the propagated walker is the determinant of the matrix whose inverse the next
@@ -1247,16 +1267,41 @@ int afq_estimates_rdm_get(afq_handle *h, double *rdm_out, int zero) {
 }
 
 int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
-    AFQ_API(h, "afq_estimates_get");
     if (!h || !est_out) return AFQ_EINVAL;
+    const int rc = afq_estimates_get_begin(h, zero);
+    return rc ? rc : afq_estimates_get_end(h, est_out);
+}
+
+int afq_estimates_get_begin(afq_handle *h, int zero) {
+    AFQ_API(h, "afq_estimates_get");
+    if (!h) return AFQ_EINVAL;
     hipSetDevice(h->device);
+    if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
+    const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
+    if (!h->est_stage) {
+        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 4), hipHostMallocDefault));
+        AFQ_HIP(h, hipEventCreateWithFlags(&h->est_event, hipEventDisableTiming));
+    }
     // the one host synchronisation of a block of steps also reports a population that collapsed in an
     // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
-    double sc[4];
-    AFQ_HIP(h, hipMemcpyAsync(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    int rc = copy_out(h, est_out, h->estimates, sizeof(cplx) * AFQ_EST_COUNT_);
-    if (rc) return rc;
+    AFQ_HIP(h, hipMemcpyAsync(h->est_stage, h->estimates, sizeof(double) * nest, hipMemcpyDeviceToHost, h->stream));
+    AFQ_HIP(h, hipMemcpyAsync(h->est_stage + nest, h->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    AFQ_HIP(h, hipEventRecord(h->est_event, h->stream));
     if (zero) AFQ_HIP(h, hipMemsetAsync(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_, h->stream));
+    h->est_pending = true;
+    return AFQ_OK;
+}
+
+int afq_estimates_get_end(afq_handle *h, double *est_out) {
+    AFQ_API(h, "afq_estimates_get");
+    if (!h || !est_out) return AFQ_EINVAL;
+    if (!h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_end without afq_estimates_get_begin");
+    hipSetDevice(h->device);
+    h->est_pending = false;
+    AFQ_HIP(h, hipEventSynchronize(h->est_event));
+    const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
+    memcpy(est_out, h->est_stage, sizeof(double) * nest);
+    const double *sc = h->est_stage + nest;
     if (sc[2] != 0.0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8 in an earlier population control");
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "population control: more walkers moved between two ranks than the "
                                                  "exchange slots hold (afq_comm_init capacity)");

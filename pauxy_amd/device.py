@@ -248,6 +248,16 @@ class AfqDevice(object):
         es = complex(eshift)
         self._ck(self.lib.afq_propagate(self.h, _p(xi), es.real, es.imag))
 
+    def propagate_begin(self, xi):
+        """Everything of a step that does not read the energy shift (afq_propagate_begin)."""
+        if xi is not None:
+            xi = _f64(xi, (self.nw, self.K))
+        self._ck(self.lib.afq_propagate_begin(self.h, _p(xi)))
+
+    def propagate_finish(self, eshift):
+        es = complex(eshift)
+        self._ck(self.lib.afq_propagate_finish(self.h, es.real, es.imag))
+
     def reortho(self, fetch=True):
         out = numpy.empty(self.nw, dtype=numpy.float64) if fetch else None
         self._ck(self.lib.afq_reortho(self.h, _p(out)))
@@ -347,6 +357,15 @@ class AfqDevice(object):
     def estimates_get(self, zero=False):
         out = numpy.empty(10, dtype=numpy.complex128)
         self._ck(self.lib.afq_estimates_get(self.h, _p(out), int(bool(zero))))
+        return out
+
+    def estimates_get_begin(self, zero=False):
+        """Enqueue the fetch; work enqueued afterwards keeps running while estimates_get_end waits for the sums."""
+        self._ck(self.lib.afq_estimates_get_begin(self.h, int(bool(zero))))
+
+    def estimates_get_end(self):
+        out = numpy.empty(10, dtype=numpy.complex128)
+        self._ck(self.lib.afq_estimates_get_end(self.h, _p(out)))
         return out
 
     # -- library-owned communicator -----------------------------------------

@@ -122,6 +122,19 @@ class Continuous(object):
         psi.phi_version += 1
         psi._invalidate('weight', 'ot', 'hybrid_energy', 'phase', 'eloc')
 
+    def propagate_walkers_begin(self, psi):
+        """The part of propagate_walkers that does not read the energy shift (device stream of fields only): everything
+        up to the propagated Slater matrices.  propagate_walkers_finish(psi, eshift) completes the step."""
+        if not self.device_rng:
+            raise NotImplementedError("split step: device stream of auxiliary fields only")
+        psi._flush()
+        self.dev.propagate_begin(None)
+
+    def propagate_walkers_finish(self, psi, eshift):
+        self.dev.propagate_finish(eshift)
+        psi.phi_version += 1
+        psi._invalidate('weight', 'ot', 'hybrid_energy', 'phase', 'eloc')
+
     def _propagate_walker(self, walker, system, trial, eshift):
         if walker._pending:
             walker._pending = False

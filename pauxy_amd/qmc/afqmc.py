@@ -132,10 +132,23 @@ class AFQMC(object):
             self.tstep += time.time() - start_step
 
     # ------------------------------------------------------------ batched loop
-    def step_batched(self, step, eshift, fetch_popcontrol=False):
-        """One step of run() with batched device calls only (qmc/afqmc.py:223-246)."""
+    def step_batched_begin(self, step):
+        """The head of step_batched(step, ...) that does not depend on the energy shift: re-orthogonalisation when due and
+        the propagation up to the new Slater matrices.  run_batched enqueues it for the first step of a block BEFORE it
+        waits for the estimators of the block just ended (which give that block's shift): the device then works through
+        the block boundary instead of idling while the host reduces, prints and derives the shift."""
         psi, dev = self.psi, self.psi.dev
         if step % self.qmc.nstblz == 0:
+            dev.reortho(fetch=False)
+            psi.phi_version += 1
+            psi._invalidate('ot', 'detR', 'weight')
+        self.propagators.propagate_walkers_begin(psi)
+
+    def step_batched(self, step, eshift, fetch_popcontrol=False, begun=False):
+        """One step of run() with batched device calls only (qmc/afqmc.py:223-246).  ``begun``: step_batched_begin(step)
+        has been called already."""
+        psi, dev = self.psi, self.psi.dev
+        if not begun and step % self.qmc.nstblz == 0:
             dev.reortho(fetch=False)
             psi.phi_version += 1
             psi._invalidate('ot', 'detR', 'weight')
@@ -147,7 +160,10 @@ class AFQMC(object):
         if not hirsch:
             # the weight cap of afqmc.py:235-236 rides on the weight-update kernel of the propagation
             dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0 if on_device else psi.total_weight)
-        self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
+        if begun:
+            self.propagators.propagate_walkers_finish(psi, eshift)
+        else:
+            self.propagators.propagate_walkers(psi, self.system, self.trial, eshift)
         if hirsch and step > 1:
             dev.cap_weights(0.10, -1.0 if on_device else psi.total_weight)
             psi._invalidate('weight')
@@ -161,12 +177,16 @@ class AFQMC(object):
         else:
             dev.estimates_update(do_energy)
 
-    def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0, on_step=None, fetch_popcontrol=False):
+    def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0, on_step=None, fetch_popcontrol=False,
+                    overlap_blocks=True):
         """Steps first_step .. first_step+nsteps_total-1 of run() with no host round trip inside a step
         (the estimator sums stay on the device until the end of a block); returns the final eshift.
         ``first_step == 1`` starts with the step-0 estimator pass of qmc/afqmc.py:214-221, like run().
         ``on_step(step, psi)`` (tests) is called after every step; ``fetch_popcontrol`` reads the comb
-        decisions back (``psi.last_parent_ix``)."""
+        decisions back (``psi.last_parent_ix``).  ``overlap_blocks``: at the end of a block the head of the next step
+        (step_batched_begin) is enqueued before the host waits for the block's sums -- same numbers, the device does not
+        idle while the host reduces / prints / derives the shift (continuous fields from the device stream, mixed
+        estimator only, no per-step callback; otherwise the plain order is used)."""
         mixed = self.estimators.estimators['mixed']
         others = [e for k, e in self.estimators.estimators.items() if k != 'mixed']
         n = self.qmc.total_steps if nsteps_total is None else nsteps_total
@@ -189,9 +209,15 @@ class AFQMC(object):
                 dev.estimates_update(True)
             else:
                 mixed.update(self.system, self.qmc, self.trial, self.psi, 0, fp)
+        hirsch = getattr(self.propagators, 'hs_type', '') == 'discrete'
+        overlap = (overlap_blocks and not others and not dcomm and not hirsch and on_step is None
+                   and getattr(self.propagators, 'device_rng', False) and mixed.eval_energy and not mixed.calc_one_rdm
+                   and not self.psi.write_restart)
+        begun = False
         try:
             for step in range(first_step, first_step + n):
-                self.step_batched(step, eshift, fetch_popcontrol)
+                self.step_batched(step, eshift, fetch_popcontrol, begun=begun)
+                begun = False
                 for est in others:                      # back-propagation: estimators/handler.py:156-162
                     est.update(self.system, self.qmc, self.trial, self.psi, step, fp)
                 if on_step is not None:
@@ -199,7 +225,13 @@ class AFQMC(object):
                 if step % self.qmc.nsteps == 0:
                     if dcomm:
                         dev.estimates_allreduce()       # mixed.py:261 on the device, 20 doubles over RCCL
-                    est = dev.estimates_get(zero=True)  # also reports a collapsed population (AFQ_EWEIGHT)
+                    if overlap and step + 1 < first_step + n:
+                        dev.estimates_get_begin(zero=True)
+                        self.step_batched_begin(step + 1)
+                        begun = True
+                        est = dev.estimates_get_end()
+                    else:
+                        est = dev.estimates_get(zero=True)  # also reports a collapsed population (AFQ_EWEIGHT)
                     mixed.estimates[:ns.time] += est[:ns.time]
                     if mixed.calc_one_rdm:
                         mixed.rdm_acc += dev.estimates_rdm_get(zero=True)

@@ -54,6 +54,28 @@ def test_call_order_and_ranges():
     dev.set(L.F_PHI, numpy.array([t.psi] * 4))
     dev.propagate(numpy.zeros((4, 10)), 0.0)
     assert numpy.all(numpy.isfinite(dev.get(L.F_WEIGHT)))
+    # a step in two calls: finish without begin, another step / a re-orthogonalisation inside a half-done step
+    with pytest.raises(L.AfqError) as e:
+        dev.propagate_finish(0.0)
+    assert e.value.code == -2
+    dev.propagate_begin(numpy.zeros((4, 10)))
+    for call in (lambda: dev.propagate_begin(numpy.zeros((4, 10))), lambda: dev.reortho(),
+                 lambda: dev.propagate(numpy.zeros((4, 10)), 0.0)):
+        with pytest.raises(L.AfqError) as e:
+            call()
+        assert e.value.code == -2 and 'half done' in str(e.value)
+    dev.set_weight_cap(0.0)                                  # allowed in between
+    dev.propagate_finish(0.0)
+    # asynchronous fetch of the estimator sums: one in flight, end needs a begin
+    with pytest.raises(L.AfqError) as e:
+        dev.estimates_get_end()
+    assert e.value.code == -2
+    dev.estimates_get_begin()
+    with pytest.raises(L.AfqError) as e:
+        dev.estimates_get_begin()
+    assert e.value.code == -2
+    assert numpy.all(numpy.isfinite(dev.estimates_get_end()))
+    assert numpy.all(numpy.isfinite(dev.get(L.F_WEIGHT)))
     dev.close()
 
 
