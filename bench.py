@@ -289,14 +289,13 @@ def main():
     eshift = afqmc.run_batched(args.warmup, first_step=1, eshift=0.0)
     barrier()
     state["phase"] = "timed region"
-    # Event pairs around the launches of the two kernels that can dominate the step (fused propagator, exchange
-    # energy), read after the timed region.  An event pair costs a few microseconds of pipeline bubble per launch:
-    # with every hot kernel traced the step is 4 % slower (553 vs 531 us), so the per-step GEMMs are timed in a
-    # separate, untimed pass below.
+    # Event pairs around a sample of the launches of the dominant kernel (fused propagator), read after the timed
+    # region.  An event pair costs a few microseconds of pipeline bubble on either side of the launch: with every hot
+    # kernel traced the step is 4 % slower, so the other kernels are timed in a separate, untimed pass below.
     from pauxy_amd import _lib as L
-    in_region = [L.K_PROPAGATOR, L.K_EXCHANGE]
-    # every launch of the exchange kernel (one per 10 steps) but only a sample of the propagator's: the event pair around
-    # a launch opens a ~5.6 us bubble on either side of it (rocprofv3 kernel trace), 3 % of the step if taken every step
+    in_region = [L.K_PROPAGATOR]
+    # only a sample of the propagator's launches: the event pair around a launch opens a ~5.6 us bubble on either side of
+    # it (rocprofv3 kernel trace), 3 % of the step if taken every step
     trace_stride = max(2, args.steps // 8)
     dev.kernel_trace_stride(L.K_PROPAGATOR, trace_stride)
     dev.kernel_trace(True, in_region)
@@ -314,10 +313,10 @@ def main():
         elapsed = float(t.item())
 
     # Rooflines of the hot kernels from HIP events recorded on the library's stream around every launch
-    # (afq_kernel_trace): the dominant candidates INSIDE the timed region, the per-step GEMMs in an extra pass of
-    # 2 blocks right after it; algorithmic flops per launch as in DESIGN.md.
+    # (afq_kernel_trace): the dominant kernel INSIDE the timed region, the GEMMs and the exchange energy in an extra pass
+    # of 4 blocks right after it; algorithmic flops per launch as in DESIGN.md.
     traced = {kind: dev.kernel_trace_get(kind) for kind in in_region}
-    extra_steps = 2 * NSTEPS_BLOCK
+    extra_steps = 4 * NSTEPS_BLOCK
     dev.kernel_trace(True)
     afqmc.run_batched(extra_steps, first_step=args.warmup + args.steps + 1, eshift=eshift)
     dev.sync()

@@ -359,9 +359,6 @@ int afq_timers(afq_handle *h, double *out_ms, int reset);
 int afq_enable_timers(afq_handle *h, int on);
 /* HIP stream of the handle (hipStream_t as void*) */
 int afq_stream(afq_handle *h, void **stream);
-/* duration of the last afq_local_energy exchange kernel, HIP events on the
- * handle's stream (bench.py roofline)                                          */
-int afq_last_energy_kernel_ms(afq_handle *h, double *ms);
 /* Per-launch durations of the hot kernels, HIP events recorded on the handle's
  * stream around the launch (no host synchronisation until _get): bench.py's
  * live roofline measurement over its timed region.  afq_kernel_trace(h, 1)

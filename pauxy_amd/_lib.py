@@ -74,7 +74,6 @@ SIGNATURES = {
     "afq_timers": [_h, _dp, c_int],
     "afq_enable_timers": [_h, c_int],
     "afq_stream": [_h, POINTER(c_void_p)],
-    "afq_last_energy_kernel_ms": [_h, POINTER(c_double)],
     "afq_inverse_overlap": [_h, _dp, _dp],
     "afq_set_propagator_hirsch": [_h, _dp, c_double, c_int],
     "afq_propagate_hirsch": [_h, c_double],

@@ -201,7 +201,6 @@ int afq_create(int device_id, afq_handle **out) {
     h->device = device_id;
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return AFQ_EHIP; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
-    hipEventCreate(&h->ev_e0); hipEventCreate(&h->ev_e1);
     if (hipMalloc(&h->estimates, sizeof(cplx) * AFQ_EST_COUNT_) != hipSuccess ||
         hipMalloc(&h->counters, sizeof(unsigned long long) * 4) != hipSuccess ||
         hipMalloc(&h->scal, sizeof(double) * 8) != hipSuccess) { delete h; return AFQ_ENOMEM; }
@@ -239,7 +238,6 @@ int afq_destroy(afq_handle *h) {
     if (h->zero_page) hipFree(h->zero_page);
     if (h->retired) hipHostFree((void *)h->retired);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
-    hipEventDestroy(h->ev_e0); hipEventDestroy(h->ev_e1);
     if (h->est_event) hipEventDestroy(h->est_event);
     if (h->est_stage) hipHostFree(h->est_stage);
     for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
@@ -986,16 +984,6 @@ int afq_exchange_algorithm(afq_handle *h, int *mode) {
     if (!h || !mode) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_GENERIC || !h->have_trial) AFQ_FAIL(h, AFQ_ESTATE, "generic system and trial must be set");
     *mode = k_exchange_uses_quadratic(h) ? 2 : 1;
-    return AFQ_OK;
-}
-
-int afq_last_energy_kernel_ms(afq_handle *h, double *ms) {
-    if (!h || !ms) return AFQ_EINVAL;
-    if (!h->energy_ev_valid) AFQ_FAIL(h, AFQ_ESTATE, "no exchange kernel launched yet");
-    AFQ_HIP(h, hipEventSynchronize(h->ev_e1));
-    float f = 0;
-    AFQ_HIP(h, hipEventElapsedTime(&f, h->ev_e0, h->ev_e1));
-    *ms = f;
     return AFQ_OK;
 }
 

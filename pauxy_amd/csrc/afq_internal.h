@@ -184,12 +184,10 @@ struct afq_handle {
     int64_t exx_part_len = 0;
     double *gfrag = nullptr;        // Ghalf in MFMA fragment order (energy kernel B operand)
     size_t gfrag_bytes = 0;
-    hipEvent_t ev_e0 = nullptr, ev_e1 = nullptr;   // brackets the exchange kernel
     bool prop_pending = false;                      // afq_propagate_begin done, afq_propagate_finish outstanding
     double *est_stage = nullptr;                    // pinned: estimator sums + scal[4] of an asynchronous fetch
     hipEvent_t est_event = nullptr;
     bool est_pending = false;
-    bool energy_ev_valid = false;
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};

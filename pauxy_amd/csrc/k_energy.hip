@@ -543,7 +543,6 @@ static int launch_exx_quadratic(afq_handle *h) {
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
     const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : (S > 1 ? 1 : 0);
-    AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
     {
         KernelTrace kt(h, AFQ_K_EXCHANGE);
         if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
@@ -559,8 +558,6 @@ static int launch_exx_quadratic(afq_handle *h) {
 #endif
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
     }
-    AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
-    h->energy_ev_valid = true;
     return S;
 }
 
@@ -607,7 +604,6 @@ int k_energy_generic(afq_handle *h) {
     a.afrag[0] = h->rchol_frag[0]; a.afrag[1] = h->rchol_frag[1];
     a.afrag_im[0] = h->rchol_frag_im[0]; a.afrag_im[1] = h->rchol_frag_im[1];
     a.gfrag = h->gfrag; a.part = h->exx_part;
-    AFQ_HIP(h, hipEventRecord(h->ev_e0, h->stream));
     {
         KernelTrace kt(h, AFQ_K_EXCHANGE);
         const long per_xcd = 2L * nxt * ((nwt + 7) / 8) * EXX_CHUNKS;
@@ -618,8 +614,6 @@ int k_energy_generic(afq_handle *h) {
             AFQ_LAUNCH(h, exx_kernel<true>, dim3(nblk), dim3(256), 0, h->stream, a);
     }
     AFQ_POST(h);
-    AFQ_HIP(h, hipEventRecord(h->ev_e1, h->stream));
-    h->energy_ev_valid = true;
     EFinArgs f;
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;

@@ -467,11 +467,6 @@ class AfqDevice(object):
         self._ck(self.lib.afq_exchange_algorithm(self.h, ctypes.byref(m)))
         return m.value
 
-    def last_energy_kernel_ms(self):
-        ms = ctypes.c_double()
-        self._ck(self.lib.afq_last_energy_kernel_ms(self.h, ctypes.byref(ms)))
-        return ms.value
-
 
 # -- in-process communicator: several AfqDevice objects driven by one host thread -----------------------------
 def _handle_array(devs):
