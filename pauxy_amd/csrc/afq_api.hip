@@ -238,7 +238,6 @@ int afq_destroy(afq_handle *h) {
     if (h->zero_page) hipFree(h->zero_page);
     if (h->retired) hipHostFree((void *)h->retired);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
-    if (h->est_event) hipEventDestroy(h->est_event);
     if (h->est_stage) hipHostFree(h->est_stage);
     for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
     hipStreamDestroy(h->stream);
@@ -1260,6 +1259,21 @@ int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
     return rc ? rc : afq_estimates_get_end(h, est_out);
 }
 
+// The sums of a block go to the host through ONE small kernel that writes them into mapped, coherent host memory, zeroes
+// them and then publishes a sequence number there; afq_estimates_get_end polls that number.  The copy / copy / event /
+// memset sequence this replaces cost ~25 us of idle device per block (rocprofv3 kernel trace: 6 us ahead of the fill
+// kernel, 17 us behind it) although more work was already queued.
+__global__ void est_publish_kernel(cplx *est, const double *scal, double *host_out, unsigned long long *host_seq,
+                                   unsigned long long seq, int nest, int zero) {
+    const int t = threadIdx.x;
+    if (t < nest) host_out[t] = ((const double *)est)[t];
+    if (t < 4) host_out[nest + t] = scal[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t < nest && zero) ((double *)est)[t] = 0.0;
+    if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int afq_estimates_get_begin(afq_handle *h, int zero) {
     AFQ_API(h, "afq_estimates_get");
     if (!h) return AFQ_EINVAL;
@@ -1267,15 +1281,19 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
-        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 4), hipHostMallocDefault));
-        AFQ_HIP(h, hipEventCreateWithFlags(&h->est_event, hipEventDisableTiming));
+        // [nest sums | scal[4] | sequence number], written by the device, polled by the host
+        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 4 + 1),
+                                 hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h->est_stage, 0, sizeof(double) * (nest + 4 + 1));
     }
     // the one host synchronisation of a block of steps also reports a population that collapsed in an
     // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
-    AFQ_HIP(h, hipMemcpyAsync(h->est_stage, h->estimates, sizeof(double) * nest, hipMemcpyDeviceToHost, h->stream));
-    AFQ_HIP(h, hipMemcpyAsync(h->est_stage + nest, h->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-    AFQ_HIP(h, hipEventRecord(h->est_event, h->stream));
-    if (zero) AFQ_HIP(h, hipMemsetAsync(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_, h->stream));
+    double *dev_view = nullptr;
+    AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
+    ++h->est_seq;
+    AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
+               (unsigned long long *)(dev_view + nest + 4), h->est_seq, (int)nest, zero);
+    AFQ_POST(h);
     h->est_pending = true;
     return AFQ_OK;
 }
@@ -1286,8 +1304,21 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     if (!h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_end without afq_estimates_get_begin");
     hipSetDevice(h->device);
     h->est_pending = false;
-    AFQ_HIP(h, hipEventSynchronize(h->est_event));
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
+    {
+        // poll the sequence number; the stream query catches a failed launch or device (no endless wait)
+        const unsigned long long *seq = (const unsigned long long *)(h->est_stage + nest + 4);
+        unsigned spins = 0;
+        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != h->est_seq) {
+            if ((++spins & 0x3ffu) == 0) {
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q == hipSuccess) break;                       // everything enqueued has run
+                if (q != hipErrorNotReady) AFQ_HIP(h, q);
+            }
+        }
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != h->est_seq)
+            AFQ_FAIL(h, AFQ_EHIP, "estimator sums were not published by the device");
+    }
     memcpy(est_out, h->est_stage, sizeof(double) * nest);
     const double *sc = h->est_stage + nest;
     if (sc[2] != 0.0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8 in an earlier population control");

@@ -185,8 +185,8 @@ struct afq_handle {
     double *gfrag = nullptr;        // Ghalf in MFMA fragment order (energy kernel B operand)
     size_t gfrag_bytes = 0;
     bool prop_pending = false;                      // afq_propagate_begin done, afq_propagate_finish outstanding
-    double *est_stage = nullptr;                    // pinned: estimator sums + scal[4] of an asynchronous fetch
-    hipEvent_t est_event = nullptr;
+    double *est_stage = nullptr;                    // mapped host memory: estimator sums + scal[4] + sequence number
+    unsigned long long est_seq = 0;
     bool est_pending = false;
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
