@@ -1169,6 +1169,188 @@ __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------
+// Cholesky-QR2 of one walker in ONE work-group (N <= 32 electrons per spin, the walker and both Gram matrices in LDS).
+// The GEMM-engine version (k_reortho_big: Gram, Cholesky, Q = phi R^-1 as three launches per pass, twice) spends
+// ~160 us per re-orthogonalisation at C3 sizes on six latency-bound launches of 25 us each for ~5 us of arithmetic; here
+// the passes run back to back out of LDS:
+//   Gram  S_s = phi_s^H phi_s          fp64 MFMA, waves 0-3 spin up, 4-7 spin down, one 16x16 tile per wave
+//   Chol  T = R^-1 (S = R^H R)         one wave per spin, register resident (chol_block8, gj_wave.h)
+//   Q     phi_s <- phi_s T             fp64 MFMA, in place: a wave owns a 16-row tile, whose fragments it holds in registers
+// Same algorithm, same fallback contract as k_reortho_big: a walker whose Cholesky breaks down (fail[w] = 1) is left
+// untouched for the Gram-Schmidt kernel.  (reference: scipy.linalg.qr + sign fix, walkers/single_det.py:228-255)
+struct RfArgs {
+    int M, na, nb, nt, nw, fp;
+    cplx *phi;
+    double *detR, *weight;
+    cplx *ot;
+    int *fail;
+};
+
+__global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cplx rowk_s[2][32];
+    __shared__ double piv_s[2][32];
+    __shared__ double logd_s[2];
+    __shared__ int bad_s[2];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int M = a.M, nt = a.nt;
+    const int n = g == 0 ? a.na : a.nb, off = g == 0 ? 0 : a.na;
+    cplx *phi_l = (cplx *)smem;                              // [M, nt]
+    cplx *S = phi_l + (long)M * nt + (long)g * 1024;         // [32, 32] Gram matrix, then T^T, of this spin
+    cplx *phi_g = a.phi + (long)w * M * nt;
+    for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
+    if (tid < 2) { logd_s[tid] = 0.0; bad_s[tid] = 0; }
+    __syncthreads();
+    const int nt16 = (n + 15) >> 4, mt16 = (M + 15) >> 4, nks = (M + 3) >> 2, nks3 = (n + 3) >> 2;
+    for (int pass = 0; pass < 2; ++pass) {
+        // ---- Gram matrix
+        for (int t = wave; t < nt16 * nt16; t += 4) {
+            const int ti = t / nt16, tj = t % nt16;
+            const int ia = ti * 16 + lr, jb = tj * 16 + lr;
+            const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;
+            d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
+            for (int ks = 0; ks < nks; ++ks) {
+                const int p = ks * 4 + lk, pc = p < M ? p : M - 1;
+                cplx x = phi_l[pc * nt + off + iac], y = phi_l[pc * nt + off + jbc];
+                if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
+                if (!(p < M && jb < n)) y = cmake(0.0, 0.0);
+                accR = mfma16(x.x, y.x, accR);               // conj(x) * y, the two chains alternate
+                accI = mfma16(x.x, y.y, accI);
+                accR = mfma16(x.y, y.y, accR);
+                accI = mfma16(-x.y, y.x, accI);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
+                if (i < n && j < n) S[i * 32 + j] = cmake(accR[r], accI[r]);
+            }
+        }
+        __syncthreads();
+        // ---- inverse Cholesky factor: T^T[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (see chol_small_kernel)
+        if (wave == 0 && n > 0) {
+            const int h2 = lane >> 5, r = lane & 31;
+            double vr[16], vi[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = 16 * h2 + j;
+                const cplx t = (r < n && c < n) ? S[r * 32 + c] : cmake(0.0, 0.0);
+                vr[j] = t.x; vi[j] = t.y;
+            }
+            if (lane < 32) piv_s[g][lane] = 1.0;
+            bool bad = false;
+            __builtin_amdgcn_wave_barrier();
+            const int nit = (n + 7) >> 3;
+            for (int it = 0; it < nit; ++it) chol_block8(vr, vi, it, n, lane, rowk_s[g], piv_s[g], bad);
+            __builtin_amdgcn_wave_barrier();
+            if (r < n) {
+                const int rot = 8 * (nit & 1);
+                const double rs = 1.0 / sqrt(piv_s[g][r]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int c = 16 * h2 + ((j + rot) & 15);
+                    if (c >= n) continue;
+                    cplx t = cmake(0.0, 0.0);
+                    if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
+                    else if (c == r) t = cmake(rs, 0.0);
+                    S[r * 32 + c] = t;
+                }
+            }
+            double l = lane < n ? log(piv_s[g][lane & 31]) : 0.0;
+            if (lane >= 32) l = 0.0;
+            for (int o = 16; o > 0; o >>= 1) l += __shfl_down(l, o);
+            // a pivot that is not a positive finite number: breakdown
+            const unsigned long long anybad = __ballot(bad || !(l == l));
+            if (lane == 0) {
+                logd_s[g] += 0.5 * l;
+                if (anybad) bad_s[g] = 1;
+            }
+        }
+        __syncthreads();
+        if (bad_s[0] | bad_s[1]) {                           // leave the walker to the Gram-Schmidt kernel
+            if (tid == 0) a.fail[w] = 1;
+            return;
+        }
+        // ---- Q = phi T in place: a wave takes whole 16-row tiles (all their columns), the row fragments in registers
+        for (int ti = wave; ti < mt16 && n > 0; ti += 4) {
+            const int pa = ti * 16 + lr, pac = pa < M ? pa : M - 1;
+            cplx xf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int k = ks * 4 + lk, kc = k < n ? k : n - 1;
+                const cplx x = phi_l[pac * nt + off + kc];
+                xf[ks] = (ks < nks3 && k < n && pa < M) ? x : cmake(0.0, 0.0);
+            }
+            d4_t p1[2], p2[2], p3[2];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                p1[tj] = (d4_t){0, 0, 0, 0}; p2[tj] = (d4_t){0, 0, 0, 0}; p3[tj] = (d4_t){0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks < nks3) {
+                    const int k = ks * 4 + lk, kc = k < n ? k : n - 1;
+                    const cplx x = xf[ks];
+                    const double xs = x.x + x.y;
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        if (tj < nt16) {
+                            const int j = tj * 16 + lr, jc = j < n ? j : n - 1;
+                            cplx y = S[jc * 32 + kc];        // T[k][j] = T^T[j][k]
+                            if (!(k < n && j < n)) y = cmake(0.0, 0.0);
+                            p1[tj] = mfma16(x.x, y.x, p1[tj]);
+                            p2[tj] = mfma16(x.y, y.y, p2[tj]);
+                            p3[tj] = mfma16(xs, y.x + y.y, p3[tj]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                if (tj < nt16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
+                        if (p < M && j < n)
+                            phi_l[p * nt + off + j] = cmake(p1[tj][r] - p2[tj][r], p3[tj][r] - p1[tj][r] - p2[tj][r]);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < M * nt; e += 512) phi_g[e] = phi_l[e];
+    if (tid == 0) {
+        const double d = exp(logd_s[0] + logd_s[1]);
+        a.fail[w] = 0;
+        a.detR[w] = d;
+        a.ot[w] = cmake(a.ot[w].x / d, a.ot[w].y / d);       // single_det.py:253
+        if (a.fp) a.weight[w] *= d;                          // walkers/handler.py:178-181
+    }
+}
+
+static bool reortho_fused_supported(afq_handle *h, size_t *lds_out) {
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    const size_t lds = sizeof(cplx) * ((size_t)h->M * h->nt + 2 * 1024);
+    *lds_out = lds;
+    static const bool off = afq_knob("AFQ_NO_REORTHO_FUSED") != nullptr;
+    return !off && nmax <= 32 && h->nb > 0 && h->M >= 16 && lds <= 150 * 1024;
+}
+
+static int k_reortho_fused(afq_handle *h, size_t lds) {
+    if (!h->qr_fail) AFQ_HIP(h, hipMalloc(&h->qr_fail, sizeof(int) * h->nw));
+    RfArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
+    a.fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
+    a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot; a.fail = h->qr_fail;
+    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+    AFQ_HIP(h, afq_raise_lds((const void *)reortho_fused_kernel, lds, lds_set));
+    AFQ_LAUNCH(h, reortho_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
 int k_reortho(afq_handle *h) {
     QrArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.flags = h->flags;
@@ -1179,7 +1361,12 @@ int k_reortho(afq_handle *h) {
     // Cholesky-QR2 on the GEMM engines: always for 45 < N <= 128; for smaller N once the population is
     // large enough that seven launches beat the one latency-bound Gram-Schmidt work-group per walker
     const bool small_ok = nmax <= 45 && h->nb > 0 && !h->no_ring && h->nw >= 64 && h->M >= 32;
-    if ((k_greens_big_supported(h) || small_ok) && !no_cholqr) {
+    size_t lds_fused = 0;
+    if (small_ok && !no_cholqr && reortho_fused_supported(h, &lds_fused)) {
+        int rc = k_reortho_fused(h, lds_fused);
+        if (rc) return rc;
+        a.only = h->qr_fail;
+    } else if ((k_greens_big_supported(h) || small_ok) && !no_cholqr) {
         int rc = k_reortho_big(h);
         if (rc) return rc;
         a.only = h->qr_fail;
