@@ -290,3 +290,34 @@ def test_spin_summed_force_bias_follows_clones_and_reorthos():
         close(dev.get(L.F_HYBRID_ENERGY), numpy.array([w['hybrid_energy'] for w in walkers]), 1e-9)
     assert cloned
     dev.close()
+
+
+def test_fused_reortho_breakdown_fallback():
+    """The one-work-group Cholesky-QR2 (N <= 32 per spin, populations of 64 walkers and more): healthy walkers against the
+    oracle's QR, a numerically rank-deficient walker (Cholesky breakdown or not: either way the result must be an
+    orthonormal basis of the same span) and na != nb with a spin of fewer than 16 electrons."""
+    M, K, na, nb, nw = 40, 12, 19, 9, 66
+    model, rng = build(M, K, na, nb, True, seed=5)
+    dev = make_device(model, nw)
+    phis = model.psi[None] + 0.05 * (rng.rand(nw, M, na + nb) + 1j * rng.rand(nw, M, na + nb))
+    phis[2][:, 7] = phis[2][:, 3] * (1.0 + 1e-9) + 1e-10 * rng.rand(M)       # cond ~ 1e9
+    phis[40][:, na + 4] = phis[40][:, na + 1] * (1.0 - 1e-9) + 1e-10 * rng.rand(M)
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_OT, numpy.ones(nw, dtype=complex))
+    detR = dev.reortho()
+    q = dev.get(L.F_PHI)
+    ot = dev.get(L.F_OT)
+    assert numpy.all(numpy.isfinite(detR)) and numpy.all(numpy.isfinite(q.view(float)))
+    for w in range(nw):
+        for sl in (slice(0, na), slice(na, na + nb)):
+            close(q[w][:, sl].conj().T @ q[w][:, sl], numpy.eye(sl.stop - sl.start), 1e-10)
+        if w not in (2, 40):
+            p = phis[w].copy()
+            d = ref.reortho(p, na, nb)
+            close(q[w], p, 1e-9)
+            close(detR[w], d, 1e-9)
+            close(ot[w], 1.0 / d, 1e-9)
+    for w, sl in ((2, slice(0, na)), (40, slice(na, na + nb))):                # span preserved for the repaired walkers
+        qa = q[w][:, sl]
+        close(qa @ (qa.conj().T @ phis[w][:, sl]), phis[w][:, sl], 1e-9)
+    dev.close()
