@@ -377,7 +377,7 @@ int k_update_weight(afq_handle *h, cplx eshift);
 int k_reortho(afq_handle *h);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);
 int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
-int k_clone_pairs(afq_handle *h, bool with_greens);
+int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights = false);
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[w]
 int k_log_shift_reortho(afq_handle *h);                            // detR -> exp(log det R - detR_shift), log_detR += log
 int k_log_ovlp_sums(afq_handle *h, double *out3);                  // sums of |ot|, |detR|, |log_detR| (device -> host)

@@ -1515,10 +1515,18 @@ struct CloneArgs {
     cplx *ghalf, *ovlp_new;
     cplx *G;             // walker.G as walker state (mixed one_rdm); null otherwise
     long gsz;
+    cplx *gsum;          // Ghalf_a + Ghalf_b of the force bias, kept in step with ghalf; null when it is not current
+    long gsum_per;
+    double *weight;      // single-rank comb: every weight back to 1 (handler.py:337-338) in this launch; null otherwise
+    int nw;
 };
 
 __global__ void clone_kernel(CloneArgs a) {
     const int pr = blockIdx.y;
+    if (a.weight && blockIdx.x == 0 && !(a.scal[1] < 0.0)) {        // (collapsed population: see comb_plan_kernel)
+        const int wr = blockIdx.y * blockDim.x + threadIdx.x;
+        if (wr < a.nw) a.weight[wr] = 1.0;
+    }
     if (pr >= (int)a.scal[1]) return;
     const int src = a.pairs[2 * pr], dst = a.pairs[2 * pr + 1];
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.per; i += (long)gridDim.x * blockDim.x)
@@ -1528,6 +1536,9 @@ __global__ void clone_kernel(CloneArgs a) {
             a.ghalf[dst * a.per + i] = a.ghalf[src * a.per + i];
         if (blockIdx.x == 0 && threadIdx.x == 0) a.ovlp_new[dst] = a.ovlp_new[src];
     }
+    if (a.gsum)
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gsum_per; i += (long)gridDim.x * blockDim.x)
+            a.gsum[dst * a.gsum_per + i] = a.gsum[src * a.gsum_per + i];
     if (a.G)
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gsz; i += (long)gridDim.x * blockDim.x)
             a.G[dst * a.gsz + i] = a.G[src * a.gsz + i];
@@ -1605,9 +1616,14 @@ int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
 }
 
 // clone_kernel over the (src, dst) pairs in h->pack_tmp, count in scal[1]; at most nw / 2 pairs
-int k_clone_pairs(afq_handle *h, bool with_greens) {
-    ++h->ghalf_version;                 // cloned walkers bring their Ghalf along (ghalf_sum goes stale)
+int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights) {
+    // cloned walkers bring their Ghalf along, and its spin sum when that is current (it then stays current)
+    const bool sum_too = with_greens && h->ghalf_sum && h->gsum_version == h->ghalf_version;
+    ++h->ghalf_version;
+    if (sum_too) h->gsum_version = h->ghalf_version;
     CloneArgs a;
+    a.gsum = sum_too ? h->ghalf_sum : nullptr; a.gsum_per = (long)h->na * h->M;
+    a.weight = reset_weights ? h->weight : nullptr; a.nw = h->nw;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;
     a.eloc = h->eloc; a.unscaled = h->unscaled; a.detR = h->detR; a.log_detR = h->log_detR;
     a.pairs = (const int *)h->pack_tmp; a.scal = h->scal;
@@ -1615,6 +1631,7 @@ int k_clone_pairs(afq_handle *h, bool with_greens) {
     a.bp_n = h->bp_n; a.hist_per = (long)h->nbp * h->K;
     a.ghalf = with_greens ? h->ghalf : nullptr; a.ovlp_new = h->ovlp_new;
     a.G = (h->rdm_on && h->G) ? h->G : nullptr; a.gsz = 2L * h->M * h->M;
+    // (grid.y * 256 threads of the x == 0 blocks cover every walker for the weight reset)
     AFQ_LAUNCH(h, clone_kernel, dim3(4, (h->nw + 1) / 2), dim3(256), 0, h->stream, a);
     AFQ_POST(h);
     return AFQ_OK;
@@ -1626,9 +1643,7 @@ int k_comb(afq_handle *h, double r, double target, bool with_greens) {
     AFQ_LAUNCH(h, comb_plan_kernel, dim3(1), dim3(256), (sizeof(double) + 3 * sizeof(int)) * (size_t)h->nw,
                h->stream, h->weight, h->unscaled, h->nw, r, target, h->parent_ix, pairs, h->scal);
     AFQ_POST(h);
-    int rc = k_clone_pairs(h, with_greens);
-    if (rc) return rc;
-    return k_reset_weights(h, true);
+    return k_clone_pairs(h, with_greens, true);       // the weights go back to 1 in the same launch
 }
 
 // --------------------------------------------------------------------------
