@@ -61,7 +61,7 @@ struct afq_handle {
     void *atil[2] = {nullptr, nullptr};
     bool rchol_same = false;        // alpha and beta blocks of rchol are bitwise equal
     int exx_mode = 0;               // afq_set_exchange_algorithm: 0 auto, 1 T-intermediate (exx_kernel), 2 quadratic form
-    cplx *exq_y = nullptr;          // [2 * slices, nw, ldy] partial products of the quadratic form
+    cplx *exq_y = nullptr;          // [2 * slices, nw, ceil(N M / 16)] per-tile partial sums of the quadratic form
     size_t exq_y_len = 0;
     cplx *H1 = nullptr;             // [2, M, M]
     cplx *rH1 = nullptr;            // half-rotated H1: [nt, M]; rH1[i][q] = sum_p conj(psi[p,i]) H1_s[p,q]

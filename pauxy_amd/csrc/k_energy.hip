@@ -231,8 +231,12 @@ struct ExxQProb {
     const void *B[EXQ_MAX_BATCH];     // Atil_s + (slice start) * ldq
     long ldq[EXQ_MAX_BATCH];
     const cplx *ghalf;
-    cplx *Y;                          // [batch, nw, ldy] partial products
-    long ldy;
+    // the product g^T Atil never goes to memory: every 16-column tile of it is contracted with g again in the epilogue
+    // (ROWDOT) and only those partial sums are stored, E[batch, nw, ncb] with ncb = ceil(cols / 16)
+    static constexpr bool ROWDOT = true;
+    long soff[EXQ_MAX_BATCH];         // first element of the batch's spin inside a walker's ghalf
+    cplx *E;
+    int ncb;
     const cplx *zero;
     __device__ bool active(int) const { return true; }
     __device__ const cplx *ptrA(int b, int row, int k) const {
@@ -259,8 +263,12 @@ struct ExxQProb {
     __device__ long kstepB(int b) const { return ldq[b]; }
     __device__ bool rowok(int, int) const { return true; }
     __device__ bool colok(int b, int col) const { return col < ncol[b]; }
-    __device__ void store(int b, int row, int col, double re, double im) const {
-        if (col < ncol[b]) Y[((long)b * rows + row) * ldy + col] = cmake(re, im);
+    __device__ void store(int, int, int, double, double) const {}
+    __device__ cplx dot_operand(int b, int row, int col) const {
+        return col < ncol[b] ? ghalf[row * astride + soff[b] + col] : cmake(0.0, 0.0);
+    }
+    __device__ void store_dot(int b, int row, int tile, double re, double im) const {
+        E[((long)b * rows + row) * ncb + tile] = cmake(re, im);
     }
 };
 
@@ -351,10 +359,9 @@ struct EFinArgs {
     double ecore;
     const cplx *rH1, *ghalf, *vbias, *part;
     cplx *energy;
-    // quadratic-form exchange: Y[2 * qsplit, nw, ldy] (null: exx_kernel partials in `part`)
-    const cplx *Yq;
-    int qsplit, na;
-    long ldy;
+    // quadratic-form exchange: E[2 * qsplit, nw, ncb] partial sums of (g^T Atil)[q] g[q] (null: exx_kernel partials in `part`)
+    const cplx *Eq;
+    int qsplit, na, nb, ncb;
 };
 
 // EF_THR threads per walker: the kernel streams Ghalf, rH1, the Coulomb partials and (quadratic-form exchange) the
@@ -368,18 +375,17 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
     const long nq = (long)a.nt * a.M;
     const cplx *gh = a.ghalf + (long)w * nq;
     double exr = 0, exi = 0;
-    const long nqa = (long)a.na * a.M;
     for (long q = tid; q < nq; q += EF_THR) {
         const cplx h = a.rH1[q], g = gh[q];
         e1r += h.x * g.x - h.y * g.y;
         e1i += h.x * g.y + h.y * g.x;
-        if (a.Yq) {      // exx += (g^T Atil)[q] g[q], slices summed in a fixed order
-            const int s = q < nqa ? 0 : 1;
-            const long c = q - (s ? nqa : 0);
-            cplx y = cmake(0.0, 0.0);
-            for (int sl = 0; sl < a.qsplit; ++sl) y = cadd(y, a.Yq[((long)(s * a.qsplit + sl) * a.nw + w) * a.ldy + c]);
-            exr += y.x * g.x - y.y * g.y;
-            exi += y.x * g.y + y.y * g.x;
+    }
+    if (a.Eq) {          // exchange: the per-tile partial sums the GEMM epilogue left, in a fixed order
+        const int nb_ = a.qsplit * (a.nb > 0 ? 2 : 1);               // the batches of a spin without electrons are never written
+        for (int t = tid; t < nb_ * a.ncb; t += EF_THR) {
+            const int b = t / a.ncb, ct = t % a.ncb;
+            const cplx v = a.Eq[((long)b * a.nw + w) * a.ncb + ct];
+            exr += v.x; exi += v.y;
         }
     }
     // Coulomb
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
     }
     // exchange partials of this walker (exx_kernel path)
     const int wt = w >> 4, wl = w & 15;
-    const int np = a.Yq ? 0 : 2 * a.nxt * EXX_CHUNKS;
+    const int np = a.Eq ? 0 : 2 * a.nxt * EXX_CHUNKS;
     for (int t = tid; t < np; t += EF_THR) {
         const int chunk = t % EXX_CHUNKS;
         const int xt = (t / EXX_CHUNKS) % a.nxt;
@@ -513,7 +519,7 @@ static int launch_exx_quadratic(afq_handle *h) {
     for (int b = 0; b < 2 * S; ++b) {
         const int s = b / S, sl = b % S;
         const long tot = s == 0 ? nma : nmb;
-        if (tot == 0) { p.goff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; p.k0[b] = 0; continue; }
+        if (tot == 0) { p.goff[b] = 0; p.soff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; p.k0[b] = 0; continue; }
         const long ldq = (tot + 1) & ~1L;
         // slices of EQUAL WORK on the triangular operand: row a meets tot - a columns, so the boundaries sit at
         // tot (1 - sqrt(1 - s / S)) (rounded to whole k-chunks); every slice is one batch = one XCD's share
@@ -526,20 +532,21 @@ static int launch_exx_quadratic(afq_handle *h) {
         };
         long k0 = bound(sl), l = bound(sl + 1) - k0;
         if (l < 0) { l = 0; k0 = 0; }
-        p.goff[b] = (s ? nma : 0) + k0;
+        p.goff[b] = (s ? nma : 0) + k0; p.soff[b] = s ? nma : 0;
         p.len[b] = (int)l; p.ncol[b] = (int)tot;
         p.B[b] = h->rchol_real ? (const void *)((const double *)h->atil[s] + k0 * ldq) : (const void *)((const cplx *)h->atil[s] + k0 * ldq);
         p.ldq[b] = ldq; p.k0[b] = k0;
         if (l > kmax) kmax = (int)l;
     }
     p.kdim = kmax;
-    const size_t need = (size_t)2 * S * h->nw * nmax;
+    p.ncb = (int)((nmax + 15) / 16);
+    const size_t need = (size_t)2 * S * h->nw * p.ncb;
     if (h->exq_y_len < need) {
         if (h->exq_y) hipFree(h->exq_y);
         AFQ_HIP(h, hipMalloc(&h->exq_y, sizeof(cplx) * need));
         h->exq_y_len = need;
     }
-    p.Y = h->exq_y; p.ldy = nmax;
+    p.E = h->exq_y;
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
     const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : (S > 1 ? 1 : 0);
@@ -574,8 +581,8 @@ int k_energy_generic(afq_handle *h) {
         EFinArgs f;
         f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
         f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = nullptr;
-        f.energy = h->energy; f.Yq = h->exq_y; f.qsplit = S; f.na = h->na;
-        f.ldy = (long)(h->na > h->nb ? h->na : h->nb) * M;
+        f.energy = h->energy; f.Eq = h->exq_y; f.qsplit = S; f.na = h->na; f.nb = h->nb;
+        f.ncb = (int)(((long)(h->na > h->nb ? h->na : h->nb) * M + 15) / 16);
         AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
         AFQ_POST(h);
         return AFQ_OK;
@@ -617,7 +624,7 @@ int k_energy_generic(afq_handle *h) {
     EFinArgs f;
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
-    f.energy = h->energy; f.Yq = nullptr; f.qsplit = 0; f.na = h->na; f.ldy = 0;
+    f.energy = h->energy; f.Eq = nullptr; f.qsplit = 0; f.na = h->na; f.nb = h->nb; f.ncb = 0;
     AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
     AFQ_POST(h);
     return AFQ_OK;

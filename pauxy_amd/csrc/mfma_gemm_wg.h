@@ -45,6 +45,24 @@ __device__ unsigned long long *afq_gemm_ts = nullptr;
 // tile at columns [col0, col0 + ncols) of batch b needs (<= kdim; B is zero beyond it for these columns: triangular B)
 template <class P, class = void> struct gemm_kcut { static constexpr bool value = false; };
 template <class P> struct gemm_kcut<P, decltype((void)P::KCUT)> { static constexpr bool value = P::KCUT; };
+// optional problem trait: static constexpr bool ROWDOT = true -- the product itself is not stored; every output element is
+// multiplied with dot_operand(b, row, col) and the sums over the 16 columns of a tile go to store_dot(b, row, tile, re, im)
+// (a quadratic form x^T A x evaluated as sum_col (x^T A)[col] x[col] without the round trip of x^T A through memory)
+template <class P, class = void> struct gemm_rowdot { static constexpr bool value = false; };
+template <class P> struct gemm_rowdot<P, decltype((void)P::ROWDOT)> { static constexpr bool value = P::ROWDOT; };
+template <int CTRL> __device__ inline double gemm_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over each group of 16 consecutive lanes, left in all of them: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ inline double gemm_row16_sum(double v) {
+    v += gemm_dpp_f64<0xB1>(v);
+    v += gemm_dpp_f64<0x4E>(v);
+    v += gemm_dpp_f64<0x141>(v);
+    v += gemm_dpp_f64<0x140>(v);
+    return v;
+}
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -421,6 +439,29 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
             }
     }
     const int wrow0 = row0 + wm * TM * 16, wcol0 = col0 + wn * TN * 16;
+    if constexpr (gemm_rowdot<P>::value) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wrow0 + i * 16 + lk + 4 * r;
+                double sr = 0.0, si = 0.0;                   // this lane's column of each of the wave's TN tiles
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = wcol0 + j * 16 + lr;
+                    if (row < p.rows && col < p.cols) {
+                        const cplx g = p.dot_operand(b, row, col);
+                        sr += accR[i][j][r] * g.x - accI[i][j][r] * g.y;
+                        si += accR[i][j][r] * g.y + accI[i][j][r] * g.x;
+                    }
+                }
+                // sum over the 16 lanes of one accumulator row (lr = lane & 15) with DPP moves; every lane takes part
+                sr = gemm_row16_sum(sr); si = gemm_row16_sum(si);
+                // one partial sum per wave and row, filed under the wave's first tile; its other tiles get a zero
+                if (lr < TN && row < p.rows && wcol0 + lr * 16 < p.cols)
+                    p.store_dot(b, row, (wcol0 >> 4) + lr, lr == 0 ? sr : 0.0, lr == 0 ? si : 0.0);
+            }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -431,6 +472,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
                 const int col = wcol0 + j * 16 + lr;
                 if (row < p.rows && col < p.cols) p.store(b, row, col, accR[i][j][r], accI[i][j][r]);
             }
+    }
 #ifdef AFQ_TUNING
     if (afq_gemm_ts && threadIdx.x == 0 && blockIdx.x < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
