@@ -870,31 +870,44 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
     } else if (alive && !alive[w]) return;
     // sums: mean-field shift (re, im), xi . xbar (re, im), xbar . xbar (re, im), clipped count
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    // a thread takes the two members of one Philox pair (elements 2 p, 2 p + 1 of the stream: consecutive fields of this
-    // walker, or its first / last field alone when the walker's K fields start or end inside a pair), so that a pair is
-    // generated once -- with a thread per field every pair was generated twice and one normal of each thrown away
+    auto element = [&](const long e, const int n, const double xdev) {
+        cplx b = FUSED ? xbar_value(xa, w, n) : xbar[e];
+        const double ab = hypot(b.x, b.y);
+        if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
+        const double x = rng.on ? xdev : xi[e];
+        const cplx sft = cmake(x - b.x, -b.y);
+        xbar[e] = b;
+        xs[e] = sft;
+        const cplx mm = mf[n];
+        acc[0] += sft.x * mm.x - sft.y * mm.y;
+        acc[1] += sft.x * mm.y + sft.y * mm.x;
+        acc[2] += x * b.x; acc[3] += x * b.y;
+        acc[4] += b.x * b.x - b.y * b.y;
+        acc[5] += 2.0 * b.x * b.y;
+    };
     const long e0 = (long)w * K;
-    for (long pr = (e0 >> 1) + threadIdx.x; pr <= ((e0 + K - 1) >> 1); pr += NTHR) {
-        double xn[2] = {0.0, 0.0};
-        if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
+    if (K <= NTHR) {
+        // a thread per field (a Philox pair is then generated by both of its threads): with few fields the evaluation of the
+        // force bias (xbar_value: a contraction per element for the lattice models) wants every thread of the work-group
+        const int n = threadIdx.x;
+        if (n < K) {
+            double xn[2] = {0.0, 0.0};
+            if (rng.on) philox_normal_pair((e0 + n) >> 1, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
+            element(e0 + n, n, xn[(e0 + n) & 1]);
+        }
+    } else {
+        // a thread takes the two members of one Philox pair (elements 2 p, 2 p + 1 of the stream: consecutive fields of
+        // this walker, or its first / last field alone when the walker's K fields start or end inside a pair), so that a
+        // pair is generated once -- with a thread per field every pair was generated twice and one normal of each thrown away
+        for (long pr = (e0 >> 1) + threadIdx.x; pr <= ((e0 + K - 1) >> 1); pr += NTHR) {
+            double xn[2] = {0.0, 0.0};
+            if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const long e = 2 * pr + m;
-            const int n = (int)(e - e0);
-            if (n < 0 || n >= K) continue;
-            cplx b = FUSED ? xbar_value(xa, w, n) : xbar[e];
-            const double ab = hypot(b.x, b.y);
-            if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
-            const double x = rng.on ? xn[m] : xi[e];
-            const cplx sft = cmake(x - b.x, -b.y);
-            xbar[e] = b;
-            xs[e] = sft;
-            const cplx mm = mf[n];
-            acc[0] += sft.x * mm.x - sft.y * mm.y;
-            acc[1] += sft.x * mm.y + sft.y * mm.x;
-            acc[2] += x * b.x; acc[3] += x * b.y;
-            acc[4] += b.x * b.x - b.y * b.y;
-            acc[5] += 2.0 * b.x * b.y;
+            for (int m = 0; m < 2; ++m) {
+                const long e = 2 * pr + m;
+                const int n = (int)(e - e0);
+                if (n >= 0 && n < K) element(e, n, xn[m]);
+            }
         }
     }
     // one reduction for all seven sums: wave shuffles, one barrier
