@@ -296,7 +296,7 @@ def main():
     in_region = [L.K_PROPAGATOR]
     # only a sample of the propagator's launches: the event pair around a launch opens a ~5.6 us bubble on either side of
     # it (rocprofv3 kernel trace), 3 % of the step if taken every step
-    trace_stride = max(2, args.steps // 8)
+    trace_stride = max(2, args.steps // 4)
     dev.kernel_trace_stride(L.K_PROPAGATOR, trace_stride)
     dev.kernel_trace(True, in_region)
     t0 = time.perf_counter()
