@@ -181,7 +181,10 @@ __device__ inline void chol_block8(double (&vr)[16], double (&vi)[16], int it, i
             const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), k),
                                               __builtin_amdgcn_readlane(__double2loint(fx), k));
             bad = bad || !(d > 0.0);
-            const double dinv = 1.0 / d;
+            // reciprocal by v_rcp_f64 + two Newton steps (see gj_block8: the IEEE division is a 12-deep dependent chain)
+            double dinv = __builtin_amdgcn_rcp(d);
+            dinv = fma(fma(-d, dinv, 1.0), dinv, dinv);
+            dinv = fma(fma(-d, dinv, 1.0), dinv, dinv);
             if (lane == 0) piv[k] = d;
             const double mx = r > k ? fx * dinv : 0.0, my = r > k ? fy * dinv : 0.0;
             __builtin_amdgcn_sched_barrier(0);

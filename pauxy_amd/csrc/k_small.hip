@@ -371,12 +371,13 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     // ---- phase 2
     __shared__ cplx gj_row[2][32], gj_piv[2][32];
     __shared__ int gj_prow[2][32];
-    if (wave == 0 && !(a.dbg & 1) && n <= 32 && !(a.dbg & 8)) {
+    // (the two single-wave inversions run on different SIMDs: spin up on wave 0, spin down on wave 1 of its group = wave 5)
+    if (wave == (n <= 32 ? g : 0) && !(a.dbg & 1) && n <= 32 && !(a.dbg & 8)) {
         cplx ph;
         int la;
         gj_wave32(O, n, lane, INVERSE, gj_row[g], gj_piv[g], gj_prow[g], ph, la);
         if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
-    } else if (wave == 0 && !(a.dbg & 1)) {
+    } else if (wave == 0 && !(a.dbg & 1) && (n > 32 || (a.dbg & 8))) {
         // det = prod of pivots, kept as (mantissa, binary exponent) so that neither log, exp nor
         // hypot sits on the per-pivot critical path
         cplx ph = cmake(1.0, 0.0);
@@ -1200,6 +1201,12 @@ struct RfArgs {
     int *fail;
 };
 
+#ifdef AFQ_TUNING
+__device__ unsigned long long *afq_rf_ts = nullptr;
+#define RF_STAMP(i) do { if (afq_rf_ts && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); afq_rf_ts[i] = t_; } } while (0)
+#else
+#define RF_STAMP(i)
+#endif
 __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cplx rowk_s[2][32];
@@ -1214,9 +1221,11 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
     cplx *phi_l = (cplx *)smem;                              // [M, nt]
     cplx *S = phi_l + (long)M * nt + (long)g * 1024;         // [32, 32] Gram matrix, then T^T, of this spin
     cplx *phi_g = a.phi + (long)w * M * nt;
+    RF_STAMP(0);
     for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
     if (tid < 2) { logd_s[tid] = 0.0; bad_s[tid] = 0; }
     __syncthreads();
+    RF_STAMP(1);
     const int nt16 = (n + 15) >> 4, mt16 = (M + 15) >> 4, nks = (M + 3) >> 2, nks3 = (n + 3) >> 2;
     for (int pass = 0; pass < 2; ++pass) {
         // ---- Gram matrix
@@ -1225,11 +1234,18 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             const int ia = ti * 16 + lr, jb = tj * 16 + lr;
             const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;
             d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
-            for (int ks = 0; ks < nks; ++ks) {
+            // the fragments of contraction step ks + 1 are read while the MFMAs of step ks run
+            auto frag = [&](int ks, cplx &x, cplx &y) {
                 const int p = ks * 4 + lk, pc = p < M ? p : M - 1;
-                cplx x = phi_l[pc * nt + off + iac], y = phi_l[pc * nt + off + jbc];
+                x = phi_l[pc * nt + off + iac]; y = phi_l[pc * nt + off + jbc];
                 if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
                 if (!(p < M && jb < n)) y = cmake(0.0, 0.0);
+            };
+            cplx xn, yn;
+            frag(0, xn, yn);
+            for (int ks = 0; ks < nks; ++ks) {
+                const cplx x = xn, y = yn;
+                if (ks + 1 < nks) frag(ks + 1, xn, yn);
                 accR = mfma16(x.x, y.x, accR);               // conj(x) * y, the two chains alternate
                 accI = mfma16(x.x, y.y, accI);
                 accR = mfma16(x.y, y.y, accR);
@@ -1242,8 +1258,9 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             }
         }
         __syncthreads();
+        RF_STAMP(2 + 3 * pass);
         // ---- inverse Cholesky factor: T^T[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (see chol_small_kernel)
-        if (wave == 0 && n > 0) {
+        if (wave == g && n > 0) {                            // (spin up on SIMD 0, spin down on SIMD 1: not both on one)
             const int h2 = lane >> 5, r = lane & 31;
             double vr[16], vi[16];
 #pragma unroll
@@ -1282,6 +1299,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             }
         }
         __syncthreads();
+        RF_STAMP(3 + 3 * pass);
         if (bad_s[0] | bad_s[1]) {                           // leave the walker to the Gram-Schmidt kernel
             if (tid == 0) a.fail[w] = 1;
             return;
@@ -1332,6 +1350,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
                 }
         }
         __syncthreads();
+        RF_STAMP(4 + 3 * pass);
     }
     for (int e = tid; e < M * nt; e += 512) phi_g[e] = phi_l[e];
     if (tid == 0) {
@@ -1341,6 +1360,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
         a.ot[w] = cmake(a.ot[w].x / d, a.ot[w].y / d);       // single_det.py:253
         if (a.fp) a.weight[w] *= d;                          // walkers/handler.py:178-181
     }
+    RF_STAMP(8);
 }
 
 static bool reortho_fused_supported(afq_handle *h, size_t *lds_out) {
@@ -1359,6 +1379,21 @@ static int k_reortho_fused(afq_handle *h, size_t lds) {
     a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot; a.fail = h->qr_fail;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)reortho_fused_kernel, lds, lds_set));
+#ifdef AFQ_TUNING
+    static unsigned long long *rfts = nullptr;
+    static int rf_launch = 0;
+    if (afq_knob("AFQ_RF_TS")) {
+        if (!rfts) { hipMalloc(&rfts, 9 * 8); hipMemset(rfts, 0, 9 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_rf_ts), &rfts, sizeof(rfts)); }
+        if (++rf_launch == 20) {
+            unsigned long long t[9];
+            hipStreamSynchronize(h->stream);
+            hipMemcpy(t, rfts, sizeof(t), hipMemcpyDeviceToHost);
+            fprintf(stderr, "RF_TS ticks: load %lld | pass 0: gram %lld chol %lld q %lld | pass 1: gram %lld chol %lld q %lld | store %lld\n",
+                    (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]),
+                    (long long)(t[5] - t[4]), (long long)(t[6] - t[5]), (long long)(t[7] - t[6]), (long long)(t[8] - t[7]));
+        }
+    }
+#endif
     AFQ_LAUNCH(h, reortho_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
     AFQ_POST(h);
     return AFQ_OK;
