@@ -337,10 +337,13 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
             if (half * 16 < nks) {
                 cplx yb[16];
 #pragma unroll
+                // (rows / columns of the tile beyond n read a clamped, valid column and are never stored; only a contraction
+                //  index past M must contribute zero, and that can only happen in the last step of a ragged M: the selects
+                //  sit behind a uniform test, the loads themselves are unconditional)
                 for (int u = 0; u < 16; ++u) {
                     const int p = (half * 16 + u) * 4 + lk;
-                    const cplx y = a.psi[w * a.psi_stride + (long)(p < M ? p : M - 1) * nt + off + jbc];
-                    yb[u] = (p < M && jb < n) ? y : cmake(0.0, 0.0);
+                    yb[u] = a.psi[w * a.psi_stride + (long)(p < M ? p : M - 1) * nt + off + jbc];
+                    if ((M & 3) && half * 16 + u == nks - 1 && p >= M) yb[u] = cmake(0.0, 0.0);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // all 16 trial-fragment loads in flight before any MFMA
                 if (t == wave && half == 0) __syncthreads();   // phi_l complete (each wave passes here once)
@@ -349,8 +352,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                     const int ks = half * 16 + u;
                     if (ks < nks) {
                         const int p = ks * 4 + lk;
-                        cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];
-                        if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
+                        const cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];   // (yb is zero past M: see above)
                         const cplx y = yb[u];
                         accR = mfma16(x.x, y.x, accR);             // x * conj(y); the two chains alternate
                         accI = mfma16(x.y, y.x, accI);
@@ -546,9 +548,8 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                 for (int ks = 0; ks < 12; ++ks) {
                     if (ks < nks3) {
                         const int j = ks * 4 + lk, jc = j < ns ? j : ns - 1;
-                        cplx y0 = phi_l[c0c * nt + offs + jc], y1 = phi_l[c1c * nt + offs + jc];
-                        if (!(j < ns && c0 < M)) y0 = cmake(0.0, 0.0);
-                        if (!(j < ns && c1 < M && two)) y1 = cmake(0.0, 0.0);
+                        // (xf is zero wherever the contraction index runs past ns; columns past M are never stored)
+                        const cplx y0 = phi_l[c0c * nt + offs + jc], y1 = phi_l[c1c * nt + offs + jc];
                         const cplx x = xf[ks];
                         const double xs = x.x + x.y;
                         p1a = mfma16(x.x, y0.x, p1a);
@@ -1193,6 +1194,7 @@ __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
 //   Q     phi_s <- phi_s T             fp64 MFMA, in place: a wave owns a 16-row tile, whose fragments it holds in registers
 // Same algorithm, same fallback contract as k_reortho_big: a walker whose Cholesky breaks down (fail[w] = 1) is left
 // untouched for the Gram-Schmidt kernel.  (reference: scipy.linalg.qr + sign fix, walkers/single_det.py:228-255)
+#define RF_LD 33
 struct RfArgs {
     int M, na, nb, nt, nw, fp;
     cplx *phi;
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
     const int M = a.M, nt = a.nt;
     const int n = g == 0 ? a.na : a.nb, off = g == 0 ? 0 : a.na;
     cplx *phi_l = (cplx *)smem;                              // [M, nt]
-    cplx *S = phi_l + (long)M * nt + (long)g * 1024;         // [32, 32] Gram matrix, then T^T, of this spin
+    cplx *S = phi_l + (long)M * nt + (long)g * (32 * RF_LD);   // [32, RF_LD] Gram matrix, then T^T, of this spin (row stride 33: no bank conflicts for a lane per row)
     cplx *phi_g = a.phi + (long)w * M * nt;
     RF_STAMP(0);
     for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
@@ -1234,19 +1236,24 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             const int ia = ti * 16 + lr, jb = tj * 16 + lr;
             const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;
             d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
-            // the fragments of contraction step ks + 1 are read while the MFMAs of step ks run
-            auto frag = [&](int ks, cplx &x, cplx &y) {
-                const int p = ks * 4 + lk, pc = p < M ? p : M - 1;
-                x = phi_l[pc * nt + off + iac]; y = phi_l[pc * nt + off + jbc];
-                if (!(p < M && ia < n)) x = cmake(0.0, 0.0);
-                if (!(p < M && jb < n)) y = cmake(0.0, 0.0);
-            };
-            cplx xn, yn;
-            frag(0, xn, yn);
-            for (int ks = 0; ks < nks; ++ks) {
-                const cplx x = xn, y = yn;
-                if (ks + 1 < nks) frag(ks + 1, xn, yn);
+            // Rows / columns of the tile beyond n read a clamped (valid) column and produce numbers that are never stored: an
+            // MFMA output element depends on its own A row and B column only.  Only the CONTRACTION index must not run past
+            // M: whole steps of four are unconditional loads (no select for the compiler to turn into a branch around the
+            // load), the last partial step selects.
+            const cplx *xp = phi_l + lk * nt + off + iac, *yp = phi_l + lk * nt + off + jbc;
+            const int nfull = M >> 2;
+            for (int ks = 0; ks < nfull; ++ks) {
+                const cplx x = xp[ks * 4 * nt], y = yp[ks * 4 * nt];
                 accR = mfma16(x.x, y.x, accR);               // conj(x) * y, the two chains alternate
+                accI = mfma16(x.x, y.y, accI);
+                accR = mfma16(x.y, y.y, accR);
+                accI = mfma16(-x.y, y.x, accI);
+            }
+            if (nfull < nks) {
+                const int p = nfull * 4 + lk, pc = p < M ? p : M - 1;
+                cplx x = phi_l[pc * nt + off + iac], y = phi_l[pc * nt + off + jbc];
+                if (p >= M) { x = cmake(0.0, 0.0); y = cmake(0.0, 0.0); }
+                accR = mfma16(x.x, y.x, accR);
                 accI = mfma16(x.x, y.y, accI);
                 accR = mfma16(x.y, y.y, accR);
                 accI = mfma16(-x.y, y.x, accI);
@@ -1254,7 +1261,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
-                if (i < n && j < n) S[i * 32 + j] = cmake(accR[r], accI[r]);
+                if (i < n && j < n) S[i * RF_LD + j] = cmake(accR[r], accI[r]);
             }
         }
         __syncthreads();
@@ -1266,7 +1273,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = 16 * h2 + j;
-                const cplx t = (r < n && c < n) ? S[r * 32 + c] : cmake(0.0, 0.0);
+                const cplx t = (r < n && c < n) ? S[r * RF_LD + c] : cmake(0.0, 0.0);
                 vr[j] = t.x; vi[j] = t.y;
             }
             if (lane < 32) piv_s[g][lane] = 1.0;
@@ -1285,7 +1292,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
                     cplx t = cmake(0.0, 0.0);
                     if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
                     else if (c == r) t = cmake(rs, 0.0);
-                    S[r * 32 + c] = t;
+                    S[r * RF_LD + c] = t;
                 }
             }
             double l = lane < n ? log(piv_s[g][lane & 31]) : 0.0;
@@ -1329,8 +1336,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
                     for (int tj = 0; tj < 2; ++tj) {
                         if (tj < nt16) {
                             const int j = tj * 16 + lr, jc = j < n ? j : n - 1;
-                            cplx y = S[jc * 32 + kc];        // T[k][j] = T^T[j][k]
-                            if (!(k < n && j < n)) y = cmake(0.0, 0.0);
+                            const cplx y = S[jc * RF_LD + kc];  // T[k][j] = T^T[j][k]; (xf is zero past n, columns past n are not stored)
                             p1[tj] = mfma16(x.x, y.x, p1[tj]);
                             p2[tj] = mfma16(x.y, y.y, p2[tj]);
                             p3[tj] = mfma16(xs, y.x + y.y, p3[tj]);
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
 
 static bool reortho_fused_supported(afq_handle *h, size_t *lds_out) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
-    const size_t lds = sizeof(cplx) * ((size_t)h->M * h->nt + 2 * 1024);
+    const size_t lds = sizeof(cplx) * ((size_t)h->M * h->nt + 2 * 32 * RF_LD);
     *lds_out = lds;
     static const bool off = afq_knob("AFQ_NO_REORTHO_FUSED") != nullptr;
     return !off && nmax <= 32 && h->nb > 0 && h->M >= 16 && lds <= 150 * 1024;
