@@ -24,6 +24,20 @@ __device__ inline unsigned gj_wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// (re, im) of one matrix entry to LDS as ONE ds_write2_b64 straight from the two register arrays: a 16-byte store costs
+// four register moves per column to build its operand (64 moves per pivot row, executed by the whole wave for two lanes);
+// the compiler re-fuses two plain 8-byte stores into exactly that, hence the instruction by hand.
+// base = LDS byte address, slot = offset of the real part in units of 8 bytes (compile-time, < 255)
+__device__ __attribute__((always_inline)) inline void gj_store_pair(unsigned base, const int slot, double re, double im) {
+    switch (slot) {
+#define AFQ_GJ_SP(S) case S: asm volatile("ds_write2_b64 %0, %1, %2 offset0:" #S " offset1:%3" ::"v"(base), "v"(re), "v"(im), "n"(S + 1) : "memory"); break;
+        AFQ_GJ_SP(0) AFQ_GJ_SP(2) AFQ_GJ_SP(4) AFQ_GJ_SP(6) AFQ_GJ_SP(8) AFQ_GJ_SP(10) AFQ_GJ_SP(12) AFQ_GJ_SP(14)
+        AFQ_GJ_SP(16) AFQ_GJ_SP(18) AFQ_GJ_SP(20) AFQ_GJ_SP(22) AFQ_GJ_SP(24) AFQ_GJ_SP(26) AFQ_GJ_SP(28) AFQ_GJ_SP(30)
+#undef AFQ_GJ_SP
+    default: break;
+    }
+}
+
 // value of half hk (lanes 32 hk ..) handed to both halves (hk wave-uniform)
 __device__ inline double gj_bcast_half(double x, int hk) {
     const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
@@ -40,6 +54,7 @@ __device__ inline void gj_block8(double (&vr)[16], double (&vi)[16], int it, int
                                  double &sx, double &sy, int &mystep, cplx *rowk, cplx *piv, int *prow) {
     const int h = lane >> 5, r = lane & 31;
     const int hk = it >> 1;
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 256u * h;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = 8 * it + u;
@@ -57,7 +72,7 @@ __device__ inline void gj_block8(double (&vr)[16], double (&vi)[16], int it, int
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
             if (isp) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) rowk[16 * h + j] = cmake(vr[j], vi[j]);
+                for (int j = 0; j < 16; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
             }
             __builtin_amdgcn_wave_barrier();
             cplx rk[16];
@@ -162,6 +177,7 @@ __device__ inline void chol_block8(double (&vr)[16], double (&vi)[16], int it, i
                                    double *piv, bool &bad) {
     const int h = lane >> 5, r = lane & 31;
     const int hk = it >> 1;
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 256u * h;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = 8 * it + u;
@@ -171,7 +187,7 @@ __device__ inline void chol_block8(double (&vr)[16], double (&vi)[16], int it, i
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
             if (isp) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) rowk[16 * h + j] = cmake(vr[j], vi[j]);
+                for (int j = 0; j < 16; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
             }
             __builtin_amdgcn_wave_barrier();
             cplx rk[16];
