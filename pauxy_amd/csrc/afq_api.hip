@@ -1085,6 +1085,7 @@ int afq_cap_weights(afq_handle *h, double frac, double total_weight) {
 
 int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *parent_ix,
                         double *total_weight_out) {
+    if (h) h->scal_cache_valid = false;
     AFQ_API(h, "afq_popcontrol_comb");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
@@ -1267,7 +1268,7 @@ __global__ void est_publish_kernel(cplx *est, const double *scal, double *host_o
                                    unsigned long long seq, int nest, int zero) {
     const int t = threadIdx.x;
     if (t < nest) host_out[t] = ((const double *)est)[t];
-    if (t < 4) host_out[nest + t] = scal[t];
+    if (t < 8) host_out[nest + t] = scal[t];
     __threadfence_system();
     __syncthreads();
     if (t < nest && zero) ((double *)est)[t] = 0.0;
@@ -1281,10 +1282,10 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
-        // [nest sums | scal[4] | sequence number], written by the device, polled by the host
-        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 4 + 1),
+        // [nest sums | scal[8] | sequence number], written by the device, polled by the host
+        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 8 + 1),
                                  hipHostMallocMapped | hipHostMallocCoherent));
-        memset(h->est_stage, 0, sizeof(double) * (nest + 4 + 1));
+        memset(h->est_stage, 0, sizeof(double) * (nest + 8 + 1));
     }
     // the one host synchronisation of a block of steps also reports a population that collapsed in an
     // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
@@ -1292,7 +1293,7 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
     ++h->est_seq;
     AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
-               (unsigned long long *)(dev_view + nest + 4), h->est_seq, (int)nest, zero);
+               (unsigned long long *)(dev_view + nest + 8), h->est_seq, (int)nest, zero);
     AFQ_POST(h);
     h->est_pending = true;
     return AFQ_OK;
@@ -1307,7 +1308,7 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     {
         // poll the sequence number; the stream query catches a failed launch or device (no endless wait)
-        const unsigned long long *seq = (const unsigned long long *)(h->est_stage + nest + 4);
+        const unsigned long long *seq = (const unsigned long long *)(h->est_stage + nest + 8);
         unsigned spins = 0;
         while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != h->est_seq) {
             if ((++spins & 0x3ffu) == 0) {
@@ -1321,6 +1322,9 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     }
     memcpy(est_out, h->est_stage, sizeof(double) * nest);
     const double *sc = h->est_stage + nest;
+    // the population-control scalars of the block ride along: afq_comm_stats right behind this call needs no synchronisation
+    memcpy(h->scal_cache, sc, sizeof(double) * 8);
+    h->scal_cache_valid = true;
     if (sc[2] != 0.0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8 in an earlier population control");
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "population control: more walkers moved between two ranks than the "
                                                  "exchange slots hold (afq_comm_init capacity)");

@@ -187,6 +187,8 @@ struct afq_handle {
     bool prop_pending = false;                      // afq_propagate_begin done, afq_propagate_finish outstanding
     double *est_stage = nullptr;                    // mapped host memory: estimator sums + scal[4] + sequence number
     unsigned long long est_seq = 0;
+    double scal_cache[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scal[] as of the last afq_estimates_get_end; stale after a population control
+    bool scal_cache_valid = false;
     bool est_pending = false;
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs

@@ -400,6 +400,7 @@ void k_comm_destroy(afq_handle *h) {
 
 // one event on an RCCL communicator (stages 1-7 above)
 int k_comm_popcontrol(afq_handle *h, double r, double target, bool with_greens) {
+    h->scal_cache_valid = false;
     afq_comm_state *c = cs_of(h);
     if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
     if (c->local) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_popcontrol_comb_local for all ranks at once");
@@ -508,8 +509,15 @@ int afq_comm_stats(afq_handle *h, int64_t *out) {
     if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
     hipSetDevice(h->device);
     double sc[8];
-    AFQ_HIP(h, hipMemcpyAsync(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->scal_cache_valid) {
+        // right behind the block's afq_estimates_get(_end): the scalars came along with the sums, no synchronisation
+        // (the driver reads the statistics at block boundaries: with a sync here the host loses its lead over the device
+        //  once per block and the first launches of the next step arrive late)
+        memcpy(sc, h->scal_cache, sizeof(sc));
+    } else {
+        AFQ_HIP(h, hipMemcpyAsync(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+        AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    }
     out[0] = (int64_t)sc[4];                 // largest number of walkers one rank sent to another in one event
     out[1] = (int64_t)sc[5];                 // events
     out[2] = c->cap > 0 ? c->cap : default_cap(h->nw);
@@ -527,6 +535,7 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
     for (int i = 0; i < n; ++i) {
         afq_handle *h = hs[i];
         hipSetDevice(h->device);
+        h->scal_cache_valid = false;
         keep[i] = h->greens_valid && h->ndet == 1;
         h->greens_valid = false;
     }
