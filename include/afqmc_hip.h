@@ -329,6 +329,12 @@ int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
 /* The same without blocking at enqueue time: _begin enqueues the copy of the sums (and their zeroing) behind the work
  * already in the stream, _end waits for that copy only -- work enqueued after _begin keeps running.  One fetch in flight
  * at a time (AFQ_ESTATE).                                                                                            */
+/* The next afq_propagate (or afq_propagate_finish) also takes the estimator terms of its step along, as an
+ * afq_estimates_update(h, 0) called right behind it would have added them: the weight update adds every walker's terms
+ * to per-walker accumulators, and the next afq_estimates_update, or the next fetch / all-reduce, folds those into the
+ * sums.  For a step that neither combs nor evaluates the energy this saves the launch of the summation kernel.
+ * Continuous propagator, not with afq_estimates_rdm on.                                                            */
+int afq_estimates_fuse_next(afq_handle *h);
 int afq_estimates_get_begin(afq_handle *h, int zero);
 int afq_estimates_get_end(afq_handle *h, double *est_out /* c128[10] */);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "afq_walkers_reset_weights": [_h],
     "afq_estimates_update": [_h, c_int],
     "afq_estimates_get": [_h, _dp, c_int],
+    "afq_estimates_fuse_next": [_h],
     "afq_estimates_get_begin": [_h, c_int],
     "afq_estimates_get_end": [_h, _dp],
     "afq_estimates_rdm": [_h, c_int],

@@ -92,6 +92,7 @@ void free_system(afq_handle *h) {
 }
 
 void free_walkers(afq_handle *h) {
+    dev_free(h->est_acc); h->est_acc_pending = false; h->fuse_est_req = false;
     dev_free(h->phi); dev_free(h->phi_t); dev_free(h->phi_t2);
     dev_free(h->weight); dev_free(h->unscaled); dev_free(h->detR); dev_free(h->log_detR);
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
@@ -894,6 +895,25 @@ int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im) {
         if ((rc = k_update_weight(h, cmake(eshift_re, eshift_im)))) return rc;
         if (h->nbp > 0 && !fp && (rc = k_bp_push(h))) return rc;     // FieldConfig.update (continuous.py:288-289)
     }
+    if (h->fuse_est_req) {                                // afq_estimates_fuse_next: the weight update took the terms along
+        h->fuse_est_req = false;
+        h->est_acc_pending = true;
+    }
+    return AFQ_OK;
+}
+
+int afq_estimates_fuse_next(afq_handle *h) {
+    if (!h) return AFQ_EINVAL;
+    if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers");
+    if (h->rdm_on) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "afq_estimates_fuse_next with the one-body RDM accumulation on");
+    if (h->hirsch) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "afq_estimates_fuse_next: continuous propagator only");
+    hipSetDevice(h->device);
+    if (!h->est_acc) {
+        int rc = dev_alloc(h, &h->est_acc, (size_t)6 * h->nw);
+        if (rc) return rc;
+        AFQ_HIP(h, hipMemsetAsync(h->est_acc, 0, sizeof(double) * 6 * h->nw, h->stream));
+    }
+    h->fuse_est_req = true;
     return AFQ_OK;
 }
 
@@ -1280,6 +1300,7 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     if (!h) return AFQ_EINVAL;
     hipSetDevice(h->device);
     if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
+    { const int rc = k_estimates(h, 0, true); if (rc) return rc; }     // sums still sitting in the per-walker accumulators
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
         // [nest sums | scal[8] | sequence number], written by the device, polled by the host

@@ -216,6 +216,10 @@ struct afq_handle {
 
     // afq_propagate -> k_greens: run the step's weight update behind the determinant (greens_small_kernel)
     bool fuse_weight_req = false, fuse_weight_done = false;
+    // afq_estimates_fuse_next: the weight update of the next step adds every walker's estimator terms to est_acc[w][6]
+    // (per walker: no cross-walker sum, no atomics); the next estimates_kernel launch, or the next fetch, folds them in
+    double *est_acc = nullptr;
+    bool fuse_est_req = false, est_acc_pending = false;
     cplx fuse_eshift;
 
     // rng
@@ -385,7 +389,7 @@ int k_log_shift_reortho(afq_handle *h);                            // detR -> ex
 int k_log_ovlp_sums(afq_handle *h, double *out3);                  // sums of |ot|, |detR|, |log_detR| (device -> host)
 int k_scale_weights(afq_handle *h, double scale);
 int k_reset_weights(afq_handle *h, bool after_comb = false);
-int k_estimates(afq_handle *h, int have_energy);
+int k_estimates(afq_handle *h, int have_energy, bool fold_only = false);
 int k_rdm_accumulate(afq_handle *h);
 int k_rng_normal(afq_handle *h);
 int k_rng_normal_into(afq_handle *h, double *out_d, long n);

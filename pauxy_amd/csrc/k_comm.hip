@@ -616,6 +616,7 @@ int afq_estimates_allreduce(afq_handle *h, double *buf, int nest) {
     if (!api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
     hipSetDevice(h->device);
     if (!buf) {     // the device accumulators of afq_estimates_update, in place: no host round trip
+        { const int rc = k_estimates(h, 0, true); if (rc) return rc; }     // (sums still in the per-walker accumulators)
         afq_note_launch(h, "ncclAllReduce(estimates)");
         AFQ_NCCL(h, api, api->AllReduce(h->estimates, h->estimates, 2 * AFQ_EST_COUNT_, ncclDouble, ncclSum, c->nccl, h->stream));
         if (h->rdm_on && h->rdm_acc)    // the one-body RDM sums are part of the same reduction in the reference (mixed.py:261)

@@ -195,6 +195,9 @@ struct WeightArgs {
     // use_log_shift (walkers/single_det.py:192): walker.ot = overlap * exp(-log_shift); the ratios of a step do not
     // see it, both of its overlaps carry the same shift.  1 when the option is off.
     double ot_scale;
+    // afq_estimates_fuse_next: per-walker accumulators [nw][6] of the estimator terms of this step (null = off)
+    double *est_acc;
+    const double *unscaled;
 };
 
 static WeightArgs weight_args(afq_handle *h, cplx eshift);
@@ -276,6 +279,20 @@ __device__ static void weight_update_and_cap(const WeightArgs &a, const int w) {
         // every walker, propagated or not, exactly like the driver's loop
         const double cap = a.cap_frac * (a.cap_total < 0.0 ? a.cap_total_dev[0] : a.cap_total);
         if (fabs(a.weight[w]) > cap) a.weight[w] = cap;
+    }
+    if (a.est_acc) {
+        // the terms estimates_kernel would add for this walker right behind this update (estimators/mixed.py:151-175,
+        // 211-225, without the energy), summed over the STEPS of this walker slot here and over the walkers later
+        const double x = a.weight[w];
+        const cplx o = a.ot[w];
+        cplx wf = cmake(x, 0.0);
+        if (a.flags & AFQ_PROP_FREE_PROJECTION) wf = cscale(cmul(o, a.phase[w]), x);
+        const cplx eh = cmul(wf, a.ehyb[w]);
+        double *acc = a.est_acc + 6 * (long)w;
+        acc[0] += a.unscaled[w];
+        acc[1] += wf.x; acc[2] += wf.y;
+        acc[3] += x * hypot(o.x, o.y);
+        acc[4] += eh.x; acc[5] += eh.y;
     }
 }
 
@@ -1100,6 +1117,7 @@ static WeightArgs weight_args(afq_handle *h, cplx eshift) {
     a.bp_flag = h->nbp > 0 ? h->bp_flag : nullptr; a.bp_cos = h->bp_cos; a.bp_ph = h->bp_ph;
     a.cap_frac = h->cap_frac; a.cap_total = h->cap_total; a.cap_total_dev = h->scal;
     a.ot_scale = h->log_shift_on ? exp(-h->log_shift) : 1.0;
+    a.est_acc = h->fuse_est_req ? h->est_acc : nullptr; a.unscaled = h->unscaled;
     return a;
 }
 
@@ -1706,12 +1724,19 @@ int k_comb(afq_handle *h, double r, double target, bool with_greens) {
 __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy, int fp, const double *weight,
                                                          const double *unscaled, const cplx *ot,
                                                          const cplx *ehyb, const cplx *phase, const cplx *energy,
-                                                         cplx *est) {
-    __shared__ double red[NTHR / 64][12];
+                                                         cplx *est, double *acc, int fold_only) {
+    __shared__ double red[NTHR / 64][18];
     // v[0]=uweight  v[1..2]=weight  v[3]=ovlp  v[4..5]=ehyb  v[6..7]=enumer  v[8..9]=e1b  v[10..11]=e2b
-    double v[12];
-    for (int k = 0; k < 12; ++k) v[k] = 0.0;
+    // v[12..17] = the first six again for the steps whose sums rode on their weight update (afq_estimates_fuse_next):
+    // kept apart, the energy denominator of THIS step is this step's weight sum only
+    double v[18];
+    for (int k = 0; k < 18; ++k) v[k] = 0.0;
     for (int w = threadIdx.x; w < nw; w += NTHR) {
+        if (acc) {       // fold and clear
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { v[12 + k] += acc[6 * w + k]; acc[6 * w + k] = 0.0; }
+        }
+        if (fold_only) continue;
         const double x = weight[w];
         // importance sampling: wfac = weight (mixed.py:217-225); free projection: weight*ot*phase (:154)
         cplx wf = cmake(x, 0.0);
@@ -1733,24 +1758,24 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
     // all sums in one pass: wave shuffles, one barrier, thread 0 adds the per-wave partials in wave order
     const int nk = have_energy ? 12 : 6;                     // the energy sums stay zero (and unused) on the other steps
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-        if (k < nk)
+    for (int k = 0; k < 18; ++k)
+        if (k < nk || (k >= 12 && acc))
             for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) red[threadIdx.x >> 6][k] = v[k];
+        for (int k = 0; k < 18; ++k) red[threadIdx.x >> 6][k] = v[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 18; ++k) {
             v[k] = 0.0;
             for (int i = 0; i < NTHR / 64; ++i) v[k] += red[i][k];
         }
-        est[AFQ_EST_UWEIGHT].x += v[0];
-        est[AFQ_EST_WEIGHT].x += v[1]; est[AFQ_EST_WEIGHT].y += v[2];
-        est[AFQ_EST_OVLP].x += v[3];
-        est[AFQ_EST_EHYB].x += v[4]; est[AFQ_EST_EHYB].y += v[5];
+        est[AFQ_EST_UWEIGHT].x += v[0] + v[12];
+        est[AFQ_EST_WEIGHT].x += v[1] + v[13]; est[AFQ_EST_WEIGHT].y += v[2] + v[14];
+        est[AFQ_EST_OVLP].x += v[3] + v[15];
+        est[AFQ_EST_EHYB].x += v[4] + v[16]; est[AFQ_EST_EHYB].y += v[5] + v[17];
         if (have_energy) {
             est[AFQ_EST_ENUMER].x += v[6]; est[AFQ_EST_ENUMER].y += v[7];
             est[AFQ_EST_E1B].x += v[8]; est[AFQ_EST_E1B].y += v[9];
@@ -1777,11 +1802,14 @@ int k_rdm_accumulate(afq_handle *h) {
     return AFQ_OK;
 }
 
-int k_estimates(afq_handle *h, int have_energy) {
+int k_estimates(afq_handle *h, int have_energy, bool fold_only) {
     const int fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
+    if (fold_only && !h->est_acc_pending) return AFQ_OK;
     AFQ_LAUNCH(h, estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, fp, h->weight,
-                       h->unscaled, h->ot, h->ehyb, h->phase, h->energy, h->estimates);
+                       h->unscaled, h->ot, h->ehyb, h->phase, h->energy, h->estimates,
+                       h->est_acc_pending ? h->est_acc : (double *)nullptr, fold_only ? 1 : 0);
     AFQ_POST(h);
+    h->est_acc_pending = false;
     return AFQ_OK;
 }
 

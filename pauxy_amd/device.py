@@ -359,6 +359,10 @@ class AfqDevice(object):
         self._ck(self.lib.afq_estimates_get(self.h, _p(out), int(bool(zero))))
         return out
 
+    def estimates_fuse_next(self):
+        """The next propagate / propagate_finish takes the step's estimator terms along (no estimates_update(False))."""
+        self._ck(self.lib.afq_estimates_fuse_next(self.h))
+
     def estimates_get_begin(self, zero=False):
         """Enqueue the fetch; work enqueued afterwards keeps running while estimates_get_end waits for the sums."""
         self._ck(self.lib.afq_estimates_get_begin(self.h, int(bool(zero))))

@@ -160,6 +160,13 @@ class AFQMC(object):
         if not hirsch:
             # the weight cap of afqmc.py:235-236 rides on the weight-update kernel of the propagation
             dev.set_weight_cap(0.10 if step > 1 else 0.0, -1.0 if on_device else psi.total_weight)
+        mixed = self.estimators.estimators['mixed']
+        do_energy = step % mixed.energy_eval_freq == 0
+        # a step that neither combs nor evaluates the energy nor ends a block: its estimator terms ride on its weight update
+        ride = (getattr(self, 'ride_estimates', True) and not hirsch and step % self.qmc.npop_control != 0
+                and not do_energy and step % self.qmc.nsteps != 0 and not mixed.calc_one_rdm)
+        if ride:
+            dev.estimates_fuse_next()
         if begun:
             self.propagators.propagate_walkers_finish(psi, eshift)
         else:
@@ -170,11 +177,9 @@ class AFQMC(object):
         if step % self.qmc.npop_control == 0:
             psi._invalidate()
             psi.pop_control(self.comm, fetch=fetch_popcontrol or not on_device)
-        do_energy = step % self.estimators.estimators['mixed'].energy_eval_freq == 0
-        mixed = self.estimators.estimators['mixed']
         if do_energy and not mixed.eval_energy:
             mixed.update(self.system, self.qmc, self.trial, psi, step, self.propagators.free_projection)
-        else:
+        elif not ride:
             dev.estimates_update(do_energy)
 
     def run_batched(self, nsteps_total=None, first_step=1, eshift=0.0, on_step=None, fetch_popcontrol=False,

@@ -92,8 +92,11 @@ def c3_afqmc(device_rng=False):
     return AFQMC(options=options, system=s, trial=t), s, t
 
 
-def run_c3(batched, fetch):
+def run_c3(batched, fetch, ride=False):
     afqmc, s, t = c3_afqmc()
+    # ride: the estimator terms of the plain steps ride on their weight update (afq_estimates_fuse_next) -- the same
+    # additions in another association, so the block sums (hence the shift, hence the weights) move by rounding
+    afqmc.ride_estimates = ride
     numpy.random.seed(1234)
     # walkers that all start on the trial keep weights within a few per cent of each other for the first blocks and
     # the comb would clone nobody: start from a spread population
@@ -133,6 +136,12 @@ def test_c3_run_batched_equals_run():
         close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-12)
     assert numpy.array_equal(a['pix'], b['pix'])
     assert a['pix'].shape == (4, C3['nw']) and a['pix'].max() >= 2         # the comb did clone walkers
+    # bench.py's mode proper: estimator terms riding on the weight update as well -- equal to rounding
+    d, blocks_d, phi_d = run_c3(True, False, ride=True)
+    for key in ('weight', 'ot', 'ehyb'):
+        close(d[key], a[key], 1e-11)
+    close(phi_d, phi_a, 1e-11)
+    close(blocks_d[:, 1:10], blocks_a[:, 1:10], 1e-12)
 
 
 def test_collapsed_population_is_reported():

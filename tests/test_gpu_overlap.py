@@ -12,7 +12,7 @@ from pauxy_amd.qmc.afqmc import AFQMC
 pytestmark = pytest.mark.gpu
 
 
-def drive(overlap, nsteps_block, total):
+def drive(overlap, nsteps_block, total, ride=True):
     s = systems.synthetic_generic(20, 30, (5, 4), seed=9)
     t = trial_mod.rhf_trial_generic(s)
     opts = {'qmc': {'timestep': 0.01, 'num_steps': nsteps_block, 'blocks': 10 ** 6, 'stabilise_freq': 4,
@@ -20,6 +20,7 @@ def drive(overlap, nsteps_block, total):
             'propagator': {'device_rng': True, 'rng_seed': 11},
             'estimators': {'mixed': {'verbose': False, 'energy_eval_freq': 2}}}
     afqmc = AFQMC(options=opts, system=s, trial=t)
+    afqmc.ride_estimates = ride
     eshift = afqmc.run_batched(total // 2, first_step=1, eshift=0.0, overlap_blocks=overlap)
     # a second call continues the run: the boundary logic restarts cleanly with nothing half done
     eshift = afqmc.run_batched(total - total // 2, first_step=total // 2 + 1, eshift=eshift, overlap_blocks=overlap)
@@ -40,3 +41,22 @@ def test_overlapped_block_boundary_is_bit_identical(nsteps_block, total):
     assert a['eshift'] == b['eshift'] and a['eshift'] != 0.0
     for k in ('weight', 'phi', 'ot'):
         assert numpy.array_equal(a[k], b[k]), k
+
+
+def test_estimator_terms_riding_on_the_weight_update_equal_the_separate_launch():
+    """afq_estimates_fuse_next: on the steps that neither comb nor evaluate the energy nor end a block the weight update
+    adds every walker's estimator terms to per-walker accumulators, folded into the sums by the next summation launch or
+    fetch (another association of the same additions: equal to rounding).  Blocks of 6 steps with comb / 3 and energy / 2
+    leave ride steps 1 and 5 of every block; blocks of 4 exercise the fold at a fetch that follows a comb step."""
+    for nsteps_block, total in ((6, 36), (7, 28)):
+        a = drive(True, nsteps_block, total, ride=False)
+        b = drive(True, nsteps_block, total, ride=True)
+        assert a['blocks'].shape == b['blocks'].shape
+        x, y = a['blocks'][:, 1:-1], b['blocks'][:, 1:-1]
+        ok = numpy.isfinite(x)
+        assert numpy.array_equal(ok, numpy.isfinite(y))
+        assert numpy.max(numpy.abs(x[ok] - y[ok]) / (1e-300 + numpy.abs(x[ok]) + numpy.abs(y[ok]))) < 1e-12
+        # the shift derived from the sums differs by rounding, hence the weights
+        assert abs(a['eshift'] - b['eshift']) < 1e-10 * max(1.0, abs(a['eshift']))
+        assert numpy.max(numpy.abs(a['weight'] - b['weight'])) < 1e-9
+        assert numpy.max(numpy.abs(a['phi'] - b['phi'])) < 1e-9
