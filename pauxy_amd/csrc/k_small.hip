@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
         const int ti = t / nt16, tj = t % nt16;
         const int ia = ti * 16 + lr, jb = tj * 16 + lr;
         const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;     // clamped: loads stay unconditional
-        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0};
+        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
 #pragma unroll
         for (int half = 0; half < GS_KSMAX / 16; ++half) {
             if (half * 16 < nks) {
@@ -371,10 +371,11 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                         const int p = ks * 4 + lk;
                         const cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];   // (yb is zero past M: see above)
                         const cplx y = yb[u];
-                        accR = mfma16(x.x, y.x, accR);             // x * conj(y); the two chains alternate
-                        accI = mfma16(x.y, y.x, accI);
-                        accR = mfma16(x.y, y.y, accR);
-                        accI = mfma16(-x.x, y.y, accI);
+                        // x * conj(y) by three multiplications: P1 = xr yr, P2 = xi yi, P3 = (xr + xi)(yr - yi);
+                        // re = P1 + P2, im = P3 - P1 + P2 (three independent accumulator chains)
+                        accR = mfma16(x.x, y.x, accR);
+                        accI = mfma16(x.y, y.y, accI);
+                        acc3 = mfma16(x.x + x.y, y.x - y.y, acc3);
                     }
                 }
             }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
-            if (i < n && j < n) O[i * n + j] = cmake(accR[r], accI[r]);
+            if (i < n && j < n) O[i * n + j] = cmake(accR[r] + accI[r], acc3[r] - accR[r] + accI[r]);
         }
     }
     if (wave >= nt16 * nt16 || (a.dbg & 4)) __syncthreads();  // waves without a tile still owe the phase-0 barrier
@@ -1260,21 +1261,27 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             // load), the last partial step selects.
             const cplx *xp = phi_l + lk * nt + off + iac, *yp = phi_l + lk * nt + off + jbc;
             const int nfull = M >> 2;
+            // conj(x) * y by three multiplications: P1 = xr yr, P2 = xi yi, P3 = (xr - xi)(yr + yi); re = P1 + P2,
+            // im = P3 - P1 + P2
+            d4_t acc3 = {0, 0, 0, 0};
             for (int ks = 0; ks < nfull; ++ks) {
                 const cplx x = xp[ks * 4 * nt], y = yp[ks * 4 * nt];
-                accR = mfma16(x.x, y.x, accR);               // conj(x) * y, the two chains alternate
-                accI = mfma16(x.x, y.y, accI);
-                accR = mfma16(x.y, y.y, accR);
-                accI = mfma16(-x.y, y.x, accI);
+                accR = mfma16(x.x, y.x, accR);
+                accI = mfma16(x.y, y.y, accI);
+                acc3 = mfma16(x.x - x.y, y.x + y.y, acc3);
             }
             if (nfull < nks) {
                 const int p = nfull * 4 + lk, pc = p < M ? p : M - 1;
                 cplx x = phi_l[pc * nt + off + iac], y = phi_l[pc * nt + off + jbc];
                 if (p >= M) { x = cmake(0.0, 0.0); y = cmake(0.0, 0.0); }
                 accR = mfma16(x.x, y.x, accR);
-                accI = mfma16(x.x, y.y, accI);
-                accR = mfma16(x.y, y.y, accR);
-                accI = mfma16(-x.y, y.x, accI);
+                accI = mfma16(x.y, y.y, accI);
+                acc3 = mfma16(x.x - x.y, y.x + y.y, acc3);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double p1 = accR[r], p2 = accI[r];
+                accR[r] = p1 + p2; accI[r] = acc3[r] - p1 + p2;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
