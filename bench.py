@@ -4,7 +4,8 @@ on the BASELINE configs[2] workload (generic Hamiltonian, Nbasis=100, Nchol=500,
 RHF trial with 25+25 electrons, 256 walkers per GPU), plus the fp64-MFMA roofline
 fraction of the Cholesky exchange-energy kernel and the CPU-oracle baseline.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: bench.py starts its N ranks itself,
+                                                            as child processes, before anything touches the GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full AFQMC step over the rank's walker batch in the reference's
@@ -176,14 +177,72 @@ def cpu_baseline(system, trial):
             "variants": variants}
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes (one per GPU, the
+    environment contract of torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT,
+    rendezvous on 127.0.0.1) before anything in this process touches the GPU -- the parent imports neither torch nor
+    the library -- relay rank 0's JSON line(s) on stdout, everything else on stderr, and return the first non-zero
+    exit status of a rank (the other ranks are then ended by their exact PIDs)."""
+    import subprocess
+    import threading
+    port = str(free_port())
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // ngpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    lines = [0]
+
+    def relay(r, proc):
+        for line in proc.stdout:
+            if r == 0 and line.startswith("{"):
+                sys.stdout.write(line)
+                sys.stdout.flush()
+                lines[0] += 1
+            else:
+                sys.stderr.write(line if r == 0 else "[rank %d] %s" % (r, line))
+    threads = [threading.Thread(target=relay, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    rc = 0
+    live = set(range(ngpus))
+    while live:
+        for r in sorted(live):
+            st = procs[r].poll()
+            if st is None:
+                continue
+            live.discard(r)
+            if st != 0 and rc == 0:
+                rc = st if st > 0 else 128 - st
+                sys.stderr.write("bench.py: rank %d exited with status %d; ending the other ranks\n" % (r, st))
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5.0)
+    if rc == 0 and lines[0] == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 but printed no result line\n")
+        rc = 4
+    return rc
+
+
+def start_watchdog(state):
     # a hang anywhere (driver, runtime, collective) ends the run with every thread's traceback instead of
     # waiting for the caller's timeout
     import faulthandler
     import threading
     limit = float(os.environ.get("AFQ_BENCH_WATCHDOG_S", "900"))
     faulthandler.dump_traceback_later(limit + 10.0, exit=True)          # backstop if the thread below cannot run
-    state = {"dev": None, "phase": "start-up"}
 
     def watchdog():
         time.sleep(limit)
@@ -199,13 +258,20 @@ def main():
         faulthandler.dump_traceback(all_threads=True)
         os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--walkers-per-gpu", type=int, default=None)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: 256 walkers per GPU (BASELINE configs[2]); strong: 2048 walkers in total (SURVEY 8e)")
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="weak",
+                    help="weak: 256 walkers per GPU (BASELINE configs[2]); strong: 2048 walkers in total (SURVEY 8e); "
+                         "both: one JSON line each, weak first")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="timed regions of --steps steps each (default: 5 below 100 steps, 3 below 500, else 1); "
+                         "the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -214,22 +280,32 @@ def main():
     if args.cpu_worker:                 # child of cpu_socket_processes: numpy only, never touches the GPU
         cpu_worker(args.cpu_worker, args.cpu_window)
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us (the driver's `python bench.py --gpus N`): this process becomes the launcher.
+        # Nothing above has imported torch or the library, so no GPU state exists in the parent.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    state = {"dev": None, "phase": "start-up"}
+    start_watchdog(state)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     # AFQ_BENCH_BACKEND=gloo runs the multi-rank code path with every rank on the visible GPUs modulo
     # their count (functional check of the N > 1 logic on a 1-GPU box; RCCL needs one GPU per rank)
     backend = os.environ.get("AFQ_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py: no GPU visible; the HIP library is the product and there is no CPU path")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one GPU per rank; "
+                         "AFQ_BENCH_BACKEND=gloo shares GPUs for a functional check)" % (world, ndev))
     if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        local_rank = local_rank % ndev
         os.environ["LOCAL_RANK"] = str(local_rank)        # pauxy_amd.context picks the GPU from it
     torch.cuda.set_device(local_rank)
     comm = None
@@ -243,20 +319,33 @@ def main():
         else:
             dist.init_process_group(backend=backend)
             comm = TorchComm(device=torch.device("cpu"))
-
-    from pauxy_amd.qmc.afqmc import AFQMC
     system, trial = build_inputs()
-    if args.steps < 100 and rank == 0:
-        sys.stderr.write("bench.py: --steps %d times a region of only ~%d ms with %d energy evaluations; use >= 100 steps "
-                         "for a stable number\n" % (args.steps, args.steps // 2, args.steps // NSTEPS_BLOCK))
+    scalings = ["weak", "strong"] if args.scaling == "both" else [args.scaling]
+    for i, scaling in enumerate(scalings):
+        out = run_bench(args, scaling, comm, world, rank, backend, system, trial, state,
+                        with_cpu_baseline=(i == 0 and not args.no_cpu_baseline and world == 1))
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+    if comm is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, with_cpu_baseline):
+    import torch
+    from pauxy_amd.qmc.afqmc import AFQMC
+    from pauxy_amd.context import release_context
     if args.walkers_per_gpu is not None:
         nw = args.walkers_per_gpu
-    elif args.scaling == "strong":
+    elif scaling == "strong":
         if STRONG_TOTAL % world:
             raise SystemExit("strong scaling: %d walkers do not divide over %d GPUs" % (STRONG_TOTAL, world))
         nw = STRONG_TOTAL // world
     else:
         nw = NW_PER_GPU
+    repeats = args.repeats if args.repeats else (5 if args.steps < 100 else 3 if args.steps < 500 else 1)
     options = {
         'qmc': {'timestep': DT, 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
                 'pop_control_freq': NPOP, 'num_walkers': nw * world, 'rng_seed': 7},
@@ -267,6 +356,11 @@ def main():
     afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
     state["dev"] = dev
+    if world > 1 and backend == "nccl" and not getattr(afqmc.psi, 'device_comm', False):
+        # the N > 1 number is the one of the device comb over the library's RCCL communicator: never report the
+        # host-mediated fallback under its name
+        raise SystemExit("bench.py: rank %d could not bring up the library's RCCL communicator (%s)"
+                         % (rank, getattr(afqmc.psi, 'device_comm_error', '') or 'unknown reason'))
 
     def barrier():
         dev.sync()
@@ -299,18 +393,35 @@ def main():
     trace_stride = max(2, args.steps // 4)
     dev.kernel_trace_stride(L.K_PROPAGATOR, trace_stride)
     dev.kernel_trace(True, in_region)
-    t0 = time.perf_counter()
-    eshift = afqmc.run_batched(args.steps, first_step=args.warmup + 1, eshift=eshift)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # `repeats` timed regions of EXACTLY --steps steps each, every one bracketed by barrier + synchronize on both sides
+    # and reduced with MAX over the ranks; the median region is the one reported (a 20-step region is ~6 ms: one
+    # sample of that is fragile evidence), all of them are listed.
+    regions, own = [], []
+    first = args.warmup + 1
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        eshift = afqmc.run_batched(args.steps, first_step=first, eshift=eshift)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        own.append(elapsed)
+        first += args.steps
+        if comm is not None:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append(elapsed)
     dev.kernel_trace(False)
     dev.kernel_trace_stride(L.K_PROPAGATOR, 1)
     state["phase"] = "after the timed region"
+    order = sorted(range(repeats), key=lambda i: regions[i])
+    imed = order[(repeats - 1) // 2]                     # lower median: an actually measured region
+    elapsed = regions[imed]
+    rank_ms = [1e3 * own[imed] / args.steps]
     if comm is not None:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        gathered = numpy.zeros(world)
+        comm.Allgather(numpy.array(rank_ms), gathered)
+        rank_ms = gathered.tolist()
 
     # Rooflines of the hot kernels from HIP events recorded on the library's stream around every launch
     # (afq_kernel_trace): the dominant kernel INSIDE the timed region, the GEMMs and the exchange energy in an extra pass
@@ -318,7 +429,7 @@ def main():
     traced = {kind: dev.kernel_trace_get(kind) for kind in in_region}
     extra_steps = 4 * NSTEPS_BLOCK
     dev.kernel_trace(True)
-    afqmc.run_batched(extra_steps, first_step=args.warmup + args.steps + 1, eshift=eshift)
+    afqmc.run_batched(extra_steps, first_step=first, eshift=eshift)
     dev.sync()
     dev.kernel_trace(False)
     nt = 2 * N
@@ -359,13 +470,20 @@ def main():
             ref_flops = 4.0 * K * nt * M * nw
             extra = {"reference_formulation_flops_per_launch": ref_flops,
                      "effective_vs_reference_formulation": ref_flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        # flops the matrix pipe actually executes per launch (MFMA instructions x their flop count, padding
+        # included, 3-multiplication complex products counted as 3): what `frac_issued` = pipe utilisation is priced on
+        issued = dev.kernel_issued_flops(kind)
+        if issued > 0:
+            extra["issued_flops_per_launch"] = issued
+            extra["frac_issued"] = issued / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
         rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg, **extra,
-                     "measured": (("timed region, every %d-th launch" % trace_stride if kind == L.K_PROPAGATOR
-                                   else "timed region") if live
-                                  else "extra pass of %d steps after the timed region" % extra_steps),
+                     "measured": (("timed regions, every %d-th launch" % trace_stride if kind == L.K_PROPAGATOR
+                                   else "timed regions") if live
+                                  else "extra pass of %d steps after the timed regions" % extra_steps),
                      # (the propagator runs once per step; only a sample of its launches is timed in the region)
                      "ms_per_step": (avg if live and kind == L.K_PROPAGATOR else
-                                     float(numpy.sum(ms)) / (args.steps if live else extra_steps)), "flops_per_launch": flops,
+                                     float(numpy.sum(ms)) / (args.steps * repeats if live else extra_steps)),
+                     "flops_per_launch": flops,
                      "achieved": flops / (avg * 1e-3) / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS})
     if not rows:
@@ -375,7 +493,8 @@ def main():
         raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
     traffic = None
     traffic_source = None
-    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json",
+                                                              "r01_pmc_traffic.json")
                   if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
     if tfile:
         traffic_source = "%s: rocprofv3 --pmc passes of this command (not collected in this run)" % os.path.relpath(tfile, ROOT)
@@ -383,6 +502,9 @@ def main():
         with open(tfile) as f:
             traffic = json.load(f).get(dom["kernel"].split(" ")[0], {}).get("traffic_bytes_per_launch")
 
+    device_comm = bool(getattr(afqmc.psi, 'device_comm', False))
+    comm_stats = dev.comm_stats() if device_comm else None
+    out = None
     if rank == 0:
         total_walkers = nw * world
         out = {
@@ -391,34 +513,42 @@ def main():
             "unit": "walker-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": args.scaling if args.walkers_per_gpu is None else "weak",
+            "ms_per_step_min": 1e3 * min(regions) / args.steps, "ms_per_step_max": 1e3 * max(regions) / args.steps,
+            "repeats": repeats, "timed_regions_ms": [1e3 * r for r in regions],
+            "statistic": "median of %d timed regions of %d steps each (max over ranks per region)" % (repeats, args.steps),
+            "higher_is_better": True, "scaling": scaling if args.walkers_per_gpu is None else "weak",
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "generic Cholesky AFQMC: Nbasis=100, Nchol=500, RHF trial 25+25 electrons, "
                                    "%d walkers/GPU, dt=0.005, reortho/10, comb/5, energy/10 "
                                    "(BASELINE configs[2])" % nw,
                        "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox",
-                       "population_control": ("device comb over the library's RCCL communicator" if
-                                              getattr(afqmc.psi, 'device_comm', False) else
+                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "population_control": ("device comb over the library's RCCL communicator" if device_comm else
                                               "device comb (one rank)" if world == 1 else
-                                              "host-mediated (torch.distributed)" +
+                                              "host-mediated (torch.distributed, backend %s)" % backend +
                                               (": " + afqmc.psi.device_comm_error
                                                if getattr(afqmc.psi, 'device_comm_error', '') else ""))},
+            "population_control": ("device comb over the library's RCCL communicator" if device_comm else
+                                   "device comb (one rank)" if world == 1 else "host-mediated (torch.distributed)"),
+            "comm_stats": comm_stats,
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
-                         "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                         "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+                         "frac_issued": dom.get("frac_issued"), "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
-                         "flops_per_launch": dom["flops_per_launch"]},
+                         "flops_per_launch": dom["flops_per_launch"],
+                         "issued_flops_per_launch": dom.get("issued_flops_per_launch")},
             "roofline_all": rows,
         }
-        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
+        if with_cpu_baseline:                                   # reported at N = 1 only
+            state["phase"] = "cpu baseline"
             out["cpu_baseline"] = cpu_baseline(system, trial)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if comm is not None:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    state["dev"] = None
+    release_context(system, trial)
+    return out
 
 
 if __name__ == "__main__":

@@ -382,6 +382,13 @@ int afq_stream(afq_handle *h, void **stream);
 int afq_kernel_trace(afq_handle *h, int on);
 int afq_kernel_trace_stride(afq_handle *h, int kind, int stride);
 int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int *n_out);
+/* Flops the matrix pipe executed in the LAST launch of a kind: MFMA instructions x their flop count (2048 per
+ * v_mfma_f64_16x16x4, 512 per 4x4x4), tile and contraction padding included, a 3-multiplication complex product
+ * counted as 3.  issued / time / peak is the utilisation of the pipe; the algorithmic count of SURVEY 8d
+ * (4 multiplications, no padding) over the same time is the figure comparable across implementations.
+ * 0 for kinds that have not been launched or do not run on the matrix pipe.  (measurement hook, no reference
+ * counterpart)                                                                                                    */
+int afq_kernel_issued_flops(afq_handle *h, int kind, double *flops_out);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     "afq_kernel_trace": [_h, c_int],
     "afq_kernel_trace_stride": [_h, c_int, c_int],
     "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],
+    "afq_kernel_issued_flops": [_h, c_int, POINTER(c_double)],
 }
 
 

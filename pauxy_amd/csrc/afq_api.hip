@@ -1712,4 +1712,10 @@ int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int
     return AFQ_OK;
 }
 
+int afq_kernel_issued_flops(afq_handle *h, int kind, double *flops_out) {
+    if (!h || !flops_out || kind < 0 || kind >= AFQ_K_COUNT) return AFQ_EINVAL;
+    *flops_out = h->issued_flops[kind];
+    return AFQ_OK;
+}
+
 }  // extern "C"

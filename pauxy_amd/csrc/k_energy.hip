@@ -552,6 +552,13 @@ static int launch_exx_quadratic(afq_handle *h) {
     const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : (S > 1 ? 1 : 0);
     {
         KernelTrace kt(h, AFQ_K_EXCHANGE);
+        {   // every configuration below multiplies 64 x 64 work-group tiles; the contraction of a tile is its KCUT length
+            auto klen = [&](int b, int col0, int ncols) -> long {
+                const long need = (long)col0 + ncols - p.k0[b];
+                return need <= 0 ? 0 : (need < p.len[b] ? need : p.len[b]);
+            };
+            h->issued_flops[AFQ_K_EXCHANGE] = mfma_gemm_wg_issued_flops<2, 2, 2, 2, ExxQProb<RC>, RC>(p, klen);
+        }
         if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
 #ifdef AFQ_TUNING
         else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));

@@ -1141,6 +1141,13 @@ int k_prop_fused(afq_handle *h) {
     static size_t lds_set[6][AFQ_MAX_DEVICES] = {{0}, {0}, {0}, {0}, {0}, {0}};
     const bool narrow = h->na <= 16 && h->nb <= 16;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
+    {   // matrix-pipe flops of this launch: (order complex products by 3 multiplications + 2 one-body applications by 2 or
+        // 3) x k-steps of 4 x existing 16 x 16 tiles (2048 flop per v_mfma_f64_16x16x4, 512 per 4x4x4 remainder unit)
+        const int nrt_ = (h->M + 15) / 16, ct = (h->na + 15) / 16 + (h->nb + 15) / 16;
+        const double ksteps = 2.0 * NCH;
+        const double per_pass = ksteps * (2048.0 * (a.rem4 ? nrt_ - 1 : nrt_) * ct + 512.0 * (a.rem4 ? ct : 0));
+        h->issued_flops[AFQ_K_PROPAGATOR] = (3.0 * h->exp_order + 2.0 * (a.b_real ? 2.0 : 3.0)) * per_pass * h->nw;
+    }
     // every tile of the deal present: wide with 5-7 row tiles (waves 4-7 own the tiles from 4 on) and two column tiles
     // per spin, or narrow with six row tiles
     const int nrt = (h->M + 15) / 16;

@@ -247,6 +247,8 @@ static int force_bias_generic_impl(afq_handle *h) {
             }
             else if (cfg == 2) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
+                h->issued_flops[AFQ_K_FORCE_BIAS] = mfma_gemm_wg_issued_flops<4, 2, 1, 2, ForceBiasProb<false>>(
+                    p, [&](int, int, int) -> long { return p.kdim; });
                 // half-chunk pipelined loop (STAG = 2): 56 us at C3 against 58 (staggered halves) / 61 (plain loop)
 #ifdef AFQ_TUNING
                 if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
@@ -382,12 +384,14 @@ int k_vhs_generic(afq_handle *h) {
             if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
             else if (xmap) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 1, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
         }
         else if (cfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 3, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else {
             KernelTrace kt(h, AFQ_K_VHS);
+            h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 2, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
             AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         }
         return AFQ_OK;

@@ -483,6 +483,26 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
 #endif
 }
 
+// Flops the matrix pipe executes for one launch of the engine (what "issued" rooflines are priced on): every work-group
+// tile multiplies its full (16 RT) x (16 CT) block over whole chunks of 8 contraction indices -- padding included --
+// with 2 real products per element pair when B is real, 3 with the 3-multiplication complex product, else 4.
+// `klen(b, col0, ncols)`: contraction length of a tile (kdim, or the KCUT trait restated on the host).
+template <int WM, int WN, int TM, int TN, class P, bool K3M = false, int KC = 1, class KLen>
+inline double mfma_gemm_wg_issued_flops(const P &p, KLen klen) {
+    constexpr int RT = WM * TM, CT = WN * TN;
+    const long tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
+    const long tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
+    const double mults = P::B_CPLX ? (K3M ? 3.0 : 4.0) : 2.0;
+    double f = 0.0;
+    for (int b = 0; b < p.batch; ++b)
+        for (long tn = 0; tn < tiles_n; ++tn) {
+            const long k = klen(b, (int)(tn * 16 * CT), 16 * CT);
+            const long kpad = (k + 8 * KC - 1) / (8 * KC) * (8 * KC);
+            f += 2.0 * mults * (double)tiles_m * (16.0 * RT) * (16.0 * CT) * (double)kpad;
+        }
+    return f;
+}
+
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;

@@ -462,6 +462,12 @@ class AfqDevice(object):
         self._ck(self.lib.afq_kernel_trace_get(self.h, int(kind), _p(out), max_n, ctypes.byref(n)))
         return out[:min(n.value, max_n)]
 
+    def kernel_issued_flops(self, kind):
+        """Matrix-pipe flops of the last launch of ``kind`` (padding included, 3M products counted as 3)."""
+        out = ctypes.c_double(0.0)
+        self._ck(self.lib.afq_kernel_issued_flops(self.h, int(kind), ctypes.byref(out)))
+        return float(out.value)
+
     def set_exchange_algorithm(self, mode):
         """0 automatic, 1 T-intermediate (exx_kernel), 2 quadratic form (see afq_set_exchange_algorithm)."""
         self._ck(self.lib.afq_set_exchange_algorithm(self.h, int(mode)))

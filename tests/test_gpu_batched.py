@@ -82,25 +82,43 @@ def test_batched_traj_hirsch(golden, monkeypatch):
 C3 = dict(M=100, K=500, N=25, nw=256)
 
 
-def c3_afqmc(device_rng=False):
-    s = systems.synthetic_generic(C3['M'], C3['K'], (C3['N'], C3['N']), seed=7)
-    t = trial_mod.rhf_trial_generic(s)
+def build_afqmc(s, t, nw, device_rng=False, prop=None):
     options = {'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': 2, 'stabilise_freq': 10, 'pop_control_freq': 5,
-                       'num_walkers': C3['nw'], 'rng_seed': 7},
-               'propagator': {'device_rng': device_rng, 'rng_seed': 7},
+                       'num_walkers': nw, 'rng_seed': 7},
+               'propagator': dict({'device_rng': device_rng, 'rng_seed': 7}, **(prop or {})),
                'estimators': {'mixed': {'verbose': False}}}
     return AFQMC(options=options, system=s, trial=t), s, t
 
 
-def run_c3(batched, fetch, ride=False):
-    afqmc, s, t = c3_afqmc()
+def c3_afqmc(device_rng=False):
+    s = systems.synthetic_generic(C3['M'], C3['K'], (C3['N'], C3['N']), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    return build_afqmc(s, t, C3['nw'], device_rng)
+
+
+def c2_afqmc(device_rng=False):
+    """BASELINE configs[1]: UEG rs=2, 14 electrons, 93 plane waves, 256 walkers."""
+    s = systems.UEG(2.0, 7, 7, 4.0)
+    return build_afqmc(s, trial_mod.hartree_fock_ueg(s), 256, device_rng)
+
+
+def c4_afqmc(device_rng=False):
+    """BASELINE configs[3] per GPU: 16x16 Hubbard U=8, 128+128 electrons, UHF trial, 256 walkers."""
+    s = systems.Hubbard(16, 16, 128, 128, 8.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    return build_afqmc(s, t, 256, device_rng, {'hubbard_stratonovich': 'continuous'})
+
+
+def run_c3(batched, fetch, ride=False, make=c3_afqmc):
+    afqmc, s, t = make()
+    nw = afqmc.psi.nw
     # ride: the estimator terms of the plain steps ride on their weight update (afq_estimates_fuse_next) -- the same
     # additions in another association, so the block sums (hence the shift, hence the weights) move by rounding
     afqmc.ride_estimates = ride
     numpy.random.seed(1234)
     # walkers that all start on the trial keep weights within a few per cent of each other for the first blocks and
     # the comb would clone nobody: start from a spread population
-    afqmc.psi.dev.set(L.F_WEIGHT, numpy.exp(0.6 * numpy.random.RandomState(5).normal(size=C3['nw'])))
+    afqmc.psi.dev.set(L.F_WEIGHT, numpy.exp(0.6 * numpy.random.RandomState(5).normal(size=nw)))
     afqmc.psi._invalidate()
     rec = dict(weight=[], ot=[], ehyb=[], pix=[])
 
@@ -119,6 +137,25 @@ def run_c3(batched, fetch, ride=False):
     phi = afqmc.psi.dev.get(L.F_PHI)
     release_context(s, t)
     return {k: numpy.array(v) for k, v in rec.items()}, blocks, phi
+
+
+@pytest.mark.parametrize("make", [c2_afqmc, c4_afqmc], ids=["C2-ueg-256", "C4-hubbard16x16-256"])
+def test_c2_c4_run_batched_equals_run(make):
+    """20 steps of BASELINE configs[1] (UEG, 93 plane waves) and configs[3] (16x16 Hubbard, 128+128 electrons: the
+    GEMM + register-resident Gauss-Jordan Green's function, the unfused propagator) at their stated 256 walkers
+    per GPU, host-drawn fields: the batched loop bench-style (no read-back at the comb) against the per-walker loop
+    -- same kernels on the same data, walkers bit-equal -- and with the comb read back, identical comb decisions."""
+    a, blocks_a, phi_a = run_c3(False, True, make=make)
+    b, blocks_b, phi_b = run_c3(True, True, make=make)
+    c, blocks_c, phi_c = run_c3(True, False, make=make)
+    assert numpy.all(numpy.isfinite(phi_a.view(float))) and numpy.all(numpy.isfinite(a['weight']))
+    for other, blocks, phi in ((b, blocks_b, phi_b), (c, blocks_c, phi_c)):
+        for key in ('weight', 'ot', 'ehyb'):
+            assert numpy.array_equal(a[key], other[key]), key
+        assert numpy.array_equal(phi_a, phi)
+        close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-12)
+    assert numpy.array_equal(a['pix'], b['pix'])
+    assert a['pix'].shape == (4, 256) and a['pix'].max() >= 2             # the comb did clone walkers
 
 
 def test_c3_run_batched_equals_run():

@@ -1,0 +1,62 @@
+"""bench.py end to end on the GPU box: the one-GPU line, and `python bench.py --gpus 2` WITHOUT a launcher (the form
+the driver's scaling run uses) -- bench.py starts its two ranks itself.  The box has one GPU and RCCL needs one GPU per
+rank, so the two ranks share it over gloo (AFQ_BENCH_BACKEND=gloo: the host-mediated population control); on a
+multi-GPU node the same command runs the device comb over the library's RCCL communicator."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return [json.loads(ln) for ln in lines]
+
+
+def check_line(out, n_gpus, steps, walkers_total):
+    assert out["metric"] == "walker_steps_per_sec" and out["unit"] == "walker-steps/s"
+    assert out["n_gpus"] == n_gpus and out["steps"] == steps and out["dtype"] == "f64"
+    assert out["config"]["walkers_total"] == walkers_total
+    assert out["repeats"] == len(out["timed_regions_ms"]) >= 1
+    assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    assert out["value"] == pytest.approx(walkers_total * 1e3 / out["ms_per_step"], rel=1e-9)
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0.0 < r["frac"] < 1.0
+    assert 0.0 < r["frac_issued"] < 1.0                               # a utilisation: can never exceed the peak
+    for row in out["roofline_all"]:
+        assert 0.0 < row["frac_issued"] < 1.0, row["kernel"]
+    assert len(out["rank_ms_per_step"]["per_rank"]) == n_gpus
+
+
+def test_bench_one_gpu_short_region_is_repeated():
+    (out,) = run_bench(["--steps", "20", "--warmup", "10"])
+    check_line(out, 1, 20, 256)
+    assert out["repeats"] == 5 and out["scaling"] == "weak"
+    assert out["population_control"] == "device comb (one rank)"
+
+
+def test_bench_two_ranks_self_launched_strong():
+    (out,) = run_bench(["--gpus", "2", "--scaling", "strong", "--steps", "10", "--warmup", "10"],
+                       {"AFQ_BENCH_BACKEND": "gloo"})
+    check_line(out, 2, 10, 2048)
+    assert out["scaling"] == "strong"
+    assert out["population_control"].startswith("host-mediated")      # gloo: never reported as the device comb
+    assert out["config"]["backend"] == "gloo"
+
+
+def test_bench_weak_and_strong_lines():
+    outs = run_bench(["--gpus", "2", "--scaling", "both", "--steps", "10", "--warmup", "10"],
+                     {"AFQ_BENCH_BACKEND": "gloo"})
+    assert [o["scaling"] for o in outs] == ["weak", "strong"]
+    check_line(outs[0], 2, 10, 512)
+    check_line(outs[1], 2, 10, 2048)

@@ -157,6 +157,12 @@ def test_c4_hubbard_16x16():
     run_fullsize(hubbard_c4(), 32, [0, 31])
 
 
+def test_c4_hubbard_16x16_256_walkers():
+    """BASELINE configs[3] at its stated population per GPU (2048 walkers over 8 GPUs): batch <-> XCD maps, 64-walker
+    GEMM tiles and the split-K slice counts all branch on the walker count."""
+    run_fullsize(hubbard_c4(), 256, [0, 129, 255])
+
+
 def test_hubbard_large_n_ragged():
     """45 < N <= 128 with na != nb and no dimension a multiple of 16: the GEMM + register-resident
     Gauss-Jordan Green's function (k_bigdet.hip), every walker against the oracle."""
@@ -201,6 +207,26 @@ def test_large_n_reortho_breakdown_fallback():
 
 def test_c2_ueg_93_planewaves():
     run_fullsize(ueg_c2(), 64, [0, 63])
+
+
+def test_c2_ueg_256_walkers():
+    """BASELINE configs[1] at its stated 256 walkers."""
+    run_fullsize(ueg_c2(), 256, [0, 100, 255])
+
+
+def generic_c5():
+    M, K, N, dt = 400, 2000, 50, 0.005
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    return ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                        H1=s.H1.astype(complex), ecore=0.0)
+
+
+def test_c5_sizes_single_determinant_256_walkers():
+    """BASELINE configs[4] sizes (M=400, K=2000, 50+50) with a single determinant at 256 walkers per GPU: three walkers
+    against the oracle (Green's function, energy, one full step, re-orthogonalisation), properties on all."""
+    run_fullsize(generic_c5(), 256, [0, 130, 255])
 
 
 def test_c5_sizes_multi_determinant_consistency():
@@ -261,14 +287,15 @@ def AfqDeviceForMsd(model, coeffs, rchol0, nw):
     return dev
 
 
-def test_c5_sizes_distinct_complex_determinants():
+@pytest.mark.parametrize("nw", [8, 256])
+def test_c5_sizes_distinct_complex_determinants(nw):
     """BASELINE configs[4] sizes (M=400, K=2000, 50+50) with a NOMSD trial of three DISTINCT complex determinants
     (complex half-rotated Cholesky vectors: the complex exchange path).  Per walker: determinant weights
     conj(c_d) <D_d|phi>, the weighted force bias (propagation/generic.py:154-157) and the energy
     sum_d w_d E[G_d] / sum_d w_d (estimators/mixed.py:439-448) with every E[G_d] evaluated by the oracle's
     half-rotated form (estimators/generic.py:156-221, equal to the reference's full-G form; the full-G intermediate
     would need 5 GB per walker here); both exchange algorithms of the device against each other for all walkers."""
-    M, K, N, dt, nw = 400, 2000, 50, 0.005, 8
+    M, K, N, dt = 400, 2000, 50, 0.005
     s = systems.synthetic_generic(M, K, (N, N), seed=7)
     t0 = trial_mod.rhf_trial_generic(s)
     rng = numpy.random.RandomState(3)
@@ -297,7 +324,7 @@ def test_c5_sizes_distinct_complex_determinants():
         dev.close()
     close(E[1], E[2], 1e-11)
     H1 = s.H1.astype(complex)
-    for w in (0, 5):
+    for w in (0, nw - 3):
         ws, Es, Gsum = [], [], 0.0
         for d in range(3):
             ov, gh, G = ref.greens_function(phis[w], dets[d], N, N)
