@@ -352,15 +352,32 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         'propagator': {'device_rng': not args.host_rng, 'rng_seed': 7, 'rng_stream': rank},
         'estimators': {'mixed': {'verbose': False}},
     }
+    if os.environ.get("AFQ_BENCH_DEVICE_COMM"):
+        # 'rccl' | 'sendrecv' | 'ipc' | '0': pin one communicator ('ipc' also works with every rank on one GPU over gloo)
+        v = os.environ["AFQ_BENCH_DEVICE_COMM"]
+        options['walkers'] = {'device_comm': False if v == '0' else v}
     state["phase"] = "set-up"
     afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
     state["dev"] = dev
-    if world > 1 and backend == "nccl" and not getattr(afqmc.psi, 'device_comm', False):
-        # the N > 1 number is the one of the device comb over the library's RCCL communicator: never report the
-        # host-mediated fallback under its name
-        raise SystemExit("bench.py: rank %d could not bring up the library's RCCL communicator (%s)"
-                         % (rank, getattr(afqmc.psi, 'device_comm_error', '') or 'unknown reason'))
+    device_comm = bool(getattr(afqmc.psi, 'device_comm', False))
+    comm_kind = getattr(afqmc.psi, 'device_comm_kind', '')
+    comm_note = getattr(afqmc.psi, 'device_comm_error', '') or ''
+    if world > 1 and backend == "nccl" and comm_kind != 'rccl':
+        # never silently: the N > 1 number is meant to be the device comb over the library's RCCL communicator with the
+        # walkers moving through mapped peer windows; anything else is said on stderr and in the result line
+        sys.stderr.write("bench.py: rank %d: population control runs as %r, not the RCCL + peer-window path (%s)\n"
+                         % (rank, comm_kind or 'host-mediated', comm_note or 'no reason recorded'))
+        if os.environ.get("AFQ_BENCH_REQUIRE_DEVICE_COMM", "0") == "1":
+            raise SystemExit(5)
+    pc_label = {'rccl': "device comb over the library's RCCL communicator (all-gather / all-reduce by RCCL, walkers written "
+                        "straight into the destination GPU's mapped window over xGMI, live slots only)",
+                'sendrecv': "device comb over the library's RCCL communicator (fixed-capacity ncclSend/ncclRecv slots)",
+                'ipc': "device comb over mapped peer windows (hipIpc, no RCCL; bootstrap over torch.distributed)"}.get(
+        comm_kind, "device comb (one rank)" if world == 1 else
+        "host-mediated (torch.distributed, backend %s)" % backend)
+    if comm_note and world > 1:
+        pc_label += " [fell through: " + comm_note + "]"
 
     def barrier():
         dev.sync()
@@ -502,7 +519,6 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         with open(tfile) as f:
             traffic = json.load(f).get(dom["kernel"].split(" ")[0], {}).get("traffic_bytes_per_launch")
 
-    device_comm = bool(getattr(afqmc.psi, 'device_comm', False))
     comm_stats = dev.comm_stats() if device_comm else None
     out = None
     if rank == 0:
@@ -524,13 +540,8 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                                    "(BASELINE configs[2])" % nw,
                        "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox",
                        "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "population_control": ("device comb over the library's RCCL communicator" if device_comm else
-                                              "device comb (one rank)" if world == 1 else
-                                              "host-mediated (torch.distributed, backend %s)" % backend +
-                                              (": " + afqmc.psi.device_comm_error
-                                               if getattr(afqmc.psi, 'device_comm_error', '') else ""))},
-            "population_control": ("device comb over the library's RCCL communicator" if device_comm else
-                                   "device comb (one rank)" if world == 1 else "host-mediated (torch.distributed)"),
+                       "population_control": pc_label},
+            "population_control": pc_label,
             "comm_stats": comm_stats,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],

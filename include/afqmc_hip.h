@@ -40,6 +40,7 @@ typedef struct afq_handle afq_handle;
 #define AFQ_EWEIGHT      (-6)   /* total weight < 1e-8 (walkers/handler.py:236)  */
 #define AFQ_EOVERFLOW    (-7)   /* more walkers moved between two ranks in one population control than the
                                    exchange slots of the communicator hold (afq_comm_set_capacity)   */
+#define AFQ_ECOMM        (-8)   /* communicator: a peer never signalled, probe mismatch, bootstrap failure */
 
 /* system kinds */
 #define AFQ_SYS_GENERIC 1
@@ -273,27 +274,56 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
  * estimators/mixed.py:261,273, on the device over RCCL (xGMI on one node), one process per GPU.
  * After afq_comm_init, afq_popcontrol_comb is a collective: every rank calls it with the same
  * target_weight (= total walkers) and rank 0's r; the weights are all-gathered on the device, every rank
- * decides the identical global comb, cloned walkers that change rank travel through fixed-capacity slot
- * buffers (one ncclSend / ncclRecv group), nothing is read back by the host unless outputs are requested
+ * decides the identical global comb, cloned walkers that change rank are written by the sending GPU straight
+ * into the receiving GPU's mapped window (live slots only), nothing is read back by the host unless outputs are requested
  * (parent_ix is then the GLOBAL int32[nranks * nw] comb, total_weight_out the global weight).  The cap of
  * afq_cap_weights / afq_set_weight_cap with total_weight < 0 uses the global weight of the last comb.
  *   afq_comm_unique_id     128-byte ncclUniqueId, made by rank 0 and handed to every rank by the caller
+ *   afq_comm_available     1 if librccl can be loaded in this process (no collective: lets the ranks AGREE on calling
+ *                          afq_comm_init before any of them blocks inside ncclCommInitRank)
  *   afq_comm_init          ncclCommInitRank on the handle's GPU (librccl is loaded here, not before)
- *   afq_comm_set_capacity  walkers one rank can send to one peer per event (default max(8, nw/8));
- *                          exceeding it raises AFQ_EOVERFLOW at the next afq_estimates_get / fetching comb
- *   afq_comm_stats         int64[6]: largest per-peer transfer seen, events, capacity, overflow flag, rank, size
+ *   afq_comm_init_ipc      the same communicator without RCCL: every rank maps every peer's window
+ *                          (hipIpcGetMemHandle / hipIpcOpenMemHandle, xGMI peer access on one node) and all three
+ *                          exchanges -- weights all-gather, walker slots, estimator reduction -- are kernels writing
+ *                          into the peers' windows, ordered by system-scope flags.  `allgather(send, recv, bytes, user)`
+ *                          is the caller's all-gather of `bytes` per rank over its own communicator (MPI /
+ *                          torch.distributed; returns 0): the bootstrap for the window handles, called on the host at
+ *                          afq_comm_init_ipc time and whenever the windows are re-made (first population control,
+ *                          capacity change) -- at the same call on every rank
+ *   afq_comm_set_transport 1 (default): walkers that change rank are written by the pack kernel straight into the
+ *                          destination rank's mapped window, LIVE SLOTS ONLY, no host knowledge of the counts, nothing
+ *                          posted by the host; 0 (RCCL communicator only; also the automatic fall-back when a rank cannot
+ *                          export / map windows): fixed-capacity slots to and from every peer in one ncclSend / ncclRecv group
+ *   afq_comm_set_capacity  walkers one rank can send to one peer per event (default nw: what a rank owns, cannot
+ *                          overflow); exceeding it raises AFQ_EOVERFLOW at the next afq_estimates_get / fetching comb.
+ *                          Only the ncclSend / ncclRecv transport pays for unused capacity
+ *   afq_comm_probe         collective known-answer round through the all-gather, one full slot to and from every peer on
+ *                          the configured transport, and the all-reduce; AFQ_ECOMM on any mismatch
+ *                          (mismatch_out int64[3], may be NULL: collective values, slot elements, flags that never came)
+ *   afq_comm_stats         int64[AFQ_COMM_NSTATS]: largest per-peer transfer seen, events, capacity, overflow flag, rank,
+ *                          size, walkers sent, bytes sent, transport (1 windows / 0 send-recv), communication error flag,
+ *                          communicator kind (0 in-process, 1 RCCL, 2 IPC), window memory kind (1 uncached,
+ *                          2 fine-grained, 3 plain)
  *   afq_estimates_allreduce  sum over ranks of buf c128[nest] (in/out, host), or with buf == NULL of the
  *                          device accumulators of afq_estimates_update in place (no host round trip; a
  *                          following afq_estimates_get returns the global sums on every rank)
+ * A kernel that waits for a peer gives up after 10 s and raises a sticky error, reported as AFQ_ECOMM by the next
+ * synchronising call (afq_estimates_get / _end, a fetching afq_popcontrol_comb) -- never a hung device.
  * In-process variant: afq_comm_init_local makes handles[0..n) (one host thread driving several GPUs, or
  * several handles on one GPU) the ranks 0..n-1 of one communicator; the collectives are then the group calls
- * afq_popcontrol_comb_local / afq_estimates_allreduce_local (same kernels, device-to-device copies ordered by
- * events instead of RCCL).                                                                               */
+ * afq_popcontrol_comb_local / afq_estimates_allreduce_local (the kernels and windows of the IPC communicator, the
+ * windows being plain device pointers of the one process).                                               */
 #define AFQ_COMM_ID_BYTES 128
+#define AFQ_COMM_NSTATS 12
+typedef int (*afq_allgather_fn)(const void *send, void *recv, int bytes, void *user);
 int afq_comm_unique_id(void *id_out);
+int afq_comm_available(void);
 int afq_comm_init(afq_handle *h, const void *unique_id, int rank, int nranks);
+int afq_comm_init_ipc(afq_handle *h, int rank, int nranks, afq_allgather_fn allgather, void *user);
 int afq_comm_destroy(afq_handle *h);
+int afq_comm_set_transport(afq_handle *h, int window);
 int afq_comm_set_capacity(afq_handle *h, int max_walkers_per_peer);
+int afq_comm_probe(afq_handle *h, int64_t *mismatch_out);
 int afq_comm_stats(afq_handle *h, int64_t *out);
 int afq_comm_parent_ix(afq_handle *h, int32_t *parent_ix_global);
 int afq_estimates_allreduce(afq_handle *h, double *buf, int nest);

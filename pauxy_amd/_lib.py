@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libafqmc_hip.so")
 
 AFQ_OK = 0
-AFQ_EWEIGHT, AFQ_EOVERFLOW = -6, -7
+AFQ_EWEIGHT, AFQ_EOVERFLOW, AFQ_ECOMM = -6, -7, -8
+AFQ_COMM_NSTATS = 12
+# the caller's all-gather lent to afq_comm_init_ipc: int (*)(const void *send, void *recv, int bytes, void *user)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 AFQ_SYS_GENERIC, AFQ_SYS_HUBBARD, AFQ_SYS_UEG = 1, 2, 3
 AFQ_PROP_HYBRID, AFQ_PROP_FORCE_BIAS, AFQ_PROP_FREE_PROJECTION, AFQ_PROP_HUBBARD_SPIN = 1, 2, 4, 8
 (F_PHI, F_WEIGHT, F_UNSCALED_WEIGHT, F_OT, F_HYBRID_ENERGY, F_PHASE, F_DETR, F_ELOC, F_GHALF, F_G,
@@ -92,7 +95,11 @@ SIGNATURES = {
     "afq_debug": [_h, c_int, c_int],
     "afq_last_launch": [_h, c_void_p, c_int, POINTER(c_uint64), POINTER(c_uint64)],
     "afq_comm_unique_id": [c_void_p],
+    "afq_comm_available": [],
     "afq_comm_init": [_h, c_void_p, c_int, c_int],
+    "afq_comm_init_ipc": [_h, c_int, c_int, ALLGATHER_FN, c_void_p],
+    "afq_comm_set_transport": [_h, c_int],
+    "afq_comm_probe": [_h, c_void_p],
     "afq_comm_destroy": [_h],
     "afq_comm_set_capacity": [_h, c_int],
     "afq_comm_stats": [_h, c_void_p],

@@ -204,10 +204,10 @@ int afq_create(int device_id, afq_handle **out) {
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     if (hipMalloc(&h->estimates, sizeof(cplx) * AFQ_EST_COUNT_) != hipSuccess ||
         hipMalloc(&h->counters, sizeof(unsigned long long) * 4) != hipSuccess ||
-        hipMalloc(&h->scal, sizeof(double) * 8) != hipSuccess) { delete h; return AFQ_ENOMEM; }
+        hipMalloc(&h->scal, sizeof(double) * AFQ_NSCAL) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_);
     hipMemset(h->counters, 0, sizeof(unsigned long long) * 4);
-    hipMemset(h->scal, 0, sizeof(double) * 8);
+    hipMemset(h->scal, 0, sizeof(double) * AFQ_NSCAL);
     if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->zero_page, 0, 256);
     // diagnostics (not tuning): AFQ_DEBUG_SYNC=1 synchronises and checks after every launch (a failing kernel is
@@ -584,7 +584,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     h->cap_frac = 0.0; h->cap_total = -1.0;       // a cap armed for an earlier population does not carry over
     {   // walker.total_weight starts as the population size (walkers/handler.py:164); with a communicator
         // the population is nw walkers on every rank
-        double sc0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double sc0[AFQ_NSCAL] = {0};
         sc0[0] = (double)nw * k_comm_size(h);
         AFQ_HIP(h, hipMemcpy(h->scal, sc0, sizeof(sc0), hipMemcpyHostToDevice));
     }
@@ -1118,11 +1118,12 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *
     if ((rc = k_comb(h, r, target_weight, keep))) return rc;
     h->greens_valid = keep;
     if (!parent_ix && !total_weight_out) return AFQ_OK;  // asynchronous: nothing read back, no host sync
-    double sc[4];
+    double sc[8];
     if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;
     if (total_weight_out) *total_weight_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8");
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "more walkers moved between two ranks than the exchange slots hold");
+    if (sc[6] != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled (waited 10 s on the device)");
     if (!parent_ix) return AFQ_OK;
     if (h->comm) return afq_comm_parent_ix(h, parent_ix);   // the global comb, [nranks * nw]
     return copy_out(h, parent_ix, h->parent_ix, sizeof(int) * h->nw);
@@ -1288,7 +1289,7 @@ __global__ void est_publish_kernel(cplx *est, const double *scal, double *host_o
                                    unsigned long long seq, int nest, int zero) {
     const int t = threadIdx.x;
     if (t < nest) host_out[t] = ((const double *)est)[t];
-    if (t < 8) host_out[nest + t] = scal[t];
+    if (t < AFQ_NSCAL) host_out[nest + t] = scal[t];
     __threadfence_system();
     __syncthreads();
     if (t < nest && zero) ((double *)est)[t] = 0.0;
@@ -1303,10 +1304,10 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     { const int rc = k_estimates(h, 0, true); if (rc) return rc; }     // sums still sitting in the per-walker accumulators
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
-        // [nest sums | scal[8] | sequence number], written by the device, polled by the host
-        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + 8 + 1),
+        // [nest sums | scal[AFQ_NSCAL] | sequence number], written by the device, polled by the host
+        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + AFQ_NSCAL + 1),
                                  hipHostMallocMapped | hipHostMallocCoherent));
-        memset(h->est_stage, 0, sizeof(double) * (nest + 8 + 1));
+        memset(h->est_stage, 0, sizeof(double) * (nest + AFQ_NSCAL + 1));
     }
     // the one host synchronisation of a block of steps also reports a population that collapsed in an
     // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
@@ -1314,7 +1315,7 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
     ++h->est_seq;
     AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
-               (unsigned long long *)(dev_view + nest + 8), h->est_seq, (int)nest, zero);
+               (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero);
     AFQ_POST(h);
     h->est_pending = true;
     return AFQ_OK;
@@ -1329,7 +1330,7 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     {
         // poll the sequence number; the stream query catches a failed launch or device (no endless wait)
-        const unsigned long long *seq = (const unsigned long long *)(h->est_stage + nest + 8);
+        const unsigned long long *seq = (const unsigned long long *)(h->est_stage + nest + AFQ_NSCAL);
         unsigned spins = 0;
         while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != h->est_seq) {
             if ((++spins & 0x3ffu) == 0) {
@@ -1344,11 +1345,13 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     memcpy(est_out, h->est_stage, sizeof(double) * nest);
     const double *sc = h->est_stage + nest;
     // the population-control scalars of the block ride along: afq_comm_stats right behind this call needs no synchronisation
-    memcpy(h->scal_cache, sc, sizeof(double) * 8);
+    memcpy(h->scal_cache, sc, sizeof(double) * AFQ_NSCAL);
     h->scal_cache_valid = true;
     if (sc[2] != 0.0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8 in an earlier population control");
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "population control: more walkers moved between two ranks than the "
                                                  "exchange slots hold (afq_comm_init capacity)");
+    if (sc[6] != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled an all-gather row / walker slots "
+                                             "(waited 10 s on the device)");
     return AFQ_OK;
 }
 

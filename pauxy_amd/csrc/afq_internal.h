@@ -34,6 +34,7 @@ __device__ inline cplx cdiv(cplx a, cplx b) {
     }
 }
 
+#define AFQ_NSCAL 12
 enum { T_GREENS = 0, T_ONEBODY, T_FB, T_VHS, T_EXP, T_OVLP, T_QR, T_ENERGY, T_COUNT };
 
 struct afq_handle {
@@ -187,7 +188,7 @@ struct afq_handle {
     bool prop_pending = false;                      // afq_propagate_begin done, afq_propagate_finish outstanding
     double *est_stage = nullptr;                    // mapped host memory: estimator sums + scal[4] + sequence number
     unsigned long long est_seq = 0;
-    double scal_cache[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scal[] as of the last afq_estimates_get_end; stale after a population control
+    double scal_cache[AFQ_NSCAL] = {0};   // scal[] as of the last afq_estimates_get_end; stale after a population control
     bool scal_cache_valid = false;
     bool est_pending = false;
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
@@ -204,7 +205,10 @@ struct afq_handle {
     unsigned long long *counters = nullptr;   // [4]
     int *alive = nullptr;           // [nw]
     int *parent_ix = nullptr;       // [nw]
-    double *scal = nullptr;         // [8] device scalars (total weight, ...)
+    // [AFQ_NSCAL] device scalars: 0 total weight of the last comb, 1 local pairs (< 0: collapsed), 2 collapse flag (sticky),
+    // 3 exchange overflow (sticky), 4 largest transfer between two ranks, 5 comb events, 6 communication error (sticky:
+    // a peer's flag never arrived), 7 walkers this rank has sent, 8 bytes this rank has sent (window transport)
+    double *scal = nullptr;
     void *pack_tmp = nullptr;
     void *zero_page = nullptr;      // 256 zero bytes: source of out-of-range LDS-DMA loads
     // Ghalf / ovlp_new describe the CURRENT phi of every walker (set by the end-of-step Green's

@@ -4,7 +4,8 @@
 //
 // One population-control event on every rank, all queued on the handle's stream, nothing read back:
 //   1. comm_prep_kernel      sendw = [ |weight_0| .. |weight_{nw-1}|, r ]      (r: rank 0's comb uniform)
-//   2. all-gather            gw[rank][nw + 1]                                   (RCCL ncclAllGather over xGMI)
+//   2. all-gather            gw[rank][nw + 1]                                   (RCCL ncclAllGather over xGMI, or peer
+//                                                                                writes into the mapped windows)
 //   3. comb_plan_global      every rank decides the IDENTICAL global comb from gw: total weight, scaling of
 //                            its own weights, teeth located by bisection of the cumulative weights,
 //                            zip(clone, kill) pairs in global walker order.  Both lists are ascending, so the
@@ -13,18 +14,33 @@
 //                            Out: pairs inside this rank, send / receive slot lists per peer, global parent_ix.
 //   4. clone_kernel          copies inside the rank
 //   5. comm_pack_kernel      walker state (phi, scalars, cached Green's function, back-propagation history)
-//                            of the outgoing walkers into the per-peer slot buffers
-//   6. exchange              fixed-capacity all-to-all: `cap` slots to and from every peer in one RCCL group
-//                            of ncclSend / ncclRecv (the host never learns the counts, so it posts the
-//                            capacity; xGMI is a full mesh, so the 7 transfers of a rank run on 7 links)
+//                            of the outgoing walkers
+//   6. exchange              WINDOW transport (default): every rank maps every peer's receive window once
+//                            (hipIpcGetMemHandle / hipIpcOpenMemHandle; xGMI peer access) and the pack kernel
+//                            writes ONLY THE LIVE SLOTS straight into the destination rank's window, then raises
+//                            that rank's flag for this event (system-scope release); the unpack kernel of the
+//                            destination waits for the flags of the peers it expects walkers from.  Bytes moved =
+//                            live slots x slot size; the host never learns the counts and posts nothing.
+//                            SENDRECV transport (fallback): `cap` slots to and from every peer in one RCCL group of
+//                            ncclSend / ncclRecv, fixed size because the host does not know the counts.
 //   7. comm_unpack_kernel    incoming walkers into the kill slots, then all weights <- 1
+// Ordering without extra barriers: the all-gather of event e completes on a rank only after every rank has
+// contributed, and a rank contributes in stream order AFTER its unpack of event e - 1 -- so when a pack kernel of
+// event e writes into a peer's window, that peer is done reading the slots of event e - 1.  Flags carry the event
+// number (monotonic), a waiting kernel gives up after ~10 s and raises the sticky error scal[6] (AFQ_ECOMM at the next
+// host synchronisation) instead of hanging the device.
 // More pairs between two ranks than `cap` slots raise the sticky flag scal[3] (AFQ_EOVERFLOW at the next
-// afq_estimates_get); scal[4] keeps the largest run seen so that the caller can size `cap`.
+// afq_estimates_get); scal[4] keeps the largest run seen.  The window transport sizes cap = nw (a rank owns nw
+// walkers: it can neither send nor receive more), so it cannot overflow.
 //
-// Two transports: RCCL (one process per GPU; the library resolves librccl at afq_comm_init, so single-GPU users
-// never load it) and an in-process communicator of several handles (afq_comm_init_local: one host thread driving
-// several GPUs, or several handles on one GPU -- which is also how the multi-rank path is tested on a 1-GPU box):
-// the same kernels, device-to-device copies ordered by events instead of RCCL calls.
+// Three communicators over the same kernels:
+//   RCCL   (afq_comm_init: one process per GPU) -- ncclAllGather / ncclAllReduce for the two collectives, windows
+//          (or ncclSend / ncclRecv) for the walkers; the library resolves librccl at afq_comm_init, so single-GPU
+//          users never load it;
+//   IPC    (afq_comm_init_ipc: one process per GPU, no RCCL) -- everything through the mapped windows; the caller
+//          lends an all-gather of a few hundred bytes (its MPI / torch.distributed communicator) as bootstrap;
+//   LOCAL  (afq_comm_init_local: one host thread driving several handles, on several GPUs or on one -- how the
+//          multi-rank path is tested on a 1-GPU box) -- the windows are plain device pointers of the same process.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -35,6 +51,9 @@
 #include "block_scan.h"
 
 namespace {
+
+constexpr int MAX_RANKS = 16;
+constexpr unsigned long long WAIT_TICKS = 1000000000ull;     // wall_clock64 runs at 100 MHz: 10 s
 
 struct RcclApi {
     void *lib = nullptr;
@@ -72,21 +91,70 @@ RcclApi *rccl_api() {
     return &api;
 }
 
+enum CommMode { COMM_LOCAL = 0, COMM_RCCL = 1, COMM_IPC = 2 };
+
+// One rank's window: memory every peer maps and writes into.  All offsets in bytes from the window base.
+//   flag_x[R]  walker exchange: flag_x[s] = number of the last event whose slots from rank s have landed
+//   flag_g[R]  weights all-gather, flag_e[R]  estimator all-gather (window collectives: IPC / LOCAL communicators)
+//   gw[2][R][nw + 1], est[2][R][est_n]  double-buffered by event parity: a rank can run at most one event ahead of a
+//   peer (its next plan / sum kernel waits for that peer's flag of the next event), never two
+//   rbuf[R][cap][slot]  slot (s, k) = k-th walker rank s sends here in the current event
+struct WinLayout {
+    long off_flag_x, off_flag_g, off_flag_e, off_gw, off_est, off_rbuf, bytes;
+    long gw_n, est_n;          // doubles per rank in gw (nw + 1) and est
+    int R, cap;
+    long slot;                 // cplx elements per slot
+    __host__ __device__ unsigned long long *flag_x(void *w) const { return (unsigned long long *)((char *)w + off_flag_x); }
+    __host__ __device__ unsigned long long *flag_g(void *w) const { return (unsigned long long *)((char *)w + off_flag_g); }
+    __host__ __device__ unsigned long long *flag_e(void *w) const { return (unsigned long long *)((char *)w + off_flag_e); }
+    __host__ __device__ double *gw(void *w, int par) const { return (double *)((char *)w + off_gw) + (long)par * R * gw_n; }
+    __host__ __device__ double *est(void *w, int par) const { return (double *)((char *)w + off_est) + (long)par * R * est_n; }
+    __host__ __device__ cplx *rbuf(void *w) const { return (cplx *)((char *)w + off_rbuf); }
+};
+
+WinLayout make_layout(int R, int nw, int cap, long slot, long est_n) {
+    WinLayout L;
+    L.R = R; L.cap = cap; L.slot = slot; L.gw_n = nw + 1; L.est_n = est_n;
+    long o = 0;
+    auto take = [&](long bytes) { const long at = o; o += (bytes + 255) & ~255L; return at; };
+    L.off_flag_x = take(8L * R); L.off_flag_g = take(8L * R); L.off_flag_e = take(8L * R);
+    L.off_gw = take(8L * 2 * R * L.gw_n);
+    L.off_est = take(8L * 2 * R * est_n);
+    L.off_rbuf = take(16L * R * cap * slot);
+    L.bytes = o;
+    return L;
+}
+
+struct PeerWindows { void *base[MAX_RANKS]; };      // every rank's window as this rank addresses it (own included)
+
 struct afq_comm_state {
     int rank = 0, nranks = 1;
-    bool local = false;                     // in-process communicator (afq_comm_init_local)
-    std::vector<afq_handle *> peers;        // local: the handle of every rank
-    ncclComm_t nccl = nullptr;
+    CommMode mode = COMM_LOCAL;
+    std::vector<afq_handle *> peers;        // LOCAL: the handle of every rank
+    ncclComm_t nccl = nullptr;              // RCCL
+    afq_allgather_fn boot = nullptr;        // IPC: the caller's all-gather (bootstrap of the window handles)
+    void *boot_user = nullptr;
+    bool window = true;                     // walkers travel by peer writes into mapped windows (else ncclSend / ncclRecv)
+    bool win_collectives = true;            // the two collectives go through the windows as well (IPC, LOCAL)
     int cap = 0;                            // walker slots per peer and event (0: default on first use)
     // sized by ensure_buffers
     int nw = 0, nbp = 0;
     size_t slot = 0;                        // cplx elements per slot
-    double *sendw = nullptr, *gw = nullptr;
+    double *sendw = nullptr, *gw = nullptr; // RCCL all-gather staging / result
     int *pix = nullptr;                     // [nranks * nw] global parent_ix
     int *lists = nullptr;                   // nsend[R] | nrecv[R] | send_idx[R][cap] | recv_idx[R][cap]
-    cplx *sbuf = nullptr, *rbuf = nullptr;  // [R][cap][slot]
+    cplx *sbuf = nullptr, *rbuf = nullptr;  // SENDRECV transport: [R][cap][slot]
+    // window transport
+    void *win = nullptr;
+    int win_kind = 0;                       // 1 uncached, 2 fine-grained, 3 plain device memory
+    WinLayout wl;
+    PeerWindows pw;
+    bool peer_opened[MAX_RANKS] = {false};
+    int *tickets = nullptr;                 // [R] pack blocks done per peer (device)
+    unsigned long long seq_x = 0, seq_g = 0, seq_e = 0;     // events so far (identical on every rank)
     hipEvent_t ev = nullptr, ev2 = nullptr;
     long events = 0;
+    unsigned long long sendrecv_bytes = 0;  // SENDRECV transport: bytes posted so far (empty slots included)
 };
 
 afq_comm_state *cs_of(afq_handle *h) { return (afq_comm_state *)h->comm; }
@@ -99,6 +167,20 @@ afq_comm_state *cs_of(afq_handle *h) { return (afq_comm_state *)h->comm; }
             return AFQ_EHIP;                                                                     \
         }                                                                                        \
     } while (0)
+
+// ---- flags between GPUs ---------------------------------------------------------------------------------------
+__device__ inline void flag_release(unsigned long long *flag, unsigned long long v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// waits until *flag >= v; false after WAIT_TICKS (the peer never wrote: error, not a hang)
+__device__ inline bool flag_wait(const unsigned long long *flag, unsigned long long v) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > WAIT_TICKS) return false;
+    }
+    return true;
+}
 
 // ---- slot layout: the walker state that has to travel, in 16-byte units ------------------------------------
 // phi | [ghalf] | [phi_old | hist] | [G] | ot ehyb phase eloc | (unscaled, detR) (log_detR, 0) | [ovlp_new] | [bp_ph | (bp_cos, bp_n)]
@@ -120,8 +202,15 @@ struct PackArgs {
     int cap, nranks, rank;
     const int *count;        // nsend / nrecv [R]
     const int *idx;          // send_idx / recv_idx [R][cap]
-    cplx *buf;               // sbuf / rbuf [R][cap][slot]
+    cplx *buf;               // SENDRECV: sbuf / rbuf [R][cap][slot]; WINDOW unpack: this rank's rbuf
     long slot;               // elements per slot (>= L.size(), fixed for the buffers)
+    // WINDOW transport
+    int window;
+    PeerWindows pw;          // pack: where peer p's window is mapped
+    WinLayout wl;
+    unsigned long long seq;  // number of this event
+    int *tickets;            // pack: blocks done per peer
+    double *scal;            // scal[6]: sticky communication error; scal[7], scal[8]: walkers / bytes sent
     cplx *phi, *ot, *ehyb, *phase, *eloc, *ghalf, *ovlp_new, *phi_old, *bp_hist, *bp_ph, *G;
     double *unscaled, *detR, *log_detR, *bp_cos;
     int *bp_n;
@@ -132,7 +221,20 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
     const int sl = blockIdx.y, peer = blockIdx.z;
     if (peer == a.rank || sl >= a.count[peer]) return;
     const int w = a.idx[peer * a.cap + sl];
-    cplx *s = a.buf + ((long)peer * a.cap + sl) * a.slot;
+    cplx *s;
+    if (a.window) {
+        // pack: straight into the window of the destination rank, row of this rank; unpack: this rank's window, row of the source
+        if (PACK) s = a.wl.rbuf(a.pw.base[peer]) + ((long)a.rank * a.cap + sl) * a.slot;
+        else s = a.buf + ((long)peer * a.cap + sl) * a.slot;
+        if (!PACK) {
+            __shared__ int ok;
+            if (threadIdx.x == 0) ok = flag_wait(a.wl.flag_x(a.pw.base[a.rank]) + peer, a.seq) ? 1 : 0;
+            __syncthreads();
+            if (!ok) { if (threadIdx.x == 0 && blockIdx.x == 0) a.scal[6] = 1.0; return; }
+        }
+    } else {
+        s = a.buf + ((long)peer * a.cap + sl) * a.slot;
+    }
     const long per = a.L.per;
     const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
     auto mv = [&](cplx *field, long n, long off) {
@@ -163,12 +265,42 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
             if (a.L.with_bp) { a.bp_ph[w] = s[o++]; a.bp_cos[w] = s[o].x; a.bp_n[w] = (int)s[o].y; ++o; }
         }
     }
+    if (PACK && a.window) {
+        // every block of this peer's slots takes a ticket once its writes are out; the last one raises the peer's flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (blockIdx.x == 0) {      // traffic statistics: walkers / bytes this rank has written into peer windows
+                atomicAdd(a.scal + 7, 1.0);
+                atomicAdd(a.scal + 8, (double)(a.L.size() * (long)sizeof(cplx)));
+            }
+            const int total = (int)gridDim.x * a.count[peer];
+            if (atomicAdd(a.tickets + peer, 1) == total - 1) {
+                a.tickets[peer] = 0;
+                __threadfence_system();
+                flag_release(a.wl.flag_x(a.pw.base[peer]) + a.rank, a.seq);
+            }
+        }
+    }
 }
 
-__global__ void comm_prep_kernel(const double *weight, int nw, double r, double *sendw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nw) sendw[i] = fabs(weight[i]);                     // handler.py:230
-    if (i == nw) sendw[nw] = r;                                   // handler.py:276 (rank 0's is the one used)
+// |weights| and rank 0's uniform: into the staging buffer of the RCCL all-gather, or (window collectives) straight into
+// row `rank` of every peer's gw of this event's parity, one block per peer, followed by that peer's flag
+__global__ __launch_bounds__(256) void comm_prep_kernel(const double *weight, int nw, double r, double *sendw,
+                                                        int window, PeerWindows pw, WinLayout wl, int rank,
+                                                        unsigned long long seq) {
+    if (!window) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < nw) sendw[i] = fabs(weight[i]);                   // handler.py:230
+        if (i == nw) sendw[nw] = r;                                 // handler.py:276 (rank 0's is the one used)
+        return;
+    }
+    const int peer = blockIdx.x;
+    double *dst = wl.gw(pw.base[peer], (int)(seq & 1)) + (long)rank * wl.gw_n;
+    for (int i = threadIdx.x; i <= nw; i += blockDim.x) dst[i] = i < nw ? fabs(weight[i]) : r;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) flag_release(wl.flag_g(pw.base[peer]) + rank, seq);
 }
 
 // walkers/handler.py:225-301 for the global population, identically on every rank.  One 256-thread work-group;
@@ -184,6 +316,8 @@ struct PlanArgs {
     int *pairs;              // local (src, dst) pairs
     int *lists;              // nsend[R] | nrecv[R] | send_idx[R][cap] | recv_idx[R][cap]
     double *scal;
+    const unsigned long long *gflag;     // window all-gather: flag_g[R] of this rank's window (else null)
+    unsigned long long seq;
 };
 
 __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
@@ -199,6 +333,18 @@ __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
     int *nsend = a.lists, *nrecv = a.lists + R, *send_idx = a.lists + 2 * R, *recv_idx = send_idx + R * a.cap;
     if (tid < R) { nsend[tid] = 0; nrecv[tid] = 0; }
     if (tid == 0) { s_nloc = 0; s_maxrun = 0; s_over = 0; }
+    if (a.gflag) {
+        // window all-gather: row s of gw is complete once rank s has raised its flag for this event
+        __shared__ int s_ok;
+        if (tid == 0) s_ok = 1;
+        __syncthreads();
+        if (tid < R && !flag_wait(a.gflag + tid, a.seq)) s_ok = 0;
+        __syncthreads();
+        if (!s_ok) {          // a peer never arrived: no clones, no transfers, sticky error for the next host synchronisation
+            if (tid == 0) { a.scal[1] = 0.0; a.scal[6] = 1.0; }
+            return;
+        }
+    }
     const int per = (N + 255) / 256;
     const int i0 = tid * per < N ? tid * per : N, i1 = (tid + 1) * per < N ? (tid + 1) * per : N;
     auto gweight = [&](int g) { return a.gw[(g / nw) * (nw + 1) + g % nw]; };
@@ -276,12 +422,26 @@ __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
     }
 }
 
-int default_cap(int nw) { return std::max(8, (nw + 7) / 8); }
+// the window transport moves only live slots, so its capacity is the bound that cannot overflow: a rank owns nw walkers,
+// it can neither send nor receive more in one event.  The fixed-size ncclSend / ncclRecv transport pays for every slot
+// of the capacity on every link, so it starts at the same safe bound and Walkers.tune_exchange_capacity shrinks it once
+// there is history.
+int default_cap(int nw) { return std::max(1, nw); }
+
+void close_peer_windows(afq_comm_state *c) {
+    for (int p = 0; p < MAX_RANKS; ++p) {
+        if (c->peer_opened[p] && c->pw.base[p]) hipIpcCloseMemHandle(c->pw.base[p]);
+        c->peer_opened[p] = false; c->pw.base[p] = nullptr;
+    }
+}
 
 void free_buffers(afq_comm_state *c) {
-    for (void *p : {(void *)c->sendw, (void *)c->gw, (void *)c->pix, (void *)c->lists, (void *)c->sbuf, (void *)c->rbuf})
+    close_peer_windows(c);
+    for (void *p : {(void *)c->sendw, (void *)c->gw, (void *)c->pix, (void *)c->lists, (void *)c->sbuf, (void *)c->rbuf,
+                    (void *)c->win, (void *)c->tickets})
         if (p) hipFree(p);
-    c->sendw = c->gw = nullptr; c->pix = c->lists = nullptr; c->sbuf = c->rbuf = nullptr;
+    c->sendw = c->gw = nullptr; c->pix = c->lists = c->tickets = nullptr; c->sbuf = c->rbuf = nullptr;
+    c->win = nullptr;
     c->nw = 0;
 }
 
@@ -292,11 +452,112 @@ SlotLayout max_layout(afq_handle *h) {
     return L;
 }
 
+bool uses_windows(const afq_comm_state *c) { return c->window || c->win_collectives; }
+
+// Window memory must be coherent between GPUs while kernels run: uncached (what RCCL itself allocates for its peer
+// buffers on gfx942 / gfx950), else fine-grained, else plain device memory (the system-scope release / acquire pairs
+// around every hand-over still apply; afq_comm_probe checks the outcome either way).
+int alloc_window(afq_handle *h, afq_comm_state *c, size_t bytes) {
+    void *p = nullptr;
+    c->win_kind = 0;
+#ifdef hipDeviceMallocUncached
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess) c->win_kind = 1;
+#endif
+    if (!c->win_kind) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess) c->win_kind = 2;
+    }
+    if (!c->win_kind) {
+        (void)hipGetLastError();
+        AFQ_HIP(h, hipMalloc(&p, bytes));
+        c->win_kind = 3;
+    }
+    AFQ_HIP(h, hipMemset(p, 0, bytes));
+    c->win = p;
+    return AFQ_OK;
+}
+
+struct WinBlob { int ok; int kind; unsigned long long bytes; hipIpcMemHandle_t handle; };
+
+// all-gather of `bytes` per rank on the host, over whatever the communicator has (collective; every stream idle)
+int host_allgather(afq_handle *h, const void *send, void *recv, int bytes) {
+    afq_comm_state *c = cs_of(h);
+    if (c->mode == COMM_IPC) {
+        if (c->boot(send, recv, bytes, c->boot_user) != 0) AFQ_FAIL(h, AFQ_ECOMM, "the caller's bootstrap all-gather failed");
+        return AFQ_OK;
+    }
+    RcclApi *api = rccl_api();
+    if (!api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
+    char *d = nullptr;
+    AFQ_HIP(h, hipMalloc(&d, (size_t)bytes * (c->nranks + 1)));
+    hipError_t e = hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, h->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = api->AllGather(d, d + bytes, (size_t)bytes, ncclChar, c->nccl, h->stream);
+    if (e == hipSuccess && r == ncclSuccess)
+        e = hipMemcpyAsync(recv, d + bytes, (size_t)bytes * c->nranks, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (r != ncclSuccess) { h->err = std::string("ncclAllGather(bootstrap): ") + api->GetErrorString(r); return AFQ_EHIP; }
+    AFQ_HIP(h, e);
+    return AFQ_OK;
+}
+
+// (re)allocates this rank's window and maps every peer's.  Collective for the RCCL / IPC communicators (the handles
+// travel through host_allgather, which also is the barrier behind which the old windows may go); the LOCAL group call
+// fills the tables itself.  A rank that cannot export or map a window makes EVERY rank fall back (RCCL: fixed-size
+// ncclSend / ncclRecv) or fail (IPC) -- decided from the gathered blobs, identically everywhere.
+int exchange_windows(afq_handle *h) {
+    afq_comm_state *c = cs_of(h);
+    const int R = c->nranks;
+    int rc = alloc_window(h, c, (size_t)c->wl.bytes);
+    WinBlob mine;
+    memset(&mine, 0, sizeof(mine));
+    mine.ok = rc == AFQ_OK; mine.kind = c->win_kind; mine.bytes = (unsigned long long)c->wl.bytes;
+    if (mine.ok && c->mode != COMM_LOCAL && R > 1 && hipIpcGetMemHandle(&mine.handle, c->win) != hipSuccess) {
+        (void)hipGetLastError();
+        // uncached / fine-grained memory that cannot be exported: try plain device memory once
+        hipFree(c->win); c->win = nullptr;
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)c->wl.bytes) == hipSuccess && hipMemset(p, 0, (size_t)c->wl.bytes) == hipSuccess &&
+            hipIpcGetMemHandle(&mine.handle, p) == hipSuccess) { c->win = p; c->win_kind = 3; mine.kind = 3; }
+        else { (void)hipGetLastError(); if (p) hipFree(p); mine.ok = 0; }
+    }
+    for (int p = 0; p < MAX_RANKS; ++p) { c->pw.base[p] = nullptr; c->peer_opened[p] = false; }
+    c->pw.base[c->rank] = c->win;
+    if (c->mode == COMM_LOCAL || R == 1) return rc;
+    std::vector<WinBlob> all(R);
+    if ((rc = host_allgather(h, &mine, all.data(), (int)sizeof(WinBlob)))) return rc;
+    bool ok = true;
+    for (int p = 0; p < R; ++p) ok = ok && all[p].ok && all[p].bytes == mine.bytes;
+    int mapped = 1;
+    if (ok) {
+        for (int p = 0; p < R && mapped; ++p) {
+            if (p == c->rank) continue;
+            void *q = nullptr;
+            if (hipIpcOpenMemHandle(&q, all[p].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); mapped = 0; break; }
+            c->pw.base[p] = q; c->peer_opened[p] = true;
+        }
+    }
+    // second round: did every rank map every window?  (also the barrier after which peers may write here)
+    std::vector<int> flags(R);
+    const int my = ok && mapped;
+    if ((rc = host_allgather(h, &my, flags.data(), (int)sizeof(int)))) return rc;
+    for (int p = 0; p < R; ++p) ok = ok && flags[p];
+    if (ok) return AFQ_OK;
+    close_peer_windows(c);
+    c->pw.base[c->rank] = c->win;
+    if (c->mode == COMM_RCCL) { c->window = false; return AFQ_OK; }     // every rank takes the ncclSend / ncclRecv transport
+    AFQ_FAIL(h, AFQ_EUNSUPPORTED, "peer windows could not be exported / mapped on every rank (hipIpcGetMemHandle / hipIpcOpenMemHandle)");
+}
+
+long est_window_doubles(afq_handle *h) { return 2L * AFQ_EST_COUNT_ + 2L * h->M * h->M; }
+
+// buffers of the current (nw, nbp, slot, cap); collective when windows have to be (re)made
 int ensure_buffers(afq_handle *h) {
     afq_comm_state *c = cs_of(h);
     if (c->cap <= 0) c->cap = default_cap(h->nw);
     const size_t slot = (size_t)max_layout(h).size();
-    if (c->nw == h->nw && c->nbp == h->nbp && c->slot == slot && c->sbuf) return AFQ_OK;
+    if (c->nw == h->nw && c->nbp == h->nbp && c->slot == slot && c->lists) return AFQ_OK;
     AFQ_HIP(h, hipStreamSynchronize(h->stream));
     free_buffers(c);
     const size_t R = c->nranks, nw = h->nw;
@@ -304,10 +565,19 @@ int ensure_buffers(afq_handle *h) {
     AFQ_HIP(h, hipMalloc(&c->gw, sizeof(double) * R * (nw + 1)));
     AFQ_HIP(h, hipMalloc(&c->pix, sizeof(int) * R * nw));
     AFQ_HIP(h, hipMalloc(&c->lists, sizeof(int) * (2 * R + 2 * R * c->cap)));
-    AFQ_HIP(h, hipMalloc(&c->sbuf, sizeof(cplx) * R * c->cap * slot));
-    AFQ_HIP(h, hipMalloc(&c->rbuf, sizeof(cplx) * R * c->cap * slot));
     AFQ_HIP(h, hipMemset(c->lists, 0, sizeof(int) * (2 * R + 2 * R * c->cap)));
+    AFQ_HIP(h, hipMalloc(&c->tickets, sizeof(int) * R));
+    AFQ_HIP(h, hipMemset(c->tickets, 0, sizeof(int) * R));
     c->nw = h->nw; c->nbp = h->nbp; c->slot = slot;
+    if (uses_windows(c)) {
+        c->wl = make_layout((int)R, h->nw, c->window ? c->cap : 0, (long)slot, est_window_doubles(h));
+        const int rc = exchange_windows(h);           // may switch an RCCL communicator to the ncclSend / ncclRecv transport
+        if (rc) { c->nw = 0; return rc; }
+    }
+    if (!c->window && R > 1) {
+        AFQ_HIP(h, hipMalloc(&c->sbuf, sizeof(cplx) * R * c->cap * slot));
+        AFQ_HIP(h, hipMalloc(&c->rbuf, sizeof(cplx) * R * c->cap * slot));
+    }
     return AFQ_OK;
 }
 
@@ -316,7 +586,13 @@ int stage_prep(afq_handle *h, double r) {
     afq_comm_state *c = cs_of(h);
     int rc = ensure_buffers(h);
     if (rc) return rc;
-    AFQ_LAUNCH(h, comm_prep_kernel, dim3((h->nw + 1 + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw, r, c->sendw);
+    ++c->seq_g; ++c->seq_x;
+    if (c->win_collectives)
+        AFQ_LAUNCH(h, comm_prep_kernel, dim3(c->nranks), dim3(256), 0, h->stream, h->weight, h->nw, r, c->sendw, 1, c->pw, c->wl,
+                   c->rank, c->seq_g);
+    else
+        AFQ_LAUNCH(h, comm_prep_kernel, dim3((h->nw + 1 + 255) / 256), dim3(256), 0, h->stream, h->weight, h->nw, r, c->sendw, 0,
+                   c->pw, c->wl, c->rank, c->seq_g);
     AFQ_POST(h);
     return AFQ_OK;
 }
@@ -327,7 +603,10 @@ void fill_pack(afq_handle *h, PackArgs &p, bool with_greens, bool send) {
     p.cap = c->cap; p.nranks = c->nranks; p.rank = c->rank;
     p.count = c->lists + (send ? 0 : c->nranks);
     p.idx = c->lists + 2 * c->nranks + (send ? 0 : c->nranks * c->cap);
-    p.buf = send ? c->sbuf : c->rbuf; p.slot = (long)c->slot;
+    p.slot = (long)c->slot;
+    p.window = c->window ? 1 : 0; p.pw = c->pw; p.wl = c->wl; p.seq = c->seq_x; p.tickets = c->tickets;
+    p.scal = h->scal;
+    p.buf = c->window ? (send ? nullptr : c->wl.rbuf(c->win)) : (send ? c->sbuf : c->rbuf);
     p.phi = h->phi; p.ot = h->ot; p.ehyb = h->ehyb; p.phase = h->phase; p.eloc = h->eloc; p.ghalf = h->ghalf;
     p.ovlp_new = h->ovlp_new; p.phi_old = h->phi_old; p.bp_hist = h->bp_hist; p.bp_ph = h->bp_ph; p.G = h->G;
     p.unscaled = h->unscaled; p.detR = h->detR; p.log_detR = h->log_detR; p.bp_cos = h->bp_cos; p.bp_n = h->bp_n;
@@ -341,7 +620,9 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)comb_plan_global_kernel, lds, lds_set));
     PlanArgs a;
-    a.gw = c->gw; a.R = c->nranks; a.nw = h->nw; a.rank = c->rank; a.cap = c->cap; a.target = target;
+    a.gw = c->win_collectives ? c->wl.gw(c->win, (int)(c->seq_g & 1)) : c->gw;
+    a.gflag = c->win_collectives ? c->wl.flag_g(c->win) : nullptr; a.seq = c->seq_g;
+    a.R = c->nranks; a.nw = h->nw; a.rank = c->rank; a.cap = c->cap; a.target = target;
     a.weight = h->weight; a.unscaled = h->unscaled; a.pix_global = c->pix; a.parent_ix = h->parent_ix;
     a.pairs = (int *)h->pack_tmp; a.lists = c->lists; a.scal = h->scal;
     AFQ_LAUNCH(h, comb_plan_global_kernel, dim3(1), dim3(256), lds, h->stream, a);
@@ -374,12 +655,144 @@ int check_group(afq_handle **hs, int n, std::string *err) {
     if (!hs || n < 1) return AFQ_EINVAL;
     for (int i = 0; i < n; ++i) {
         afq_comm_state *c = hs[i] ? cs_of(hs[i]) : nullptr;
-        if (!c || !c->local || c->nranks != n || c->rank != i || c->peers.size() != (size_t)n || c->peers[0] != hs[0]) {
+        if (!c || c->mode != COMM_LOCAL || c->nranks != n || c->rank != i || c->peers.size() != (size_t)n || c->peers[0] != hs[0]) {
             if (err) *err = "the handles are not the ranks 0..n-1 of one afq_comm_init_local communicator";
             return AFQ_ESTATE;
         }
         if (hs[i]->nw != hs[0]->nw || !hs[i]->nw) { if (err) *err = "every rank needs the same number of walkers"; return AFQ_ESTATE; }
     }
+    return AFQ_OK;
+}
+
+// LOCAL communicator: (re)make the buffers of every rank and point every rank at every window (same process: the
+// windows are ordinary device pointers; ranks on different GPUs need peer access)
+int ensure_group(afq_handle **hs, int n) {
+    bool fresh = false;
+    for (int i = 0; i < n; ++i) {
+        afq_comm_state *c = cs_of(hs[i]);
+        hipSetDevice(hs[i]->device);
+        const bool had = c->lists && c->nw == hs[i]->nw && c->nbp == hs[i]->nbp && c->slot == (size_t)max_layout(hs[i]).size();
+        const int rc = ensure_buffers(hs[i]);
+        if (rc) return rc;
+        fresh = fresh || !had;
+    }
+    if (!fresh) return AFQ_OK;
+    for (int i = 0; i < n; ++i) {
+        afq_comm_state *c = cs_of(hs[i]);
+        hipSetDevice(hs[i]->device);
+        for (int j = 0; j < n; ++j) {
+            if (cs_of(hs[j])->cap != c->cap || cs_of(hs[j])->slot != c->slot) AFQ_FAIL(hs[i], AFQ_ESTATE, "ranks disagree on the slot layout");
+            c->pw.base[j] = cs_of(hs[j])->win;
+            if (hs[j]->device != hs[i]->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(hs[j]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) AFQ_HIP(hs[i], e);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    return AFQ_OK;
+}
+
+// ---- estimator reduction through the windows (IPC / LOCAL): every rank writes its vector into row `rank` of every
+// peer's est buffer and raises the peer's flag; every rank then adds the R rows in rank order -- the same additions in
+// the same order everywhere, so all ranks hold bit-identical sums
+__global__ __launch_bounds__(256) void est_put_kernel(const double *src, long n, PeerWindows pw, WinLayout wl, int rank,
+                                                      unsigned long long seq) {
+    const int peer = blockIdx.x;
+    double *dst = wl.est(pw.base[peer], (int)(seq & 1)) + (long)rank * wl.est_n;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) flag_release(wl.flag_e(pw.base[peer]) + rank, seq);
+}
+
+__global__ __launch_bounds__(256) void est_sum_kernel(double *dst, long n, void *win, WinLayout wl, unsigned long long seq,
+                                                      double *scal) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    if (threadIdx.x < wl.R && !flag_wait(wl.flag_e(win) + threadIdx.x, seq)) s_ok = 0;
+    __syncthreads();
+    if (!s_ok) { if (threadIdx.x == 0 && blockIdx.x == 0) scal[6] = 1.0; return; }
+    const double *rows = wl.est(win, (int)(seq & 1));
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int s = 0; s < wl.R; ++s) acc += rows[(long)s * wl.est_n + i];
+        dst[i] = acc;
+    }
+}
+
+// sum over ranks of the device vector v[0..n) in place, window collectives (chunks of the window's est rows)
+int window_allreduce(afq_handle *h, double *v, long n) {
+    afq_comm_state *c = cs_of(h);
+    for (long o = 0; o < n; o += c->wl.est_n) {
+        const long m = std::min(c->wl.est_n, n - o);
+        ++c->seq_e;
+        AFQ_LAUNCH(h, est_put_kernel, dim3(c->nranks), dim3(256), 0, h->stream, v + o, m, c->pw, c->wl, c->rank, c->seq_e);
+        AFQ_POST(h);
+        const unsigned nblk = (unsigned)std::min<long>(64, (m + 255) / 256);
+        AFQ_LAUNCH(h, est_sum_kernel, dim3(nblk), dim3(256), 0, h->stream, v + o, m, c->win, c->wl, c->seq_e, h->scal);
+        AFQ_POST(h);
+    }
+    return AFQ_OK;
+}
+
+// ---- known-answer probe (afq_comm_probe) ----------------------------------------------------------------------
+__device__ inline double probe_value(int src, int dst, long i) { return 1000.0 * src + 10.0 * dst + 0.001 * (double)(i % 997); }
+
+__global__ __launch_bounds__(256) void probe_fill_kernel(cplx *sbuf, long slot, long cap, int rank, int R) {
+    const int peer = blockIdx.x;
+    cplx *s = sbuf + (long)peer * cap * slot;
+    for (long i = threadIdx.x; i < slot; i += blockDim.x) s[i] = cmake(probe_value(rank, peer, i), -probe_value(rank, peer, i));
+}
+
+__global__ __launch_bounds__(256) void probe_put_kernel(long slot, long cap, PeerWindows pw, WinLayout wl, int rank,
+                                                        unsigned long long seq) {
+    const int peer = blockIdx.x;
+    if (peer == rank) return;
+    cplx *s = wl.rbuf(pw.base[peer]) + (long)rank * cap * slot;
+    for (long i = threadIdx.x; i < slot; i += blockDim.x) s[i] = cmake(probe_value(rank, peer, i), -probe_value(rank, peer, i));
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) flag_release(wl.flag_x(pw.base[peer]) + rank, seq);
+}
+
+// mismatches of slot 0 of every peer row of rbuf against the pattern -> bad[0]; bad[1] = 1 if a flag never came
+__global__ __launch_bounds__(256) void probe_check_kernel(const cplx *rbuf, long slot, long cap, int rank, int R,
+                                                          const unsigned long long *flags, unsigned long long seq,
+                                                          unsigned long long *bad) {
+    const int peer = blockIdx.x;
+    if (peer == rank) return;
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = flags ? (flag_wait(flags + peer, seq) ? 1 : 0) : 1;
+    __syncthreads();
+    if (!ok) { if (threadIdx.x == 0) atomicAdd(bad + 1, 1ull); return; }
+    const cplx *s = rbuf + (long)peer * cap * slot;
+    unsigned long long n = 0;
+    for (long i = threadIdx.x; i < slot; i += blockDim.x) {
+        const double v = probe_value(peer, rank, i);
+        if (s[i].x != v || s[i].y != -v) ++n;
+    }
+    if (n) atomicAdd(bad, n);
+}
+
+// the rows of a window all-gather are complete once every rank's flag has arrived; bad[1] counts flags that never came
+__global__ void probe_wait_kernel(const unsigned long long *flags, int R, unsigned long long seq, unsigned long long *bad) {
+    if ((int)threadIdx.x < R && !flag_wait(flags + threadIdx.x, seq)) atomicAdd(bad + 1, 1ull);
+}
+
+int sendrecv_slots(afq_handle *h, RcclApi *api) {
+    afq_comm_state *c = cs_of(h);
+    const size_t bytes = sizeof(cplx) * (size_t)c->cap * c->slot;
+    afq_note_launch(h, "ncclSend/Recv(walker slots)");
+    AFQ_NCCL(h, api, api->GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        if (p == c->rank) continue;
+        AFQ_NCCL(h, api, api->Send(c->sbuf + (size_t)p * c->cap * c->slot, bytes, ncclChar, p, c->nccl, h->stream));
+        AFQ_NCCL(h, api, api->Recv(c->rbuf + (size_t)p * c->cap * c->slot, bytes, ncclChar, p, c->nccl, h->stream));
+    }
+    AFQ_NCCL(h, api, api->GroupEnd());
+    c->sendrecv_bytes += (unsigned long long)bytes * (c->nranks - 1);
     return AFQ_OK;
 }
 
@@ -398,34 +811,28 @@ void k_comm_destroy(afq_handle *h) {
     h->comm = nullptr;
 }
 
-// one event on an RCCL communicator (stages 1-7 above)
+// one event on an RCCL or IPC communicator (stages 1-7 above)
 int k_comm_popcontrol(afq_handle *h, double r, double target, bool with_greens) {
     h->scal_cache_valid = false;
     afq_comm_state *c = cs_of(h);
     if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
-    if (c->local) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_popcontrol_comb_local for all ranks at once");
-    RcclApi *api = rccl_api();
-    if (!api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
+    if (c->mode == COMM_LOCAL) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_popcontrol_comb_local for all ranks at once");
+    RcclApi *api = c->mode == COMM_RCCL ? rccl_api() : nullptr;
+    if (c->mode == COMM_RCCL && !api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
     int rc = stage_prep(h, r);
     if (rc) return rc;
-    afq_note_launch(h, "ncclAllGather(weights)");
-    AFQ_NCCL(h, api, api->AllGather(c->sendw, c->gw, (size_t)h->nw + 1, ncclDouble, c->nccl, h->stream));
-    if ((rc = stage_plan_pack(h, target, with_greens))) return rc;
-    if (c->nranks > 1) {
-        const size_t bytes = sizeof(cplx) * (size_t)c->cap * c->slot;
-        afq_note_launch(h, "ncclSend/Recv(walker slots)");
-        AFQ_NCCL(h, api, api->GroupStart());
-        for (int p = 0; p < c->nranks; ++p) {
-            if (p == c->rank) continue;
-            AFQ_NCCL(h, api, api->Send(c->sbuf + (size_t)p * c->cap * c->slot, bytes, ncclChar, p, c->nccl, h->stream));
-            AFQ_NCCL(h, api, api->Recv(c->rbuf + (size_t)p * c->cap * c->slot, bytes, ncclChar, p, c->nccl, h->stream));
-        }
-        AFQ_NCCL(h, api, api->GroupEnd());
+    if (!c->win_collectives) {
+        afq_note_launch(h, "ncclAllGather(weights)");
+        AFQ_NCCL(h, api, api->AllGather(c->sendw, c->gw, (size_t)h->nw + 1, ncclDouble, c->nccl, h->stream));
     }
+    if ((rc = stage_plan_pack(h, target, with_greens))) return rc;
+    if (c->nranks > 1 && !c->window && (rc = sendrecv_slots(h, api))) return rc;
     return stage_unpack(h, with_greens);
 }
 
 extern "C" {
+
+int afq_comm_available(void) { return rccl_api() ? 1 : 0; }
 
 int afq_comm_unique_id(void *id_out) {
     if (!id_out) return AFQ_EINVAL;
@@ -438,14 +845,24 @@ int afq_comm_unique_id(void *id_out) {
     return AFQ_OK;
 }
 
+static int comm_attach(afq_handle *h, afq_comm_state *c) {
+    h->comm = c;
+    if (h->nw) {    // walker.total_weight starts as the size of the whole population (walkers/handler.py:164)
+        const double tw0 = (double)h->nw * c->nranks;
+        AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
+    }
+    return AFQ_OK;
+}
+
 int afq_comm_init(afq_handle *h, const void *unique_id, int rank, int nranks) {
-    if (!h || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return AFQ_EINVAL;
+    if (!h || !unique_id || nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return AFQ_EINVAL;
     hipSetDevice(h->device);
     RcclApi *api = rccl_api();
     if (!api) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "librccl could not be loaded (dlopen librccl.so.1)");
     k_comm_destroy(h);
     afq_comm_state *c = new afq_comm_state();
-    c->rank = rank; c->nranks = nranks;
+    c->rank = rank; c->nranks = nranks; c->mode = COMM_RCCL;
+    c->window = true; c->win_collectives = false;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclResult_t r = api->CommInitRank(&c->nccl, nranks, id, rank);
@@ -454,31 +871,35 @@ int afq_comm_init(afq_handle *h, const void *unique_id, int rank, int nranks) {
         delete c;
         return AFQ_EHIP;
     }
-    h->comm = c;
-    if (h->nw) {    // walker.total_weight starts as the size of the whole population (walkers/handler.py:164)
-        const double tw0 = (double)h->nw * nranks;
-        AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
-    }
-    return AFQ_OK;
+    return comm_attach(h, c);
+}
+
+int afq_comm_init_ipc(afq_handle *h, int rank, int nranks, afq_allgather_fn allgather, void *user) {
+    if (!h || !allgather || nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    k_comm_destroy(h);
+    afq_comm_state *c = new afq_comm_state();
+    c->rank = rank; c->nranks = nranks; c->mode = COMM_IPC;
+    c->window = true; c->win_collectives = true;
+    c->boot = allgather; c->boot_user = user;
+    return comm_attach(h, c);
 }
 
 int afq_comm_init_local(afq_handle **handles, int n) {
-    if (!handles || n < 1) return AFQ_EINVAL;
+    if (!handles || n < 1 || n > MAX_RANKS) return AFQ_EINVAL;
     for (int i = 0; i < n; ++i) if (!handles[i]) return AFQ_EINVAL;
     for (int i = 0; i < n; ++i) {
         afq_handle *h = handles[i];
         hipSetDevice(h->device);
         k_comm_destroy(h);
         afq_comm_state *c = new afq_comm_state();
-        c->rank = i; c->nranks = n; c->local = true;
+        c->rank = i; c->nranks = n; c->mode = COMM_LOCAL;
+        c->window = true; c->win_collectives = true;
         c->peers.assign(handles, handles + n);
         hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming);
-        h->comm = c;
-        if (h->nw) {
-            const double tw0 = (double)h->nw * n;
-            AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
-        }
+        const int rc = comm_attach(h, c);
+        if (rc) return rc;
     }
     return AFQ_OK;
 }
@@ -488,6 +909,19 @@ int afq_comm_destroy(afq_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     k_comm_destroy(h);
+    return AFQ_OK;
+}
+
+int afq_comm_set_transport(afq_handle *h, int window) {
+    if (!h) return AFQ_EINVAL;
+    afq_comm_state *c = cs_of(h);
+    if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
+    if (c->mode != COMM_RCCL && !window) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "only an RCCL communicator has the ncclSend / ncclRecv transport");
+    if (c->window == (window != 0)) return AFQ_OK;
+    hipSetDevice(h->device);
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    free_buffers(c);
+    c->window = window != 0;
     return AFQ_OK;
 }
 
@@ -508,7 +942,7 @@ int afq_comm_stats(afq_handle *h, int64_t *out) {
     afq_comm_state *c = cs_of(h);
     if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
     hipSetDevice(h->device);
-    double sc[8];
+    double sc[AFQ_NSCAL];
     if (h->scal_cache_valid) {
         // right behind the block's afq_estimates_get(_end): the scalars came along with the sums, no synchronisation
         // (the driver reads the statistics at block boundaries: with a sync here the host loses its lead over the device
@@ -523,6 +957,12 @@ int afq_comm_stats(afq_handle *h, int64_t *out) {
     out[2] = c->cap > 0 ? c->cap : default_cap(h->nw);
     out[3] = (int64_t)sc[3];                 // overflow flag
     out[4] = c->rank; out[5] = c->nranks;
+    out[6] = c->window ? (int64_t)sc[7] : -1;                                          // walkers this rank has sent
+    out[7] = c->window ? (int64_t)sc[8] : (int64_t)c->sendrecv_bytes;                  // bytes this rank has sent
+    out[8] = c->window ? 1 : 0;              // transport: 1 peer windows (live slots only), 0 fixed-size ncclSend / ncclRecv
+    out[9] = (int64_t)sc[6];                 // sticky communication error (a peer's flag never arrived)
+    out[10] = (int64_t)c->mode;              // 0 in-process, 1 RCCL, 2 IPC windows
+    out[11] = c->win ? c->win_kind : 0;      // window memory: 1 uncached, 2 fine-grained, 3 plain device memory
     return AFQ_OK;
 }
 
@@ -542,51 +982,35 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
     // a cached Green's function travels only if every rank has one (the slots of a pair must agree)
     bool with_greens = true;
     for (int i = 0; i < n; ++i) with_greens = with_greens && keep[i];
+    if ((rc = ensure_group(hs, n))) return rc;
+    // One host thread queues every rank's kernels, each stage for all ranks before the next: whatever a kernel waits for
+    // (a peer's flag) has been queued before it, also when several streams share a hardware queue.  The events order
+    // the streams on top of the flags, so that a rank never even starts a stage before its inputs are complete.
     for (int i = 0; i < n; ++i) {
         hipSetDevice(hs[i]->device);
-        if ((rc = stage_prep(hs[i], i == 0 ? r : 0.0))) return rc;
+        if ((rc = stage_prep(hs[i], i == 0 ? r : 0.0))) return rc;        // window all-gather: writes row i of every rank's gw
         AFQ_HIP(hs[i], hipEventRecord(cs_of(hs[i])->ev, hs[i]->stream));
     }
-    for (int i = 0; i < n; ++i) {                                    // all-gather
-        afq_handle *h = hs[i];
-        hipSetDevice(h->device);
-        for (int j = 0; j < n; ++j) {
-            AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev, 0));
-            AFQ_HIP(h, hipMemcpyAsync(cs_of(h)->gw + (size_t)j * (nw + 1), cs_of(hs[j])->sendw, sizeof(double) * (nw + 1),
-                                      hipMemcpyDeviceToDevice, h->stream));
-        }
-    }
     for (int i = 0; i < n; ++i) {
-        hipSetDevice(hs[i]->device);
-        if ((rc = stage_plan_pack(hs[i], target, with_greens))) return rc;
-        AFQ_HIP(hs[i], hipEventRecord(cs_of(hs[i])->ev2, hs[i]->stream));
-    }
-    for (int i = 0; i < n; ++i) {                                    // all-to-all of the slot buffers
         afq_handle *h = hs[i];
-        afq_comm_state *c = cs_of(h);
         hipSetDevice(h->device);
-        const size_t chunk = (size_t)c->cap * c->slot;
-        for (int j = 0; j < n; ++j) {
-            if (j == i) continue;
-            if (cs_of(hs[j])->cap != c->cap || cs_of(hs[j])->slot != c->slot) AFQ_FAIL(h, AFQ_ESTATE, "ranks disagree on the slot layout");
-            AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev2, 0));
-            AFQ_HIP(h, hipMemcpyAsync(c->rbuf + j * chunk, cs_of(hs[j])->sbuf + i * chunk, sizeof(cplx) * chunk,
-                                      hipMemcpyDeviceToDevice, h->stream));
-        }
-        AFQ_HIP(h, hipEventRecord(c->ev, h->stream));                // this rank's reads of the others' buffers are done
+        for (int j = 0; j < n; ++j) if (j != i) AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev, 0));
+        if ((rc = stage_plan_pack(h, target, with_greens))) return rc;     // pack: live slots straight into the peers' windows
+        AFQ_HIP(h, hipEventRecord(cs_of(h)->ev2, h->stream));
     }
     for (int i = 0; i < n; ++i) {
         afq_handle *h = hs[i];
         hipSetDevice(h->device);
-        for (int j = 0; j < n; ++j)
-            if (j != i) AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev, 0));
+        for (int j = 0; j < n; ++j) if (j != i) AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev2, 0));
         if ((rc = stage_unpack(h, with_greens))) return rc;
         h->greens_valid = with_greens;
+        // a rank's next prep overwrites rows of the OTHER ranks' gw of the other parity only; its next pack writes into
+        // their windows only after their next prep (all-gather), which follows their unpack in stream order
     }
     if (!parent_ix && !total_out) return AFQ_OK;
     afq_handle *h0 = hs[0];
     hipSetDevice(h0->device);
-    double sc[4];
+    double sc[8];
     AFQ_HIP(h0, hipMemcpyAsync(sc, h0->scal, sizeof(sc), hipMemcpyDeviceToHost, h0->stream));
     if (parent_ix)
         AFQ_HIP(h0, hipMemcpyAsync(parent_ix, cs_of(h0)->pix, sizeof(int) * (size_t)n * nw, hipMemcpyDeviceToHost, h0->stream));
@@ -594,6 +1018,7 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
     if (total_out) *total_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h0, AFQ_EWEIGHT, "total walker weight below 1e-8");
     if (sc[3] != 0.0) AFQ_FAIL(h0, AFQ_EOVERFLOW, "more walkers moved between two ranks than the exchange slots hold");
+    if (sc[6] != 0.0) AFQ_FAIL(h0, AFQ_ECOMM, "communicator: a rank never signalled (waited 10 s on the device)");
     return AFQ_OK;
 }
 
@@ -611,12 +1036,18 @@ int afq_estimates_allreduce(afq_handle *h, double *buf, int nest) {
     if (!h || (buf && nest < 1)) return AFQ_EINVAL;
     afq_comm_state *c = cs_of(h);
     if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
-    if (c->local) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_estimates_allreduce_local");
-    RcclApi *api = rccl_api();
-    if (!api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
+    if (c->mode == COMM_LOCAL) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_estimates_allreduce_local");
+    RcclApi *api = c->mode == COMM_RCCL ? rccl_api() : nullptr;
+    if (c->mode == COMM_RCCL && !api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
     hipSetDevice(h->device);
+    if (c->win_collectives) { const int rc = ensure_buffers(h); if (rc) return rc; }
     if (!buf) {     // the device accumulators of afq_estimates_update, in place: no host round trip
         { const int rc = k_estimates(h, 0, true); if (rc) return rc; }     // (sums still in the per-walker accumulators)
+        if (c->win_collectives) {
+            int rc = window_allreduce(h, (double *)h->estimates, 2 * AFQ_EST_COUNT_);
+            if (!rc && h->rdm_on && h->rdm_acc) rc = window_allreduce(h, h->rdm_acc, 2L * h->M * h->M);
+            return rc;
+        }
         afq_note_launch(h, "ncclAllReduce(estimates)");
         AFQ_NCCL(h, api, api->AllReduce(h->estimates, h->estimates, 2 * AFQ_EST_COUNT_, ncclDouble, ncclSum, c->nccl, h->stream));
         if (h->rdm_on && h->rdm_acc)    // the one-body RDM sums are part of the same reduction in the reference (mixed.py:261)
@@ -627,13 +1058,23 @@ int afq_estimates_allreduce(afq_handle *h, double *buf, int nest) {
     AFQ_HIP(h, hipMalloc(&tmp, sizeof(double) * 2 * (size_t)nest));
     hipError_t e = hipMemcpyAsync(tmp, buf, sizeof(double) * 2 * (size_t)nest, hipMemcpyHostToDevice, h->stream);
     ncclResult_t r = ncclSuccess;
-    if (e == hipSuccess) r = api->AllReduce(tmp, tmp, 2 * (size_t)nest, ncclDouble, ncclSum, c->nccl, h->stream);
-    if (e == hipSuccess && r == ncclSuccess)
+    int rcw = AFQ_OK;
+    if (e == hipSuccess) {
+        if (c->win_collectives) rcw = window_allreduce(h, tmp, 2L * nest);
+        else r = api->AllReduce(tmp, tmp, 2 * (size_t)nest, ncclDouble, ncclSum, c->nccl, h->stream);
+    }
+    if (e == hipSuccess && r == ncclSuccess && rcw == AFQ_OK)
         e = hipMemcpyAsync(buf, tmp, sizeof(double) * 2 * (size_t)nest, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(tmp);
+    if (rcw) return rcw;
     if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + api->GetErrorString(r); return AFQ_EHIP; }
     AFQ_HIP(h, e);
+    if (c->win_collectives) {       // a flag that never came leaves garbage in buf: report it here, this call synchronises anyway
+        double err = 0.0;
+        AFQ_HIP(h, hipMemcpy(&err, h->scal + 6, sizeof(double), hipMemcpyDeviceToHost));
+        if (err != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled its estimator row (waited 10 s on the device)");
+    }
     return AFQ_OK;
 }
 
@@ -641,31 +1082,121 @@ int afq_estimates_allreduce_local(afq_handle **hs, int n) {
     std::string err;
     int rc = check_group(hs, n, &err);
     if (rc) { if (hs && n > 0 && hs[0]) hs[0]->err = err; return rc; }
-    std::vector<double> sum(2 * AFQ_EST_COUNT_, 0.0), one(2 * AFQ_EST_COUNT_);
-    for (int i = 0; i < n; ++i) {
-        hipSetDevice(hs[i]->device);
-        AFQ_HIP(hs[i], hipMemcpyAsync(one.data(), hs[i]->estimates, sizeof(double) * one.size(), hipMemcpyDeviceToHost, hs[i]->stream));
-        AFQ_HIP(hs[i], hipStreamSynchronize(hs[i]->stream));
-        for (size_t k = 0; k < one.size(); ++k) sum[k] += one[k];
-    }
-    for (int i = 0; i < n; ++i) {
-        hipSetDevice(hs[i]->device);
-        AFQ_HIP(hs[i], hipMemcpyAsync(hs[i]->estimates, sum.data(), sizeof(double) * sum.size(), hipMemcpyHostToDevice, hs[i]->stream));
-        AFQ_HIP(hs[i], hipStreamSynchronize(hs[i]->stream));
-    }
-    if (hs[0]->rdm_on && hs[0]->rdm_acc) {
-        const size_t m = (size_t)2 * hs[0]->M * hs[0]->M;
-        std::vector<double> rs(m, 0.0), ro(m);
-        for (int i = 0; i < n; ++i) {
-            if (!hs[i]->rdm_acc) AFQ_FAIL(hs[0], AFQ_ESTATE, "one_rdm switched on for some ranks only");
-            hipSetDevice(hs[i]->device);
-            AFQ_HIP(hs[i], hipMemcpy(ro.data(), hs[i]->rdm_acc, sizeof(double) * m, hipMemcpyDeviceToHost));
-            for (size_t k = 0; k < m; ++k) rs[k] += ro[k];
+    if ((rc = ensure_group(hs, n))) return rc;
+    const bool rdm = hs[0]->rdm_on && hs[0]->rdm_acc;
+    for (int i = 0; i < n; ++i) if (rdm && !hs[i]->rdm_acc) AFQ_FAIL(hs[0], AFQ_ESTATE, "one_rdm switched on for some ranks only");
+    // the window reduction of the IPC communicator, stage by stage for all ranks (see afq_popcontrol_comb_local)
+    for (int pass = 0; pass < (rdm ? 2 : 1); ++pass) {
+        const long nn = pass == 0 ? 2L * AFQ_EST_COUNT_ : 2L * hs[0]->M * hs[0]->M;
+        for (long o = 0; o < nn; o += cs_of(hs[0])->wl.est_n) {
+            const long m = std::min(cs_of(hs[0])->wl.est_n, nn - o);
+            for (int i = 0; i < n; ++i) {
+                afq_handle *h = hs[i];
+                afq_comm_state *c = cs_of(h);
+                hipSetDevice(h->device);
+                if (pass == 0 && o == 0) { rc = k_estimates(h, 0, true); if (rc) return rc; }
+                double *v = (pass == 0 ? (double *)h->estimates : h->rdm_acc) + o;
+                ++c->seq_e;
+                AFQ_LAUNCH(h, est_put_kernel, dim3(n), dim3(256), 0, h->stream, v, m, c->pw, c->wl, c->rank, c->seq_e);
+                AFQ_POST(h);
+                AFQ_HIP(h, hipEventRecord(c->ev, h->stream));
+            }
+            for (int i = 0; i < n; ++i) {
+                afq_handle *h = hs[i];
+                afq_comm_state *c = cs_of(h);
+                hipSetDevice(h->device);
+                for (int j = 0; j < n; ++j) if (j != i) AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev, 0));
+                double *v = (pass == 0 ? (double *)h->estimates : h->rdm_acc) + o;
+                const unsigned nblk = (unsigned)std::min<long>(64, (m + 255) / 256);
+                AFQ_LAUNCH(h, est_sum_kernel, dim3(nblk), dim3(256), 0, h->stream, v, m, c->win, c->wl, c->seq_e, h->scal);
+                AFQ_POST(h);
+            }
         }
-        for (int i = 0; i < n; ++i) {
-            hipSetDevice(hs[i]->device);
-            AFQ_HIP(hs[i], hipMemcpy(hs[i]->rdm_acc, rs.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+    }
+    return AFQ_OK;
+}
+
+// Known-answer round through every piece the first population control will use, before any walker depends on it:
+// the all-gather (a pattern per rank), one full exchange slot to and from every peer through the configured transport
+// (window writes + flags, or the ncclSend / ncclRecv group), and the all-reduce.  Collective; synchronises.
+// mismatch_out (may be NULL): [0] wrong all-gather / all-reduce values, [1] wrong slot elements, [2] flags that never came.
+int afq_comm_probe(afq_handle *h, int64_t *mismatch_out) {
+    if (!h) return AFQ_EINVAL;
+    afq_comm_state *c = cs_of(h);
+    if (!c) AFQ_FAIL(h, AFQ_ESTATE, "no communicator");
+    if (c->mode == COMM_LOCAL) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: nothing to probe");
+    if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "allocate the walkers first (the buffers are sized from them)");
+    hipSetDevice(h->device);
+    RcclApi *api = c->mode == COMM_RCCL ? rccl_api() : nullptr;
+    if (c->mode == COMM_RCCL && !api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const int R = c->nranks, nw = h->nw;
+    int64_t bad[3] = {0, 0, 0};
+    // ---- all-gather: rank s contributes [1000 s + i] and r = 0.5 + s
+    std::vector<double> wts(nw), gathered((size_t)R * (nw + 1));
+    for (int i = 0; i < nw; ++i) wts[i] = 1000.0 * c->rank + i;
+    double *wdev = nullptr;
+    AFQ_HIP(h, hipMalloc(&wdev, sizeof(double) * nw));
+    AFQ_HIP(h, hipMemcpyAsync(wdev, wts.data(), sizeof(double) * nw, hipMemcpyHostToDevice, h->stream));
+    ++c->seq_g;
+    const double *gsrc = nullptr;
+    if (c->win_collectives) {
+        AFQ_LAUNCH(h, comm_prep_kernel, dim3(R), dim3(256), 0, h->stream, wdev, nw, 0.5 + c->rank, c->sendw, 1, c->pw, c->wl, c->rank, c->seq_g);
+        AFQ_POST(h);
+        gsrc = c->wl.gw(c->win, (int)(c->seq_g & 1));     // (complete once every rank's flag has arrived: waited for below)
+    } else {
+        AFQ_LAUNCH(h, comm_prep_kernel, dim3((nw + 1 + 255) / 256), dim3(256), 0, h->stream, wdev, nw, 0.5 + c->rank, c->sendw, 0, c->pw, c->wl, c->rank, c->seq_g);
+        AFQ_POST(h);
+        AFQ_NCCL(h, api, api->AllGather(c->sendw, c->gw, (size_t)nw + 1, ncclDouble, c->nccl, h->stream));
+        gsrc = c->gw;
+    }
+    // ---- one slot to and from every peer
+    ++c->seq_x;
+    unsigned long long *badd = nullptr;
+    AFQ_HIP(h, hipMalloc(&badd, 16));
+    AFQ_HIP(h, hipMemsetAsync(badd, 0, 16, h->stream));
+    if (c->win_collectives) {
+        AFQ_LAUNCH(h, probe_wait_kernel, dim3(1), dim3(64), 0, h->stream, c->wl.flag_g(c->win), R, c->seq_g, badd);
+        AFQ_POST(h);
+    }
+    if (R > 1) {
+        if (c->window) {
+            AFQ_LAUNCH(h, probe_put_kernel, dim3(R), dim3(256), 0, h->stream, (long)c->slot, (long)c->cap, c->pw, c->wl, c->rank, c->seq_x);
+            AFQ_POST(h);
+            AFQ_LAUNCH(h, probe_check_kernel, dim3(R), dim3(256), 0, h->stream, c->wl.rbuf(c->win), (long)c->slot, (long)c->cap,
+                       c->rank, R, c->wl.flag_x(c->win), c->seq_x, badd);
+            AFQ_POST(h);
+        } else {
+            AFQ_LAUNCH(h, probe_fill_kernel, dim3(R), dim3(256), 0, h->stream, c->sbuf, (long)c->slot, (long)c->cap, c->rank, R);
+            AFQ_POST(h);
+            if ((rc = sendrecv_slots(h, api))) { hipFree(wdev); hipFree(badd); return rc; }
+            AFQ_LAUNCH(h, probe_check_kernel, dim3(R), dim3(256), 0, h->stream, c->rbuf, (long)c->slot, (long)c->cap, c->rank, R,
+                       (const unsigned long long *)nullptr, c->seq_x, badd);
+            AFQ_POST(h);
         }
+    }
+    // ---- all-reduce of [rank + 1, 2 (rank + 1), ...] (host-buffer variant: the device variant is the same call underneath)
+    double red[8];
+    for (int i = 0; i < 8; ++i) red[i] = (i + 1.0) * (c->rank + 1);
+    if ((rc = afq_estimates_allreduce(h, red, 4))) { hipFree(wdev); hipFree(badd); return rc; }
+    AFQ_HIP(h, hipMemcpy(gathered.data(), gsrc, sizeof(double) * gathered.size(), hipMemcpyDeviceToHost));
+    for (int s = 0; s < R; ++s) {
+        for (int i = 0; i < nw; ++i) if (gathered[(size_t)s * (nw + 1) + i] != 1000.0 * s + i) ++bad[0];
+        if (gathered[(size_t)s * (nw + 1) + nw] != 0.5 + s) ++bad[0];
+    }
+    for (int i = 0; i < 8; ++i) if (red[i] != (i + 1.0) * (R * (R + 1) / 2)) ++bad[0];
+    unsigned long long bh[2] = {0, 0};
+    AFQ_HIP(h, hipMemcpy(bh, badd, 16, hipMemcpyDeviceToHost));
+    bad[1] = (int64_t)bh[0]; bad[2] += (int64_t)bh[1];
+    hipFree(wdev); hipFree(badd);
+    if (mismatch_out) { mismatch_out[0] = bad[0]; mismatch_out[1] = bad[1]; mismatch_out[2] = bad[2]; }
+    if (bad[0] || bad[1] || bad[2]) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "communicator probe failed: %lld wrong collective values, %lld wrong slot elements, %lld flags "
+                 "that never came (transport %s)", (long long)bad[0], (long long)bad[1], (long long)bad[2],
+                 c->window ? "peer windows" : "ncclSend/ncclRecv");
+        AFQ_FAIL(h, AFQ_ECOMM, msg);
     }
     return AFQ_OK;
 }

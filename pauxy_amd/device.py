@@ -373,6 +373,10 @@ class AfqDevice(object):
         return out
 
     # -- library-owned communicator -----------------------------------------
+    def comm_available(self):
+        """librccl loadable in this process (no collective, no GPU work)."""
+        return bool(self.lib.afq_comm_available())
+
     def comm_unique_id(self):
         buf = ctypes.create_string_buffer(128)
         rc = self.lib.afq_comm_unique_id(buf)
@@ -381,21 +385,47 @@ class AfqDevice(object):
         return buf.raw
 
     def comm_init(self, unique_id, rank, nranks):
-        assert len(unique_id) == 128
         self._ck(self.lib.afq_comm_init(self.h, ctypes.c_char_p(unique_id), int(rank), int(nranks)))
-        self.comm_rank, self.comm_size = int(rank), int(nranks)
+
+    def comm_init_ipc(self, rank, nranks, allgather):
+        """Communicator over mapped peer windows, no RCCL.  ``allgather(send_bytes) -> bytes of every rank
+        concatenated`` is the caller's all-gather (its MPI / torch.distributed communicator): the bootstrap of the
+        window handles, called on the host whenever the library (re)makes its windows."""
+        def thunk(send, recv, nbytes, _user):
+            try:
+                out = allgather(ctypes.string_at(send, nbytes))
+                if len(out) != nbytes * nranks:
+                    return 1
+                ctypes.memmove(recv, out, len(out))
+                return 0
+            except Exception:                                   # noqa: BLE001  (must not unwind through C)
+                return 1
+        self._ipc_thunk = L.ALLGATHER_FN(thunk)                 # kept alive as long as the communicator
+        self._ck(self.lib.afq_comm_init_ipc(self.h, int(rank), int(nranks), self._ipc_thunk, None))
 
     def comm_destroy(self):
         self._ck(self.lib.afq_comm_destroy(self.h))
-        self.comm_rank, self.comm_size = 0, 1
+
+    def comm_set_transport(self, window):
+        self._ck(self.lib.afq_comm_set_transport(self.h, 1 if window else 0))
 
     def comm_set_capacity(self, cap):
         self._ck(self.lib.afq_comm_set_capacity(self.h, int(cap)))
 
+    def comm_probe(self):
+        """Collective known-answer round (all-gather, one slot per peer, all-reduce); raises AfqError(AFQ_ECOMM)."""
+        bad = numpy.zeros(3, dtype=numpy.int64)
+        self._ck(self.lib.afq_comm_probe(self.h, _p(bad)))
+        return bad
+
     def comm_stats(self):
-        out = numpy.zeros(6, dtype=numpy.int64)
+        out = numpy.zeros(L.AFQ_COMM_NSTATS, dtype=numpy.int64)
         self._ck(self.lib.afq_comm_stats(self.h, _p(out)))
-        return dict(zip(['max_transfer', 'events', 'capacity', 'overflow', 'rank', 'size'], out.tolist()))
+        st = dict(zip(['max_transfer', 'events', 'capacity', 'overflow', 'rank', 'size', 'walkers_sent', 'bytes_sent',
+                       'window', 'error', 'kind', 'window_memory'], out.tolist()))
+        st['transport'] = 'peer windows' if st['window'] else 'ncclSend/ncclRecv'
+        st['kind'] = {0: 'in-process', 1: 'rccl', 2: 'ipc'}.get(st['kind'], st['kind'])
+        return st
 
     def estimates_allreduce(self, buf=None):
         """Sum over the ranks of the communicator: the device accumulators in place (buf None) or a host array."""

@@ -190,8 +190,9 @@ class AFQMC(object):
         ``on_step(step, psi)`` (tests) is called after every step; ``fetch_popcontrol`` reads the comb
         decisions back (``psi.last_parent_ix``).  ``overlap_blocks``: at the end of a block the head of the next step
         (step_batched_begin) is enqueued before the host waits for the block's sums -- same numbers, the device does not
-        idle while the host reduces / prints / derives the shift (one rank, continuous fields from the device stream,
-        mixed estimator only, no per-step callback; otherwise the plain order is used)."""
+        idle while the host reduces / prints / derives the shift (one rank, or several ranks on the library-owned
+        communicator, whose block reduction is queued on the stream like everything else; continuous fields from the
+        device stream, mixed estimator only, no per-step callback; otherwise the plain order is used)."""
         mixed = self.estimators.estimators['mixed']
         others = [e for k, e in self.estimators.estimators.items() if k != 'mixed']
         n = self.qmc.total_steps if nsteps_total is None else nsteps_total
@@ -215,7 +216,7 @@ class AFQMC(object):
             else:
                 mixed.update(self.system, self.qmc, self.trial, self.psi, 0, fp)
         hirsch = getattr(self.propagators, 'hs_type', '') == 'discrete'
-        overlap = (overlap_blocks and not others and not dcomm and self.comm.size == 1 and not hirsch and on_step is None
+        overlap = (overlap_blocks and not others and (dcomm or self.comm.size == 1) and not hirsch and on_step is None
                    and getattr(self.propagators, 'device_rng', False) and mixed.eval_energy and not mixed.calc_one_rdm
                    and not self.psi.write_restart)
         begun = False

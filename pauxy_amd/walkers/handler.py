@@ -210,15 +210,17 @@ class Walkers(object):
             raise NotImplementedError("use_log_shift: single-determinant walkers only (as in the reference, "
                                       "walkers/multi_det.py has no shifts)")
         self.dev.set_log_shift(self.use_log_shift)
-        # Population control on the device over the library-owned RCCL communicator (afq_comm_init) whenever the
-        # ranks sit on GPUs: rank 0's ncclUniqueId travels over the communicator the driver was given.  The
-        # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo).
-        self.device_comm, self.device_comm_error = False, ''
-        want = walker_opts.get('device_comm', os.environ.get('AFQ_DEVICE_COMM', '1') != '0')
-        forced = walker_opts.get('device_comm', None) is True        # tried whatever the driver's communicator sits on
+        # Population control on the device over the library-owned communicator whenever the ranks sit on GPUs
+        # (_init_device_comm: RCCL collectives + peer windows for the walkers, with agreed fall-backs).  The
+        # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo) and as the last resort.
+        # walkers: {device_comm: True / 'rccl' / 'ipc' / 'sendrecv' / False}; AFQ_DEVICE_COMM=0 forces the host path.
+        self.device_comm, self.device_comm_error, self.device_comm_kind = False, '', ''
+        opt = walker_opts.get('device_comm', None)
+        want = opt if opt is not None else os.environ.get('AFQ_DEVICE_COMM', '1') != '0'
+        forced = opt is not None and opt is not False        # tried whatever the driver's communicator sits on
         if (comm is not None and comm.size > 1 and want and
                 (forced or (getattr(comm, 'device', None) is not None and comm.device.type == 'cuda'))):
-            self.device_comm, self.device_comm_error = self._init_device_comm(comm)
+            self.device_comm, self.device_comm_error = self._init_device_comm(comm, want)
         self.target_weight = qmc.ntot_walkers
         # host mirrors of the per-walker scalars
         self._host = {}
@@ -334,7 +336,10 @@ class Walkers(object):
         pass
 
     def add_field_config(self, *a, **k):
-        raise NotImplementedError("back propagation is not on the device path yet")
+        """walkers/handler.py:183-199: the reference appends the step's fields to every walker's FieldConfig from the
+        host.  Here the history is written on the device by the weight-update kernel of the step itself
+        (afq_bp_configure), so there is nothing for the driver to add."""
+        return None
 
     def get_write_buffers(self):
         """[nw, 3 + M*(Na+Nb)] rows of (weight, phase, ot, phi) -- walkers/handler.py:432-435, batched."""
@@ -443,39 +448,105 @@ class Walkers(object):
         self.phi_version += 1
         self._invalidate()
 
-    def _init_device_comm(self, comm):
-        """afq_comm_init on every rank plus a probe reduction whose answer is known; all ranks agree (one Allreduce of
-        the outcome flags over the communicator the driver was given) on whether the device communicator is used.
-        A rank that cannot bring it up must not leave the others waiting inside the first population control, so any
-        failure sends every rank to the host-mediated path, with the reason kept in ``device_comm_error``."""
-        err = ''
-        try:
-            uid = self.dev.comm_unique_id() if comm.rank == 0 else bytes(128)
-        except L.AfqError as e:
-            uid, err = bytes(128), str(e)
-        uid = comm.bcast(uid, root=0)
-        if uid == bytes(128):
-            return False, err or 'rank 0 could not create the communicator id'
-        try:
-            self.dev.comm_init(uid, comm.rank, comm.size)
-            probe = self.dev.estimates_allreduce(numpy.arange(1.0, 5.0) * (comm.rank + 1))
-            want = numpy.arange(1.0, 5.0) * (comm.size * (comm.size + 1) // 2)
-            if not numpy.allclose(probe, want, rtol=0, atol=1e-12):
-                err = 'probe all-reduce returned %r, expected %r' % (probe.real.tolist(), want.tolist())
-        except L.AfqError as e:
-            err = str(e)
-        flags = numpy.zeros(1)
-        comm.Allreduce(numpy.array([0.0 if err else 1.0]), flags)
-        if int(round(flags[0])) == comm.size:
-            return True, ''
-        try:
-            self.dev.comm_destroy()
-        except L.AfqError:
-            pass
+    def _init_device_comm(self, comm, want=True):
+        """Brings up the library-owned communicator on every rank, or on none.  Candidates in order (``want`` picks one:
+        'rccl', 'sendrecv', 'ipc'; True tries all):
+          rccl      ncclCommInitRank; RCCL all-gather / all-reduce, walkers through mapped peer windows (live slots only)
+          sendrecv  the same communicator with the fixed-capacity ncclSend / ncclRecv transport
+          ipc       no RCCL at all: every exchange through the mapped windows, this communicator as the bootstrap
+        Nothing that can block on a peer (ncclCommInitRank, the probe) is entered before ALL ranks have agreed -- one
+        Allreduce of a flag over the driver's communicator -- that they can enter it: a rank that cannot load librccl
+        must not leave the others waiting inside the collective.  Every candidate ends with afq_comm_probe (a
+        known-answer round through the all-gather, one full slot to and from every peer on the chosen transport, and
+        the all-reduce) and a last agreement; any rank's failure sends every rank on to the next candidate, and finally
+        to the host-mediated path with the reasons kept in ``device_comm_error``."""
+        dev = self.dev
+
+        def agree(ok):
+            flags = numpy.zeros(1)
+            comm.Allreduce(numpy.array([1.0 if ok else 0.0]), flags)
+            return int(round(flags[0])) == comm.size
+
+        def allgather_bytes(mine):
+            send = numpy.frombuffer(mine, dtype=numpy.uint8).astype(numpy.float64)
+            recv = numpy.zeros(comm.size * send.size)
+            comm.Allgather(send, recv)
+            return recv.astype(numpy.uint8).tobytes()
+
+        def teardown():
+            try:
+                dev.comm_destroy()
+            except L.AfqError:
+                pass
+
+        candidates = [want] if want in ('rccl', 'sendrecv', 'ipc') else ['rccl', 'sendrecv', 'ipc']
+        errors = []
+        rccl_up = rccl_failed = False
+        for kind in candidates:
+            err = ''
+            if kind in ('rccl', 'sendrecv'):
+                if rccl_failed:
+                    continue                      # the communicator itself did not come up: no point in its other transport
+                if not rccl_up:
+                    rccl_failed = True            # until ncclCommInitRank has succeeded everywhere
+                    # 1. can every rank load librccl?  (local question, then agreement)
+                    if not agree(dev.comm_available()):
+                        errors.append(kind + ': librccl is not loadable on every rank')
+                        continue
+                    # 2. rank 0's id to everybody; ncclCommInitRank is a blocking collective, entered by all or none
+                    try:
+                        uid = dev.comm_unique_id() if comm.rank == 0 else bytes(128)
+                    except L.AfqError as e:
+                        uid, err = bytes(128), str(e)
+                    uid = comm.bcast(uid, root=0)
+                    if uid == bytes(128):
+                        errors.append(kind + ': ' + (err or 'rank 0 could not create the communicator id'))
+                        continue
+                    try:
+                        dev.comm_init(uid, comm.rank, comm.size)
+                    except L.AfqError as e:
+                        err = str(e)
+                    if not agree(not err):
+                        teardown()
+                        errors.append(kind + ': ' + (err or 'ncclCommInitRank failed on another rank'))
+                        continue
+                    rccl_up, rccl_failed = True, False
+                try:
+                    dev.comm_set_transport(kind == 'rccl')
+                except L.AfqError as e:
+                    err = str(e)
+            else:
+                if rccl_up:
+                    teardown()
+                    rccl_up = False
+                try:
+                    dev.comm_init_ipc(comm.rank, comm.size, allgather_bytes)
+                except L.AfqError as e:
+                    err = str(e)
+            if not agree(not err):
+                errors.append(kind + ': ' + (err or 'set-up failed on another rank'))
+                if kind == 'ipc':
+                    teardown()
+                continue
+            # 3. known-answer probe through everything the first population control will use (collective)
+            try:
+                dev.comm_probe()
+                if kind == 'rccl' and not dev.comm_stats()['window']:
+                    err = 'peer windows could not be exported / mapped on every rank'     # (agreed inside the library)
+            except L.AfqError as e:
+                err = str(e)
+            if agree(not err):
+                self.device_comm_kind = kind
+                return True, '; '.join(errors)
+            errors.append(kind + ': ' + (err or 'probe failed on another rank'))
+            if kind == 'ipc':
+                teardown()
+        if rccl_up:
+            teardown()
+        reason = '; '.join(errors)
         if comm.rank == 0:
-            print("# Warning: device communicator not used (%s); population control goes through the host."
-                  % (err or 'another rank failed'))
-        return False, err or 'another rank failed'
+            print("# Warning: device communicator not used (%s); population control goes through the host." % reason)
+        return False, reason
 
     def update_log_ovlp(self, comm):
         """walkers/handler.py:456-475: running averages of log <|ot|>, log <|detR|>, <|log_detR|> over the global
@@ -498,14 +569,17 @@ class Walkers(object):
         self.dev.set_log_shift(True, self.log_shift, self.detR_shift)
 
     def tune_exchange_capacity(self):
-        """Device communicator: size the per-peer exchange slots from the largest transfer seen so far (four times that
-        + 8, at least 8, at most nw; an overflow aborts the run, spare slots only cost link time).  Called at block
-        boundaries, right behind the block's host sync; every rank computes the same global comb, hence the same
-        statistic and the same new capacity (send and receive sizes must agree).  Growing is immediate, shrinking waits
-        for 20 events of history."""
+        """Device communicator with the fixed-size ncclSend / ncclRecv transport only (the window transport moves live
+        slots and keeps the capacity that cannot overflow): size the per-peer exchange slots from the largest transfer
+        seen so far -- four times that + 8, at least 8, at most nw.  The capacity STARTS at nw (what a rank owns: no
+        overflow before there is history) and shrinks only after 20 events; an overflow aborts the run, spare slots only
+        cost link time.  Called at block boundaries, right behind the block's host sync; every rank computes the same
+        global comb, hence the same statistic and the same new capacity (send and receive sizes must agree)."""
         if not self.device_comm:
             return
         st = self.dev.comm_stats()
+        if st['window']:
+            return
         want = min(self.nw, max(8, 4 * st['max_transfer'] + 8))
         if want > st['capacity'] or (st['events'] >= 20 and want < 0.6 * st['capacity']):
             self.dev.comm_set_capacity(want)

@@ -58,6 +58,7 @@ def test_comb_across_ranks_equals_one_rank(golden, nranks, nw):
     model, one, ranks, rng = start(golden, nranks, nw)
     ntot = nranks * nw
     xi = rng.normal(size=(ntot, one.K))
+    sent = [0] * nranks
     for step in range(3):
         # one step with a cached Green's function at its end (the cache has to travel with the clones),
         # then the comb; the next step consumes the cache
@@ -72,6 +73,16 @@ def test_comb_across_ranks_equals_one_rank(golden, nranks, nw):
         same_population(one, ranks, exact=(step == 0))     # later steps: the total weight differs in the last bit
         st = ranks[0].comm_stats()
         assert st['overflow'] == 0 and st['size'] == nranks and st['events'] == step + 1
+        # count-aware exchange: every rank has written exactly the walkers the comb sent from it to other ranks -- bytes
+        # moved == live slots x slot size (phi + Ghalf + cached overlap + 6 scalars, 16 bytes each), no empty slots
+        for c_, k_ in zip(numpy.where(pix > 1)[0], numpy.where(pix == 0)[0]):
+            if c_ // nw != k_ // nw:
+                sent[c_ // nw] += 1
+        for i, rk in enumerate(ranks):
+            sti = rk.comm_stats()
+            assert sti['window'] == 1 and sti['error'] == 0 and sti['kind'] == 'in-process'
+            assert sti['walkers_sent'] == sent[i]
+            assert sti['bytes_sent'] == sent[i] * 16 * (2 * one.M * (one.na + one.nb) + 7)
     pairs_cross = sum(1 for c, k in zip(numpy.where(pix > 1)[0], numpy.where(pix == 0)[0]) if c // nw != k // nw)
     assert ranks[0].comm_stats()['max_transfer'] >= (1 if pairs_cross else 0)
     close_all([one] + ranks)
@@ -242,6 +253,44 @@ def test_rccl_communicator_of_one_rank(golden):
     assert numpy.array_equal(withcomm.estimates_allreduce(buf.copy()), buf)
     st = withcomm.comm_stats()
     assert (st['rank'], st['size'], st['events']) == (0, 1, 1)
+    withcomm.comm_destroy()
+    close_all([plain, withcomm])
+
+
+def test_ipc_communicator_of_one_rank(golden):
+    """afq_comm_init_ipc with one rank: the window all-gather, the window all-reduce and afq_comm_probe run (a rank also
+    writes its own row through the same kernels), the bootstrap callback is called; equal to the plain single-rank path."""
+    d = golden('generic_ops.npz')
+    model = generic_model(d, 'A_')
+    nw = 8
+    rng = numpy.random.RandomState(11)
+    M, nt = model.M, model.na + model.nb
+    phis = numpy.array([model.psi + 0.05 * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for _ in range(nw)])
+    w = numpy.exp(rng.normal(size=nw))
+    plain, withcomm = make_device(model, nw), make_device(model, nw)
+    calls = []
+    withcomm.comm_init_ipc(0, 1, lambda mine: (calls.append(len(mine)), mine)[1])
+    assert list(withcomm.comm_probe()) == [0, 0, 0]
+    xi = rng.normal(size=(nw, plain.K))
+    for dev in (plain, withcomm):
+        dev.set(L.F_PHI, phis); dev.set(L.F_WEIGHT, w)
+        dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, model.na, model.nb) for p in phis]))
+        dev.propagate(xi, 0.0)
+    pa, ta = plain.popcontrol_comb(0.61, nw)
+    pb, tb = withcomm.popcontrol_comb(0.61, nw)
+    assert numpy.array_equal(pa, pb) and ta == tb
+    for f in FIELDS:
+        assert numpy.array_equal(plain.get(f), withcomm.get(f)), f
+    for dev in (plain, withcomm):
+        dev.estimates_update(True)
+    withcomm.estimates_allreduce()
+    assert numpy.array_equal(plain.estimates_get(), withcomm.estimates_get())
+    buf = rng.rand(7) + 1j * rng.rand(7)
+    assert numpy.array_equal(withcomm.estimates_allreduce(buf.copy()), buf)
+    big = rng.rand(3 * M * M) + 1j * rng.rand(3 * M * M)         # longer than one window row: reduced in chunks
+    assert numpy.array_equal(withcomm.estimates_allreduce(big.copy()), big)
+    st = withcomm.comm_stats()
+    assert (st['rank'], st['size'], st['events'], st['kind'], st['error']) == (0, 1, 1, 'ipc', 0)
     withcomm.comm_destroy()
     close_all([plain, withcomm])
 

@@ -75,14 +75,19 @@ def drive(comm, nw_total, first, count, walkers=None):
         if step % 5 == 0:
             rec['pix'].append(numpy.array(psi.last_parent_ix).copy())
 
-    afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
+    if os.environ.get('AFQ_TEST_NO_CALLBACK', '0') == '1':
+        afqmc.run_batched()             # bench.py's mode: nothing read back at the comb, overlapped block boundaries
+    else:
+        afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
     mixed = afqmc.estimators.estimators['mixed']
     blocks = numpy.array(mixed.blocks) if comm is None or comm.rank == 0 else None
     rdm = numpy.array(mixed.one_rdm) if (comm is None or comm.rank == 0) and mixed.calc_one_rdm else None
     phi = numpy.array([w.phi for w in afqmc.psi.walkers])
     return dict(weight=numpy.array(rec['weight']), ot=numpy.array(rec['ot']), pix=numpy.array(rec['pix']),
                 blocks=blocks, rdm=rdm, phi=phi, device_comm=bool(getattr(afqmc.psi, 'device_comm', False)),
-                device_comm_error=getattr(afqmc.psi, 'device_comm_error', ''))
+                device_comm_error=getattr(afqmc.psi, 'device_comm_error', ''),
+                device_comm_kind=getattr(afqmc.psi, 'device_comm_kind', ''),
+                comm_stats=afqmc.psi.dev.comm_stats() if getattr(afqmc.psi, 'device_comm', False) else None)
 
 
 def _worker(rank, port, walkers, q):
@@ -166,14 +171,73 @@ def test_two_ranks_equal_one_rank_with_twice_the_walkers():
     compare(one, a, b)
 
 
-def test_device_communicator_refused_then_host_path():
-    """walkers: {device_comm: True} on a gloo group: afq_comm_init is attempted, RCCL refuses two ranks on one GPU
-    (or the probe fails); both ranks must fall back together and still match the single-rank run."""
+def test_rccl_refused_then_host_path():
+    """walkers: {device_comm: 'rccl'} on a gloo group: afq_comm_init is attempted (after the ranks agreed that librccl
+    loads), RCCL refuses two ranks on one GPU; both ranks must fall back together and still match the single-rank run."""
     one = single_rank()
-    a, b = two_ranks({'device_comm': True})
+    a, b = two_ranks({'device_comm': 'rccl'})
     assert not a['device_comm'] and not b['device_comm']
     assert a['device_comm_error'] and b['device_comm_error']
     compare(one, a, b)
+
+
+def check_ipc(one, a, b):
+    assert a['device_comm'] and b['device_comm']
+    assert a['device_comm_kind'] == 'ipc' and b['device_comm_kind'] == 'ipc'
+    compare(one, a, b)
+    from pauxy_amd.walkers.handler import comb_pairs
+    # traffic: every rank wrote exactly the walkers the global comb sent from it to the other rank, nothing else
+    for rank, out in enumerate((a, b)):
+        st = out['comm_stats']
+        assert st['kind'] == 'ipc' and st['window'] == 1 and st['error'] == 0 and st['overflow'] == 0
+        sent = sum(1 for pix in one['pix'] for c, k in comb_pairs(pix) if c // NW == rank and k // NW != rank)
+        assert st['walkers_sent'] == sent and sent > 0
+        per = 12 * 6                                        # M x (na + nb) of build()
+        # a slot is phi + 6 scalars, plus Ghalf + its overlap when the Green's function is cached, plus walker.G with one_rdm
+        assert 16 * (per + 6) * sent <= st['bytes_sent'] <= 16 * (2 * per + 7 + 2 * 12 * 12) * sent
+
+
+def test_device_comb_over_ipc_windows_two_processes():
+    """The device path across REAL process boundaries on the one GPU of the box: walkers: {device_comm: 'ipc'} -- every
+    rank maps the other's window (hipIpcGetMemHandle / hipIpcOpenMemHandle, bootstrap over the gloo group), weights
+    all-gather, walker slots and the block reduction are kernels of one process writing into the other's memory, ordered
+    by system-scope flags; nothing of the comb is read back by the host.  Must equal the single-rank run."""
+    one = single_rank()
+    a, b = two_ranks({'device_comm': 'ipc'})
+    check_ipc(one, a, b)
+
+
+def test_device_communicator_falls_through_to_ipc_windows():
+    """walkers: {device_comm: True} tries RCCL first (refused here: two ranks on one GPU), then -- every rank agreeing at
+    each step -- the IPC-window communicator, which works on one GPU as well."""
+    one = single_rank()
+    a, b = two_ranks({'device_comm': True})
+    assert 'rccl' in a['device_comm_error']               # the reason the first candidate was dropped is kept
+    check_ipc(one, a, b)
+
+
+def test_ipc_windows_with_riding_estimator_terms(monkeypatch):
+    """Without the one-body RDM the estimator terms of the plain steps ride on the weight update on every rank, and the
+    block reduction runs through the windows."""
+    monkeypatch.setenv('AFQ_TEST_ONE_RDM', '0')
+    one = single_rank()
+    a, b = two_ranks({'device_comm': 'ipc'})
+    check_ipc(one, a, b)
+
+
+def test_ipc_windows_bench_mode_overlapped_block_boundary(monkeypatch):
+    """run_batched exactly as bench.py drives it on several GPUs -- no per-step callback, so nothing is read back at the
+    comb and the head of the next block's first step is queued BEFORE the host waits for the block's (window-reduced)
+    sums -- must leave the same walkers and block rows as the single-rank run."""
+    monkeypatch.setenv('AFQ_TEST_ONE_RDM', '0')
+    monkeypatch.setenv('AFQ_TEST_NO_CALLBACK', '1')
+    one = single_rank()
+    a, b = two_ranks({'device_comm': 'ipc'})
+    assert a['device_comm_kind'] == 'ipc' and a['comm_stats']['walkers_sent'] + b['comm_stats']['walkers_sent'] > 0
+    got_phi = numpy.concatenate([a['phi'], b['phi']])
+    assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
+    assert a['blocks'].shape == one['blocks'].shape
+    assert numpy.max(numpy.abs(a['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
 
 
 def test_two_ranks_with_estimator_terms_riding_on_the_weight_update(monkeypatch):
