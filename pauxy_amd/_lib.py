@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libafqmc_hip.so")
+# AFQ_LIBRARY selects another build of the same C ABI (the tuning build of `make TUNING=1`, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("AFQ_LIBRARY") or os.path.join(HERE, "libafqmc_hip.so")
 
 AFQ_OK = 0
 AFQ_EWEIGHT, AFQ_EOVERFLOW, AFQ_ECOMM = -6, -7, -8

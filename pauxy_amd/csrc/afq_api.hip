@@ -289,6 +289,7 @@ static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
     ++h->ghalf_version;                 // force-bias partials contracted with the old vectors are stale
     h->rchol_same = h->na == h->nb && memcmp(rchol, rchol + 2 * (size_t)h->na * h->M * K, sizeof(double) * 2 * (size_t)h->na * h->M * K) == 0;
     k_free_atil(h->atil);                  // the quadratic-form operand belongs to the old vectors
+    h->atil_unavailable = false;
     if ((rc = dev_upload(h, &h->rchol_re, re.data(), re.size()))) return rc;
     if (!real) {
         std::vector<double> im(nq * h->ld_rc, 0.0);

@@ -60,6 +60,7 @@ struct afq_handle {
     // quadratic-form exchange (k_energy.hip): Atil_s [(N_s M), ldq] f64 (c128 when rchol is complex), built on first
     // use; atil[1] == atil[0] when both spins have the same half-rotated vectors (closed-shell trial)
     void *atil[2] = {nullptr, nullptr};
+    bool atil_unavailable = false;  // automatic mode: Atil did not fit when it was to be built -> T-intermediate kernel
     bool rchol_same = false;        // alpha and beta blocks of rchol are bitwise equal
     int exx_mode = 0;               // afq_set_exchange_algorithm: 0 auto, 1 T-intermediate (exx_kernel), 2 quadratic form
     cplx *exq_y = nullptr;          // [2 * slices, nw, ceil(N M / 16)] per-tile partial sums of the quadratic form

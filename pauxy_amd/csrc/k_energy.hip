@@ -475,8 +475,16 @@ static double atil_bytes(afq_handle *h) {
 int k_exchange_uses_quadratic(afq_handle *h) {
     if (h->exx_mode == 1) return 0;
     if (h->exx_mode == 2) return 1;
-    // K / M times fewer flops; the operands of every determinant must fit a quarter of the 288 GB
-    return h->K >= h->M && atil_bytes(h) * h->ndet <= 72e9;
+    if (h->atil_unavailable) return 0;           // an earlier allocation failed: T-intermediate kernel from then on
+    if (h->K < h->M) return 0;                    // K / M times fewer flops only when K >= M
+    if (h->atil[0]) return 1;                     // already built
+    // the operands of every determinant must fit what is free NOW on this GPU (other handles, other processes), and at
+    // most a quarter of the memory: the walkers, the HS potential and the work buffers want the rest
+    size_t free_b = 0, total_b = 0;
+    hipSetDevice(h->device);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return atil_bytes(h) * h->ndet <= 72e9; }
+    const double need = atil_bytes(h) * h->ndet;
+    return need <= 0.25 * (double)total_b && need <= 0.8 * (double)free_b;
 }
 
 static int ensure_atil(afq_handle *h) {
@@ -488,7 +496,12 @@ static int ensure_atil(afq_handle *h) {
         if (s == 1 && h->rchol_same) { h->atil[1] = h->atil[0]; break; }
         const long NM = (long)ns * M, ldq = (NM + 1) & ~1L;
         const size_t bytes = (size_t)NM * ldq * (h->rchol_real ? sizeof(double) : sizeof(cplx));
-        if (hipMalloc(&h->atil[s], bytes) != hipSuccess) AFQ_FAIL(h, AFQ_ENOMEM, "quadratic-form exchange operand does not fit");
+        if (hipMalloc(&h->atil[s], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->atil[s] = nullptr;
+            k_free_atil(h->atil);                 // the other spin's operand, if it was made
+            AFQ_FAIL(h, AFQ_ENOMEM, "quadratic-form exchange operand does not fit");
+        }
         AFQ_HIP(h, hipMemsetAsync(h->atil[s], 0, bytes, h->stream));
         const dim3 grid((unsigned)((NM + 63) / 64), (unsigned)((NM + 63) / 64));
         const long row0 = s == 0 ? 0 : (long)h->na * M;
@@ -581,8 +594,15 @@ int k_energy_generic(afq_handle *h) {
     // Coulomb vectors: the force-bias contraction on the current Ghalf
     int rc = k_force_bias_generic(h);
     if (rc) return rc;
-    if (k_exchange_uses_quadratic(h)) {
-        if ((rc = ensure_atil(h))) return rc;
+    bool quadratic = k_exchange_uses_quadratic(h);
+    if (quadratic && (rc = ensure_atil(h))) {
+        // automatic choice: an operand that does not fit is not an error, the T-intermediate kernel needs none
+        if (rc != AFQ_ENOMEM || h->exx_mode == 2) return rc;
+        h->atil_unavailable = true;
+        h->err.clear();
+        quadratic = false;
+    }
+    if (quadratic) {
         const int S = h->rchol_real ? launch_exx_quadratic<false>(h) : launch_exx_quadratic<true>(h);
         if (S < 0) return S;
         EFinArgs f;

@@ -386,6 +386,7 @@ class AfqDevice(object):
 
     def comm_init(self, unique_id, rank, nranks):
         self._ck(self.lib.afq_comm_init(self.h, ctypes.c_char_p(unique_id), int(rank), int(nranks)))
+        self.comm_rank, self.comm_size = int(rank), int(nranks)
 
     def comm_init_ipc(self, rank, nranks, allgather):
         """Communicator over mapped peer windows, no RCCL.  ``allgather(send_bytes) -> bytes of every rank
@@ -402,9 +403,11 @@ class AfqDevice(object):
                 return 1
         self._ipc_thunk = L.ALLGATHER_FN(thunk)                 # kept alive as long as the communicator
         self._ck(self.lib.afq_comm_init_ipc(self.h, int(rank), int(nranks), self._ipc_thunk, None))
+        self.comm_rank, self.comm_size = int(rank), int(nranks)
 
     def comm_destroy(self):
         self._ck(self.lib.afq_comm_destroy(self.h))
+        self.comm_rank, self.comm_size = 0, 1
 
     def comm_set_transport(self, window):
         self._ck(self.lib.afq_comm_set_transport(self.h, 1 if window else 0))

@@ -2,7 +2,8 @@
 # A/B runs of bench.py in a tuning build on the GPU box:  bash tools/ab_bench.sh <tag> "VAR=val ..." "VAR2=val ..." ...
 out=gpurun_out/$1; shift
 mkdir -p $out
-make -C pauxy_amd/csrc -B -j32 TUNING=1 > $out/build.log 2>&1 || { tail -5 $out/build.log; exit 1; }
+make -C pauxy_amd/csrc -j32 TUNING=1 > $out/build.log 2>&1 || { tail -5 $out/build.log; exit 1; }
+export AFQ_LIBRARY=$PWD/pauxy_amd/libafqmc_hip_tuning.so      # the product library is left alone
 i=0
 for envs in "$@"; do
   i=$((i+1))

@@ -2,19 +2,42 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy
-from tests.test_gpu_batched import run_c3, c4_afqmc
+from pauxy_amd import _lib as L
+from pauxy_amd.context import release_context
+from tests.test_gpu_batched import c4_afqmc
 
-a, ba, pa = run_c3(False, True, make=c4_afqmc)
-b, bb, pb = run_c3(True, True, make=c4_afqmc)
-b2, bb2, pb2 = run_c3(True, True, make=c4_afqmc)
-a2, ba2, pa2 = run_c3(False, True, make=c4_afqmc)
-for name, x, y in (("run vs batched", a, b), ("batched vs batched", b, b2), ("run vs run", a, a2)):
-    for key in ('weight', 'ot', 'ehyb'):
-        d = x[key] != y[key]
-        if d.any():
-            st, w = numpy.argwhere(d)[0]
-            rel = abs(x[key][st, w] - y[key][st, w]) / abs(x[key][st, w])
-            print(name, key, "first diff at step", st + 1, "walker", w, "rel", rel, "count", d.sum(), "steps with diffs", sorted(set(numpy.argwhere(d)[:, 0] + 1)))
-        else:
-            print(name, key, "bit-equal")
-    print(name, "pix equal", numpy.array_equal(x['pix'], y['pix']))
+
+def go(batched, force_greens=False):
+    afqmc, s, t = c4_afqmc()
+    nw = afqmc.psi.nw
+    numpy.random.seed(1234)
+    afqmc.psi.dev.set(L.F_WEIGHT, numpy.exp(0.6 * numpy.random.RandomState(5).normal(size=nw)))
+    afqmc.psi._invalidate()
+    rec = {}
+
+    def on_step(step, psi):
+        if step in (9, 10, 11):
+            rec['ghalf%d' % step] = psi.dev.get(L.F_GHALF)
+            rec['phi%d' % step] = psi.dev.get(L.F_PHI)
+            rec['ot%d' % step] = psi.dev.get(L.F_OT)
+            rec['w%d' % step] = psi.dev.get(L.F_WEIGHT)
+        if force_greens:
+            psi.dev.greens(want_G=False)
+
+    if batched:
+        afqmc.run_batched(on_step=on_step, fetch_popcontrol=True)
+    else:
+        afqmc.run(on_step=on_step)
+    release_context(s, t)
+    return rec
+
+
+a = go(False)
+b = go(True)
+c = go(True, force_greens=True)
+for name, x, y in (("run vs batched", a, b), ("run vs batched+forced greens", a, c), ("batched vs batched+forced", b, c)):
+    for k in sorted(x):
+        d = numpy.abs(x[k] - y[k])
+        print(name, k, "equal" if not d.any() else "max abs diff %.3e (max |x| %.3e), walkers differing %d" % (
+            d.max(), numpy.abs(x[k]).max(), int((d.reshape(d.shape[0], -1).max(axis=1) > 0).sum())))
+print("weights step 10:", numpy.sort(a['w10'])[:5], numpy.sort(a['w10'])[-5:], "alive", int((numpy.abs(a['w10']) > 1e-8).sum()))

@@ -3,7 +3,8 @@
 # (tuning build: the AFQ_* switches exist only with make TUNING=1).  Output under gpurun_out/$1.
 out=gpurun_out/${1:-pmc_prop}
 mkdir -p $out
-make -C pauxy_amd/csrc -B -j32 TUNING=1 > $out/build.log 2>&1 || { tail -5 $out/build.log; exit 1; }
+make -C pauxy_amd/csrc -j32 TUNING=1 > $out/build.log 2>&1 || { tail -5 $out/build.log; exit 1; }
+export AFQ_LIBRARY=$PWD/pauxy_amd/libafqmc_hip_tuning.so      # the product library is left alone
 export TMPDIR=/tmp
 for v in t4 t16; do
   if [ $v = t16 ]; then export AFQ_NO_T4=1; else unset AFQ_NO_T4; fi
