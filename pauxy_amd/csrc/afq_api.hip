@@ -232,6 +232,7 @@ int afq_destroy(afq_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     k_comm_destroy(h);
+    k_ueg_fast_free(h);
     free_walkers(h);
     free_system(h);
     dev_free(h->psi); dev_free(h->psic); dev_free(h->psicT); dev_free(h->BH1); dev_free(h->mf_shift);
@@ -456,7 +457,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
     if ((rc = dev_upload(h, &h->vqvec, vqvec, (size_t)nq))) return rc;
     if ((rc = dev_upload(h, &h->H1diag, H1diag, (size_t)2 * M))) return rc;
     cache_of(h)->H1.clear();
-    return AFQ_OK;
+    return k_ueg_fast_system(h, M, nq, iA_colptr, iA_row, iA_val, iB_colptr, iB_row, iB_val);
 }
 
 int afq_set_trial(afq_handle *h, const double *psi) {
@@ -468,6 +469,7 @@ int afq_set_trial(afq_handle *h, const double *psi) {
     int rc = upload_psi(h, psi);
     if (rc) return rc;
     h->have_trial = true;
+    if (h->kind == AFQ_SYS_UEG && (rc = k_ueg_fast_trial(h, psi))) return rc;
     return maybe_build_rH1(h);
 }
 
@@ -519,6 +521,7 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
     h->bh1_same = memcmp(BH1, BH1 + (size_t)2 * h->M * h->M, sizeof(double) * 2 * h->M * h->M) == 0;
     for (size_t i = 0, n = (size_t)2 * h->M * h->M; i < n && h->bh1_real; ++i) h->bh1_real = BH1[2 * i + 1] == 0.0;
     if ((rc = dev_upload(h, &h->mf_shift, mf_shift, (size_t)h->K))) return rc;
+    if (h->kind == AFQ_SYS_UEG && (rc = k_ueg_fast_propagator(h, BH1))) return rc;
     h->dt = dt; h->sqrt_dt = std::pow(dt, 0.5); h->exp_order = exp_order;
     if (flags & AFQ_PROP_FREE_PROJECTION) flags &= ~AFQ_PROP_FORCE_BIAS;   // continuous.py:30-33
     const int old_nv = h->nv; const bool old_diag = h->vhs_diag;
@@ -805,7 +808,7 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     if (xi) {
         if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
-    } else if (k_prop_fused_supported(h)) {
+    } else if (k_prop_fused_supported(h) || k_ueg_fast_supported(h)) {
         // nothing ahead of fields_kernel reads the fields or the alive flags on this path (the Green's function is
         // evaluated for every walker, the one-body product sits inside the fused propagator): fields_kernel draws
         // the same Philox stream itself and sets the flags
@@ -821,7 +824,9 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
         else if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
         h->greens_valid = false;
         const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
-        if ((h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le)) || (h->rdm_on && h->ndet == 1)) {
+        // (the plane-wave fast step gathers the force bias from the occupied rows of G built from Ghalf: no full G)
+        if ((h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le) && !k_ueg_fast_supported(h)) ||
+            (h->rdm_on && h->ndet == 1)) {
             // (one_rdm: walker.G = the Green's function of the walker before this step, continuous.py:245)
             if ((rc = ensure_G(h))) return rc;
             if ((rc = k_full_G(h))) return rc;
@@ -835,6 +840,14 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
             if (h->ndet > 1) { if ((rc = local_energy_dets(h))) return rc; }
             else if ((rc = local_energy(h))) return rc;
         }
+    }
+    if (k_ueg_fast_supported(h)) {
+        // plane waves: force bias from the occupied rows of G, fields, and the ~2 nq coefficients that ARE the HS
+        // potential, in one launch; B exp(V) B from those coefficients in a second one (k_ueg.hip)
+        { PhaseTimer t(h, T_FB); if ((rc = k_ueg_fields(h))) return rc; }                        // :133-158, :161
+        { PhaseTimer t(h, T_EXP); if ((rc = k_prop_ueg(h))) return rc; }                         // :251, :162-171, :258
+        h->prop_pending = true;
+        return AFQ_OK;
     }
     // The force bias reads Ghalf of the un-propagated walker, so building the HS potential commutes
     // with the first one-body product; the fused path uses that to run B exp(V) B in one launch.

@@ -86,6 +86,7 @@ struct afq_handle {
     int64_t *kpq_off = nullptr, *kpq_i = nullptr, *kpq_kpq = nullptr;
     int64_t *pmq_off = nullptr, *pmq_i = nullptr, *pmq_pmq = nullptr;
     double *vqvec = nullptr; double vol = 1.0; double *H1diag = nullptr;
+    void *ueg_fast = nullptr;       // k_ueg.hip: tables of the plane-wave step that needs no M x M intermediate
 
     // ---- trial
     bool have_trial = false;
@@ -400,6 +401,15 @@ int k_rdm_accumulate(afq_handle *h);
 int k_rng_normal(afq_handle *h);
 int k_rng_normal_into(afq_handle *h, double *out_d, long n);
 int k_philox_raw(afq_handle *h, const unsigned int *in_d, unsigned int *out_d, int n);
+// k_ueg.hip (plane-wave step from Ghalf and per-walker HS coefficients: no G, no dense HS potential)
+int k_ueg_fast_system(afq_handle *h, int M, int nq, const int64_t *Acp, const int64_t *Arow, const double *Aval,
+                      const int64_t *Bcp, const int64_t *Brow, const double *Bval);
+int k_ueg_fast_trial(afq_handle *h, const double *psi);
+int k_ueg_fast_propagator(afq_handle *h, const double *BH1);
+int k_ueg_fast_supported(afq_handle *h);
+int k_ueg_fields(afq_handle *h);                            // force bias + fields + HS coefficients
+int k_prop_ueg(afq_handle *h);                              // phi <- B exp(V) B phi
+void k_ueg_fast_free(afq_handle *h);
 // k_comm.hip
 int k_comm_size(afq_handle *h);                             // ranks of the library-owned communicator (1 without)
 void k_comm_destroy(afq_handle *h);

@@ -149,10 +149,25 @@ def test_c2_c4_run_batched_equals_run(make):
     b, blocks_b, phi_b = run_c3(True, True, make=make)
     c, blocks_c, phi_c = run_c3(True, False, make=make)
     assert numpy.all(numpy.isfinite(phi_a.view(float))) and numpy.all(numpy.isfinite(a['weight']))
+    # the two batched variants (comb read back or not) queue identical work: bit-equal
+    for key in ('weight', 'ot', 'ehyb'):
+        assert numpy.array_equal(b[key], c[key]), key
+    assert numpy.array_equal(phi_b, phi_c)
+    exact = make is c2_afqmc
     for other, blocks, phi in ((b, blocks_b, phi_b), (c, blocks_c, phi_c)):
         for key in ('weight', 'ot', 'ehyb'):
-            assert numpy.array_equal(a[key], other[key]), key
-        assert numpy.array_equal(phi_a, phi)
+            if exact:
+                assert numpy.array_equal(a[key], other[key]), key
+            else:
+                # C4: bit-equal through the first re-orthogonalisation + energy evaluation (step 10); from step 11 on the
+                # Green's functions of the two loops differ in the last bits (1e-15: measured with tools/dbg_c4_batched.py,
+                # walkers, overlaps and weights of step 10 identical, Ghalf not), which then spreads at rounding level
+                assert numpy.array_equal(a[key][:10], other[key][:10]), key
+                close(a[key], other[key], 1e-11)
+        if exact:
+            assert numpy.array_equal(phi_a, phi)
+        else:
+            close(phi, phi_a, 1e-11)
         close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-12)
     assert numpy.array_equal(a['pix'], b['pix'])
     assert a['pix'].shape == (4, 256) and a['pix'].max() >= 2             # the comb did clone walkers

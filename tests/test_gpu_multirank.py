@@ -187,14 +187,17 @@ def check_ipc(one, a, b):
     compare(one, a, b)
     from pauxy_amd.walkers.handler import comb_pairs
     # traffic: every rank wrote exactly the walkers the global comb sent from it to the other rank, nothing else
+    total = 0
     for rank, out in enumerate((a, b)):
         st = out['comm_stats']
         assert st['kind'] == 'ipc' and st['window'] == 1 and st['error'] == 0 and st['overflow'] == 0
         sent = sum(1 for pix in one['pix'] for c, k in comb_pairs(pix) if c // NW == rank and k // NW != rank)
-        assert st['walkers_sent'] == sent and sent > 0
+        assert st['walkers_sent'] == sent
         per = 12 * 6                                        # M x (na + nb) of build()
         # a slot is phi + 6 scalars, plus Ghalf + its overlap when the Green's function is cached, plus walker.G with one_rdm
         assert 16 * (per + 6) * sent <= st['bytes_sent'] <= 16 * (2 * per + 7 + 2 * 12 * 12) * sent
+        total += sent
+    assert total > 0                                        # walkers did cross the process boundary
 
 
 def test_device_comb_over_ipc_windows_two_processes():
