@@ -124,8 +124,16 @@ int afq_set_trial(afq_handle *h, const double *psi);
  *                          walker w survived the first kinetic step, i.e. weight != 0 after it);
  *                          fields_out int32[nw, M] (chosen field 0/1, -1 not visited), used_out int32[nw]
  *                          (uniforms consumed; < M only when both field probabilities vanish) -- both
- *                          may be NULL.                                                                   */
+ *                          may be NULL.
+ *   afq_hirsch_free_projection / afq_propagate_hirsch_free   propagate_walker_free (:303-343): no importance
+ *                          sampling -- kinetic half step, every site takes field 0 (uniform < 0.5) or 1 and scales its row
+ *                          of phi, kinetic half step, weight *= exp(dt eshift) |wfac|, phase *= exp(i arg wfac),
+ *                          ot = <psi_T|phi>.  The first call switches the mode (the estimators then accumulate
+ *                          weight * ot * phase, mixed.py:151-175, and the re-orthogonalisation folds det R into weight and
+ *                          phase); u f64[nw, M] numpy's uniforms or NULL for the device stream, fields_out may be NULL. */
 int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition);
+int afq_hirsch_free_projection(afq_handle *h, int on);
+int afq_propagate_hirsch_free(afq_handle *h, const double *u, int32_t *fields_out, double eshift);
 int afq_propagate_hirsch(afq_handle *h, double eshift);
 int afq_hirsch_kinetic(afq_handle *h);
 int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int32_t *used_out);

@@ -533,6 +533,34 @@ def propagate_walker_hirsch(model, w, uniform, eshift):
     return fields
 
 
+def propagate_walker_hirsch_free(model, w, uniform, eshift=0):
+    """propagation/hubbard.py:303-343 (propagate_walker_free): no importance sampling; every site takes field 0 or 1
+    with probability 1/2, the weight picks up |prod aux_wfac| and exp(dt eshift), the phase arg(prod aux_wfac)."""
+    na, M = model.na, model.M
+    kinetic_real(w['phi'], model.bt2, na)
+    wfac = 1.0
+    fields = []
+    for i in range(M):
+        if abs(w['weight']) > 0:
+            r = uniform()
+            xi = 0 if r < 0.5 else 1
+            vtup = w['phi'][i, :na] * model.delta[xi, 0]
+            vtdown = w['phi'][i, na:] * model.delta[xi, 1]
+            w['phi'][i, :na] = w['phi'][i, :na] + vtup
+            w['phi'][i, na:] = w['phi'][i, na:] + vtdown
+            wfac *= model.aux_wfac[xi]
+            fields.append(xi)
+    kinetic_real(w['phi'], model.bt2, na)
+    hirsch_inverse_overlap(model, w)
+    ovlp = hirsch_calc_otrial(w, getattr(model, 'log_shift', 0.0))
+    magn, dtheta = cmath.polar(wfac)
+    w['weight'] *= numpy.exp(model.dt * eshift) * magn
+    w['phase'] = w.get('phase', 1.0 + 0j) * numpy.exp(1j * dtheta)
+    w['ot'] = ovlp
+    w['ovlp'] = ovlp
+    return fields
+
+
 # --------------------------------------------------------------------------
 # Back-propagation (SURVEY section 8f-2)
 # --------------------------------------------------------------------------
@@ -1012,7 +1040,9 @@ def run_afqmc(model, walkers, xi_source, r_source, nsteps, nblocks, nstblz=10,
         uni = uniform_source(step) if uniform_source is not None else None
         for iw, w in enumerate(walkers):
             if abs(w['weight']) > 1e-8:
-                if uni is not None:
+                if uni is not None and free_projection:
+                    propagate_walker_hirsch_free(model, w, uni, eshift)
+                elif uni is not None:
                     propagate_walker_hirsch(model, w, uni, eshift)
                 elif free_projection:
                     propagate_walker_free(model, w, xi_source(step, iw), eshift)

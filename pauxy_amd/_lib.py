@@ -82,6 +82,8 @@ SIGNATURES = {
     "afq_inverse_overlap": [_h, _dp, _dp],
     "afq_set_propagator_hirsch": [_h, _dp, c_double, c_int],
     "afq_propagate_hirsch": [_h, c_double],
+    "afq_hirsch_free_projection": [_h, c_int],
+    "afq_propagate_hirsch_free": [_h, _dp, c_void_p, c_double],
     "afq_hirsch_kinetic": [_h],
     "afq_hirsch_two_body": [_h, _dp, _dp, _dp],
     "afq_hirsch_finish": [_h, c_double],

@@ -1563,6 +1563,30 @@ int afq_propagate_hirsch(afq_handle *h, double eshift) {
     return k_alive(h);
 }
 
+int afq_hirsch_free_projection(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    if (!h->hirsch) AFQ_FAIL(h, AFQ_ESTATE, "afq_set_propagator_hirsch first");
+    if (on && h->nbp > 0) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "no field history in free projection");
+    // the estimators (mixed.py:151-175) and the re-orthogonalisation (walkers/handler.py:176-180) read the flag
+    if (on) h->flags |= AFQ_PROP_FREE_PROJECTION; else h->flags &= ~AFQ_PROP_FREE_PROJECTION;
+    return AFQ_OK;
+}
+
+int afq_propagate_hirsch_free(afq_handle *h, const double *u, int32_t *fields_out, double eshift) {
+    AFQ_API(h, "afq_propagate_hirsch_free");
+    if (h) h->greens_valid = false;
+    if (!h) return AFQ_EINVAL;
+    int rc = hirsch_ready(h);
+    if (rc) return rc;
+    if (!(h->flags & AFQ_PROP_FREE_PROJECTION)) AFQ_FAIL(h, AFQ_ESTATE, "afq_hirsch_free_projection(h, 1) first");
+    if ((rc = k_hirsch_alive(h, 0))) return rc;                   // the driver's test |weight| > 1e-8 (qmc/afqmc.py:232)
+    if (u) AFQ_HIP(h, hipMemcpyAsync(h->hs_u, u, sizeof(double) * (size_t)h->nw * h->M, hipMemcpyHostToDevice, h->stream));
+    else if ((rc = k_rng_uniform(h, h->hs_u, (long)h->nw * h->M))) return rc;
+    if ((rc = k_hirsch_free(h, eshift))) return rc;
+    if (fields_out && (rc = copy_out(h, fields_out, h->hs_fields, sizeof(int) * (size_t)h->nw * h->M))) return rc;
+    return k_alive(h);
+}
+
 // ---------------------------------------------------------------- back-propagation
 int afq_bp_configure(afq_handle *h, int nbp) {
     if (!h || nbp < 1) return AFQ_EINVAL;

@@ -360,6 +360,7 @@ int k_hirsch_alive(afq_handle *h, int mode);
 int k_hirsch_kinetic(afq_handle *h);
 int k_hirsch_two_body(afq_handle *h);
 int k_hirsch_eshift(afq_handle *h, double fac);
+int k_hirsch_free(afq_handle *h, double eshift);           // free-projection step from the uniforms in hs_u
 int k_rng_uniform(afq_handle *h, double *u, long n);
 // k_fullg.hip
 int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev);   // estimators/generic.py:398-434

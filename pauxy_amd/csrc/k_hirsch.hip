@@ -207,6 +207,67 @@ int k_hirsch_two_body(afq_handle *h) {
     return AFQ_OK;
 }
 
+// ---- free projection (propagation/hubbard.py:303-343): no importance sampling, every site takes field 0 or 1 with
+// probability 1/2 (r < 0.5 -> 0), row i of phi is scaled by 1 + delta[x_i, spin], wfac = prod_i aux_wfac[x_i] (in site
+// order, as the reference multiplies), then weight *= exp(dt eshift) |wfac|, phase *= exp(i arg wfac), ot = <psi_T|phi>.
+__global__ __launch_bounds__(256) void hirsch_free_sites_kernel(cplx *phi_all, const double *u, const int *alive, int *fields,
+                                                                cplx *wfac_out, int M, int nt, int na, cplx d00, cplx d01,
+                                                                cplx d10, cplx d11, cplx wf0, cplx wf1) {
+    const int w = blockIdx.x;
+    if (!alive[w]) return;
+    cplx *phi = phi_all + (long)w * M * nt;
+    const double *uw = u + (long)w * M;
+    for (int e = threadIdx.x; e < M * nt; e += blockDim.x) {
+        const int i = e / nt, c = e - i * nt;
+        const int xi = uw[i] < 0.5 ? 0 : 1;                                  // :326-330
+        const cplx d = xi == 0 ? (c < na ? d00 : d01) : (c < na ? d10 : d11);
+        const cplx v = phi[e];
+        phi[e] = cadd(v, cmul(v, d));                                         // phi + phi * delta, :331-334
+    }
+    if (threadIdx.x == 0) {
+        cplx wf = cmake(1.0, 0.0);
+        for (int i = 0; i < M; ++i) {
+            const int xi = uw[i] < 0.5 ? 0 : 1;
+            fields[(long)w * M + i] = xi;
+            wf = cmul(wf, xi == 0 ? wf0 : wf1);                               // :335
+        }
+        wfac_out[w] = wf;
+    }
+}
+
+__global__ void hirsch_free_weight_kernel(double *weight, cplx *phase, cplx *ot, const cplx *ot_new, const cplx *wfac,
+                                          const int *alive, int nw, double efac, double scale) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw || !alive[w]) return;
+    const cplx wf = wfac[w];
+    const double magn = hypot(wf.x, wf.y), dtheta = atan2(wf.y, wf.x);        // cmath.polar(wfac), :341
+    weight[w] *= efac * magn;                                                 // :342
+    double sn, cs;
+    sincos(dtheta, &sn, &cs);
+    phase[w] = cmul(phase[w], cmake(cs, sn));                                 // :343
+    ot[w] = cscale(ot_new[w], scale);                                         // :344
+}
+
+int k_hirsch_free(afq_handle *h, double eshift) {
+    int rc;
+    if ((rc = k_onebody(h))) return rc;                                       // kinetic_real, :320
+    {
+        const long n = (long)h->nw * h->M;
+        AFQ_LAUNCH(h, hirsch_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_fields, n);
+        AFQ_POST(h);
+    }
+    AFQ_LAUNCH(h, hirsch_free_sites_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->phi, h->hs_u, h->alive, h->hs_fields,
+               h->cmf, h->M, h->nt, h->na, h->hs_delta[0][0], h->hs_delta[0][1], h->hs_delta[1][0], h->hs_delta[1][1],
+               h->hs_wfac[0], h->hs_wfac[1]);
+    AFQ_POST(h);
+    if ((rc = k_onebody(h))) return rc;                                       // :336
+    if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;      // :337-339
+    AFQ_LAUNCH(h, hirsch_free_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->phase, h->ot,
+               h->ovlp_new, h->cmf, h->alive, h->nw, exp(h->dt * eshift), h->log_shift_on ? exp(h->log_shift) : 1.0);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
 int k_hirsch_eshift(afq_handle *h, double fac) {
     AFQ_LAUNCH(h, hirsch_eshift_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->hs_alive0,
                        h->nw, fac);

@@ -4,10 +4,10 @@
 // the sparse iA / iB (a column per field), and scatters the shifted fields back through iA / iB into a dense M x M HS
 // potential that the Taylor series then multiplies six times.  Two structural facts of a plane-wave Hamiltonian make all
 // three M x M objects unnecessary (both are CHECKED at upload on the matrices the caller hands over, not assumed):
-//   * an element (i, j) of the HS potential receives at most ONE entry of iA and ONE of iB (the momentum transfer
-//     k_i - k_j fixes the field), and the distinct (field, value) combinations are few: V[w][i, j] = c[w][id(i, j)] with
-//     c[w][id] = sqrt(dt) (vA_id xs[w][qA_id] + vB_id xs[w][nq + qB_id]) -- about 2 nq coefficients per walker (24 KB at
-//     C2) and one int16 map id(i, j) shared by all walkers;
+//   * an element (i, j) of the HS potential receives a handful of entries of [iA | iB] (the momentum transfer k_i - k_j
+//     fixes the fields: +q and -q of iA and of iB, four terms), and the DISTINCT term lists are few -- one per momentum
+//     transfer: V[w][i, j] = c[w][id(i, j)] with c[w][id] = sqrt(dt) sum_t v_t xs[w][n_t] -- a few hundred coefficients
+//     per walker (9 KB at C2) and one int16 map id(i, j) shared by all walkers;
 //   * the trial occupies few orbitals: G_s = conj(psi_s) Ghalf_s has non-zero rows only where psi has non-zero rows (the
 //     7 + 7 occupied plane waves of the Hartree-Fock trial), so the force bias gathers from `nrows` rows of
 //     G_up + G_dn, built from Ghalf in LDS, with a per-field list restricted to those rows (~14 entries instead of ~190).
@@ -32,9 +32,12 @@
 
 namespace {
 
-constexpr int UF_NT = 512;              // threads of both kernels
+constexpr int UF_NT = 512;              // threads of the propagator
+constexpr int UF_NTF = 1024;            // threads of the field kernel: latency bound (dependent table / LDS gathers, the
+                                        // Philox + Box-Muller chain), one work-group per CU -- 16 waves hide twice as much as 8
 constexpr int UF_MAX_COEF = 4095;       // coefficients per walker that fit the LDS budget with room to spare
 constexpr int UF_MAX_ROWS = 32;
+constexpr int UF_TERMS = 8;             // entries of [iA | iB] one element of the HS potential may collect
 
 struct UegFast {
     // host copies of the sparse operators (the trial-dependent tables are rebuilt at afq_set_trial)
@@ -44,15 +47,18 @@ struct UegFast {
     // element structure
     bool elem_ok = false;
     int ncoef = 0, Mp = 0;
-    short *elem_id = nullptr;       // [Mp][Mp] coefficient of element (i, j); ncoef = the zero coefficient
-    int *coef_q = nullptr;          // [ncoef][2] field of the iA / iB entry, -1 without
-    cplx *coef_v = nullptr;         // [ncoef][2] their values
+    short *elem_id = nullptr;       // [nrt][nks][64] coefficient of element (i, k) in MFMA A-fragment order: row tile rt,
+                                    // k-step ks, lane (k & 3) * 16 + (i & 15); ncoef = the zero coefficient
+    int nterms = 0;                 // terms per coefficient (padded with field -1)
+    int *coef_q = nullptr;          // [ncoef][nterms] fields n_t (index into the K shifted fields), -1 = no term
+    cplx *coef_v = nullptr;         // [ncoef][nterms] values v_t
     // trial structure
     bool trial_ok = false;
-    int nrows = 0, fb_len = 0;
+    int nrows = 0;
     cplx *psic_rows = nullptr;      // [nrows][nt] conj(psi[row, :])
-    int *fb_idx = nullptr;          // [fb_len][K] index into the compact G (row slot * M + column); padded entries carry a zero value
-    cplx *fb_val = nullptr;         // [fb_len][K]
+    int *fb_off = nullptr;          // [K + 1] entries of field n: fb_off[n] .. fb_off[n + 1]  (1.7 on average at C2, at most 14)
+    int *fb_idx = nullptr;          // index into the compact G (row slot * M + column)
+    cplx *fb_val = nullptr;
     // walkers
     cplx *vcoef = nullptr;          // [nw][ncoef + 1]
     int vcoef_nw = 0;
@@ -73,10 +79,11 @@ template <class T> int upload_vec(afq_handle *h, T **dst, const std::vector<T> &
 
 // ------------------------------------------------------------------------------------------------ fields
 struct UegFieldArgs {
-    int M, nt, K, nq, nrows, fb_len, ncoef;
+    int M, nt, K, nq, nrows, ncoef, nterms;
     double sqrt_dt;
     const cplx *ghalf;          // [nw, nt, M]
     const cplx *psic_rows;      // [nrows, nt]
+    const int *fb_off;
     const int *fb_idx;
     const cplx *fb_val;
     const int *coef_q;
@@ -89,11 +96,11 @@ struct UegFieldArgs {
     int force_bias;             // AFQ_PROP_FORCE_BIAS set
 };
 
-__global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, FieldRng rng) {
+__global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, FieldRng rng) {
     extern __shared__ __align__(16) unsigned char smem[];
     cplx *gc = (cplx *)smem;                                 // [nrows][M] rows of G_up + G_dn
     cplx *xl = gc + (size_t)a.nrows * a.M;                   // [K] shifted fields
-    __shared__ double red[UF_NT / 64][8];
+    __shared__ double red[UF_NTF / 64][8];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (rng.on) {
         const bool live = fabs(rng.weight[w]) > 1e-8;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, Field
     } else if (a.alive && !a.alive[w]) return;
     // rows of G_up + G_dn that are not identically zero: sum over ALL columns of the trial (both spins) of conj(psi[row, c]) Ghalf[c, :]
     const cplx *gh = a.ghalf + (long)w * a.nt * a.M;
-    for (int e = tid; e < a.nrows * a.M; e += UF_NT) {
+    for (int e = tid; e < a.nrows * a.M; e += UF_NTF) {
         const int rr = e / a.M, j = e - rr * a.M;
         cplx acc = cmake(0.0, 0.0);
         for (int c = 0; c < a.nt; ++c) cfma(acc, a.psic_rows[rr * a.nt + c], gh[(long)c * a.M + j]);
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, Field
         if (a.force_bias) {
             // propagation/planewave.py:70-76: vbias[n] = (G_up + G_dn) . column n of [iA | iB], xbar = -sqrt(dt) vbias
             cplx v = cmake(0.0, 0.0);
-            for (int k = 0; k < a.fb_len; ++k) cfma(v, a.fb_val[(long)k * K + n], gc[a.fb_idx[(long)k * K + n]]);
+            for (int z = a.fb_off[n], z1 = a.fb_off[n + 1]; z < z1; ++z) cfma(v, a.fb_val[z], gc[a.fb_idx[z]]);
             b = cmake(-a.sqrt_dt * v.x, -a.sqrt_dt * v.y);
         }
         const double ab = hypot(b.x, b.y);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, Field
     };
     // a thread takes the two members of one Philox pair (the stream of fields_kernel: element e = w K + n is member e & 1
     // of pair e >> 1)
-    for (long pr = (e0 >> 1) + tid; pr <= ((e0 + K - 1) >> 1); pr += UF_NT) {
+    for (long pr = (e0 >> 1) + tid; pr <= ((e0 + K - 1) >> 1); pr += UF_NTF) {
         double xn[2] = {0.0, 0.0};
         if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
 #pragma unroll
@@ -160,20 +167,21 @@ __global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, Field
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
             t[q] = 0.0;
-            for (int i = 0; i < UF_NT / 64; ++i) t[q] += red[i][q];
+            for (int i = 0; i < UF_NTF / 64; ++i) t[q] += red[i][q];
         }
         a.cmf[w] = cmake(-a.sqrt_dt * t[0], -a.sqrt_dt * t[1]);
         a.cfb[w] = cmake(t[2] - 0.5 * t[4], t[3] - 0.5 * t[5]);
         if (t[6] > 0 && a.counters) atomicAdd(&a.counters[0], (unsigned long long)t[6]);
     }
-    // coefficients of the HS potential (propagation/planewave.py:109-112): c[id] = sqrt(dt) (vA xs[qA] + vB xs[nq + qB])
+    // coefficients of the HS potential (propagation/planewave.py:109-112): c[id] = sqrt(dt) sum_t v_t xs[n_t]
     cplx *vc = a.vcoef + (long)w * (a.ncoef + 1);
-    for (int id = tid; id <= a.ncoef; id += UF_NT) {
+    for (int id = tid; id <= a.ncoef; id += UF_NTF) {
         cplx c = cmake(0.0, 0.0);
         if (id < a.ncoef) {
-            const int qa = a.coef_q[2 * id], qb = a.coef_q[2 * id + 1];
-            if (qa >= 0) cfma(c, a.coef_v[2 * id], xl[qa]);
-            if (qb >= 0) cfma(c, a.coef_v[2 * id + 1], xl[a.nq + qb]);
+            for (int t = 0; t < a.nterms; ++t) {
+                const int n = a.coef_q[id * a.nterms + t];
+                if (n >= 0) cfma(c, a.coef_v[id * a.nterms + t], xl[n]);
+            }
             c = cmake(a.sqrt_dt * c.x, a.sqrt_dt * c.y);
         }
         vc[id] = c;
@@ -183,20 +191,24 @@ __global__ __launch_bounds__(UF_NT) void ueg_fields_kernel(UegFieldArgs a, Field
 // ------------------------------------------------------------------------------------------------ propagator
 struct PropUegArgs {
     int M, na, nb, nt, order, ncoef, Mp, nrt, nks;
-    const short *elem_id;       // [Mp][Mp]
+    const short *elem_id;       // [nrt][nks][64] fragment order
     const cplx *vcoef;          // [nw][ncoef + 1]
     const cplx *bdiag;          // [2][M]
     cplx *phi;                  // [nw][M][nt], updated in place
     const int *alive;
 };
 
-// One 512-thread work-group per live walker.  Matrix product C = V T with V [Mp x Mp] (never stored: element (i, k) is
-// coef[id[i][k]], both in LDS) and T [Mp x 16] (both spins side by side in the one column tile; LDS, B-fragment order:
-// k-step ks = 4 rows of T, lane (k & 3) * 16 + column, 16 bytes each).  The nrt row tiles of C times two halves of the
-// contraction are the 2 nrt units of a product, dealt to the 8 waves (unit u -> wave u & 7): with 6 row tiles every SIMD
-// carries 3 units.  The second-half units park their partial tile in LDS, the first-half unit of the same row tile adds
-// it, scales by 1 / n (Taylor term n), adds it to the running sum it keeps in registers and writes it back into T for the
-// next product: two barriers per product.
+// One 512-thread work-group per live walker.  Matrix product C = V T with V [Mp x Mp] (never stored in memory: element
+// (i, k) is coef[id[i][k]], both staged in LDS) and T [Mp x 16] (both spins side by side in the one column tile; LDS,
+// B-fragment order: k-step ks = 4 rows of T, lane (k & 3) * 16 + column, 16 bytes each).  The nrt row tiles of C times
+// two halves of the contraction are the 2 nrt units of a product, dealt to the 8 waves (unit u -> wave u & 7): with 6 row
+// tiles every SIMD carries 3 units.  A wave's units are the same in all `order` products, so it gathers its operand
+// fragments of V ONCE (id map and coefficients through LDS, bank-conflicted 16-byte gathers) and keeps them -- re, im and
+// re + im for the 3-multiplication product -- in registers: per product only the T fragments (conflict-free, lane-linear)
+// come from LDS.  The second-half units park their partial tile in LDS, the first-half unit of the same row tile adds it,
+// scales by 1 / n (Taylor term n), adds it to the running sum it keeps in registers and writes it back into T for the
+// next product: two barriers per product.  KSU = k-steps per unit (ceil(nks / 2), compile time: static register indices).
+template <int KSU>
 __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = blockIdx.x;
@@ -204,14 +216,12 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int M = a.M, nt = a.nt, Mp = a.Mp, nrt = a.nrt, nks = a.nks;
-    // ---- LDS carve: coefficients | id map | T | partial tiles
+    // ---- LDS carve: coefficients | T | partial tiles
     cplx *coef = (cplx *)smem;                                                   // [ncoef + 1]
-    short *idm = (short *)(smem + (((size_t)(a.ncoef + 1) * 16 + 15) & ~(size_t)15));   // [Mp][Mp]
-    unsigned char *Tb = (unsigned char *)idm + (((size_t)Mp * Mp * 2 + 15) & ~(size_t)15);   // [nks][1024]
+    unsigned char *Tb = smem + (((size_t)(a.ncoef + 1) * 16 + 15) & ~(size_t)15);   // [nks][1024]
     unsigned char *Pb = Tb + (size_t)nks * 1024;                                  // [nrt][2][4][64] doubles (re / im)
     const cplx *vc = a.vcoef + (long)w * (a.ncoef + 1);
     for (int i = tid; i <= a.ncoef; i += UF_NT) coef[i] = vc[i];
-    for (int i = tid; i < Mp * Mp / 2; i += UF_NT) ((int *)idm)[i] = ((const int *)a.elem_id)[i];
     cplx *phi = a.phi + (long)w * M * nt;
     // ---- units of this wave: u = wave and wave + 8; unit u: half kh = u / nrt of the contraction, row tile rt = u % nrt.
     // The kh == 0 unit of a row tile owns that tile of the running sum S and of T.
@@ -220,12 +230,11 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
     const bool has0 = u0 < nunits, has1 = u1 < nunits;
     const int rt0 = has0 ? u0 % nrt : 0, kh0 = has0 ? u0 / nrt : 0;
     const int rt1 = has1 ? u1 % nrt : 0, kh1 = has1 ? u1 / nrt : 0;
-    const int ksplit = (nks + 1) >> 1;                           // k-steps [0, ksplit) and [ksplit, nks)
+    const int ksplit = (nks + 1) >> 1;                           // k-steps [0, ksplit) and [ksplit, nks); ksplit <= KSU
     // element (row 4 r + lk of the tile, column lr) of a tile in accumulator layout <-> T entry (k-step rt * 4 + r, lane)
     const bool col_ok = lr < nt;
     const int spin = lr < a.na ? 0 : 1;
-    // S tile(s) this wave owns (kh == 0 units): at most two (u0 always kh == 0 when it exists and wave < nrt; u1 = wave + 8
-    // is a kh == 0 unit only when nrt > 8, which M <= 112 excludes)
+    // (u0 is a kh == 0 unit whenever wave < nrt; u1 = wave + 8 never is: nrt <= 7)
     const bool own = has0 && kh0 == 0;
     d4_t Sr = {0, 0, 0, 0}, Si = {0, 0, 0, 0};
     // ---- T_0 = B phi (row scaling), S = T_0
@@ -240,46 +249,67 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
         }
     }
     __syncthreads();
-    const unsigned coef_l = lds_addr(coef), id_l = lds_addr(idm), t_l = lds_addr(Tb);
-    // one unit: rows rt * 16 .. + 15 of V times T over k-steps [k0, k1): returns the (re, im) partial tile
-    auto unit = [&](const int rt, const int k0, const int k1, d4_t &Cr, d4_t &Ci) __attribute__((always_inline)) {
+    // ---- operand fragments of V for this wave's units: lane (lr, lk) holds V[rt * 16 + lr][4 ks + lk] for its k-steps.
+    // The coefficient ids come lane-contiguous from the fragment-ordered map (one 128-byte line per fragment, all loads in
+    // flight together, L2 resident: the map is the same for every walker), the coefficients from LDS.
+    double ar0[KSU], ai0[KSU], as0[KSU], ar1[KSU], ai1[KSU], as1[KSU];
+    const int k00 = kh0 ? ksplit : 0, n0 = has0 ? (kh0 ? nks - ksplit : ksplit) : 0;
+    const int k10 = kh1 ? ksplit : 0, n1 = has1 ? (kh1 ? nks - ksplit : ksplit) : 0;
+    {
+        short id0[KSU], id1[KSU];
+#pragma unroll
+        for (int j = 0; j < KSU; ++j) {
+            id0[j] = j < n0 ? a.elem_id[((long)rt0 * nks + k00 + j) * 64 + lane] : (short)a.ncoef;
+            id1[j] = j < n1 ? a.elem_id[((long)rt1 * nks + k10 + j) * 64 + lane] : (short)a.ncoef;
+        }
+#pragma unroll
+        for (int j = 0; j < KSU; ++j) {
+            const cplx v0 = coef[id0[j]], v1 = coef[id1[j]];
+            ar0[j] = v0.x; ai0[j] = v0.y; as0[j] = v0.x + v0.y;
+            ar1[j] = v1.x; ai1[j] = v1.y; as1[j] = v1.x + v1.y;
+        }
+    }
+    const unsigned t_l = lds_addr(Tb);
+    // one unit: its rows of V (registers) times T over its k-steps (k-steps beyond the unit's count multiply zeros: never
+    // more than one, nks = 2 KSU or 2 KSU - 1)
+    auto unit = [&](const double (&ar)[KSU], const double (&ai)[KSU], const double (&as)[KSU], const int k0, const int cnt,
+                    d4_t &Cr, d4_t &Ci) __attribute__((always_inline)) {
         d4_t P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0}, P3 = {0, 0, 0, 0};
-        const unsigned idrow = id_l + (unsigned)((rt * 16 + lr) * Mp + lk) * 2;      // id[row][4 ks + lk]
-        // software pipeline, depth 2: the id of k-step ks + 2 and the coefficient of ks + 1 are in flight under the MFMAs of ks
-        auto ld_id = [&](int ks) -> int {
-            int v;
-            asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(idrow + (unsigned)ks * 8));
-            return v;
-        };
-        int idn = 0, idnn = 0;
-        d2_t an = {0, 0}, bn = {0, 0};
-        idn = ld_id(k0);
-        if (k0 + 1 < k1) idnn = ld_id(k0 + 1);
+        d2_t b[KSU];
+#pragma unroll
+        for (int j = 0; j < KSU; ++j) {
+            const int ks = k0 + (j < cnt ? j : 0);
+            b[j] = lds_read_b128(t_l + (unsigned)ks * 1024 + lane * 16);
+        }
+        // LDS returns in order: the first half of the fragments has landed when at most KSU - KSU / 2 reads are outstanding
+        // (the sched_barriers keep the MFMAs, which the compiler sees no dependence for, behind the waits)
+        constexpr int H = KSU / 2;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KSU - H) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            P1 = mfma16(ar[j], b[j][0], P1);
+            P2 = mfma16(ai[j], b[j][1], P2);
+            P3 = mfma16(as[j], b[j][0] + b[j][1], P3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        an = lds_read_b128(coef_l + (unsigned)idn * 16);
-        bn = lds_read_b128(t_l + (unsigned)k0 * 1024 + lane * 16);
-        for (int ks = k0; ks < k1; ++ks) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const d2_t av = an, bv = bn;
-            const int idc = idnn;
-            if (ks + 1 < k1) {
-                an = lds_read_b128(coef_l + (unsigned)idc * 16);
-                bn = lds_read_b128(t_l + (unsigned)(ks + 1) * 1024 + lane * 16);
-            }
-            if (ks + 2 < k1) idnn = ld_id(ks + 2);
-            P1 = mfma16(av[0], bv[0], P1);
-            P2 = mfma16(av[1], bv[1], P2);
-            P3 = mfma16(av[0] + av[1], bv[0] + bv[1], P3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = H; j < KSU; ++j) {
+            P1 = mfma16(ar[j], b[j][0], P1);
+            P2 = mfma16(ai[j], b[j][1], P2);
+            P3 = mfma16(as[j], b[j][0] + b[j][1], P3);
         }
         Cr = P1 - P2;
         Ci = P3 - P1 - P2;
     };
     for (int n = 1; n <= a.order; ++n) {
         d4_t C0r = {0, 0, 0, 0}, C0i = {0, 0, 0, 0}, C1r, C1i;
-        if (has0) unit(rt0, kh0 ? ksplit : 0, kh0 ? nks : ksplit, C0r, C0i);
+        if (has0) unit(ar0, ai0, as0, k00, n0, C0r, C0i);
         if (has1) {
-            unit(rt1, kh1 ? ksplit : 0, kh1 ? nks : ksplit, C1r, C1i);
-            // (u1 is always a second-half unit here: park the partial tile)
+            unit(ar1, ai1, as1, k10, n1, C1r, C1i);
+            // (u1 is always a second-half unit: park the partial tile)
             double *p = (double *)Pb + (size_t)rt1 * 512;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { p[r * 64 + lane] = C1r[r]; p[256 + r * 64 + lane] = C1i[r]; }
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
 void k_ueg_fast_free(afq_handle *h) {
     UegFast *f = uf_of(h);
     if (!f) return;
-    for (void *p : {(void *)f->elem_id, (void *)f->coef_q, (void *)f->coef_v, (void *)f->psic_rows, (void *)f->fb_idx,
+    for (void *p : {(void *)f->elem_id, (void *)f->coef_q, (void *)f->coef_v, (void *)f->psic_rows, (void *)f->fb_off, (void *)f->fb_idx,
                     (void *)f->fb_val, (void *)f->vcoef, (void *)f->bdiag})
         if (p) hipFree(p);
     delete f;
@@ -335,46 +365,58 @@ int k_ueg_fast_system(afq_handle *h, int M, int nq, const int64_t *Acp, const in
     f->Arow.assign(Arow, Arow + Acp[nq]); f->Brow.assign(Brow, Brow + Bcp[nq]);
     f->Aval.assign(Aval, Aval + 2 * Acp[nq]); f->Bval.assign(Bval, Bval + 2 * Bcp[nq]);
     const long mm = (long)M * M;
-    std::vector<int> qa(mm, -1), qb(mm, -1);
-    std::vector<double> va(2 * mm, 0.0), vb(2 * mm, 0.0);
-    bool ok = M <= 112;
-    for (int pass = 0; pass < 2 && ok; ++pass) {
+    if (M > 112) return AFQ_OK;          // general kernels
+    // terms of every element, in the order of the fields (iA columns 0 .. nq - 1, then iB columns as fields nq ..)
+    typedef std::vector<std::tuple<int, double, double>> Terms;
+    std::vector<Terms> terms(mm);
+    for (int pass = 0; pass < 2; ++pass) {
         const int64_t *cp = pass ? Bcp : Acp, *row = pass ? Brow : Arow;
         const double *val = pass ? Bval : Aval;
-        std::vector<int> &q_ = pass ? qb : qa;
-        std::vector<double> &v_ = pass ? vb : va;
-        for (int q = 0; q < nq && ok; ++q)
+        for (int q = 0; q < nq; ++q)
             for (int64_t z = cp[q]; z < cp[q + 1]; ++z) {
                 const int64_t e = row[z];
-                if (e < 0 || e >= mm || q_[e] >= 0) { ok = false; break; }       // a second entry for this element
-                q_[e] = q; v_[2 * e] = val[2 * z]; v_[2 * e + 1] = val[2 * z + 1];
+                if (e < 0 || e >= mm) return AFQ_OK;
+                terms[e].emplace_back(pass * nq + q, val[2 * z], val[2 * z + 1]);
+                if ((int)terms[e].size() > UF_TERMS) return AFQ_OK;
             }
     }
-    if (!ok) return AFQ_OK;              // general kernels
-    typedef std::tuple<int, double, double, int, double, double> Key;
-    std::map<Key, int> ids;
-    std::vector<int> cq;
-    std::vector<cplx> cv;
+    std::map<Terms, int> ids;
+    std::vector<const Terms *> order;
     const int Mp = ((M + 15) / 16) * 16;
     std::vector<short> eid((size_t)Mp * Mp, (short)-1);
+    int nterms = 1;
     for (long e = 0; e < mm; ++e) {
-        if (qa[e] < 0 && qb[e] < 0) continue;
-        const Key key(qa[e], va[2 * e], va[2 * e + 1], qb[e], vb[2 * e], vb[2 * e + 1]);
-        auto it = ids.find(key);
+        if (terms[e].empty()) continue;
+        auto it = ids.find(terms[e]);
         int id;
         if (it == ids.end()) {
             id = (int)ids.size();
             if (id >= UF_MAX_COEF) return AFQ_OK;
-            ids.emplace(key, id);
-            cq.push_back(qa[e]); cq.push_back(qb[e]);
-            cv.push_back(cmake(va[2 * e], va[2 * e + 1])); cv.push_back(cmake(vb[2 * e], vb[2 * e + 1]));
+            it = ids.emplace(terms[e], id).first;
+            order.push_back(&it->first);
+            nterms = std::max(nterms, (int)terms[e].size());
         } else id = it->second;
         eid[(size_t)(e / M) * Mp + (e % M)] = (short)id;
     }
+    std::vector<int> cq((size_t)ids.size() * nterms, -1);
+    std::vector<cplx> cv((size_t)ids.size() * nterms, cmake(0.0, 0.0));
+    for (size_t id = 0; id < order.size(); ++id)
+        for (size_t t = 0; t < order[id]->size(); ++t) {
+            cq[id * nterms + t] = std::get<0>((*order[id])[t]);
+            cv[id * nterms + t] = cmake(std::get<1>((*order[id])[t]), std::get<2>((*order[id])[t]));
+        }
+    f->nterms = nterms;
     f->ncoef = (int)ids.size(); f->Mp = Mp;
     for (short &s : eid) if (s < 0) s = (short)f->ncoef;            // the zero coefficient
+    // A-fragment order: what lane (lr, lk) of a wave multiplying row tile rt at k-step ks needs is element
+    // (rt * 16 + lr, 4 ks + lk); stored lane-contiguous so that a wave's load of one fragment is one 128-byte line
+    std::vector<short> frag((size_t)Mp * Mp);
+    for (int rt = 0; rt < Mp / 16; ++rt)
+        for (int ks = 0; ks < Mp / 4; ++ks)
+            for (int l = 0; l < 64; ++l)
+                frag[((size_t)rt * (Mp / 4) + ks) * 64 + l] = eid[(size_t)(rt * 16 + (l & 15)) * Mp + 4 * ks + (l >> 4)];
     int rc;
-    if ((rc = upload_vec(h, &f->elem_id, eid))) return rc;
+    if ((rc = upload_vec(h, &f->elem_id, frag))) return rc;
     if ((rc = upload_vec(h, &f->coef_q, cq))) return rc;
     if ((rc = upload_vec(h, &f->coef_v, cv))) return rc;
     f->elem_ok = true;
@@ -401,8 +443,8 @@ int k_ueg_fast_trial(afq_handle *h, const double *psi) {
         for (int c = 0; c < nt; ++c)
             pr[(size_t)rr * nt + c] = cmake(psi[2 * ((size_t)rows[rr] * nt + c)], -psi[2 * ((size_t)rows[rr] * nt + c) + 1]);
     // per field n (column of [iA | iB]): the entries whose row of G is occupied
-    std::vector<std::vector<std::pair<int, cplx>>> lists(K);
-    int L = 0;
+    std::vector<int> fo(K + 1, 0), fi;
+    std::vector<cplx> fv;
     for (int n = 0; n < K; ++n) {
         const bool isB = n >= nq;
         const int q = isB ? n - nq : n;
@@ -410,18 +452,13 @@ int k_ueg_fast_trial(afq_handle *h, const double *psi) {
         const std::vector<double> &val = isB ? f->Bval : f->Aval;
         for (int64_t z = cp[q]; z < cp[q + 1]; ++z) {
             const int i = (int)(row[z] / M), j = (int)(row[z] % M);
-            if (slot[i] >= 0) lists[n].emplace_back(slot[i] * M + j, cmake(val[2 * z], val[2 * z + 1]));
+            if (slot[i] >= 0) { fi.push_back(slot[i] * M + j); fv.push_back(cmake(val[2 * z], val[2 * z + 1])); }
         }
-        L = std::max(L, (int)lists[n].size());
+        fo[n + 1] = (int)fi.size();
     }
-    if (L == 0) L = 1;
-    f->fb_len = L;
-    std::vector<int> fi((size_t)L * K, 0);
-    std::vector<cplx> fv((size_t)L * K, cmake(0.0, 0.0));
-    for (int n = 0; n < K; ++n)
-        for (size_t k = 0; k < lists[n].size(); ++k) { fi[k * K + n] = lists[n][k].first; fv[k * K + n] = lists[n][k].second; }
     int rc;
     if ((rc = upload_vec(h, &f->psic_rows, pr))) return rc;
+    if ((rc = upload_vec(h, &f->fb_off, fo))) return rc;
     if ((rc = upload_vec(h, &f->fb_idx, fi))) return rc;
     if ((rc = upload_vec(h, &f->fb_val, fv))) return rc;
     f->trial_ok = true;
@@ -474,15 +511,15 @@ int k_ueg_fields(afq_handle *h) {
         h->rng_inline = false;
     }
     UegFieldArgs a;
-    a.M = h->M; a.nt = h->nt; a.K = h->K; a.nq = h->nq; a.nrows = f->nrows; a.fb_len = f->fb_len; a.ncoef = f->ncoef;
-    a.sqrt_dt = h->sqrt_dt; a.ghalf = h->ghalf; a.psic_rows = f->psic_rows; a.fb_idx = f->fb_idx; a.fb_val = f->fb_val;
-    a.coef_q = f->coef_q; a.coef_v = f->coef_v; a.xi = h->xi; a.mf = h->mf_shift; a.xbar = h->xbar; a.xs = h->xs;
+    a.M = h->M; a.nt = h->nt; a.K = h->K; a.nq = h->nq; a.nrows = f->nrows; a.ncoef = f->ncoef;
+    a.sqrt_dt = h->sqrt_dt; a.ghalf = h->ghalf; a.psic_rows = f->psic_rows; a.fb_off = f->fb_off; a.fb_idx = f->fb_idx; a.fb_val = f->fb_val;
+    a.nterms = f->nterms; a.coef_q = f->coef_q; a.coef_v = f->coef_v; a.xi = h->xi; a.mf = h->mf_shift; a.xbar = h->xbar; a.xs = h->xs;
     a.cmf = h->cmf; a.cfb = h->cfb; a.vcoef = f->vcoef; a.counters = h->counters; a.alive = h->alive;
     a.force_bias = (h->flags & AFQ_PROP_FORCE_BIAS) ? 1 : 0;
     const size_t lds = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K);
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)ueg_fields_kernel, lds, lds_set));
-    AFQ_LAUNCH(h, ueg_fields_kernel, dim3(h->nw), dim3(UF_NT), lds, h->stream, a, rng);
+    AFQ_LAUNCH(h, ueg_fields_kernel, dim3(h->nw), dim3(UF_NTF), lds, h->stream, a, rng);
     AFQ_POST(h);
     return AFQ_OK;
 }
@@ -493,14 +530,27 @@ int k_prop_ueg(afq_handle *h) {
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order; a.ncoef = f->ncoef; a.Mp = f->Mp;
     a.nrt = f->Mp / 16; a.nks = f->Mp / 4;
     a.elem_id = f->elem_id; a.vcoef = f->vcoef; a.bdiag = f->bdiag; a.phi = h->phi; a.alive = h->alive;
-    const size_t lds = (((size_t)(f->ncoef + 1) * 16 + 15) & ~(size_t)15) + (((size_t)f->Mp * f->Mp * 2 + 15) & ~(size_t)15) +
-                       (size_t)a.nks * 1024 + (size_t)a.nrt * 4096;
-    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
-    AFQ_HIP(h, afq_raise_lds((const void *)prop_ueg_kernel, lds, lds_set));
+    const size_t lds = (((size_t)(f->ncoef + 1) * 16 + 15) & ~(size_t)15) + (size_t)a.nks * 1024 + (size_t)a.nrt * 4096;
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
-    // matrix-pipe flops: order products x row tiles x k-steps x 3 multiplications x 2048
-    h->issued_flops[AFQ_K_PROPAGATOR] = 3.0 * h->exp_order * a.nrt * a.nks * 2048.0 * h->nw;
-    AFQ_LAUNCH(h, prop_ueg_kernel, dim3(h->nw), dim3(UF_NT), lds, h->stream, a);
+    // matrix-pipe flops: order products x 2 nrt units x KSU k-steps x 3 multiplications x 2048
+    const int ksu = (a.nks + 1) / 2;
+    h->issued_flops[AFQ_K_PROPAGATOR] = 3.0 * h->exp_order * 2.0 * a.nrt * ksu * 2048.0 * h->nw;
+#define PU_LAUNCH_(KSU_, SLOT_)                                                                                \
+    do {                                                                                                      \
+        static size_t lds_set_[AFQ_MAX_DEVICES] = {0};                                                        \
+        AFQ_HIP(h, afq_raise_lds((const void *)prop_ueg_kernel<KSU_>, lds, lds_set_));                        \
+        AFQ_LAUNCH(h, prop_ueg_kernel<KSU_>, dim3(h->nw), dim3(UF_NT), lds, h->stream, a);                    \
+    } while (0)
+    switch (ksu) {
+    case 2: PU_LAUNCH_(2, 0); break;
+    case 4: PU_LAUNCH_(4, 1); break;
+    case 6: PU_LAUNCH_(6, 2); break;
+    case 8: PU_LAUNCH_(8, 3); break;
+    case 10: PU_LAUNCH_(10, 4); break;
+    case 12: PU_LAUNCH_(12, 5); break;
+    default: PU_LAUNCH_(14, 6); break;
+    }
+#undef PU_LAUNCH_
     AFQ_POST(h);
     return AFQ_OK;
 }

@@ -129,6 +129,16 @@ class AfqDevice(object):
     def propagate_hirsch(self, eshift):
         self._ck(self.lib.afq_propagate_hirsch(self.h, float(numpy.real(eshift))))
 
+    def hirsch_free_projection(self, on=True):
+        self._ck(self.lib.afq_hirsch_free_projection(self.h, 1 if on else 0))
+
+    def propagate_hirsch_free(self, u, eshift, fetch_fields=False):
+        """propagation/hubbard.py:303-343 for every walker with |weight| > 1e-8; u [nw, M] or None (device stream)."""
+        u_ = None if u is None else _f64(u, (self.nw, self.M))
+        fields = numpy.zeros((self.nw, self.M), dtype=numpy.int32) if fetch_fields else None
+        self._ck(self.lib.afq_propagate_hirsch_free(self.h, _p(u_), _p(fields), float(eshift)))
+        return fields
+
     def hirsch_kinetic(self):
         self._ck(self.lib.afq_hirsch_kinetic(self.h))
 

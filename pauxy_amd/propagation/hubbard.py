@@ -1,7 +1,8 @@
 """Discrete Hirsch Hubbard-Stratonovich propagator on the device.
 
 Mirrors pauxy/propagation/hubbard.py:12-343 (``Hirsch``) for RHF/UHF-type single-determinant
-trials with the classic single-site update: same constructor signature, the same constants
+trials with the classic single-site update (constrained path, and ``free_projection: True`` =
+``propagate_walker_free``, :303-343): same constructor signature, the same constants
 (``bt2``, ``BT_BP``, ``gamma``, ``auxf``, ``aux_wfac``, ``delta``), ``hybrid == False`` and the
 ``propagate_walker(walker, system, trial, eshift)`` entry point the driver calls per walker.
 
@@ -27,8 +28,6 @@ class Hirsch(object):
         if options.get('ffts', False):
             raise NotImplementedError("k-space kinetic propagation is not on the device path")
         self.free_projection = options.get('free_projection', False)
-        if self.free_projection:
-            raise NotImplementedError("free projection with the discrete transformation is not on the device path")
         self.bt2 = numpy.array([scipy.linalg.expm(-0.5 * qmc.dt * system.T[0]),
                                 scipy.linalg.expm(-0.5 * qmc.dt * system.T[1])])          # hubbard.py:36-37
         self.BT_BP = self.bt2
@@ -58,7 +57,9 @@ class Hirsch(object):
         if self.device_rng:
             self.dev.rng_seed(options.get('rng_seed', getattr(qmc, 'rng_seed', 0) or 0),
                               options.get('rng_stream', self.dev.device_id))
-        self.propagate_walker = self.propagate_walker_constrained
+        if self.free_projection:                                                          # hubbard.py:84-89
+            self.dev.hirsch_free_projection(True)
+        self.propagate_walker = self.propagate_walker_free if self.free_projection else self.propagate_walker_constrained
         self.nfb_trig = 0
         self.nhe_trig = 0
         self.last_fields = None
@@ -68,6 +69,19 @@ class Hirsch(object):
         """hubbard.py:285-312 for every walker with |weight| > 1e-8."""
         psi._flush()
         dev = self.dev
+        if self.free_projection:
+            # hubbard.py:303-343: M uniforms per propagated walker, in site order (:326)
+            u = None
+            if not self.device_rng:
+                live0 = numpy.abs(psi._mirror('weight')) > 1e-8
+                u = numpy.zeros((dev.nw, dev.M))
+                for iw in numpy.nonzero(live0)[0]:
+                    for i in range(dev.M):
+                        u[iw, i] = numpy.random.random()
+            self.last_fields = dev.propagate_hirsch_free(u, eshift, fetch_fields=not self.device_rng)
+            psi.phi_version += 1
+            psi._invalidate('weight', 'ot', 'phase')
+            return
         if self.device_rng:
             dev.propagate_hirsch(eshift)
         else:
@@ -88,6 +102,9 @@ class Hirsch(object):
             dev.hirsch_finish(eshift)
         psi.phi_version += 1
         psi._invalidate('weight', 'ot')
+
+    def propagate_walker_free(self, walker, system, trial, eshift=0):
+        self.propagate_walker_constrained(walker, system, trial, eshift)
 
     def propagate_walker_constrained(self, walker, system, trial, eshift):
         if walker._pending:

@@ -810,7 +810,7 @@ def make_traj_bp(name='traj_bp.npz', restore_weights=None, blocks=10, energy=Fal
 
 
 def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pin=None, mean_pin=None, walkers=None,
-                     bp=None):
+                     bp=None, prop_extra=None):
     """qmc/tests/test_afqmc.py:99-143: discrete Hirsch HS (single-site updates, propagation/hubbard.py:12-343),
     4x4 U=4 with 7+7 electrons, UHF trial.  Every uniform the run draws (one per site per live walker, then the
     comb's) is recorded per step."""
@@ -818,6 +818,7 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     prop = {'hubbard_stratonovich': 'discrete'}
     if charge:
         prop['charge_decomposition'] = True
+    prop.update(prop_extra or {})
     options = {'verbosity': 0, 'get_sha1': False,
                'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': blocks, 'rng_seed': 8},
                'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 7, "U": 4, 'ndown': 7},
@@ -840,7 +841,7 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     out['nelec'] = numpy.array([afqmc.system.nup, afqmc.system.ndown])
     draws = []
     cur = []
-    traj = dict(weight=[], unscaled_weight=[], ot=[])
+    traj = dict(weight=[], unscaled_weight=[], ot=[], phase=[])
     _random = numpy.random.random
 
     def random(*a, **k):
@@ -854,6 +855,7 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
         traj['weight'].append([w.weight for w in psi_.walkers])
         traj['unscaled_weight'].append([w.unscaled_weight for w in psi_.walkers])
         traj['ot'].append([w.ot for w in psi_.walkers])
+        traj['phase'].append([w.phase for w in psi_.walkers])
         draws.append(numpy.array(cur))
         del cur[:]
         return est_update(system, qmc, trial, psi_, step, fp)
@@ -872,6 +874,8 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     out['weight'] = numpy.array(traj['weight'], dtype=numpy.float64)
     out['unscaled_weight'] = numpy.array(traj['unscaled_weight'], dtype=numpy.float64)
     out['ot'] = numpy.array(traj['ot'], dtype=numpy.complex128)
+    out['phase'] = numpy.array(traj['phase'], dtype=numpy.complex128)
+    out['free_projection'] = bool(afqmc.propagators.free_projection)
     out['parent_ix'] = numpy.array(pix, dtype=numpy.int32).reshape(len(pix), -1)
     store = h5py._STORE[afqmc.estimators.filename]
     keys = sorted(k for k in store if k.startswith('basic/energies/'))
@@ -983,6 +987,11 @@ if __name__ == '__main__':
         make_traj_log_shift()
         # discrete fields + use_log_shift: calc_otrial shifts the determinant of the inverse overlap (single_det.py:159)
         make_traj_hirsch('traj_hirsch_logshift.npz', blocks=4, walkers={'use_log_shift': True})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_fp':
+        # propagate_walker_free (propagation/hubbard.py:303-343) through the reference driver, spin and charge decomposition
+        make_traj_hirsch('traj_hirsch_fp.npz', blocks=3, prop_extra={'free_projection': True})
+        make_traj_hirsch('traj_hirsch_fp_charge.npz', charge=True, blocks=2, prop_extra={'free_projection': True})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_bp':
         make_traj_hirsch('traj_hirsch_bp.npz', blocks=4, bp={'tau_bp': 0.04, 'one_rdm': True})

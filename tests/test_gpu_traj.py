@@ -263,7 +263,7 @@ def test_traj_use_log_shift(golden, monkeypatch):
         assert psi.walkers[3].log_shift == psi.log_shift
 
 
-def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None, bp=None):
+def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None, bp=None, fp=False):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -271,6 +271,8 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     prop = {'hubbard_stratonovich': 'discrete'}
     if bool(d['charge']):
         prop['charge_decomposition'] = True
+    if fp:
+        prop['free_projection'] = True
     options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
                        'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
                        'num_walkers': d['phi0'].shape[0]},
@@ -286,11 +288,12 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     close(afqmc.propagators.bt2, d['bt2'], 1e-12)
     stream = iter(d['u'])
     monkeypatch.setattr(numpy.random, 'random', lambda: next(stream))
-    rec = dict(weight=[], ot=[], pix=[])
+    rec = dict(weight=[], ot=[], pix=[], phase=[])
 
     def on_step(step, psi):
         rec['weight'].append(psi._mirror('weight').copy())
         rec['ot'].append(psi._mirror('ot').copy())
+        rec['phase'].append(psi._mirror('phase').copy())
         if step % afqmc.qmc.npop_control == 0:
             rec['pix'].append(psi.last_parent_ix.copy())
 
@@ -301,6 +304,8 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     assert next(stream, None) is None                      # consumed exactly the reference's uniforms
     close(numpy.array(rec['weight']), d['weight'])
     close(numpy.array(rec['ot']), d['ot'])
+    if fp:
+        close(numpy.array(rec['phase']), d['phase'])
     assert numpy.array_equal(numpy.array(rec['pix']), d['parent_ix'])
     mixed = afqmc.estimators.estimators['mixed']
     close(numpy.array(mixed.blocks)[:, 1:10], d['blocks'][:, 1:10])
@@ -312,12 +317,21 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     if walker_opts and walker_opts.get('use_log_shift'):
         assert afqmc.psi.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-9)
         assert afqmc.psi.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-9)
-    mixed.update(s, afqmc.qmc, t, afqmc.psi, 0, False)
+    mixed.update(s, afqmc.qmc, t, afqmc.psi, 0, fp)
     close(mixed.estimates[:9], d['final_estimates'][:9])
     est = mixed.estimates.copy()
     afqmc.finalise()
     release_context(s, t)
     return est
+
+
+def test_traj_hirsch_free_projection(golden, monkeypatch):
+    """propagation/hubbard.py:303-343 (Hirsch.propagate_walker_free): no importance sampling, |wfac| into the weight
+    and arg wfac into the phase, estimators in their free-projection form (mixed.py:151-175), det R of the
+    re-orthogonalisation folded into weight and phase; spin and charge decomposition, per-walker and batched loops."""
+    for name in ('traj_hirsch_fp.npz', 'traj_hirsch_fp_charge.npz'):
+        for batched in (False, True):
+            run_hirsch(golden, monkeypatch, name, batched=batched, fp=True)
 
 
 def test_traj_hubbard_hirsch(golden, monkeypatch, tmp_path):

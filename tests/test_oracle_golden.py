@@ -351,7 +351,7 @@ def test_use_log_shift(golden):
     assert numpy.all(d['final_log_shift'] == d['final_log_shift'][0])
 
 
-def run_hirsch(d, use_log_shift=False, bp_out=None):
+def run_hirsch(d, use_log_shift=False, bp_out=None, free_projection=False):
     na, nb = [int(x) for x in d['nelec']]
     m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
     close(m.bt2, d['bt2'])
@@ -367,7 +367,10 @@ def run_hirsch(d, use_log_shift=False, bp_out=None):
     blocks = ref.run_afqmc(m, walkers, None, None, int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
                            npop_control=int(d['npop_control']), energy_eval_freq=int(d['energy_eval_freq']),
                            record=rec, uniform_source=usrc, hybrid=False, use_log_shift=use_log_shift,
-                           nbp=int(d['nbp']) if bp_out is not None else None, bp_out=bp_out)
+                           nbp=int(d['nbp']) if bp_out is not None else None, bp_out=bp_out,
+                           free_projection=free_projection)
+    if free_projection:
+        close(numpy.array([x['phase'] for x in rec]), d['phase'], 1e-9)
     if use_log_shift:
         assert m.log_shift == pytest.approx(d['final_log_shift'][0].real, rel=1e-10)
         assert m.detR_shift == pytest.approx(d['final_detR_shift'][0].real, rel=1e-10)
@@ -378,7 +381,7 @@ def run_hirsch(d, use_log_shift=False, bp_out=None):
     close(numpy.array(blocks)[:, :9], d['blocks'][:, 1:10], 1e-9)
     close(numpy.array([w['phi'] for w in walkers]), d['final_phi'], 1e-9)
     est = numpy.zeros(10, dtype=numpy.complex128)
-    ref.mixed_update(m, est, walkers, 0, 1)
+    ref.mixed_update(m, est, walkers, 0, 1, free_projection)
     close(est[:9], d['final_estimates'][:9], 1e-9)
     return est, numpy.array(blocks)
 
@@ -417,6 +420,19 @@ def test_traj_hubbard_hirsch_charge(golden):
     d = golden('traj_hubbard_hirsch_charge.npz')
     assert bool(d['charge'])
     run_hirsch(d)
+
+
+def test_traj_hirsch_free_projection(golden):
+    """propagation/hubbard.py:303-343 (propagate_walker_free) through the reference driver: spin decomposition
+    (aux_wfac = 1: the weights only move with the comb and the shift) and charge decomposition (complex aux_wfac:
+    the phase rotates and |wfac| enters the weight)."""
+    d = golden('traj_hirsch_fp.npz')
+    assert bool(d['free_projection']) and not bool(d['charge'])
+    run_hirsch(d, free_projection=True)
+    d = golden('traj_hirsch_fp_charge.npz')
+    assert bool(d['free_projection']) and bool(d['charge'])
+    run_hirsch(d, free_projection=True)
+    assert numpy.max(numpy.abs(d['phase'] - 1.0)) > 1e-3            # the phase does rotate in this run
 
 
 def test_comb_truncation_quirk():
