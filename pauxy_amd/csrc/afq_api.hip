@@ -98,6 +98,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ot); dev_free(h->ehyb); dev_free(h->phase); dev_free(h->eloc);
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0; h->vbias_version = 0;
+    dev_free(h->gdiag); h->gdiag_version = 0; h->gdiag_parts = 0;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
@@ -150,6 +151,8 @@ static int upload_psi(afq_handle *h, const double *psi) {
     int rc = dev_upload(h, &h->psi, psi, n);
     if (rc) return rc;
     cache_of(h)->psi.assign(psi, psi + 2 * n);
+    h->psi_real = true;
+    for (size_t i = 0; i < n && h->psi_real; ++i) h->psi_real = psi[2 * i + 1] == 0.0;
     std::vector<double> pc(psi, psi + 2 * n);
     for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
     if (h->ndet <= 1) {     // transposed copy (Hubbard force bias: diag of G from rows of conj(psi)^T and Ghalf)
@@ -530,7 +533,8 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
     h->nv = (h->kind == AFQ_SYS_HUBBARD && (flags & AFQ_PROP_HUBBARD_SPIN)) ? 2 : 1;
     h->have_prop = true;
     if (h->nw && (old_nv != h->nv || old_diag != h->vhs_diag || !h->vhs)) {
-        const size_t per = h->vhs_diag ? (size_t)h->nv * h->M : (size_t)h->nv * h->M * h->M;
+        // (diagonal potential: a second block of the same size holds its Taylor factors)
+        const size_t per = h->vhs_diag ? (size_t)2 * h->nv * h->M : (size_t)h->nv * h->M * h->M;
         if ((rc = dev_alloc(h, &h->vhs, per * h->nw))) return rc;
     }
     return AFQ_OK;
@@ -579,7 +583,8 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     }
     if (h->kind == AFQ_SYS_UEG) A_(h->G, (size_t)2 * h->M * h->M * n)
     {
-        const size_t pv = h->kind == AFQ_SYS_HUBBARD ? (size_t)2 * h->M : (size_t)h->M * h->M;
+        // Hubbard: diagonals of up to two HS matrices, and their Taylor factors behind them
+        const size_t pv = h->kind == AFQ_SYS_HUBBARD ? (size_t)4 * h->M : (size_t)h->M * h->M;
         A_(h->vhs, pv * n)
     }
 #undef A_
@@ -846,6 +851,24 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
         // potential, in one launch; B exp(V) B from those coefficients in a second one (k_ueg.hip)
         { PhaseTimer t(h, T_FB); if ((rc = k_ueg_fields(h))) return rc; }                        // :133-158, :161
         { PhaseTimer t(h, T_EXP); if ((rc = k_prop_ueg(h))) return rc; }                         // :251, :162-171, :258
+        h->prop_pending = true;
+        return AFQ_OK;
+    }
+    if (h->vhs_diag && !h->no_fused) {
+        // Hubbard, continuous fields: the HS potential is diagonal, exp(V) a row scaling.  The force bias reads Ghalf of
+        // the un-propagated walker, so fields, potential and the scaling factors are made FIRST and the factors ride on
+        // the store of the first one-body product: phi <- B [exp(V) (B phi)] in two GEMM launches, the walkers pass
+        // through memory twice instead of three times (exp_diag_kernel: 537 MB of traffic at C4).
+        {
+            PhaseTimer t(h, T_FB);                                                      // :133-158
+            if ((rc = force_bias(h, false))) return rc;
+            if ((rc = k_xbar_fields(h))) return rc;
+        }
+        { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                 // :161
+        cplx *fac = h->vhs + (size_t)h->nw * h->nv * h->M;                              // second half of the vhs buffer
+        { PhaseTimer t(h, T_EXP); if ((rc = k_exp_diag_factors(h, h->vhs, fac))) return rc; }   // :162-171
+        { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h, fac))) return rc; }        // :251 + the row scaling
+        { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }             // :258
         h->prop_pending = true;
         return AFQ_OK;
     }
@@ -1478,7 +1501,8 @@ int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int c
     hipSetDevice(h->device);
     int rc;
     if ((rc = dev_upload(h, &h->BH1, bt2, (size_t)2 * h->M * h->M))) return rc;
-    h->bh1_real = false;
+    h->bh1_real = true;         // (expm of a real hopping matrix: the one-body GEMM then needs two real products per pair)
+    for (size_t i = 0, n = (size_t)2 * h->M * h->M; i < n && h->bh1_real; ++i) h->bh1_real = bt2[2 * i + 1] == 0.0;
     h->bh1_same = false;
     // propagation/hubbard.py:66-82
     typedef std::complex<double> C;

@@ -94,6 +94,7 @@ struct afq_handle {
     cplx *psic = nullptr;           // conj(psi) [M, nt] (B operand of the overlap GEMM)
     cplx *psicT = nullptr;          // conj(psi)^T [nt, M]: coalesced reads of the Hubbard force bias (single-determinant upload only)
     long psi_stride = 0;            // elements between per-walker 'trials' (back-propagation only; 0 = shared psi)
+    bool psi_real = false;          // every imaginary part of the uploaded trial is exactly zero
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one
@@ -172,6 +173,11 @@ struct afq_handle {
     // function kernel writes the sum itself, otherwise k_force_bias_generic runs ghalf_sum_kernel first)
     unsigned long long ghalf_version = 1, gsum_version = 0;
     unsigned long long vbias_version = 0;       // ghalf_version the force-bias partials in vbias were contracted from
+    // Hubbard: diag(G_s) as partial sums over row blocks of Ghalf, written by the Ghalf GEMM itself (k_bigdet.hip);
+    // current when gdiag_version == ghalf_version, cloned along by the comb
+    cplx *gdiag = nullptr;          // [2 nw, gdiag_parts, M]
+    int gdiag_parts = 0;
+    unsigned long long gdiag_version = 0;
     cplx *xbar = nullptr, *xs = nullptr;              // [nw, K]
     cplx *cmf = nullptr, *cfb = nullptr;              // [nw]
     cplx *vhs = nullptr;            // [nw, nv, M, M] or [nw, nv, M] when vhs_diag
@@ -346,7 +352,7 @@ struct KernelTrace {
 
 // ---- launchers implemented in the kernel translation units -----------------
 // k_gemm.hip
-int k_onebody(afq_handle *h);                               // phi <- BH1 phi (all live walkers)
+int k_onebody(afq_handle *h, const cplx *rowscale = nullptr);   // phi <- [diag(rowscale_w)] BH1 phi (all live walkers)
 int k_force_bias_generic(afq_handle *h);                    // ghalf -> vbias[2,nw,K]
 bool k_fb_use_sum(afq_handle *h);                           // force bias runs once over Ghalf_a + Ghalf_b
 int k_vhs_generic(afq_handle *h);                           // xs -> vhs
@@ -423,6 +429,7 @@ void k_free_atil(void *(&atil)[2]);
 // k_models.hip (Hubbard / UEG)
 int k_vhs_hubbard(afq_handle *h);
 int k_apply_exponential_diag(afq_handle *h, const cplx *vhs_diag);
+int k_exp_diag_factors(afq_handle *h, const cplx *vhs_diag, cplx *out);   // out[w, v, p] = sum_{n <= order} d^n / n!
 int k_energy_hubbard(afq_handle *h);
 int k_vbias_ueg(afq_handle *h);
 int k_vhs_ueg(afq_handle *h);

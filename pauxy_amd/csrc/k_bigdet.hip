@@ -17,8 +17,10 @@
 #define GJ_N 128
 
 // ------------------------------------------------------------------ 1. overlap matrices
-struct OvlpProb {
-    static constexpr bool A_CPLX = true, B_CPLX = true;
+// BR: the trial has no imaginary part (checked at upload): two real multiplications per element pair instead of three
+template <bool BR>
+struct OvlpProbT {
+    static constexpr bool A_CPLX = true, B_CPLX = true, B_REAL = BR;
     int batch, rows, cols, kdim;     // 2 nw, nmax, nmax, M
     int nt, na, nb, ld;
     const cplx *phi;                 // [nw, M, nt]
@@ -50,11 +52,27 @@ struct OvlpProb {
     }
 };
 
+typedef OvlpProbT<false> OvlpProb;
+
 // ------------------------------------------------------------------ 3. Ghalf = Oinv phi^T
-struct GhalfProb {
-    static constexpr bool A_CPLX = true, B_CPLX = true;
+// CD: also leave diag(G_s)[n] = sum_i conj(psi[n, i]) Ghalf_s[i, n] behind, as one partial sum per block of 32 rows
+// (gdiag[2 w + s][part][n]): the Hubbard force bias needs nothing else of the Green's function, and reading Ghalf back
+// for it costs 268 MB per step at C4
+template <bool CD>
+struct GhalfProbT {
+    static constexpr bool A_CPLX = true, B_CPLX = true, COLDOT = CD;
     int batch, rows, cols, kdim;     // 2 nw, nmax, M, nmax
     int nt, na, nb, ld, M;
+    const cplx *psicT;               // conj(psi)^T [nt, M]
+    cplx *gdiag;                     // [2 nw, nparts, M]
+    int nparts;
+    __device__ cplx coldot_coef(int b, int row, int col) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return row < ns ? psicT[(long)((s ? na : 0) + row) * M + col] : cmake(0.0, 0.0);
+    }
+    __device__ void store_coldot(int b, int part, int col, double re, double im) const {
+        gdiag[((long)b * nparts + part) * M + col] = cmake(re, im);
+    }
     const cplx *Oinv;                // [2 nw, ld * ld]
     const cplx *phi;
     cplx *ghalf;                     // [nw, nt, M]
@@ -83,6 +101,8 @@ struct GhalfProb {
         if (row < ns) ghalf[((long)(b >> 1) * nt + (s ? na : 0) + row) * M + col] = cmake(re, im);
     }
 };
+
+typedef GhalfProbT<false> GhalfProb;
 
 // ------------------------------------------------------------------ 2. register-resident Gauss-Jordan
 struct GjArgs {
@@ -300,12 +320,16 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
         AFQ_HIP(h, hipMalloc(&h->detm, sizeof(cplx) * nb2));
         AFQ_HIP(h, hipMalloc(&h->dete, sizeof(int) * nb2));
     }
-    {
-        OvlpProb p;
+    auto overlap = [&](auto p) -> int {
         p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
         p.phi = h->phi; p.psic = h->psic; p.psi_stride = h->psi_stride; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
-        AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OvlpProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        return AFQ_OK;
+    };
+    {
+        const int rc = (h->psi_real && h->psi_stride == 0 && h->ndet == 1) ? overlap(OvlpProbT<true>()) : overlap(OvlpProbT<false>());
+        if (rc) return rc;
     }
     {
         GjArgs a;
@@ -320,11 +344,31 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
     if (oinv)    // [nw, 2, nmax, nmax]: the layout of the workspace (batch = 2 w + spin)
         AFQ_HIP(h, hipMemcpyAsync(oinv, h->big_ws, sizeof(cplx) * wsn, hipMemcpyDeviceToDevice, h->stream));
     if (ghalf) {
-        GhalfProb p;
-        p.batch = nb2; p.rows = nmax; p.cols = h->M; p.kdim = nmax;
-        p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
-        p.Oinv = h->big_ws; p.phi = h->phi; p.ghalf = ghalf; p.zero = (const cplx *)h->zero_page;
-        AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GhalfProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        auto run = [&](auto p) -> int {
+            p.batch = nb2; p.rows = nmax; p.cols = h->M; p.kdim = nmax;
+            p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
+            p.Oinv = h->big_ws; p.phi = h->phi; p.ghalf = ghalf; p.zero = (const cplx *)h->zero_page;
+            p.psicT = h->psicT; p.gdiag = h->gdiag; p.nparts = h->gdiag_parts;
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            return AFQ_OK;
+        };
+        // Hubbard, the walkers' own Ghalf, shared single-determinant trial: the diagonal of G comes along
+        const bool want_diag = h->kind == AFQ_SYS_HUBBARD && ghalf == h->ghalf && h->ndet == 1 && h->psi_stride == 0 && h->psicT;
+        if (want_diag) {
+            const int parts = (nmax + 31) / 32;                      // 2 x 2 waves of 2 x 2 tiles: a wave block covers 32 rows
+            if (!h->gdiag || h->gdiag_parts != parts) {
+                if (h->gdiag) hipFree(h->gdiag);
+                h->gdiag = nullptr;
+                AFQ_HIP(h, hipMalloc(&h->gdiag, sizeof(cplx) * (size_t)nb2 * parts * h->M));
+                h->gdiag_parts = parts;
+            }
+            const int rc = run(GhalfProbT<true>());
+            if (rc) return rc;
+            h->gdiag_version = h->ghalf_version;
+        } else {
+            const int rc = run(GhalfProbT<false>());
+            if (rc) return rc;
+        }
     }
     return AFQ_OK;
 }

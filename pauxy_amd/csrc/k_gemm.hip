@@ -40,14 +40,21 @@ static const TileChoice kCplxTiles[] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
 static const TileChoice kMixedTiles[] = {{2, 4}, {2, 2}, {1, 4}, {1, 2}, {1, 1}};
 
 // ---------------------------------------------------------------- one body
-struct OneBodyProb {
-    static constexpr bool A_CPLX = true, B_CPLX = true;
+// AR: BH1 has no imaginary part (real hopping / kinetic matrix and real mean-field terms: checked at
+// afq_set_propagator) -- two real multiplications per element pair instead of three
+template <bool AR>
+struct OneBodyProbT {
+    static constexpr bool A_CPLX = true, B_CPLX = true, A_REAL = AR;
     int batch, rows, cols, kdim;     // batch = nw, rows = M, cols = ns, kdim = M
     int nt, off;                     // phi row stride, first column of this spin
     const cplx *B1;                  // BH1[s]  [M, M]
     const cplx *src;                 // phi     [nw, M, nt]
     cplx *dst;
     const int *alive;
+    // optional: row p of walker b's product is multiplied by rowscale[b * rs_stride + p] on the way out (the diagonal
+    // Taylor propagator of the Hubbard HS potential folded into the one-body product ahead of it)
+    const cplx *rowscale;
+    long rs_stride;
     __device__ bool active(int b) const { return alive[b] != 0; }
     __device__ cplx loadA(int, int row, int k) const { return B1[(long)row * kdim + k]; }
     __device__ cplx loadB(int b, int k, int col) const {
@@ -64,9 +71,13 @@ struct OneBodyProb {
     __device__ bool rowok(int, int) const { return true; }
     __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
-        dst[((long)b * rows + row) * nt + off + col] = cmake(re, im);
+        cplx v = cmake(re, im);
+        if (rowscale) v = cmul(rowscale[b * rs_stride + row], v);
+        dst[((long)b * rows + row) * nt + off + col] = v;
     }
 };
+
+typedef OneBodyProbT<false> OneBodyProb;
 
 __global__ void copy_dead_kernel(const cplx *src, cplx *dst, const int *alive, long per) {
     const int w = blockIdx.y;
@@ -75,30 +86,40 @@ __global__ void copy_dead_kernel(const cplx *src, cplx *dst, const int *alive, l
         dst[w * per + i] = src[w * per + i];
 }
 
-int k_onebody(afq_handle *h) {
+template <bool AR>
+static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
+    const int M = h->M;
+    const int ns = s == 0 ? h->na : h->nb;
+    OneBodyProbT<AR> p;
+    p.batch = h->nw; p.rows = M; p.cols = ns; p.kdim = M;
+    p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
+    p.B1 = h->BH1 + (long)s * M * M;
+    p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
+    // rowscale: [nw, nv, M] factors; spin s takes its own row of them when there are two (spin decomposition)
+    p.rowscale = rowscale ? rowscale + (h->nv == 2 ? (long)s * M : 0L) : nullptr;
+    p.rs_stride = (long)h->nv * M;
+    if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
+        // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
+        AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+    } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
+        // large systems: 128 x 64 work-group tiles, 3M complex products (2 real ones when BH1 is real)
+        AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+    } else {
+        OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
+        q.batch = p.batch; q.rows = p.rows; q.cols = p.cols; q.kdim = p.kdim; q.nt = p.nt; q.off = p.off;
+        q.B1 = p.B1; q.src = p.src; q.dst = p.dst; q.alive = p.alive; q.rowscale = p.rowscale; q.rs_stride = p.rs_stride;
+        const TileChoice tc = pick_tiles(q.batch, q.rows, q.cols, kCplxTiles, 4);
+        DISPATCH_TILES(h, q, tc, MAP_COLS_FAST, 4);
+    }
+    return AFQ_OK;
+}
+
+int k_onebody(afq_handle *h, const cplx *rowscale) {
     const int M = h->M;
     for (int s = 0; s < 2; ++s) {
-        const int ns = s == 0 ? h->na : h->nb;
-        if (ns == 0) continue;
-        OneBodyProb p;
-        p.batch = h->nw; p.rows = M; p.cols = ns; p.kdim = M;
-        p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
-        p.B1 = h->BH1 + (long)s * M * M;
-        p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
-        if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
-            // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
-            AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-        } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
-            // large systems: 128 x 64 work-group tiles, 3M complex products
-#ifdef AFQ_TUNING
-            if (afq_knob("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
-            else
-#endif
-            AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-        } else {
-            const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
-            DISPATCH_TILES(h, p, tc, MAP_COLS_FAST, 4);
-        }
+        if ((s == 0 ? h->na : h->nb) == 0) continue;
+        const int rc = h->bh1_real ? onebody_spin<true>(h, s, rowscale) : onebody_spin<false>(h, s, rowscale);
+        if (rc) return rc;
     }
     // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
     AFQ_LAUNCH(h, copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,

@@ -62,6 +62,29 @@ int k_apply_exponential_diag(afq_handle *h, const cplx *vd) {
     return AFQ_OK;
 }
 
+// The same propagator as ONE factor per (walker, HS matrix, site): f = sum_{n<=order} d^n / n! with the recurrence
+// t = d t / n.  The step multiplies row p of B phi by f in the epilogue of the one-body product ahead of it
+// (k_onebody(h, factors)) instead of sweeping the walkers through memory once more.
+__global__ void exp_diag_factor_kernel(const cplx *vd, cplx *out, long n, int order) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const cplx d = vd[e];
+    cplx acc = cmake(1.0, 0.0), t = acc;
+    for (int k = 1; k <= order; ++k) {
+        t = cmul(d, t);
+        t = cmake(t.x / k, t.y / k);
+        acc = cadd(acc, t);
+    }
+    out[e] = acc;
+}
+
+int k_exp_diag_factors(afq_handle *h, const cplx *vd, cplx *out) {
+    const long n = (long)h->nw * h->nv * h->M;
+    AFQ_LAUNCH(h, exp_diag_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, vd, out, n, h->exp_order);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
 // ke = sum_s sum_{i,q} rT[i,q] Ghalf_s[i,q];  pe = U sum_n G_up[n,n] G_dn[n,n]
 __global__ __launch_bounds__(256) void energy_hubbard_kernel(const cplx *rH1, const cplx *ghalf, const cplx *psi,
                                                              cplx *energy, int M, int na, int nb, int nt,

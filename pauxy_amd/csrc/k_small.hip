@@ -680,6 +680,8 @@ struct XbarArgs {
     double sqrt_dt, U;
     const cplx *vbias, *mf, *ghalf, *psi;
     const cplx *psicT;      // conj(psi)^T [nt, M] or null
+    const cplx *gdiag;      // Hubbard: diag(G_s) partial sums [2 nw, gparts, M] left by the Ghalf GEMM, or null
+    int gparts;
     cplx *xbar;
     int ndet;               // > 1: vbias holds ndet slices of det_stride elements, combined with detw
     long det_stride;
@@ -722,6 +724,10 @@ __device__ inline cplx xbar_value(const XbarArgs &a, int w, int n) {
         } else if (a.kind == AFQ_SYS_HUBBARD) {
             // diag of G_s = conj(psi_s) Ghalf_s at site n
             cplx g[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+            if (a.gdiag) {
+                for (int s = 0; s < 2; ++s)
+                    for (int pt = 0; pt < a.gparts; ++pt) g[s] = cadd(g[s], a.gdiag[((long)(2 * w + s) * a.gparts + pt) * a.M + n]);
+            } else
             for (int s = 0; s < 2; ++s) {
                 const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
                 for (int i = 0; i < ns; ++i) {
@@ -763,6 +769,8 @@ static XbarArgs xbar_args(afq_handle *h) {
     a.sqrt_dt = h->sqrt_dt; a.U = h->U;
     a.vbias = h->vbias; a.mf = h->mf_shift; a.ghalf = h->ghalf; a.psi = h->psi; a.xbar = h->xbar;
     a.psicT = (h->ndet <= 1 && h->psi_stride == 0) ? h->psicT : nullptr;
+    a.gdiag = (h->kind == AFQ_SYS_HUBBARD && h->gdiag && h->gdiag_version == h->ghalf_version) ? h->gdiag : nullptr;
+    a.gparts = h->gdiag_parts;
     a.ndet = h->ndet; a.detw = h->detw; a.det_stride = (long)2 * h->fb_split * h->nw * h->K;
     if (h->ndet > 1) a.vbias = h->vbias_all;
     return a;
@@ -1559,6 +1567,8 @@ struct CloneArgs {
     long gsz;
     cplx *gsum;          // Ghalf_a + Ghalf_b of the force bias, kept in step with ghalf; null when it is not current
     long gsum_per;
+    cplx *gdiag;         // Hubbard: diag(G) partial sums, kept in step with ghalf; null when they are not current
+    long gdiag_per;
     double *weight;      // single-rank comb: every weight back to 1 (handler.py:337-338) in this launch; null otherwise
     int nw;
 };
@@ -1581,6 +1591,9 @@ __global__ void clone_kernel(CloneArgs a) {
     if (a.gsum)
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gsum_per; i += (long)gridDim.x * blockDim.x)
             a.gsum[dst * a.gsum_per + i] = a.gsum[src * a.gsum_per + i];
+    if (a.gdiag)
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gdiag_per; i += (long)gridDim.x * blockDim.x)
+            a.gdiag[dst * a.gdiag_per + i] = a.gdiag[src * a.gdiag_per + i];
     if (a.G)
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.gsz; i += (long)gridDim.x * blockDim.x)
             a.G[dst * a.gsz + i] = a.G[src * a.gsz + i];
@@ -1661,9 +1674,12 @@ int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d) {
 int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights) {
     // cloned walkers bring their Ghalf along, and its spin sum when that is current (it then stays current)
     const bool sum_too = with_greens && h->ghalf_sum && h->gsum_version == h->ghalf_version;
+    const bool diag_too = with_greens && h->gdiag && h->gdiag_version == h->ghalf_version;
     ++h->ghalf_version;
     if (sum_too) h->gsum_version = h->ghalf_version;
+    if (diag_too) h->gdiag_version = h->ghalf_version;
     CloneArgs a;
+    a.gdiag = diag_too ? h->gdiag : nullptr; a.gdiag_per = 2L * h->gdiag_parts * h->M;
     a.gsum = sum_too ? h->ghalf_sum : nullptr; a.gsum_per = (long)h->na * h->M;
     a.weight = reset_weights ? h->weight : nullptr; a.nw = h->nw;
     a.per = (long)h->M * h->nt; a.phi = h->phi; a.ot = h->ot; a.ehyb = h->ehyb; a.phase = h->phase;

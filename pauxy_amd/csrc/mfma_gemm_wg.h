@@ -50,6 +50,11 @@ template <class P> struct gemm_kcut<P, decltype((void)P::KCUT)> { static constex
 // (a quadratic form x^T A x evaluated as sum_col (x^T A)[col] x[col] without the round trip of x^T A through memory)
 template <class P, class = void> struct gemm_rowdot { static constexpr bool value = false; };
 template <class P> struct gemm_rowdot<P, decltype((void)P::ROWDOT)> { static constexpr bool value = P::ROWDOT; };
+// optional problem trait: static constexpr bool COLDOT = true -- besides being stored, every output element is multiplied
+// with coldot_coef(b, row, col) and summed over the rows of the wave's tile block: store_coldot(b, part, col, re, im) with
+// part = first row of the block / (16 TM) receives one partial sum per column (diag(C^T X) without reading X back)
+template <class P, class = void> struct gemm_coldot { static constexpr bool value = false; };
+template <class P> struct gemm_coldot<P, decltype((void)P::COLDOT)> { static constexpr bool value = P::COLDOT; };
 template <int CTRL> __device__ inline double gemm_dpp_f64(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
@@ -63,6 +68,14 @@ __device__ inline double gemm_row16_sum(double v) {
     v += gemm_dpp_f64<0x140>(v);
     return v;
 }
+// optional problem trait: static constexpr bool A_REAL = true -- every imaginary part of A is exactly zero (the
+// caller has checked): the products with it are not issued, 2 real multiplications per element pair instead of 3 / 4.
+// A is still stored and staged as complex numbers.
+template <class P, class = void> struct gemm_areal { static constexpr bool value = false; };
+template <class P> struct gemm_areal<P, decltype((void)P::A_REAL)> { static constexpr bool value = P::A_REAL; };
+// ... and the same for B: static constexpr bool B_REAL = true on a problem with B_CPLX (complex storage, zero imaginary parts)
+template <class P, class = void> struct gemm_breal { static constexpr bool value = false; };
+template <class P> struct gemm_breal<P, decltype((void)P::B_REAL)> { static constexpr bool value = P::B_REAL; };
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -257,7 +270,13 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (P::B_CPLX && K3M) {
+                if (P::B_CPLX && gemm_areal<P>::value) {
+                    accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);
+                    accI[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][1], accI[i][j]);
+                } else if (P::B_CPLX && gemm_breal<P>::value) {
+                    accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);
+                    accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][0], accI[i][j]);
+                } else if (P::B_CPLX && K3M) {
                     accR[i][j] = mfma16(a[sub][i][s][0], bc[sub][j][s][0], accR[i][j]);                          // P1
                     accI[i][j] = mfma16(a[sub][i][s][1], bc[sub][j][s][1], accI[i][j]);                          // P2
                     acc3[i][j] = mfma16(a[sub][i][s][0] + a[sub][i][s][1], bc[sub][j][s][0] + bc[sub][j][s][1], acc3[i][j]);  // P3
@@ -312,7 +331,13 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
         constexpr int NG = TM * TN, NR = TM + TN;
         constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;
         auto mfma_tile = [&](int i, int j, int s) __attribute__((always_inline)) {
-            if (P::B_CPLX && K3M) {
+            if (P::B_CPLX && gemm_areal<P>::value) {
+                accR[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][0], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][1], accI[i][j]);
+            } else if (P::B_CPLX && gemm_breal<P>::value) {
+                accR[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][0], accR[i][j]);
+                accI[i][j] = mfma16(a[0][i][s][1], bc[0][j][s][0], accI[i][j]);
+            } else if (P::B_CPLX && K3M) {
                 accR[i][j] = mfma16(a[0][i][s][0], bc[0][j][s][0], accR[i][j]);
                 accI[i][j] = mfma16(a[0][i][s][1], bc[0][j][s][1], accI[i][j]);
                 acc3[i][j] = mfma16(a[0][i][s][0] + a[0][i][s][1], bc[0][j][s][0] + bc[0][j][s][1], acc3[i][j]);
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime(), tr2 = __builtin_amdgcn_s_memrealtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (P::B_CPLX && K3M) {
+    if (P::B_CPLX && K3M && !gemm_areal<P>::value && !gemm_breal<P>::value) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -472,6 +497,28 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
                 const int col = wcol0 + j * 16 + lr;
                 if (row < p.rows && col < p.cols) p.store(b, row, col, accR[i][j][r], accI[i][j][r]);
             }
+    if constexpr (gemm_coldot<P>::value) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wcol0 + j * 16 + lr;
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wrow0 + i * 16 + lk + 4 * r;
+                    if (row < p.rows && col < p.cols) {
+                        const cplx c = p.coldot_coef(b, row, col);
+                        sr += accR[i][j][r] * c.x - accI[i][j][r] * c.y;
+                        si += accR[i][j][r] * c.y + accI[i][j][r] * c.x;
+                    }
+                }
+            // the four lanes lr, lr + 16, lr + 32, lr + 48 hold the rows lk + 4 r of this column
+            sr += __shfl_xor(sr, 16); si += __shfl_xor(si, 16);
+            sr += __shfl_xor(sr, 32); si += __shfl_xor(si, 32);
+            if (lk == 0 && col < p.cols && wrow0 < p.rows) p.store_coldot(b, wrow0 / (16 * TM), col, sr, si);
+        }
+    }
     }
 #ifdef AFQ_TUNING
     if (afq_gemm_ts && threadIdx.x == 0 && blockIdx.x < 64) {
@@ -492,7 +539,7 @@ inline double mfma_gemm_wg_issued_flops(const P &p, KLen klen) {
     constexpr int RT = WM * TM, CT = WN * TN;
     const long tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
     const long tiles_n = (p.cols + 16 * CT - 1) / (16 * CT);
-    const double mults = P::B_CPLX ? (K3M ? 3.0 : 4.0) : 2.0;
+    const double mults = P::B_CPLX ? ((gemm_areal<P>::value || gemm_breal<P>::value) ? 2.0 : K3M ? 3.0 : 4.0) : 2.0;
     double f = 0.0;
     for (int b = 0; b < p.batch; ++b)
         for (long tn = 0; tn < tiles_n; ++tn) {
