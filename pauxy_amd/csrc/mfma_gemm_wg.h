@@ -247,12 +247,18 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) a[sub][i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+            for (int s = 0; s < 2; ++s) {
+                // (a real operand is read as its real half only: a 16-byte read whose upper half is never used lets the
+                //  register allocator hand that half to another value while the asynchronous read is still in flight)
+                if (gemm_areal<P>::value) a[sub][i][s][0] = lds_read_b64(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+                else a[sub][i][s] = lds_read_b128(sl + ((wm * TM + i) * 2 + s) * 1024 + lane * 16);
+            }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                if (P::B_CPLX) bc[sub][j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
+                if (P::B_CPLX && gemm_breal<P>::value) bc[sub][j][s][0] = lds_read_b64(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
+                else if (P::B_CPLX) bc[sub][j][s] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s) * 1024 + lane * 16);
                 else br[sub][j][s] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s * 512 + lane * 8);
             }
     };
@@ -352,7 +358,11 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
             }
         };
         auto read_one = [&](unsigned sl, int r, int s) __attribute__((always_inline)) {      // fragment r of sub-step s
-            if (r < TM) a[0][r][s] = lds_read_b128(sl + ((wm * TM + r) * 2 + s) * 1024 + lane * 16);
+            if (r < TM) {
+                if (gemm_areal<P>::value) a[0][r][s][0] = lds_read_b64(sl + ((wm * TM + r) * 2 + s) * 1024 + lane * 16);
+                else a[0][r][s] = lds_read_b128(sl + ((wm * TM + r) * 2 + s) * 1024 + lane * 16);
+            }
+            else if (P::B_CPLX && gemm_breal<P>::value) bc[0][r - TM][s][0] = lds_read_b64(sl + (NA + (wn * TN + r - TM) * 2 + s) * 1024 + lane * 16);
             else if (P::B_CPLX) bc[0][r - TM][s] = lds_read_b128(sl + (NA + (wn * TN + r - TM) * 2 + s) * 1024 + lane * 16);
             else br[0][r - TM][s] = lds_read_b64(sl + (NA + wn * TN + r - TM) * 1024 + s * 512 + lane * 8);
         };
