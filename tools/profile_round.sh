@@ -10,6 +10,7 @@ run_stats() {   # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -o $name -- "$@" > $out/$name.json 2> $out/$name.err
   f=$(ls $out/$name/*kernel_stats.csv $out/$name/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
+  f=$(ls $out/$name/*kernel_trace.csv $out/$name/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/${name}_kernel_trace.csv
 }
 run_pmc() {     # name, counter, command...
   local name=$1 ctr=$2; shift; shift

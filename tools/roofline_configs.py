@@ -5,9 +5,20 @@
 
 For every BASELINE configuration: throughput (the JSON line tools/bench_configs.py printed under the profiler) and, for
 its top kernels, the algorithmic work per launch (flops with 4 per real-by-complex and 8 per complex MAC, or bytes for
-the gather kernels: SURVEY 8d conventions), the average duration rocprofv3 measured, and the fraction of the fp64 MFMA
-peak (78.6 TFLOP/s) or of the HBM peak (8 TB/s).  With the FETCH_SIZE / WRITE_SIZE passes present, the HBM-side
-traffic per launch (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 bytes) is added."""
+the gather kernels: SURVEY 8d conventions), the average duration rocprofv3 measured, and two fractions of the fp64 MFMA
+peak (78.6 TFLOP/s):
+  frac_algorithmic  the SURVEY 8d count (4 multiplications per complex product, no padding) over the time -- comparable
+                    across implementations, can exceed the share of the pipe that is busy (a 3-multiplication kernel
+                    tops out at 1.33) and is therefore NOT a utilisation;
+  frac_issued       MFMA instructions x their flop count over the time (tile and contraction padding included, a
+                    3-multiplication product counted as 3, a real operand as 2), from the launch geometry encoded in the
+                    kernel's template arguments -- the utilisation of the matrix pipe, never above 1.
+`frac` of a row is frac_issued when it is known (else frac_algorithmic clipped to the ceiling of its product form).
+HBM-bound kernels: algorithmic bytes over the time against 8 TB/s.  Per-kernel averages come from the kernel TRACE when it
+is present, with launches shorter than 10 % of the median dropped (a population in which every fourth launch is a
+near-no-op on dead walkers would otherwise halve the average); else from the statistics file.  With the FETCH_SIZE /
+WRITE_SIZE passes present, the HBM-side traffic per launch (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64
+bytes) is added."""
 import csv
 import json
 import os
@@ -69,8 +80,83 @@ def work(name, c):
     if 'greens_small_kernel<true>' in name:
         return 'hbm', (2.0 * M * nt * 16) * nw, 'B', 'reads phi, writes Ghalf per walker (latency bound: Gauss-Jordan)'
     if name.startswith('gj_big_kernel'):
-        return 'valu', 8.0 * 2 * na ** 3 * nw * 2, 'flop', 'register-resident Gauss-Jordan inverse, 8 N^3 per matrix'
+        return 'valu', 8.0 * na ** 3 * nw * 2, 'flop', 'register-resident Gauss-Jordan inverse, 8 N^3 flops per N x N complex matrix, 2 nw matrices'
+    if 'prop_ueg_kernel' in name:
+        return 'mfma', 8.0 * M * M * nt * 6 * nw, 'flop', 'exp(V) phi from per-walker coefficients: 6 products of M x M by M x (na+nb); B is diagonal (row scaling)'
+    if 'ueg_fields_kernel' in name:
+        return 'hbm', (nt * M * 16 + 2 * K * 16 + 600 * 16) * nw, 'B', 'reads Ghalf, writes xbar, xs and the HS coefficients per walker (latency bound: RNG chain, dependent gathers)'
     return None
+
+
+def gemm_issued(name, c):
+    """Matrix-pipe flops of one launch of the ring GEMM engine from its template arguments
+    mfma_gemm_wg_kernel<WM, WN, TM, TN, D, Prob, MAP, K3M, KC, STAG> and the problem shape; None when unknown."""
+    m = re.match(r'void mfma_gemm_wg_kernel<(\d+), (\d+), (\d+), (\d+), \d+, (\w+)(<(\w+)>)?, \d+, (true|false)', name)
+    if not m:
+        return None
+    WM, WN, TM, TN = (int(m.group(i)) for i in range(1, 5))
+    prob, targ, k3m = m.group(5), m.group(7), m.group(8) == 'true'
+    M, na, nb, K, nw = c['M'], c['na'], c['nb'], c['K'], c['nw']
+    nt, nmax = na + nb, max(na, nb)
+    tri = False
+    if prob == 'VhsProb':
+        batch, rows, cols, kdim, mults = 1, nw, (M * (M + 1) // 2 if c['kind'] == 'generic' else M * M), K, 2
+    elif prob == 'ForceBiasProb':
+        contr = (na if (c.get('ndet', 1) == 1 and not c.get('cplx') and na == nb) else nt) * M
+        batch, rows, cols, kdim, mults = 1, nw, K, contr, 2
+    elif prob == 'ExxQProb':
+        batch, rows, cols, kdim, mults, tri = 2, nw, na * M, na * M, (3 if targ == 'true' else 2), True
+    elif prob == 'TaylorProb':
+        batch, rows, cols, kdim, mults = nw, M, nt, M, 3 if k3m else 4
+    elif prob in ('OneBodyProb', 'OneBodyProbT'):
+        batch, rows, cols, kdim, mults = nw, M, na, M, (2 if targ == 'true' else 3 if k3m else 4)
+    elif prob in ('OvlpProb', 'OvlpProbT', 'GramProb'):
+        batch, rows, cols, kdim, mults = 2 * nw, nmax, nmax, M, (2 if targ == 'true' else 3 if k3m else 4)
+    elif prob in ('GhalfProb', 'GhalfProbT'):
+        batch, rows, cols, kdim, mults = 2 * nw, nmax, M, nmax, 3 if k3m else 4
+    elif prob == 'QProb':
+        batch, rows, cols, kdim, mults = 2 * nw, M, nmax, nmax, 3 if k3m else 4
+    else:
+        return None
+    tr, tc = 16 * WM * TM, 16 * WN * TN
+    tiles_m, tiles_n = -(-rows // tr), -(-cols // tc)
+    if tri:     # triangular operand: column tile tn contracts min(cols, tc (tn + 1)) rows
+        ksum = sum(-(-min(kdim, tc * (tn + 1)) // 8) * 8 for tn in range(tiles_n))
+        return 2.0 * mults * batch * tiles_m * tr * tc * ksum
+    kpad = -(-kdim // 8) * 8
+    return 2.0 * mults * batch * tiles_m * tiles_n * tr * tc * kpad
+
+
+def issued_flops(name, c):
+    M, na, nb, nw = c['M'], c['na'], c['nb'], c['nw']
+    if 'prop_fused_kernel' in name:
+        nrt, ct, nch = -(-M // 16), -(-na // 16) + -(-nb // 16), -(-M // 8)
+        rem4 = 96 < M <= 100
+        per_pass = 2.0 * nch * (2048.0 * (nrt - 1 if rem4 else nrt) * ct + 512.0 * (ct if rem4 else 0))
+        return (3.0 * 6 + 2.0 * 2.0) * per_pass * nw          # real BH1 (two real products per one-body application)
+    if 'prop_ueg_kernel' in name:
+        mp = -(-M // 16) * 16
+        return 3.0 * 6 * 2.0 * (mp // 16) * (mp // 8) * 2048.0 * nw
+    return gemm_issued(name, c)
+
+
+def trace_averages(path):
+    """{kernel name: (average ns over the launches kept, launches kept, launches dropped)} from a rocprofv3 kernel trace."""
+    if not os.path.exists(path):
+        return {}
+    per = {}
+    for r in csv.DictReader(open(path)):
+        try:
+            per.setdefault(r['Kernel_Name'], []).append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+        except (KeyError, ValueError):
+            return {}
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        med = v[len(v) // 2]
+        keep = [x for x in v if x >= 0.1 * med]
+        out[k] = (sum(keep) / len(keep), len(keep), len(v) - len(keep))
+    return out
 
 
 def main():
@@ -97,6 +183,7 @@ def main():
                     m = re.match(r'(.*\S)\s+%s\s+n=\s*\d+ mean=(\S+)' % ctr, ln)
                     if m:
                         pmc.setdefault(m.group(1)[:60], {})[ctr] = float(m.group(2))
+        trace = trace_averages(os.path.join(root, name + '_kernel_trace.csv'))
         rows = list(csv.DictReader(open(stats)))
         total = sum(float(r['TotalDurationNs']) for r in rows)
         kern = []
@@ -105,6 +192,10 @@ def main():
             avg = float(r['AverageNs'])
             e = {"kernel": r['Name'][:110], "calls": int(r['Calls']), "avg_us": avg / 1e3,
                  "share_of_kernel_time": float(r['TotalDurationNs']) / total}
+            if r['Name'] in trace:
+                avg, kept, dropped = trace[r['Name']]
+                e["avg_us"] = avg / 1e3
+                e["averaged_over"] = "%d launches of the trace (%d shorter than 10 %% of the median dropped)" % (kept, dropped)
             if w:
                 bound, amount, unit, note = w
                 e["bound"] = bound
@@ -115,15 +206,19 @@ def main():
                     e["achieved"] = amount / (avg * 1e-9) / 1e12
                     e["peak"] = PEAK_TF
                     e["unit"] = "TFLOP/s"
-                    # complex-by-complex products by the 3-multiplication form issue 6 flops per complex MAC where the
-                    # algorithmic count says 8: the share of the MFMA pipe actually used is 3/4 of the fraction below
-                    if re.search(r', true, \d>\(', r['Name']) or r['Name'].startswith('prop_fused_kernel'):
-                        e["issued_fraction_of_peak"] = 0.75 * e["achieved"] / PEAK_TF
+                    e["frac_algorithmic"] = e["achieved"] / PEAK_TF
+                    iss = issued_flops(r['Name'], c) if bound == 'mfma' else None
+                    if iss:
+                        e["issued_flops_per_launch"] = iss
+                        e["frac_issued"] = iss / (avg * 1e-9) / 1e12 / PEAK_TF
+                        e["frac"] = e["frac_issued"]
+                    else:
+                        e["frac"] = min(e["frac_algorithmic"], 1.0)
                 else:
                     e["achieved"] = amount / (avg * 1e-9) / 1e12
                     e["peak"] = PEAK_TBS
                     e["unit"] = "TB/s (algorithmic bytes)"
-                e["frac"] = e["achieved"] / e["peak"]
+                    e["frac"] = e["achieved"] / e["peak"]
             t = pmc.get(r['Name'][:60])
             if t and 'FETCH_SIZE' in t and 'WRITE_SIZE' in t:
                 e["traffic_bytes_per_launch"] = (2.0 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024.0
@@ -133,8 +228,13 @@ def main():
         out.append({"config": cfg, "sizes": c, "bench_line": line,
                     "roofline": None if dom is None else {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"],
                                                           "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                                                          "frac_algorithmic": dom.get("frac_algorithmic"),
+                                                          "frac_issued": dom.get("frac_issued"),
                                                           "traffic": dom.get("traffic_bytes_per_launch")},
                     "kernels": kern})
+    bad = [(o["config"], k["kernel"][:50], k["frac"]) for o in out for k in o["kernels"] if k.get("frac", 0) > 1.0]
+    if bad:
+        sys.stderr.write("roofline_configs: fractions above 1: %r\n" % (bad,))
     json.dump(out, sys.stdout, indent=1)
 
 
