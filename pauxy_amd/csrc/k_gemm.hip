@@ -483,7 +483,13 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             if (!h->no_ring && M > 128 && p.cols > 32 && h->nw >= 64) {
                 // large systems: 128 x 64 work-group tiles, 3M complex products
 #ifdef AFQ_TUNING
+                const int tcfg = afq_knob("AFQ_TAYLOR_CFG") ? atoi(afq_knob("AFQ_TAYLOR_CFG")) : 0;
                 if (afq_knob("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                else if (tcfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                else if (tcfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                else if (tcfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 2, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                else if (tcfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                else if (tcfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                 else
 #endif
                 AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));

@@ -225,6 +225,12 @@ def main():
                 e["traffic_TBs"] = e["traffic_bytes_per_launch"] / (avg * 1e-9) / 1e12
             kern.append(e)
         dom = max((k for k in kern if 'frac' in k), key=lambda k: k['share_of_kernel_time'], default=None)
+        if line and isinstance(line.get('roofline'), dict) and line['roofline'].get('kernel'):
+            # bench.py names its dominant kernel itself (per step; the profile also holds the clock pre-heat's energy evaluations)
+            first = line['roofline']['kernel'].split(' ')[0].split('<')[0]
+            named = [k for k in kern if 'frac' in k and first in k['kernel']]
+            if named:
+                dom = named[0]
         out.append({"config": cfg, "sizes": c, "bench_line": line,
                     "roofline": None if dom is None else {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"],
                                                           "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
