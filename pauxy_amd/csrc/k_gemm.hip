@@ -86,13 +86,15 @@ __global__ void copy_dead_kernel(const cplx *src, cplx *dst, const int *alive, l
         dst[w * per + i] = src[w * per + i];
 }
 
+// s = 0 / 1: the columns of one spin; s = 2: both spins in one launch (BH1[0] == BH1[1], one row-scale set)
 template <bool AR>
 static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
     const int M = h->M;
-    const int ns = s == 0 ? h->na : h->nb;
+    const int ns = s == 2 ? h->nt : s == 0 ? h->na : h->nb;
     OneBodyProbT<AR> p;
     p.batch = h->nw; p.rows = M; p.cols = ns; p.kdim = M;
-    p.nt = h->nt; p.off = s == 0 ? 0 : h->na;
+    p.nt = h->nt; p.off = s == 1 ? h->na : 0;
+    if (s == 2) s = 0;
     p.B1 = h->BH1 + (long)s * M * M;
     p.src = h->phi; p.dst = h->phi_t; p.alive = h->alive;
     // rowscale: [nw, nv, M] factors; spin s takes its own row of them when there are two (spin decomposition)
@@ -102,8 +104,12 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
         AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     } else if (!h->no_ring && M > 128 && ns > 32 && h->nw >= 64) {
-        // large systems: 128 x 64 work-group tiles, 3M complex products (2 real ones when BH1 is real)
-        AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        // large systems: 128 x 64 or 64 x 128 work-group tiles, whichever pads the output less (M = 400, 100 columns:
+        // 448 x 128 against 512 x 128), 3M complex products (2 real ones when BH1 is real); the 64 x 128 shape runs the
+        // half-chunk pipelined loop (measured at C5 on the Taylor product: 813 -> 683 us)
+        const long padA = (long)((M + 127) / 128) * 128 * ((ns + 63) / 64) * 64, padB = (long)((M + 63) / 64) * 64 * ((ns + 127) / 128) * 128;
+        if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
         q.batch = p.batch; q.rows = p.rows; q.cols = p.cols; q.kdim = p.kdim; q.nt = p.nt; q.off = p.off;
@@ -116,8 +122,12 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
 
 int k_onebody(afq_handle *h, const cplx *rowscale) {
     const int M = h->M;
-    for (int s = 0; s < 2; ++s) {
-        if ((s == 0 ? h->na : h->nb) == 0) continue;
+    // both spins share the matrix (and the row-scale set, if any): one launch over all na + nb columns pads the column
+    // tiles once instead of twice (M = 400, 50 + 50 columns: 448 x 128 against 2 x 512 x 64)
+    const bool merged = h->bh1_same && h->na > 0 && h->nb > 0 && (!rowscale || h->nv == 1) && M > 128 && h->nt > 32 &&
+                        h->nw >= 64 && !h->no_ring;
+    for (int s = merged ? 2 : 0; s < (merged ? 3 : 2); ++s) {
+        if (s < 2 && (s == 0 ? h->na : h->nb) == 0) continue;
         const int rc = h->bh1_real ? onebody_spin<true>(h, s, rowscale) : onebody_spin<false>(h, s, rowscale);
         if (rc) return rc;
     }
@@ -492,7 +502,14 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                 else if (tcfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                 else
 #endif
-                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                {
+                    // 128 x 64 or 64 x 128 tiles, whichever pads the M x ncols output less; the 64 x 128 shape with the
+                    // half-chunk pipelined loop (C5, 400 x 100: 813 -> 683 us per product)
+                    const long padA = (long)((M + 127) / 128) * 128 * ((p.cols + 63) / 64) * 64;
+                    const long padB = (long)((M + 63) / 64) * 64 * ((p.cols + 127) / 128) * 128;
+                    if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                }
                 continue;
             }
             const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
