@@ -324,6 +324,10 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
         p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
         p.phi = h->phi; p.psic = h->psic; p.psi_stride = h->psi_stride; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
+#ifdef AFQ_TUNING
+        if (afq_knob("AFQ_OVLP_CFG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else
+#endif
         AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         return AFQ_OK;
     };
@@ -349,13 +353,18 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
             p.Oinv = h->big_ws; p.phi = h->phi; p.ghalf = ghalf; p.zero = (const cplx *)h->zero_page;
             p.psicT = h->psicT; p.gdiag = h->gdiag; p.nparts = h->gdiag_parts;
+#ifdef AFQ_TUNING
+            if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            else
+#endif
             AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             return AFQ_OK;
         };
         // Hubbard, the walkers' own Ghalf, shared single-determinant trial: the diagonal of G comes along
         const bool want_diag = h->kind == AFQ_SYS_HUBBARD && ghalf == h->ghalf && h->ndet == 1 && h->psi_stride == 0 && h->psicT;
         if (want_diag) {
-            const int parts = (nmax + 31) / 32;                      // 2 x 2 waves of 2 x 2 tiles: a wave block covers 32 rows
+            // a wave block covers 16 TM rows: 32 with the 2 x 2 waves of 2 x 2 tiles
+            const int parts = afq_knob("AFQ_GHALF_CFG") ? (nmax + 15) / 16 : (nmax + 31) / 32;
             if (!h->gdiag || h->gdiag_parts != parts) {
                 if (h->gdiag) hipFree(h->gdiag);
                 h->gdiag = nullptr;

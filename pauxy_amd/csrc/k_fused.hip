@@ -34,6 +34,25 @@
 #define PF_NT (64 * PF_NW)
 #define PF_FPW (16 / PF_NW)      // operand fragments each wave moves per chunk
 
+// Tuning builds (make TUNING=1 -> libafqmc_hip_tuning.so) carry timing ablations (a.dbg bits: WRONG results, timing only)
+// and s_memtime probes.  They all sit behind this one macro family, which expands to NOTHING in the product build, so the
+// kernel below reads straight through and its barrier / vmcnt invariants can be audited without mentally compiling
+// anything out:
+//   PF_UNLESS(bits) stmt;   the statement is skipped when an ablation bit is set
+//   PF_TUNE(code)           code that exists in tuning builds only
+//   PF_STAGE(i), PF_BND(n, i)   s_memtime stamps of the phases / product boundaries
+#ifdef AFQ_TUNING
+#define PF_UNLESS(bits) if (!(a.dbg & (bits)))
+#define PF_TUNE(...) __VA_ARGS__
+#define PF_STAGE(i) stage_stamp(i)
+#define PF_BND(n, i) bnd_stamp(n, i)
+#else
+#define PF_UNLESS(bits)
+#define PF_TUNE(...)
+#define PF_STAGE(i)
+#define PF_BND(n, i)
+#endif
+
 struct PropFusedArgs {
     int M, na, nb, nt, order;
     int t4;                     // Taylor products on v_mfma_f64_4x4x4 (see taylor4 below)
@@ -123,9 +142,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     cplx *phi = a.phi + (long)w * M * nt;
     const cplx *vhs = a.vhs + (long)w * M * M;
 
-#ifdef AFQ_TUNING
-    // coarse stage stamps (AFQ_PF_TS=1): work-group 0, wave 0 -> a.ts[128 + i]
-    auto stage_stamp = [&](int i) {
+    // (tuning: coarse stage stamps (AFQ_PF_TS=1), work-group 0, wave 0 -> a.ts[128 + i]; product build: nothing)
+    PF_TUNE(auto stage_stamp = [&](int i) {
         if (a.ts && w == 0 && wave == 0) {
             unsigned long long t;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
@@ -138,13 +156,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
             if (lane == 0) a.ts[144 + (wave >> 2) * 8 + (n == 4 ? 4 : 0) + i] = t;
         }
-    };
-#define PF_BND(n, i) bnd_stamp(n, i)
-#define PF_STAGE(i) stage_stamp(i)
-#else
-#define PF_STAGE(i)
-#define PF_BND(n, i)
-#endif
+    };)
     PF_STAGE(0);
     // ---- A stream: global chunk g = phase * NCH + c; phases: B0 B1 V..V B0 B1, or B V..V B when both spins
     // share one propagator matrix (BH1[0] == BH1[1]: every closed-shell-type Hamiltonian) -- the one-body
@@ -164,9 +176,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     const int p_row0 = (wave >> 1) * 16 + lr;                    // fragment f = wave + t * PF_NW: row tile f>>1,
     const int p_kl = 2 * lk + (wave & 1);                        // sub-step f&1 (the same for every t: PF_NW is even)
     auto prepare = [&]() __attribute__((always_inline)) {
-#ifdef AFQ_TUNING
-        if ((a.dbg & 1024) && gi > 2) { prepared = true; return; }       // stale addresses (timing only)
-#endif
+        PF_TUNE(if ((a.dbg & 1024) && gi > 2) { prepared = true; return; })       // stale addresses (timing only)
         const bool in_v = gi_phase >= nob && gi_phase < nob + a.order;
         const int spin = gi_phase < nob ? gi_phase : gi_phase - nob - a.order;      // 0 or 1 on live chunks
         const cplx *A = in_v ? vhs : a.BH1 + (spin == 1 ? MM : 0L);
@@ -195,11 +205,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     auto issueA = [&]() __attribute__((always_inline)) {
         if (!prepared) prepare();
         unsigned char *dst = ring + (size_t)gi_slot * 16384;
-#ifdef AFQ_TUNING
-        if (a.dbg & 512) {                                   // addresses computed, DMA not issued
-            for (int t = 0; t < PF_FPW; ++t) asm volatile("" ::"v"(nsrc[t]), "s"(dst));
-        } else
-#endif
+        PF_TUNE(if (a.dbg & 512) { for (int t = 0; t < PF_FPW; ++t) asm volatile("" ::"v"(nsrc[t]), "s"(dst)); } else)   // addresses computed, DMA not issued
 #pragma unroll
         for (int t = 0; t < PF_FPW; ++t) glds16(nsrc[t], dst + (wave + t * PF_NW) * 1024);
         if (++gi_slot == PF_D) gi_slot = 0;
@@ -212,9 +218,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     // ((chunk * 4 + slot) * 2 + (p & 1)) * 64 + ((p & 7) >> 1) * 16 + column in the slot, i.e. shifts and masks only), each
     // either a walker element or a zero -- instead of a zero fill, a barrier and a sweep over the walker with a division
     // by the column count per element
-#ifdef AFQ_TUNING
-    if (!(a.dbg & (32 | 128)))
-#endif
+    PF_UNLESS((32 | 128))
     for (int e = tid; e < NCH * 512; e += PF_NT) {
         const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
         const int p = ch * 8 + 2 * kk + pb, sp = slot >> 1, col = (slot & 1) * 16 + j;
@@ -241,17 +245,11 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     int ring_slot = 0;                                           // slot of the chunk being consumed
     // one k-chunk of a product: wait own DMA, barrier, refill the ring, hand back the slot base
     auto next_chunk = [&]() __attribute__((always_inline)) -> unsigned {
-#ifdef AFQ_TUNING
-        if (!(a.dbg & 18))
-#endif
+        PF_UNLESS(18)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF_D - 2) * PF_FPW) : "memory");
-#ifdef AFQ_TUNING
-        if (!(a.dbg & 1))
-#endif
+        PF_UNLESS(1)
         __builtin_amdgcn_s_barrier();
-#ifdef AFQ_TUNING
-        if (!(a.dbg & 2))
-#endif
+        PF_UNLESS(2)
         issueA();
         const unsigned sl = ring_l + ring_slot * 16384;
         if (++ring_slot == PF_D) ring_slot = 0;
@@ -294,9 +292,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         };
         auto mfmas = [&](d2_t (&av)[2], d2_t (&bv)[NSL][2]) {
             __builtin_amdgcn_sched_barrier(0);
-#ifdef AFQ_TUNING
-            if (!(a.dbg & 64))
-#endif
+            PF_UNLESS(64)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -412,9 +408,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
                         const int row = rt * 16 + lk_e + 4 * r, col = (cs & 1) * 16 + lr_e;
-#ifdef AFQ_TUNING
-                        if (!(a.dbg & 256))
-#endif
+                        PF_UNLESS(256)
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
                     } else if (t_ok(rt, r)) {
                         *(d2_t *)(Tf + t_addr(rt, r, cs)) = (d2_t){re, im};
@@ -547,9 +541,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #if PF_NW == 8
         if constexpr (FULL == 7) {
             bool col_deal = a.rem4 && a.same_b;
-#ifdef AFQ_TUNING
-            if (a.dbg & (to_global ? 16384 : 8192)) col_deal = false;
-#endif
+            PF_TUNE(if (a.dbg & (to_global ? 16384 : 8192)) col_deal = false;)
             if (col_deal) {
                 if (a.b_real) {
                     if (wave < 4) one_body_col(to_global, std::true_type{}, std::false_type{});
@@ -654,9 +646,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // (second register set) while the MFMAs of chunk c run, so the LDS pipe and the MFMA pipe overlap instead
         // of alternating in lock step behind the per-chunk barrier.
         auto load_frags = [&](unsigned sl, int c, d2_t (&av)[NI][2], d2_t (&bv)[NJ][2]) {
-#ifdef AFQ_TUNING
-            if (a.dbg & 4) return;
-#endif
+            PF_TUNE(if (a.dbg & 4) return;)
             const unsigned abase = sl + r0 * 2048 + lane * 16;
             const unsigned bbase = tf_l + (c * 4 + c0) * 2048 + lane * 16;
 #pragma unroll
@@ -679,9 +669,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 }
             double Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;                   // remainder unit (REM)
             auto mfma_ss = [&](d2_t (&av)[NI][2], d2_t (&bv)[NJ][2], const int ss) __attribute__((always_inline)) {
-#ifdef AFQ_TUNING
-                if (a.dbg & 8) return;
-#endif
+                PF_TUNE(if (a.dbg & 8) return;)
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -731,10 +719,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                         const int g = REM ? (gt == 0 ? 0 : gt - 1) : gt;
                         const int i = g / NJ, j = g % NJ;
                         if (!(REM && gt == 0))
-#ifdef AFQ_TUNING
-                        // timing ablation (wrong results): the MFMA load a hybrid 16x16x4 / 4x4x4 tiling would leave at most
-                        if (!((a.dbg & 4096) && ((NI == 2 && NJ == 2 && g == 3) || (NI == 3 && i == 2))))
-#endif
+                        // (tuning: timing ablation with the MFMA load a hybrid 16x16x4 / 4x4x4 tiling would leave at most)
+                        PF_TUNE(if (!((a.dbg & 4096) && ((NI == 2 && NJ == 2 && g == 3) || (NI == 3 && i == 2)))))
                         {
                         P1[i][j] = mfma16(ax[i][0], bx[j][0], P1[i][j]);
                         P2[i][j] = mfma16(ax[i][1], bx[j][1], P2[i][j]);
@@ -775,29 +761,20 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 if (n == 4) PF_BND(4, 1);
                 for (int c = 0; c < NCH; ++c) {
                     const bool more = c + 1 < NCH;
-#ifdef AFQ_TUNING
-                    // s_memtime lands in SGPRs; the values are read behind the lgkmcnt(0) wait that closes a half
-                    unsigned long long t0, t1, t2, t3;
-                    asm volatile("s_memtime %0" : "=s"(t0));
-#endif
+                    // (tuning: s_memtime lands in SGPRs; the values are read behind the lgkmcnt(0) wait that closes a half)
+                    PF_TUNE(unsigned long long t0, t1, t2, t3; asm volatile("s_memtime %0" : "=s"(t0));)
                     // sub-step 0 of chunk c; fetch its sub-step 1 fragments
                     half(a0, b0, q0, a1, b1, q1, sl + r0 * 2048 + lane * 16, tf_l + (c * 4 + c0) * 2048 + lane * 16, sl + rem_a, 1, true, false);
-#ifdef AFQ_TUNING
-                    asm volatile("s_memtime %0" : "=s"(t1));
-#endif
+                    PF_TUNE(asm volatile("s_memtime %0" : "=s"(t1));)
                     if (more) sl = next_chunk_sync();             // chunk c + 1 has landed
-#ifdef AFQ_TUNING
-                    asm volatile("s_memtime %0" : "=s"(t2));
-#endif
+                    PF_TUNE(asm volatile("s_memtime %0" : "=s"(t2));)
                     // sub-step 1 of chunk c; refill the ring, fetch the sub-step 0 fragments of chunk c + 1
                     half(a1, b1, q1, a0, b0, q0, sl + r0 * 2048 + lane * 16, tf_l + ((c + 1) * 4 + c0) * 2048 + lane * 16, sl + rem_a, 0, more, more);
-#ifdef AFQ_TUNING
-                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3));
-                    if (a.ts && w == 0 && n == 3 && (wave & 3) == 0 && lane == 0) {
-                        unsigned long long *o = a.ts + ((wave >> 2) * 16 + c) * 4;
-                        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
-                    }
-#endif
+                    PF_TUNE(asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3));
+                            if (a.ts && w == 0 && n == 3 && (wave & 3) == 0 && lane == 0) {
+                                unsigned long long *o = a.ts + ((wave >> 2) * 16 + c) * 4;
+                                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+                            })
                 }
             } else
 #endif
@@ -911,159 +888,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     // is a 2-way bank conflict in the spin-padded fragment layout.  The kernel is bound by the per-chunk
     // synchronisation skeleton, not by MFMA issue.  The variant is compiled only into tuning builds (AFQ_T4=1).
 #ifdef AFQ_TUNING
-    // ------------------------------------------------------------------ Taylor series on v_mfma_f64_4x4x4_4b_f64
-    // The 16x16x4 tile grid pads M = 100 rows to 112 and 25 columns per spin to 32: 30 % of the MFMA cycles of a
-    // Taylor product multiply zeros.  The 4x4x4 instruction runs four independent 4x4x4 products (lane layouts,
-    // decoded on gfx950 with tools/mfma4x4_probe: A lane = 16 k + 4 blk + i, B lane = 16 k + 4 blk + j,
-    // D lane = 16 i + 4 blk + j) at the same flop rate, which allows two finer shapes on the SAME operand data:
-    //   * 16 rows x 4 columns: blk = 4-row group of a 16-row tile, so the A operand IS the 16x16x4 A fragment of
-    //     the DMA ring; the B operand is one 4-column group of T broadcast to the four blk (a permuted
-    //     ds_read_b128 of the T fragment).  A spin needs ceil(N / 4) column groups: 7 for N = 25 instead of 8.
-    //   * 4 rows x 16 columns for the rows 96 .. M-1 (M <= 100): blk = 4-column group, the B operand IS the T
-    //     fragment, the A operand the first four rows of the ring fragment of row tile 6 broadcast to the four blk.
-    // Per 4 contraction indices that is 6 x 14 + 4 = 88 instructions of 16 cycles against 28 x 64: 79 % of the
-    // MFMA cycles (the one-body products and the spin-padded column slots of T keep their 16x16x4 form).
-    // Deal: wave (trip = wave >> 2, q) owns row tiles 3 trip .. 3 trip + 2 and a quarter q of the column groups
-    // (4 or 3 of 14); waves w and w + 4 share a SIMD and get a long and a short quarter; waves 4-7 also take the
-    // 4-row remainder of column slot wave - 4.  Products by the 3-multiplication form as above.
-    auto taylor4 = [&]() __attribute__((always_inline)) {
-        const int trip = wave >> 2;
-        const int q = ((wave & 3) + 2 * trip) & 3;
-        const int nga = (a.na + 3) >> 2, ngb = (a.nb + 3) >> 2, G = nga + ngb;
-        const int gbase = G >> 2, gext = G & 3;
-        const int g0 = q * gbase + (q < gext ? q : gext), gcnt = gbase + (q < gext ? 1 : 0);
-        const bool rem4 = M > 96;                                 // rows 96 .. M-1 (M <= 100)
-        const int nfull = rem4 ? 6 : nrt;
-        bool rv[3], gv[4];
-        unsigned boff[4];                                        // byte offset of group u inside a T chunk (ss = 0)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rv[i] = 3 * trip + i < nfull;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            gv[u] = u < gcnt;
-            const int Gi = g0 + (u < gcnt ? u : 0);
-            const int sp = Gi >= nga ? 1 : 0, g = Gi - (sp ? nga : 0);
-            boff[u] = (unsigned)((2 * sp + (g >> 2)) * 2048 + (g & 3) * 64);
-        }
-        const int rslot = wave - 4;                              // remainder unit of waves 4-7: column slot
-        const bool remv = rem4 && wave >= 4 && (rslot & 1) < ((((rslot >> 1) ? a.nb : a.na) + 15) >> 4);
-        // lane parts of the addresses
-        const int l_i = lane >> 4, l_blk = (lane >> 2) & 3, l_j = lane & 3;
-        const unsigned bc_lane = (unsigned)((16 * (lane >> 4) + (lane & 3)) * 16);      // 4-wide group broadcast to the 4 blk
-        // D element of a 16 x 4 unit: row 16 R + 4 blk + i, column 4 g + j
-        const unsigned d_lane = (unsigned)((l_blk >> 1) * 8192 + (l_i & 1) * 1024 + ((2 * (l_blk & 1) + (l_i >> 1)) * 16 + l_j) * 16);
-        // D element of the 4 x 16 remainder unit: row 96 + i, column 16 slot + 4 blk + j
-        const unsigned r_lane = (unsigned)((l_i & 1) * 1024 + ((l_i >> 1) * 16 + 4 * l_blk + l_j) * 16);
-        auto d_addr = [&](int i, int u) -> unsigned {
-            unsigned base = d_lane;
-            asm volatile("" : "+v"(base));
-            return base + (unsigned)(2 * (3 * trip + i) * 8192) + boff[u];
-        };
-        auto d_ok = [&](int i) -> bool { return 2 * (3 * trip + i) + (l_blk >> 1) < NCH; };
-        const unsigned r_addr = (unsigned)((12 * 4 + (rslot & 3)) * 2048) + r_lane;
-        double SR[3][4], SI[3][4], RR = 0.0, RI = 0.0;           // running sums
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                d2_t v = (d2_t){0.0, 0.0};
-                if (rv[i] && gv[u] && d_ok(i)) v = *(const d2_t *)(Tf + d_addr(i, u));
-                SR[i][u] = v[0]; SI[i][u] = v[1];
-            }
-        if (remv) { const d2_t v = *(const d2_t *)(Tf + r_addr); RR = v[0]; RI = v[1]; }
-        for (int n = 1; n <= a.order; ++n) {
-            double P1[3][4], P2[3][4], P3[3][4], Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { P1[i][u] = 0.0; P2[i][u] = 0.0; P3[i][u] = 0.0; }
-            // Two operand sets at sub-step granularity: while the MFMAs of (chunk c, sub-step 0) issue, the fragments of
-            // sub-step 1 travel LDS -> registers, and while those of sub-step 1 issue, the ring has already been
-            // advanced (barrier in the MIDDLE of the chunk) and the fragments of (c + 1, 0) are on their way: every
-            // s_waitcnt lgkmcnt(0) sits behind a burst of ~40 MFMAs.
-            d2_t av[2][3], bv[2][4];
-            unsigned sl = 0;
-            auto rd = [&](int set, int c, int ss) __attribute__((always_inline)) {
-                const unsigned abase = sl + (3 * trip) * 2048 + lane * 16;
-                const unsigned bbase = tf_l + c * 8192 + bc_lane + ss * 1024;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) av[set][i] = lds_read_frag(abase, i * 2 + ss);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bv[set][u] = lds_read_c(bbase + boff[u]);
-            };
-            // REM: the remainder unit of this chunk (both sub-steps) rides on the first burst -- its fragments must be
-            // read before the ring advances in the middle of the chunk, because that refills this chunk's slot
-            auto mm = [&](int set, auto rem_tag, unsigned sl_cur, int c) __attribute__((always_inline)) {
-                constexpr bool REM = decltype(rem_tag)::value;
-                d2_t a4 = (d2_t){0.0, 0.0}, b4 = (d2_t){0.0, 0.0};
-                if (REM && rem4 && wave >= 4) {
-                    a4 = lds_read_c(sl_cur + 6 * 2048 + bc_lane);
-                    b4 = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + lane * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!gv[u]) continue;
-                    const double bs = bv[set][u][0] + bv[set][u][1];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        if (rv[i]) {
-                            P1[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][0], bv[set][u][0], P1[i][u], 0, 0, 0);
-                            P2[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][1], bv[set][u][1], P2[i][u], 0, 0, 0);
-                            P3[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[set][i][0] + av[set][i][1], bs, P3[i][u], 0, 0, 0);
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!prepared) prepare();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the other set and the remainder fragments have landed
-                if (REM && rem4 && wave >= 4) {
-                    // sub-step 1 fragments of the remainder unit: one exposed LDS round trip per chunk (waves 4-7)
-                    const d2_t a5 = lds_read_c(sl_cur + 6 * 2048 + 1024 + bc_lane);
-                    const d2_t b5 = lds_read_c(tf_l + c * 8192 + (rslot & 3) * 2048 + 1024 + lane * 16);
-                    if (remv) {
-                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0], b4[0], Q1, 0, 0, 0);
-                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[1], b4[1], Q2, 0, 0, 0);
-                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0] + a4[1], b4[0] + b4[1], Q3, 0, 0, 0);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (remv) {
-                        Q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[0], b5[0], Q1, 0, 0, 0);
-                        Q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[1], b5[1], Q2, 0, 0, 0);
-                        Q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a5[0] + a5[1], b5[0] + b5[1], Q3, 0, 0, 0);
-                    }
-                }
-            };
-            sl = next_chunk();
-            rd(0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int c = 0; c < NCH; ++c) {
-                rd(1, c, 1);
-                mm(0, std::true_type{}, sl, c);
-                if (c + 1 < NCH) { sl = next_chunk(); rd(0, c + 1, 0); }
-                mm(1, std::false_type{}, sl, c);
-            }
-            __builtin_amdgcn_s_barrier();                        // everyone finished reading T_{n-1}
-            const double inv_n = 1.0 / n;
-            const bool last = n == a.order;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (rv[i] && gv[u]) {
-                        const double re = (P1[i][u] - P2[i][u]) * inv_n;
-                        const double im = (P3[i][u] - P1[i][u] - P2[i][u]) * inv_n;
-                        SR[i][u] += re; SI[i][u] += im;
-                        if (d_ok(i))
-                            *(d2_t *)(Tf + d_addr(i, u)) = last ? (d2_t){SR[i][u], SI[i][u]} : (d2_t){re, im};
-                    }
-            if (remv) {
-                const double re = (Q1 - Q2) * inv_n, im = (Q3 - Q1 - Q2) * inv_n;
-                RR += re; RI += im;
-                *(d2_t *)(Tf + r_addr) = last ? (d2_t){RR, RI} : (d2_t){re, im};
-            }
-            lds_barrier();                                       // T_n visible
-        }
-    };
+#include "k_fused_t4.inc"      // taylor4(): the same products on v_mfma_f64_4x4x4 (tuning builds only)
 #endif
 #if PF_NW == 16
     {
@@ -1075,10 +900,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         else taylor(I2{}, I1{}, std::false_type{}, 2 * g, wave & 3, 2, std::false_type{});
     }
 #else
-#ifdef AFQ_TUNING
-    if (a.t4) taylor4();
-    else
-#endif
+    PF_TUNE(if (a.t4) taylor4(); else)
     if (NARROW && FULL) {
         // six row tiles, one column tile per spin: waves 0-3 a pair of the row tiles 0-3, waves 4-7 one of the tiles 4, 5
         using I1 = std::integral_constant<int, 1>;
