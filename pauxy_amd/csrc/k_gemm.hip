@@ -409,6 +409,8 @@ int k_vhs_generic(afq_handle *h) {
             else if (afq_knob("AFQ_VHS_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_RREG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_RREG8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8X")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
             else
 #endif

@@ -306,10 +306,68 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
 #ifdef AFQ_TUNING
     const unsigned long long ts1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // STAG == 4: the ring is refilled THROUGH REGISTERS (global_load_dwordx4, ds_write_b128 one chunk later) instead of by
+    // LDS-DMA.  A global_load ... lds instruction keeps its wave's instruction issue busy for 150+ cycles and only a few
+    // MFMAs queue up ahead of it, so with one wave per SIMD the four refill instructions of a chunk idle the matrix pipe
+    // for ~600 of its 1900 cycles (VhsProb at C3: SQ_WAIT_INST_LDS 1.5 % and zero bank conflicts -- it is not the LDS).
+    // A plain load and a plain LDS store issue in a few cycles each; the price is 16 bytes of staging registers per
+    // fragment and chunk in flight -- and only ONE chunk of latency tolerance (the loads of chunk c + D are waited for one
+    // iteration later, in program order ahead of half the MFMAs).  MEASURED NEGATIVE (round 3, VhsProb at C3, tuning knob
+    // AFQ_VHS_RREG): correct, 67.9 us against 61.5 us with the DMA ring; 63 % of that kernel's L2 accesses miss
+    // (TCC_MISS / (HIT + MISS), profiles/r03_pmc_sq_tcp_bench_kernels.txt), so the three chunks the DMA ring keeps in
+    // flight matter more than the issue slots it costs.  Kept for tuning builds only.
+    if constexpr (STAG == 4) {
+        static_assert(KC == 1 && gemm_incr<P>::value, "register-staged refill: incremental problems, one sub-chunk per slot");
+        d2_t stgA[LPA], stgB[LPB];
+        auto gload = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < LPA; ++t) {
+                const int f = wave + t * NW;
+                const bool ok = okA[t] && kcur + 2 * lk + (f & 1) < klim;
+                stgA[t] = *(const d2_t *)(ok ? (const void *)curA[t] : zero16);
+                curA[t] += 8 * p.kstepA();
+            }
+#pragma unroll
+            for (int t = 0; t < LPB; ++t) {
+                const int f = wave + t * NW;
+                const int kl = P::B_CPLX ? 2 * lk + (f & 1) : 2 * b_kk + b_half;
+                const bool ok = okB[t] && kcur + kl < klim;
+                stgB[t] = *(const d2_t *)(ok ? (const void *)curB[t] : zero16);
+                curB[t] += 8 * p.kstepB(b);
+            }
+            kcur += 8;
+        };
+        auto lstore = [&](int slot) __attribute__((always_inline)) {
+            unsigned char *dst = smem + (size_t)slot * CHUNK + lane * 16;
+#pragma unroll
+            for (int t = 0; t < LPA; ++t) { const int f = wave + t * NW; if (f < NA) *(d2_t *)(dst + f * 1024) = stgA[t]; }
+#pragma unroll
+            for (int t = 0; t < LPB; ++t) { const int f = wave + t * NW; if (f < NB) *(d2_t *)(dst + (NA + f) * 1024) = stgB[t]; }
+        };
+#pragma unroll
+        for (int c = 0; c < D - 1; ++c) { gload(); lstore(c); }
+        gload();                                              // chunk D - 1 waits in registers
+        for (int c = 0; c < nchunks; ++c) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's stores of chunk c + D - 2 have landed
+            __builtin_amdgcn_s_barrier();                          // chunk c complete; everyone is done reading chunk c - 1
+            read_sub(ring_l + (c & (D - 1)) * CHUNK, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            conj_sub(0);
+            mfma_step(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore((c + D - 1) & (D - 1));                         // chunk c + D - 1, loaded one iteration ago, into the slot of c - 1
+            gload();                                               // chunk c + D
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(0, 1);
+        }
+    } else
     if (STAG != 3 || loader) {
 #pragma unroll
         for (int c = 0; c < D - 1; ++c) issue(c, c);
     }
+    if constexpr (STAG == 4) {
+    } else
     if (STAG == 3 && loader) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -332,6 +390,8 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     // refilled (address arithmetic included) and the sub-step 0 fragments of chunk c + 1 are read.  The plain loop below
     // does refill, reads and the wait for them in a block behind the barrier with the matrix pipe idle, which only
     // works out when several waves share a SIMD; the small-output contractions of this library run one wave per SIMD.
+    if constexpr (STAG == 4) {
+    } else
     if ((STAG == 2 || STAG == 3) && KC == 1) {
         constexpr bool own_refill = STAG == 2;
         constexpr int NG = TM * TN, NR = TM + TN;
