@@ -321,3 +321,63 @@ def test_fused_reortho_breakdown_fallback():
         qa = q[w][:, sl]
         close(qa @ (qa.conj().T @ phis[w][:, sl]), phis[w][:, sl], 1e-9)
     dev.close()
+
+
+# ----------------------------------------------------------------------------- plane-wave step (k_ueg.hip)
+def ueg_model_of(rs, nup, ndown, ecut, psi=None, dt=0.005):
+    s = systems.UEG(rs, nup, ndown, ecut)
+    t = trial_mod.hartree_fock_ueg(s) if psi is None else trial_mod.SingleDetTrial(s, psi(s))
+    BH1, mf = setup.ueg_propagator_arrays(s, t, dt)
+    H1diag = numpy.array([numpy.diag(s.H1[0]), numpy.diag(s.H1[1])])
+    return ref.RefModel('ueg', s.nbasis, nup, ndown, t.psi, BH1, mf, dt, iA=s.iA, iB=s.iB, H1diag=H1diag,
+                        vqvec=s.vqvec, vol=s.vol, ikpq_i=s.ikpq_i, ikpq_kpq=s.ikpq_kpq, ipmq_i=s.ipmq_i,
+                        ipmq_pmq=s.ipmq_pmq, ecore=s.ecore)
+
+
+def rotated_trial(s):
+    """Occupied orbitals mixed among ALL plane waves: G has no zero rows, the step must take the general kernels."""
+    rng = numpy.random.RandomState(17)
+    M, ne = s.nbasis, s.nup + s.ndown
+    a = numpy.eye(M, dtype=complex)[:, :max(s.nup, s.ndown)] + 0.05 * (rng.rand(M, max(s.nup, s.ndown)) + 1j * rng.rand(M, max(s.nup, s.ndown)))
+    q, _ = numpy.linalg.qr(a)
+    return numpy.concatenate([q[:, :s.nup], q[:, :s.ndown]], axis=1)
+
+
+@pytest.mark.parametrize("rs,nup,ndown,ecut,psi", [(2.0, 7, 7, 4.0, None), (1.0, 7, 5, 2.5, None), (2.0, 2, 1, 1.0, None),
+                                                    (2.0, 7, 7, 2.5, rotated_trial)],
+                         ids=["C2-93pw", "7+5-unequal-spins", "2+1-tiny-basis", "rotated-trial-general-kernels"])
+def test_planewave_step_shapes(rs, nup, ndown, ecut, psi):
+    """One full step of the plane-wave path against the oracle for several shapes: the C2 system, unequal spins (the one
+    16-column tile holds 7 + 5 columns), a basis of a handful of plane waves (one row tile, contraction of 2 k-steps per
+    half) and a trial whose orbitals mix all plane waves (no zero rows of G: the checks of k_ueg.hip send the step to the
+    general kernels).  Dead walkers in between; the force bias the step used (xbar) against the stand-alone
+    afq_force_bias of the general gather kernel, its shifted fields against the oracle's."""
+    model = ueg_model_of(rs, nup, ndown, ecut, psi)
+    M, nt, K = model.M, nup + ndown, model.nfields
+    nw = 21
+    rng = numpy.random.RandomState(3)
+    dev = make_device(model, nw)
+    phis = numpy.array([model.psi + 0.05 * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for _ in range(nw)])
+    dev.set(L.F_PHI, phis)
+    w0 = numpy.ones(nw)
+    w0[3::7] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, nup, ndown) for p in phis]))
+    dev.greens(want_G=True)
+    xbar_general = dev.force_bias()                       # afq_force_bias: full G + sparse gather (k_models.hip)
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, 0.2)
+    out_phi, out_w, out_e = dev.get(L.F_PHI), dev.get(L.F_WEIGHT), dev.get(L.F_HYBRID_ENERGY)
+    xbar_step, xs_step = dev.get(L.F_XBAR), dev.get(L.F_XSHIFTED)
+    for i in range(nw):
+        if w0[i] == 0.0:
+            assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+            continue
+        close(xbar_step[i], xbar_general[i], 1e-12)
+        w = ref.new_walker(model, phis[i])
+        ref.propagate_walker_phaseless(model, w, xi[i], 0.2)
+        close(out_phi[i], w['phi'])
+        close(out_w[i], w['weight'])
+        close(out_e[i], w['hybrid_energy'])
+        close(xs_step[i], xi[i] - xbar_general[i], 1e-12)
+    dev.close()
