@@ -216,66 +216,72 @@ struct PackArgs {
     int *bp_n;
 };
 
+// grid (4, min(cap, COMM_GRID_Y), R): block (x, y, peer) moves quarter x of the slots y, y + gridDim.y, ... of that peer.
+// (one block row per slot of the capacity would launch thousands of work-groups that find nothing to do: the capacity
+//  is what a rank COULD send, a comb moves a handful)
+#define COMM_GRID_Y 32
 template <bool PACK>
 __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
-    const int sl = blockIdx.y, peer = blockIdx.z;
-    if (peer == a.rank || sl >= a.count[peer]) return;
-    const int w = a.idx[peer * a.cap + sl];
-    cplx *s;
-    if (a.window) {
-        // pack: straight into the window of the destination rank, row of this rank; unpack: this rank's window, row of the source
-        if (PACK) s = a.wl.rbuf(a.pw.base[peer]) + ((long)a.rank * a.cap + sl) * a.slot;
-        else s = a.buf + ((long)peer * a.cap + sl) * a.slot;
-        if (!PACK) {
-            __shared__ int ok;
-            if (threadIdx.x == 0) ok = flag_wait(a.wl.flag_x(a.pw.base[a.rank]) + peer, a.seq) ? 1 : 0;
-            __syncthreads();
-            if (!ok) { if (threadIdx.x == 0 && blockIdx.x == 0) a.scal[6] = 1.0; return; }
-        }
-    } else {
-        s = a.buf + ((long)peer * a.cap + sl) * a.slot;
+    const int peer = blockIdx.z;
+    if (peer == a.rank) return;
+    const int count = a.count[peer];
+    if ((int)blockIdx.y >= count) return;                         // (work-group uniform)
+    if (a.window && !PACK) {
+        // the slots of this peer are complete once it has raised its flag for this event
+        __shared__ int ok;
+        if (threadIdx.x == 0) ok = flag_wait(a.wl.flag_x(a.pw.base[a.rank]) + peer, a.seq) ? 1 : 0;
+        __syncthreads();
+        if (!ok) { if (threadIdx.x == 0 && blockIdx.x == 0) a.scal[6] = 1.0; return; }
     }
     const long per = a.L.per;
     const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    auto mv = [&](cplx *field, long n, long off) {
-        for (long i = t0; i < n; i += stride) {
-            if (PACK) s[off + i] = field[(long)w * n + i];
-            else field[(long)w * n + i] = s[off + i];
-        }
-    };
-    long off = 0;
-    mv(a.phi, per, off); off += per;
-    if (a.L.with_greens) { mv(a.ghalf, per, off); off += per; }
-    if (a.L.with_bp) { mv(a.phi_old, per, off); off += per; mv(a.bp_hist, a.L.hist_per, off); off += a.L.hist_per; }
-    if (a.L.with_rdm) { mv(a.G, a.L.gsz, off); off += a.L.gsz; }
-    if (t0 == 0) {
-        if (PACK) {
-            s[off] = a.ot[w]; s[off + 1] = a.ehyb[w]; s[off + 2] = a.phase[w]; s[off + 3] = a.eloc[w];
-            s[off + 4] = cmake(a.unscaled[w], a.detR[w]);
-            s[off + 5] = cmake(a.log_detR[w], 0.0);
-            long o = off + 6;
-            if (a.L.with_greens) s[o++] = a.ovlp_new[w];
-            if (a.L.with_bp) { s[o++] = a.bp_ph[w]; s[o++] = cmake(a.bp_cos[w], (double)a.bp_n[w]); }
-        } else {
-            a.ot[w] = s[off]; a.ehyb[w] = s[off + 1]; a.phase[w] = s[off + 2]; a.eloc[w] = s[off + 3];
-            a.unscaled[w] = s[off + 4].x; a.detR[w] = s[off + 4].y;
-            a.log_detR[w] = s[off + 5].x;
-            long o = off + 6;
-            if (a.L.with_greens) a.ovlp_new[w] = s[o++];
-            if (a.L.with_bp) { a.bp_ph[w] = s[o++]; a.bp_cos[w] = s[o].x; a.bp_n[w] = (int)s[o].y; ++o; }
+    for (int sl = blockIdx.y; sl < count; sl += gridDim.y) {
+        const int w = a.idx[peer * a.cap + sl];
+        cplx *s;
+        // window pack: straight into the window of the destination rank, row of this rank; window unpack: this rank's window,
+        // row of the source; send / receive buffers otherwise
+        if (a.window && PACK) s = a.wl.rbuf(a.pw.base[peer]) + ((long)a.rank * a.cap + sl) * a.slot;
+        else s = a.buf + ((long)peer * a.cap + sl) * a.slot;
+        auto mv = [&](cplx *field, long n, long off) {
+            for (long i = t0; i < n; i += stride) {
+                if (PACK) s[off + i] = field[(long)w * n + i];
+                else field[(long)w * n + i] = s[off + i];
+            }
+        };
+        long off = 0;
+        mv(a.phi, per, off); off += per;
+        if (a.L.with_greens) { mv(a.ghalf, per, off); off += per; }
+        if (a.L.with_bp) { mv(a.phi_old, per, off); off += per; mv(a.bp_hist, a.L.hist_per, off); off += a.L.hist_per; }
+        if (a.L.with_rdm) { mv(a.G, a.L.gsz, off); off += a.L.gsz; }
+        if (t0 == 0) {
+            if (PACK) {
+                s[off] = a.ot[w]; s[off + 1] = a.ehyb[w]; s[off + 2] = a.phase[w]; s[off + 3] = a.eloc[w];
+                s[off + 4] = cmake(a.unscaled[w], a.detR[w]);
+                s[off + 5] = cmake(a.log_detR[w], 0.0);
+                long o = off + 6;
+                if (a.L.with_greens) s[o++] = a.ovlp_new[w];
+                if (a.L.with_bp) { s[o++] = a.bp_ph[w]; s[o++] = cmake(a.bp_cos[w], (double)a.bp_n[w]); }
+                if (a.window) {     // traffic statistics: walkers / bytes this rank has written into peer windows
+                    atomicAdd(a.scal + 7, 1.0);
+                    atomicAdd(a.scal + 8, (double)(a.L.size() * (long)sizeof(cplx)));
+                }
+            } else {
+                a.ot[w] = s[off]; a.ehyb[w] = s[off + 1]; a.phase[w] = s[off + 2]; a.eloc[w] = s[off + 3];
+                a.unscaled[w] = s[off + 4].x; a.detR[w] = s[off + 4].y;
+                a.log_detR[w] = s[off + 5].x;
+                long o = off + 6;
+                if (a.L.with_greens) a.ovlp_new[w] = s[o++];
+                if (a.L.with_bp) { a.bp_ph[w] = s[o++]; a.bp_cos[w] = s[o].x; a.bp_n[w] = (int)s[o].y; ++o; }
+            }
         }
     }
     if (PACK && a.window) {
-        // every block of this peer's slots takes a ticket once its writes are out; the last one raises the peer's flag
+        // every block that had slots of this peer takes a ticket once its writes are out; the last one raises the peer's flag
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
-            if (blockIdx.x == 0) {      // traffic statistics: walkers / bytes this rank has written into peer windows
-                atomicAdd(a.scal + 7, 1.0);
-                atomicAdd(a.scal + 8, (double)(a.L.size() * (long)sizeof(cplx)));
-            }
-            const int total = (int)gridDim.x * a.count[peer];
-            if (atomicAdd(a.tickets + peer, 1) == total - 1) {
+            const int rows = count < (int)gridDim.y ? count : (int)gridDim.y;
+            if (atomicAdd(a.tickets + peer, 1) == (int)gridDim.x * rows - 1) {
                 a.tickets[peer] = 0;
                 __threadfence_system();
                 flag_release(a.wl.flag_x(a.pw.base[peer]) + a.rank, a.seq);
@@ -632,7 +638,7 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
     if (c->nranks > 1) {
         PackArgs p;
         fill_pack(h, p, with_greens, true);
-        AFQ_LAUNCH(h, comm_pack_kernel<true>, dim3(4, c->cap, c->nranks), dim3(256), 0, h->stream, p);
+        AFQ_LAUNCH(h, comm_pack_kernel<true>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
         AFQ_POST(h);
     }
     return AFQ_OK;
@@ -644,7 +650,7 @@ int stage_unpack(afq_handle *h, bool with_greens) {
     if (c->nranks > 1) {
         PackArgs p;
         fill_pack(h, p, with_greens, false);
-        AFQ_LAUNCH(h, comm_pack_kernel<false>, dim3(4, c->cap, c->nranks), dim3(256), 0, h->stream, p);
+        AFQ_LAUNCH(h, comm_pack_kernel<false>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
         AFQ_POST(h);
     }
     c->events += 1;

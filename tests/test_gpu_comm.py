@@ -88,9 +88,11 @@ def test_comb_across_ranks_equals_one_rank(golden, nranks, nw):
     close_all([one] + ranks)
 
 
-def test_walkers_did_change_rank(golden):
-    """The case the transport exists for: every heavy walker on rank 0, every dead one on rank 1."""
-    nranks, nw = 2, 8
+@pytest.mark.parametrize("nw", [8, 48])
+def test_walkers_did_change_rank(golden, nw):
+    """The case the transport exists for: every heavy walker on rank 0, every dead one on rank 1 (48: more slots per
+    peer than the pack / unpack grid has block rows, every row loops)."""
+    nranks = 2
     model, one, ranks, rng = start(golden, nranks, nw)
     w = numpy.concatenate([numpy.full(nw, 3.0), numpy.full(nw, 1e-3)])
     one.set(L.F_WEIGHT, w); ranks[0].set(L.F_WEIGHT, w[:nw]); ranks[1].set(L.F_WEIGHT, w[nw:])
@@ -102,6 +104,7 @@ def test_walkers_did_change_rank(golden):
     assert numpy.all(pix[nw:] == 0) and numpy.all(pix[:nw] == 2)
     same_population(one, ranks)
     assert ranks[0].comm_stats()['max_transfer'] == nw
+    assert ranks[0].comm_stats()['walkers_sent'] == nw and ranks[1].comm_stats()['walkers_sent'] == 0
     # the walkers of rank 1 now ARE those of rank 0
     assert numpy.array_equal(ranks[1].get(L.F_PHI), ranks[0].get(L.F_PHI))
     close_all([one] + ranks)
