@@ -46,55 +46,52 @@ __device__ inline double gj_bcast_half(double x, int hk) {
     return __hiloint2double((int)(hk ? b[1] : b[0]), (int)(hk ? a[1] : a[0]));
 }
 
-// column (cr, ci) of half hk to every lane of its row, and the pivot row of that column: largest fp32-rounded
-// |re| + |im| among the rows not used yet, ties -> lowest row
-__device__ __attribute__((always_inline)) inline void gj_search(double cr, double ci, int hk, bool used, int r, int n,
-                                                                double &fx, double &fy, int &p) {
-    fx = gj_bcast_half(cr, hk); fy = gj_bcast_half(ci, hk);
-    const unsigned mb = __float_as_uint((float)(fabs(fx) + fabs(fy)));
-    const unsigned key = (used || r >= n) ? 0u : ((((mb >> 6) + 1u) << 5) | (unsigned)(31 - r));
-    p = 31 - (int)(gj_wave_max_u32(key) & 31u);
-}
-
-// Eight pivot steps k = 8 it .. 8 it + 7 with static register indices: physical register u holds
-// the column that is active at step u of the block (the caller swaps the two halves of the
-// register array after every block).  The body is a loop of <= 4 iterations over this block so that
-// the code (8 steps ~ 14 KB) stays in the instruction cache instead of streaming 32 unrolled steps.
-// Look-ahead: step k eliminates column k + 1 FIRST and starts that column's hand-over and pivot search (two
-// v_permlane32_swap, six dependent DPP maxima, a v_readlane: a chain of ~300 cycles with nothing else to issue) under the
-// elimination of the other fifteen columns; (fx, fy, p) of the step to come travel in registers, across blocks too.
-__device__ inline void gj_block8(double (&vr)[16], double (&vi)[16], int it, int n, int lane, bool &used,
-                                 double &sx, double &sy, int &mystep, cplx *rowk, cplx *piv, int *prow,
-                                 double &fx, double &fy, int &p) {
+// One block of <= 8 pivot steps with static register indices.  Lane (h, r) keeps RJ columns of row r: columns
+// RJ h .. RJ h + RJ - 1 (RJ = ceil(n / 2) rounded up to 4, 8, 12, 13 or 16: every instruction of a step -- 4 fp64 FMAs, one
+// LDS store and one LDS load per register -- is issued for BOTH halves, so the columns are split evenly and no more
+// registers are carried than the matrix needs; the step is bound by the instruction issue of its one wave).
+//   RJ <= 8: block `it` = half `it`, registers 0 .. RJ - 1.
+//   RJ > 8:  blocks 2 hk and 2 hk + 1 of half hk cover its registers 0..7 and 8..RJ - 1; the caller's register array is
+//            rotated by 8 after every block (swap j <-> j + 8), so the active column of step u is always physical register u.
+// The body is a loop over the blocks so that the code stays in the instruction cache instead of streaming n unrolled steps.
+template <int RJ>
+__device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int n, int lane, bool &used,
+                                 double &sx, double &sy, int &mystep, cplx *rowk, cplx *piv, int *prow) {
     const int h = lane >> 5, r = lane & 31;
-    const int hk = it >> 1;
-    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 256u * h;
+    const int hk = RJ <= 8 ? it : it >> 1;
+    const int kbase = hk * RJ + (RJ <= 8 ? 0 : 8 * (it & 1));
+    const int nu = RJ <= 8 ? RJ : ((it & 1) ? RJ - 8 : 8);
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 16u * RJ * h;
+    constexpr int NU = RJ < 8 ? RJ : 8;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = 8 * it + u;
-        if (k < n) {
-            // 1./2. column k (fx, fy) and its pivot row p were found during the previous step
-            const double cx = fx, cy = fy;
-            const int pk = p;
-            const bool isp = r == pk;
+    for (int u = 0; u < NU; ++u) {
+        const int k = kbase + u;
+        if (u < nu && k < n) {
+            // 1. column k to every lane of its row
+            const double fx = gj_bcast_half(vr[u], hk), fy = gj_bcast_half(vi[u], hk);
+            // 2. pivot row: largest fp32-rounded |re| + |im| among unused rows, ties -> lowest row
+            const unsigned mb = __float_as_uint((float)(fabs(fx) + fabs(fy)));
+            const unsigned key = (used || r >= n) ? 0u : ((((mb >> 6) + 1u) << 5) | (unsigned)(31 - r));
+            const int p = 31 - (int)(gj_wave_max_u32(key) & 31u);
+            const bool isp = r == p;
             used = used || isp;
             // 3. slot (., k) becomes the identity column of the pivot row; the (unscaled) pivot row goes
             //    to LDS first so that its round trip overlaps the reciprocal below
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
             if (isp) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
+                for (int j = 0; j < RJ; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
             }
             __builtin_amdgcn_wave_barrier();
-            cplx rk[16];
+            cplx rk[RJ];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rk[j] = rowk[16 * h + j];
+            for (int j = 0; j < RJ; ++j) rk[j] = rowk[RJ * h + j];
             __builtin_amdgcn_sched_barrier(0);
             // 4. pivot value (uniform), its reciprocal, multipliers (zero for the pivot row itself)
-            const double dx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cx), pk),
-                                               __builtin_amdgcn_readlane(__double2loint(cx), pk));
-            const double dy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cy), pk),
-                                               __builtin_amdgcn_readlane(__double2loint(cy), pk));
+            const double dx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), p),
+                                               __builtin_amdgcn_readlane(__double2loint(fx), p));
+            const double dy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fy), p),
+                                               __builtin_amdgcn_readlane(__double2loint(fy), p));
             // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is a 12-deep
             // dependent chain on the per-pivot critical path; this one is 5 deep, < 1 ulp off)
             const double nn = dx * dx + dy * dy;
@@ -102,65 +99,67 @@ __device__ inline void gj_block8(double (&vr)[16], double (&vi)[16], int it, int
             dn = fma(fma(-nn, dn, 1.0), dn, dn);
             dn = fma(fma(-nn, dn, 1.0), dn, dn);
             const double ix = dx * dn, iy = -dy * dn;
-            if (lane == 0) { piv[k] = cmake(dx, dy); prow[k] = pk; }
+            if (lane == 0) { piv[k] = cmake(dx, dy); prow[k] = p; }
             if (isp) { sx = ix; sy = iy; mystep = k; }
-            const double mx = isp ? 0.0 : cx * ix - cy * iy, my = isp ? 0.0 : cx * iy + cy * ix;
+            const double mx = isp ? 0.0 : fx * ix - fy * iy, my = isp ? 0.0 : fx * iy + fy * ix;
             __builtin_amdgcn_sched_barrier(0);
-            // 5. eliminate: the column of the next step first (register u + 1; the first column of the next block still
-            //    sits in register 8, the halves are swapped below), then its search among the other columns' updates
-            const int un = u < 7 ? u + 1 : 8;
-            const int hkn = u < 7 ? hk : (it + 1) >> 1;
-            auto elim = [&](int j) __attribute__((always_inline)) {
+            // 5. eliminate
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
                 vr[j] = fma(-mx, rk[j].x, vr[j]); vr[j] = fma(my, rk[j].y, vr[j]);
                 vi[j] = fma(-mx, rk[j].y, vi[j]); vi[j] = fma(-my, rk[j].x, vi[j]);
-            };
-            const bool more = k + 1 < n;               // (wave-uniform)
-            elim(un);
-            if (more) gj_search(vr[un], vi[un], hkn, used, r, n, fx, fy, p);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j != un) elim(j);
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (RJ > 8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double t = vr[j]; vr[j] = vr[j + 8]; vr[j + 8] = t;
-        t = vi[j]; vi[j] = vi[j + 8]; vi[j + 8] = t;
+        for (int j = 0; j + 8 < RJ; ++j) {
+            double t = vr[j]; vr[j] = vr[j + 8]; vr[j + 8] = t;
+            t = vi[j]; vi[j] = vi[j + 8]; vi[j + 8] = t;
+        }
+    }
+}
+
+// the inversion proper for one register count; `mystep`, (sx, sy) = step and reciprocal pivot of this lane's row
+template <int RJ>
+__device__ inline void gj_wave_rj(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow) {
+    const int h = lane >> 5, r = lane & 31;
+    double vr[RJ], vi[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int c = RJ * h + j;
+        const cplx t = (r < n && c < n) ? O[r * n + c] : cmake(0.0, 0.0);
+        vr[j] = t.x; vi[j] = t.y;
+    }
+    bool used = false;
+    double sx = 1.0, sy = 0.0;
+    int mystep = r;
+    __builtin_amdgcn_wave_barrier();
+    // (an even number of blocks per half: the register rotation of RJ > 8 is back where it started)
+    constexpr int NIT = RJ <= 8 ? 2 : 4;
+    for (int it = 0; it < NIT; ++it) gj_block8<RJ>(vr, vi, it, n, lane, used, sx, sy, mystep, rowk, piv, prow);
+    __builtin_amdgcn_wave_barrier();
+    if (write_inverse && r < n) {
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int c = RJ * h + j;
+            if (c < n) O[mystep * n + prow[c]] = cmake(vr[j] * sx - vi[j] * sy, vr[j] * sy + vi[j] * sx);
+        }
     }
 }
 
 // O: n x n row-major in LDS (overwritten with the inverse when write_inverse); returns det via ph / la
 __device__ inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
                                  cplx &ph, int &la) {
-    const int h = lane >> 5, r = lane & 31;
-    double vr[16], vi[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c = 16 * h + j;
-        const cplx t = (r < n && c < n) ? O[r * n + c] : cmake(0.0, 0.0);
-        vr[j] = t.x; vi[j] = t.y;
-    }
     if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
-    bool used = false;
-    double sx = 1.0, sy = 0.0;
-    int mystep = r;
-    __builtin_amdgcn_wave_barrier();
     n = __builtin_amdgcn_readfirstlane(n);
-    const int nit = (n + 7) >> 3;
-    double fx, fy;
-    int p;
-    gj_search(vr[0], vi[0], 0, used, r, n, fx, fy, p);
-    for (int it = 0; it < nit; ++it) gj_block8(vr, vi, it, n, lane, used, sx, sy, mystep, rowk, piv, prow, fx, fy, p);
+    if (n <= 8) gj_wave_rj<4>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 16) gj_wave_rj<8>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 24) gj_wave_rj<12>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 26) gj_wave_rj<13>(O, n, lane, write_inverse, rowk, piv, prow);
+    else gj_wave_rj<16>(O, n, lane, write_inverse, rowk, piv, prow);
     __builtin_amdgcn_wave_barrier();
-    if (write_inverse && r < n) {
-        const int rot = 8 * (nit & 1);           // the register halves were swapped nit times
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = 16 * h + ((j + rot) & 15);
-            if (c < n) O[mystep * n + prow[c]] = cmake(vr[j] * sx - vi[j] * sy, vr[j] * sy + vi[j] * sx);
-        }
-    }
     // determinant: product of the pivots (lanes 0..31, normalised after every multiply) and the
     // parity of the pivot permutation from its inversion count
     const cplx d = piv[lane & 31];

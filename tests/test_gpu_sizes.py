@@ -381,3 +381,23 @@ def test_planewave_step_shapes(rs, nup, ndown, ecut, psi):
         close(out_e[i], w['hybrid_energy'])
         close(xs_step[i], xi[i] - xbar_general[i], 1e-12)
     dev.close()
+
+
+@pytest.mark.parametrize("na,nb", [(n, max(n - (n % 3), 0)) for n in range(1, 33)])
+def test_greens_every_electron_count(na, nb):
+    """The register-resident Gauss-Jordan keeps ceil(n / 2) columns per lane rounded up to 4 / 8 / 12 / 13 / 16 registers
+    (gj_wave.h): overlap, Ghalf and G against the oracle for every n <= 32, unequal spins, walkers far from the trial
+    (the pivot order is not the identity)."""
+    M, nw = 40, 6
+    model, rng = build(M, 12, na, nb, True, seed=na)
+    dev = make_device(model, nw)
+    phi = rng.rand(nw, M, na + nb) - 0.5 + 1j * (rng.rand(nw, M, na + nb) - 0.5)
+    dev.set(L.F_PHI, phi)
+    ot = dev.greens(want_G=True)
+    G, gh = dev.get(L.F_G), dev.get(L.F_GHALF)
+    for w in range(nw):
+        det, ghalf_ref, G_ref = ref.greens_function(phi[w], model.psi, na, nb)
+        assert abs(ot[w] - det) <= 1e-10 * abs(det)
+        close(G[w], G_ref, 1e-9)
+        close(gh[w].reshape(na + nb, M), numpy.concatenate([g for g in ghalf_ref if g is not None and len(g)]), 1e-9)
+    dev.close()
