@@ -5,8 +5,10 @@
 // LDS when they fit and in a global workspace otherwise.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "mfma_gemm.h"
 #include "gj_wave.h"
+#include "lds_dma.h"
 
 #include "block_scan.h"
 #define NTHR 256
@@ -97,6 +99,7 @@ struct GreensArgs {
     int only_alive;
     const int *alive;
     int dbg;            // timing experiments only (AFQ_GREENS_DBG): 1 skip pivot loop, 2 skip phase 3, 4 skip phase 1
+    int psi_real;       // every imaginary part of the (single, shared) trial is exactly zero (checked at upload)
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -315,7 +318,15 @@ __global__ void weight_kernel(WeightArgs a) {
 // wa.weight != null: the hybrid / free-projection weight update of this walker (propagation/continuous.py:264-292,
 // :194-200) and the driver's weight cap run right behind its determinant (a.det IS wa.ovlp_new then), which
 // saves the separate weight_kernel launch of the step.
-template <bool INVERSE>
+#ifdef AFQ_TUNING
+__device__ unsigned long long *afq_gs_ts = nullptr;      // [8 waves][12 stamps] of work-group 0 (AFQ_GS_TS)
+#define GS_STAMP(i) do { if (afq_gs_ts && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); afq_gs_ts[(threadIdx.x >> 6) * 12 + (i)] = t_; } } while (0)
+#else
+#define GS_STAMP(i)
+#endif
+// WGJ: both spins have n <= 32 and invert by one wave each in registers (gj_wave.h); otherwise the LDS Gauss-Jordan of
+// wave 0.  Two instantiations, so that neither carries the other's registers and scalars.
+template <bool INVERSE, bool WGJ>
 __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cplx ph_s[2];
@@ -340,64 +351,130 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     const int lr = lane & 15, lk = lane >> 4;
     const int nt16 = (n + 15) >> 4;
     const int nks = (M + 3) >> 2;
-    // ---- phase 0: the walker's Slater matrix into LDS, one coalesced sweep
-    for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
-    // ---- phase 1: O = phi_s^T conj(psi_s).  The trial fragments of the wave's first tile are
-    // fetched up front (all loads in flight at once); phi fragments come from LDS.
-    for (int t = wave; t < ((a.dbg & 4) ? 0 : nt16 * nt16); t += 4) {
-        const int ti = t / nt16, tj = t % nt16;
-        const int ia = ti * 16 + lr, jb = tj * 16 + lr;
-        const int iac = ia < n ? ia : n - 1, jbc = jb < n ? jb : n - 1;     // clamped: loads stay unconditional
-        d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+    GS_STAMP(0);
+    // ---- phases 0 and 1: the walker's Slater matrix into LDS, O = phi_s^T conj(psi_s) by MFMA (phi fragments from LDS, trial
+    // fragments from memory).  k-steps go in groups of four.  The first sixteen trial fragments of the wave's first tile are
+    // requested BEFORE the copy (they do not depend on the walker: their latency runs under phase 0), the rest right behind
+    // the barrier, ahead of the first MFMA.  The MFMA loop is pipelined by hand: the four phi fragments of group g + 1 are
+    // read from LDS before the twelve MFMAs of group g are issued, and there is ONE uniform branch per group -- with a branch
+    // per k-step every LDS read sat in its own basic block right in front of the three MFMAs that wait for it (~800 cycles
+    // per k-step measured, 64 x 3 of them MFMA).  Addresses are 32-bit offsets from wave-uniform bases.
+    constexpr int NG = GS_KSMAX / 4;
+    const int ng = (nks + 3) >> 2;
+    // real trial (RHF / UHF orbitals of a real Hamiltonian, plane waves, lattice sites): x * y by two MFMAs per k-step
+    // instead of three -- the phase is bound by the matrix pipe, two waves per SIMD.  The choice is made ONCE, around the
+    // whole phase (a generic lambda instantiated for both cases): a test inside the loops is a branch per k-step.
+    const bool yreal = WGJ && a.psi_real != 0;
+    const char *psi_w = (const char *)(a.psi + w * a.psi_stride);
+    const bool has_tile = wave < nt16 * nt16 && !(a.dbg & 4);
+    auto phase01 = [&](auto yr_tag) __attribute__((always_inline)) {
+        constexpr bool YR = decltype(yr_tag)::value;
+        using y_t = typename std::conditional<YR, double, cplx>::type;
+        y_t yf[GS_KSMAX];
+        // sixteen k-steps of trial fragments: unconditional loads of clamped rows, nothing that reads them in between (a
+        // select on a loaded value in this block makes the compiler wait for every group of loads before it issues the
+        // next); rows past M are zeroed where they are used
+        auto load_trial = [&](int tj, const int g0) __attribute__((always_inline)) {
+            const int jb = tj * 16 + lr, jbc = jb < n ? jb : n - 1;
+            const unsigned col = (unsigned)(off + jbc) * 16u, rowb = (unsigned)nt * 16u;
 #pragma unroll
-        for (int half = 0; half < GS_KSMAX / 16; ++half) {
-            if (half * 16 < nks) {
-                cplx yb[16];
+            for (int q = 0; q < 16; ++q) {
+                const int ks = g0 * 4 + q, p = ks * 4 + lk;
+                yf[ks] = *(const y_t *)(psi_w + ((unsigned)(p < M ? p : M - 1) * rowb + col));
+            }
+        };
+        const int tj0 = has_tile ? wave % nt16 : 0;
+        if (has_tile) {
+            load_trial(tj0, 0);
+            if (ng > 4) load_trial(tj0, 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // the walker by LDS-DMA: 1 KB per wave and instruction straight into phi_l, all requests of a wave in flight at once
+            const unsigned total = (unsigned)(M * nt) * 16u;
+            const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+            for (unsigned b0 = (unsigned)wave8 * 1024u; b0 < total; b0 += 8 * 1024u) {
+                const unsigned bo = b0 + (unsigned)lane * 16u;
+                if (bo < total) glds16((const char *)phi_g + bo, (char *)phi_l + b0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        GS_STAMP(1);
+        __syncthreads();                                         // phi_l complete
+        for (int t = wave; t < ((a.dbg & 4) ? 0 : nt16 * nt16); t += 4) {
+            const int ti = t / nt16, tj = t % nt16;
+            const int ia = ti * 16 + lr;
+            const int iac = ia < n ? ia : n - 1;
+            if (!WGJ && t != wave) {                             // (n <= 32: four tiles per spin, one per wave)
+                load_trial(tj, 0);
+                if (ng > 4) load_trial(tj, 4);
+            }
+            d4_t accR = {0, 0, 0, 0}, accI = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+            cplx xa[4], xb[4];
+            const unsigned xcol = (unsigned)(off + iac), xrow = (unsigned)nt;
+            auto readx = [&](cplx (&x)[4], const int gq) __attribute__((always_inline)) {
 #pragma unroll
-                // (rows / columns of the tile beyond n read a clamped, valid column and are never stored; only a contraction
-                //  index past M must contribute zero, and that can only happen in the last step of a ragged M: the selects
-                //  sit behind a uniform test, the loads themselves are unconditional)
-                for (int u = 0; u < 16; ++u) {
-                    const int p = (half * 16 + u) * 4 + lk;
-                    yb[u] = a.psi[w * a.psi_stride + (long)(p < M ? p : M - 1) * nt + off + jbc];
-                    if ((M & 3) && half * 16 + u == nks - 1 && p >= M) yb[u] = cmake(0.0, 0.0);
+                for (int u = 0; u < 4; ++u) {
+                    const int p = (gq * 4 + u) * 4 + lk;
+                    x[u] = phi_l[xcol + (unsigned)(p < M ? p : M - 1) * xrow];
                 }
-                __builtin_amdgcn_sched_barrier(0);      // all 16 trial-fragment loads in flight before any MFMA
-                if (t == wave && half == 0) __syncthreads();   // phi_l complete (each wave passes here once)
+            };
+            auto mf = [&](const cplx (&x)[4], const int gq) __attribute__((always_inline)) {
+                const bool last = gq == ng - 1;                  // (uniform) only the last group can run past M
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int ks = half * 16 + u;
-                    if (ks < nks) {
-                        const int p = ks * 4 + lk;
-                        const cplx x = phi_l[(p < M ? p : M - 1) * nt + off + iac];   // (yb is zero past M: see above)
-                        const cplx y = yb[u];
+                for (int u = 0; u < 4; ++u) {
+                    const bool dead = last && (gq * 4 + u) * 4 + lk >= M;
+                    if constexpr (YR) {
+                        const double y = dead ? 0.0 : yf[gq * 4 + u];
+                        accR = mfma16(x[u].x, y, accR);
+                        acc3 = mfma16(x[u].y, y, acc3);
+                    } else {
+                        const cplx y = dead ? cmake(0.0, 0.0) : yf[gq * 4 + u];
                         // x * conj(y) by three multiplications: P1 = xr yr, P2 = xi yi, P3 = (xr + xi)(yr - yi);
                         // re = P1 + P2, im = P3 - P1 + P2 (three independent accumulator chains)
-                        accR = mfma16(x.x, y.x, accR);
-                        accI = mfma16(x.y, y.y, accI);
-                        acc3 = mfma16(x.x + x.y, y.x - y.y, acc3);
+                        accR = mfma16(x[u].x, y.x, accR);
+                        accI = mfma16(x[u].y, y.y, accI);
+                        acc3 = mfma16(x[u].x + x[u].y, y.x - y.y, acc3);
                     }
                 }
-            }
-        }
+            };
+            readx(xa, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
-            if (i < n && j < n) O[i * n + j] = cmake(accR[r] + accI[r], acc3[r] - accR[r] + accI[r]);
+            for (int gq = 0; gq < NG; gq += 2) {
+                if (gq < ng) {
+                    if (gq + 1 < ng) readx(xb, gq + 1);
+                    mf(xa, gq);
+                }
+                if (gq + 1 < ng) {
+                    if (gq + 2 < ng) readx(xa, gq + 2 < NG ? gq + 2 : 0);
+                    mf(xb, gq + 1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
+                if (i < n && j < n) O[i * n + j] = YR ? cmake(accR[r], acc3[r]) : cmake(accR[r] + accI[r], acc3[r] - accR[r] + accI[r]);
+            }
+            if (WGJ) break;
         }
-    }
-    if (wave >= nt16 * nt16 || (a.dbg & 4)) __syncthreads();  // waves without a tile still owe the phase-0 barrier
+    };
+    if (yreal) phase01(std::true_type{});
+    else phase01(std::false_type{});
+    GS_STAMP(2);
     __syncthreads();
+    GS_STAMP(3);
     // ---- phase 2
     __shared__ cplx gj_row[2][32], gj_piv[2][32];
     __shared__ int gj_prow[2][32];
     // (the two single-wave inversions run on different SIMDs: spin up on wave 0, spin down on wave 1 of its group = wave 5)
-    if (wave == (n <= 32 ? g : 0) && !(a.dbg & 1) && n <= 32 && !(a.dbg & 8)) {
-        cplx ph;
-        int la;
-        gj_wave32(O, n, lane, INVERSE, gj_row[g], gj_piv[g], gj_prow[g], ph, la);
-        if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
-    } else if (wave == 0 && !(a.dbg & 1) && (n > 32 || (a.dbg & 8))) {
+    if (WGJ) {
+        if (wave == g && !(a.dbg & 1)) {
+            cplx ph;
+            int la;
+            gj_wave32(O, n, lane, INVERSE, gj_row[g], gj_piv[g], gj_prow[g], ph, la);
+            if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
+        }
+    } else if (wave == 0 && !(a.dbg & 1)) {
         // det = prod of pivots, kept as (mantissa, binary exponent) so that neither log, exp nor
         // hypot sits on the per-pivot critical path
         cplx ph = cmake(1.0, 0.0);
@@ -516,13 +593,16 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
         }
         if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
     }
+    GS_STAMP(4);
     __syncthreads();
+    GS_STAMP(5);
     if (tid == 0) {
         const cplx p2 = (a.dbg & 1) ? cmake(1.0, 0.0) : cmul(ph_s[0], ph_s[1]);
         const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
         if (wa.weight) weight_update_and_cap(wa, w);
     }
+    GS_STAMP(6);
     if (INVERSE && a.oinv) {
         cplx *oo = a.oinv + ((long)w * 2 + g) * nmax * nmax;
         for (int e = tid & 255; e < n * n; e += 256) oo[(e / n) * nmax + (e % n)] = O[e];
@@ -562,6 +642,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                 }
                 d4_t p1a = {0, 0, 0, 0}, p2a = {0, 0, 0, 0}, p3a = {0, 0, 0, 0};
                 d4_t p1b = {0, 0, 0, 0}, p2b = {0, 0, 0, 0}, p3b = {0, 0, 0, 0};
+                GS_STAMP(7 + 2 * (s & 1));
 #pragma unroll
                 for (int ks = 0; ks < 12; ++ks) {
                     if (ks < nks3) {
@@ -580,13 +661,14 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                         }
                     }
                 }
+                GS_STAMP(8 + 2 * (s & 1));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = ti * 16 + lk + 4 * r;
                     const double ra = p1a[r] - p2a[r], ima = p3a[r] - p1a[r] - p2a[r];
                     const double rb = p1b[r] - p2b[r], imb = p3b[r] - p1b[r] - p2b[r];
-                    if (i < ns && c0 < M) gh[(long)i * M + c0] = cmake(ra, ima);
-                    if (two && i < ns && c1 < M) gh[(long)i * M + c1] = cmake(rb, imb);
+                    if (i < ns && c0 < M && !(a.dbg & 16)) gh[(long)i * M + c0] = cmake(ra, ima);
+                    if (two && i < ns && c1 < M && !(a.dbg & 16)) gh[(long)i * M + c1] = cmake(rb, imb);
                     sra[r] += ra; sia[r] += ima; srb[r] += rb; sib[r] += imb;
                 }
             }
@@ -601,6 +683,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
             }
         }
     }
+    GS_STAMP(11);
 }
 
 static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, cplx *oinv = nullptr) {
@@ -609,6 +692,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     if (ghalf) ++h->ghalf_version;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
+    a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
     if (k_greens_big_supported(h)) {
@@ -626,11 +710,34 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         h->fuse_weight_req = false;
         static const int dbg = afq_knob("AFQ_GREENS_DBG") ? atoi(afq_knob("AFQ_GREENS_DBG")) : 0;
         a.dbg = dbg;
+#ifdef AFQ_TUNING
+        static unsigned long long *gsts = nullptr;
+        static int gs_launch = 0;
+        if (afq_knob("AFQ_GS_TS")) {
+            if (!gsts) { hipMalloc(&gsts, 96 * 8); hipMemset(gsts, 0, 96 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_gs_ts), &gsts, sizeof(gsts)); }
+            if (++gs_launch == 30) {
+                unsigned long long t[96];
+                hipStreamSynchronize(h->stream);
+                hipMemcpy(t, gsts, sizeof(t), hipMemcpyDeviceToHost);
+                for (int wv = 0; wv < 8; ++wv) {
+                    fprintf(stderr, "gs_ts wave %d:", wv);
+                    for (int i = 1; i < 12; ++i) fprintf(stderr, " %6lld", t[wv * 12 + i] ? (long long)(t[wv * 12 + i] - t[0]) : -1LL);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+#endif
         if (h->M > 4 * GS_KSMAX) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "fast Green's kernel supports M <= 128");
         const size_t lds = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) +
                                            (size_t)h->M * h->nt);
         // raise the dynamic-LDS cap once per kernel and device, not per launch
-        static size_t lds_set1[AFQ_MAX_DEVICES] = {0}, lds_set0[AFQ_MAX_DEVICES] = {0};
+        static size_t lds_set[4][AFQ_MAX_DEVICES] = {{0}};
+        const bool wgj = nmax <= 32;
+#ifdef AFQ_TUNING
+        const bool wgj_on = wgj && !(dbg & 8);
+#else
+        const bool wgj_on = wgj;
+#endif
         if (ghalf || oinv) {
             // the spin sum the force bias contracts (every walker written: not on the only_alive path)
             const bool want_sum = ghalf && ghalf == h->ghalf && !only_alive && k_fb_use_sum(h) && h->psi_stride == 0;
@@ -638,13 +745,21 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
                 if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)h->na * h->M * h->nw));
                 a.gsum = h->ghalf_sum;
             }
-            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true>, lds, lds_set1));
             KernelTrace kt(h, AFQ_K_GREENS);
-            AFQ_LAUNCH(h, greens_small_kernel<true>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
+            if (wgj_on) {
+                AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true, true>, lds, lds_set[0]));
+                AFQ_LAUNCH(h, (greens_small_kernel<true, true>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
+            } else {
+                AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true, false>, lds, lds_set[1]));
+                AFQ_LAUNCH(h, (greens_small_kernel<true, false>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
+            }
             if (want_sum) h->gsum_version = h->ghalf_version;
+        } else if (wgj_on) {
+            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false, true>, lds, lds_set[2]));
+            AFQ_LAUNCH(h, (greens_small_kernel<false, true>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
         } else {
-            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false>, lds, lds_set0));
-            AFQ_LAUNCH(h, greens_small_kernel<false>, dim3(h->nw), dim3(512), lds, h->stream, a, wa);
+            AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false, false>, lds, lds_set[3]));
+            AFQ_LAUNCH(h, (greens_small_kernel<false, false>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
         }
         AFQ_POST(h);
         return AFQ_OK;
