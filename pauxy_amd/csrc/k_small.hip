@@ -596,7 +596,8 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     GS_STAMP(4);
     __syncthreads();
     GS_STAMP(5);
-    if (tid == 0) {
+    // (the last wave: its phase-3 item is the half-width one, the first wave's is full)
+    if (tid == 448) {
         const cplx p2 = (a.dbg & 1) ? cmake(1.0, 0.0) : cmul(ph_s[0], ph_s[1]);
         const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
