@@ -1330,7 +1330,16 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
     cplx *S = phi_l + (long)M * nt + (long)g * (32 * RF_LD);   // [32, RF_LD] Gram matrix, then T^T, of this spin (row stride 33: no bank conflicts for a lane per row)
     cplx *phi_g = a.phi + (long)w * M * nt;
     RF_STAMP(0);
-    for (int e = tid; e < M * nt; e += 512) phi_l[e] = phi_g[e];
+    {
+        // the walker by LDS-DMA: 1 KB per wave and instruction, all requests of a wave in flight at once
+        const unsigned total = (unsigned)(M * nt) * 16u;
+        const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (unsigned b0 = (unsigned)wave8 * 1024u; b0 < total; b0 += 8 * 1024u) {
+            const unsigned bo = b0 + (unsigned)lane * 16u;
+            if (bo < total) glds16((const char *)phi_g + bo, (char *)phi_l + b0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (tid < 2) { logd_s[tid] = 0.0; bad_s[tid] = 0; }
     __syncthreads();
     RF_STAMP(1);
@@ -1351,7 +1360,32 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             // conj(x) * y by three multiplications: P1 = xr yr, P2 = xi yi, P3 = (xr - xi)(yr + yi); re = P1 + P2,
             // im = P3 - P1 + P2
             d4_t acc3 = {0, 0, 0, 0};
-            for (int ks = 0; ks < nfull; ++ks) {
+            // pairs of k-steps, the fragments of the next pair read from LDS ahead of the six MFMAs of this one (one k-step per
+            // loop iteration put every pair of LDS reads directly in front of the MFMAs that wait for them)
+            const int ngrp = nfull >> 1;
+            cplx xa[2], ya[2], xb[2], yb[2];
+            auto rd = [&](cplx (&x)[2], cplx (&y)[2], const int gq) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { x[u] = xp[(gq * 2 + u) * 4 * nt]; y[u] = yp[(gq * 2 + u) * 4 * nt]; }
+            };
+            auto mf = [&](const cplx (&x)[2], const cplx (&y)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    accR = mfma16(x[u].x, y[u].x, accR);
+                    accI = mfma16(x[u].y, y[u].y, accI);
+                    acc3 = mfma16(x[u].x - x[u].y, y[u].x + y[u].y, acc3);
+                }
+            };
+            if (ngrp > 0) rd(xa, ya, 0);
+            for (int gq = 0; gq < ngrp; gq += 2) {
+                if (gq + 1 < ngrp) rd(xb, yb, gq + 1);
+                mf(xa, ya);
+                if (gq + 1 < ngrp) {
+                    if (gq + 2 < ngrp) rd(xa, ya, gq + 2);
+                    mf(xb, yb);
+                }
+            }
+            for (int ks = ngrp * 2; ks < nfull; ++ks) {
                 const cplx x = xp[ks * 4 * nt], y = yp[ks * 4 * nt];
                 accR = mfma16(x.x, y.x, accR);
                 accI = mfma16(x.y, y.y, accI);
