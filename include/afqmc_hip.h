@@ -130,9 +130,14 @@ int afq_set_trial(afq_handle *h, const double *psi);
  *                          of phi, kinetic half step, weight *= exp(dt eshift) |wfac|, phase *= exp(i arg wfac),
  *                          ot = <psi_T|phi>.  The first call switches the mode (the estimators then accumulate
  *                          weight * ot * phase, mixed.py:151-175, and the re-orthogonalisation folds det R into weight and
- *                          phase); u f64[nw, M] numpy's uniforms or NULL for the device stream, fields_out may be NULL. */
+ *                          phase); u f64[nw, M] numpy's uniforms or NULL for the device stream, fields_out may be NULL.
+ *   afq_hirsch_single_site    on = 0 replaces the M single-site updates of the three calls above (and of
+ *                          afq_propagate_hirsch) by two_body_direct (:222-275, `single_site_update: False`): all M fields
+ *                          drawn from the dynamic force bias of the current Green's function, phi scaled once, one overlap;
+ *                          M uniforms per walker with a non-zero weight, no field history (back propagation: AFQ_EUNSUPPORTED). */
 int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition);
 int afq_hirsch_free_projection(afq_handle *h, int on);
+int afq_hirsch_single_site(afq_handle *h, int on);
 int afq_propagate_hirsch_free(afq_handle *h, const double *u, int32_t *fields_out, double eshift);
 int afq_propagate_hirsch(afq_handle *h, double eshift);
 int afq_hirsch_kinetic(afq_handle *h);

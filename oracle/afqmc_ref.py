@@ -519,12 +519,51 @@ def hirsch_two_body_single_site(model, w, uniform):
     return fields
 
 
+def hirsch_two_body_direct(model, w, uniform):
+    """propagation/hubbard.py:222-275 (two_body_direct, ``single_site_update: False``): every site's field drawn from the
+    dynamic force bias of the CURRENT Green's function (Phys. Rev. A 92, 033603), all sites applied at once, one overlap."""
+    na, M = model.na, model.M
+    det, Ghalf, G = greens_function(w['phi'], model.psi, na, model.nb)                 # :238 walker.greens_function(trial)
+    nia, nib = G[0].diagonal(), G[1].diagonal()
+    fb_term = nia + nib - 1 if model.charge else nia - nib                            # :242-245
+    fields = []
+    fb_fac = 1.0
+    for i in range(M):
+        pp = 0.5 * numpy.exp(model.gamma * fb_term[i]).real
+        pm = 0.5 * numpy.exp(-model.gamma * fb_term[i]).real
+        norm = pp + pm
+        r = uniform()
+        if r < pp / norm:
+            fields.append(0)
+            fb_fac *= 0.5 * norm * numpy.exp(-model.gamma * fb_term[i]).real
+        else:
+            fields.append(1)
+            fb_fac *= 0.5 * norm * numpy.exp(model.gamma * fb_term[i]).real
+    BVa = numpy.array([model.auxf[xi, 0] for xi in fields])
+    BVb = numpy.array([model.auxf[xi, 1] for xi in fields])
+    w['phi'][:, :na] = BVa[:, None] * w['phi'][:, :na]                               # :261-264
+    w['phi'][:, na:] = BVb[:, None] * w['phi'][:, na:]
+    ovlp = calc_overlap(w['phi'], model.psi, na, model.nb, getattr(model, 'log_shift', 0.0))
+    wfac = 1.0 + 0j
+    for xi in fields:
+        wfac *= model.aux_wfac[xi]
+    ratio = wfac * ovlp / w['ot']
+    if abs(cmath.phase(ratio)) < 0.5 * math.pi:
+        w['ot'] = ovlp
+        w['weight'] *= (fb_fac * ratio).real
+    else:
+        w['weight'] = 0
+    return fields
+
+
 def propagate_walker_hirsch(model, w, uniform, eshift):
     """propagation/hubbard.py:285-312 (propagate_walker_constrained)."""
     fields = None
     if abs(w['weight']) > 0:
         hirsch_kinetic_importance_sampling(model, w)
-    if abs(w['weight']) > 0:
+    if abs(w['weight']) > 0 and not getattr(model, 'single_site', True):
+        fields = hirsch_two_body_direct(model, w, uniform)
+    elif abs(w['weight']) > 0:
         fields = hirsch_two_body_single_site(model, w, uniform)
     if abs(numpy.real(w['weight'])) > 0:
         hirsch_kinetic_importance_sampling(model, w)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "afq_set_propagator_hirsch": [_h, _dp, c_double, c_int],
     "afq_propagate_hirsch": [_h, c_double],
     "afq_hirsch_free_projection": [_h, c_int],
+    "afq_hirsch_single_site": [_h, c_int],
     "afq_propagate_hirsch_free": [_h, _dp, c_void_p, c_double],
     "afq_hirsch_kinetic": [_h],
     "afq_hirsch_two_body": [_h, _dp, _dp, _dp],

@@ -101,6 +101,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->gdiag); h->gdiag_version = 0; h->gdiag_parts = 0;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
+    dev_free(h->hs_fbfac);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
     dev_free(h->phi_old); dev_free(h->phi_bp); dev_free(h->BH1dag); dev_free(h->bp_xs); dev_free(h->bp_est);
     h->nbp = 0; dev_free(h->xbar); dev_free(h->xs);
@@ -1523,10 +1524,14 @@ int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int c
     for (int x = 0; x < 2; ++x) {
         h->hs_wfac[x] = cmake(wfac[x].real(), wfac[x].imag());
         for (int sp = 0; sp < 2; ++sp) {
-            const C d = auxf[x][sp] * e - 1.0;
+            const C f = auxf[x][sp] * e, d = f - 1.0;
+            h->hs_auxf[x][sp] = cmake(f.real(), f.imag());
             h->hs_delta[x][sp] = cmake(d.real(), d.imag());
         }
     }
+    h->hs_gamma = cmake(gamma.real(), gamma.imag());
+    h->hs_charge = charge_decomposition != 0;
+    h->hs_direct = false;
     if (!h->mf_shift) {
         std::vector<double> z(2 * (size_t)h->K, 0.0);
         if ((rc = dev_upload(h, &h->mf_shift, z.data(), (size_t)h->K))) return rc;
@@ -1585,6 +1590,14 @@ int afq_propagate_hirsch(afq_handle *h, double eshift) {
     if ((rc = k_hirsch_kinetic(h))) return rc;
     if ((rc = k_hirsch_eshift(h, std::exp(h->dt * eshift)))) return rc;
     return k_alive(h);
+}
+
+int afq_hirsch_single_site(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    if (!h->hirsch) AFQ_FAIL(h, AFQ_ESTATE, "afq_set_propagator_hirsch first");
+    if (!on && h->nbp > 0) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "the direct Hirsch update records no field history (hubbard.py:222-275)");
+    h->hs_direct = !on;
+    return AFQ_OK;
 }
 
 int afq_hirsch_free_projection(afq_handle *h, int on) {

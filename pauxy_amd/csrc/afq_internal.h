@@ -131,6 +131,11 @@ struct afq_handle {
     bool hirsch = false;
     cplx hs_delta[2][2];            // auxf - 1, [field][spin]
     cplx hs_wfac[2];                // aux_wfac
+    cplx hs_auxf[2][2];             // auxf exp(-dt U / 2), [field][spin]
+    cplx hs_gamma;                  // arccosh(exp(+-dt U / 2)) (complex for the charge decomposition)
+    bool hs_charge = false;
+    bool hs_direct = false;         // single_site_update: False -- two_body_direct (hubbard.py:222-275)
+    double *hs_fbfac = nullptr;     // [nw] force-bias factor of the direct update
     cplx *hs_oinv = nullptr;        // [nw, 2, nmax, nmax] inverse overlaps O^-1 (= inv_ovlp^T of the reference)
     double *hs_u = nullptr;         // [nw, M] uniforms of the site updates
     int *hs_fields = nullptr;       // [nw, M] chosen fields (-1: not visited)

@@ -184,7 +184,123 @@ int k_hirsch_kinetic(afq_handle *h) {
     return AFQ_OK;
 }
 
+// ---- two_body_direct (propagation/hubbard.py:222-275, `single_site_update: False`): every site's field is drawn from the
+// dynamic force bias of the walker's CURRENT Green's function (n_i = G_ii per spin, from the inverse overlap the kinetic step
+// left behind), all rows of phi are scaled at once, ONE overlap and one importance-sampling test follow.
+struct HirschDirectArgs {
+    int M, na, nb, nt, nmax, charge;
+    cplx *phi;
+    const cplx *psi, *oinv;
+    const double *u;
+    const int *alive;
+    int *fields, *used;
+    double *fbfac;
+    cplx *wfac_out;
+    cplx gamma, auxf[2][2], wfac[2];
+};
+
+__device__ inline cplx cexp_(cplx z) {
+    double sn, cs;
+    sincos(z.y, &sn, &cs);
+    const double e = exp(z.x);
+    return cmake(e * cs, e * sn);
+}
+
+__global__ __launch_bounds__(256) void hirsch_direct_sites_kernel(HirschDirectArgs a) {
+    __shared__ double fac_s[256];
+    __shared__ int xi_s[256];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (!a.alive[w]) { if (tid == 0) a.used[w] = 0; return; }
+    const int M = a.M, nt = a.nt, nmax = a.nmax;
+    cplx *phi = a.phi + (long)w * M * nt;
+    const cplx *og = a.oinv + (long)w * 2 * nmax * nmax;
+    for (int i0 = 0; i0 < M; i0 += 256) {
+        const int i = i0 + tid;
+        if (i < M) {
+            cplx n[2];
+            for (int s = 0; s < 2; ++s) {
+                const int ns = s == 0 ? a.na : a.nb, off = s == 0 ? 0 : a.na;
+                const cplx *iv = og + (long)s * nmax * nmax;
+                cplx g = cmake(0.0, 0.0);
+                for (int k = 0; k < ns; ++k) {
+                    cplx q = cmake(0.0, 0.0);
+                    for (int l = 0; l < ns; ++l) cfma(q, iv[k * nmax + l], phi[(long)i * nt + off + l]);
+                    cfma(g, cconj(a.psi[(long)i * nt + off + k]), q);
+                }
+                n[s] = g;
+            }
+            const cplx fb = a.charge ? cmake(n[0].x + n[1].x - 1.0, n[0].y + n[1].y) : cmake(n[0].x - n[1].x, n[0].y - n[1].y);
+            const cplx gf = cmul(a.gamma, fb);
+            const double ep = cexp_(gf).x, em = cexp_(cmake(-gf.x, -gf.y)).x;            // exp(+-gamma fb).real, :248-249
+            const double pp = 0.5 * ep, pm = 0.5 * em, norm = pp + pm;
+            const int xi = a.u[(long)w * M + i] < pp / norm ? 0 : 1;
+            xi_s[tid] = xi;
+            fac_s[tid] = 0.5 * norm * (xi == 0 ? em : ep);                                 // :254, :257
+            a.fields[(long)w * M + i] = xi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double fb_fac = i0 == 0 ? 1.0 : a.fbfac[w];
+            cplx wf = i0 == 0 ? cmake(1.0, 0.0) : a.wfac_out[w];
+            const int cnt = M - i0 < 256 ? M - i0 : 256;
+            for (int j = 0; j < cnt; ++j) { fb_fac *= fac_s[j]; wf = cmul(wf, a.wfac[xi_s[j]]); }   // in site order
+            a.fbfac[w] = fb_fac; a.wfac_out[w] = wf;
+            a.used[w] = M;
+        }
+        // rows i0 .. i0 + 255: phi[i, :na] *= auxf[x_i, 0], phi[i, na:] *= auxf[x_i, 1]   (:259-264)
+        const int cnt = M - i0 < 256 ? M - i0 : 256;
+        for (int e = tid; e < cnt * nt; e += 256) {
+            const int j = e / nt, c = e - j * nt;
+            const cplx f = a.auxf[xi_s[j]][c < a.na ? 0 : 1];
+            cplx *x = phi + (long)(i0 + j) * nt + c;
+            *x = cmul(*x, f);
+        }
+        __syncthreads();
+    }
+}
+
+// ratio = wfac ovlp / ot; |arg| < pi / 2: ot = ovlp, weight *= (fb_fac ratio).real, else weight = 0   (:265-275)
+__global__ void hirsch_direct_weight_kernel(double *weight, cplx *ot, const cplx *ot_new, const cplx *wfac, const double *fbfac,
+                                            const int *alive, int nw, double scale) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw || !alive[w]) return;
+    const cplx ov = cscale(ot_new[w], scale);
+    const cplx ratio = cdiv(cmul(wfac[w], ov), ot[w]);
+    if (fabs(atan2(ratio.y, ratio.x)) < 0.5 * 3.14159265358979323846) {
+        ot[w] = ov;
+        weight[w] *= fbfac[w] * ratio.x;
+    } else {
+        weight[w] = 0.0;
+    }
+}
+
+static int k_hirsch_two_body_direct(afq_handle *h) {
+    const int nmax = h->na > h->nb ? h->na : h->nb;
+    if (h->nbp > 0) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "the direct Hirsch update records no field history (hubbard.py:222-275)");
+    if (!h->hs_fbfac) AFQ_HIP(h, hipMalloc(&h->hs_fbfac, sizeof(double) * h->nw));
+    {
+        const long n = (long)h->nw * h->M;
+        AFQ_LAUNCH(h, hirsch_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->hs_fields, n);
+        AFQ_POST(h);
+    }
+    HirschDirectArgs a;
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nmax = nmax; a.charge = h->hs_charge ? 1 : 0;
+    a.phi = h->phi; a.psi = h->psi; a.oinv = h->hs_oinv; a.u = h->hs_u; a.alive = h->alive;
+    a.fields = h->hs_fields; a.used = h->hs_used; a.fbfac = h->hs_fbfac; a.wfac_out = h->cmf;
+    a.gamma = h->hs_gamma;
+    for (int x = 0; x < 2; ++x) { a.wfac[x] = h->hs_wfac[x]; for (int s = 0; s < 2; ++s) a.auxf[x][s] = h->hs_auxf[x][s]; }
+    AFQ_LAUNCH(h, hirsch_direct_sites_kernel, dim3(h->nw), dim3(256), 0, h->stream, a);
+    AFQ_POST(h);
+    int rc;
+    if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;             // walker.calc_overlap(trial), :265
+    AFQ_LAUNCH(h, hirsch_direct_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
+               h->ovlp_new, h->cmf, h->hs_fbfac, h->alive, h->nw, h->log_shift_on ? exp(-h->log_shift) : 1.0);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
 int k_hirsch_two_body(afq_handle *h) {
+    if (h->hs_direct) return k_hirsch_two_body_direct(h);
     const int nmax = h->na > h->nb ? h->na : h->nb;
     {
         const long n = (long)h->nw * h->M;

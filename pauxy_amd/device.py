@@ -129,6 +129,10 @@ class AfqDevice(object):
     def propagate_hirsch(self, eshift):
         self._ck(self.lib.afq_propagate_hirsch(self.h, float(numpy.real(eshift))))
 
+    def hirsch_single_site(self, on=True):
+        """on=False: two_body_direct (propagation/hubbard.py:222-275) instead of the M single-site updates."""
+        self._ck(self.lib.afq_hirsch_single_site(self.h, 1 if on else 0))
+
     def hirsch_free_projection(self, on=True):
         self._ck(self.lib.afq_hirsch_free_projection(self.h, 1 if on else 0))
 

@@ -1,7 +1,8 @@
 """Discrete Hirsch Hubbard-Stratonovich propagator on the device.
 
 Mirrors pauxy/propagation/hubbard.py:12-343 (``Hirsch``) for RHF/UHF-type single-determinant
-trials with the classic single-site update (constrained path, and ``free_projection: True`` =
+trials with the classic single-site update or, with ``single_site_update: False``, the dynamic-force-bias
+update of all sites at once (``two_body_direct``, :222-275) (constrained path, and ``free_projection: True`` =
 ``propagate_walker_free``, :303-343): same constructor signature, the same constants
 (``bt2``, ``BT_BP``, ``gamma``, ``auxf``, ``aux_wfac``, ``delta``), ``hybrid == False`` and the
 ``propagate_walker(walker, system, trial, eshift)`` entry point the driver calls per walker.
@@ -23,8 +24,7 @@ class Hirsch(object):
     def __init__(self, system, trial, qmc, options={}, verbose=False, device_id=None):
         if getattr(trial, 'type', '') == 'GHF' or getattr(trial, 'name', '') == 'multi_determinant':
             raise NotImplementedError("device Hirsch propagator: RHF/UHF-type single-determinant trials")
-        if not options.get('single_site_update', True):
-            raise NotImplementedError("dynamic force bias update (two_body_direct) is not on the device path")
+        self.single_site = options.get('single_site_update', True)                       # hubbard.py:49-57
         if options.get('ffts', False):
             raise NotImplementedError("k-space kinetic propagation is not on the device path")
         self.free_projection = options.get('free_projection', False)
@@ -57,6 +57,8 @@ class Hirsch(object):
         if self.device_rng:
             self.dev.rng_seed(options.get('rng_seed', getattr(qmc, 'rng_seed', 0) or 0),
                               options.get('rng_stream', self.dev.device_id))
+        if not self.single_site:
+            self.dev.hirsch_single_site(False)                                            # two_body_direct, :222-275
         if self.free_projection:                                                          # hubbard.py:84-89
             self.dev.hirsch_free_projection(True)
         self.propagate_walker = self.propagate_walker_free if self.free_projection else self.propagate_walker_constrained

@@ -876,6 +876,7 @@ def make_traj_hirsch(name='traj_hubbard_hirsch.npz', charge=False, blocks=10, pi
     out['ot'] = numpy.array(traj['ot'], dtype=numpy.complex128)
     out['phase'] = numpy.array(traj['phase'], dtype=numpy.complex128)
     out['free_projection'] = bool(afqmc.propagators.free_projection)
+    out['single_site'] = bool(prop.get('single_site_update', True))
     out['parent_ix'] = numpy.array(pix, dtype=numpy.int32).reshape(len(pix), -1)
     store = h5py._STORE[afqmc.estimators.filename]
     keys = sorted(k for k in store if k.startswith('basic/energies/'))
@@ -992,6 +993,11 @@ if __name__ == '__main__':
         # propagate_walker_free (propagation/hubbard.py:303-343) through the reference driver, spin and charge decomposition
         make_traj_hirsch('traj_hirsch_fp.npz', blocks=3, prop_extra={'free_projection': True})
         make_traj_hirsch('traj_hirsch_fp_charge.npz', charge=True, blocks=2, prop_extra={'free_projection': True})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_direct':
+        # propagation/hubbard.py:222-275 (two_body_direct: dynamic force bias, all sites at once), both decompositions
+        make_traj_hirsch('traj_hirsch_direct.npz', blocks=3, prop_extra={'single_site_update': False})
+        make_traj_hirsch('traj_hirsch_direct_charge.npz', charge=True, blocks=2, prop_extra={'single_site_update': False})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hirsch_bp':
         make_traj_hirsch('traj_hirsch_bp.npz', blocks=4, bp={'tau_bp': 0.04, 'one_rdm': True})

@@ -263,7 +263,7 @@ def test_traj_use_log_shift(golden, monkeypatch):
         assert psi.walkers[3].log_shift == psi.log_shift
 
 
-def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None, bp=None, fp=False):
+def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_opts=None, bp=None, fp=False, direct=False):
     d = golden(name)
     na, nb = [int(x) for x in d['nelec']]
     s = systems.Hubbard(4, 4, na, nb, float(d['U']))
@@ -273,6 +273,8 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
         prop['charge_decomposition'] = True
     if fp:
         prop['free_projection'] = True
+    if direct:
+        prop['single_site_update'] = False
     options = {'qmc': {'timestep': float(d['dt']), 'num_steps': int(d['nsteps']), 'blocks': int(d['nblocks']),
                        'stabilise_freq': int(d['nstblz']), 'pop_control_freq': int(d['npop_control']),
                        'num_walkers': d['phi0'].shape[0]},
@@ -323,6 +325,15 @@ def run_hirsch(golden, monkeypatch, name, basename=None, batched=False, walker_o
     afqmc.finalise()
     release_context(s, t)
     return est
+
+
+def test_traj_hirsch_direct_update(golden, monkeypatch):
+    """propagation/hubbard.py:222-275 (two_body_direct, ``single_site_update: False``): the fields of all sites from the
+    dynamic force bias of the current Green's function, one overlap; trajectories of the reference itself, spin and
+    charge decomposition, per-walker and batched loops, the reference's uniforms."""
+    for name in ('traj_hirsch_direct.npz', 'traj_hirsch_direct_charge.npz'):
+        for batched in (False, True):
+            run_hirsch(golden, monkeypatch, name, batched=batched, direct=True)
 
 
 def test_traj_hirsch_free_projection(golden, monkeypatch):

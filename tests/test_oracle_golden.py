@@ -354,6 +354,7 @@ def test_use_log_shift(golden):
 def run_hirsch(d, use_log_shift=False, bp_out=None, free_projection=False):
     na, nb = [int(x) for x in d['nelec']]
     m = ref.HirschModel(d['T'], float(d['U']), d['psi'], na, nb, float(d['dt']), bool(d['charge']))
+    m.single_site = bool(d['single_site']) if 'single_site' in d else True
     close(m.bt2, d['bt2'])
     nw = d['phi0'].shape[0]
     walkers = [ref.new_walker(m, d['phi0'][i]) for i in range(nw)]
@@ -420,6 +421,15 @@ def test_traj_hubbard_hirsch_charge(golden):
     d = golden('traj_hubbard_hirsch_charge.npz')
     assert bool(d['charge'])
     run_hirsch(d)
+
+
+def test_traj_hirsch_direct_update(golden):
+    """propagation/hubbard.py:222-275 (two_body_direct, ``single_site_update: False``) against trajectories of the
+    reference itself, spin and charge decomposition (tests/golden/make_golden.py hirsch_direct)."""
+    for name in ('traj_hirsch_direct.npz', 'traj_hirsch_direct_charge.npz'):
+        d = golden(name)
+        assert not bool(d['single_site'])
+        run_hirsch(d)
 
 
 def test_traj_hirsch_free_projection(golden):
