@@ -77,7 +77,7 @@ def work(name, c):
         return 'hbm', (K * 16 + M * M * 16) * nw, 'B', 'reads xs [K], writes VHS [M, M] per walker'
     if 'energy_ueg' in name:
         return 'hbm', (2.0 * M * M * 16) * nw, 'B', 'reads G [2, M, M] per walker'
-    if 'greens_small_kernel<true>' in name:
+    if 'greens_small_kernel<true' in name:
         return 'hbm', (2.0 * M * nt * 16) * nw, 'B', 'reads phi, writes Ghalf per walker (latency bound: Gauss-Jordan)'
     if name.startswith('gj_big_kernel'):
         return 'valu', 8.0 * na ** 3 * nw * 2, 'flop', 'register-resident Gauss-Jordan inverse, 8 N^3 flops per N x N complex matrix, 2 nw matrices'
@@ -88,7 +88,7 @@ def work(name, c):
     return None
 
 
-def gemm_issued(name, c):
+def gemm_issued(name, c, merged=False):
     """Matrix-pipe flops of one launch of the ring GEMM engine from its template arguments
     mfma_gemm_wg_kernel<WM, WN, TM, TN, D, Prob, MAP, K3M, KC, STAG> and the problem shape; None when unknown."""
     m = re.match(r'void mfma_gemm_wg_kernel<(\d+), (\d+), (\d+), (\d+), \d+, (\w+)(<(\w+)>)?, \d+, (true|false)', name)
@@ -109,7 +109,7 @@ def gemm_issued(name, c):
     elif prob == 'TaylorProb':
         batch, rows, cols, kdim, mults = nw, M, nt, M, 3 if k3m else 4
     elif prob in ('OneBodyProb', 'OneBodyProbT'):
-        batch, rows, cols, kdim, mults = nw, M, na, M, (2 if targ == 'true' else 3 if k3m else 4)
+        batch, rows, cols, kdim, mults = nw, M, (nt if merged else na), M, (2 if targ == 'true' else 3 if k3m else 4)
     elif prob in ('OvlpProb', 'OvlpProbT', 'GramProb'):
         batch, rows, cols, kdim, mults = 2 * nw, nmax, nmax, M, (2 if targ == 'true' else 3 if k3m else 4)
     elif prob in ('GhalfProb', 'GhalfProbT'):
@@ -127,7 +127,7 @@ def gemm_issued(name, c):
     return 2.0 * mults * batch * tiles_m * tiles_n * tr * tc * kpad
 
 
-def issued_flops(name, c):
+def issued_flops(name, c, merged=False):
     M, na, nb, nw = c['M'], c['na'], c['nb'], c['nw']
     if 'prop_fused_kernel' in name:
         nrt, ct, nch = -(-M // 16), -(-na // 16) + -(-nb // 16), -(-M // 8)
@@ -137,7 +137,7 @@ def issued_flops(name, c):
     if 'prop_ueg_kernel' in name:
         mp = -(-M // 16) * 16
         return 3.0 * 6 * 2.0 * (mp // 16) * (mp // 8) * 2048.0 * nw
-    return gemm_issued(name, c)
+    return gemm_issued(name, c, merged)
 
 
 def trace_averages(path):
@@ -187,9 +187,13 @@ def main():
         rows = list(csv.DictReader(open(stats)))
         total = sum(float(r['TotalDurationNs']) for r in rows)
         kern = []
+        # one-body products: the library launches both spins at once when they share one real matrix (k_onebody: two launches
+        # per step instead of four) -- the template arguments do not show it, the launch count per step does
+        nsteps = next((int(r['Calls']) for r in rows if 'fields_kernel' in r['Name']), 0)
         for r in rows[:14]:
             w = work(r['Name'], c)
             avg = float(r['AverageNs'])
+            merged = 'OneBodyProb' in r['Name'] and nsteps > 0 and int(r['Calls']) / float(nsteps) < 3.0
             e = {"kernel": r['Name'][:110], "calls": int(r['Calls']), "avg_us": avg / 1e3,
                  "share_of_kernel_time": float(r['TotalDurationNs']) / total}
             if r['Name'] in trace:
@@ -198,6 +202,8 @@ def main():
                 e["averaged_over"] = "%d launches of the trace (%d shorter than 10 %% of the median dropped)" % (kept, dropped)
             if w:
                 bound, amount, unit, note = w
+                if merged:
+                    amount, note = 2.0 * amount, 'BH1 phi, both spins in one launch'
                 e["bound"] = bound
                 e["work_per_launch"] = amount
                 e["work_unit"] = unit
@@ -207,7 +213,7 @@ def main():
                     e["peak"] = PEAK_TF
                     e["unit"] = "TFLOP/s"
                     e["frac_algorithmic"] = e["achieved"] / PEAK_TF
-                    iss = issued_flops(r['Name'], c) if bound == 'mfma' else None
+                    iss = issued_flops(r['Name'], c, merged) if bound == 'mfma' else None
                     if iss:
                         e["issued_flops_per_launch"] = iss
                         e["frac_issued"] = iss / (avg * 1e-9) / 1e12 / PEAK_TF
