@@ -37,16 +37,16 @@ def options(nw_total, walkers=None):
     return o
 
 
-def tables():
+def tables(nr=2):
     rng = numpy.random.RandomState(77)
-    return rng.normal(size=(NSTEPS * NBLOCKS, 2 * NW, 10)), rng.rand(NSTEPS * NBLOCKS)
+    return rng.normal(size=(NSTEPS * NBLOCKS, nr * NW, 10)), rng.rand(NSTEPS * NBLOCKS)
 
 
 class Feed(object):
     """numpy.random.{normal, random} stand-ins handing out the table rows of this rank's walkers in order."""
 
-    def __init__(self, first, count):
-        xi, r = tables()
+    def __init__(self, first, count, nr=2):
+        xi, r = tables(nr)
         self.rows = iter(xi[:, first:first + count].reshape(-1, 10))
         self.r = iter(r[4::5])                 # one comb uniform per population control (every 5th step)
 
@@ -57,14 +57,14 @@ class Feed(object):
         return next(self.r)
 
 
-def drive(comm, nw_total, first, count, walkers=None):
+def drive(comm, nw_total, first, count, walkers=None, nr=2):
     from pauxy_amd.qmc.afqmc import AFQMC
     s, t = build()
-    feed = Feed(first, count)
+    feed = Feed(first, count, nr)
     numpy.random.normal, numpy.random.random = feed.normal, feed.random
     afqmc = AFQMC(comm=comm, options=options(nw_total, walkers), system=s, trial=t)
     # weights spread over a decade so that the comb clones and kills, also across the two ranks
-    w0 = numpy.exp(0.9 * numpy.random.RandomState(5).normal(size=2 * NW))[first:first + count]
+    w0 = numpy.exp(0.9 * numpy.random.RandomState(5).normal(size=nr * NW))[first:first + count]
     for i, w in enumerate(afqmc.psi.walkers):
         w.weight = w0[i]
     rec = dict(weight=[], ot=[], pix=[])
@@ -90,16 +90,16 @@ def drive(comm, nw_total, first, count, walkers=None):
                 comm_stats=afqmc.psi.dev.comm_stats() if getattr(afqmc.psi, 'device_comm', False) else None)
 
 
-def _worker(rank, port, walkers, q):
+def _worker(rank, port, walkers, q, nr=2):
     try:
-        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(nr),
                           LOCAL_RANK='0')
         import torch
         import torch.distributed as dist
         from pauxy_amd.comm import TorchComm
-        dist.init_process_group('gloo', rank=rank, world_size=2)
+        dist.init_process_group('gloo', rank=rank, world_size=nr)
         comm = TorchComm(device=torch.device('cpu'))
-        out = drive(comm, 2 * NW, rank * NW, NW, walkers)
+        out = drive(comm, nr * NW, rank * NW, NW, walkers, nr)
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
@@ -116,11 +116,11 @@ def free_port():
     return p
 
 
-def two_ranks(walkers=None):
+def many_ranks(nr, walkers=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, walkers, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, walkers, q, nr)) for r in range(nr)]
     for p in procs:
         p.start()
     try:
@@ -132,16 +132,20 @@ def two_ranks(walkers=None):
                 p.kill()
     for rank, out in res:
         assert isinstance(out, dict), (rank, out)
-    return res[0][1], res[1][1]
+    return [r[1] for r in res]
 
 
-def single_rank():
-    import numpy.random as nr
-    keep = nr.normal, nr.random
+def two_ranks(walkers=None):
+    return tuple(many_ranks(2, walkers))
+
+
+def single_rank(nr=2):
+    import numpy.random as npr
+    keep = npr.normal, npr.random
     try:
-        return drive(None, 2 * NW, 0, 2 * NW)
+        return drive(None, nr * NW, 0, nr * NW, None, nr)
     finally:
-        nr.normal, nr.random = keep
+        npr.normal, npr.random = keep
 
 
 def compare(one, a, b):
@@ -208,6 +212,37 @@ def test_device_comb_over_ipc_windows_two_processes():
     one = single_rank()
     a, b = two_ranks({'device_comm': 'ipc'})
     check_ipc(one, a, b)
+
+
+def test_device_comb_over_ipc_windows_four_processes():
+    """More than one peer per rank: four processes on the one GPU, every rank maps three windows, the comb's walkers go to
+    whichever rank the global plan names (one flag and one ticket counter per peer), the weights all-gather and the block
+    reduction run over four windows.  Must equal the single-rank run with four times the walkers."""
+    nr = 4
+    one = single_rank(nr)
+    outs = many_ranks(nr, {'device_comm': 'ipc'})
+    from pauxy_amd.walkers.handler import comb_pairs
+    assert all(o['device_comm'] and o['device_comm_kind'] == 'ipc' for o in outs)
+    assert (one['pix'] > 1).any() and (one['pix'] == 0).any()
+    for o in outs:
+        assert numpy.array_equal(o['pix'], one['pix'])
+    for key in ('weight', 'ot'):
+        got = numpy.concatenate([o[key] for o in outs], axis=1)
+        assert got.shape == one[key].shape
+        assert numpy.max(numpy.abs(got - one[key])) <= 1e-9 * max(1.0, numpy.max(numpy.abs(one[key]))), key
+    got_phi = numpy.concatenate([o['phi'] for o in outs])
+    assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
+    assert numpy.max(numpy.abs(outs[0]['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
+    if one['rdm'] is not None:
+        assert numpy.max(numpy.abs(outs[0]['rdm'] - one['rdm'])) <= 1e-9 * numpy.max(numpy.abs(one['rdm']))
+    total = 0
+    for rank, o in enumerate(outs):
+        st = o['comm_stats']
+        assert st['kind'] == 'ipc' and st['window'] == 1 and st['error'] == 0 and st['overflow'] == 0 and st['size'] == nr
+        sent = sum(1 for pix in one['pix'] for c, k in comb_pairs(pix) if c // NW == rank and k // NW != rank)
+        assert st['walkers_sent'] == sent
+        total += sent
+    assert total > 0
 
 
 def test_device_communicator_falls_through_to_ipc_windows():
