@@ -123,7 +123,7 @@ __device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int
 
 // the inversion proper for one register count; `mystep`, (sx, sy) = step and reciprocal pivot of this lane's row
 template <int RJ>
-__device__ inline void gj_wave_rj(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow) {
+__device__ __attribute__((always_inline)) inline void gj_wave_rj(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow) {
     const int h = lane >> 5, r = lane & 31;
     double vr[RJ], vi[RJ];
 #pragma unroll
@@ -150,7 +150,7 @@ __device__ inline void gj_wave_rj(cplx *O, int n, int lane, bool write_inverse, 
 }
 
 // O: n x n row-major in LDS (overwritten with the inverse when write_inverse); returns det via ph / la
-__device__ inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
+__device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
                                  cplx &ph, int &la) {
     if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
     n = __builtin_amdgcn_readfirstlane(n);

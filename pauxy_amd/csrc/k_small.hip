@@ -276,7 +276,7 @@ __device__ static void weight_update(const WeightArgs &a, const int w) {
     }
 }
 
-__device__ static void weight_update_and_cap(const WeightArgs &a, const int w) {
+__device__ __attribute__((always_inline)) static void weight_update_and_cap(const WeightArgs &a, const int w) {
     weight_update(a, w);
     if (a.cap_frac > 0.0) {
         // every walker, propagated or not, exactly like the driver's loop
