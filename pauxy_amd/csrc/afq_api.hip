@@ -984,9 +984,10 @@ int afq_reortho(afq_handle *h, double *detR_out) {
     // the end of the last step stays valid across the QR; only the cached overlap picks up 1 / det R.
     const bool keep = h->greens_valid && h->ndet == 1;
     h->greens_valid = false;
-    { PhaseTimer t(h, T_QR); if ((rc = k_reortho(h))) return rc; }
+    bool scaled = false;
+    { PhaseTimer t(h, T_QR); if ((rc = k_reortho(h, keep ? h->ovlp_new : nullptr, &scaled))) return rc; }
     if (keep) {
-        if ((rc = k_scale_by_inverse(h, h->ovlp_new, h->detR))) return rc;
+        if (!scaled && (rc = k_scale_by_inverse(h, h->ovlp_new, h->detR))) return rc;
         h->greens_valid = true;
     }
     // the cached overlap above needs det R itself; walker.detR / walker.ot / log_detR take the shifted one

@@ -399,7 +399,7 @@ int k_xbar_fields(afq_handle *h);                           // xbar + clip + shi
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch
 int k_update_weight(afq_handle *h, cplx eshift);
-int k_reortho(afq_handle *h);
+int k_reortho(afq_handle *h, cplx *keep = nullptr, bool *keep_done = nullptr);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);
 int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
 int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights = false);

@@ -1221,6 +1221,7 @@ struct QrArgs {
     double *detR, *weight;
     cplx *ot;
     const int *only;    // when set: redo only the walkers flagged by the Cholesky-QR path
+    cplx *keep;         // cached overlap of a Green's function that stays valid across the QR (ovlp /= det R), or null
 };
 
 __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
@@ -1286,6 +1287,7 @@ __global__ __launch_bounds__(NTHR) void reortho_kernel(QrArgs a) {
         const double d = exp(logdet);
         a.detR[w] = d;
         a.ot[w] = cmake(a.ot[w].x / d, a.ot[w].y / d);           // single_det.py:253
+        if (a.keep) a.keep[w] = cmake(a.keep[w].x / d, a.keep[w].y / d);
         if (a.flags & AFQ_PROP_FREE_PROJECTION) a.weight[w] *= d;  // walkers/handler.py:178-181
     }
 }
@@ -1307,6 +1309,7 @@ struct RfArgs {
     double *detR, *weight;
     cplx *ot;
     int *fail;
+    cplx *keep;          // cached overlap of a Green's function that stays valid across the QR (ovlp /= det R), or null
 };
 
 #ifdef AFQ_TUNING
@@ -1510,6 +1513,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
         a.fail[w] = 0;
         a.detR[w] = d;
         a.ot[w] = cmake(a.ot[w].x / d, a.ot[w].y / d);       // single_det.py:253
+        if (a.keep) a.keep[w] = cmake(a.keep[w].x / d, a.keep[w].y / d);
         if (a.fp) a.weight[w] *= d;                          // walkers/handler.py:178-181
     }
     RF_STAMP(8);
@@ -1523,12 +1527,12 @@ static bool reortho_fused_supported(afq_handle *h, size_t *lds_out) {
     return !off && nmax <= 32 && h->nb > 0 && h->M >= 16 && lds <= 150 * 1024;
 }
 
-static int k_reortho_fused(afq_handle *h, size_t lds) {
+static int k_reortho_fused(afq_handle *h, size_t lds, cplx *keep) {
     if (!h->qr_fail) AFQ_HIP(h, hipMalloc(&h->qr_fail, sizeof(int) * h->nw));
     RfArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
-    a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot; a.fail = h->qr_fail;
+    a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot; a.fail = h->qr_fail; a.keep = keep;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)reortho_fused_kernel, lds, lds_set));
 #ifdef AFQ_TUNING
@@ -1551,11 +1555,14 @@ static int k_reortho_fused(afq_handle *h, size_t lds) {
     return AFQ_OK;
 }
 
-int k_reortho(afq_handle *h) {
+// keep: the cached overlap to divide by det R along the way (null: none).  *keep_done tells the caller whether the kernels
+// did that (fused Cholesky-QR path and its Gram-Schmidt fallback) or a separate pass is still due.
+int k_reortho(afq_handle *h, cplx *keep, bool *keep_done) {
     QrArgs a;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw; a.flags = h->flags;
     a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot;
-    a.only = nullptr;
+    a.only = nullptr; a.keep = nullptr;
+    if (keep_done) *keep_done = false;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     static const bool no_cholqr = afq_knob("AFQ_NO_CHOLQR") != nullptr;
     // Cholesky-QR2 on the GEMM engines: always for 45 < N <= 128; for smaller N once the population is
@@ -1563,9 +1570,10 @@ int k_reortho(afq_handle *h) {
     const bool small_ok = nmax <= 45 && h->nb > 0 && !h->no_ring && h->nw >= 64 && h->M >= 32;
     size_t lds_fused = 0;
     if (small_ok && !no_cholqr && reortho_fused_supported(h, &lds_fused)) {
-        int rc = k_reortho_fused(h, lds_fused);
+        int rc = k_reortho_fused(h, lds_fused, keep);
         if (rc) return rc;
-        a.only = h->qr_fail;
+        a.only = h->qr_fail; a.keep = keep;
+        if (keep_done) *keep_done = keep != nullptr;
     } else if ((k_greens_big_supported(h) || small_ok) && !no_cholqr) {
         int rc = k_reortho_big(h);
         if (rc) return rc;
