@@ -98,7 +98,8 @@ struct GreensArgs {
     int o_in_lds;
     int only_alive;
     const int *alive;
-    int dbg;            // timing experiments only (AFQ_GREENS_DBG): 1 skip pivot loop, 2 skip phase 3, 4 skip phase 1
+    int dbg;            // timing experiments only (AFQ_GREENS_DBG, tuning builds; 0 in the product): 1 skip pivot loop,
+                        // 2 skip phase 3, 4 skip phase 1, 8 LDS Gauss-Jordan instead of the register one, 16 no per-spin Ghalf store
     int psi_real;       // every imaginary part of the (single, shared) trial is exactly zero (checked at upload)
 };
 
