@@ -401,3 +401,27 @@ def test_greens_every_electron_count(na, nb):
         close(G[w], G_ref, 1e-9)
         close(gh[w].reshape(na + nb, M), numpy.concatenate([g for g in ghalf_ref if g is not None and len(g)]), 1e-9)
     dev.close()
+
+
+@pytest.mark.parametrize("M", [17, 63, 64, 65, 97, 113, 128])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_greens_basis_sizes_real_and_complex_trial(M, cplx):
+    """Overlap phase of the small Green's function kernel: k-steps in groups of four with the trial fragments requested in
+    two halves of sixteen (M <= 64: one half), ragged M (the last group runs past M), two products per k-step for a real
+    trial and three for a complex one; 9 + 8 electrons (two row / column tiles would need n > 16: one tile per spin here)
+    and 20 + 19 (four tiles per spin)."""
+    for na, nb in ((9, 8), (20, 19)):
+        if na >= M:
+            continue
+        model, rng = build(M, 6, na, nb, cplx, seed=M)
+        nw = 5
+        dev = make_device(model, nw)
+        phi = rng.rand(nw, M, na + nb) - 0.5 + 1j * (rng.rand(nw, M, na + nb) - 0.5)
+        dev.set(L.F_PHI, phi)
+        ot = dev.greens(want_G=False)
+        gh = dev.get(L.F_GHALF)
+        for w in range(nw):
+            det, ghalf_ref, _ = ref.greens_function(phi[w], model.psi, na, nb)
+            assert abs(ot[w] - det) <= 1e-10 * abs(det)
+            close(gh[w].reshape(na + nb, M), numpy.concatenate(ghalf_ref), 1e-9)
+        dev.close()
