@@ -311,7 +311,7 @@ static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
 
 int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const double *hs_pot,
                            const double *rchol, const double *H1, double ecore) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !hs_pot || !rchol || !H1) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_GENERIC, M, K, na, nb);
     if (rc) return rc;
@@ -357,7 +357,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
 }
 
 int afq_set_system_hubbard(afq_handle *h, int M, int na, int nb, double U, const double *T) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !T) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_HUBBARD, M, M, na, nb);
     if (rc) return rc;
@@ -393,7 +393,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
                        const int64_t *kpq_i, const int64_t *kpq_kpq, const int64_t *pmq_off,
                        const int64_t *pmq_i, const int64_t *pmq_pmq, const double *vqvec, double vol,
                        const double *H1diag, double ecore) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !iA_colptr || !iB_colptr || !kpq_off || !pmq_off || !vqvec || !H1diag) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_UEG, M, 2 * nq, na, nb);
     if (rc) return rc;
@@ -465,7 +465,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
 }
 
 int afq_set_trial(afq_handle *h, const double *psi) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !psi) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the trial");
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_ESTATE, "a multi-determinant trial is set; set the system again first");
@@ -478,7 +478,7 @@ int afq_set_trial(afq_handle *h, const double *psi) {
 }
 
 int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double *coeffs, const double *rchol) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !psi || !coeffs || !rchol || ndet < 1) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_GENERIC) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "multi-determinant trials need a generic system");
     if (h->nw) AFQ_FAIL(h, AFQ_ESTATE, "set the trial before allocating walkers");
@@ -515,7 +515,7 @@ int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double
 
 int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift, double dt, int exp_order,
                        int flags) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !BH1 || !mf_shift || dt <= 0 || exp_order < 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the propagator");
     hipSetDevice(h->device);
@@ -543,7 +543,7 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
 
 // ------------------------------------------------------------------ walkers
 int afq_walkers_alloc(afq_handle *h, int nw) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || nw <= 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before allocating walkers");
     hipSetDevice(h->device);
@@ -639,8 +639,10 @@ static int field_info(afq_handle *h, int field, void **base, size_t *bytes) {
     return AFQ_OK;
 }
 
+static int ensure_spin_ghalf(afq_handle *h);
+
 int afq_walkers_set(afq_handle *h, int field, const void *host, int first, int count) {
-    if (h && (field == AFQ_F_PHI || field == AFQ_F_GHALF)) { h->greens_valid = false; ++h->ghalf_version; }
+    if (h && (field == AFQ_F_PHI || field == AFQ_F_GHALF)) { h->greens_valid = false; h->gsum_only = false; ++h->ghalf_version; }
     if (!h || !host) return AFQ_EINVAL;
     if (!h->nw) AFQ_FAIL(h, AFQ_ESTATE, "no walkers allocated");
     if (first < 0 || count < 0 || first + count > h->nw) AFQ_FAIL(h, AFQ_EINVAL, "walker range out of bounds");
@@ -661,13 +663,14 @@ int afq_walkers_get(afq_handle *h, int field, void *host, int first, int count) 
     void *base; size_t bytes;
     int rc = field_info(h, field, &base, &bytes);
     if (rc) return rc;
+    if (field == AFQ_F_GHALF && (rc = ensure_spin_ghalf(h))) return rc;
     AFQ_HIP(h, hipMemcpyAsync(host, (char *)base + bytes * first, bytes * count, hipMemcpyDeviceToHost, h->stream));
     AFQ_HIP(h, hipStreamSynchronize(h->stream));
     return AFQ_OK;
 }
 
 int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *bytes_per_walker) {
-    if (h) { h->greens_valid = false; h->greens_cache = false; }   // the caller may write through the pointer
+    if (h) { h->greens_valid = false; h->gsum_only = false; h->greens_cache = false; }   // the caller may write through the pointer
     if (!h || !dev_ptr) return AFQ_EINVAL;
     void *base; size_t bytes;
     int rc = field_info(h, field, &base, &bytes);
@@ -688,6 +691,16 @@ static int need_ready(afq_handle *h, bool prop) {
     return AFQ_OK;
 }
 
+// The last step left its Green's function behind as overlap + spin sum of Ghalf only (afq_propagate_finish on a step the
+// driver announced with afq_estimates_fuse_next): somebody wants the per-spin Ghalf after all -- evaluate it.
+static int ensure_spin_ghalf(afq_handle *h) {
+    if (!h->gsum_only) return AFQ_OK;
+    h->gsum_only = false;
+    const int rc = greens_any(h, h->ovlp_new, true);
+    h->greens_valid = rc == AFQ_OK;
+    return rc;
+}
+
 static int ensure_G(afq_handle *h) {
     if (!h->G) {
         int rc = dev_alloc(h, &h->G, (size_t)2 * h->M * h->M * h->nw);
@@ -705,7 +718,7 @@ static int copy_out(afq_handle *h, void *host, const void *dev, size_t bytes) {
 
 int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
     AFQ_API(h, "afq_greens");
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -721,7 +734,7 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
 }
 
 int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !oinv_out) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -744,7 +757,7 @@ int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
 
 int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
     AFQ_API(h, "afq_calc_overlap");
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -826,9 +839,12 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     const bool fp = (h->flags & AFQ_PROP_FREE_PROJECTION) != 0;
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
         PhaseTimer t(h, T_GREENS);                         // continuous.py:245
-        if (h->greens_valid) std::swap(h->ovlp_old, h->ovlp_new);   // computed at the end of the last step
+        // (the spin sum alone will not do when this step needs more than the force bias: local-energy weights, one_rdm)
+        const bool sum_ok = h->gsum_only && (h->flags & AFQ_PROP_HYBRID) && !h->rdm_on && h->kind == AFQ_SYS_GENERIC;
+        if (h->greens_valid || sum_ok) std::swap(h->ovlp_old, h->ovlp_new);   // computed at the end of the last step
+                                                                   // (gsum_only: as overlap + spin sum of Ghalf, all the force bias reads)
         else if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
-        h->greens_valid = false;
+        h->greens_valid = false; h->gsum_only = false;
         const bool le = !fp && !(h->flags & AFQ_PROP_HYBRID);
         // (the plane-wave fast step gathers the force bias from the occupied rows of G built from Ghalf: no full G)
         if ((h->kind == AFQ_SYS_UEG && ((h->flags & AFQ_PROP_FORCE_BIAS) || le) && !k_ueg_fast_supported(h)) ||
@@ -918,10 +934,20 @@ int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im) {
         h->fuse_weight_req = h->ndet == 1 && !le_msd;       // single determinant: k_greens may take the weight update along
         h->fuse_eshift = cmake(eshift_re, eshift_im);
         if (h->greens_cache && !fp) {
+            // afq_estimates_fuse_next told us that nothing but the next step's force bias will read this Green's function
+            // (no comb, no energy, no block end behind this step): when that force bias contracts the spin sum
+            // Ghalf_a + Ghalf_b (k_fb_use_sum), the per-spin Ghalf -- 2/3 of the kernel's stores, 20 MB per step at C3 --
+            // is not written at all.  Everything else sees "no cached Green's function" and recomputes if it asks.
+            h->ghalf_skip_store = h->fuse_est_req && h->ndet == 1 && h->kind == AFQ_SYS_GENERIC && k_fb_use_sum(h) &&
+                                  (h->flags & AFQ_PROP_HYBRID) && (h->flags & AFQ_PROP_FORCE_BIAS) && !h->rdm_on &&
+                                  h->nbp == 0 && h->psi_stride == 0 && !afq_knob("AFQ_NO_GHALF_SKIP");
+            h->ghalf_skipped = false;
             rc = greens_any(h, h->ovlp_new, true);
             h->fuse_weight_req = false;
+            h->ghalf_skip_store = false;
             if (rc) return rc;
-            h->greens_valid = true;
+            h->greens_valid = !h->ghalf_skipped;
+            h->gsum_only = h->ghalf_skipped;
         } else {
             rc = greens_any(h, h->ovlp_new, false);
             h->fuse_weight_req = false;
@@ -979,16 +1005,17 @@ int afq_reortho(afq_handle *h, double *detR_out) {
     AFQ_API(h, "afq_reortho");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
-    if (rc) { h->greens_valid = false; return rc; }
+    if (rc) { h->greens_valid = false; h->gsum_only = false; return rc; }
     // Ghalf = (phi^T psi*)^-1 phi^T does not change when phi -> phi R^-1, so a Green's function kept from
     // the end of the last step stays valid across the QR; only the cached overlap picks up 1 / det R.
-    const bool keep = h->greens_valid && h->ndet == 1;
-    h->greens_valid = false;
+    const bool keep = (h->greens_valid || h->gsum_only) && h->ndet == 1;
+    const bool sum_only = h->gsum_only;                  // (the spin sum of Ghalf is as invariant as Ghalf itself)
+    h->greens_valid = false; h->gsum_only = false;
     bool scaled = false;
     { PhaseTimer t(h, T_QR); if ((rc = k_reortho(h, keep ? h->ovlp_new : nullptr, &scaled))) return rc; }
     if (keep) {
         if (!scaled && (rc = k_scale_by_inverse(h, h->ovlp_new, h->detR))) return rc;
-        h->greens_valid = true;
+        h->greens_valid = !sum_only; h->gsum_only = sum_only;
     }
     // the cached overlap above needs det R itself; walker.detR / walker.ot / log_detR take the shifted one
     if (h->log_shift_on && (rc = k_log_shift_reortho(h))) return rc;
@@ -1028,6 +1055,7 @@ int afq_local_energy(afq_handle *h, double *E_out) {
     int rc = need_ready(h, false);
     if (rc) return rc;
     if (!h->rH1 && h->kind != AFQ_SYS_UEG) AFQ_FAIL(h, AFQ_ESTATE, "half-rotated H1 missing (set trial)");
+    if ((rc = ensure_spin_ghalf(h))) return rc;
     { PhaseTimer t(h, T_ENERGY); if ((rc = local_energy(h))) return rc; }
     return copy_out(h, E_out, h->energy, sizeof(cplx) * 3 * h->nw);
 }
@@ -1096,7 +1124,7 @@ int afq_vhs(afq_handle *h, const double *xs, double *vhs_out) {
 }
 
 int afq_apply_exponential(afq_handle *h, const double *vhs) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !vhs) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -1118,7 +1146,7 @@ int afq_apply_exponential(afq_handle *h, const double *vhs) {
 }
 
 int afq_kinetic(afq_handle *h) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -1148,14 +1176,14 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *
     AFQ_API(h, "afq_popcontrol_comb");
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
-    if (rc) { h->greens_valid = false; return rc; }
+    if (rc) { h->greens_valid = false; h->gsum_only = false; return rc; }
     const int nranks = k_comm_size(h);
     if (h->nw * nranks == 1) return AFQ_OK;              // handler.py:226-227
     // a kept Green's function travels with the cloned walkers (the clone / pack kernels copy Ghalf and the cached overlap)
     const bool keep = h->greens_valid && h->ndet == 1;
-    h->greens_valid = false;
+    h->greens_valid = false; h->gsum_only = false;
     if ((rc = k_comb(h, r, target_weight, keep))) return rc;
-    h->greens_valid = keep;
+    h->greens_valid = keep; h->gsum_only = false;
     if (!parent_ix && !total_weight_out) return AFQ_OK;  // asynchronous: nothing read back, no host sync
     double sc[8];
     if ((rc = copy_out(h, sc, h->scal, sizeof(sc)))) return rc;
@@ -1237,7 +1265,7 @@ int afq_walker_pack(afq_handle *h, int iw, void *dev_buf) {
 }
 
 int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !dev_buf) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1246,7 +1274,7 @@ int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
 }
 
 int afq_walkers_copy(afq_handle *h, int src, int dst) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1496,7 +1524,7 @@ static int hirsch_ready(afq_handle *h) {
 }
 
 int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !bt2 || dt <= 0) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_HUBBARD) AFQ_FAIL(h, AFQ_ESTATE, "the Hirsch transformation needs a Hubbard system");
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: single-determinant trials");
@@ -1544,7 +1572,7 @@ int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int c
 }
 
 int afq_hirsch_kinetic(afq_handle *h) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1553,7 +1581,7 @@ int afq_hirsch_kinetic(afq_handle *h) {
 }
 
 int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int32_t *used_out) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !u) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1566,7 +1594,7 @@ int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int
 }
 
 int afq_hirsch_finish(afq_handle *h, double eshift) {
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1578,7 +1606,7 @@ int afq_hirsch_finish(afq_handle *h, double eshift) {
 
 int afq_propagate_hirsch(afq_handle *h, double eshift) {
     AFQ_API(h, "afq_propagate_hirsch");
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1612,7 +1640,7 @@ int afq_hirsch_free_projection(afq_handle *h, int on) {
 
 int afq_propagate_hirsch_free(afq_handle *h, const double *u, int32_t *fields_out, double eshift) {
     AFQ_API(h, "afq_propagate_hirsch_free");
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1669,7 +1697,7 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
                   int reset, double *est_out) {
     AFQ_API(h, "afq_bp_update");
-    if (h) h->greens_valid = false;
+    if (h) h->greens_valid = false; h->gsum_only = false;
     if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;

@@ -238,6 +238,8 @@ struct afq_handle {
     // (per walker: no cross-walker sum, no atomics); the next estimates_kernel launch, or the next fetch, folds them in
     double *est_acc = nullptr;
     bool fuse_est_req = false, est_acc_pending = false;
+    // the Green's function cached at the end of a step as overlap + spin sum of Ghalf only (afq_propagate_finish)
+    bool gsum_only = false, ghalf_skip_store = false, ghalf_skipped = false;
     cplx fuse_eshift;
 
     // rng

@@ -983,7 +983,7 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
         hipSetDevice(h->device);
         h->scal_cache_valid = false;
         keep[i] = h->greens_valid && h->ndet == 1;
-        h->greens_valid = false;
+        h->greens_valid = false; h->gsum_only = false;
     }
     // a cached Green's function travels only if every rank has one (the slots of a pair must agree)
     bool with_greens = true;
@@ -1009,7 +1009,7 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
         hipSetDevice(h->device);
         for (int j = 0; j < n; ++j) if (j != i) AFQ_HIP(h, hipStreamWaitEvent(h->stream, cs_of(hs[j])->ev2, 0));
         if ((rc = stage_unpack(h, with_greens))) return rc;
-        h->greens_valid = with_greens;
+        h->greens_valid = with_greens; h->gsum_only = false;
         // a rank's next prep overwrites rows of the OTHER ranks' gw of the other parity only; its next pack writes into
         // their windows only after their next prep (all-gather), which follows their unpack in stream order
     }

@@ -99,8 +99,9 @@ struct GreensArgs {
     int only_alive;
     const int *alive;
     int dbg;            // timing experiments only (AFQ_GREENS_DBG, tuning builds; 0 in the product): 1 skip pivot loop,
-                        // 2 skip phase 3, 4 skip phase 1, 8 LDS Gauss-Jordan instead of the register one, 16 no per-spin Ghalf store
+                        // 2 skip phase 3, 4 skip phase 1, 8 LDS Gauss-Jordan instead of the register one
     int psi_real;       // every imaginary part of the (single, shared) trial is exactly zero (checked at upload)
+    int skip_spin;      // with gsum: do not store the per-spin Ghalf (nobody will read it: afq_propagate_finish)
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -669,8 +670,8 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                     const int i = ti * 16 + lk + 4 * r;
                     const double ra = p1a[r] - p2a[r], ima = p3a[r] - p1a[r] - p2a[r];
                     const double rb = p1b[r] - p2b[r], imb = p3b[r] - p1b[r] - p2b[r];
-                    if (i < ns && c0 < M && !(a.dbg & 16)) gh[(long)i * M + c0] = cmake(ra, ima);
-                    if (two && i < ns && c1 < M && !(a.dbg & 16)) gh[(long)i * M + c1] = cmake(rb, imb);
+                    if (i < ns && c0 < M && !a.skip_spin) gh[(long)i * M + c0] = cmake(ra, ima);
+                    if (two && i < ns && c1 < M && !a.skip_spin) gh[(long)i * M + c1] = cmake(rb, imb);
                     sra[r] += ra; sia[r] += ima; srb[r] += rb; sib[r] += imb;
                 }
             }
@@ -695,6 +696,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
+    a.skip_spin = 0;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
     if (k_greens_big_supported(h)) {
@@ -746,6 +748,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
             if (want_sum) {
                 if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)h->na * h->M * h->nw));
                 a.gsum = h->ghalf_sum;
+                if (h->ghalf_skip_store && wgj_on && !oinv) { a.skip_spin = 1; h->ghalf_skipped = true; }
             }
             KernelTrace kt(h, AFQ_K_GREENS);
             if (wgj_on) {

@@ -60,3 +60,41 @@ def test_estimator_terms_riding_on_the_weight_update_equal_the_separate_launch()
         assert abs(a['eshift'] - b['eshift']) < 1e-10 * max(1.0, abs(a['eshift']))
         assert numpy.max(numpy.abs(a['weight'] - b['weight'])) < 1e-9
         assert numpy.max(numpy.abs(a['phi'] - b['phi'])) < 1e-9
+
+
+def test_per_spin_ghalf_not_stored_on_announced_steps_is_recomputed_on_demand():
+    """afq_estimates_fuse_next announces a step behind which nothing but the next force bias reads the Green's function:
+    the kernel then leaves the per-spin Ghalf unwritten (RHF-type trial: the force bias contracts the spin sum).  Asking
+    for the energy or for Ghalf afterwards must give what a handle without the announcement gives, and the walkers of
+    both handles must stay bit-identical over further steps."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import _lib as L
+    from pauxy_amd.propagation.setup import generic_propagator_arrays
+    from tests.helpers import make_device
+    M, K, N, nw = 24, 30, 5, 64
+    s = systems.synthetic_generic(M, K, (N, N), seed=11)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = generic_propagator_arrays(s, t, 0.01)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, 0.01, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=s.ecore)
+    rng = numpy.random.RandomState(3)
+    phi = numpy.array([t.psi + 0.05 * (rng.rand(M, 2 * N) + 1j * rng.rand(M, 2 * N)) for _ in range(nw)])
+    devs = [make_device(model, nw) for _ in range(2)]
+    for d in devs:
+        d.set(L.F_PHI, phi)
+        d.set(L.F_OT, d.calc_overlap())
+    for step in range(4):
+        xi = rng.normal(size=(nw, K))
+        devs[0].estimates_fuse_next()                       # announced: per-spin Ghalf not stored
+        devs[0].propagate(xi, 0.1)
+        devs[1].propagate(xi, 0.1)
+        devs[1].estimates_update(False)
+        if step == 1:
+            assert numpy.array_equal(devs[0].local_energy(), devs[1].local_energy())
+        if step == 2:
+            assert numpy.array_equal(devs[0].get(L.F_GHALF), devs[1].get(L.F_GHALF))
+        for f in (L.F_PHI, L.F_WEIGHT, L.F_OT, L.F_HYBRID_ENERGY):
+            assert numpy.array_equal(devs[0].get(f), devs[1].get(f)), (step, f)
+    assert numpy.allclose(devs[0].estimates_get(), devs[1].estimates_get(), rtol=1e-12, atol=0)
+    for d in devs:
+        d.close()
