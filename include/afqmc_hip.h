@@ -376,6 +376,10 @@ int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
  * afq_estimates_update(h, 0) called right behind it would have added them: the weight update adds every walker's terms
  * to per-walker accumulators, and the next afq_estimates_update, or the next fetch / all-reduce, folds those into the
  * sums.  For a step that neither combs nor evaluates the energy this saves the launch of the summation kernel.
+ * The call also tells the library that nothing but the next step's force bias will read the Green's function this step
+ * leaves behind: where that force bias contracts Ghalf_a + Ghalf_b (generic system, both spins sharing the half-rotated
+ * Cholesky block, hybrid weights) the per-spin Ghalf is not stored; afq_local_energy / afq_walkers_get(AFQ_F_GHALF)
+ * called afterwards evaluate it first (same numbers, one more kernel).
  * Continuous propagator, not with afq_estimates_rdm on.                                                            */
 int afq_estimates_fuse_next(afq_handle *h);
 int afq_estimates_get_begin(afq_handle *h, int zero);
