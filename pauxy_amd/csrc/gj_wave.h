@@ -194,26 +194,30 @@ __device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, 
 // data layout and block structure as gj_block8, but the pivot of step k is row k (no search) and only
 // the rows below it are eliminated: forward elimination of [S | I] in place, so that at the end
 // v[i][j] (j < i) = Ltilde^-1[i][j] with S = Ltilde D Ltilde^H and piv[k] = D_k.
-__device__ inline void chol_block8(double (&vr)[16], double (&vi)[16], int it, int n, int lane, cplx *rowk,
-                                   double *piv, bool &bad) {
+template <int RJ>
+__device__ __attribute__((always_inline)) inline void chol_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int n, int lane,
+                                                                  cplx *rowk, double *piv, bool &bad) {
     const int h = lane >> 5, r = lane & 31;
-    const int hk = it >> 1;
-    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 256u * h;
+    const int hk = RJ <= 8 ? it : it >> 1;
+    const int kbase = hk * RJ + (RJ <= 8 ? 0 : 8 * (it & 1));
+    const int nu = RJ <= 8 ? RJ : ((it & 1) ? RJ - 8 : 8);
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 16u * RJ * h;
+    constexpr int NU = RJ < 8 ? RJ : 8;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = 8 * it + u;
-        if (k < n) {
+    for (int u = 0; u < NU; ++u) {
+        const int k = kbase + u;
+        if (u < nu && k < n) {
             const double fx = gj_bcast_half(vr[u], hk), fy = gj_bcast_half(vi[u], hk);
             const bool isp = r == k;
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
             if (isp) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
+                for (int j = 0; j < RJ; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
             }
             __builtin_amdgcn_wave_barrier();
-            cplx rk[16];
+            cplx rk[RJ];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rk[j] = rowk[16 * h + j];
+            for (int j = 0; j < RJ; ++j) rk[j] = rowk[RJ * h + j];
             __builtin_amdgcn_sched_barrier(0);
             const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), k),
                                               __builtin_amdgcn_readlane(__double2loint(fx), k));
@@ -226,15 +230,60 @@ __device__ inline void chol_block8(double (&vr)[16], double (&vi)[16], int it, i
             const double mx = r > k ? fx * dinv : 0.0, my = r > k ? fy * dinv : 0.0;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < RJ; ++j) {
                 vr[j] = fma(-mx, rk[j].x, vr[j]); vr[j] = fma(my, rk[j].y, vr[j]);
                 vi[j] = fma(-mx, rk[j].y, vi[j]); vi[j] = fma(-my, rk[j].x, vi[j]);
             }
         }
     }
+    if constexpr (RJ > 8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double t = vr[j]; vr[j] = vr[j + 8]; vr[j + 8] = t;
-        t = vi[j]; vi[j] = vi[j + 8]; vi[j + 8] = t;
+        for (int j = 0; j + 8 < RJ; ++j) {
+            double t = vr[j]; vr[j] = vr[j + 8]; vr[j + 8] = t;
+            t = vi[j]; vi[j] = vi[j + 8]; vi[j + 8] = t;
+        }
     }
+}
+
+// S [n, n] (leading dimension ld) -> Tt[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (c < r), 1 / sqrt(D_r) (c == r), 0 above
+// (leading dimension ldt; S and Tt may be the same array: everything is loaded before anything is stored); piv[k] = D_k
+template <int RJ>
+__device__ __attribute__((always_inline)) inline void chol_wave_rj(const cplx *S, long ld, cplx *Tt, long ldt, int n, int lane,
+                                                                   cplx *rowk, double *piv, bool &bad) {
+    const int h = lane >> 5, r = lane & 31;
+    double vr[RJ], vi[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int c = RJ * h + j;
+        const cplx t = (r < n && c < n) ? S[(long)r * ld + c] : cmake(0.0, 0.0);
+        vr[j] = t.x; vi[j] = t.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NIT = RJ <= 8 ? 2 : 4;      // (an even number of blocks per half: the register rotation is undone)
+    for (int it = 0; it < NIT; ++it) chol_block8<RJ>(vr, vi, it, n, lane, rowk, piv, bad);
+    __builtin_amdgcn_wave_barrier();
+    if (r < n) {
+        const double rs = 1.0 / sqrt(piv[r]);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int c = RJ * h + j;
+            if (c >= n) continue;
+            cplx t = cmake(0.0, 0.0);
+            if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
+            else if (c == r) t = cmake(rs, 0.0);
+            Tt[(long)r * ldt + c] = t;
+        }
+    }
+}
+
+// n <= 32, one wave; piv must hold 32 doubles (set to 1 here); ceil(n / 2) columns per lane as in gj_wave32
+__device__ __attribute__((always_inline)) inline void chol_wave32(const cplx *S, long ld, cplx *Tt, long ldt, int n, int lane,
+                                                                  cplx *rowk, double *piv, bool &bad) {
+    if (lane < 32) piv[lane] = 1.0;
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n <= 8) chol_wave_rj<4>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
+    else if (n <= 16) chol_wave_rj<8>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
+    else if (n <= 24) chol_wave_rj<12>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
+    else if (n <= 26) chol_wave_rj<13>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
+    else chol_wave_rj<16>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
 }

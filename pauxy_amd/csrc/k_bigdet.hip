@@ -579,33 +579,8 @@ __global__ __launch_bounds__(256) void chol_small_kernel(CholArgs a, int nmat) {
     cplx *Tt = a.Tt + (long)b * a.ld * a.ld;
     cplx *rowk = rowk_s[wave];
     double *piv = piv_s[wave];
-    const int h = lane >> 5, r = lane & 31;
-    double vr[16], vi[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c = 16 * h + j;
-        const cplx t = (r < n && c < n) ? S[(long)r * a.ld + c] : cmake(0.0, 0.0);
-        vr[j] = t.x; vi[j] = t.y;
-    }
-    if (lane < 32) piv[lane] = 1.0;
     bool bad = false;
-    __builtin_amdgcn_wave_barrier();
-    const int nit = (n + 7) >> 3;
-    for (int it = 0; it < nit; ++it) chol_block8(vr, vi, it, n, lane, rowk, piv, bad);
-    __builtin_amdgcn_wave_barrier();
-    if (r < n) {
-        const int rot = 8 * (nit & 1);
-        const double rs = 1.0 / sqrt(piv[r]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = 16 * h + ((j + rot) & 15);
-            if (c >= n) continue;
-            cplx t = cmake(0.0, 0.0);
-            if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
-            else if (c == r) t = cmake(rs, 0.0);
-            Tt[(long)r * a.ld + c] = t;
-        }
-    }
+    chol_wave32(S, a.ld, Tt, a.ld, n, lane, rowk, piv, bad);
     double l = lane < 32 ? log(piv[lane]) : 0.0;
     for (int o = 16; o > 0; o >>= 1) l += __shfl_down(l, o);
     if (lane == 0) {

@@ -1421,33 +1421,8 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
         RF_STAMP(2 + 3 * pass);
         // ---- inverse Cholesky factor: T^T[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (see chol_small_kernel)
         if (wave == g && n > 0) {                            // (spin up on SIMD 0, spin down on SIMD 1: not both on one)
-            const int h2 = lane >> 5, r = lane & 31;
-            double vr[16], vi[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int c = 16 * h2 + j;
-                const cplx t = (r < n && c < n) ? S[r * RF_LD + c] : cmake(0.0, 0.0);
-                vr[j] = t.x; vi[j] = t.y;
-            }
-            if (lane < 32) piv_s[g][lane] = 1.0;
             bool bad = false;
-            __builtin_amdgcn_wave_barrier();
-            const int nit = (n + 7) >> 3;
-            for (int it = 0; it < nit; ++it) chol_block8(vr, vi, it, n, lane, rowk_s[g], piv_s[g], bad);
-            __builtin_amdgcn_wave_barrier();
-            if (r < n) {
-                const int rot = 8 * (nit & 1);
-                const double rs = 1.0 / sqrt(piv_s[g][r]);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int c = 16 * h2 + ((j + rot) & 15);
-                    if (c >= n) continue;
-                    cplx t = cmake(0.0, 0.0);
-                    if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
-                    else if (c == r) t = cmake(rs, 0.0);
-                    S[r * RF_LD + c] = t;
-                }
-            }
+            chol_wave32(S, RF_LD, S, RF_LD, n, lane, rowk_s[g], piv_s[g], bad);
             double l = lane < n ? log(piv_s[g][lane & 31]) : 0.0;
             if (lane >= 32) l = 0.0;
             for (int o = 16; o > 0; o >>= 1) l += __shfl_down(l, o);
