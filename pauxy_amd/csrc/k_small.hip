@@ -1322,6 +1322,9 @@ __device__ unsigned long long *afq_rf_ts = nullptr;
 #else
 #define RF_STAMP(i)
 #endif
+// RJ: registers per lane of the Cholesky wave (ceil(nmax / 2) rounded up to 4 / 8 / 13 / 16; one instantiation each: a kernel that
+// carries all of them spills)
+template <int RJ>
 __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cplx rowk_s[2][32];
@@ -1422,7 +1425,8 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
         // ---- inverse Cholesky factor: T^T[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (see chol_small_kernel)
         if (wave == g && n > 0) {                            // (spin up on SIMD 0, spin down on SIMD 1: not both on one)
             bool bad = false;
-            chol_wave32(S, RF_LD, S, RF_LD, n, lane, rowk_s[g], piv_s[g], bad);
+            if (lane < 32) piv_s[g][lane] = 1.0;
+            chol_wave_rj<RJ>(S, RF_LD, S, RF_LD, n, lane, rowk_s[g], piv_s[g], bad);
             double l = lane < n ? log(piv_s[g][lane & 31]) : 0.0;
             if (lane >= 32) l = 0.0;
             for (int o = 16; o > 0; o >>= 1) l += __shfl_down(l, o);
@@ -1512,8 +1516,12 @@ static int k_reortho_fused(afq_handle *h, size_t lds, cplx *keep) {
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
     a.phi = h->phi; a.detR = h->detR; a.weight = h->weight; a.ot = h->ot; a.fail = h->qr_fail; a.keep = keep;
-    static size_t lds_set[AFQ_MAX_DEVICES] = {0};
-    AFQ_HIP(h, afq_raise_lds((const void *)reortho_fused_kernel, lds, lds_set));
+    const int nmax_rj = h->na > h->nb ? h->na : h->nb;
+    const int rji = nmax_rj <= 8 ? 0 : nmax_rj <= 16 ? 1 : nmax_rj <= 26 ? 2 : 3;
+    const void *kfn[4] = {(const void *)reortho_fused_kernel<4>, (const void *)reortho_fused_kernel<8>,
+                          (const void *)reortho_fused_kernel<13>, (const void *)reortho_fused_kernel<16>};
+    static size_t lds_set4[4][AFQ_MAX_DEVICES] = {{0}};
+    AFQ_HIP(h, afq_raise_lds(kfn[rji], lds, lds_set4[rji]));
 #ifdef AFQ_TUNING
     static unsigned long long *rfts = nullptr;
     static int rf_launch = 0;
@@ -1529,7 +1537,10 @@ static int k_reortho_fused(afq_handle *h, size_t lds, cplx *keep) {
         }
     }
 #endif
-    AFQ_LAUNCH(h, reortho_fused_kernel, dim3(h->nw), dim3(512), lds, h->stream, a);
+    if (rji == 0) AFQ_LAUNCH(h, reortho_fused_kernel<4>, dim3(h->nw), dim3(512), lds, h->stream, a);
+    else if (rji == 1) AFQ_LAUNCH(h, reortho_fused_kernel<8>, dim3(h->nw), dim3(512), lds, h->stream, a);
+    else if (rji == 2) AFQ_LAUNCH(h, reortho_fused_kernel<13>, dim3(h->nw), dim3(512), lds, h->stream, a);
+    else AFQ_LAUNCH(h, reortho_fused_kernel<16>, dim3(h->nw), dim3(512), lds, h->stream, a);
     AFQ_POST(h);
     return AFQ_OK;
 }
