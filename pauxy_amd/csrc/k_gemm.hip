@@ -108,7 +108,11 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // 448 x 128 against 512 x 128), 3M complex products (2 real ones when BH1 is real); the 64 x 128 shape runs the
         // half-chunk pipelined loop (measured at C5 on the Taylor product: 813 -> 683 us)
         const long padA = (long)((M + 127) / 128) * 128 * ((ns + 63) / 64) * 64, padB = (long)((M + 63) / 64) * 64 * ((ns + 127) / 128) * 128;
-        if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        // 128 x 128 tiles (two 16-row and four 16-column MFMA tiles per wave, pipelined loop) when they pad no more than the
+        // smaller shapes: twice the MFMAs per chunk and barrier (C4, 256 x 256 per walker: 302 -> 272 us, 1.84 -> 1.77 ms per step)
+        const long padC = (long)((M + 127) / 128) * 128 * ((ns + 127) / 128) * 128;
+        if (padC <= padA && padC <= padB) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
