@@ -840,7 +840,9 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     if (!fp || (h->flags & AFQ_PROP_FORCE_BIAS)) {
         PhaseTimer t(h, T_GREENS);                         // continuous.py:245
         // (the spin sum alone will not do when this step needs more than the force bias: local-energy weights, one_rdm)
-        const bool sum_ok = h->gsum_only && (h->flags & AFQ_PROP_HYBRID) && !h->rdm_on && h->kind == AFQ_SYS_GENERIC;
+        const bool sum_ok = h->gsum_only && (h->flags & AFQ_PROP_HYBRID) && !h->rdm_on &&
+                            (h->kind == AFQ_SYS_GENERIC ||
+                             (h->kind == AFQ_SYS_HUBBARD && h->gdiag && h->gdiag_version == h->ghalf_version));
         if (h->greens_valid || sum_ok) std::swap(h->ovlp_old, h->ovlp_new);   // computed at the end of the last step
                                                                    // (gsum_only: as overlap + spin sum of Ghalf, all the force bias reads)
         else if ((rc = greens_any(h, h->ovlp_old, true))) return rc;
@@ -938,7 +940,11 @@ int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im) {
             // (no comb, no energy, no block end behind this step): when that force bias contracts the spin sum
             // Ghalf_a + Ghalf_b (k_fb_use_sum), the per-spin Ghalf -- 2/3 of the kernel's stores, 20 MB per step at C3 --
             // is not written at all.  Everything else sees "no cached Green's function" and recomputes if it asks.
-            h->ghalf_skip_store = h->fuse_est_req && h->ndet == 1 && h->kind == AFQ_SYS_GENERIC && k_fb_use_sum(h) &&
+            // (Hubbard, continuous fields, N > 45: the force bias reads the diagonal sums the Ghalf GEMM leaves behind --
+            //  268 MB of Ghalf per step at C4 that nobody reads)
+            const bool fb_sum = h->kind == AFQ_SYS_GENERIC && k_fb_use_sum(h);
+            const bool fb_diag = h->kind == AFQ_SYS_HUBBARD && !h->hirsch && h->psicT && k_greens_big_supported(h);
+            h->ghalf_skip_store = h->fuse_est_req && h->ndet == 1 && (fb_sum || fb_diag) &&
                                   (h->flags & AFQ_PROP_HYBRID) && (h->flags & AFQ_PROP_FORCE_BIAS) && !h->rdm_on &&
                                   h->nbp == 0 && h->psi_stride == 0 && !afq_knob("AFQ_NO_GHALF_SKIP");
             h->ghalf_skipped = false;

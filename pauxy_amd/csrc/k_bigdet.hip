@@ -76,6 +76,7 @@ struct GhalfProbT {
     const cplx *Oinv;                // [2 nw, ld * ld]
     const cplx *phi;
     cplx *ghalf;                     // [nw, nt, M]
+    int skip_store;                  // only the diagonal sums are wanted (afq_propagate_finish on an announced step)
     const cplx *zero;
     __device__ bool active(int) const { return true; }
     __device__ cplx loadA(int, int, int) const { return cmake(0, 0); }
@@ -98,7 +99,7 @@ struct GhalfProbT {
     __device__ bool colok(int, int) const { return true; }
     __device__ void store(int b, int row, int col, double re, double im) const {
         const int s = b & 1, ns = s ? nb : na;
-        if (row < ns) ghalf[((long)(b >> 1) * nt + (s ? na : 0) + row) * M + col] = cmake(re, im);
+        if (row < ns && !skip_store) ghalf[((long)(b >> 1) * nt + (s ? na : 0) + row) * M + col] = cmake(re, im);
     }
 };
 
@@ -353,6 +354,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
             p.Oinv = h->big_ws; p.phi = h->phi; p.ghalf = ghalf; p.zero = (const cplx *)h->zero_page;
             p.psicT = h->psicT; p.gdiag = h->gdiag; p.nparts = h->gdiag_parts;
+            p.skip_store = 0;
+            if (decltype(p)::COLDOT && h->ghalf_skip_store) { p.skip_store = 1; h->ghalf_skipped = true; }
 #ifdef AFQ_TUNING
             if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else
