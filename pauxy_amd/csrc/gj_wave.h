@@ -8,7 +8,7 @@
 // Register-resident Gauss-Jordan inverse of an n x n complex matrix, n <= 32, by ONE wave:
 // lane (h = lane >> 5, r = lane & 31) keeps row r, columns 16 h .. 16 h + 15, in VGPRs.  Per pivot
 // step (fully unrolled, so every register index is static): the half that owns column k hands it
-// to the other half with v_permlane32_swap, a DPP wave maximum of a packed (|pivot|, row) key picks
+// to the other half with v_permlane32_swap (the owning half is a template argument of the block), a DPP wave maximum of a packed (|pivot|, row) key picks
 // the pivot row among the rows not used yet (implicit pivoting: no row swaps), the pivot row crosses
 // the wave through 32 x 16 bytes of LDS, and every lane updates its 16 entries.  The division by the
 // pivot is deferred: row p is only scaled once, at the end.  No barrier, no atomics; the matrix never
@@ -38,12 +38,13 @@ __device__ __attribute__((always_inline)) inline void gj_store_pair(unsigned bas
     }
 }
 
-// value of half hk (lanes 32 hk ..) handed to both halves (hk wave-uniform)
-__device__ inline double gj_bcast_half(double x, int hk) {
+// value of half HK (lanes 32 HK ..) handed to both halves, HK known at compile time: one swap per dword, no selects
+template <int HK>
+__device__ __attribute__((always_inline)) inline double gj_bcast_half_s(double x) {
     const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
     const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)(hk ? b[1] : b[0]), (int)(hk ? a[1] : a[0]));
+    return __hiloint2double((int)b[HK], (int)a[HK]);
 }
 
 // One block of <= 8 pivot steps with static register indices.  Lane (h, r) keeps RJ columns of row r: columns
@@ -54,13 +55,13 @@ __device__ inline double gj_bcast_half(double x, int hk) {
 //   RJ > 8:  blocks 2 hk and 2 hk + 1 of half hk cover its registers 0..7 and 8..RJ - 1; the caller's register array is
 //            rotated by 8 after every block (swap j <-> j + 8), so the active column of step u is always physical register u.
 // The body is a loop over the blocks so that the code stays in the instruction cache instead of streaming n unrolled steps.
-template <int RJ>
+template <int RJ, int HK>
 __device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int n, int lane, bool &used,
-                                 double &sx, double &sy, int &mystep, cplx *rowk, cplx *piv, int *prow) {
+                                 double &sx, double &sy, double &pdx, double &pdy, int &mystep, cplx *rowk) {
     const int h = lane >> 5, r = lane & 31;
-    const int hk = RJ <= 8 ? it : it >> 1;
-    const int kbase = hk * RJ + (RJ <= 8 ? 0 : 8 * (it & 1));
-    const int nu = RJ <= 8 ? RJ : ((it & 1) ? RJ - 8 : 8);
+    constexpr int hk = HK;                                   // (it: block of this half, 0 or 1 when RJ > 8)
+    const int kbase = hk * RJ + 8 * it;
+    const int nu = RJ <= 8 ? RJ : (it ? RJ - 8 : 8);
     const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 16u * RJ * h;
     constexpr int NU = RJ < 8 ? RJ : 8;
 #pragma unroll
@@ -68,13 +69,22 @@ __device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int
         const int k = kbase + u;
         if (u < nu && k < n) {
             // 1. column k to every lane of its row
-            const double fx = gj_bcast_half(vr[u], hk), fy = gj_bcast_half(vi[u], hk);
-            // 2. pivot row: largest fp32-rounded |re| + |im| among unused rows, ties -> lowest row
-            const unsigned mb = __float_as_uint((float)(fabs(fx) + fabs(fy)));
-            const unsigned key = (used || r >= n) ? 0u : ((((mb >> 6) + 1u) << 5) | (unsigned)(31 - r));
+            const double fx = gj_bcast_half_s<HK>(vr[u]), fy = gj_bcast_half_s<HK>(vi[u]);
+            // 2. pivot row: largest |re| + |im| among unused rows, compared on the top 26 bits of the double (exponent + 15
+            //    mantissa bits: positive doubles order like their bit patterns), ties -> lowest row
+            const unsigned mb = (unsigned)__double2hiint(fabs(fx) + fabs(fy));
+            const unsigned key = used ? 0u : ((((mb >> 5) + 1u) << 5) | (unsigned)(31 - r));
+            // every lane's own reciprocal, speculatively: independent of the search, it issues under the DPP chain (the
+            // reciprocal of the row that wins is then two v_readlane pairs away instead of a 12-deep chain behind them)
+            const double nnl = fx * fx + fy * fy;
+            double dnl = __builtin_amdgcn_rcp(nnl);
+            dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
+            dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
+            const double ixl = fx * dnl, iyl = -fy * dnl;
             const int p = 31 - (int)(gj_wave_max_u32(key) & 31u);
             const bool isp = r == p;
             used = used || isp;
+            const double fxz = isp ? 0.0 : fx, fyz = isp ? 0.0 : fy;     // (the pivot row's own multiplier is zero)
             // 3. slot (., k) becomes the identity column of the pivot row; the (unscaled) pivot row goes
             //    to LDS first so that its round trip overlaps the reciprocal below
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
@@ -87,21 +97,15 @@ __device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int
 #pragma unroll
             for (int j = 0; j < RJ; ++j) rk[j] = rowk[RJ * h + j];
             __builtin_amdgcn_sched_barrier(0);
-            // 4. pivot value (uniform), its reciprocal, multipliers (zero for the pivot row itself)
-            const double dx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), p),
-                                               __builtin_amdgcn_readlane(__double2loint(fx), p));
-            const double dy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fy), p),
-                                               __builtin_amdgcn_readlane(__double2loint(fy), p));
-            // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is a 12-deep
-            // dependent chain on the per-pivot critical path; this one is 5 deep, < 1 ulp off)
-            const double nn = dx * dx + dy * dy;
-            double dn = __builtin_amdgcn_rcp(nn);
-            dn = fma(fma(-nn, dn, 1.0), dn, dn);
-            dn = fma(fma(-nn, dn, 1.0), dn, dn);
-            const double ix = dx * dn, iy = -dy * dn;
-            if (lane == 0) { piv[k] = cmake(dx, dy); prow[k] = p; }
-            if (isp) { sx = ix; sy = iy; mystep = k; }
-            const double mx = isp ? 0.0 : fx * ix - fy * iy, my = isp ? 0.0 : fx * iy + fy * ix;
+            // 4. reciprocal of the pivot (uniform; v_rcp_f64 + two Newton steps, < 1 ulp off: the IEEE division sequence is a
+            //    12-deep dependent chain), multipliers (zero for the pivot row itself).  The pivot row's lanes keep their
+            //    pivot and its step for the determinant and the un-permutation at the end.
+            const double ix = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ixl), p),
+                                               __builtin_amdgcn_readlane(__double2loint(ixl), p));
+            const double iy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(iyl), p),
+                                               __builtin_amdgcn_readlane(__double2loint(iyl), p));
+            if (isp) { sx = ix; sy = iy; pdx = fx; pdy = fy; mystep = k; }
+            const double mx = fxz * ix - fyz * iy, my = fxz * iy + fyz * ix;
             __builtin_amdgcn_sched_barrier(0);
             // 5. eliminate
 #pragma unroll
@@ -132,13 +136,16 @@ __device__ __attribute__((always_inline)) inline void gj_wave_rj(cplx *O, int n,
         const cplx t = (r < n && c < n) ? O[r * n + c] : cmake(0.0, 0.0);
         vr[j] = t.x; vi[j] = t.y;
     }
-    bool used = false;
-    double sx = 1.0, sy = 0.0;
+    bool used = r >= n;                                      // rows that are no pivot candidates (any more)
+    double sx = 1.0, sy = 0.0, pdx = 1.0, pdy = 0.0;
     int mystep = r;
     __builtin_amdgcn_wave_barrier();
     // (an even number of blocks per half: the register rotation of RJ > 8 is back where it started)
-    constexpr int NIT = RJ <= 8 ? 2 : 4;
-    for (int it = 0; it < NIT; ++it) gj_block8<RJ>(vr, vi, it, n, lane, used, sx, sy, mystep, rowk, piv, prow);
+    constexpr int NSUB = RJ <= 8 ? 1 : 2;
+    for (int it = 0; it < NSUB; ++it) gj_block8<RJ, 0>(vr, vi, it, n, lane, used, sx, sy, pdx, pdy, mystep, rowk);
+    for (int it = 0; it < NSUB; ++it) gj_block8<RJ, 1>(vr, vi, it, n, lane, used, sx, sy, pdx, pdy, mystep, rowk);
+    // pivots in step order and the pivot row of every step, for the determinant and the un-permutation
+    if (h == 0 && r < n) { piv[mystep] = cmake(pdx, pdy); prow[mystep] = r; }
     __builtin_amdgcn_wave_barrier();
     if (write_inverse && r < n) {
 #pragma unroll
@@ -194,20 +201,20 @@ __device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, 
 // data layout and block structure as gj_block8, but the pivot of step k is row k (no search) and only
 // the rows below it are eliminated: forward elimination of [S | I] in place, so that at the end
 // v[i][j] (j < i) = Ltilde^-1[i][j] with S = Ltilde D Ltilde^H and piv[k] = D_k.
-template <int RJ>
+template <int RJ, int HK>
 __device__ __attribute__((always_inline)) inline void chol_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int n, int lane,
                                                                   cplx *rowk, double *piv, bool &bad) {
     const int h = lane >> 5, r = lane & 31;
-    const int hk = RJ <= 8 ? it : it >> 1;
-    const int kbase = hk * RJ + (RJ <= 8 ? 0 : 8 * (it & 1));
-    const int nu = RJ <= 8 ? RJ : ((it & 1) ? RJ - 8 : 8);
+    constexpr int hk = HK;                                   // (it: block of this half, 0 or 1 when RJ > 8)
+    const int kbase = hk * RJ + 8 * it;
+    const int nu = RJ <= 8 ? RJ : (it ? RJ - 8 : 8);
     const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 16u * RJ * h;
     constexpr int NU = RJ < 8 ? RJ : 8;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int k = kbase + u;
         if (u < nu && k < n) {
-            const double fx = gj_bcast_half(vr[u], hk), fy = gj_bcast_half(vi[u], hk);
+            const double fx = gj_bcast_half_s<HK>(vr[u]), fy = gj_bcast_half_s<HK>(vi[u]);
             const bool isp = r == k;
             if (h == hk) { vr[u] = isp ? 1.0 : 0.0; vi[u] = 0.0; }
             if (isp) {
@@ -259,8 +266,9 @@ __device__ __attribute__((always_inline)) inline void chol_wave_rj(const cplx *S
         vr[j] = t.x; vi[j] = t.y;
     }
     __builtin_amdgcn_wave_barrier();
-    constexpr int NIT = RJ <= 8 ? 2 : 4;      // (an even number of blocks per half: the register rotation is undone)
-    for (int it = 0; it < NIT; ++it) chol_block8<RJ>(vr, vi, it, n, lane, rowk, piv, bad);
+    constexpr int NSUB = RJ <= 8 ? 1 : 2;     // (an even number of blocks per half: the register rotation is undone)
+    for (int it = 0; it < NSUB; ++it) chol_block8<RJ, 0>(vr, vi, it, n, lane, rowk, piv, bad);
+    for (int it = 0; it < NSUB; ++it) chol_block8<RJ, 1>(vr, vi, it, n, lane, rowk, piv, bad);
     __builtin_amdgcn_wave_barrier();
     if (r < n) {
         const double rs = 1.0 / sqrt(piv[r]);
