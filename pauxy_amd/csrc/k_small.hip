@@ -702,7 +702,9 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     if (k_greens_big_supported(h)) {
         return k_greens_big(h, ghalf, det, oinv);
     }
-    if (nmax <= 45 && h->M <= 4 * GS_KSMAX) {
+    // (the fast kernel keeps the walker, both overlap matrices and their inverses in LDS: 160 KB per work-group)
+    const size_t lds_small = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) + (size_t)h->M * h->nt);
+    if (nmax <= 45 && h->M <= 4 * GS_KSMAX && lds_small <= 160 * 1024) {
         a.o_in_lds = 1; a.only_alive = only_alive; a.alive = h->alive;
         // the step's weight update rides on this launch when afq_propagate asked for it and this IS the
         // overlap of the propagated walkers
@@ -769,6 +771,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         AFQ_POST(h);
         return AFQ_OK;
     }
+    if (oinv) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "inverse overlaps: the walker and both overlap matrices must fit 160 KB of LDS (N <= 45) or N > 45");
     const size_t need = sizeof(cplx) * (size_t)nmax * nmax;
     a.o_in_lds = need <= 64 * 1024;
     a.only_alive = only_alive; a.alive = h->alive;

@@ -425,3 +425,21 @@ def test_greens_basis_sizes_real_and_complex_trial(M, cplx):
             assert abs(ot[w] - det) <= 1e-10 * abs(det)
             close(gh[w].reshape(na + nb, M), numpy.concatenate(ghalf_ref), 1e-9)
         dev.close()
+
+
+@pytest.mark.parametrize("M,na,nb,cplx", [(64, 40, 37, False), (100, 45, 33, True), (90, 33, 33, False)])
+def test_greens_33_to_45_electrons(M, na, nb, cplx):
+    """33 .. 45 electrons per spin: nine overlap tiles per spin (up to three per wave: the trial fragments of the second and
+    third are fetched inside the loop) and the LDS Gauss-Jordan of the small Green's function kernel."""
+    model, rng = build(M, 6, na, nb, cplx, seed=M + na)
+    nw = 4
+    dev = make_device(model, nw)
+    phi = rng.rand(nw, M, na + nb) - 0.5 + 1j * (rng.rand(nw, M, na + nb) - 0.5)
+    dev.set(L.F_PHI, phi)
+    ot = dev.greens(want_G=False)
+    gh = dev.get(L.F_GHALF)
+    for w in range(nw):
+        det, ghalf_ref, _ = ref.greens_function(phi[w], model.psi, na, nb)
+        assert abs(ot[w] - det) <= 1e-9 * abs(det)
+        close(gh[w].reshape(na + nb, M), numpy.concatenate(ghalf_ref), 1e-8)
+    dev.close()
