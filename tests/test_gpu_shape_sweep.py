@@ -14,3 +14,23 @@ pytestmark = pytest.mark.gpu
 ])
 def test_operators_and_step_on_boundary_shapes(M, K, na, nb, nw, cplx):
     run_shape(M, K, na, nb, nw, cplx)
+
+
+@pytest.mark.parametrize("nx,ny,na,nb,nw,spin", [
+    (7, 7, 24, 23, 66, False), (10, 10, 45, 45, 64, False), (9, 9, 40, 38, 65, True), (6, 6, 18, 18, 70, False),
+    (10, 8, 46, 45, 64, False), (12, 11, 66, 66, 9, False),
+])
+def test_hubbard_continuous_on_boundary_shapes(nx, ny, na, nb, nw, spin):
+    """Hubbard, continuous fields: lattices whose electron counts straddle the 32 / 45 limits of the small Green's function
+    kernel and its LDS budget, odd site counts, charge and spin decomposition, populations around 64."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.propagation import setup
+    from tests.test_gpu_fullsize import run_fullsize
+    s = systems.Hubbard(nx, ny, na, nb, 4.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    dt = 0.01
+    BH1, mf = setup.hubbard_propagator_arrays(s, t, dt, not spin)
+    model = ref.RefModel('hubbard_spin' if spin else 'hubbard', nx * ny, na, nb, t.psi, BH1, mf, dt, U=4.0,
+                         H1=s.T.astype(complex))
+    run_fullsize(model, nw, [0, 1, nw // 2, nw - 1])
