@@ -307,9 +307,13 @@ __global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det,
     det[w] = cmake(ldexp(p.x, e), ldexp(p.y, e));
 }
 
+// N > 45, or a smaller determinant whose walker does not fit the one-work-group kernel of k_small.hip (M > 128, or walker +
+// overlap matrices above 160 KB of LDS: e.g. 45 + 45 electrons on 100 sites)
 int k_greens_big_supported(afq_handle *h) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
-    return nmax > 45 && nmax <= GJ_N && h->nb > 0 && !h->no_ring;
+    const size_t lds_small = sizeof(cplx) * (2 * ((size_t)nmax * nmax + 2 * nmax) + ((2 * nmax + 3) / 4 + 1) + (size_t)h->M * h->nt);
+    const bool small_fits = nmax <= 45 && h->M <= 128 && lds_small <= 160 * 1024;
+    return !small_fits && nmax > 16 && nmax <= GJ_N && h->nb > 0 && !h->no_ring;
 }
 
 int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {

@@ -372,7 +372,7 @@ def test_c5_sizes_back_propagation_window():
     dev.close()
 
 
-@pytest.mark.parametrize("nx,ny,ne", [(8, 8, 30), (16, 16, 128)])
+@pytest.mark.parametrize("nx,ny,ne", [(8, 8, 30), (10, 10, 45), (16, 16, 128)])
 def test_hirsch_large_lattices(nx, ny, ne):
     """The discrete Hirsch step (propagation/hubbard.py:148-225,285-312) beyond N = 45: 8x8 with 30+30 electrons
     (inverse overlaps still in LDS) and the BASELINE configs[3] lattice 16x16 with 128+128 (inverse overlaps from
