@@ -34,3 +34,10 @@ def test_hubbard_continuous_on_boundary_shapes(nx, ny, na, nb, nw, spin):
     model = ref.RefModel('hubbard_spin' if spin else 'hubbard', nx * ny, na, nb, t.psi, BH1, mf, dt, U=4.0,
                          H1=s.T.astype(complex))
     run_fullsize(model, nw, [0, 1, nw // 2, nw - 1])
+
+
+@pytest.mark.parametrize("K,nw", [(1, 1), (255, 33), (256, 65), (257, 31), (513, 64), (2, 129)])
+def test_field_counts_and_populations_on_kernel_boundaries(K, nw):
+    """Field counts around the work-group size of the fields kernel (a thread per field up to 256, a Philox pair per thread
+    above), one field, populations around the 32 / 64-walker thresholds of the work-group-tiled GEMMs and a single walker."""
+    run_shape(20, K, 4, 3, nw, K % 2 == 1)
