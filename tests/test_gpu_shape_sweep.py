@@ -41,3 +41,43 @@ def test_field_counts_and_populations_on_kernel_boundaries(K, nw):
     """Field counts around the work-group size of the fields kernel (a thread per field up to 256, a Philox pair per thread
     above), one field, populations around the 32 / 64-walker thresholds of the work-group-tiled GEMMs and a single walker."""
     run_shape(20, K, 4, 3, nw, K % 2 == 1)
+
+
+def _generic_40():
+    from pauxy_amd import systems, trial as trial_mod
+    from tests.test_gpu_batched import build_afqmc
+    s = systems.synthetic_generic(64, 12, (40, 40), seed=5)
+    return build_afqmc(s, trial_mod.rhf_trial_generic(s), 66)
+
+
+def _generic_m130():
+    from pauxy_amd import systems, trial as trial_mod
+    from tests.test_gpu_batched import build_afqmc
+    s = systems.synthetic_generic(130, 10, (20, 20), seed=6)
+    return build_afqmc(s, trial_mod.rhf_trial_generic(s), 65)
+
+
+def _hubbard_10x10():
+    from pauxy_amd import systems, trial as trial_mod
+    from tests.test_gpu_batched import build_afqmc
+    s = systems.Hubbard(10, 10, 45, 45, 4.0)
+    return build_afqmc(s, trial_mod.uhf_trial_hubbard(s, ueff=0.4), 64, False, {'hubbard_stratonovich': 'continuous'})
+
+
+@pytest.mark.parametrize("make", [_generic_40, _generic_m130, _hubbard_10x10], ids=["generic-40e", "generic-M130", "hubbard-10x10-45e"])
+def test_driver_loops_agree_on_boundary_shapes(make):
+    """20 steps of the per-walker loop, the batched loop and the batched loop with the estimator terms riding on the weight
+    update (which also announces the steps whose per-spin Ghalf is not stored) on shapes that take the dispatch paths
+    between the benchmark configurations: same walkers, weights and block rows to rounding, identical comb decisions."""
+    import numpy
+    from tests.test_gpu_batched import run_c3, close
+    a, blocks_a, phi_a = run_c3(False, True, make=make)
+    b, blocks_b, phi_b = run_c3(True, True, make=make)
+    d, blocks_d, phi_d = run_c3(True, False, ride=True, make=make)
+    assert numpy.all(numpy.isfinite(phi_a.view(float))) and numpy.all(numpy.isfinite(a['weight']))
+    assert numpy.array_equal(a['pix'], b['pix'])
+    for other, blocks, phi in ((b, blocks_b, phi_b), (d, blocks_d, phi_d)):
+        for key in ('weight', 'ot', 'ehyb'):
+            close(other[key], a[key], 1e-9)
+        close(phi, phi_a, 1e-9)
+        close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-9)
