@@ -229,13 +229,17 @@ def test_c5_sizes_single_determinant_256_walkers():
     run_fullsize(generic_c5(), 256, [0, 130, 255])
 
 
-def test_c5_sizes_multi_determinant_consistency():
-    """BASELINE configs[4] sizes (M=400, K=2000, 50+50 electrons).  Size-independent property of the
+@pytest.mark.parametrize("M,K,N,nw", [(400, 2000, 50, 32), (130, 24, 20, 33), (100, 20, 45, 9), (40, 16, 33, 65)],
+                         ids=["C5", "M130-20e", "M100-45e", "M40-33e"])
+def test_c5_sizes_multi_determinant_consistency(M, K, N, nw):
+    """BASELINE configs[4] sizes (M=400, K=2000, 50+50 electrons), and smaller shapes that take the other dispatch paths
+    of the determinant kernels with several determinants (the GEMM + register Gauss-Jordan path below 45 electrons, the
+    LDS Gauss-Jordan of the one-work-group kernel).  Size-independent property of the
     multi-determinant path: a trial made of three IDENTICAL determinants with coefficients c_d must
     reproduce the single-determinant force bias, energy and propagated walkers, with overlap
     sum_d conj(c_d) times the single-determinant overlap.  One walker is also checked directly against
     the oracle (Green's function, force bias, half-rotated energy)."""
-    M, K, N, dt, nw = 400, 2000, 50, 0.005, 32
+    dt = 0.005
     s = systems.synthetic_generic(M, K, (N, N), seed=7)
     t = trial_mod.rhf_trial_generic(s)
     BH1, mf = setup.generic_propagator_arrays(s, t, dt)
@@ -251,9 +255,9 @@ def test_c5_sizes_multi_determinant_consistency():
     xbar = dev.force_bias()
     E = dev.local_energy()
     d, gh, Gr = ref.greens_function(phis[3], model.psi, N, N)
-    close(det[3], d, 1e-10)
-    close(xbar[3], model.force_bias(gh, Gr), 1e-10)
-    close(E[3], numpy.array(model.local_energy(Gr, gh)), 1e-10)
+    close(det[3], d, 1e-9)
+    close(xbar[3], model.force_bias(gh, Gr), 1e-9)
+    close(E[3], numpy.array(model.local_energy(Gr, gh)), 1e-9)
     dev.set(L.F_OT, det)
     dev.propagate(xi, 0.0)
     phi_sd, w_sd = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
