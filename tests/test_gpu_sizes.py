@@ -99,7 +99,7 @@ def test_vhs_nonsymmetric_cholesky():
     dev.close()
 
 
-@pytest.mark.parametrize("M,K,na,nb,restore", [(37, 45, 7, 6, None), (120, 40, 9, 9, 'full')])
+@pytest.mark.parametrize("M,K,na,nb,restore", [(37, 45, 7, 6, None), (120, 40, 9, 9, 'full'), (64, 12, 40, 40, None), (100, 10, 45, 45, None)])
 def test_back_propagation_with_reortho(M, K, na, nb, restore):
     """afq_bp_update against the oracle with a window longer than the stabilisation period (the
     re-orthogonalisation inside the back-propagation, propagation/generic.py:286-288, is not reached by
