@@ -159,9 +159,12 @@ def test_c2_c4_run_batched_equals_run(make):
             if exact:
                 assert numpy.array_equal(a[key], other[key]), key
             else:
-                # C4: bit-equal through the first re-orthogonalisation + energy evaluation (step 10); from step 11 on the
-                # Green's functions of the two loops differ in the last bits (1e-15: measured with tools/dbg_c4_batched.py,
-                # walkers, overlaps and weights of step 10 identical, Ghalf not), which then spreads at rounding level
+                # C4: bit-equal through the first re-orthogonalisation + energy evaluation (step 10).  The zero shift of the
+                # first block (E ~ +700 on this lattice) takes every walker below the 1e-8 threshold from step 8 to 10: the
+                # per-walker loop then has nothing to propagate and makes no call, the batched loop queues its step, whose
+                # closing Green's function evaluation sees the freshly re-orthogonalised walkers (Ghalf of phi R^-1
+                # instead of the one kept across the QR: 1e-15, tools/dbg_c4_batched2.py); the comb revives the
+                # population and the difference spreads at rounding level
                 assert numpy.array_equal(a[key][:10], other[key][:10]), key
                 close(a[key], other[key], 1e-11)
         if exact:
