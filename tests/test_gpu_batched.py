@@ -82,8 +82,8 @@ def test_batched_traj_hirsch(golden, monkeypatch):
 C3 = dict(M=100, K=500, N=25, nw=256)
 
 
-def build_afqmc(s, t, nw, device_rng=False, prop=None):
-    options = {'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': 2, 'stabilise_freq': 10, 'pop_control_freq': 5,
+def build_afqmc(s, t, nw, device_rng=False, prop=None, dt=0.005):
+    options = {'qmc': {'timestep': dt, 'num_steps': 10, 'blocks': 2, 'stabilise_freq': 10, 'pop_control_freq': 5,
                        'num_walkers': nw, 'rng_seed': 7},
                'propagator': dict({'device_rng': device_rng, 'rng_seed': 7}, **(prop or {})),
                'estimators': {'mixed': {'verbose': False}}}
@@ -107,6 +107,14 @@ def c4_afqmc(device_rng=False):
     s = systems.Hubbard(16, 16, 128, 128, 8.0)
     t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
     return build_afqmc(s, t, 256, device_rng, {'hubbard_stratonovich': 'continuous'})
+
+
+def c4_small_step_afqmc(device_rng=False):
+    """The same lattice with a ten times smaller time step: the zero energy shift of the first block (E ~ +700) then
+    costs a factor 0.03 in weight over the block instead of 1e-15, and every walker stays above the 1e-8 threshold."""
+    s = systems.Hubbard(16, 16, 128, 128, 8.0)
+    t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    return build_afqmc(s, t, 256, device_rng, {'hubbard_stratonovich': 'continuous'}, dt=0.0005)
 
 
 def run_c3(batched, fetch, ride=False, make=c3_afqmc):
@@ -139,7 +147,8 @@ def run_c3(batched, fetch, ride=False, make=c3_afqmc):
     return {k: numpy.array(v) for k, v in rec.items()}, blocks, phi
 
 
-@pytest.mark.parametrize("make", [c2_afqmc, c4_afqmc], ids=["C2-ueg-256", "C4-hubbard16x16-256"])
+@pytest.mark.parametrize("make", [c2_afqmc, c4_afqmc, c4_small_step_afqmc],
+                         ids=["C2-ueg-256", "C4-hubbard16x16-256", "C4-hubbard16x16-256-all-alive"])
 def test_c2_c4_run_batched_equals_run(make):
     """20 steps of BASELINE configs[1] (UEG, 93 plane waves) and configs[3] (16x16 Hubbard, 128+128 electrons: the
     GEMM + register-resident Gauss-Jordan Green's function, the unfused propagator) at their stated 256 walkers
@@ -153,13 +162,22 @@ def test_c2_c4_run_batched_equals_run(make):
     for key in ('weight', 'ot', 'ehyb'):
         assert numpy.array_equal(b[key], c[key]), key
     assert numpy.array_equal(phi_b, phi_c)
-    exact = make is c2_afqmc
     for other, blocks, phi in ((b, blocks_b, phi_b), (c, blocks_c, phi_c)):
         for key in ('weight', 'ot', 'ehyb'):
-            if exact:
+            if make is c2_afqmc:
                 assert numpy.array_equal(a[key], other[key]), key
+            elif make is c4_small_step_afqmc:
+                # every walker alive: Slater matrices and overlaps bit-equal over all 20 steps; the block sums of the two
+                # loops are the same terms in another association (the per-walker loop adds every step on the host), so
+                # the shift derived from block 1 differs in its last bit (E ~ +700) and with it, from step 11 on, the
+                # weights and the hybrid energies (one ulp: tools/dbg_c4_batched3.py)
+                assert numpy.array_equal(a[key][:10], other[key][:10]), key
+                if key == 'ot':
+                    assert numpy.array_equal(a[key], other[key]), key
+                close(a[key], other[key], 1e-13)
             else:
-                # C4: bit-equal through the first re-orthogonalisation + energy evaluation (step 10).  The zero shift of the
+                # C4 at the time step of the other configurations: bit-equal through the first re-orthogonalisation +
+                # energy evaluation (step 10).  The zero shift of the
                 # first block (E ~ +700 on this lattice) takes every walker below the 1e-8 threshold from step 8 to 10: the
                 # per-walker loop then has nothing to propagate and makes no call, the batched loop queues its step, whose
                 # closing Green's function evaluation sees the freshly re-orthogonalised walkers (Ghalf of phi R^-1
@@ -167,10 +185,10 @@ def test_c2_c4_run_batched_equals_run(make):
                 # population and the difference spreads at rounding level
                 assert numpy.array_equal(a[key][:10], other[key][:10]), key
                 close(a[key], other[key], 1e-11)
-        if exact:
-            assert numpy.array_equal(phi_a, phi)
-        else:
+        if make is c4_afqmc:
             close(phi, phi_a, 1e-11)
+        else:
+            assert numpy.array_equal(phi_a, phi)
         close(blocks[:, 1:10], blocks_a[:, 1:10], 1e-12)
     assert numpy.array_equal(a['pix'], b['pix'])
     assert a['pix'].shape == (4, 256) and a['pix'].max() >= 2             # the comb did clone walkers
