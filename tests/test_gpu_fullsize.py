@@ -376,25 +376,21 @@ def test_c5_sizes_back_propagation_window():
     dev.close()
 
 
-@pytest.mark.parametrize("nx,ny,ne", [(8, 8, 30), (10, 10, 45), (16, 16, 128)])
-def test_hirsch_large_lattices(nx, ny, ne):
-    """The discrete Hirsch step (propagation/hubbard.py:148-225,285-312) beyond N = 45: 8x8 with 30+30 electrons
-    (inverse overlaps still in LDS) and the BASELINE configs[3] lattice 16x16 with 128+128 (inverse overlaps from
-    the register-resident Gauss-Jordan kernel, updated in place in global memory).  Kinetic importance sampling,
-    site loop (chosen fields exact), second kinetic step, against the oracle."""
+def run_hirsch_lattice(nx, ny, na, nb, charge=False, nw=4):
+    """Kinetic importance sampling, site loop (chosen fields exact), against the oracle on one lattice."""
     from pauxy_amd.device import AfqDevice
-    s = systems.Hubbard(nx, ny, ne, ne, 4.0)
+    s = systems.Hubbard(nx, ny, na, nb, 4.0)
     t = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
-    m = ref.HirschModel(s.T.astype(complex), 4.0, t.psi, ne, ne, 0.01, False)
-    nw, M = 4, m.M
+    m = ref.HirschModel(s.T.astype(complex), 4.0, t.psi, na, nb, 0.01, charge)
+    M = m.M
     rng = numpy.random.RandomState(9)
     dev = AfqDevice(0)
-    dev.set_system_hubbard(m.H1, m.U, ne, ne)
+    dev.set_system_hubbard(m.H1, m.U, na, nb)
     dev.set_trial(m.psi)
-    dev.set_propagator_hirsch(m.bt2, 0.01, False)
+    dev.set_propagator_hirsch(m.bt2, 0.01, charge)
     dev.walkers_alloc(nw)
-    phis = numpy.array([m.psi + 0.02 * (rng.rand(M, 2 * ne) + 1j * rng.rand(M, 2 * ne)) for _ in range(nw)])
-    w0 = numpy.array([1.0, 0.7, 0.0, 1.3])
+    phis = numpy.array([m.psi + 0.02 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    w0 = numpy.resize(numpy.array([1.0, 0.7, 0.0, 1.3]), nw)
     dev.set(L.F_PHI, phis)
     dev.set(L.F_WEIGHT, w0)
     dev.set(L.F_OT, dev.calc_overlap())
@@ -417,3 +413,12 @@ def test_hirsch_large_lattices(nx, ny, ne):
     close(dev.get(L.F_WEIGHT), numpy.array([wk['weight'] for wk in walkers]), 1e-8)
     close(dev.get(L.F_OT), numpy.array([wk['ot'] for wk in walkers]), 1e-8)
     dev.close()
+
+
+@pytest.mark.parametrize("nx,ny,ne", [(8, 8, 30), (10, 10, 45), (16, 16, 128)])
+def test_hirsch_large_lattices(nx, ny, ne):
+    """The discrete Hirsch step (propagation/hubbard.py:148-225,285-312) beyond N = 45: 8x8 with 30+30 electrons
+    (inverse overlaps still in LDS) and the BASELINE configs[3] lattice 16x16 with 128+128 (inverse overlaps from
+    the register-resident Gauss-Jordan kernel, updated in place in global memory).  Kinetic importance sampling,
+    site loop (chosen fields exact), second kinetic step, against the oracle."""
+    run_hirsch_lattice(nx, ny, ne, ne)

@@ -16,9 +16,20 @@ def test_operators_and_step_on_boundary_shapes(M, K, na, nb, nw, cplx):
     run_shape(M, K, na, nb, nw, cplx)
 
 
+@pytest.mark.parametrize("M,K,na,nb,nw,cplx", [
+    (2, 1, 1, 1, 1, False), (3, 2, 2, 1, 2, True), (4, 2, 4, 3, 5, False), (6, 3, 2, 0, 7, False), (5, 3, 1, 1, 257, True),
+    (20, 10, 3, 2, 600, False), (16, 5, 16, 15, 64, False), (33, 4, 1, 0, 64, True), (17, 1, 8, 8, 63, False),
+])
+def test_operators_and_step_on_degenerate_shapes(M, K, na, nb, nw, cplx):
+    """The other end: two orbitals, one field, one walker; a filled band (na = M); no beta electrons; populations that are
+    not a multiple of any tile (257, 600)."""
+    run_shape(M, K, na, nb, nw, cplx)
+
+
 @pytest.mark.parametrize("nx,ny,na,nb,nw,spin", [
     (7, 7, 24, 23, 66, False), (10, 10, 45, 45, 64, False), (9, 9, 40, 38, 65, True), (6, 6, 18, 18, 70, False),
-    (10, 8, 46, 45, 64, False), (12, 11, 66, 66, 9, False),
+    (10, 8, 46, 45, 64, False), (12, 11, 66, 66, 9, False), (2, 2, 2, 2, 5, False), (8, 1, 4, 4, 64, True),
+    (3, 3, 5, 4, 33, False), (4, 2, 3, 1, 65, True),
 ])
 def test_hubbard_continuous_on_boundary_shapes(nx, ny, na, nb, nw, spin):
     """Hubbard, continuous fields: lattices whose electron counts straddle the 32 / 45 limits of the small Green's function
@@ -34,6 +45,40 @@ def test_hubbard_continuous_on_boundary_shapes(nx, ny, na, nb, nw, spin):
     model = ref.RefModel('hubbard_spin' if spin else 'hubbard', nx * ny, na, nb, t.psi, BH1, mf, dt, U=4.0,
                          H1=s.T.astype(complex))
     run_fullsize(model, nw, [0, 1, nw // 2, nw - 1])
+
+
+@pytest.mark.parametrize("nx,ny,na,nb,charge,nw", [
+    (2, 2, 2, 2, False, 4), (8, 1, 4, 4, False, 5), (3, 3, 5, 4, False, 7), (4, 2, 3, 1, True, 4), (6, 6, 18, 17, True, 9),
+    (9, 9, 40, 33, False, 4), (12, 12, 72, 70, False, 3),
+])
+def test_hirsch_on_small_and_odd_lattices(nx, ny, na, nb, charge, nw):
+    """Discrete Hirsch fields on a 2 x 2 plaquette, a chain, odd site counts, unequal spins (either side of the 32 / 45 /
+    68 electron limits of its kernels), spin and charge decomposition, a few walkers."""
+    from tests.test_gpu_fullsize import run_hirsch_lattice
+    run_hirsch_lattice(nx, ny, na, nb, charge, nw)
+
+
+@pytest.mark.parametrize("rs,nup,ndown,ecut,nw", [
+    (1.0, 1, 1, 1.0, 5), (3.0, 7, 7, 2.0, 65), (2.0, 19, 19, 3.0, 64), (2.0, 7, 1, 2.5, 66), (0.5, 2, 2, 6.0, 33),
+    (2.0, 7, 7, 1.0, 256),
+])
+def test_ueg_on_other_densities_and_cutoffs(rs, nup, ndown, ecut, nw):
+    """Electron gas away from BASELINE configs[1]: one electron per spin, a spin-polarised gas, 19 + 19 electrons (more
+    columns than the fused plane-wave propagator takes), 179 plane waves (more rows than it takes), a 19-plane-wave basis."""
+    import numpy
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.propagation import setup
+    from tests.test_gpu_fullsize import run_fullsize
+    s = systems.UEG(rs, nup, ndown, ecut)
+    t = trial_mod.hartree_fock_ueg(s)
+    dt = 0.005
+    BH1, mf = setup.ueg_propagator_arrays(s, t, dt)
+    H1diag = numpy.array([numpy.diag(s.H1[0]), numpy.diag(s.H1[1])])
+    model = ref.RefModel('ueg', s.nbasis, nup, ndown, t.psi, BH1, mf, dt, iA=s.iA, iB=s.iB, H1diag=H1diag,
+                         vqvec=s.vqvec, vol=s.vol, ikpq_i=s.ikpq_i, ikpq_kpq=s.ikpq_kpq, ipmq_i=s.ipmq_i,
+                         ipmq_pmq=s.ipmq_pmq, ecore=s.ecore)
+    run_fullsize(model, nw, sorted({0, 2, nw // 2, nw - 1}))
 
 
 @pytest.mark.parametrize("K,nw", [(1, 1), (255, 33), (256, 65), (257, 31), (513, 64), (2, 129)])
