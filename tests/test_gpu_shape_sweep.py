@@ -58,6 +58,65 @@ def test_hirsch_on_small_and_odd_lattices(nx, ny, na, nb, charge, nw):
     run_hirsch_lattice(nx, ny, na, nb, charge, nw)
 
 
+@pytest.mark.parametrize("M,K,na,nb,ndet,nw", [
+    (24, 10, 5, 4, 2, 9), (100, 30, 25, 25, 7, 64), (64, 12, 40, 37, 3, 20), (130, 8, 20, 19, 2, 33), (37, 9, 7, 6, 16, 65),
+    (16, 4, 3, 0, 2, 5), (48, 6, 33, 33, 2, 8),
+])
+def test_distinct_complex_determinants_on_boundary_shapes(M, K, na, nb, ndet, nw):
+    """NOMSD trials of 2..16 distinct complex determinants (walkers/multi_det.py:27-77, propagation/generic.py:154-157,
+    estimators/mixed.py:439-448) on the dispatch boundaries of the single-determinant kernels they reuse: determinant
+    weights, total overlap, weighted force bias and energy per walker against the oracle, both exchange algorithms."""
+    import numpy
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import _lib as L
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.device import AfqDevice
+    from pauxy_amd.propagation import setup
+    from tests.test_gpu_traj import close
+    dt = 0.005
+    s = systems.synthetic_generic(M, K, (na, nb), seed=7)
+    t0 = trial_mod.rhf_trial_generic(s)
+    rng = numpy.random.RandomState(3)
+    nt = na + nb
+    dets = numpy.array([t0.psi + (0.0 if d == 0 else 0.05) * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for d in range(ndet)])
+    coeffs = (rng.rand(ndet) + 0.2) * numpy.exp(1j * rng.rand(ndet))
+    t = trial_mod.MultiDetTrial(s, (coeffs, dets), init=t0.psi)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    phis = t0.psi[None] + 0.05 * (rng.rand(nw, M, nt) + 1j * rng.rand(nw, M, nt))
+    per = M * nt
+    E = {}
+    for mode in (1, 2):
+        dev = AfqDevice(0)
+        dev.set_exchange_algorithm(mode)
+        dev.set_system_generic(s.hs_pot, t._rchol[:per], s.H1.astype(complex), s.ecore, na, nb)
+        dev.set_trial_multi(dets, coeffs, t._rchol)
+        dev.set_propagator(BH1, mf, dt)
+        dev.walkers_alloc(nw)
+        dev.set(L.F_PHI, phis)
+        tot = dev.greens()
+        wts = dev.det_weights()
+        xbar = dev.force_bias()
+        dev.greens()
+        E[mode] = dev.local_energy()
+        dev.close()
+    close(E[1], E[2], 1e-11)
+    H1 = s.H1.astype(complex)
+    for w in sorted({0, nw // 2, nw - 1}):
+        ws, Es, Gsum = [], [], 0.0
+        for d in range(ndet):
+            ov, gh, G = ref.greens_function(phis[w], dets[d], na, nb)
+            ws.append(numpy.conj(coeffs[d]) * ov)
+            Es.append(numpy.array(ref.local_energy_generic_cholesky_opt(H1, s.ecore, G, gh, t._rchol[d * per:(d + 1) * per],
+                                                                        na, nb)))
+            Gsum = Gsum + ws[-1] * (G[0] + G[1])
+        ws = numpy.array(ws)
+        close(wts[w], ws, 1e-10)
+        close(tot[w], ws.sum(), 1e-10)
+        close(E[2][w], (ws[:, None] * numpy.array(Es)).sum(0) / ws.sum(), 1e-10)
+        vbias = s.hs_pot.T.dot((Gsum / ws.sum()).ravel())
+        close(xbar[w], -dt ** 0.5 * (1j * vbias - mf), 1e-10)
+
+
 @pytest.mark.parametrize("rs,nup,ndown,ecut,nw", [
     (1.0, 1, 1, 1.0, 5), (3.0, 7, 7, 2.0, 65), (2.0, 19, 19, 3.0, 64), (2.0, 7, 1, 2.5, 66), (0.5, 2, 2, 6.0, 33),
     (2.0, 7, 7, 1.0, 256),
