@@ -115,6 +115,29 @@ def test_distinct_complex_determinants_on_boundary_shapes(M, K, na, nb, ndet, nw
         close(E[2][w], (ws[:, None] * numpy.array(Es)).sum(0) / ws.sum(), 1e-10)
         vbias = s.hs_pot.T.dot((Gsum / ws.sum()).ravel())
         close(xbar[w], -dt ** 0.5 * (1j * vbias - mf), 1e-10)
+    # one full step (hybrid weights, phaseless constraint, some walkers dead) against the oracle's multi-determinant walker
+    from tests.helpers import make_device
+    model = ref.RefModel('generic_msd', M, na, nb, dets, BH1, mf, dt, coeffs=coeffs, hs_pot=s.hs_pot,
+                         H1=numpy.array([s.H1[0], s.H1[1]]).astype(complex), ecore=s.ecore)
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    w0 = numpy.ones(nw)
+    w0[1::4] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, tot)
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, -0.7)
+    out_phi, out_w, out_ot = dev.get(L.F_PHI), dev.get(L.F_WEIGHT), dev.get(L.F_OT)
+    dev.close()
+    for w in sorted({0, 1, nw // 2, nw - 1}):
+        if w0[w] == 0.0:
+            assert numpy.array_equal(out_phi[w], phis[w]) and out_w[w] == 0.0
+            continue
+        wk = ref.new_walker(model, phis[w])
+        ref.propagate_walker_phaseless(model, wk, xi[w], -0.7)
+        close(out_phi[w], wk['phi'], 1e-9)
+        close(out_w[w], wk['weight'], 1e-9)
+        close(out_ot[w], wk['ot'], 1e-9)
 
 
 @pytest.mark.parametrize("rs,nup,ndown,ecut,nw", [
