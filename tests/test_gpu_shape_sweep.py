@@ -140,6 +140,66 @@ def test_distinct_complex_determinants_on_boundary_shapes(M, K, na, nb, ndet, nw
         close(out_ot[w], wk['ot'], 1e-9)
 
 
+@pytest.mark.parametrize("variant", ["local_energy", "free_projection", "order4", "order9", "no_force_bias"])
+@pytest.mark.parametrize("M,K,na,nb,nw,cplx", [
+    (100, 30, 25, 25, 64, False), (64, 20, 40, 37, 20, True), (130, 16, 20, 20, 33, False), (37, 9, 7, 6, 65, True),
+    (20, 8, 3, 0, 9, False),
+])
+def test_propagator_options_on_boundary_shapes(M, K, na, nb, nw, cplx, variant):
+    """The other propagator options (continuous.py:30-33,82-111,175-200,264-300) on shapes of every dispatch path: local-energy
+    weights, free projection, Taylor orders 4 and 9, no force bias -- one step against the oracle."""
+    import numpy
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import _lib as L
+    from tests.helpers import make_device
+    from tests.test_gpu_sizes import build
+    from tests.test_gpu_traj import close
+    model, rng = build(M, K, na, nb, cplx)
+    kw = {}
+    if variant == "local_energy":
+        kw['hybrid'] = False
+    elif variant == "free_projection":
+        kw['free_projection'] = True
+        kw['force_bias'] = False
+    elif variant == "no_force_bias":
+        kw['force_bias'] = False
+    elif variant.startswith("order"):
+        model.exp_order = int(variant[5:])
+    dev = make_device(model, nw, **kw)
+    phis = numpy.array([model.psi + 0.1 * (rng.rand(M, na + nb) + 1j * rng.rand(M, na + nb)) for _ in range(nw)])
+    dev.set(L.F_PHI, phis)
+    w0 = numpy.ones(nw)
+    w0[2::5] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, dev.calc_overlap())
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, -1.1)
+    out = {f: dev.get(getattr(L, 'F_' + f)) for f in ('PHI', 'WEIGHT', 'OT', 'PHASE', 'HYBRID_ENERGY')}
+    dev.close()
+    for w in sorted({0, 1, 2, nw // 2, nw - 1}):
+        if w0[w] == 0.0:
+            assert numpy.array_equal(out['PHI'][w], phis[w]) and out['WEIGHT'][w] == 0.0
+            continue
+        wk = ref.new_walker(model, phis[w])
+        if variant == "free_projection":
+            ref.propagate_walker_free(model, wk, xi[w], -1.1)
+        elif variant == "no_force_bias":
+            fb = model.force_bias
+            model.force_bias = lambda Ghalf, G: numpy.zeros(K, dtype=complex)
+            try:
+                ref.propagate_walker_phaseless(model, wk, xi[w], -1.1)
+            finally:
+                model.force_bias = fb
+        else:
+            ref.propagate_walker_phaseless(model, wk, xi[w], -1.1, hybrid=(variant != "local_energy"))
+        close(out['PHI'][w], wk['phi'], 1e-9)
+        close(out['WEIGHT'][w], wk['weight'], 1e-9)
+        close(out['OT'][w], wk['ot'], 1e-9)
+        close(out['PHASE'][w], wk['phase'], 1e-9)
+        if variant not in ("free_projection", "local_energy"):
+            close(out['HYBRID_ENERGY'][w], wk['hybrid_energy'], 1e-9)
+
+
 @pytest.mark.parametrize("rs,nup,ndown,ecut,nw", [
     (1.0, 1, 1, 1.0, 5), (3.0, 7, 7, 2.0, 65), (2.0, 19, 19, 3.0, 64), (2.0, 7, 1, 2.5, 66), (0.5, 2, 2, 6.0, 33),
     (2.0, 7, 7, 1.0, 256),
