@@ -230,6 +230,42 @@ def test_field_counts_and_populations_on_kernel_boundaries(K, nw):
     run_shape(20, K, 4, 3, nw, K % 2 == 1)
 
 
+@pytest.mark.parametrize("nw", [2, 3, 63, 64, 65, 257, 1000, 4096])
+@pytest.mark.parametrize("spread", [0.3, 2.0, "zeros"])
+def test_comb_on_random_populations(nw, spread):
+    """walkers/handler.py:225-338 on one rank for populations from 2 to 4096 walkers and weight distributions from narrow to
+    very wide (a third of the walkers dead): parent_ix exact against the oracle's comb, the (clone, kill) pairs applied the
+    reference's way (handler.py:295-301: ``zip`` truncates), every weight 1 afterwards, total weight returned."""
+    import numpy
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import _lib as L
+    from tests.helpers import make_device
+    from tests.test_gpu_sizes import build
+    M, K, na, nb = 8, 3, 2, 2
+    model, rng = build(M, K, na, nb, False)
+    rs = numpy.random.RandomState(nw)
+    dev = make_device(model, nw)
+    phis = model.psi[None] + 0.1 * (rs.rand(nw, M, na + nb) + 1j * rs.rand(nw, M, na + nb))
+    wts = numpy.exp((0.8 if spread == "zeros" else spread) * rs.normal(size=nw))
+    if spread == "zeros":
+        wts[rs.rand(nw) < 0.33] = 0.0
+        wts[0] = max(wts[0], 0.5)
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, wts)
+    r = float(rs.rand())
+    pix, tw = dev.popcontrol_comb(r, nw)
+    scale = sum(wts) / nw
+    want = ref.comb_parent_ix(wts / scale, nw, r)
+    assert numpy.array_equal(pix, want)
+    assert abs(tw - sum(wts)) <= 1e-12 * sum(wts)
+    expect = phis.copy()
+    for c, k in ref.comb_pairs(want):
+        expect[k] = phis[c]
+    assert numpy.array_equal(dev.get(L.F_PHI), expect)
+    assert numpy.all(dev.get(L.F_WEIGHT) == 1.0)
+    dev.close()
+
+
 def _generic_40():
     from pauxy_amd import systems, trial as trial_mod
     from tests.test_gpu_batched import build_afqmc
