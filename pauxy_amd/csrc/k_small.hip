@@ -1404,6 +1404,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
                 accI = mfma16(x.y, y.y, accI);
                 acc3 = mfma16(x.x - x.y, y.x + y.y, acc3);
             }
+            RF_STAMP(9 + pass);
             if (nfull < nks) {
                 const int p = nfull * 4 + lk, pc = p < M ? p : M - 1;
                 cplx x = phi_l[pc * nt + off + iac], y = phi_l[pc * nt + off + jbc];
@@ -1423,6 +1424,7 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
                 if (i < n && j < n) S[i * RF_LD + j] = cmake(accR[r], accI[r]);
             }
         }
+        RF_STAMP(11 + pass);
         __syncthreads();
         RF_STAMP(2 + 3 * pass);
         // ---- inverse Cholesky factor: T^T[r][c] = conj(Ltilde^-1[r][c]) / sqrt(D_r) (see chol_small_kernel)
@@ -1529,14 +1531,17 @@ static int k_reortho_fused(afq_handle *h, size_t lds, cplx *keep) {
     static unsigned long long *rfts = nullptr;
     static int rf_launch = 0;
     if (afq_knob("AFQ_RF_TS")) {
-        if (!rfts) { hipMalloc(&rfts, 9 * 8); hipMemset(rfts, 0, 9 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_rf_ts), &rfts, sizeof(rfts)); }
+        if (!rfts) { hipMalloc(&rfts, 13 * 8); hipMemset(rfts, 0, 13 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_rf_ts), &rfts, sizeof(rfts)); }
         if (++rf_launch == 20) {
-            unsigned long long t[9];
+            unsigned long long t[13];
             hipStreamSynchronize(h->stream);
             hipMemcpy(t, rfts, sizeof(t), hipMemcpyDeviceToHost);
             fprintf(stderr, "RF_TS ticks: load %lld | pass 0: gram %lld chol %lld q %lld | pass 1: gram %lld chol %lld q %lld | store %lld\n",
                     (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]),
                     (long long)(t[5] - t[4]), (long long)(t[6] - t[5]), (long long)(t[7] - t[6]), (long long)(t[8] - t[7]));
+            fprintf(stderr, "RF_TS gram detail: pass 0 k-loop %lld, to own end %lld, barrier %lld | pass 1 k-loop %lld, to own end %lld, barrier %lld\n",
+                    (long long)(t[9] - t[1]), (long long)(t[11] - t[9]), (long long)(t[2] - t[11]),
+                    (long long)(t[10] - t[4]), (long long)(t[12] - t[10]), (long long)(t[5] - t[12]));
         }
     }
 #endif
