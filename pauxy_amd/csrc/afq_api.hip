@@ -311,7 +311,7 @@ static int upload_rchol(afq_handle *h, const double *rchol, bool real) {
 
 int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const double *hs_pot,
                            const double *rchol, const double *H1, double ecore) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !hs_pot || !rchol || !H1) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_GENERIC, M, K, na, nb);
     if (rc) return rc;
@@ -357,7 +357,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
 }
 
 int afq_set_system_hubbard(afq_handle *h, int M, int na, int nb, double U, const double *T) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !T) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_HUBBARD, M, M, na, nb);
     if (rc) return rc;
@@ -393,7 +393,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
                        const int64_t *kpq_i, const int64_t *kpq_kpq, const int64_t *pmq_off,
                        const int64_t *pmq_i, const int64_t *pmq_pmq, const double *vqvec, double vol,
                        const double *H1diag, double ecore) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !iA_colptr || !iB_colptr || !kpq_off || !pmq_off || !vqvec || !H1diag) return AFQ_EINVAL;
     int rc = set_dims(h, AFQ_SYS_UEG, M, 2 * nq, na, nb);
     if (rc) return rc;
@@ -465,7 +465,7 @@ int afq_set_system_ueg(afq_handle *h, int M, int nq, int na, int nb, const int64
 }
 
 int afq_set_trial(afq_handle *h, const double *psi) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !psi) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the trial");
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_ESTATE, "a multi-determinant trial is set; set the system again first");
@@ -478,7 +478,7 @@ int afq_set_trial(afq_handle *h, const double *psi) {
 }
 
 int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double *coeffs, const double *rchol) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !psi || !coeffs || !rchol || ndet < 1) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_GENERIC) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "multi-determinant trials need a generic system");
     if (h->nw) AFQ_FAIL(h, AFQ_ESTATE, "set the trial before allocating walkers");
@@ -515,7 +515,7 @@ int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double
 
 int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift, double dt, int exp_order,
                        int flags) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !BH1 || !mf_shift || dt <= 0 || exp_order < 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before the propagator");
     hipSetDevice(h->device);
@@ -543,7 +543,7 @@ int afq_set_propagator(afq_handle *h, const double *BH1, const double *mf_shift,
 
 // ------------------------------------------------------------------ walkers
 int afq_walkers_alloc(afq_handle *h, int nw) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || nw <= 0) return AFQ_EINVAL;
     if (!h->kind) AFQ_FAIL(h, AFQ_ESTATE, "set the system before allocating walkers");
     hipSetDevice(h->device);
@@ -718,7 +718,7 @@ static int copy_out(afq_handle *h, void *host, const void *dev, size_t bytes) {
 
 int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
     AFQ_API(h, "afq_greens");
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -734,7 +734,7 @@ int afq_greens(afq_handle *h, int want_G, double *ovlp_out) {
 }
 
 int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !oinv_out) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -757,7 +757,7 @@ int afq_inverse_overlap(afq_handle *h, double *oinv_out, double *ovlp_out) {
 
 int afq_calc_overlap(afq_handle *h, double *ovlp_out) {
     AFQ_API(h, "afq_calc_overlap");
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1130,7 +1130,7 @@ int afq_vhs(afq_handle *h, const double *xs, double *vhs_out) {
 }
 
 int afq_apply_exponential(afq_handle *h, const double *vhs) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !vhs) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -1152,7 +1152,7 @@ int afq_apply_exponential(afq_handle *h, const double *vhs) {
 }
 
 int afq_kinetic(afq_handle *h) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;
@@ -1271,7 +1271,7 @@ int afq_walker_pack(afq_handle *h, int iw, void *dev_buf) {
 }
 
 int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !dev_buf) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1280,7 +1280,7 @@ int afq_walker_unpack(afq_handle *h, int iw, const void *dev_buf) {
 }
 
 int afq_walkers_copy(afq_handle *h, int src, int dst) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = need_ready(h, false);
     if (rc) return rc;
@@ -1530,7 +1530,7 @@ static int hirsch_ready(afq_handle *h) {
 }
 
 int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int charge_decomposition) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !bt2 || dt <= 0) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_HUBBARD) AFQ_FAIL(h, AFQ_ESTATE, "the Hirsch transformation needs a Hubbard system");
     if (h->ndet > 1) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "Hirsch propagator: single-determinant trials");
@@ -1578,7 +1578,7 @@ int afq_set_propagator_hirsch(afq_handle *h, const double *bt2, double dt, int c
 }
 
 int afq_hirsch_kinetic(afq_handle *h) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1587,7 +1587,7 @@ int afq_hirsch_kinetic(afq_handle *h) {
 }
 
 int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int32_t *used_out) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !u) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1600,7 +1600,7 @@ int afq_hirsch_two_body(afq_handle *h, const double *u, int32_t *fields_out, int
 }
 
 int afq_hirsch_finish(afq_handle *h, double eshift) {
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1612,7 +1612,7 @@ int afq_hirsch_finish(afq_handle *h, double eshift) {
 
 int afq_propagate_hirsch(afq_handle *h, double eshift) {
     AFQ_API(h, "afq_propagate_hirsch");
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1646,7 +1646,7 @@ int afq_hirsch_free_projection(afq_handle *h, int on) {
 
 int afq_propagate_hirsch_free(afq_handle *h, const double *u, int32_t *fields_out, double eshift) {
     AFQ_API(h, "afq_propagate_hirsch_free");
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h) return AFQ_EINVAL;
     int rc = hirsch_ready(h);
     if (rc) return rc;
@@ -1703,7 +1703,7 @@ int afq_bp_steps(afq_handle *h, int32_t *steps_out) {
 int afq_bp_update(afq_handle *h, const double *phi_bp0, int nstblz, int restore_weights, int eval_energy,
                   int reset, double *est_out) {
     AFQ_API(h, "afq_bp_update");
-    if (h) h->greens_valid = false; h->gsum_only = false;
+    if (h) { h->greens_valid = false; h->gsum_only = false; }
     if (!h || !phi_bp0 || !est_out || nstblz < 1 || restore_weights < 0 || restore_weights > 2) return AFQ_EINVAL;
     int rc = need_ready(h, true);
     if (rc) return rc;

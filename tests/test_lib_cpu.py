@@ -41,3 +41,40 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_every_entry_point_refuses_a_null_handle():
+    """Every function of the C-ABI that takes the handle first returns AFQ_EINVAL for a null handle (no dereference, no
+    HIP call): run in a child process so that a crash would be a failure, not the end of the test session."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from pauxy_amd import _lib
+lib = _lib.load()
+n = 0
+for name, args in _lib.SIGNATURES.items():
+    if not args or args[0] is not _lib._h:
+        continue
+    call = []
+    for a in args:
+        if a in (ctypes.c_int, ctypes.c_int64, ctypes.c_uint64):
+            call.append(0)
+        elif a is ctypes.c_double:
+            call.append(0.0)
+        elif hasattr(a, '_flags_') and hasattr(a, '_restype_'):
+            call.append(a())
+        else:
+            call.append(None)
+    r = getattr(lib, name)(*call)
+    if name == "afq_last_error":
+        assert r == b"null handle", r
+    else:
+        assert r == -1, (name, r)
+    n += 1
+print("checked", n)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.split()[-1]) >= 80
