@@ -1448,49 +1448,65 @@ __global__ __launch_bounds__(512) void reortho_fused_kernel(RfArgs a) {
             if (tid == 0) a.fail[w] = 1;
             return;
         }
-        // ---- Q = phi T in place: a wave takes whole 16-row tiles (all their columns), the row fragments in registers
-        for (int ti = wave; ti < mt16 && n > 0; ti += 4) {
-            const int pa = ti * 16 + lr, pac = pa < M ? pa : M - 1;
-            cplx xf[8];
+        // ---- Q = phi T in place: a wave takes whole 16-row tiles (all their columns), the row fragments in registers.
+        // The fragments of T are the same for every row tile: read once per pass, all loads unconditional on clamped
+        // indices (a clamped entry meets a zero of the row fragment or a column that is not stored), trip counts from RJ --
+        // no branch between an LDS read and the MFMAs that wait for it.  T is upper triangular: the column tile j < 16
+        // contracts k < 16 only.
+        if (n > 0) {
+            constexpr int KSN = (2 * RJ + 3) / 4 > 8 ? 8 : (2 * RJ + 3) / 4, TJN = 2 * RJ > 16 ? 2 : 1;
+            cplx yf[TJN][KSN];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int k = ks * 4 + lk, kc = k < n ? k : n - 1;
-                const cplx x = phi_l[pac * nt + off + kc];
-                xf[ks] = (ks < nks3 && k < n && pa < M) ? x : cmake(0.0, 0.0);
-            }
-            d4_t p1[2], p2[2], p3[2];
+            for (int tj = 0; tj < TJN; ++tj)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                p1[tj] = (d4_t){0, 0, 0, 0}; p2[tj] = (d4_t){0, 0, 0, 0}; p3[tj] = (d4_t){0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks < nks3) {
+                for (int ks = 0; ks < KSN; ++ks) {
                     const int k = ks * 4 + lk, kc = k < n ? k : n - 1;
+                    const int jq = tj * 16 + lr, jc = jq < n ? jq : n - 1;
+                    yf[tj][ks] = S[jc * RF_LD + kc];         // T[k][j] = T^T[j][k]
+                }
+            auto load_x = [&](cplx (&xf)[KSN], const int ti) __attribute__((always_inline)) {
+                const int pa = ti * 16 + lr, pac = pa < M ? pa : M - 1;
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) {
+                    const int k = ks * 4 + lk, kc = k < n ? k : n - 1;
+                    const cplx x = phi_l[pac * nt + off + kc];
+                    xf[ks] = (k < n && pa < M) ? x : cmake(0.0, 0.0);
+                }
+            };
+            auto mul_store = [&](const cplx (&xf)[KSN], const int ti) __attribute__((always_inline)) {
+                d4_t p1[TJN], p2[TJN], p3[TJN];
+#pragma unroll
+                for (int tj = 0; tj < TJN; ++tj) {
+                    p1[tj] = (d4_t){0, 0, 0, 0}; p2[tj] = (d4_t){0, 0, 0, 0}; p3[tj] = (d4_t){0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) {
                     const cplx x = xf[ks];
                     const double xs = x.x + x.y;
 #pragma unroll
-                    for (int tj = 0; tj < 2; ++tj) {
-                        if (tj < nt16) {
-                            const int j = tj * 16 + lr, jc = j < n ? j : n - 1;
-                            const cplx y = S[jc * RF_LD + kc];  // T[k][j] = T^T[j][k]; (xf is zero past n, columns past n are not stored)
-                            p1[tj] = mfma16(x.x, y.x, p1[tj]);
-                            p2[tj] = mfma16(x.y, y.y, p2[tj]);
-                            p3[tj] = mfma16(xs, y.x + y.y, p3[tj]);
-                        }
+                    for (int tj = 0; tj < TJN; ++tj) {
+                        if (tj == 0 && TJN == 2 && ks >= 4) continue;      // (compile time) T[k][j] = 0 for k >= 16 > j
+                        const cplx y = yf[tj][ks];
+                        p1[tj] = mfma16(x.x, y.x, p1[tj]);
+                        p2[tj] = mfma16(x.y, y.y, p2[tj]);
+                        p3[tj] = mfma16(xs, y.x + y.y, p3[tj]);
                     }
                 }
-            }
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-                if (tj < nt16) {
+                for (int tj = 0; tj < TJN; ++tj) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int p = ti * 16 + lk + 4 * r, j = tj * 16 + lr;
-                        if (p < M && j < n)
-                            phi_l[p * nt + off + j] = cmake(p1[tj][r] - p2[tj][r], p3[tj][r] - p1[tj][r] - p2[tj][r]);
+                        const int p = ti * 16 + lk + 4 * r, jq = tj * 16 + lr;
+                        if (p < M && jq < n)
+                            phi_l[p * nt + off + jq] = cmake(p1[tj][r] - p2[tj][r], p3[tj][r] - p1[tj][r] - p2[tj][r]);
                     }
                 }
+            };
+            for (int ti = wave; ti < mt16; ti += 4) {
+                cplx xa[KSN];
+                load_x(xa, ti);
+                mul_store(xa, ti);
+            }
         }
         __syncthreads();
         RF_STAMP(4 + 3 * pass);
