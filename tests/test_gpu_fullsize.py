@@ -127,6 +127,61 @@ def test_c3_generic_256_walkers():
     run_fullsize(generic_c3(256), 256, [0, 100, 255])
 
 
+def position_independence(model, n0, rep, tol=1e-11):
+    """rep copies of n0 distinct walkers with the same fields: Green's function, force bias, one full step (hybrid weights,
+    some walkers dead), energies and the re-orthogonalisation bit-equal between the copies, and the first copy equal to an
+    n0-walker run of the same walkers to rounding (contractions are split differently for the two populations)."""
+    rng = numpy.random.RandomState(21)
+    M, nt, K = model.M, model.na + model.nb, model.nfields
+    phis0 = model.psi[None] + 0.05 * (rng.rand(n0, M, nt) + 1j * rng.rand(n0, M, nt))
+    xi0 = rng.normal(size=(n0, K))
+    w0 = numpy.ones(n0)
+    w0[3::7] = 0.0
+    out = {}
+    for nw in (n0 * rep, n0):
+        r = nw // n0
+        dev = make_device(model, nw)
+        dev.set(L.F_PHI, numpy.tile(phis0, (r, 1, 1)))
+        det = dev.greens(want_G=(model.kind == 'ueg'))
+        xbar = dev.force_bias()
+        dev.set(L.F_WEIGHT, numpy.tile(w0, r))
+        dev.set(L.F_OT, det)
+        dev.propagate(numpy.tile(xi0, (r, 1)), -0.3)
+        if model.kind == 'ueg':
+            dev.greens(want_G=True)
+        E = dev.local_energy()
+        res = dict(det=det, xbar=xbar, phi=dev.get(L.F_PHI), weight=dev.get(L.F_WEIGHT), ot=dev.get(L.F_OT),
+                   ehyb=dev.get(L.F_HYBRID_ENERGY), E=E)
+        res['detR'] = dev.reortho()
+        res['q'] = dev.get(L.F_PHI)
+        dev.close()
+        out[nw] = res
+    big, small = out[n0 * rep], out[n0]
+    for key, v in big.items():
+        v = numpy.asarray(v)
+        assert numpy.all(numpy.isfinite(v.view(float))), key
+        for c in range(1, rep):
+            assert numpy.array_equal(v[c * n0:(c + 1) * n0], v[:n0]), (key, c)
+        close(v[:n0], small[key], tol)
+
+
+def test_c3_large_population_is_position_independent():
+    """2048 walkers at the BASELINE configs[2] size (the single-GPU leg of the strong-scaling bench) made of 8 copies of 256
+    distinct walkers: what a walker gets must not depend on where in the population it sits."""
+    position_independence(generic_c3(256), 256, 8)
+
+
+@pytest.mark.parametrize("which", ["C2-ueg", "C4-hubbard16x16", "C5-single-determinant"])
+def test_other_configs_are_position_independent(which):
+    """The same for the other BASELINE sizes: 1024 walkers of the electron gas, 512 of the 16 x 16 lattice, 256 at M = 400."""
+    if which == "C2-ueg":
+        position_independence(ueg_c2(), 256, 4)
+    elif which == "C4-hubbard16x16":
+        position_independence(hubbard_c4(), 256, 2, 1e-10)
+    else:
+        position_independence(generic_c5(), 128, 2, 1e-10)
+
+
 def test_c3_exchange_algorithms_agree():
     """BASELINE configs[2] size, 256 walkers: quadratic-form exchange energy (the default there, K = 5 M) against the
     T-intermediate kernel for every walker, and a sample against the oracle."""
