@@ -350,7 +350,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         'qmc': {'timestep': DT, 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
                 'pop_control_freq': NPOP, 'num_walkers': nw * world, 'rng_seed': 7},
         'propagator': {'device_rng': not args.host_rng, 'rng_seed': 7, 'rng_stream': rank},
-        'estimators': {'mixed': {'verbose': False}},
+        'estimators': {'mixed': {'verbose': False}, 'write_file': False},      # in-memory block rows only
     }
     if os.environ.get("AFQ_BENCH_DEVICE_COMM"):
         # 'rccl' | 'sendrecv' | 'ipc' | '0': pin one communicator ('ipc' also works with every rank on one GPU over gloo)

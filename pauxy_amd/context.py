@@ -6,12 +6,46 @@ Here all three must talk to ONE library handle on one GPU; this module hands
 that shared handle out, keyed by the identity of the system and trial objects.
 """
 import os
+import weakref
 
 import numpy
 
 from pauxy_amd.device import AfqDevice
 
 _contexts = {}
+
+
+class hidden(object):
+    """Data descriptor that keeps a member OUT of the instance ``__dict__``.
+
+    The genuine driver describes itself at the end of ``AFQMC.__init__`` (qmc/afqmc.py:193 -> utils/io.py:44-48 ->
+    utils/misc.py:72-135 ``serialise``): it walks ``__dict__`` of every attribute that has one, without a cycle guard,
+    and dumps the result as JSON.  The plug-in objects therefore keep in their ``__dict__`` only what the reference's
+    own classes keep there (numbers, strings, arrays, option flags); handles to the device, the shared context, the
+    communicator and back references (walker -> population) are class-level ``hidden()`` members, stored per
+    instance in a WeakKeyDictionary.  Values must not refer back to their owner (an entry whose value keeps its key
+    alive is never collected)."""
+
+    def __init__(self):
+        self._store = weakref.WeakKeyDictionary()
+        self._name = '?'
+
+    def __set_name__(self, owner, name):
+        self._name = name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        try:
+            return self._store[obj]
+        except KeyError:
+            raise AttributeError(self._name)
+
+    def __set__(self, obj, value):
+        self._store[obj] = value
+
+    def __delete__(self, obj):
+        self._store.pop(obj, None)
 
 
 def local_device_id():
@@ -88,3 +122,27 @@ def release_context(system, trial):
     ctx = _contexts.pop((id(system), id(trial)), None)
     if ctx is not None:
         ctx.close()
+    ent = _scratch.pop(id(system), None)
+    if ent is not None:
+        ent[1].close()
+
+
+_scratch = {}
+
+
+def scratch_device(system):
+    """One-walker handle holding ``system`` for the reference's free functions that name no walker
+    (``pauxy.estimators.mixed.local_energy(system, G, Ghalf)``, mixed.py:383-437): a second handle with the same
+    uploads as the context the propagator / walkers / estimators of ``system`` share, so that evaluating an energy
+    for a bare Green's function never touches the population's arrays or the library's caches of them."""
+    ent = _scratch.get(id(system))
+    if ent is not None and ent[0] is system:
+        return ent[1].dev
+    for ctx in list(_contexts.values()):
+        if ctx.system is system:
+            scratch = Context(system, ctx.trial, ctx.dev.device_id)
+            scratch.dev.walkers_alloc(1)
+            _scratch[id(system)] = (system, scratch)
+            return scratch.dev
+    raise ValueError("local_energy(system, ...): no device context holds this system yet -- build the propagator or "
+                     "the walkers first (they upload it), or pass device=")

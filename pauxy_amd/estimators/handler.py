@@ -3,10 +3,10 @@
 ``print_step``.  The ITCF estimator is not on the device path.
 
 Output file (handler.py:60-71,117-124): ``<basename>.<index>.h5`` (or ``filename``),
-created empty by the root rank, ``metadata`` = JSON description of the run.  One
-deviation: with neither ``filename`` nor ``basename`` in the options no file is
-written (the reference always writes ``estimates.0.h5``); the per-block rows are
-kept in memory either way (``Mixed.blocks``)."""
+created empty by the root rank, ``metadata`` = JSON description of the run; as in
+the reference the default is ``estimates.<index>.h5`` in the working directory.
+Opting out: ``estimators: {write_file: False}`` (or ``AFQ_ESTIMATES_FILE=0`` in the
+environment, for harnesses that only want the in-memory rows ``Mixed.blocks``)."""
 import os
 
 from pauxy_amd.estimators.back_propagation import BackPropagation
@@ -28,10 +28,11 @@ class Estimators(object):
     def __init__(self, estimates, root, qmc, system, trial, BT2, verbose=False):
         opts = estimates
         self.index = opts.get('index', 0)
-        self.basename = opts.get('basename')
+        self.basename = opts.get('basename', 'estimates')                    # handler.py:62
         self.flush_every = opts.get('flush_every')
-        name = opts.get('filename') if root else None
-        if root and name is None and self.basename is not None:
+        write = opts.get('write_file', os.environ.get('AFQ_ESTIMATES_FILE', '1') != '0')
+        name = opts.get('filename') if (root and write) else None
+        if root and write and name is None:
             # first free slot of the series unless overwriting is allowed (handler.py:63-69)
             keep_existing = not opts.get('overwrite', True)
             name = _series_file(self.basename, self.index)
@@ -39,8 +40,6 @@ class Estimators(object):
                 self.index += 1
                 name = _series_file(self.basename, self.index)
         self.filename = name
-        if self.basename is None:
-            self.basename = 'estimates'
         if name is not None:
             _touch(name)
         self.estimators = {}

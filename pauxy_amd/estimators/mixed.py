@@ -49,6 +49,20 @@ class Mixed(object):
         self.estimates[self.names.time] = time.time()
         self.global_estimates = numpy.zeros(self.nreg, dtype=dtype)
         self.eshift = numpy.array([0, 0])
+        self.key = {                                                    # mixed.py:113-126
+            'Iteration': "Simulation iteration. iteration*dt = tau.",
+            'WeightFactor': "Rescaling Factor from population control.",
+            'Weight': "Total walker weight.",
+            'E_num': "Numerator for projected energy estimator.",
+            'E_denom': "Denominator for projected energy estimator.",
+            'ETotal': "Projected energy estimator.",
+            'E1Body': "Mixed one-body energy estimator.",
+            'E2Body': "Mixed two-body energy estimator.",
+            'EHybrid': "Hybrid energy.",
+            'Overlap': "Walker average overlap.",
+            'Nav': "Average number of electrons.",
+            'Time': "Time per processor to complete one iteration.",
+        }
         self.blocks = []
         self.root = root
         self.flush_every = mixed.get('flush_every', None)
@@ -146,7 +160,12 @@ class Mixed(object):
         self.estimates[self.names.time] = time.time()
 
     def print_key(self, eol='', encode=False):
-        pass
+        """mixed.py:290-310: what the output columns are (same keys and texts, so logs read alike)."""
+        header = eol + '# Explanation of output column headers:\n' + '# -------------------------------------' + eol
+        print(header.encode('utf-8') if encode else header)
+        for k, v in self.key.items():
+            line = '# %s : %s' % (k, v) + eol
+            print(line.encode('utf-8') if encode else line)
 
     def print_header(self, eol='', encode=False):
         print(" ".join("{:>17s}".format(x) for x in self.header) + eol)
@@ -163,12 +182,15 @@ class Mixed(object):
 def local_energy(system, G, Ghalf=None, two_rdm=None, rchol=None, eri=None, C0=None, ecoul0=None,
                  exxa0=None, exxb0=None, UVT=None, device=None):
     """pauxy.estimators.mixed.local_energy (mixed.py:383-437) for ONE Green's
-    function, evaluated by the device energy kernels.  ``device`` is the
-    AfqDevice that already holds ``system`` (see pauxy_amd.context); ``Ghalf``
-    (half-rotated form) or, without it, the full ``G`` is used for Generic; ``G`` for UEG."""
+    function, evaluated by the device energy kernels: ``Ghalf`` (half-rotated form) or, without it, the
+    full ``G`` is used for Generic; ``G`` for Hubbard and the UEG.  Call-compatible with the reference:
+    the device is the handle ``pauxy_amd.context`` already holds for ``system`` (the one the propagator,
+    walkers and estimators of that system share); ``device=`` names another one.  The evaluation uses a
+    scratch handle when the shared one carries a population (its walkers are not disturbed)."""
     from pauxy_amd import _lib as L
+    from pauxy_amd import context
     if device is None:
-        raise ValueError("local_energy needs the AfqDevice holding the system (device=...)")
+        device = context.scratch_device(system)
     if device.nw < 1:
         device.walkers_alloc(1)
     if device.kind == 'ueg':

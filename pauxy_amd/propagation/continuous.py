@@ -17,15 +17,16 @@ their walker already propagated and return immediately.
 """
 import numpy
 
-from pauxy_amd.context import get_context
+from pauxy_amd.context import get_context, hidden
 from pauxy_amd.propagation import setup
 
 
 class _SystemPropagator(object):
     """The ``Continuous.propagator`` member: constants + per-walker test hooks."""
+    _dev = hidden()         # no back reference to the driver object: the reference's serialise has no cycle guard
 
-    def __init__(self, driver, system, trial, qmc, options):
-        self._driver = driver
+    def __init__(self, dev, system, trial, qmc, options):
+        self._dev = dev
         self.dt = qmc.dt
         self.sqrt_dt = qmc.dt ** 0.5
         self.isqrt_dt = 1j * self.sqrt_dt
@@ -58,7 +59,7 @@ class _SystemPropagator(object):
 
     def construct_VHS(self, system, xshifted):
         """<system>.construct_VHS(system, xshifted) -> [M,M] (or [2,M,M] for spin HS)."""
-        dev = self._driver.dev
+        dev = self._dev
         xs = numpy.zeros((dev.nw, dev.K), dtype=numpy.complex128)
         xs[0] = xshifted
         v = dev.vhs(xs)[0]
@@ -66,6 +67,9 @@ class _SystemPropagator(object):
 
 
 class Continuous(object):
+    ctx = hidden()
+    dev = hidden()
+
     def __init__(self, system, trial, qmc, options={}, verbose=False, device_id=None):
         self.free_projection = options.get('free_projection', False)
         self.hybrid = options.get('hybrid', True)
@@ -81,7 +85,7 @@ class Continuous(object):
         self.isqrt_dt = 1j * self.sqrt_dt
         self.ctx = get_context(system, trial, device_id)
         self.dev = self.ctx.dev
-        self.propagator = _SystemPropagator(self, system, trial, qmc, options)
+        self.propagator = _SystemPropagator(self.dev, system, trial, qmc, options)
         self.dev.set_propagator(self.propagator.BH1, self.propagator.mf_shift, qmc.dt,
                                 exp_order=self.exp_nmax, hybrid=self.hybrid, force_bias=self.force_bias,
                                 free_projection=self.free_projection,

@@ -17,10 +17,13 @@ import numpy
 import scipy.linalg
 
 from pauxy_amd import _lib as L
-from pauxy_amd.context import get_context
+from pauxy_amd.context import get_context, hidden
 
 
 class Hirsch(object):
+    ctx = hidden()
+    dev = hidden()
+
     def __init__(self, system, trial, qmc, options={}, verbose=False, device_id=None):
         if getattr(trial, 'type', '') == 'GHF' or getattr(trial, 'name', '') == 'multi_determinant':
             raise NotImplementedError("device Hirsch propagator: RHF/UHF-type single-determinant trials")

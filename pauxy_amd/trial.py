@@ -78,6 +78,17 @@ class SingleDetTrial(object):
 
     rot_hs_pot = rot_chol
 
+    def calculate_energy(self, system):
+        """trial_wavefunction/multi_slater.py:145-170 / uhf.py / hartree_fock.py: the variational energy of the trial,
+        which the driver asks for once before it builds the propagator (qmc/afqmc.py:147).  One determinant: the
+        local energy of the trial's own Green's function, evaluated by the device energy kernels (this uploads the
+        system and the trial to the context the propagator, walkers and estimators will share)."""
+        from pauxy_amd.context import get_context
+        from pauxy_amd.estimators.mixed import local_energy
+        get_context(system, self)
+        (self.energy, self.e1b, self.e2b) = local_energy(system, self.G, Ghalf=self.GH)
+        return self.energy
+
 
 def _adjugate(S):
     """adj(S) = det(S) S^-1, computed through the SVD so that it is also defined for singular S
@@ -156,6 +167,37 @@ class MultiDetTrial(object):
         return self._rchol[idet * stride + alpha:(idet + 1) * stride]
 
     rot_hs_pot = rot_chol
+
+    def calculate_energy(self, system):
+        """trial_wavefunction/multi_slater.py:145-170 -> estimators/mixed.py:292-343 (variational_energy_multi_det):
+        sum_ij conj(c_i) c_j <D_i|D_j> E[G_ij] / sum_ij conj(c_i) c_j <D_i|D_j> with the transition Green's functions
+        G_ij = gab(D_i, D_j); every E[G_ij] is one full-G device energy evaluation (ndets^2 of them, once at set-up).
+        Orthogonal (particle-hole) expansions have singular transition overlaps; the reference treats them with
+        Slater-Condon rules (estimators/ci.py), which are not part of the device path."""
+        if self.ortho_expansion:
+            raise NotImplementedError("variational energy of a particle-hole (orthogonal) expansion: not on the "
+                                      "device path (the walkers' energies do not need it)")
+        from pauxy_amd.context import get_context
+        from pauxy_amd.estimators.mixed import local_energy
+        get_context(system, self)
+        na = self._nalpha
+        num = numpy.zeros(3, dtype=numpy.complex128)
+        den = 0.0
+        for i, (ci, Di) in enumerate(zip(self.coeffs, self.psi)):
+            for j, (cj, Dj) in enumerate(zip(self.coeffs, self.psi)):
+                Oa = Di[:, :na].conj().T.dot(Dj[:, :na])
+                Ob = Di[:, na:].conj().T.dot(Dj[:, na:])
+                ovlp = numpy.linalg.det(Oa) * (numpy.linalg.det(Ob) if Ob.size else 1.0)
+                if abs(ovlp) < 1e-16:
+                    continue
+                Ga = Dj[:, :na].dot(numpy.linalg.solve(Oa, Di[:, :na].conj().T)).T           # gab(D_i, D_j)
+                Gb = Dj[:, na:].dot(numpy.linalg.solve(Ob, Di[:, na:].conj().T)).T if Ob.size else numpy.zeros_like(Ga)
+                e = numpy.array(local_energy(system, numpy.array([Ga, Gb])))
+                w = ci.conj() * cj * ovlp
+                num += w * e
+                den += w
+        (self.energy, self.e1b, self.e2b) = tuple(num / den)
+        return self.energy
 
     def one_body_density(self):
         """(Gamma[M, M], denom) with contract_one_body(ints) = sum_pq ints[p, q] Gamma[p, q] / denom.

@@ -15,6 +15,7 @@ batched launch and flushed back before the next one if the driver wrote to it.
 """
 import os
 import sys
+import weakref
 
 import time
 
@@ -22,7 +23,7 @@ import numpy
 
 from pauxy_amd import _lib as L
 from pauxy_amd.utils import io as _io
-from pauxy_amd.context import get_context, trial_psi
+from pauxy_amd.context import get_context, trial_psi, hidden
 
 _SCALARS = {
     'weight': (L.F_WEIGHT, numpy.float64),
@@ -64,7 +65,9 @@ class WalkerView(object):
     the driver and the estimators touch)."""
 
     def __init__(self, handler, i):
-        object.__setattr__(self, '_h', handler)
+        # the population this walker is a row of, as a weak reference: the population lists its walkers, and the
+        # reference's serialise (utils/misc.py:72-135) follows every __dict__ without a cycle guard
+        object.__setattr__(self, '_href', weakref.ref(handler))
         object.__setattr__(self, '_i', i)
         object.__setattr__(self, '_pending', False)
         object.__setattr__(self, 'total_weight', 0.0)
@@ -73,6 +76,10 @@ class WalkerView(object):
         object.__setattr__(self, 'field_configs', None)
         object.__setattr__(self, 'stack', None)
         object.__setattr__(self, 'alive', 1)
+
+    @property
+    def _h(self):
+        return self._href()
 
     # -- scalar attributes through the host mirror
     def __getattr__(self, name):
@@ -177,6 +184,11 @@ class WalkerView(object):
 
 class Walkers(object):
     """Drop-in for pauxy.walkers.handler.Walkers (single-determinant walkers)."""
+    ctx = hidden()
+    dev = hidden()
+    comm = hidden()
+    system = hidden()
+    trial = hidden()
 
     def __init__(self, system, trial, qmc, walker_opts={}, verbose=False, comm=None, nprop_tot=None,
                  nbp=None, device_id=None):

@@ -968,9 +968,274 @@ def make_io():
     print('io_formats.npz: %d arrays' % len(out))
 
 
+
+# --------------------------------------------------------------------------------------------------------------
+# dropin: the GENUINE driver (pauxy/qmc/afqmc.py, unchanged but for the three plug-in imports INTEGRATION.md section 3
+# names) over the pauxy_amd plug-in classes.  There is no GPU here, so the classes sit on the test-only numpy stand-in
+# for AfqDevice (tests/oracle_device.py, oracle arithmetic); everything the driver touches -- constructors,
+# AFQMC.__init__'s to_json/serialise walk, run(), finalise() -- is the reference's own code.  Outputs:
+#   * asserts that the run reproduces the committed golden trajectory the genuine classes produced;
+#   * dropin_trace.json: which attributes of which plug-in object the reference's code read / wrote / called, and what
+#     its serialise made of every object (key -> JSON kind): tests/test_dropin_cpu.py and tests/test_gpu_dropin.py hold
+#     the real classes to it wherever they run.
+# --------------------------------------------------------------------------------------------------------------
+DROPIN_IMPORTS = (
+    ("from pauxy.estimators.handler import Estimators", "from pauxy_amd.estimators.handler import Estimators"),
+    ("from pauxy.propagation.utils import get_propagator_driver",
+     "from pauxy_amd.propagation.continuous import get_propagator_driver"),
+    ("from pauxy.walkers.handler import Walkers", "from pauxy_amd.walkers.handler import Walkers"),
+)
+
+
+def dropin_driver_module():
+    """qmc/afqmc.py of the scratch copy with exactly the three import lines switched, as module pauxy.qmc.afqmc_dropin."""
+    src = open(os.path.join(SCRATCH, "pauxy/qmc/afqmc.py")).read()
+    for old, new in DROPIN_IMPORTS:
+        assert src.count(old) == 1, old
+        src = src.replace(old, new)
+    with open(os.path.join(SCRATCH, "pauxy/qmc/afqmc_dropin.py"), "w") as f:
+        f.write(src)
+    import importlib
+    return importlib.import_module("pauxy.qmc.afqmc_dropin")
+
+
+class AccessTrace(object):
+    """Records what code under SCRATCH/pauxy (the reference) does to the traced objects; accesses the plug-in classes
+    make on themselves are not the driver's and are left out."""
+
+    def __init__(self):
+        self.log = {}
+
+    def entry(self, label):
+        return self.log.setdefault(label, {'read': set(), 'written': set(), 'called': set()})
+
+    @staticmethod
+    def from_reference(only=None, depth=2):
+        """Is the code doing the access the reference's (``only``: that one file of it)?"""
+        name = sys._getframe(depth).f_code.co_filename
+        if only is not None:
+            return name == os.path.join(SCRATCH, "pauxy", only)
+        return name.startswith(os.path.join(SCRATCH, "pauxy"))
+
+    def attach(self, obj, label, only=None):
+        cls = type(obj)
+        if getattr(cls, '_traced', False):
+            return obj
+        ent = self.entry(label)
+        trace = self
+
+        class Traced(cls):
+            _traced = True
+
+            def __getattribute__(self, name):
+                try:
+                    value = cls.__getattribute__(self, name)
+                except AttributeError:
+                    if not hasattr(cls, '__getattr__'):
+                        raise
+                    value = cls.__getattr__(self, name)
+                if trace.from_reference(only):
+                    if callable(value) and not isinstance(value, type) and hasattr(value, '__call__') \
+                            and (hasattr(value, '__self__') or hasattr(value, '__func__')):
+                        ent['called'].add(name)
+                    else:
+                        ent['read'].add(name)
+                return value
+
+            def __setattr__(self, name, value):
+                if trace.from_reference(only):
+                    ent['written'].add(name)
+                cls.__setattr__(self, name, value)
+
+        Traced.__name__ = cls.__name__
+        Traced.__qualname__ = cls.__qualname__
+        obj.__class__ = Traced
+        return obj
+
+
+def json_kinds(tree):
+    """serialise output -> the same tree with every leaf replaced by the name of its JSON kind."""
+    if isinstance(tree, dict):
+        return dict((k, json_kinds(v)) for k, v in tree.items())
+    if isinstance(tree, (list, tuple)):
+        return 'array'
+    if isinstance(tree, bool):
+        return 'bool'
+    if isinstance(tree, (int, float)):
+        return 'number'
+    if tree is None:
+        return 'null'
+    return 'string'
+
+
+def make_dropin():
+    import contextlib
+    import io
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))            # /root/repo: pauxy_amd, tests, oracle
+    os.environ.pop('AFQ_ESTIMATES_FILE', None)
+    from tests import oracle_device
+    oracle_device.install()
+    mod = dropin_driver_module()
+    import pauxy_amd.propagation.continuous as amd_prop
+    import pauxy_amd.walkers.handler as amd_walkers
+    import pauxy_amd.estimators.handler as amd_est
+    assert mod.get_propagator_driver is amd_prop.get_propagator_driver
+    assert mod.Walkers is amd_walkers.Walkers and mod.Estimators is amd_est.Estimators
+    trace = AccessTrace()
+
+    # the traced classes are attached where the driver receives the objects: wrap the three constructors it calls
+    def traced_factory(fn, label, also=None):
+        def build(*a, **k):
+            obj = trace.attach(fn(*a, **k), label)
+            if also:
+                also(obj)
+            return obj
+        return build
+
+    def trace_walkers(psi):
+        for w in psi.walkers:
+            trace.attach(w, 'Walker')
+
+    def trace_estimators(est):
+        for name, e in est.estimators.items():
+            trace.attach(e, {'mixed': 'Mixed', 'back_prop': 'BackPropagation'}[name])
+
+    def trace_prop(prop):
+        trace.attach(prop.propagator, 'Continuous.propagator')
+
+    mod.get_propagator_driver = traced_factory(amd_prop.get_propagator_driver, 'Propagator', trace_prop)
+    mod.Walkers = traced_factory(amd_walkers.Walkers, 'Walkers', trace_walkers)
+    mod.Estimators = traced_factory(amd_est.Estimators, 'Estimators', trace_estimators)
+    # the genuine system / trial objects: only what the DRIVER reads of them (their own classes read far more), so that
+    # pauxy_amd.systems / pauxy_amd.trial objects can be checked for the same surface
+    driver_file = "qmc/afqmc_dropin.py"
+    get_system, get_trial = mod.get_system, mod.get_trial_wavefunction
+    mod.get_system = lambda *a, **k: trace.attach(get_system(*a, **k), 'system', only=driver_file)
+    mod.get_trial_wavefunction = lambda *a, **k: trace.attach(get_trial(*a, **k), 'trial', only=driver_file)
+    comm = MPI.COMM_WORLD
+    doc = {'cases': {}}
+
+    def run_case(name, golden, options, system=None, verbose=0):
+        d = numpy.load(os.path.join(HERE, golden))
+        with contextlib.redirect_stdout(io.StringIO()):
+            afqmc = mod.AFQMC(comm=comm, system=system, options=options, verbose=verbose)
+        # AFQMC.__init__ has run to_json(self) -> serialise (utils/misc.py:72-135) over the plug-in objects and stored
+        # the string as the metadata of the estimator file
+        meta = json.loads(afqmc.estimators.json_string)
+        for key in ('propagators', 'estimators', 'psi'):
+            assert key in meta, key
+        store = h5py._STORE[afqmc.estimators.filename]
+        assert json.loads(str(store['metadata'])) == meta
+        rec = dict(weight=[], unscaled_weight=[], ot=[], ehyb=[], phase=[], eloc=[], pix=[])
+        est_update = afqmc.estimators.update
+
+        def update(system_, qmc, trial, psi_, step, fp):
+            rec['weight'].append([w.weight for w in psi_.walkers])
+            rec['unscaled_weight'].append([w.unscaled_weight for w in psi_.walkers])
+            rec['ot'].append([w.ot for w in psi_.walkers])
+            rec['ehyb'].append([w.hybrid_energy for w in psi_.walkers])
+            rec['phase'].append([w.phase for w in psi_.walkers])
+            rec['eloc'].append([w.eloc for w in psi_.walkers])
+            if step % qmc.npop_control == 0 and psi_.ntot_walkers > 1:
+                rec['pix'].append(numpy.array(psi_.last_parent_ix))
+            return est_update(system_, qmc, trial, psi_, step, fp)
+
+        object.__setattr__(afqmc.estimators, 'update', update)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                afqmc.run(comm=comm, verbose=verbose)
+                afqmc.finalise(verbose=True)
+        finally:
+            object.__delattr__(afqmc.estimators, 'update')
+        afqmc.estimators.flush()
+
+        def close(a, b, what, tol=1e-8):
+            a, b = numpy.asarray(a), numpy.asarray(b)
+            assert a.shape == b.shape, (what, a.shape, b.shape)
+            err = float(numpy.max(numpy.abs(a - b))) / max(1.0, float(numpy.max(numpy.abs(b))))
+            assert err <= tol, (what, err)
+            return err
+
+        errs = {}
+        errs['weight'] = close(rec['weight'], d['weight'], 'weight')
+        errs['unscaled_weight'] = close(rec['unscaled_weight'], d['unscaled_weight'], 'unscaled_weight')
+        errs['ot'] = close(rec['ot'], d['ot'], 'ot')
+        errs['ehyb'] = close(rec['ehyb'], d['ehyb'], 'ehyb')
+        errs['phase'] = close(rec['phase'], d['phase'], 'phase')
+        errs['eloc'] = close(rec['eloc'], d['eloc'], 'eloc')
+        assert numpy.array_equal(numpy.array(rec['pix']).reshape(d['parent_ix'].shape), d['parent_ix']), 'parent_ix'
+        keys = sorted(k for k in store if k.startswith('basic/energies/'))
+        blocks = numpy.array([store[k] for k in keys])
+        errs['blocks'] = close(blocks[:, 1:10], d['blocks'][:, 1:10], 'blocks')
+        errs['final_phi'] = close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'], 'final_phi')
+        assert afqmc.propagators.nfb_trig == int(d['nfb_trig']) and afqmc.propagators.nhe_trig == int(d['nhe_trig'])
+        dev = oracle_device.OracleDevice.instances[-1]
+        nprop = dev.calls.count('propagate')
+        assert nprop == afqmc.qmc.total_steps, (nprop, afqmc.qmc.total_steps)      # ONE batched launch per step
+        doc['cases'][name] = {'golden': golden, 'steps': int(afqmc.qmc.total_steps),
+                              'max_rel_err': dict((k, float(v)) for k, v in errs.items()),
+                              'serialised': dict((k, json_kinds(meta[k])) for k in ('propagators', 'estimators', 'psi'))}
+        print('dropin %-12s %s: genuine driver over the plug-in classes == %s  (max rel err %.1e)'
+              % (name, 'verbose' if verbose else 'quiet', golden, max(errs.values())))
+        import pauxy_amd.context as amd_ctx
+        amd_ctx.release_context(afqmc.system, afqmc.trial)
+        return afqmc
+
+    # BASELINE configs[0]: 4x4 U=4 half filling, 10 walkers, comb every 5 steps (the options of make_traj_hubbard)
+    run_case('hubbard_c1', 'traj_hubbard_c1.npz',
+             {'verbosity': 0, 'get_sha1': False,
+              'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8, 'num_walkers': 10,
+                      'pop_control_freq': 5},
+              'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 8, "U": 4, 'ndown': 8},
+              'trial': {'name': 'UHF'}, 'estimates': {'mixed': {'energy_eval_freq': 1}},
+              'propagator': {'hubbard_stratonovich': 'continuous'}})
+    # qmc/tests/test_afqmc.py:190-229: generic Cholesky Hamiltonian, RHF-type MultiSlater trial (the options of make_traj_generic)
+    nmo, nelec = 11, (3, 3)
+    numpy.random.seed(7)
+    h1e, chol, enuc, eri = generate_hamiltonian(nmo, nelec, cplx=False)
+    system = Generic(nelec=nelec, h1e=numpy.array([h1e, h1e]), chol=chol.reshape((-1, nmo * nmo)).T.copy(), ecore=enuc)
+    run_case('generic', 'traj_generic.npz',
+             {'verbosity': 0, 'get_sha1': False, 'qmc': {'timestep': 0.005, 'steps': 10, 'blocks': 10, 'rng_seed': 8},
+              'estimates': {'mixed': {'energy_eval_freq': 1}}, 'trial': {'name': 'MultiSlater'}}, system=system)
+    # the local-energy weight update and free projection take other branches of the driver-facing classes
+    for name, golden, extra in (('hubbard_le', 'traj_hubbard_le.npz', {'hybrid': False}),
+                                ('hubbard_fp', 'traj_hubbard_fp.npz', {'free_projection': True})):
+        run_case(name, golden,
+                 {'verbosity': 0, 'get_sha1': False,
+                  'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 4, 'rng_seed': 8, 'num_walkers': 10,
+                          'pop_control_freq': 5},
+                  'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 8, "U": 4, 'ndown': 8},
+                  'trial': {'name': 'UHF'}, 'estimates': {'mixed': {'energy_eval_freq': 1}},
+                  'propagator': dict({'hubbard_stratonovich': 'continuous'}, **extra)})
+    # once more with the driver's verbose branches (print_key, print_header, the step-0 print_step): same numbers apart
+    # from the step-0 row, which a verbose run prints and zeroes instead of folding it into the first block
+    # (utils/misc.py:265 get_sys_info reads numpy.__config__.blas_opt_info, which numpy 2 no longer has: the one call of
+    #  the verbose constructor that cannot run in this image is replaced; it does not touch the plug-in objects)
+    mod.get_sys_info = lambda sha1, branch, uuid, nranks: {}
+    with contextlib.redirect_stdout(io.StringIO()) as text:
+        mod.AFQMC(comm=comm, verbose=1, options={
+            'verbosity': 1, 'get_sha1': False,
+            'qmc': {'timestep': 0.01, 'num_steps': 5, 'blocks': 2, 'rng_seed': 8, 'num_walkers': 4, 'pop_control_freq': 5},
+            'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 8, "U": 4, 'ndown': 8}, 'trial': {'name': 'UHF'},
+            'estimates': {'mixed': {'energy_eval_freq': 1}},
+            'propagator': {'hubbard_stratonovich': 'continuous'}}).run(comm=comm, verbose=True)
+    assert '# Explanation of output column headers:' in text.getvalue() and 'WeightFactor' in text.getvalue()
+    doc['trace'] = dict((label, dict((k, sorted(v)) for k, v in ent.items())) for label, ent in sorted(trace.log.items()))
+    doc['driver_imports_switched'] = [new for _, new in DROPIN_IMPORTS]
+    with open(os.path.join(HERE, 'dropin_trace.json'), 'w') as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+        f.write('\n')
+    for label, ent in sorted(trace.log.items()):
+        print('%-22s read %d, wrote %d, called %d' % (label, len(ent['read']), len(ent['written']), len(ent['called'])))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'io':
         make_io()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dropin':
+        make_dropin()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hirsch':
         make_traj_hirsch(pin=-152.68468568462666)

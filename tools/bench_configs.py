@@ -19,7 +19,7 @@ def run(name, system, trial, nw, dt, steps, warmup, prop=None, npop=5):
     prop.update({'device_rng': True, 'rng_seed': 7})
     options = {'qmc': {'timestep': dt, 'num_steps': 10, 'blocks': 10 ** 6, 'stabilise_freq': 10,
                        'pop_control_freq': npop, 'num_walkers': nw, 'rng_seed': 7},
-               'propagator': prop, 'estimators': {'mixed': {'verbose': False}}}
+               'propagator': prop, 'estimators': {'mixed': {'verbose': False}, 'write_file': False}}
     afqmc = AFQMC(options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
     es = afqmc.run_batched(warmup, first_step=1, eshift=0.0)
