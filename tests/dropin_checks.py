@@ -31,20 +31,24 @@ def build_like_the_driver(d, est_opts=None):
     in the driver's order with the driver's arguments, on this package's own system / trial classes."""
     s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
     t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
-    qmc = QMCOpts({'timestep': 0.01, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8, 'num_walkers': 10,
-                   'pop_control_freq': 5}, s)
+    return build_shell(s, t, {'timestep': 0.01, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8, 'num_walkers': 10,
+                              'pop_control_freq': 5}, {'hubbard_stratonovich': 'continuous'}, est_opts)
+
+
+def build_shell(s, t, qmc_opts, prop_opts, est_opts=None, walker_opts=None):
+    qmc = QMCOpts(qmc_opts, s)
     comm = FakeComm()
     shell = DriverShell()
     shell.verbosity = 0
     shell.root, shell.rank = True, 0
     shell.system, shell.qmc, shell.trial = s, qmc, t
-    shell.propagators = get_propagator_driver(s, t, qmc, options={'hubbard_stratonovich': 'continuous'}, verbose=False)
+    shell.propagators = get_propagator_driver(s, t, qmc, options=prop_opts, verbose=False)
     est = dict(est_opts or {'mixed': {'energy_eval_freq': 1}})
     est['stack_size'] = 1                                                        # afqmc.py:160
     shell.estimators = Estimators(est, True, qmc, s, t, shell.propagators.BT_BP, False)
     qmc.nwalkers = int(qmc.nwalkers / comm.size)
     qmc.ntot_walkers = qmc.nwalkers * comm.size
-    shell.psi = Walkers(s, t, qmc, walker_opts={}, verbose=False, nprop_tot=shell.estimators.nprop_tot,
+    shell.psi = Walkers(s, t, qmc, walker_opts=walker_opts or {}, verbose=False, nprop_tot=shell.estimators.nprop_tot,
                         nbp=shell.estimators.nbp, comm=comm)
     return shell, comm
 

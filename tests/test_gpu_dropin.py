@@ -93,3 +93,45 @@ def test_multi_determinant_trial_energy(golden):
             den += ci.conj() * cj * ov
     numpy.testing.assert_allclose([t.energy, t.e1b, t.e2b], num / den, rtol=1e-9)
     release_context(s, t)
+
+
+def _walk_and_dump(shell):
+    from tests import serialise_walk
+    tree = serialise_walk.walk(shell)
+    assert json.loads(json.dumps(tree, indent=4)).keys() == tree.keys()
+    return tree
+
+
+def test_every_plugin_variant_survives_the_serialise_walk(golden):
+    """The other objects the driver can be handed: the discrete Hirsch propagator with the back-propagated estimator,
+    a Generic system with back-propagation and the mixed one-body RDM, the UEG -- before and after they have worked."""
+    d = golden('traj_hubbard_c1.npz')
+    s = systems.Hubbard(4, 4, 8, 8, float(d['U']))
+    t = trial_mod.SingleDetTrial(s, d['psi'], name='UHF')
+    qmc = {'timestep': 0.01, 'num_steps': 5, 'blocks': 2, 'num_walkers': 6, 'pop_control_freq': 5}
+    variants = [(s, t, {'hubbard_stratonovich': 'discrete'},
+                 {'mixed': {'energy_eval_freq': 1}, 'back_propagated': {'tau_bp': 0.04, 'one_rdm': True}}, {})]
+    g = golden('traj_generic.npz')
+    na, nb = [int(x) for x in g['nelec']]
+    sg = systems.Generic((na, nb), numpy.array([g['h1e'], g['h1e']]), g['chol'], float(g['ecore']))
+    tg = trial_mod.SingleDetTrial(sg, g['psi'])
+    variants.append((sg, tg, {}, {'mixed': {'energy_eval_freq': 1, 'one_rdm': True},
+                                  'back_propagated': {'tau_bp': 0.04, 'one_rdm': True}}, {'use_log_shift': True}))
+    su = systems.UEG(2.44, 7, 7, 2.0)
+    variants.append((su, trial_mod.hartree_fock_ueg(su), {}, {'mixed': {'energy_eval_freq': 1}}, {}))
+    for (sys_, tr, prop, est, wopt) in variants:
+        est = dict(est, write_file=False)
+        shell, comm = dropin_checks.build_shell(sys_, tr, qmc, prop, est, wopt)
+        tree = _walk_and_dump(shell)
+        assert {'propagators', 'estimators', 'psi'} <= set(tree)
+        numpy.random.seed(11)
+        for step in range(1, 6):
+            for w in shell.psi.walkers:
+                if abs(w.weight) > 1e-8:
+                    shell.propagators.propagate_walker(w, sys_, tr, 0.0)
+            if step == 5:
+                shell.psi.pop_control(comm)
+            shell.estimators.update(sys_, shell.qmc, tr, shell.psi, step, False)
+            shell.estimators.print_step(comm, comm.size, step)
+        _walk_and_dump(shell)
+        release_context(sys_, tr)
