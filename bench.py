@@ -47,6 +47,232 @@ def build_inputs():
     return system, trial
 
 
+# ---- the other BASELINE configurations (--config): one GPU's shard each, through the same step loop -----------------
+CONFIGS = {
+    # name: sizes (M, na, nb, K, walkers), time step, default steps / warm-up, what BASELINE.json calls it
+    "C1": dict(M=16, na=8, nb=8, K=16, nw=10, dt=0.01, steps=400, warmup=50, kind="hubbard",
+               label="4x4 Hubbard U=4 half filling, 10 walkers, phaseless continuous propagator (BASELINE configs[0])"),
+    "C2": dict(M=93, na=7, nb=7, K=1500, nw=256, dt=0.005, steps=100, warmup=20, kind="ueg", nq=750,
+               label="UEG rs=2, 14 electrons, ecut=4 (M=93 plane waves, 750 momentum transfers), 256 walkers "
+                     "(BASELINE configs[1])"),
+    "C4": dict(M=256, na=128, nb=128, K=256, nw=256, dt=0.005, steps=20, warmup=10, kind="hubbard",
+               label="16x16 Hubbard U=8 half filling, UHF trial, 256 walkers = one GPU's shard of 2048 "
+                     "(BASELINE configs[3])"),
+    "C5sd": dict(M=400, na=50, nb=50, K=2000, nw=256, dt=0.005, steps=10, warmup=5, kind="generic",
+                 label="generic Nbasis=400, Nchol=2000, 50+50 electrons, single-determinant RHF trial, 256 walkers "
+                       "(BASELINE configs[4] sizes without the multi-determinant trial)"),
+    "C5": dict(M=400, na=50, nb=50, K=2000, nw=256, dt=0.005, steps=10, warmup=5, kind="generic", ndet=4,
+               label="generic Nbasis=400, Nchol=2000, 50+50 electrons, 4-determinant NOMSD trial, 256 walkers = one GPU's "
+                     "shard (BASELINE configs[4])"),
+}
+
+
+def build_config(name):
+    from pauxy_amd import systems, trial as trial_mod
+    c = CONFIGS[name]
+    if name == "C1":
+        s = systems.Hubbard(4, 4, 8, 8, 4.0)
+        return s, trial_mod.uhf_trial_hubbard(s)
+    if name == "C2":
+        s = systems.UEG(2.0, 7, 7, 4.0)
+        return s, trial_mod.hartree_fock_ueg(s)
+    if name == "C4":
+        s = systems.Hubbard(16, 16, 128, 128, 8.0)
+        return s, trial_mod.uhf_trial_hubbard(s)
+    s = systems.synthetic_generic(c["M"], c["K"], (c["na"], c["nb"]), seed=7)
+    t0 = trial_mod.rhf_trial_generic(s)
+    if name == "C5sd":
+        return s, t0
+    rng = numpy.random.RandomState(3)
+    dets = numpy.array([t0.psi + (0.0 if d == 0 else 0.05) * (rng.rand(c["M"], 100) + 1j * rng.rand(c["M"], 100))
+                        for d in range(4)])
+    return s, trial_mod.MultiDetTrial(s, (numpy.array([0.8, 0.3, 0.2, 0.1], dtype=complex), dets), init=t0.psi)
+
+
+def launch_work(name, c):
+    """(bound, algorithmic work of ONE launch, note) of the launches afq_launch_trace names (kernel names for plain
+    launches, the launching function for the GEMM engines); SURVEY 8d conventions: 8 flops per complex MAC, 4 per
+    real-by-complex MAC, no padding.  None for launches that are bookkeeping."""
+    M, na, nb, K, nw = c["M"], c["na"], c["nb"], c["K"], c["nw"]
+    nt, ndet = na + nb, c.get("ndet", 1)
+    cx = 2.0 if ndet > 1 else 1.0                       # perturbed determinants make the half-rotated vectors complex
+    table = (
+        ("prop_fused_kernel", "mfma", 8.0 * M * M * nt * 8 * nw, "B exp(V) B: 2 + 6 products of M x M by M x (na+nb)"),
+        ("prop_ueg_kernel", "mfma", 8.0 * M * M * nt * 6 * nw, "exp(V) phi from per-walker coefficients: 6 products"),
+        ("k_apply_exponential", "mfma", 8.0 * M * M * nt * nw, "one Taylor product V T, both spins"),
+        ("onebody_spin", "mfma", 8.0 * M * M * nt * nw, "BH1 phi, both spins in one launch"),
+        ("k_vhs_generic", "mfma", 4.0 * (M * (M + 1) // 2) * K * nw, "HS potential, packed symmetric columns"),
+        ("force_bias_generic_impl", "mfma",
+         4.0 * K * (na if (ndet == 1 and na == nb) else nt) * M * nw, "force bias / Coulomb vectors, one real-B pass"),
+        ("launch_exx_quadratic", "mfma", 4.0 * cx * (na * M * (na * M + 1) / 2.0 + nb * M * (nb * M + 1) / 2.0) * nw,
+         "exchange energy as the quadratic form on the upper triangle of Atil (one determinant)"),
+        ("exx_kernel", "mfma", 4.0 * cx * K * M * (na * na + nb * nb) * nw, "exchange energy, T intermediate"),
+        ("OvlpProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "phi^T conj(psi), both spins"),
+        ("GhalfProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "O^-1 phi^T, both spins"),
+        ("GramProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "Cholesky-QR Gram matrix, both spins"),
+        ("QProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "Cholesky-QR Q = phi T, both spins"),
+        ("gj_big_kernel", "valu", 8.0 * na ** 3 * nw * 2, "register-resident Gauss-Jordan, 8 N^3 flops per matrix"),
+        ("greens_small_kernel", "hbm", 2.0 * M * nt * 16 * nw, "reads phi, writes Ghalf (latency bound: Gauss-Jordan chain)"),
+        ("ueg_fields_kernel", "hbm", (nt * M * 16 + 2 * K * 16 + 600 * 16) * nw,
+         "reads Ghalf, writes xbar, xs and the HS coefficients (latency bound: RNG chain, dependent gathers)"),
+    )
+    for key, bound, work, note in table:
+        if key in name:
+            return bound, work, note
+    return None
+
+
+PEAK_F64_VALU_TFLOPS = 78.6          # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak on CDNA4
+PEAK_HBM_TBS = 8.0
+
+
+def config_cpu_baseline(name, system, trial, budget_s=15.0):
+    """The oracle (per-walker numpy/scipy loop of oracle/afqmc_ref.py) on this host for the same configuration and
+    cadence, one process with the BLAS threads of one socket, over a bounded sample: blocks of 10 steps for a few
+    walkers until about `budget_s` seconds have passed (one warm-up block first)."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd.propagation import setup
+    c = CONFIGS[name]
+    M, na, nb, dt = c["M"], c["na"], c["nb"], c["dt"]
+    if c.get("ndet", 1) > 1:
+        return {"value": None, "unit": "walker-steps/s", "cores": 0, "kind": "port",
+                "sample": "not timed: see the single-determinant configuration C5sd (the oracle's multi-determinant step "
+                          "is ndet^2 single-determinant evaluations)"}
+    if c["kind"] == "generic":
+        BH1, mf = setup.generic_propagator_arrays(system, trial, dt)
+        model = ref.RefModel('generic', M, na, nb, trial.psi, BH1, mf, dt, hs_pot=system.hs_pot, rchol=trial._rchol,
+                             H1=system.H1.astype(complex), ecore=system.ecore)
+    elif c["kind"] == "hubbard":
+        BH1, mf = setup.hubbard_propagator_arrays(system, trial, dt, True)
+        model = ref.RefModel('hubbard', M, na, nb, trial.psi, BH1, mf, dt, U=system.U, H1=system.T.astype(complex))
+    else:
+        BH1, mf = setup.ueg_propagator_arrays(system, trial, dt)
+        H1diag = numpy.array([numpy.diag(system.H1[0]).real, numpy.diag(system.H1[1]).real])
+        model = ref.RefModel('ueg', M, na, nb, trial.psi, BH1, mf, dt, iA=system.iA, iB=system.iB, H1diag=H1diag,
+                             vqvec=system.vqvec, vol=system.vol, ikpq_i=system.ikpq_i, ikpq_kpq=system.ikpq_kpq,
+                             ipmq_i=system.ipmq_i, ipmq_pmq=system.ipmq_pmq, ecore=system.ecore)
+    cpu_model, socket_cores, sockets = host_cpu()
+    rng = numpy.random.RandomState(11)
+    K = model.nfields
+
+    def block(nw_):
+        walkers = [ref.new_walker(model, trial.psi) for _ in range(nw_)]
+        ref.run_afqmc(model, walkers, lambda s_, w: rng.normal(size=K), lambda s_: rng.random_sample(), NSTEPS_BLOCK, 1,
+                      nstblz=NSTBLZ, npop_control=NPOP, energy_eval_freq=NSTEPS_BLOCK)
+        return nw_ * NSTEPS_BLOCK
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=socket_cores)
+    except Exception:                                   # noqa: BLE001
+        limit = contextlib.nullcontext()
+    with limit:
+        t0 = time.time()
+        block(1)
+        warm = time.time() - t0
+        nw_ = 2 if warm * 2 < budget_s / 3 else 1
+        done, t0 = 0, time.time()
+        while time.time() - t0 < budget_s:
+            done += block(nw_)
+        el = time.time() - t0
+    return {"value": done / el, "unit": "walker-steps/s", "cores": socket_cores, "kind": "port",
+            "cpu": "%s, %d cores/socket x %d sockets" % (cpu_model, socket_cores, sockets),
+            "sample": "%d walker-steps (blocks of %d walkers x %d steps in the bench cadence incl. the per-block energy "
+                      "evaluation), numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s wall, BLAS threads of one socket"
+                      % (done, nw_, NSTEPS_BLOCK, el)}
+
+
+def run_config(args, name, state):
+    """`--config C1|C2|C4|C5sd|C5`: the same harness on another BASELINE configuration, one GPU: W warm-up steps, then
+    `repeats` timed regions of EXACTLY --steps steps, each bracketed by synchronisation, median reported; an extra pass
+    under afq_launch_trace names every launch of the step and prices the dominant one against its roof."""
+    import torch
+    from pauxy_amd.qmc.afqmc import AFQMC
+    from pauxy_amd.context import release_context
+    c = CONFIGS[name]
+    steps = args.steps if args.steps_given else c["steps"]
+    warmup = args.warmup if args.warmup_given else c["warmup"]
+    state["phase"] = "set-up"
+    system, trial = build_config(name)
+    options = {'qmc': {'timestep': c["dt"], 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
+                       'pop_control_freq': NPOP, 'num_walkers': c["nw"], 'rng_seed': 7},
+               'propagator': {'device_rng': True, 'rng_seed': 7},
+               'estimators': {'mixed': {'verbose': False}, 'write_file': False}}
+    afqmc = AFQMC(options=options, system=system, trial=trial)
+    dev = afqmc.psi.dev
+    state["dev"] = dev
+
+    def sync():
+        dev.sync()
+        torch.cuda.synchronize()
+    state["phase"] = "warm-up"
+    eshift = afqmc.run_batched(warmup, first_step=1, eshift=0.0)
+    sync()
+    state["phase"] = "timed region"
+    repeats = args.repeats if args.repeats else (5 if steps < 100 else 3 if steps < 500 else 1)
+    regions, first = [], warmup + 1
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        eshift = afqmc.run_batched(steps, first_step=first, eshift=eshift)
+        sync()
+        regions.append(time.perf_counter() - t0)
+        first += steps
+    elapsed = sorted(regions)[(repeats - 1) // 2]
+    state["phase"] = "launch trace"
+    extra = 2 * NSTEPS_BLOCK
+    dev.launch_trace(True)
+    afqmc.run_batched(extra, first_step=first, eshift=eshift)
+    dev.sync()
+    dev.launch_trace(False)
+    trace = dev.launch_trace_get()
+    rows = []
+    for lname, (count, ms) in sorted(trace.items(), key=lambda kv: -kv[1][1]):
+        row = {"launch": lname, "launches": count, "avg_ms": ms / count, "ms_per_step": ms / extra}
+        w = launch_work(lname, c)
+        if w:
+            bound, work, note = w
+            t = ms / count * 1e-3
+            if bound == "hbm":
+                row.update(bound="hbm", achieved=work / t / 1e9, peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
+                           frac=work / t / 1e12 / PEAK_HBM_TBS, bytes_per_launch=work, note=note)
+            else:
+                row.update(bound=bound, achieved=work / t / 1e12, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
+                           frac=work / t / 1e12 / PEAK_F64_MFMA_TFLOPS, flops_per_launch=work, note=note)
+        rows.append(row)
+    priced = [r for r in rows if "frac" in r]
+    if not priced:
+        raise RuntimeError("no launch of this configuration has a work model: %r" % [r["launch"] for r in rows[:6]])
+    dom = max(priced, key=lambda r: r["ms_per_step"])
+    mixed = afqmc.estimators.estimators['mixed']
+    out = {
+        "metric": "walker_steps_per_sec", "value": c["nw"] * steps / elapsed, "unit": "walker-steps/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "ms_per_step_min": 1e3 * min(regions) / steps, "ms_per_step_max": 1e3 * max(regions) / steps,
+        "repeats": repeats, "timed_regions_ms": [1e3 * r for r in regions],
+        "statistic": "median of %d timed regions of %d steps each" % (repeats, steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": c["label"] + ", dt=%g, reortho/10, comb/5, energy/10" % c["dt"], "name": name,
+                   "walkers_total": c["nw"], "rng": "device-philox",
+                   "sizes": {k: c[k] for k in ("M", "na", "nb", "K", "nw")}},
+        "last_block_ETotal": float(numpy.real(mixed.blocks[-1][6])) if mixed.blocks else None,
+        "roofline": {"bound": "hbm" if dom["bound"] == "hbm" else "mfma", "kernel": dom["launch"] + " (" + dom["note"] + ")",
+                     "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                     "traffic": None, "kernel_ms": dom["avg_ms"], "launches": dom["launches"],
+                     "measured": "extra pass of %d steps under afq_launch_trace right behind the timed regions" % extra,
+                     "pipe": "fp64 vector ALU (same peak as the matrix pipe on gfx950)" if dom["bound"] == "valu" else None},
+        "roofline_all": rows[:16],
+        "step_ms_in_traced_launches": sum(r["ms_per_step"] for r in rows),
+    }
+    if not args.no_cpu_baseline:
+        state["phase"] = "cpu baseline"
+        out["cpu_baseline"] = config_cpu_baseline(name, system, trial)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    state["dev"] = None
+    release_context(system, trial)
+    return out
+
+
 def host_cpu():
     """(model name, physical cores of one socket, sockets) from /proc/cpuinfo."""
     model, cores, sockets = "unknown", None, set()
@@ -263,8 +489,11 @@ def start_watchdog(state):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["C3"] + sorted(CONFIGS), default="C3",
+                    help="BASELINE configuration: C3 (default; the one the metric is quoted on: generic M=100 K=500, 256 "
+                         "walkers per GPU, 1..8 GPUs) or one GPU's shard of C1 / C2 / C4 / C5 / C5sd")
     ap.add_argument("--walkers-per-gpu", type=int, default=None)
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="weak",
                     help="weak: 256 walkers per GPU (BASELINE configs[2]); strong: 2048 walkers in total (SURVEY 8e); "
@@ -277,6 +506,11 @@ def main():
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-window", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.steps_given, args.warmup_given = args.steps is not None, args.warmup is not None
+    if args.steps is None:
+        args.steps = 100
+    if args.warmup is None:
+        args.warmup = 20
     if args.cpu_worker:                 # child of cpu_socket_processes: numpy only, never touches the GPU
         cpu_worker(args.cpu_worker, args.cpu_window)
         return
@@ -319,6 +553,12 @@ def main():
         else:
             dist.init_process_group(backend=backend)
             comm = TorchComm(device=torch.device("cpu"))
+    if args.config != "C3":
+        if world > 1:
+            raise SystemExit("bench.py: --config %s is one GPU's shard; the multi-GPU line is --config C3" % args.config)
+        print(json.dumps(run_config(args, args.config, state)))
+        sys.stdout.flush()
+        return
     system, trial = build_inputs()
     scalings = ["weak", "strong"] if args.scaling == "both" else [args.scaling]
     for i, scaling in enumerate(scalings):
@@ -510,7 +750,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
     traffic = None
     traffic_source = None
-    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json",
+    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
                                                               "r01_pmc_traffic.json")
                   if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
     if tfile:
@@ -520,6 +760,18 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
             traffic = json.load(f).get(dom["kernel"].split(" ")[0], {}).get("traffic_bytes_per_launch")
 
     comm_stats = dev.comm_stats() if device_comm else None
+    comm_per_rank = None
+    if device_comm and comm is not None:
+        # every rank's traffic of the run: walkers it wrote into peers' windows, events, largest per-peer transfer, flags
+        keys = ('walkers_sent', 'bytes_sent', 'events', 'max_transfer', 'overflow', 'error')
+        mine = numpy.array([float(comm_stats[k]) for k in keys])
+        allr = numpy.zeros(world * len(keys))
+        comm.Allgather(mine, allr)
+        allr = allr.reshape(world, len(keys))
+        comm_per_rank = {k: [int(x) for x in allr[:, i]] for i, k in enumerate(keys)}
+        ev = max(1, int(allr[0, 2]))
+        comm_per_rank["walkers_sent_per_event"] = float(allr[:, 0].sum()) / ev
+    exq = next((r for r in rows if "exchange energy" in r["kernel"]), None)
     out = None
     if rank == 0:
         total_walkers = nw * world
@@ -543,6 +795,11 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                        "population_control": pc_label},
             "population_control": pc_label,
             "comm_stats": comm_stats,
+            "comm_stats_per_rank": comm_per_rank,
+            # Walkers._init_device_comm returns a communicator only after afq_comm_probe (known-answer all-gather, one
+            # full slot to and from every peer on the chosen transport, all-reduce) passed on EVERY rank
+            "comm_probe": ("passed on every rank (%s)" % comm_kind) if device_comm else
+                          (None if world == 1 else "no device communicator: " + (comm_note or "not requested")),
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
@@ -550,7 +807,14 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                          "traffic_source": traffic_source,
                          "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
                          "flops_per_launch": dom["flops_per_launch"],
-                         "issued_flops_per_launch": dom.get("issued_flops_per_launch")},
+                         "issued_flops_per_launch": dom.get("issued_flops_per_launch"),
+                         # BASELINE's second figure: fp64 MFMA fraction of the Cholesky energy contraction
+                         "cholesky_energy": None if exq is None else {
+                             "kernel": exq["kernel"], "kernel_ms": exq["avg_ms"], "launches": exq["launches"],
+                             "flops_per_launch": exq["flops_per_launch"], "achieved": exq["achieved"],
+                             "frac": exq["frac"], "frac_issued": exq.get("frac_issued"),
+                             "frac_vs_reference_formulation": exq.get("effective_vs_reference_formulation"),
+                             "measured": exq["measured"]}},
             "roofline_all": rows,
         }
         if with_cpu_baseline:                                   # reported at N = 1 only

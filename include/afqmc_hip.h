@@ -307,9 +307,14 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
  *                          destination rank's mapped window, LIVE SLOTS ONLY, no host knowledge of the counts, nothing
  *                          posted by the host; 0 (RCCL communicator only; also the automatic fall-back when a rank cannot
  *                          export / map windows): fixed-capacity slots to and from every peer in one ncclSend / ncclRecv group
- *   afq_comm_set_capacity  walkers one rank can send to one peer per event (default nw: what a rank owns, cannot
- *                          overflow); exceeding it raises AFQ_EOVERFLOW at the next afq_estimates_get / fetching comb.
- *                          Only the ncclSend / ncclRecv transport pays for unused capacity
+ *   afq_comm_set_capacity  walkers one rank can send to one peer per event (default nw up to 512 walkers per rank:
+ *                          what a rank owns, cannot overflow; max(512, nw / 4) above, so that the windows stay a few
+ *                          hundred MB); exceeding it raises AFQ_EOVERFLOW at the next afq_estimates_get / fetching comb.
+ *                          Only the ncclSend / ncclRecv transport pays link time for unused capacity
+ *   afq_comm_set_timeout   how long (seconds, > 0) a kernel waits for a peer before it gives up; default 300 s, or
+ *                          AFQ_COMM_TIMEOUT_S from the environment when a communicator is created.  The budget covers
+ *                          whatever may delay one rank between two collectives (rank 0 writing output or restart files,
+ *                          a file-system stall, first-use code loading); it is per process and GPU, not per handle
  *   afq_comm_probe         collective known-answer round through the all-gather, one full slot to and from every peer on
  *                          the configured transport, and the all-reduce; AFQ_ECOMM on any mismatch
  *                          (mismatch_out int64[3], may be NULL: collective values, slot elements, flags that never came)
@@ -320,8 +325,9 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight,
  *   afq_estimates_allreduce  sum over ranks of buf c128[nest] (in/out, host), or with buf == NULL of the
  *                          device accumulators of afq_estimates_update in place (no host round trip; a
  *                          following afq_estimates_get returns the global sums on every rank)
- * A kernel that waits for a peer gives up after 10 s and raises a sticky error, reported as AFQ_ECOMM by the next
- * synchronising call (afq_estimates_get / _end, a fetching afq_popcontrol_comb) -- never a hung device.
+ * A kernel that waits for a peer gives up after the wait budget and raises a sticky error, reported as AFQ_ECOMM by
+ * the next synchronising call (afq_estimates_get / _end, a fetching afq_popcontrol_comb) -- never a hung device.  The
+ * sticky flags and statistics belong to the communicator: creating or destroying one clears them.
  * In-process variant: afq_comm_init_local makes handles[0..n) (one host thread driving several GPUs, or
  * several handles on one GPU) the ranks 0..n-1 of one communicator; the collectives are then the group calls
  * afq_popcontrol_comb_local / afq_estimates_allreduce_local (the kernels and windows of the IPC communicator, the
@@ -336,6 +342,7 @@ int afq_comm_init_ipc(afq_handle *h, int rank, int nranks, afq_allgather_fn allg
 int afq_comm_destroy(afq_handle *h);
 int afq_comm_set_transport(afq_handle *h, int window);
 int afq_comm_set_capacity(afq_handle *h, int max_walkers_per_peer);
+int afq_comm_set_timeout(afq_handle *h, double seconds);
 int afq_comm_probe(afq_handle *h, int64_t *mismatch_out);
 int afq_comm_stats(afq_handle *h, int64_t *out);
 int afq_comm_parent_ix(afq_handle *h, int32_t *parent_ix_global);
@@ -429,6 +436,16 @@ int afq_stream(afq_handle *h, void **stream);
 int afq_kernel_trace(afq_handle *h, int on);
 int afq_kernel_trace_stride(afq_handle *h, int kind, int stride);
 int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int *n_out);
+/* Profile pass over EVERY launch of the library, whatever the configuration dispatches to: afq_launch_trace(h, 1)
+ * clears and starts recording an event pair around each launch (up to 65536), keyed by the name the launch leaves in
+ * the breadcrumb ring (the kernel for plain launches, the launching function for the GEMM engines: k_onebody,
+ * k_vhs_generic ...); (h, 0) stops.  afq_launch_trace_get synchronises and returns, per distinct name, the summed
+ * duration and the number of launches: names_out receives the names back to back, NUL-terminated.  The pairs cost a few
+ * microseconds of bubble per launch: for an extra pass behind a timed region, not for the region itself.
+ * (measurement hook, no reference counterpart)                                                                   */
+int afq_launch_trace(afq_handle *h, int on);
+int afq_launch_trace_get(afq_handle *h, char *names_out, int names_len, double *total_ms, int64_t *launches,
+                         int max_names, int *n_out);
 /* Flops the matrix pipe executed in the LAST launch of a kind: MFMA instructions x their flop count (2048 per
  * v_mfma_f64_16x16x4, 512 per 4x4x4), tile and contraction padding included, a 3-multiplication complex product
  * counted as 3.  issued / time / peak is the utilisation of the pipe; the algorithmic count of SURVEY 8d

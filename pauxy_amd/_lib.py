@@ -106,6 +106,9 @@ SIGNATURES = {
     "afq_comm_probe": [_h, c_void_p],
     "afq_comm_destroy": [_h],
     "afq_comm_set_capacity": [_h, c_int],
+    "afq_comm_set_timeout": [_h, c_double],
+    "afq_launch_trace": [_h, c_int],
+    "afq_launch_trace_get": [_h, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)],
     "afq_comm_stats": [_h, c_void_p],
     "afq_comm_parent_ix": [_h, c_void_p],
     "afq_estimates_allreduce": [_h, _dp, c_int],

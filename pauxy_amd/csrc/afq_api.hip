@@ -177,9 +177,30 @@ static int maybe_build_rH1(afq_handle *h) {
 
 __global__ void afq_marker_kernel(volatile unsigned long long *retired, unsigned long long n) { *retired = n; }
 
+// afq_launch_trace: one event at the head of every launch (name != nullptr) and one behind it (name == nullptr, from
+// afq_post_launch); launches queued without a post in between close their predecessor with their own head event.
+void afq_launch_trace_mark(afq_handle *h, const char *name) {
+    const size_t pairs = h->ltrace_name.size();
+    if (name && pairs >= 65536) return;
+    auto event_at = [&](size_t i) {
+        while (h->ltrace_ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); h->ltrace_ev.push_back(e); }
+        return h->ltrace_ev[i];
+    };
+    if (h->ltrace_open) {            // close the launch in flight
+        hipEventRecord(event_at(2 * pairs - 1), h->stream);
+        h->ltrace_open = false;
+    }
+    if (name) {
+        hipEventRecord(event_at(2 * pairs), h->stream);
+        h->ltrace_name.push_back(name);
+        h->ltrace_open = true;
+    }
+}
+
 hipError_t afq_post_launch(afq_handle *h) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (h->ltrace_open) afq_launch_trace_mark(h, nullptr);
     if (h->debug_markers) {
         unsigned long long *dptr = nullptr;
         if (hipHostGetDevicePointer((void **)&dptr, (void *)h->retired, 0) == hipSuccess)
@@ -246,6 +267,7 @@ int afq_destroy(afq_handle *h) {
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->est_stage) hipHostFree(h->est_stage);
     for (int k = 0; k < AFQ_K_COUNT; ++k) for (hipEvent_t e : h->ktrace_ev[k]) hipEventDestroy(e);
+    for (hipEvent_t e : h->ltrace_ev) hipEventDestroy(e);
     hipStreamDestroy(h->stream);
     delete static_cast<afq_handle_full *>(h);
     return AFQ_OK;
@@ -1196,7 +1218,7 @@ int afq_popcontrol_comb(afq_handle *h, double r, double target_weight, int32_t *
     if (total_weight_out) *total_weight_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h, AFQ_EWEIGHT, "total walker weight below 1e-8");
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "more walkers moved between two ranks than the exchange slots hold");
-    if (sc[6] != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled (waited 10 s on the device)");
+    if (sc[6] != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled (the wait budget of afq_comm_set_timeout ran out on the device)");
     if (!parent_ix) return AFQ_OK;
     if (h->comm) return afq_comm_parent_ix(h, parent_ix);   // the global comb, [nranks * nw]
     return copy_out(h, parent_ix, h->parent_ix, sizeof(int) * h->nw);
@@ -1424,7 +1446,7 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
     if (sc[3] != 0.0) AFQ_FAIL(h, AFQ_EOVERFLOW, "population control: more walkers moved between two ranks than the "
                                                  "exchange slots hold (afq_comm_init capacity)");
     if (sc[6] != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled an all-gather row / walker slots "
-                                             "(waited 10 s on the device)");
+                                             "(the wait budget of afq_comm_set_timeout ran out on the device)");
     return AFQ_OK;
 }
 
@@ -1822,6 +1844,43 @@ int afq_kernel_trace_get(afq_handle *h, int kind, double *ms_out, int max_n, int
         ms_out[i] = f;
     }
     *n_out = h->ktrace_used[kind];
+    return AFQ_OK;
+}
+
+int afq_launch_trace(afq_handle *h, int on) {
+    if (!h) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    if (h->ltrace_open) afq_launch_trace_mark(h, nullptr);
+    if (on) h->ltrace_name.clear();
+    h->ltrace_on = on != 0;
+    return AFQ_OK;
+}
+
+int afq_launch_trace_get(afq_handle *h, char *names_out, int names_len, double *total_ms, int64_t *launches,
+                         int max_names, int *n_out) {
+    if (!h || !n_out || (max_names > 0 && (!names_out || !total_ms || !launches))) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    if (h->ltrace_open) afq_launch_trace_mark(h, nullptr);
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<std::string> names;
+    std::vector<double> ms;
+    std::vector<int64_t> cnt;
+    for (size_t i = 0; i < h->ltrace_name.size(); ++i) {
+        float f = 0;
+        AFQ_HIP(h, hipEventElapsedTime(&f, h->ltrace_ev[2 * i], h->ltrace_ev[2 * i + 1]));
+        size_t k = 0;
+        while (k < names.size() && names[k] != h->ltrace_name[i]) ++k;
+        if (k == names.size()) { names.push_back(h->ltrace_name[i]); ms.push_back(0.0); cnt.push_back(0); }
+        ms[k] += f; cnt[k] += 1;
+    }
+    *n_out = (int)names.size();
+    size_t at = 0;
+    for (int k = 0; k < (int)names.size() && k < max_names; ++k) {
+        if (at + names[k].size() + 1 > (size_t)names_len) AFQ_FAIL(h, AFQ_EINVAL, "afq_launch_trace_get: names buffer too small");
+        memcpy(names_out + at, names[k].c_str(), names[k].size() + 1);
+        at += names[k].size() + 1;
+        total_ms[k] = ms[k]; launches[k] = cnt[k];
+    }
     return AFQ_OK;
 }
 

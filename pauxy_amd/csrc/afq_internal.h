@@ -209,6 +209,11 @@ struct afq_handle {
     double issued_flops[AFQ_K_COUNT] = {0, 0, 0, 0, 0};   // matrix-pipe flops of the last launch of each kind (afq_kernel_issued_flops)
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
     int ktrace_stride[AFQ_K_COUNT] = {1, 1, 1, 1, 1}, ktrace_seen[AFQ_K_COUNT] = {0, 0, 0, 0, 0};   // every n-th launch of a kind is timed
+    // afq_launch_trace: an event pair around EVERY launch, keyed by the launch's breadcrumb name (a profile pass, not
+    // something to leave on inside a timed region)
+    bool ltrace_on = false, ltrace_open = false;
+    std::vector<hipEvent_t> ltrace_ev;
+    std::vector<const char *> ltrace_name;
     cplx *estimates = nullptr;      // [10]
     // Mixed estimator with one_rdm: True (estimators/mixed.py:226-229): G then is per-walker STATE (walker.G: the
     // Green's function the walker last evaluated -- before the step's propagation, or at an energy evaluation),
@@ -285,9 +290,11 @@ inline const char *afq_knob(const char *) { return nullptr; }
 // every kernel launch goes through AFQ_LAUNCH / AFQ_GEMM + AFQ_POST: the name of the kernel is left in the
 // handle's breadcrumb ring before the launch, and AFQ_POST checks the launch (and, in the debug modes,
 // queues a marker or synchronises so that a failing or hanging kernel is identified by name)
+void afq_launch_trace_mark(afq_handle *h, const char *name);      // afq_api.hip
 inline void afq_note_launch(afq_handle *h, const char *name) {
     h->crumb_name[h->n_launch & 63] = name;
     h->n_launch = h->n_launch + 1;
+    if (h->ltrace_on) afq_launch_trace_mark(h, name);
 }
 hipError_t afq_post_launch(afq_handle *h);      // afq_api.hip
 #define AFQ_LAUNCH(h, kern, ...) do { afq_note_launch((h), #kern); hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
@@ -299,9 +306,11 @@ hipError_t afq_post_launch(afq_handle *h);      // afq_api.hip
             return AFQ_EHIP;                                                    \
         }                                                                       \
     } while (0)
-#define AFQ_GEMM(h, call)                                                       \
+#define AFQ_GEMM(h, call) AFQ_GEMM_AS(h, __func__, call)
+// the same with the breadcrumb / launch-trace name chosen by the caller (functions that launch several different GEMMs)
+#define AFQ_GEMM_AS(h, name, call)                                              \
     do {                                                                        \
-        afq_note_launch((h), __func__);                                         \
+        afq_note_launch((h), name);                                             \
         hipError_t e_ = (call);                                                 \
         if (e_ == hipSuccess) e_ = afq_post_launch(h);                          \
         if (e_ != hipSuccess) {                                                 \

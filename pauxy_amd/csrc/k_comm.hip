@@ -27,7 +27,7 @@
 // Ordering without extra barriers: the all-gather of event e completes on a rank only after every rank has
 // contributed, and a rank contributes in stream order AFTER its unpack of event e - 1 -- so when a pack kernel of
 // event e writes into a peer's window, that peer is done reading the slots of event e - 1.  Flags carry the event
-// number (monotonic), a waiting kernel gives up after ~10 s and raises the sticky error scal[6] (AFQ_ECOMM at the next
+// number (monotonic), a waiting kernel gives up after the wait budget (afq_comm_set_timeout, 300 s by default) and raises the sticky error scal[6] (AFQ_ECOMM at the next
 // host synchronisation) instead of hanging the device.
 // More pairs between two ranks than `cap` slots raise the sticky flag scal[3] (AFQ_EOVERFLOW at the next
 // afq_estimates_get); scal[4] keeps the largest run seen.  The window transport sizes cap = nw (a rank owns nw
@@ -53,7 +53,12 @@
 namespace {
 
 constexpr int MAX_RANKS = 16;
-constexpr unsigned long long WAIT_TICKS = 1000000000ull;     // wall_clock64 runs at 100 MHz: 10 s
+// How long a kernel waits for a peer's flag before it gives up and raises the sticky error (never a hung device).  The
+// budget has to cover everything that can legitimately delay ONE rank between two collectives -- rank 0 writing HDF5
+// output or restart files, a file-system stall, first-use code-object loading -- so it is minutes, not seconds, and the
+// caller can set it (afq_comm_set_timeout, AFQ_COMM_TIMEOUT_S).  wall_clock64 runs at 100 MHz.
+constexpr double WAIT_SECONDS_DEFAULT = 300.0;
+__device__ unsigned long long g_wait_ticks = (unsigned long long)(WAIT_SECONDS_DEFAULT * 1e8);
 
 struct RcclApi {
     void *lib = nullptr;
@@ -172,12 +177,13 @@ afq_comm_state *cs_of(afq_handle *h) { return (afq_comm_state *)h->comm; }
 __device__ inline void flag_release(unsigned long long *flag, unsigned long long v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// waits until *flag >= v; false after WAIT_TICKS (the peer never wrote: error, not a hang)
+// waits until *flag >= v; false after the wait budget (the peer never wrote: error, not a hang)
 __device__ inline bool flag_wait(const unsigned long long *flag, unsigned long long v) {
     const unsigned long long t0 = wall_clock64();
+    const unsigned long long budget = g_wait_ticks;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > WAIT_TICKS) return false;
+        if (wall_clock64() - t0 > budget) return false;
     }
     return true;
 }
@@ -432,7 +438,10 @@ __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
 // it can neither send nor receive more in one event.  The fixed-size ncclSend / ncclRecv transport pays for every slot
 // of the capacity on every link, so it starts at the same safe bound and Walkers.tune_exchange_capacity shrinks it once
 // there is history.
-int default_cap(int nw) { return std::max(1, nw); }
+// Above 512 walkers per rank the windows are sized for a quarter of the population per peer (a comb moves a handful of
+// walkers; nw slots per peer would be 330 MB per rank at the bench shape and several GB at 2048 walkers per rank), with the
+// overflow flag scal[3] as the guard; afq_comm_set_capacity overrides.
+int default_cap(int nw) { return nw <= 512 ? std::max(1, nw) : std::max(512, nw / 4); }
 
 void close_peer_windows(afq_comm_state *c) {
     for (int p = 0; p < MAX_RANKS; ++p) {
@@ -479,6 +488,9 @@ int alloc_window(afq_handle *h, afq_comm_state *c, size_t bytes) {
         c->win_kind = 3;
     }
     AFQ_HIP(h, hipMemset(p, 0, bytes));
+    // the zeroes must be in memory before the handle is published: a peer's first flag write is ordered against this
+    // memset by nothing but the host bootstrap that follows
+    AFQ_HIP(h, hipDeviceSynchronize());
     c->win = p;
     return AFQ_OK;
 }
@@ -525,7 +537,7 @@ int exchange_windows(afq_handle *h) {
         hipFree(c->win); c->win = nullptr;
         void *p = nullptr;
         if (hipMalloc(&p, (size_t)c->wl.bytes) == hipSuccess && hipMemset(p, 0, (size_t)c->wl.bytes) == hipSuccess &&
-            hipIpcGetMemHandle(&mine.handle, p) == hipSuccess) { c->win = p; c->win_kind = 3; mine.kind = 3; }
+            hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(&mine.handle, p) == hipSuccess) { c->win = p; c->win_kind = 3; mine.kind = 3; }
         else { (void)hipGetLastError(); if (p) hipFree(p); mine.ok = 0; }
     }
     for (int p = 0; p < MAX_RANKS; ++p) { c->pw.base[p] = nullptr; c->peer_opened[p] = false; }
@@ -806,9 +818,22 @@ int sendrecv_slots(afq_handle *h, RcclApi *api) {
 
 int k_comm_size(afq_handle *h) { return h->comm ? cs_of(h)->nranks : 1; }
 
+// scal[3..8] belong to the communicator (overflow flag, largest run, events, sticky error, walkers / bytes sent): a new
+// communicator -- or the host-mediated path after a failed candidate -- must not inherit the previous one's sticky flags
+static void clear_comm_scalars(afq_handle *h) {
+    if (h->scal) { (void)hipMemset(h->scal + 3, 0, 6 * sizeof(double)); h->scal_cache_valid = false; }
+}
+
+static int set_wait_budget(double seconds) {
+    if (!(seconds > 0.0)) return AFQ_EINVAL;
+    const unsigned long long ticks = (unsigned long long)std::min(seconds * 1e8, 9.0e17);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks)) == hipSuccess ? AFQ_OK : AFQ_EHIP;
+}
+
 void k_comm_destroy(afq_handle *h) {
     afq_comm_state *c = cs_of(h);
     if (!c) return;
+    clear_comm_scalars(h);
     free_buffers(c);
     if (c->nccl) { RcclApi *api = rccl_api(); if (api) api->CommDestroy(c->nccl); }
     if (c->ev) hipEventDestroy(c->ev);
@@ -853,6 +878,9 @@ int afq_comm_unique_id(void *id_out) {
 
 static int comm_attach(afq_handle *h, afq_comm_state *c) {
     h->comm = c;
+    clear_comm_scalars(h);
+    const char *env = getenv("AFQ_COMM_TIMEOUT_S");
+    if (env && atof(env) > 0.0 && set_wait_budget(atof(env)) != AFQ_OK) AFQ_FAIL(h, AFQ_EHIP, "could not set the communicator's wait budget");
     if (h->nw) {    // walker.total_weight starts as the size of the whole population (walkers/handler.py:164)
         const double tw0 = (double)h->nw * c->nranks;
         AFQ_HIP(h, hipMemcpy(h->scal, &tw0, sizeof(double), hipMemcpyHostToDevice));
@@ -915,6 +943,16 @@ int afq_comm_destroy(afq_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     k_comm_destroy(h);
+    return AFQ_OK;
+}
+
+int afq_comm_set_timeout(afq_handle *h, double seconds) {
+    if (!h) return AFQ_EINVAL;
+    hipSetDevice(h->device);
+    AFQ_HIP(h, hipStreamSynchronize(h->stream));
+    const int rc = set_wait_budget(seconds);
+    if (rc == AFQ_EINVAL) AFQ_FAIL(h, AFQ_EINVAL, "afq_comm_set_timeout: seconds must be positive");
+    if (rc) AFQ_FAIL(h, rc, "afq_comm_set_timeout: hipMemcpyToSymbol failed");
     return AFQ_OK;
 }
 
@@ -1024,7 +1062,7 @@ int afq_popcontrol_comb_local(afq_handle **hs, int n, double r, double target, i
     if (total_out) *total_out = sc[0];
     if (sc[1] < 0) AFQ_FAIL(h0, AFQ_EWEIGHT, "total walker weight below 1e-8");
     if (sc[3] != 0.0) AFQ_FAIL(h0, AFQ_EOVERFLOW, "more walkers moved between two ranks than the exchange slots hold");
-    if (sc[6] != 0.0) AFQ_FAIL(h0, AFQ_ECOMM, "communicator: a rank never signalled (waited 10 s on the device)");
+    if (sc[6] != 0.0) AFQ_FAIL(h0, AFQ_ECOMM, "communicator: a rank never signalled (the wait budget of afq_comm_set_timeout ran out on the device)");
     return AFQ_OK;
 }
 
@@ -1079,7 +1117,7 @@ int afq_estimates_allreduce(afq_handle *h, double *buf, int nest) {
     if (c->win_collectives) {       // a flag that never came leaves garbage in buf: report it here, this call synchronises anyway
         double err = 0.0;
         AFQ_HIP(h, hipMemcpy(&err, h->scal + 6, sizeof(double), hipMemcpyDeviceToHost));
-        if (err != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled its estimator row (waited 10 s on the device)");
+        if (err != 0.0) AFQ_FAIL(h, AFQ_ECOMM, "communicator: a peer rank never signalled its estimator row (the wait budget of afq_comm_set_timeout ran out on the device)");
     }
     return AFQ_OK;
 }

@@ -429,6 +429,10 @@ class AfqDevice(object):
     def comm_set_capacity(self, cap):
         self._ck(self.lib.afq_comm_set_capacity(self.h, int(cap)))
 
+    def comm_set_timeout(self, seconds):
+        """Wait budget of the kernels that wait for a peer (default 300 s; AFQ_COMM_TIMEOUT_S)."""
+        self._ck(self.lib.afq_comm_set_timeout(self.h, float(seconds)))
+
     def comm_probe(self):
         """Collective known-answer round (all-gather, one slot per peer, all-reduce); raises AfqError(AFQ_ECOMM)."""
         bad = numpy.zeros(3, dtype=numpy.int64)
@@ -508,6 +512,26 @@ class AfqDevice(object):
         n = ctypes.c_int()
         self._ck(self.lib.afq_kernel_trace_get(self.h, int(kind), _p(out), max_n, ctypes.byref(n)))
         return out[:min(n.value, max_n)]
+
+    def launch_trace(self, on=True):
+        """Event pairs around every launch, keyed by name (afq_launch_trace): a profile pass."""
+        self._ck(self.lib.afq_launch_trace(self.h, int(bool(on))))
+
+    def launch_trace_get(self):
+        """{name: (launches, total ms)} of the launches recorded since launch_trace(True)."""
+        cap = 256
+        names = ctypes.create_string_buffer(cap * 96)
+        ms = numpy.zeros(cap, dtype=numpy.float64)
+        cnt = numpy.zeros(cap, dtype=numpy.int64)
+        n = ctypes.c_int()
+        self._ck(self.lib.afq_launch_trace_get(self.h, ctypes.cast(names, ctypes.c_void_p), len(names), _p(ms), _p(cnt),
+                                               cap, ctypes.byref(n)))
+        out, at = {}, 0
+        for k in range(min(n.value, cap)):
+            end = names.raw.index(b'\0', at)
+            out[names.raw[at:end].decode()] = (int(cnt[k]), float(ms[k]))
+            at = end + 1
+        return out
 
     def kernel_issued_flops(self, kind):
         """Matrix-pipe flops of the last launch of ``kind`` (padding included, 3M products counted as 3)."""

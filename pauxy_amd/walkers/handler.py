@@ -584,7 +584,7 @@ class Walkers(object):
         """Device communicator with the fixed-size ncclSend / ncclRecv transport only (the window transport moves live
         slots and keeps the capacity that cannot overflow): size the per-peer exchange slots from the largest transfer
         seen so far -- four times that + 8, at least 32, at most nw.  The capacity STARTS at nw (what a rank owns: no
-        overflow before there is history) and shrinks only after 4 events (every slot of the capacity crosses the link at
+        overflow before there is history) and shrinks only after 20 events (every slot of the capacity crosses the link at
         every event on this transport: nw slots of 160 KB to each of 7 peers are 290 MB per event at the bench sizes); an
         overflow aborts the run, spare slots only cost link time.  Called at block boundaries, right behind the block's host sync; every rank computes the same
         global comb, hence the same statistic and the same new capacity (send and receive sizes must agree)."""
@@ -594,7 +594,7 @@ class Walkers(object):
         if st['window']:
             return
         want = min(self.nw, max(32, 4 * st['max_transfer'] + 8))
-        if want > st['capacity'] or (st['events'] >= 4 and want < 0.6 * st['capacity']):
+        if want > st['capacity'] or (st['events'] >= 20 and want < 0.6 * st['capacity']):
             self.dev.comm_set_capacity(want)
 
     def _pop_control_distributed(self, comm):

@@ -170,7 +170,7 @@ def test_c2_c4_run_batched_equals_run(make):
                 # every walker alive: Slater matrices and overlaps bit-equal over all 20 steps; the block sums of the two
                 # loops are the same terms in another association (the per-walker loop adds every step on the host), so
                 # the shift derived from block 1 differs in its last bit (E ~ +700) and with it, from step 11 on, the
-                # weights and the hybrid energies (one ulp: tools/dbg_c4_batched3.py)
+                # weights and the hybrid energies (one ulp)
                 assert numpy.array_equal(a[key][:10], other[key][:10]), key
                 if key == 'ot':
                     assert numpy.array_equal(a[key], other[key]), key
@@ -181,7 +181,7 @@ def test_c2_c4_run_batched_equals_run(make):
                 # first block (E ~ +700 on this lattice) takes every walker below the 1e-8 threshold from step 8 to 10: the
                 # per-walker loop then has nothing to propagate and makes no call, the batched loop queues its step, whose
                 # closing Green's function evaluation sees the freshly re-orthogonalised walkers (Ghalf of phi R^-1
-                # instead of the one kept across the QR: 1e-15, tools/dbg_c4_batched2.py); the comb revives the
+                # instead of the one kept across the QR: 1e-15); the comb revives the
                 # population and the difference spreads at rounding level
                 assert numpy.array_equal(a[key][:10], other[key][:10]), key
                 close(a[key], other[key], 1e-11)

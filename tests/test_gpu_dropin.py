@@ -33,7 +33,7 @@ def test_object_graph_survives_the_reference_serialise(golden, monkeypatch, tmp_
         shell.propagators.propagate_walker(w, shell.system, shell.trial, 0.0)
     shell.psi.pop_control(comm)
     shell.estimators.update(shell.system, shell.qmc, shell.trial, shell.psi, 1, False)
-    dropin_checks.check_serialisable(shell)
+    dropin_checks.check_serialisable(shell, fresh=False)
     release_context(shell.system, shell.trial)
 
 

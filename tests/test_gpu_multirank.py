@@ -214,15 +214,23 @@ def test_device_comb_over_ipc_windows_two_processes():
     check_ipc(one, a, b)
 
 
-def test_device_comb_over_ipc_windows_four_processes():
-    """More than one peer per rank: four processes on the one GPU, every rank maps three windows, the comb's walkers go to
-    whichever rank the global plan names (one flag and one ticket counter per peer), the weights all-gather and the block
-    reduction run over four windows.  Must equal the single-rank run with four times the walkers."""
-    nr = 4
+def check_many(nr, bench_mode=False):
     one = single_rank(nr)
     outs = many_ranks(nr, {'device_comm': 'ipc'})
     from pauxy_amd.walkers.handler import comb_pairs
     assert all(o['device_comm'] and o['device_comm_kind'] == 'ipc' for o in outs)
+    got_phi = numpy.concatenate([o['phi'] for o in outs])
+    assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
+    assert outs[0]['blocks'].shape == one['blocks'].shape
+    assert numpy.max(numpy.abs(outs[0]['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
+    if one['rdm'] is not None:
+        assert numpy.max(numpy.abs(outs[0]['rdm'] - one['rdm'])) <= 1e-9 * numpy.max(numpy.abs(one['rdm']))
+    for o in outs:
+        st = o['comm_stats']
+        assert st['kind'] == 'ipc' and st['window'] == 1 and st['error'] == 0 and st['overflow'] == 0 and st['size'] == nr
+    if bench_mode:          # nothing was read back at the combs: only the totals can be checked
+        assert sum(o['comm_stats']['walkers_sent'] for o in outs) > 0
+        return
     assert (one['pix'] > 1).any() and (one['pix'] == 0).any()
     for o in outs:
         assert numpy.array_equal(o['pix'], one['pix'])
@@ -230,19 +238,122 @@ def test_device_comb_over_ipc_windows_four_processes():
         got = numpy.concatenate([o[key] for o in outs], axis=1)
         assert got.shape == one[key].shape
         assert numpy.max(numpy.abs(got - one[key])) <= 1e-9 * max(1.0, numpy.max(numpy.abs(one[key]))), key
-    got_phi = numpy.concatenate([o['phi'] for o in outs])
-    assert numpy.max(numpy.abs(got_phi - one['phi'])) <= 1e-9
-    assert numpy.max(numpy.abs(outs[0]['blocks'][:, 1:10] - one['blocks'][:, 1:10])) <= 1e-9 * numpy.max(numpy.abs(one['blocks'][:, 1:10]))
-    if one['rdm'] is not None:
-        assert numpy.max(numpy.abs(outs[0]['rdm'] - one['rdm'])) <= 1e-9 * numpy.max(numpy.abs(one['rdm']))
     total = 0
     for rank, o in enumerate(outs):
-        st = o['comm_stats']
-        assert st['kind'] == 'ipc' and st['window'] == 1 and st['error'] == 0 and st['overflow'] == 0 and st['size'] == nr
         sent = sum(1 for pix in one['pix'] for c, k in comb_pairs(pix) if c // NW == rank and k // NW != rank)
-        assert st['walkers_sent'] == sent
+        assert o['comm_stats']['walkers_sent'] == sent
         total += sent
     assert total > 0
+
+
+def test_device_comb_over_ipc_windows_four_processes():
+    """More than one peer per rank: four processes on the one GPU, every rank maps three windows, the comb's walkers go to
+    whichever rank the global plan names (one flag and one ticket counter per peer), the weights all-gather and the block
+    reduction run over four windows.  Must equal the single-rank run with four times the walkers."""
+    check_many(4)
+
+
+def test_device_comb_over_ipc_windows_eight_processes():
+    """The rank count of the node the scaling bench runs on: eight processes (here all on the one GPU), seven mapped
+    windows per rank, 48 walkers in all.  Must equal the single-rank run with eight times the walkers, comb decisions
+    and per-rank traffic included."""
+    check_many(8)
+
+
+def test_eight_processes_bench_mode_overlapped_block_boundary(monkeypatch):
+    """Eight ranks driven exactly as bench.py --gpus 8 drives them: no per-step callback, nothing read back at the comb,
+    estimator terms riding on the weight updates, the head of the next block queued before the window-reduced sums of the
+    block are waited for."""
+    monkeypatch.setenv('AFQ_TEST_ONE_RDM', '0')
+    monkeypatch.setenv('AFQ_TEST_NO_CALLBACK', '1')
+    check_many(8, bench_mode=True)
+
+
+def _timeout_worker(rank, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+        import time
+        import torch
+        import torch.distributed as dist
+        from pauxy_amd import _lib as L
+        from pauxy_amd.comm import TorchComm
+        from pauxy_amd.context import get_context
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        comm = TorchComm(device=torch.device('cpu'))
+        s, t = build()
+        dev = get_context(s, t).dev
+        dev.walkers_alloc(NW)
+        dev.set(L.F_PHI, numpy.broadcast_to(t.psi, (NW,) + t.psi.shape).copy())
+        dev.set(L.F_OT, dev.calc_overlap())
+
+        def allgather_bytes(mine):
+            send = numpy.frombuffer(mine, dtype=numpy.uint8).astype(numpy.float64)
+            recv = numpy.zeros(comm.size * send.size)
+            comm.Allgather(send, recv)
+            return recv.astype(numpy.uint8).tobytes()
+
+        dev.comm_init_ipc(rank, 2, allgather_bytes)
+        dev.comm_probe()
+        dev.comm_set_timeout(0.5)
+        out = {}
+        if rank == 0:
+            # the peer never enters this population control: the plan kernel must give up after the budget, not hang
+            t0 = time.time()
+            dev.popcontrol_comb(0.3, 2 * NW, fetch=False)
+            dev.estimates_update(False)
+            try:
+                dev.estimates_get(zero=True)
+                out['first'] = 'no error'
+            except L.AfqError as e:
+                out['first'] = e.code
+            out['waited'] = time.time() - t0
+        comm.barrier()
+        # tear down on both ranks: the sticky flag belongs to the communicator that raised it
+        dev.comm_destroy()
+        dev.reset_weights()
+        dev.estimates_update(False)
+        dev.estimates_get(zero=True)                   # must not report the old communicator's error
+        out['after_destroy'] = 'ok'
+        # a fresh communicator on the same handles works, with clean statistics
+        dev.comm_init_ipc(rank, 2, allgather_bytes)
+        dev.comm_probe()
+        dev.comm_set_timeout(30.0)
+        pix, total = dev.popcontrol_comb(0.3, 2 * NW)
+        dev.estimates_update(False)
+        dev.estimates_get(zero=True)
+        st = dev.comm_stats()
+        out.update(events=st['events'], error=st['error'], total=total)
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+
+
+def test_wait_budget_is_configurable_and_sticky_flags_die_with_their_communicator():
+    """a rank whose peer never shows up gives up after the configured budget (afq_comm_set_timeout: 0.5 s here,
+    300 s by default) with AFQ_ECOMM at the next host synchronisation; destroying the communicator clears the sticky
+    flag, and a new communicator on the same handles starts clean."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict(q.get(timeout=300) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    for rank in (0, 1):
+        assert isinstance(res[rank], dict), res[rank]
+        assert res[rank]['after_destroy'] == 'ok' and res[rank]['error'] == 0 and res[rank]['events'] == 1
+        assert abs(res[rank]['total'] - 2 * NW) < 1e-9
+    assert res[0]['first'] == -8                        # AFQ_ECOMM
+    assert 0.4 < res[0]['waited'] < 20.0
 
 
 def test_device_communicator_falls_through_to_ipc_windows():

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 i=0
 for envs in "$@"; do
   i=$((i+1))
-  ( export $envs; rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$i -o c5 -- python3 tools/bench_configs.py C5sd > $out/run$i.json 2> $out/run$i.err )
+  ( export $envs; rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$i -o c5 -- python3 bench.py --config C5sd --no-cpu-baseline > $out/run$i.json 2> $out/run$i.err )
   f=$(ls $out/p$i/*kernel_stats.csv $out/p$i/*/*kernel_stats.csv 2>/dev/null | head -1)
   echo "[$envs] $(cut -c1-140 $out/run$i.json | grep -o '"ms_per_step": [0-9.]*')"
   grep -E "TaylorProb|OneBodyProb" $f | cut -d, -f1-4 | cut -c1-150

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 i=0
 for envs in "$@"; do
   i=$((i+1))
-  ( export $envs; rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$i -o p -- python3 tools/bench_configs.py $cfg > $out/run$i.json 2> $out/run$i.err )
+  ( export $envs; rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$i -o p -- python3 bench.py --config $cfg --no-cpu-baseline > $out/run$i.json 2> $out/run$i.err )
   f=$(ls $out/p$i/*kernel_stats.csv $out/p$i/*/*kernel_stats.csv 2>/dev/null | head -1)
   echo "[$envs] $(grep -o '"ms_per_step": [0-9.]*' $out/run$i.json)"
   python3 - "$f" "$pat" <<'PY'

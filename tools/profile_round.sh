@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the profile evidence of a round on the GPU box (rocprofv3): kernel-trace statistics of bench.py and of every
-# BASELINE configuration through tools/bench_configs.py, and the HBM-side traffic counters (separate --pmc passes, as
+# BASELINE configuration through bench.py --config, and the HBM-side traffic counters (separate --pmc passes, as
 # MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass) for bench.py and the UEG configuration.
 #   bash tools/profile_round.sh <tag>       -> gpurun_out/<tag>/...
 out=gpurun_out/${1:-prof}
@@ -18,9 +18,9 @@ run_pmc() {     # name, counter, command...
   f=$(ls $out/${name}_$ctr/*counter_collection.csv $out/${name}_$ctr/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/pmc_csv.py $f > $out/${name}_pmc_$ctr.txt
 }
 run_stats bench_c3 python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline
-for c in C1 C2 C4 C5sd C5; do run_stats cfg_$c python3 tools/bench_configs.py $c; done
+for c in C1 C2 C4 C5sd C5; do run_stats cfg_$c python3 bench.py --config $c --no-cpu-baseline; done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   run_pmc bench_c3 $ctr python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
-  run_pmc cfg_C2 $ctr python3 tools/bench_configs.py C2
+  run_pmc cfg_C2 $ctr python3 bench.py --config C2 --no-cpu-baseline
 done
 ls $out

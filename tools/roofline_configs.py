@@ -3,7 +3,7 @@
 
   python tools/roofline_configs.py gpurun_out/<tag> > profiles/rNN_configs_roofline.json
 
-For every BASELINE configuration: throughput (the JSON line tools/bench_configs.py printed under the profiler) and, for
+For every BASELINE configuration: throughput (the JSON line bench.py --config printed under the profiler) and, for
 its top kernels, the algorithmic work per launch (flops with 4 per real-by-complex and 8 per complex MAC, or bytes for
 the gather kernels: SURVEY 8d conventions), the average duration rocprofv3 measured, and two fractions of the fp64 MFMA
 peak (78.6 TFLOP/s):
