@@ -5,8 +5,9 @@
 Output file (handler.py:60-71,117-124): ``<basename>.<index>.h5`` (or ``filename``),
 created empty by the root rank, ``metadata`` = JSON description of the run; as in
 the reference the default is ``estimates.<index>.h5`` in the working directory.
-Opting out: ``estimators: {write_file: False}`` (or ``AFQ_ESTIMATES_FILE=0`` in the
-environment, for harnesses that only want the in-memory rows ``Mixed.blocks``)."""
+Opting out: ``estimators: {write_file: False}``, or ``AFQ_ESTIMATES_FILE=0`` in the
+environment for harnesses that only want the in-memory rows ``Mixed.blocks`` (the
+variable only changes the default: a run that names its file still gets it)."""
 import os
 
 from pauxy_amd.estimators.back_propagation import BackPropagation
@@ -30,7 +31,8 @@ class Estimators(object):
         self.index = opts.get('index', 0)
         self.basename = opts.get('basename', 'estimates')                    # handler.py:62
         self.flush_every = opts.get('flush_every')
-        write = opts.get('write_file', os.environ.get('AFQ_ESTIMATES_FILE', '1') != '0')
+        named = opts.get('filename') is not None or 'basename' in opts
+        write = opts.get('write_file', named or os.environ.get('AFQ_ESTIMATES_FILE', '1') != '0')
         name = opts.get('filename') if (root and write) else None
         if root and write and name is None:
             # first free slot of the series unless overwriting is allowed (handler.py:63-69)

@@ -73,7 +73,7 @@ def test_multi_determinant_trial_energy(golden):
     """variational_energy_multi_det (estimators/mixed.py:292-343) through the device full-G energy, against the same sum
     evaluated with the oracle's full-G Cholesky energy."""
     d = golden('msd_ops.npz')
-    tag = 'PL_'
+    tag = 'N_'                                          # the non-orthogonal expansion (get_random_nomsd)
     na, nb = [int(x) for x in d['nelec']]
     h1e = d['h1e']
     s = systems.Generic((na, nb), numpy.array([h1e, h1e]), d['chol'], float(d['ecore']))
