@@ -572,11 +572,17 @@ static int launch_exx_quadratic(afq_handle *h) {
             };
             h->issued_flops[AFQ_K_EXCHANGE] = mfma_gemm_wg_issued_flops<2, 2, 2, 2, ExxQProb<RC>, RC>(p, klen);
         }
-        if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        // round 4: four compute waves with 2 x 2 tiles + four loader waves (STAG = 3: the ring refill kept out of the waves
+        // that issue MFMAs; see the HS-potential GEMM in k_gemm.hip): 155 -> 139 us per evaluation at C3 against the eight
+        // compute waves with 1 x 2 tiles that refill the ring themselves (cfg 9, the round-3 choice)
+        if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
 #ifdef AFQ_TUNING
         else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
         else if (cfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        else if (cfg == 7) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        else if (cfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
 #endif
         else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD, RC>(p, h->stream, h->zero_page)));

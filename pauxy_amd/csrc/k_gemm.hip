@@ -288,9 +288,17 @@ static int force_bias_generic_impl(afq_handle *h) {
 #ifdef AFQ_TUNING
                 if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
                 else if (afq_knob("AFQ_GEMM_STAG1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 1>(p, h->stream, h->zero_page)));
+                else if (afq_knob("AFQ_FB_LOADER")) {
+                    const int v = atoi(afq_knob("AFQ_FB_LOADER"));
+                    if (v == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                    else if (v == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 4, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                }
+                else if (afq_knob("AFQ_FB_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
                 else
 #endif
-                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
+                // round 4: the ring refill on eight loader waves of its own (STAG = 3; see the HS-potential GEMM): 32.9 -> 31.8 us
+                AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
             }
             else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
@@ -386,6 +394,14 @@ static void gemm_ts_dump(afq_handle *h, const char *what) {
 int k_vhs_generic(afq_handle *h) {
 #ifdef AFQ_TUNING
     struct Dump { afq_handle *h; ~Dump() { gemm_ts_dump(h, "after VHS"); } } dump_{h};
+    // timing ablations of the ring loop (mfma_gemm_wg.h: afq_gemm_abl), for this GEMM only: set and cleared in stream order
+    static const int vhs_abl = afq_knob("AFQ_VHS_ABL") ? atoi(afq_knob("AFQ_VHS_ABL")) : 0;
+    static const int abl_zero = 0;
+    struct Abl {
+        afq_handle *h;
+        Abl(afq_handle *h_) : h(h_) { if (vhs_abl) hipMemcpyToSymbolAsync(HIP_SYMBOL(afq_gemm_abl), &vhs_abl, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
+        ~Abl() { if (vhs_abl) hipMemcpyToSymbolAsync(HIP_SYMBOL(afq_gemm_abl), &abl_zero, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
+    } abl_guard_{h};
 #endif
     VhsProb p;
     p.batch = 1; p.rows = h->nw; p.cols = h->hs_sym ? h->M * (h->M + 1) / 2 : h->M * h->M; p.kdim = h->K;
@@ -410,7 +426,15 @@ int k_vhs_generic(afq_handle *h) {
             static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
 #ifdef AFQ_TUNING
             if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_LOADER")) {
+                const int v = atoi(afq_knob("AFQ_VHS_LOADER"));
+                if (v == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+            }
             else if (afq_knob("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_VHS_RREG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
@@ -420,7 +444,16 @@ int k_vhs_generic(afq_handle *h) {
 #endif
             if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
             else if (xmap) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_VHS_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            // Round 4: four LOADER waves beside the four compute waves (STAG = 3) and the column panels pinned to XCDs.
+            // Timing ablations of the plain loop (tools/vhs_ablate.sh, cycles per chunk of 8 contraction indices at C3):
+            // 1938 as it was = 1385 for the 20 MFMAs alone + 790 for refill, fragment reads and barrier alone, of which
+            // only 240 overlapped -- an LDS-DMA instruction holds its wave's instruction issue for 100+ cycles, and a wave
+            // that is alone on its SIMD idles the matrix pipe meanwhile, wherever in the loop the refill sits (the
+            // pipelined loop: 1882).  With the refill on waves of its own: 1611, 59.0 -> 52.2 us.  The XCD map makes the
+            // eight row tiles of a column panel share one L2: HBM-side fetch 160 -> 38 MB per launch
+            // (profiles/r04_vhs_variants.txt), no effect on the time by itself.
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
             h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 1, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
         }
         else if (cfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));

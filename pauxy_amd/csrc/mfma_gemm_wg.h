@@ -40,6 +40,12 @@ template <class P> struct gemm_incr<P, decltype((void)P::INCR)> { static constex
 #ifdef AFQ_TUNING
 // tuning builds: when set (hipMemcpyToSymbol), work-groups 0-63 of every ring GEMM leave their s_memtime phases here
 __device__ unsigned long long *afq_gemm_ts = nullptr;
+// tuning builds: timing ablations of the plain chunk loop (WRONG results): bit 0 no MFMAs, bit 1 no ring refill,
+// bit 2 no fragment reads, bit 3 no chunk barrier, bit 4 no output stores
+__device__ int afq_gemm_abl = 0;
+#define GEMM_UNLESS(bits) if (!(abl & (bits)))
+#else
+#define GEMM_UNLESS(bits)
 #endif
 // optional problem trait: static constexpr bool KCUT = true -- kcut(b, col0, ncols) is the contraction length the work-group
 // tile at columns [col0, col0 + ncols) of batch b needs (<= kdim; B is zero beyond it for these columns: triangular B)
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     };
 
 #ifdef AFQ_TUNING
+    const int abl = afq_gemm_abl;
     const unsigned long long ts1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // STAG == 4: the ring is refilled THROUGH REGISTERS (global_load_dwordx4, ds_write_b128 one chunk later) instead of by
@@ -501,9 +508,12 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     } else
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+        GEMM_UNLESS(8)
         __builtin_amdgcn_s_barrier();
+        GEMM_UNLESS(2)
         issue(c + D - 1, (c + D - 1) & (D - 1));
         const unsigned sl0 = ring_l + (c & (D - 1)) * CHUNK;
+        GEMM_UNLESS(4)
         read_sub(sl0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
             read_sub(sl0, KC - 1);                         // in flight under the MFMAs of the first half
             __builtin_amdgcn_sched_barrier(0);
         }
+        GEMM_UNLESS(1)
         mfma_sub(0);
         if (KC == 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -565,6 +576,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
             for (int r = 0; r < 4; ++r) {
                 const int row = wrow0 + i * 16 + lk + 4 * r;
                 const int col = wcol0 + j * 16 + lr;
+                GEMM_UNLESS(16)
                 if (row < p.rows && col < p.cols) p.store(b, row, col, accR[i][j][r], accI[i][j][r]);
             }
     if constexpr (gemm_coldot<P>::value) {
