@@ -333,7 +333,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
         if (afq_knob("AFQ_OVLP_CFG")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else
 #endif
-        AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         return AFQ_OK;
     };
     {
@@ -364,7 +365,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
             if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else
 #endif
-            AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
             return AFQ_OK;
         };
         // Hubbard, the walkers' own Ghalf, shared single-determinant trial: the diagonal of G comes along
@@ -625,7 +627,8 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
-            AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         }
         {
             CholArgs a;
@@ -640,7 +643,8 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
-            AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         }
     }
     AFQ_LAUNCH(h, qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,

@@ -562,7 +562,8 @@ static int launch_exx_quadratic(afq_handle *h) {
     p.E = h->exq_y;
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
-    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : (S > 1 ? 1 : 0);
+    // (round 4: the loader-wave configuration for long contractions too: C5 sizes 6.63 -> 6.36 ms per evaluation)
+    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : 1;
     {
         KernelTrace kt(h, AFQ_K_EXCHANGE);
         {   // every configuration below multiplies 64 x 64 work-group tiles; the contraction of a tile is its KCUT length

@@ -111,9 +111,22 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // 128 x 128 tiles (two 16-row and four 16-column MFMA tiles per wave, pipelined loop) when they pad no more than the
         // smaller shapes: twice the MFMAs per chunk and barrier (C4, 256 x 256 per walker: 302 -> 272 us, 1.84 -> 1.77 ms per step)
         const long padC = (long)((M + 127) / 128) * 128 * ((ns + 127) / 128) * 128;
-        if (padC <= padA && padC <= padB) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
-        else if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
-        else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+#ifdef AFQ_TUNING
+        const int ocfg = afq_knob("AFQ_OB_CFG") ? atoi(afq_knob("AFQ_OB_CFG")) : 0;
+        if (ocfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (ocfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 8, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (ocfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else
+#endif
+        if (afq_knob("AFQ_OB_NOLOADER")) {
+            if (padC <= padA && padC <= padB) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            else if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        }
+        // round 4: 64 x 64 tiles on four compute waves (2 x 2 MFMA tiles each) + four loader waves that do nothing but the
+        // ring refill (STAG = 3): C4 (256 x 256 per walker, real BH1) 338 -> 300 us against the 128 x 128 tiles above, C5
+        // sizes (400 x 100) 444 -> 384 us against 64 x 128; the small tile also pads least
+        else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
         q.batch = p.batch; q.rows = p.rows; q.cols = p.cols; q.kdim = p.kdim; q.nt = p.nt; q.off = p.off;
@@ -539,6 +552,9 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                 else if (tcfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 2, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 else if (tcfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                 else if (tcfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                else if (tcfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+                else if (tcfg == 7) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 8, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+                else if (tcfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                 else
 #endif
                 {
@@ -546,8 +562,12 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                     // half-chunk pipelined loop (C5, 400 x 100: 813 -> 683 us per product)
                     const long padA = (long)((M + 127) / 128) * 128 * ((p.cols + 63) / 64) * 64;
                     const long padB = (long)((M + 63) / 64) * 64 * ((p.cols + 127) / 128) * 128;
-                    if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
-                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                    if (afq_knob("AFQ_TAYLOR_NOLOADER")) {
+                        if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                        else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+                    }
+                    // round 4: 64 x 64 tiles, four compute + four loader waves (STAG = 3; see k_vhs_generic): C5 sizes 689 -> 627 us
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                 }
                 continue;
             }

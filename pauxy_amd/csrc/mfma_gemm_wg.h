@@ -375,6 +375,10 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     }
     if constexpr (STAG == 4) {
     } else
+#ifdef AFQ_TUNING
+    if (STAG == 3 && (abl & 32) && !loader) __builtin_amdgcn_s_setprio(3);       // experiment: compute waves first
+    if (STAG == 3 && (abl & 64) && loader) __builtin_amdgcn_s_setprio(3);        // experiment: loader waves first
+#endif
     if (STAG == 3 && loader) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
