@@ -62,6 +62,10 @@ struct PropFusedArgs {
     int same_b;                 // BH1[0] == BH1[1]: one one-body pass serves both spins
     int b_real;                 // BH1 is real: one-body products take 2 real multiplications instead of 3
     int rem4;                   // M <= 100 in the full 7-row-tile deal: rows 96.. as one 4x4x4 unit (see taylor)
+    int hyb;                    // > 0: a column slot with at most 4 * hyb <= 12 live columns is multiplied as hyb units of
+                                // 16 rows x 4 columns on v_mfma_f64_4x4x4 (see taylor_h)
+    int contig;                 // the columns of T are the na + nb columns of the walker back to back (slot = column / 16)
+                                // instead of two slots per spin: every matrix of the chain acts on both spins alike
     const cplx *BH1;            // [2, M, M]
     const cplx *vhs;            // [nw, M, M]
     cplx *phi;                  // [nw, M, nt], updated in place
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     PF_UNLESS((32 | 128))
     for (int e = tid; e < NCH * 512; e += PF_NT) {
         const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
-        const int p = ch * 8 + 2 * kk + pb, sp = slot >> 1, col = (slot & 1) * 16 + j;
-        const int ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const int p = ch * 8 + 2 * kk + pb, sp = a.contig ? 0 : slot >> 1, col = (a.contig ? slot : slot & 1) * 16 + j;
+        const int ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
         const bool ok = p < M && col < ns_;
         const cplx v = phi[ok ? p * nt + off_ + col : 0];
         ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
@@ -400,14 +404,14 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NSL; ++j)
             if (cv[j]) {
-                const int cs = slot0 + j * SS, sp = cs >> 1;
-                const int ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+                const int cs = slot0 + j * SS, sp = a.contig ? 0 : cs >> 1;
+                const int ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double re = BR ? P1[j][r] : P1[j][r] - P2[j][r];
                     const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
-                        const int row = rt * 16 + lk_e + 4 * r, col = (cs & 1) * 16 + lr_e;
+                        const int row = rt * 16 + lk_e + 4 * r, col = (a.contig ? cs : cs & 1) * 16 + lr_e;
                         PF_UNLESS(256)
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
                     } else if (t_ok(rt, r)) {
@@ -511,7 +515,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // and needs no barrier at all
         int lk_e = lk, lr_e = lr, ln_e = lane;                   // laundered (see one_body)
         asm volatile("" : "+v"(lk_e), "+v"(lr_e), "+v"(ln_e));
-        const int sp = c0 >> 1, ns_ = sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const int sp = a.contig ? 0 : c0 >> 1, ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const int cb = (a.contig ? c0 : c0 & 1) * 16;            // first walker column of the slot (within the spin block)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 const double re = BR ? P1[i][r] : P1[i][r] - P2[i][r];
                 const double im = BR ? P2[i][r] : P3[i][r] - P1[i][r] - P2[i][r];
                 if (to_global) {
-                    const int row = (r0 + i) * 16 + lk_e + 4 * r, col = (c0 & 1) * 16 + lr_e;
+                    const int row = (r0 + i) * 16 + lk_e + 4 * r, col = cb + lr_e;
                     if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
                 } else if (t_ok(r0 + i, r)) {
                     *(d2_t *)(Tf + t_addr(r0 + i, r, c0)) = (d2_t){re, im};
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         if (REM) {
             const double re = BR ? Q1 : Q1 - Q2, im = BR ? Q2 : Q3 - Q1 - Q2;
             if (to_global) {
-                const int row = 96 + (ln_e >> 4), col = (c0 & 1) * 16 + (ln_e & 15);
+                const int row = 96 + (ln_e >> 4), col = cb + (ln_e & 15);
                 if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
             } else {
                 *(d2_t *)(Tf + rem_t) = (d2_t){re, im};
@@ -881,6 +886,174 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         }
     };
 
+    // ------------------------------------------------------------------ Taylor series, hybrid column tiling (round 4)
+    // With 17 .. 28 electrons per spin the second column slot of a spin is mostly padding (C3: 9 live columns of 16).  A
+    // 16x16x4 MFMA on it costs 64 cycles whatever it holds; the same rows as NU = ceil((n - 16) / 4) units of 16 rows x 4
+    // columns on v_mfma_f64_4x4x4 (blk = 4-row group: the A operand IS the ring fragment of the row tile, lane 16 k + row;
+    // the B operand repeats T[k][4 u + j] in every blk; D lane 16 i + 4 blk + j = element (row 4 blk + i, column 4 u + j))
+    // cost 16 NU <= 48.  Deal of the full M <= 100 shape (per k-step, in MFMA cycles, three products per tile / unit):
+    //   waves 0-3   row tiles (0,1) or (2,3) x [full slot | unit slot] of one spin     2 x (192 + 48 NU)
+    //   waves 4, 5  row tiles 4, 5 of the full slot of a spin (the plain taylor() deal)  384
+    //   waves 6, 7  row tiles 4, 5 of the unit slot of a spin + the two remainder units
+    //               (rows 96 .. M-1, see REM in taylor) of BOTH slots of that spin       96 NU + 96
+    // NU = 3: every SIMD (waves w, w + 4) carries 1056 instead of 1200 cycles per k-step.  Same half-chunk pipeline, same
+    // barriers per chunk and per product as taylor(); the short groups go first so that the long ones cover the reads.
+    auto taylor_h = [&](auto hf_tag, auto rem_tag, auto nu_tag, const int r0, const int cf, const int cu, const int cr)
+        __attribute__((always_inline)) {
+        constexpr bool HF = decltype(hf_tag)::value;             // the wave also owns the full slot cf of its row tiles
+        constexpr bool HR = decltype(rem_tag)::value;            // the wave owns the remainder units of slots cr, cr + 1
+        constexpr int NU = decltype(nu_tag)::value;
+        constexpr int NI = 2, NRU = HR ? 2 : 0;
+        static_assert(FULL == 7, "hybrid tiling: the full wide deal");
+        // B operand of unit u: lane (k = lane >> 4, blk, j = lane & 3) reads T[k][4 u + j] of the fragment (+ 64 u bytes)
+        const unsigned u_rd = (unsigned)((lane >> 4) * 256 + (lane & 3) * 16);
+        // D lane of a unit -> entry of T: row 4 blk + i of the tile = chunk half blk >> 1, sub-step i & 1, k 2 (blk & 1) + (i >> 1)
+        const int ui = lane >> 4, ub = (lane >> 2) & 3;
+        const unsigned u_wr = (unsigned)((ub >> 1) * 8192 + (ui & 1) * 1024 + ((2 * (ub & 1) + (ui >> 1)) * 16 + (lane & 3)) * 16);
+        auto u_addr = [&](int ti, int u) -> unsigned {
+            unsigned base = u_wr;
+            asm volatile("" : "+v"(base));                       // (laundered like t_addr: no address register per unit kept alive)
+            return base + (unsigned)((2 * ti * 4 + cu) * 2048 + u * 64);
+        };
+        const unsigned rem_a = (unsigned)(6 * 2048 + ((lane >> 4) * 16 + (lane & 3)) * 16);
+        auto rem_t = [&](int t) -> unsigned {
+            return (unsigned)((((12 * 4 + cr + t) * 2 + ((lane >> 4) & 1)) * 1024) + (((lane >> 5) * 16) + (lane & 15)) * 16);
+        };
+        // running sums: full tiles (accumulator layout), units (one element per lane), remainder units
+        d4_t SR[NI], SI[NI];
+        double UR[NI][NU], UI[NI][NU], RR[2] = {0.0, 0.0}, RI[2] = {0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d2_t v = (d2_t){0.0, 0.0};
+                if (HF) v = *(const d2_t *)(Tf + t_addr(r0 + i, r, cf));
+                SR[i][r] = v[0]; SI[i][r] = v[1];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) { const d2_t v = *(const d2_t *)(Tf + u_addr(r0 + i, u)); UR[i][u] = v[0]; UI[i][u] = v[1]; }
+        }
+        if (HR) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { const d2_t v = *(const d2_t *)(Tf + rem_t(t)); RR[t] = v[0]; RI[t] = v[1]; }
+        }
+        struct Frag { d2_t a[NI]; d2_t bf; d2_t bu[NU]; d2_t q; d2_t br[2]; };
+        constexpr int NG = NI * NU + NRU + (HF ? NI : 0);        // MFMA groups per sub-step, short ones first
+        constexpr int NR = NI + NU + (HF ? 1 : 0) + (HR ? 3 : 0);   // fragment reads per sub-step
+        constexpr int NGAP = HF ? NG - 1 : NG - 3;               // gaps that take reads (all-short waves: keep the tail free)
+        constexpr int RPG = (NR + NGAP - 1) / NGAP;
+        for (int n = 1; n <= a.order; ++n) {
+            double inv_n = 1.0 / n;
+            asm volatile("" : "+v"(inv_n));
+            d4_t P1[NI], P2[NI], P3[NI];
+            double U1[NI][NU], U2[NI][NU], U3[NI][NU], Q1[2] = {0.0, 0.0}, Q2[2] = {0.0, 0.0}, Q3[2] = {0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                P1[i] = (d4_t){0, 0, 0, 0}; P2[i] = (d4_t){0, 0, 0, 0}; P3[i] = (d4_t){0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < NU; ++u) { U1[i][u] = 0.0; U2[i][u] = 0.0; U3[i][u] = 0.0; }
+            }
+            // fragment r of sub-step ys of the chunk at ring slot `sl`, T chunk c
+            auto read_one = [&](Frag &f, const int r, const unsigned sl, const int c, const int ys) __attribute__((always_inline)) {
+                const unsigned abase = sl + r0 * 2048 + lane * 16;
+                if (r < NI) { f.a[r] = lds_read_frag(abase, r * 2 + ys); return; }
+                if (r < NI + NU) {
+                    const int u = r - NI;
+                    const unsigned ubase = tf_l + (c * 4 + cu) * 2048 + u_rd + ys * 1024;
+                    f.bu[u] = u == 0 ? lds_read_off<0>(ubase) : u == 1 ? lds_read_off<64>(ubase) : lds_read_off<128>(ubase);
+                    return;
+                }
+                int k = r - NI - NU;
+                if (HF) {
+                    if (k == 0) { f.bf = lds_read_frag(tf_l + (c * 4 + cf) * 2048 + lane * 16, ys); return; }
+                    --k;
+                }
+                if (HR) {
+                    if (k == 0) f.q = lds_read_frag(sl + rem_a, ys);
+                    else f.br[k - 1] = lds_read_frag(tf_l + (c * 4 + cr + k - 1) * 2048 + lane * 16, ys);
+                }
+            };
+            // MFMA groups of the fragments in X; the reads of sub-step ys of (slot sl, chunk c) into Y in between
+            auto half = [&](Frag &x, Frag &y, const unsigned sl, const int c, const int ys, const bool fetch, const bool refill)
+                __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < NI * NU) {                            // a unit of 16 rows x 4 columns
+                        const int i = g / NU, u = g % NU;
+                        U1[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.a[i][0], x.bu[u][0], U1[i][u], 0, 0, 0);
+                        U2[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.a[i][1], x.bu[u][1], U2[i][u], 0, 0, 0);
+                        U3[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.a[i][0] + x.a[i][1], x.bu[u][0] + x.bu[u][1], U3[i][u], 0, 0, 0);
+                    } else if (g < NI * NU + NRU) {               // a remainder unit of 4 rows x 16 columns
+                        const int t = g - NI * NU;
+                        Q1[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.q[0], x.br[t][0], Q1[t], 0, 0, 0);
+                        Q2[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.q[1], x.br[t][1], Q2[t], 0, 0, 0);
+                        Q3[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.q[0] + x.q[1], x.br[t][0] + x.br[t][1], Q3[t], 0, 0, 0);
+                    } else {                                      // a full 16 x 16 tile
+                        const int i = g - NI * NU - NRU;
+                        P1[i] = mfma16(x.a[i][0], x.bf[0], P1[i]);
+                        P2[i] = mfma16(x.a[i][1], x.bf[1], P2[i]);
+                        P3[i] = mfma16(x.a[i][0] + x.a[i][1], x.bf[0] + x.bf[1], P3[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 0 && refill) issueA();
+                    if (g == 0 && !refill && !prepared) prepare();
+                    if (fetch && g < NGAP) {
+#pragma unroll
+                        for (int q = 0; q < RPG; ++q)
+                            if (g * RPG + q < NR) read_one(y, g * RPG + q, sl, c, ys);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            Frag f0, f1;
+            f0.q = (d2_t){0.0, 0.0}; f1.q = (d2_t){0.0, 0.0};
+            unsigned sl = next_chunk_sync();
+#pragma unroll
+            for (int r = 0; r < NR; ++r) read_one(f0, r, sl, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issueA();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int c = 0; c < NCH; ++c) {
+                const bool more = c + 1 < NCH;
+                half(f0, f1, sl, c, 1, true, false);             // sub-step 0 of chunk c; fetch its sub-step 1
+                if (more) sl = next_chunk_sync();                 // chunk c + 1 has landed
+                half(f1, f0, sl, c + 1, 0, more, more);          // sub-step 1 of chunk c; refill, fetch sub-step 0 of chunk c + 1
+            }
+            // T_n = product / n back into T (rows below the last chunk: nobody reads them any more behind the last chunk
+            // barrier), the barrier, then the remainder rows -- exactly the sequence of taylor() with store_first
+            const bool last = n == a.order;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (HF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double re = (P1[i][r] - P2[i][r]) * inv_n, im = (P3[i][r] - P1[i][r] - P2[i][r]) * inv_n;
+                        SR[i][r] += re; SI[i][r] += im;
+                        *(d2_t *)(Tf + t_addr(r0 + i, r, cf)) = last ? (d2_t){SR[i][r], SI[i][r]} : (d2_t){re, im};
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const double re = (U1[i][u] - U2[i][u]) * inv_n, im = (U3[i][u] - U1[i][u] - U2[i][u]) * inv_n;
+                    UR[i][u] += re; UI[i][u] += im;
+                    *(d2_t *)(Tf + u_addr(r0 + i, u)) = last ? (d2_t){UR[i][u], UI[i][u]} : (d2_t){re, im};
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            if (HR) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const double re = (Q1[t] - Q2[t]) * inv_n, im = (Q3[t] - Q1[t] - Q2[t]) * inv_n;
+                    RR[t] += re; RI[t] += im;
+                    *(d2_t *)(Tf + rem_t(t)) = last ? (d2_t){RR[t], RI[t]} : (d2_t){re, im};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
     // Measured negative result (round 2, profiles/r02_pmc_prop_fused_t4_vs_t16.txt): the same products on
     // v_mfma_f64_4x4x4 (16 x 4 and 4 x 16 units, 79 % of the MFMA cycles of the padded 16x16x4 grid) are CORRECT but
     // not faster -- 183 us against 177 us: MFMA-busy cycles drop 18 %, wave-parked cycles (s_waitcnt / barrier) rise
@@ -917,6 +1090,46 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2, std::false_type{});
         else if (nrt <= 6) taylor(I2{}, I1{}, std::true_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1, std::false_type{});
         else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2, std::false_type{});
+    }
+    else if (FULL == 7 && a.contig) {
+        // Contiguous columns (one matrix for both spins, 48 < na + nb <= 56): three full column slots and a fourth with
+        // na + nb - 48 live columns, multiplied as NU = a.hyb units of 16 rows x 4 columns (taylor_h).  The 18 full tiles,
+        // 6 NU units and 4 remainder units are dealt so that no SIMD (waves w, w + 4) carries more than 1056 MFMA cycles
+        // per k-step at NU = 1 (1200 in the two-slots-per-spin layout):
+        //   waves 0, 2   row tiles (0,1) / (2,3) x slots 0, 1                                  768
+        //   waves 1, 3   row tiles (0,1) / (2,3) x [slot 2 | unit slot 3]                      384 + 96 NU
+        //   wave 4       row tile 4 x slot 0 + remainder unit of slot 0                        240
+        //   wave 5       row tile 5 x slots 0, 1                                               384
+        //   wave 6       row tile 4 x slot 1 + remainder unit of slot 1                        240
+        //   wave 7       row tiles 4, 5 x [slot 2 | unit slot 3] + remainder units of 2, 3     384 + 96 NU + 96
+        if constexpr (FULL == 7) {
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            auto deal = [&](auto nu) __attribute__((always_inline)) {
+                if (wave == 0 || wave == 2) taylor(I2{}, I2{}, std::false_type{}, wave, 0, 2, std::false_type{});
+                else if (wave == 1 || wave == 3) taylor_h(std::true_type{}, std::false_type{}, nu, wave - 1, 2, 3, 0);
+                else if (wave == 4 || wave == 6) taylor(I1{}, I1{}, std::true_type{}, 4, (wave - 4) >> 1, 1, std::true_type{});
+                else if (wave == 5) taylor(I1{}, I2{}, std::true_type{}, 5, 0, 1, std::false_type{});
+                else taylor_h(std::true_type{}, std::true_type{}, nu, 4, 2, 3, 2);
+            };
+            if (a.hyb == 2) deal(I2{});
+            else deal(I1{});
+        }
+    }
+    else if (FULL == 7 && a.hyb) {
+        if constexpr (FULL == 7) {
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            auto deal = [&](auto nu) __attribute__((always_inline)) {
+                if (wave < 4) taylor_h(std::true_type{}, std::false_type{}, nu, 2 * (wave >> 1), 2 * (wave & 1), 2 * (wave & 1) + 1, 0);
+                else if (wave < 6) taylor(I2{}, I1{}, std::true_type{}, 4, 2 * (wave - 4), 2, std::false_type{});
+                else taylor_h(std::false_type{}, std::true_type{}, nu, 4, 0, 2 * (wave - 6) + 1, 2 * (wave - 6));
+            };
+            if (a.hyb == 3) deal(I3{});
+            else if (a.hyb == 2) deal(I2{});
+            else deal(I1{});
+        }
     }
     else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2, std::false_type{});
     else if constexpr (FULL == 7) {
@@ -957,6 +1170,22 @@ int k_prop_fused(afq_handle *h) {
     a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
     a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
     a.rem4 = (h->M > 96 && h->M <= 100 && !afq_knob("AFQ_PF_NOREM")) ? 1 : 0;
+    // hybrid column tiling: both spins with 17 .. 28 electrons and the same number of 4-column units in their second slot
+    // (measured NEGATIVE at C3, round 4: 148.6 us against 145.5 us -- three 4x4x4 units need 9 MFMA + 3 add instructions where
+    //  the padded 16x16x4 tile needs 3 + 1, and a wave that multiplies mostly units is bound by instruction issue, not by the
+    //  matrix pipe; tuning builds only, AFQ_PF_HYB=1)
+    a.hyb = 0;
+    if (a.rem4 && h->na > 16 && h->nb > 16 && h->na <= 28 && h->nb <= 28 && (h->na - 13) / 4 == (h->nb - 13) / 4 &&
+        PF_NW == 8 && afq_knob("AFQ_PF_HYB"))
+        a.hyb = (h->na - 13) / 4;
+    // contiguous columns: one one-body matrix for both spins (the HS potential never depends on the spin), 48 < na + nb <= 56
+    // (a third unit per row tile would unbalance the deal and push wave 7 over 256 registers)
+    a.contig = 0;
+    if (a.rem4 && a.same_b && h->na > 16 && h->nb > 16 && h->nt > 48 && h->nt <= 56 && PF_NW == 8 && !a.hyb &&
+        !afq_knob("AFQ_PF_NOCONTIG")) {
+        a.contig = 1;
+        a.hyb = (h->nt - 48 + 3) / 4;
+    }
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
@@ -968,7 +1197,10 @@ int k_prop_fused(afq_handle *h) {
         const int nrt_ = (h->M + 15) / 16, ct = (h->na + 15) / 16 + (h->nb + 15) / 16;
         const double ksteps = 2.0 * NCH;
         const double per_pass = ksteps * (2048.0 * (a.rem4 ? nrt_ - 1 : nrt_) * ct + 512.0 * (a.rem4 ? ct : 0));
-        h->issued_flops[AFQ_K_PROPAGATOR] = (3.0 * h->exp_order + 2.0 * (a.b_real ? 2.0 : 3.0)) * per_pass * h->nw;
+        // hybrid tiling of the Taylor products: per spin one full slot + hyb units per row tile, four remainder units in all
+        const double taylor_pass = a.contig ? ksteps * (2048.0 * (nrt_ - 1) * 3 + 512.0 * (nrt_ - 1) * a.hyb + 512.0 * 4)
+                                   : a.hyb ? ksteps * (2048.0 * (nrt_ - 1) * 2 + 512.0 * (nrt_ - 1) * 2 * a.hyb + 512.0 * 4) : per_pass;
+        h->issued_flops[AFQ_K_PROPAGATOR] = (3.0 * h->exp_order * taylor_pass + 2.0 * (a.b_real ? 2.0 : 3.0) * per_pass) * h->nw;
     }
     // every tile of the deal present: wide with 5-7 row tiles (waves 4-7 own the tiles from 4 on) and two column tiles
     // per spin, or narrow with six row tiles

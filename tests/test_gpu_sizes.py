@@ -209,7 +209,17 @@ def test_exchange_algorithms_odd_sizes(M, K, na, nb, nw, cplx):
 
 
 @pytest.mark.parametrize("M,na,nb,onebody", [
-    (100, 25, 25, 'same-real'),      # wide deal, every tile present (prop_fused_kernel<false, 7>)
+    (100, 25, 25, 'same-real'),      # wide deal, every tile present (prop_fused_kernel<false, 7>); contiguous columns, 1 unit
+    (100, 28, 27, 'same-real'),      # contiguous columns (one matrix for both spins): 55 columns = 3 slots + 2 units
+    (97, 28, 28, 'same-real'),       # ... 56 columns, one remainder row
+    (98, 30, 27, 'same-real'),       # 57 columns: the two-slots-per-spin layout
+    (99, 17, 32, 'same-real'),       # ... 49 columns: one live column in the unit slot
+    (100, 31, 30, 'same-real'),      # 61 columns: the two-slots-per-spin layout
+    (100, 28, 25, 'spin-complex'),   # hybrid column tiling (second slot of a spin as 4-column units): 3 units, na != nb
+    (99, 21, 24, 'same-real'),       # ... 2 units, three remainder rows
+    (97, 17, 20, 'spin-complex'),    # ... 1 unit (one and four live columns), one remainder row
+    (98, 24, 25, 'same-real'),       # unit counts differ between the spins (2 and 3): the plain deal
+    (100, 29, 25, 'same-real'),      # 13 live columns in the second slot: the plain deal
     (97, 17, 32, 'spin-complex'),    # the same with spin-dependent complex one-body matrices
     (104, 30, 18, 'same-real'),
     (93, 7, 7, 'same-real'),         # one column tile per spin, six row tiles (prop_fused_kernel<true, 6>)
