@@ -692,11 +692,17 @@ int afq_walkers_get(afq_handle *h, int field, void *host, int first, int count) 
 }
 
 int afq_walkers_device_ptr(afq_handle *h, int field, void **dev_ptr, int64_t *bytes_per_walker) {
-    if (h) { h->greens_valid = false; h->gsum_only = false; h->greens_cache = false; }   // the caller may write through the pointer
     if (!h || !dev_ptr) return AFQ_EINVAL;
     void *base; size_t bytes;
     int rc = field_info(h, field, &base, &bytes);
     if (rc) return rc;
+    // a reader of the per-spin Ghalf must find the CURRENT walkers' there: a step announced with afq_estimates_fuse_next
+    // leaves only overlap + spin sum behind
+    if (field == AFQ_F_GHALF && h->gsum_only) {
+        hipSetDevice(h->device);
+        if ((rc = ensure_spin_ghalf(h))) return rc;
+    }
+    h->greens_valid = false; h->gsum_only = false; h->greens_cache = false;             // the caller may write through the pointer
     *dev_ptr = base;
     if (bytes_per_walker) *bytes_per_walker = (int64_t)bytes;
     return AFQ_OK;

@@ -32,7 +32,15 @@
 #define PF_NW 8
 #endif
 #define PF_NT (64 * PF_NW)
-#define PF_FPW (16 / PF_NW)      // operand fragments each wave moves per chunk
+// waves that refill the operand ring: all of them (PF_LW == PF_NW: two fragments per wave and chunk), or the last PF_LW.
+// Measured NEGATIVE (round 4, C3): PF_LW = 4 -- waves 4-7, the lighter half of the contiguous-column deal, issuing four
+// LDS-DMA instructions per chunk each so that the waves with the 2 x 2 tile blocks never stall in DMA issue -- 149.3 us
+// against 140.2 us: four back-to-back DMA instructions hold a wave for several hundred cycles and the chunk barrier makes
+// everybody wait for it.
+#ifndef PF_LW
+#define PF_LW PF_NW
+#endif
+#define PF_FPW (16 / PF_LW)      // operand fragments each refilling wave moves per chunk
 
 // Tuning builds (make TUNING=1 -> libafqmc_hip_tuning.so) carry timing ablations (a.dbg bits: WRONG results, timing only)
 // and s_memtime probes.  They all sit behind this one macro family, which expands to NOTHING in the product build, so the
@@ -177,9 +185,12 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     // of integer instructions it would skip, and one basic block lets the scheduler place them between MFMAs.
     const void *nsrc[PF_FPW];
     bool prepared = false;
-    const int p_row0 = (wave >> 1) * 16 + lr;                    // fragment f = wave + t * PF_NW: row tile f>>1,
-    const int p_kl = 2 * lk + (wave & 1);                        // sub-step f&1 (the same for every t: PF_NW is even)
+    const bool refills = wave >= PF_NW - PF_LW;                  // wave-uniform
+    const int lw = wave - (PF_NW - PF_LW);
+    const int p_row0 = (lw >> 1) * 16 + lr;                      // fragment f = lw + t * PF_LW: row tile f>>1,
+    const int p_kl = 2 * lk + (lw & 1);                          // sub-step f&1 (the same for every t: PF_LW is even)
     auto prepare = [&]() __attribute__((always_inline)) {
+        if (!refills) { prepared = true; return; }
         PF_TUNE(if ((a.dbg & 1024) && gi > 2) { prepared = true; return; })       // stale addresses (timing only)
         const bool in_v = gi_phase >= nob && gi_phase < nob + a.order;
         const int spin = gi_phase < nob ? gi_phase : gi_phase - nob - a.order;      // 0 or 1 on live chunks
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         const int k = gi_c * 8 + p_kl;
 #pragma unroll
         for (int t = 0; t < PF_FPW; ++t) {
-            const int row = p_row0 + t * (PF_NW / 2) * 16;
+            const int row = p_row0 + t * (PF_LW / 2) * 16;
             // upper-triangle storage of V: element (row, k < row) lives at (k, row); the 16 lanes of one k then
             // read 256 contiguous bytes instead of 16 rows
             // (branch-free on purpose: a global_load_lds inside a divergent region leaves the LDS slots of the
@@ -207,11 +218,12 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         prepared = true;
     };
     auto issueA = [&]() __attribute__((always_inline)) {
+        if (!refills) return;
         if (!prepared) prepare();
         unsigned char *dst = ring + (size_t)gi_slot * 16384;
         PF_TUNE(if (a.dbg & 512) { for (int t = 0; t < PF_FPW; ++t) asm volatile("" ::"v"(nsrc[t]), "s"(dst)); } else)   // addresses computed, DMA not issued
 #pragma unroll
-        for (int t = 0; t < PF_FPW; ++t) glds16(nsrc[t], dst + (wave + t * PF_NW) * 1024);
+        for (int t = 0; t < PF_FPW; ++t) glds16(nsrc[t], dst + (lw + t * PF_LW) * 1024);
         if (++gi_slot == PF_D) gi_slot = 0;
         prepared = false;
     };

@@ -292,7 +292,11 @@ static int k_hirsch_two_body_direct(afq_handle *h) {
     AFQ_LAUNCH(h, hirsch_direct_sites_kernel, dim3(h->nw), dim3(256), 0, h->stream, a);
     AFQ_POST(h);
     int rc;
-    if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;             // walker.calc_overlap(trial), :265
+    // walker.calc_overlap(trial), :265 -- with use_log_shift the reference's two overlap routines carry OPPOSITE factors:
+    // calc_overlap (single_det.py:192) returns det * exp(-log_shift), calc_otrial (:159-161, used by the kinetic and the
+    // free-projection updates) 1 / (det(O^-1) exp(-log_shift)) = det * exp(+log_shift).  Both are reproduced as they are
+    // (traj_hirsch_logshift.npz); the factors below are therefore exp(-log_shift) here and exp(+log_shift) there.
+    if ((rc = k_inverse_overlap(h, h->hs_oinv, h->ovlp_new))) return rc;
     AFQ_LAUNCH(h, hirsch_direct_weight_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->weight, h->ot,
                h->ovlp_new, h->cmf, h->hs_fbfac, h->alive, h->nw, h->log_shift_on ? exp(-h->log_shift) : 1.0);
     AFQ_POST(h);

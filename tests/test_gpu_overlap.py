@@ -93,6 +93,22 @@ def test_per_spin_ghalf_not_stored_on_announced_steps_is_recomputed_on_demand():
             assert numpy.array_equal(devs[0].local_energy(), devs[1].local_energy())
         if step == 2:
             assert numpy.array_equal(devs[0].get(L.F_GHALF), devs[1].get(L.F_GHALF))
+        if step == 3:
+            # the same through afq_walkers_device_ptr (a caller that maps the buffer, e.g. a custom estimator): the pointer
+            # must hand out the CURRENT walkers' per-spin Ghalf, not an earlier step's
+            import ctypes
+            hip = ctypes.CDLL('libamdhip64.so')
+            got = []
+            for d in devs:
+                ptr, per = ctypes.c_void_p(), ctypes.c_int64()
+                assert d.lib.afq_walkers_device_ptr(d.h, L.F_GHALF, ctypes.byref(ptr), ctypes.byref(per)) == 0
+                d.sync()
+                buf = numpy.empty((nw, 2 * N, M), dtype=numpy.complex128)
+                assert per.value == buf[0].nbytes
+                assert hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ptr, ctypes.c_size_t(buf.nbytes), 2) == 0
+                got.append(buf)
+            assert numpy.array_equal(got[0], got[1])
+            assert numpy.array_equal(got[0], devs[1].get(L.F_GHALF))
         for f in (L.F_PHI, L.F_WEIGHT, L.F_OT, L.F_HYBRID_ENERGY):
             assert numpy.array_equal(devs[0].get(f), devs[1].get(f)), (step, f)
     assert numpy.allclose(devs[0].estimates_get(), devs[1].estimates_get(), rtol=1e-12, atol=0)
