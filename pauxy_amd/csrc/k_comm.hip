@@ -824,8 +824,10 @@ static void clear_comm_scalars(afq_handle *h) {
     if (h->scal) { (void)hipMemset(h->scal + 3, 0, 6 * sizeof(double)); h->scal_cache_valid = false; }
 }
 
+static double g_wait_seconds_host = WAIT_SECONDS_DEFAULT;    // what the device symbol currently holds (per process)
 static int set_wait_budget(double seconds) {
     if (!(seconds > 0.0)) return AFQ_EINVAL;
+    g_wait_seconds_host = seconds;
     const unsigned long long ticks = (unsigned long long)std::min(seconds * 1e8, 9.0e17);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks)) == hipSuccess ? AFQ_OK : AFQ_EHIP;
 }
@@ -1175,6 +1177,16 @@ int afq_comm_probe(afq_handle *h, int64_t *mismatch_out) {
     if (c->mode == COMM_RCCL && !api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
     int rc = ensure_buffers(h);
     if (rc) return rc;
+    // The ranks enter the probe together (the caller agrees on every step of the bring-up first), so nothing legitimate
+    // delays a peer here: a transport that does not work must fail the probe within seconds, not after the long budget of
+    // the step loop (three candidates x 300 s would outlast a benchmark's time limit).  Restored on every way out.
+    struct ProbeBudget {
+        double keep; afq_handle *h;
+        ProbeBudget(afq_handle *h_) : keep(g_wait_seconds_host), h(h_) {
+            if (keep > 20.0) { hipStreamSynchronize(h->stream); set_wait_budget(20.0); }
+        }
+        ~ProbeBudget() { if (keep > 20.0) { hipStreamSynchronize(h->stream); set_wait_budget(keep); } }
+    } probe_budget(h);
     const int R = c->nranks, nw = h->nw;
     int64_t bad[3] = {0, 0, 0};
     // ---- all-gather: rank s contributes [1000 s + i] and r = 0.5 + s
