@@ -90,10 +90,13 @@ def check_surface(shell):
     trace = trace_fixture()['trace']
     objs = {'Propagator': shell.propagators, 'Continuous.propagator': shell.propagators.propagator,
             'Walkers': shell.psi, 'Walker': shell.psi.walkers[0], 'Estimators': shell.estimators,
-            'Mixed': shell.estimators.estimators['mixed'], 'system': shell.system, 'trial': shell.trial}
+            'Mixed': shell.estimators.estimators['mixed'], 'system': shell.system, 'trial': shell.trial,
+            'BackPropagation': shell.estimators.estimators.get('back_prop')}
     assert set(trace) <= set(objs), set(trace) - set(objs)
     for label, ent in trace.items():
         obj = objs[label]
+        if obj is None:                  # this shell was built without that estimator
+            continue
         for name in ent['read'] + ent['called']:
             assert hasattr(obj, name), (label, name)
         for name in ent['called']:

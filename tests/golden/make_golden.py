@@ -1217,6 +1217,34 @@ def make_dropin():
     run_case('generic', 'traj_generic.npz',
              {'verbosity': 0, 'get_sha1': False, 'qmc': {'timestep': 0.005, 'steps': 10, 'blocks': 10, 'rng_seed': 8},
               'estimates': {'mixed': {'energy_eval_freq': 1}}, 'trial': {'name': 'MultiSlater'}}, system=system)
+    # qmc/tests/test_afqmc.py:49-97: the electron gas (plane-wave propagator, sparse density operators, HartreeFock trial)
+    run_case('ueg', 'traj_ueg.npz',
+             {'verbosity': 0, 'get_sha1': False, 'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 5, 'rng_seed': 8},
+              'model': {'name': "UEG", 'rs': 2.44, 'ecut': 2, 'nup': 7, 'ndown': 7},
+              'estimates': {'mixed': {'energy_eval_freq': 1}}, 'trial': {'name': 'hartree_fock'}})
+    # qmc/tests/test_afqmc.py:232-278: the back-propagated one-body RDM (estimators/back_propagation.py through the driver:
+    # Estimators builds BackPropagation, Walkers gets nbp, every step's fields go into the walkers' history)
+    numpy.random.seed(7)
+    h1e, chol, enuc, eri = generate_hamiltonian(nmo, nelec, cplx=False)
+    system = Generic(nelec=nelec, h1e=numpy.array([h1e, h1e]), chol=chol.reshape((-1, nmo * nmo)).T.copy(), ecore=enuc)
+    bp_run = run_case('generic_bp', 'traj_bp.npz',
+                      {'verbosity': 0, 'get_sha1': False, 'qmc': {'timestep': 0.005, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8},
+                       'trial': {'name': 'MultiSlater'},
+                       'estimator': {'back_propagated': {'tau_bp': 0.025, 'one_rdm': True}, 'mixed': {'energy_eval_freq': 1}}},
+                      system=system)
+    d = numpy.load(os.path.join(HERE, 'traj_bp.npz'))
+    store = h5py._STORE[bp_run.estimators.filename]
+    nbp = bp_run.estimators.nbp
+    dk = sorted(k for k in store if k.startswith('back_propagated/denominator_%d/' % nbp))
+    rk = sorted(k for k in store if k.startswith('back_propagated/one_rdm_%d/' % nbp))
+    got_den = numpy.array([store[k] for k in dk]).reshape(len(dk))
+    got_rdm = numpy.array([store[k] for k in rk])
+    assert got_den.shape == d['bp_denominator'].shape and got_rdm.shape == d['bp_one_rdm'].shape
+    assert numpy.max(numpy.abs(got_den - d['bp_denominator'])) <= 1e-9 * numpy.max(numpy.abs(d['bp_denominator']))
+    assert numpy.max(numpy.abs(got_rdm - d['bp_one_rdm'])) <= 1e-9 * numpy.max(numpy.abs(d['bp_one_rdm']))
+    rdm = got_rdm / got_den[:, None, None, None]
+    assert abs(rdm[11, 0, 1, 3].real - (-0.121883381144845)) < 1e-9           # the value qmc/tests/test_afqmc.py pins
+    print('dropin generic_bp   back-propagated one-body RDM of the genuine driver over the plug-in classes == traj_bp.npz')
     # the local-energy weight update and free projection take other branches of the driver-facing classes
     for name, golden, extra in (('hubbard_le', 'traj_hubbard_le.npz', {'hybrid': False}),
                                 ('hubbard_fp', 'traj_hubbard_fp.npz', {'free_projection': True})):

@@ -13,7 +13,8 @@ It is installed by rebinding ``pauxy_amd.context.AfqDevice`` from a test; nothin
 it (or the oracle), and the ``-m gpu`` tests never use it: they run the same classes over the HIP library.
 
 Coverage: single-determinant walkers, continuous Hubbard-Stratonovich fields (Generic, Hubbard charge / spin, UEG),
-phaseless hybrid / local-energy weights, free projection, comb, mixed estimator, weight cap, log shifts.  Per-walker
+phaseless hybrid / local-energy weights, free projection, comb, mixed estimator, back-propagated one-body RDM, weight cap,
+log shifts.  Per-walker
 arithmetic is the oracle's, one walker at a time, in walker order.
 """
 import numpy
@@ -311,6 +312,23 @@ class OracleDevice(object):
     def estimates_rdm(self, on=True):
         if on:
             raise NotImplementedError("one_rdm accumulation is not part of the stand-in")
+
+    # -- back-propagation (afq_bp_configure / afq_bp_steps / afq_bp_update): the oracle's field history per walker
+    def bp_configure(self, nbp):
+        self.nbp = int(nbp)
+        for w in self._w:
+            w['bp'] = ref.bp_new(self.K, self.nbp)
+            w['phi_old'] = w['phi'].copy()
+
+    def bp_steps(self):
+        return numpy.array([w['bp']['step'] for w in self._w], dtype=numpy.int32)
+
+    def bp_update(self, phi_bp0, nstblz, restore_weights=None, eval_energy=False, reset=True):
+        self._log('bp_update')
+        est = numpy.zeros(4 + 2 * self.M * self.M, dtype=numpy.complex128)
+        ref.bp_update(self._model, self._w, nstblz, est, restore_weights, init=numpy.asarray(phi_bp0),
+                      eval_energy=eval_energy, reset=reset)
+        return est[:3], est[3], est[4:].reshape(2, self.M, self.M)
 
     def counters(self, reset=False):
         out = self._ntrig.copy()

@@ -65,13 +65,33 @@ def test_surface_the_genuine_driver_touches(golden, standin):
     release_context(shell.system, shell.trial)
 
 
+def test_surface_with_the_back_propagated_estimator(golden, standin):
+    """The same for the objects of a run with `estimators: {back_propagated: ...}` (Generic system): BackPropagation is
+    built by Estimators, its nmax reaches Walkers as nbp / nprop_tot, everything survives the serialise walk."""
+    d = golden('traj_bp.npz')
+    s = systems.Generic((3, 3), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    shell, comm = dropin_checks.build_shell(s, t, {'timestep': 0.005, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8}, {},
+                                            {'back_propagated': {'tau_bp': 0.025, 'one_rdm': True},
+                                             'mixed': {'energy_eval_freq': 1}, 'write_file': False})
+    assert shell.estimators.nbp == 5 and shell.psi.nbp == 5
+    dropin_checks.check_surface(shell)
+    tree = serialise_walk.walk(shell)
+    json.dumps(tree)
+    want = dropin_checks.trace_fixture()['cases']['generic_bp']['serialised']['estimators']['estimators']['back_prop']
+    got = serialise_walk.kinds(tree)['estimators']['estimators']['back_prop']
+    want = dict(want, output='null')                       # (this shell writes no file)
+    assert got == want, dropin_checks._diff(got, want)
+    release_context(s, t)
+
+
 def test_trace_fixture_is_what_the_dropin_run_recorded():
     doc = dropin_checks.trace_fixture()
     assert doc['driver_imports_switched'] == [
         "from pauxy_amd.estimators.handler import Estimators",
         "from pauxy_amd.propagation.continuous import get_propagator_driver",
         "from pauxy_amd.walkers.handler import Walkers"]
-    assert set(doc['cases']) == {'hubbard_c1', 'generic', 'hubbard_le', 'hubbard_fp'}
+    assert set(doc['cases']) == {'hubbard_c1', 'generic', 'ueg', 'generic_bp', 'hubbard_le', 'hubbard_fp'}
     for case in doc['cases'].values():
         assert max(case['max_rel_err'].values()) < 1e-8
     t = doc['trace']
@@ -81,7 +101,7 @@ def test_trace_fixture_is_what_the_dropin_run_recorded():
 
 
 CASES = [('traj_hubbard_c1.npz', {}), ('traj_hubbard_le.npz', {'hybrid': False}),
-         ('traj_hubbard_fp.npz', {'free_projection': True}), ('traj_generic.npz', None)]
+         ('traj_hubbard_fp.npz', {'free_projection': True}), ('traj_generic.npz', None), ('traj_ueg.npz', 'ueg')]
 
 
 @pytest.mark.parametrize('name,extra', CASES, ids=[c[0][5:-4] for c in CASES])
@@ -89,7 +109,11 @@ def test_plugin_classes_over_the_standin_reproduce_the_golden_trajectory(golden,
     """The host logic of the plug-in classes (mirrors, dirty flags, one launch per sweep, lazy Green's functions, block
     rows) with the oracle's arithmetic underneath, through the restated per-walker loop."""
     d = golden(name)
-    if extra is None:
+    if extra == 'ueg':
+        s = systems.UEG(2.44, 7, 7, 2.0)
+        t = trial_mod.hartree_fock_ueg(s)
+        opts = {}
+    elif extra is None:
         na, nb = [int(x) for x in d['nelec']]
         s = systems.Generic((na, nb), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
         t = trial_mod.SingleDetTrial(s, d['psi'])
