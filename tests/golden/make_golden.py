@@ -1121,7 +1121,8 @@ def make_dropin():
             trace.attach(e, {'mixed': 'Mixed', 'back_prop': 'BackPropagation'}[name])
 
     def trace_prop(prop):
-        trace.attach(prop.propagator, 'Continuous.propagator')
+        if hasattr(prop, 'propagator'):                      # (the discrete Hirsch propagator has no inner object)
+            trace.attach(prop.propagator, 'Continuous.propagator')
 
     mod.get_propagator_driver = traced_factory(amd_prop.get_propagator_driver, 'Propagator', trace_prop)
     mod.Walkers = traced_factory(amd_walkers.Walkers, 'Walkers', trace_walkers)
@@ -1180,15 +1181,16 @@ def make_dropin():
         errs['weight'] = close(rec['weight'], d['weight'], 'weight')
         errs['unscaled_weight'] = close(rec['unscaled_weight'], d['unscaled_weight'], 'unscaled_weight')
         errs['ot'] = close(rec['ot'], d['ot'], 'ot')
-        errs['ehyb'] = close(rec['ehyb'], d['ehyb'], 'ehyb')
-        errs['phase'] = close(rec['phase'], d['phase'], 'phase')
-        errs['eloc'] = close(rec['eloc'], d['eloc'], 'eloc')
+        for key in ('ehyb', 'phase', 'eloc'):                # (the discrete-field fixtures record fewer walker scalars)
+            if key in d.files:
+                errs[key] = close(rec[key], d[key], key)
         assert numpy.array_equal(numpy.array(rec['pix']).reshape(d['parent_ix'].shape), d['parent_ix']), 'parent_ix'
         keys = sorted(k for k in store if k.startswith('basic/energies/'))
         blocks = numpy.array([store[k] for k in keys])
         errs['blocks'] = close(blocks[:, 1:10], d['blocks'][:, 1:10], 'blocks')
         errs['final_phi'] = close(numpy.array([w.phi for w in afqmc.psi.walkers]), d['final_phi'], 'final_phi')
-        assert afqmc.propagators.nfb_trig == int(d['nfb_trig']) and afqmc.propagators.nhe_trig == int(d['nhe_trig'])
+        if 'nfb_trig' in d.files:
+            assert afqmc.propagators.nfb_trig == int(d['nfb_trig']) and afqmc.propagators.nhe_trig == int(d['nhe_trig'])
         dev = oracle_device.OracleDevice.instances[-1]
         nprop = dev.calls.count('propagate')
         assert nprop == afqmc.qmc.total_steps, (nprop, afqmc.qmc.total_steps)      # ONE batched launch per step
@@ -1245,6 +1247,14 @@ def make_dropin():
     rdm = got_rdm / got_den[:, None, None, None]
     assert abs(rdm[11, 0, 1, 3].real - (-0.121883381144845)) < 1e-9           # the value qmc/tests/test_afqmc.py pins
     print('dropin generic_bp   back-propagated one-body RDM of the genuine driver over the plug-in classes == traj_bp.npz')
+    # the discrete Hirsch fields (propagation/hubbard.py:12-343 behind get_propagator_driver's 'discrete' branch): the options
+    # of make_traj_hirsch; numpy.random.random is drawn M times per surviving walker by the plug-in class, in walker order
+    run_case('hubbard_hirsch', 'traj_hubbard_hirsch.npz',
+             {'verbosity': 0, 'get_sha1': False,
+              'qmc': {'timestep': 0.01, 'num_steps': 10, 'blocks': 10, 'rng_seed': 8},
+              'model': {'name': "Hubbard", 'nx': 4, 'ny': 4, 'nup': 7, "U": 4, 'ndown': 7},
+              'trial': {'name': 'UHF'}, 'estimates': {'mixed': {'energy_eval_freq': 1}},
+              'propagator': {'hubbard_stratonovich': 'discrete'}})
     # the local-energy weight update and free projection take other branches of the driver-facing classes
     for name, golden, extra in (('hubbard_le', 'traj_hubbard_le.npz', {'hybrid': False}),
                                 ('hubbard_fp', 'traj_hubbard_fp.npz', {'free_projection': True})):

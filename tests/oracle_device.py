@@ -313,6 +313,62 @@ class OracleDevice(object):
         if on:
             raise NotImplementedError("one_rdm accumulation is not part of the stand-in")
 
+    # -- discrete Hirsch fields (afq_set_propagator_hirsch / afq_hirsch_kinetic / _two_body / _finish), constrained path:
+    #    propagation/hubbard.py:285-312 split where the host-uniform path of the library splits it
+    def set_propagator_hirsch(self, bt2, dt, charge_decomposition=False):
+        self.nv = 1
+        self._model = ref.HirschModel(self._sys['H1'], self._sys['U'], self._psi, self.na, self.nb, float(dt),
+                                      bool(charge_decomposition))
+        assert numpy.allclose(self._model.bt2, bt2, rtol=1e-13, atol=1e-15)
+        self._model.single_site = True
+        self._hybrid, self._free = False, False
+        self._apply_log_shift()
+
+    def hirsch_single_site(self, on=True):
+        self._model.single_site = bool(on)
+
+    def hirsch_free_projection(self, on=True):
+        if on:
+            raise NotImplementedError("free projection with discrete fields is not part of the stand-in")
+
+    def hirsch_kinetic(self):
+        self._log('hirsch_kinetic')
+        self._live = [abs(w['weight']) > 1e-8 for w in self._w]                 # qmc/afqmc.py:232, at the start of the sweep
+        for w, live in zip(self._w, self._live):
+            if live and abs(w['weight']) > 0:
+                ref.hirsch_kinetic_importance_sampling(self._model, w)
+
+    def hirsch_two_body(self, u):
+        self._log('propagate')                                                  # the one batched site-loop launch per step
+        u = numpy.asarray(u, dtype=numpy.float64).reshape(self.nw, self.M)
+        fields = numpy.zeros((self.nw, self.M), dtype=numpy.int32)
+        used = numpy.zeros(self.nw, dtype=numpy.int32)
+        for i, (w, live) in enumerate(zip(self._w, self._live)):
+            if not (live and abs(w['weight']) > 0):
+                continue
+            it = iter(u[i])
+            count = [0]
+
+            def uniform():
+                count[0] += 1
+                return next(it)
+            if self._model.single_site:
+                f = ref.hirsch_two_body_single_site(self._model, w, uniform)
+            else:
+                f = ref.hirsch_two_body_direct(self._model, w, uniform)
+            fields[i, :len(f)] = f
+            used[i] = count[0]
+        return fields, used
+
+    def hirsch_finish(self, eshift):
+        for w, live in zip(self._w, self._live):
+            if not live:
+                continue
+            if abs(numpy.real(w['weight'])) > 0:
+                ref.hirsch_kinetic_importance_sampling(self._model, w)
+            w['weight'] *= numpy.exp(self._model.dt * eshift)
+            w['ovlp'] = w['ot']
+
     # -- back-propagation (afq_bp_configure / afq_bp_steps / afq_bp_update): the oracle's field history per walker
     def bp_configure(self, nbp):
         self.nbp = int(nbp)

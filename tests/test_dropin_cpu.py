@@ -17,7 +17,7 @@ from pauxy_amd.context import release_context
 from pauxy_amd.estimators.mixed import local_energy
 from pauxy_amd.utils import io as pio
 from tests import dropin_checks, oracle_device, serialise_walk
-from tests.test_gpu_traj import replay
+from tests.test_gpu_traj import replay, run_hirsch
 
 
 @pytest.fixture
@@ -91,7 +91,7 @@ def test_trace_fixture_is_what_the_dropin_run_recorded():
         "from pauxy_amd.estimators.handler import Estimators",
         "from pauxy_amd.propagation.continuous import get_propagator_driver",
         "from pauxy_amd.walkers.handler import Walkers"]
-    assert set(doc['cases']) == {'hubbard_c1', 'generic', 'ueg', 'generic_bp', 'hubbard_le', 'hubbard_fp'}
+    assert set(doc['cases']) == {'hubbard_c1', 'generic', 'ueg', 'generic_bp', 'hubbard_hirsch', 'hubbard_le', 'hubbard_fp'}
     for case in doc['cases'].values():
         assert max(case['max_rel_err'].values()) < 1e-8
     t = doc['trace']
@@ -125,6 +125,29 @@ def test_plugin_classes_over_the_standin_reproduce_the_golden_trajectory(golden,
     replay(d, s, t, opts, monkeypatch)
     dev = standin.instances[-1]
     assert dev.calls.count('propagate') == int(d['nsteps']) * int(d['nblocks'])   # one batched launch per step
+
+
+@pytest.mark.parametrize('name,kw', [('traj_hubbard_hirsch.npz', {}), ('traj_hubbard_hirsch_charge.npz', {}),
+                                     ('traj_hirsch_direct.npz', {'direct': True}),
+                                     ('traj_hirsch_bp.npz', {'bp': {'tau_bp': 0.04, 'one_rdm': True}})],
+                         ids=['single-site', 'charge', 'direct', 'back-propagation'])
+def test_hirsch_plugin_class_over_the_standin(golden, standin, monkeypatch, name, kw):
+    """The discrete-field propagator class (batched site loop with the reference's stream of uniforms, the half step that
+    decides who still draws) over the stand-in, through the restated per-walker loop."""
+    run_hirsch(golden, monkeypatch, name, **kw)
+
+
+def test_back_propagation_plugin_class_over_the_standin(golden, standin, monkeypatch):
+    """BackPropagation (window bookkeeping, split lengths, output rows) with the oracle's field history underneath."""
+    d = golden('traj_bp.npz')
+    s = systems.Generic((3, 3), numpy.array([d['h1e'], d['h1e']]), d['chol'], float(d['ecore']))
+    t = trial_mod.SingleDetTrial(s, d['psi'])
+    out = {}
+    replay(d, s, t, {}, monkeypatch, est_extra={'back_propagated': {'tau_bp': 0.025, 'one_rdm': True}}, out=out)
+    est = out['afqmc'].estimators.estimators['back_prop']
+    numpy.testing.assert_allclose(numpy.array(est.denominator), d['bp_denominator'], rtol=1e-9)
+    numpy.testing.assert_allclose(numpy.array(est.one_rdm), d['bp_one_rdm'], rtol=1e-8, atol=1e-10)
+    assert abs(est.rdm()[11, 0, 1, 3].real - (-0.121883381144845)) < 1e-9
 
 
 def test_default_output_file_is_the_reference_s(golden, standin, monkeypatch, tmp_path):
