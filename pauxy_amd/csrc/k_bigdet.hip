@@ -185,7 +185,12 @@ __global__ __launch_bounds__(512) void gj_big_kernel(GjArgs a) {
             const bool own = wave == ((p & 15) >> 1);                               // wave-uniform
             if (own) {
                 const cplx d = colk[buf][p];
-                const double dn = 1.0 / (d.x * d.x + d.y * d.y);
+                // reciprocal by v_rcp_f64 + two Newton steps (< 1 ulp off; the IEEE division sequence is a 12-deep dependent
+                // chain on the critical path of every pivot step: see gj_block8 in gj_wave.h)
+                const double nn = d.x * d.x + d.y * d.y;
+                double dn = __builtin_amdgcn_rcp(nn);
+                dn = fma(fma(-nn, dn, 1.0), dn, dn);
+                dn = fma(fma(-nn, dn, 1.0), dn, dn);
                 const double dix = d.x * dn, diy = -d.y * dn;
                 const int x0 = p >> 4;
                 const bool mine = tr == (p & 15);
