@@ -106,7 +106,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->phi_old); dev_free(h->phi_bp); dev_free(h->BH1dag); dev_free(h->bp_xs); dev_free(h->bp_est);
     h->nbp = 0; dev_free(h->xbar); dev_free(h->xs);
     dev_free(h->cmf); dev_free(h->cfb); dev_free(h->vhs); dev_free(h->lu_ws);
-    dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
+    dev_free(h->gj_flag); dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag); dev_free(h->exq_y); h->exq_y_len = 0;
     dev_free(h->alive); dev_free(h->parent_ix); dev_free(h->rdm_acc); h->rdm_on = false;
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }

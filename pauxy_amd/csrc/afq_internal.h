@@ -214,6 +214,7 @@ struct afq_handle {
     bool ltrace_on = false, ltrace_open = false;
     std::vector<hipEvent_t> ltrace_ev;
     std::vector<const char *> ltrace_name;
+    int *gj_flag = nullptr;         // [2 nw] blocked Gauss-Jordan: 1 = a pivot block was poorly conditioned (k_bigdet.hip)
     cplx *estimates = nullptr;      // [10]
     // Mixed estimator with one_rdm: True (estimators/mixed.py:226-229): G then is per-walker STATE (walker.G: the
     // Green's function the walker last evaluated -- before the step's propagation, or at an energy evaluation),

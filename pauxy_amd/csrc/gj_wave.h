@@ -156,19 +156,9 @@ __device__ __attribute__((always_inline)) inline void gj_wave_rj(cplx *O, int n,
     }
 }
 
-// O: n x n row-major in LDS (overwritten with the inverse when write_inverse); returns det via ph / la
-__device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
-                                 cplx &ph, int &la) {
-    if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
-    n = __builtin_amdgcn_readfirstlane(n);
-    if (n <= 8) gj_wave_rj<4>(O, n, lane, write_inverse, rowk, piv, prow);
-    else if (n <= 16) gj_wave_rj<8>(O, n, lane, write_inverse, rowk, piv, prow);
-    else if (n <= 24) gj_wave_rj<12>(O, n, lane, write_inverse, rowk, piv, prow);
-    else if (n <= 26) gj_wave_rj<13>(O, n, lane, write_inverse, rowk, piv, prow);
-    else gj_wave_rj<16>(O, n, lane, write_inverse, rowk, piv, prow);
-    __builtin_amdgcn_wave_barrier();
-    // determinant: product of the pivots (lanes 0..31, normalised after every multiply) and the
-    // parity of the pivot permutation from its inversion count
+// determinant from the pivots: their product (lanes 0..31, normalised after every multiply) and the parity of the pivot
+// permutation from its inversion count
+__device__ __attribute__((always_inline)) inline void gj_wave_det(int n, int lane, const cplx *piv, const int *prow, cplx &ph, int &la) {
     const cplx d = piv[lane & 31];
     double px = d.x, py = d.y;
     int e;
@@ -193,6 +183,31 @@ __device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, 
     const double sg = (__popcll(odd) & 1) ? -1.0 : 1.0;
     ph = cmake(sg * px, sg * py);
     la = e;
+}
+
+// O: n x n row-major in LDS (overwritten with the inverse when write_inverse); returns det via ph / la
+__device__ __attribute__((always_inline)) inline void gj_wave32(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
+                                 cplx &ph, int &la) {
+    if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n <= 8) gj_wave_rj<4>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 16) gj_wave_rj<8>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 24) gj_wave_rj<12>(O, n, lane, write_inverse, rowk, piv, prow);
+    else if (n <= 26) gj_wave_rj<13>(O, n, lane, write_inverse, rowk, piv, prow);
+    else gj_wave_rj<16>(O, n, lane, write_inverse, rowk, piv, prow);
+    __builtin_amdgcn_wave_barrier();
+    gj_wave_det(n, lane, piv, prow, ph, la);
+}
+
+// the same for n <= 16 only: carries the register arrays of one, not five, instantiations (a caller that keeps a lot of
+// its own state in registers: the blocked Gauss-Jordan of k_bigdet.hip)
+__device__ __attribute__((always_inline)) inline void gj_wave16(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
+                                 cplx &ph, int &la) {
+    if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
+    n = __builtin_amdgcn_readfirstlane(n);
+    gj_wave_rj<8>(O, n, lane, write_inverse, rowk, piv, prow);       // (columns beyond n are zero, steps beyond n skipped)
+    __builtin_amdgcn_wave_barrier();
+    gj_wave_det(n, lane, piv, prow, ph, la);
 }
 
 

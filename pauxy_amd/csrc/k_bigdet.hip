@@ -111,6 +111,9 @@ struct GjArgs {
     cplx *O;                         // [2 nw, ld * ld], inverse written in place
     cplx *detm;                      // [2 nw] mantissa of det O_s
     int *dete;                       // [2 nw] binary exponent
+    const int *only = nullptr;       // when set: only the matrices with a non-zero entry are processed
+    int dbg = 0;                     // tuning builds: timing ablations of gj_mfma_kernel (WRONG results): 1 no inversion of the
+                                     // pivot tile, 2 no rank-16 update, 4 no parking, 8 no row scaling
 };
 
 // wave-wide maximum of a 32-bit key by DPP row shifts / row broadcasts (no LDS traffic)
@@ -139,6 +142,7 @@ __device__ inline unsigned wave_max_u32(unsigned v) {
 // unused rows (ties -> lowest row), which differs from LAPACK's choice only in exact-tie/rounding
 // cases; determinant and inverse do not depend on the pivot order beyond rounding.
 __global__ __launch_bounds__(512) void gj_big_kernel(GjArgs a) {
+    if (a.only && !a.only[blockIdx.x]) return;           // (second pass behind the blocked kernel: flagged matrices only)
     __shared__ cplx colk[2][GJ_N], rowk[2][GJ_N], piv[GJ_N];
     __shared__ int prow[GJ_N], invp[GJ_N], s_par;
     __shared__ cplx stage[16][GJ_N];
@@ -304,6 +308,217 @@ __global__ __launch_bounds__(512) void gj_big_kernel(GjArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ 2b. blocked Gauss-Jordan on the matrix pipe (round 4)
+// The step-by-step kernel above spends 4.4 k cycles per pivot on two barriers and a dependent LDS hand-over for 1 k cycles
+// of FMAs (0.23 of the fp64 vector peak).  Here the pivots are 16 x 16 BLOCKS (one MFMA tile): block k is inverted by ONE
+// wave with the register Gauss-Jordan of gj_wave.h (partial pivoting inside the block, no barrier; 1.2 k cycles per pivot),
+// and the rest of a block step is rank-16 matrix arithmetic on MFMA:
+//     P = O[k,k];  O[k,:] <- P^-1 O[k,:] (O[k,k] <- P^-1);  O[i,:] <- O[i,:] - O[i,k] O[k,:] (O[i,k] <- -O[i,k] P^-1), i != k
+// which leaves the inverse in place after the last block; det O = prod det P_k (the P_k are the successive Schur
+// complements).  No pivoting ACROSS blocks: a leading block whose condition is poor loses digits that the full partial
+// pivoting of the kernel above keeps -- a matrix in which the smallest pivot of a block is below 1e-10 of its largest is
+// flagged, left untouched, and redone by that kernel.
+// One 512-thread work-group per matrix; the matrix lives in the registers of the 8 waves as 8 x 8 tiles of 16 x 16 in MFMA
+// accumulator layout (element (4 r + lk, lr) of a tile in register r of lane (lk, lr) -- which is also the B-fragment
+// layout of its four k-steps), wave w owning the tiles (I, (I + w) mod 8): one tile in every tile row and every tile
+// column, so that every block step gives every wave the same work (seven tiles to update, one to scale) and the pivot
+// tile always belongs to wave 0.  Per block step the block column (negated, A-fragment order: 32 KB), the block row
+// (B-fragment order: 32 KB) and the pivot tile (row-major for the inverting wave, then A-fragment order: 4 KB) pass
+// through LDS.
+struct GjMfmaLds {
+    static constexpr int FP = 0, RP = 32768, PL = 65536, SMALL = 69632;         // byte offsets
+    static constexpr int PARK = SMALL + 512 + 512 + 128 + 64;                   // (rowk, piv, prow, scalars in between)
+    static constexpr int BYTES = PARK + 32768;                                  // the parked tiles of wave 0
+};
+
+__global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
+    extern __shared__ __align__(16) unsigned char gsm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, lr = lane & 15;
+    const int n = (b & 1) ? a.nb : a.na;
+    const int nt16 = (n + 15) >> 4;                                    // tile rows / columns that exist
+    cplx *O = a.O + (long)b * a.ld * a.ld;
+    d2_t *Fp = (d2_t *)(gsm + GjMfmaLds::FP), *Rp = (d2_t *)(gsm + GjMfmaLds::RP);
+    cplx *Pl = (cplx *)(gsm + GjMfmaLds::PL);
+    d2_t *Pa = (d2_t *)(gsm + GjMfmaLds::PL);                          // P^-1 in A-fragment order, after the leaf
+    cplx *rowk = (cplx *)(gsm + GjMfmaLds::SMALL);
+    cplx *piv = rowk + 32;
+    int *prow = (int *)(piv + 32);
+    double *scal = (double *)(prow + 32);                              // [0..1] running mantissa, [2] exponent, [3] worst pivot ratio
+    // ---- load: tile i of this wave is (I = i, J = (i + wave) & 7)
+    d4_t Cr[8], Ci[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int J = (i + wave) & 7;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * J + lr;
+            const cplx t = (row < n && col < n) ? O[(long)row * a.ld + col] : cmake(0.0, 0.0);
+            Cr[i][r] = t.x; Ci[i][r] = t.y;
+        }
+    }
+    if (tid == 0) { scal[0] = 1.0; scal[1] = 0.0; scal[2] = 0.0; scal[3] = 1.0; }
+    for (int kb = 0; kb < nt16; ++kb) {
+        const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
+        const int Jk = (kb + wave) & 7;                                // this wave's tile of the block row is (kb, Jk)
+        // ---- S1: block column (negated) -> Fp, block row -> Rp, pivot tile -> Pl
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int J = (i + wave) & 7;
+            if (i < nt16 && J == kb) {                                 // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Fp[(i * 4 + (lr >> 2)) * 64 + (lr & 3) * 16 + 4 * r + lk] = (d2_t){-Cr[i][r], -Ci[i][r]};
+            }
+            if (i == kb && J < nt16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Rp[(J * 4 + r) * 64 + lane] = (d2_t){Cr[i][r], Ci[i][r]};
+                    if (J == kb && 4 * r + lk < nblk && lr < nblk) Pl[(4 * r + lk) * nblk + lr] = cmake(Cr[i][r], Ci[i][r]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- S2: one wave inverts the pivot tile
+        if (wave == 0) {
+            // (wave 0 parks its tiles in LDS around the inversion: the register Gauss-Jordan needs ~100 registers on
+            //  top of the 128 the matrix takes, and the kernel has 256 per lane)
+            d2_t *park = (d2_t *)(gsm + GjMfmaLds::PARK);
+            if (!(a.dbg & 4)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) park[(i * 4 + r) * 64 + lane] = (d2_t){Cr[i][r], Ci[i][r]};
+            }
+            cplx ph = cmake(1.0, 0.0); int la = 0;
+            if (!(a.dbg & 1)) gj_wave16(Pl, nblk, lane, true, rowk, piv, prow, ph, la);
+            if (!(a.dbg & 4)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const d2_t v = park[(i * 4 + r) * 64 + lane]; Cr[i][r] = v[0]; Ci[i][r] = v[1]; }
+            }
+            // pivots of the block: smallest against largest modulus (a poorly conditioned leading block is flagged)
+            const double pm = lane < nblk ? fabs(piv[lane & 31].x) + fabs(piv[lane & 31].y) : 0.0;
+            double pmin = lane < nblk ? pm : 1e300, pmax = pm;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                pmin = fmin(pmin, __shfl_xor(pmin, off));
+                pmax = fmax(pmax, __shfl_xor(pmax, off));
+            }
+            if (lane == 0) {
+                const double mx = scal[0] * ph.x - scal[1] * ph.y, my = scal[0] * ph.y + scal[1] * ph.x;
+                int e2;
+                (void)frexp(fmax(fabs(mx), fabs(my)), &e2);
+                scal[0] = ldexp(mx, -e2); scal[1] = ldexp(my, -e2); scal[2] += (double)(la + e2);
+                const double ratio = pmax > 0.0 ? pmin / pmax : 0.0;
+                if (ratio < scal[3]) scal[3] = ratio;
+            }
+        }
+        __syncthreads();
+        // ---- S3: P^-1 out of Pl: one element per thread of the first four waves for the re-layout; wave 0's pivot tile
+        cplx pe = cmake(0.0, 0.0);
+        if (tid < 256) {
+            const int row = tid >> 4, col = tid & 15;
+            if (row < nblk && col < nblk) pe = Pl[row * nblk + col];
+        }
+        d4_t Nr = (d4_t){0, 0, 0, 0}, Ni = (d4_t){0, 0, 0, 0};         // new value of this wave's tile of the block row
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx t = (4 * r + lk < nblk && lr < nblk) ? Pl[(4 * r + lk) * nblk + lr] : cmake(0.0, 0.0);
+                Nr[r] = t.x; Ni[r] = t.y;
+            }
+        }
+        __syncthreads();
+        // ---- S4: P^-1 in A-fragment order (lane (k, row) of fragment ks = P^-1[row][4 ks + k])
+        if (tid < 256) {
+            const int row = tid >> 4, col = tid & 15;
+            Pa[(col >> 2) * 64 + (col & 3) * 16 + row] = (d2_t){pe.x, pe.y};
+        }
+        __syncthreads();
+        // ---- S5: row scaling R' = P^-1 R for this wave's tile of the block row (wave 0: P^-1 itself, above)
+        const int nks = (nblk + 3) >> 2;                               // k-steps of 4 that hold anything
+        if (wave != 0 && Jk < nt16 && !(a.dbg & 8)) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                d2_t av[2], bv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { av[q] = Pa[(2 * half + q) * 64 + lane]; bv[q] = Rp[(Jk * 4 + 2 * half + q) * 64 + lane]; }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (2 * half + q < nks) {
+                        Nr = mfma16(av[q][0], bv[q][0], Nr); Nr = mfma16(-av[q][1], bv[q][1], Nr);
+                        Ni = mfma16(av[q][0], bv[q][1], Ni); Ni = mfma16(av[q][1], bv[q][0], Ni);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                               // every read of the old block row is done
+        // ---- S6: the new block row into this wave's registers and into Rp
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i == kb) {                                             // wave-uniform; static register index
+                Cr[i] = Nr; Ci[i] = Ni;
+            }
+        }
+        if (Jk < nt16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rp[(Jk * 4 + r) * 64 + lane] = (d2_t){Nr[r], Ni[r]};
+        }
+        __syncthreads();
+        // ---- S7: rank-16 update of every tile outside the block row: C <- (J == kb ? 0 : C) + (-F) R'
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int J = (i + wave) & 7;
+            if (i < nt16 && J < nt16 && i != kb && !(a.dbg & 2)) {
+                d4_t accr = Cr[i], acci = Ci[i];
+                if (J == kb) { accr = (d4_t){0, 0, 0, 0}; acci = (d4_t){0, 0, 0, 0}; }
+                // the fragments of two k-steps at a time (four LDS reads in flight, then eight MFMAs): two LDS latencies per
+                // tile instead of four (fragments beyond nblk hold zeros or stale finite numbers times zeros:
+                // the block column beyond nblk is the matrix's zero padding)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    d2_t av[2], bv[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        av[q] = Fp[(i * 4 + 2 * half + q) * 64 + lane]; bv[q] = Rp[(J * 4 + 2 * half + q) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (2 * half + q < nks) {
+                            accr = mfma16(av[q][0], bv[q][0], accr); accr = mfma16(-av[q][1], bv[q][1], accr);
+                            acci = mfma16(av[q][0], bv[q][1], acci); acci = mfma16(av[q][1], bv[q][0], acci);
+                        }
+                    }
+                }
+                Cr[i] = accr; Ci[i] = acci;
+            }
+        }
+        __syncthreads();                                               // panels free for the next block step
+    }
+    // ---- the inverse back in place, the determinant, the conditioning flag (a flagged matrix is left as it came: the
+    //      step-by-step kernel redoes it)
+    const bool bad = scal[3] < 1e-10;
+    if (a.write_inverse && !bad) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int J = (i + wave) & 7;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * r + lk, col = 16 * J + lr;
+                if (row < n && col < n) O[(long)row * a.ld + col] = cmake(Cr[i][r], Ci[i][r]);
+            }
+        }
+    }
+    if (tid == 0) {
+        a.detm[b] = cmake(scal[0], scal[1]);
+        a.dete[b] = (int)scal[2];
+        flag[b] = bad ? 1 : 0;
+    }
+}
+
 __global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det, int nw) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
@@ -350,7 +565,21 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
         GjArgs a;
         a.na = h->na; a.nb = h->nb; a.ld = nmax; a.write_inverse = ghalf != nullptr || oinv != nullptr;
         a.O = h->big_ws; a.detm = h->detm; a.dete = h->dete;
-        AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+        a.dbg = afq_knob("AFQ_GJ_DBG") ? atoi(afq_knob("AFQ_GJ_DBG")) : 0;
+        // blocked Gauss-Jordan on the matrix pipe for more than one block of 32; the step-by-step kernel for matrices it flags
+        // as poorly conditioned block-wise (none in any test or benchmark so far) and for tuning builds that ask for it
+        const bool blocked = nmax > 32 && !afq_knob("AFQ_GJ_STEPWISE");     // (up to 32: one leaf would do all the work)
+        if (blocked) {
+            static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+            AFQ_HIP(h, afq_raise_lds((const void *)gj_mfma_kernel, GjMfmaLds::BYTES, lds_set));
+            if (!h->gj_flag) AFQ_HIP(h, hipMalloc(&h->gj_flag, sizeof(int) * nb2));
+            AFQ_LAUNCH(h, gj_mfma_kernel, dim3(nb2), dim3(512), GjMfmaLds::BYTES, h->stream, a, h->gj_flag);
+            AFQ_POST(h);
+            a.only = h->gj_flag;                                      // (work-groups of unflagged matrices return at once)
+            AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+        } else {
+            AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+        }
         AFQ_POST(h);
         AFQ_LAUNCH(h, det_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detm,
                            h->dete, det, h->nw);

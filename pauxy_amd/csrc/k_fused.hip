@@ -791,6 +791,10 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                             if (a.ts && w == 0 && n == 3 && (wave & 3) == 0 && lane == 0) {
                                 unsigned long long *o = a.ts + ((wave >> 2) * 16 + c) * 4;
                                 o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+                            }
+                            if (a.ts && w == 0 && n == 3 && lane == 0) {
+                                unsigned long long *o = a.ts + 256 + (wave * 16 + c) * 4;
+                                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
                             })
                 }
             } else
@@ -1029,9 +1033,17 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (int c = 0; c < NCH; ++c) {
                 const bool more = c + 1 < NCH;
+                PF_TUNE(unsigned long long t0, t1, t2, t3; asm volatile("s_memtime %0" : "=s"(t0));)
                 half(f0, f1, sl, c, 1, true, false);             // sub-step 0 of chunk c; fetch its sub-step 1
+                PF_TUNE(asm volatile("s_memtime %0" : "=s"(t1));)
                 if (more) sl = next_chunk_sync();                 // chunk c + 1 has landed
+                PF_TUNE(asm volatile("s_memtime %0" : "=s"(t2));)
                 half(f1, f0, sl, c + 1, 0, more, more);          // sub-step 1 of chunk c; refill, fetch sub-step 0 of chunk c + 1
+                PF_TUNE(asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3));
+                        if (a.ts && w == 0 && n == 3 && lane == 0) {
+                            unsigned long long *o = a.ts + 256 + (wave * 16 + c) * 4;
+                            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+                        })
             }
             // T_n = product / n back into T (rows below the last chunk: nobody reads them any more behind the last chunk
             // barrier), the barrier, then the remainder rows -- exactly the sequence of taylor() with store_first
@@ -1175,7 +1187,7 @@ int k_prop_fused(afq_handle *h) {
     static unsigned long long *ts_dev = nullptr;
     static int ts_launch = 0;
     if (afq_knob("AFQ_PF_TS")) {
-        if (!ts_dev) { hipMalloc(&ts_dev, (128 + 32) * 8); hipMemset(ts_dev, 0, (128 + 32) * 8); }
+        if (!ts_dev) { hipMalloc(&ts_dev, (256 + 512) * 8); hipMemset(ts_dev, 0, (256 + 512) * 8); }
         a.ts = ts_dev;
     }
 #endif
@@ -1234,7 +1246,7 @@ int k_prop_fused(afq_handle *h) {
     AFQ_POST(h);
 #ifdef AFQ_TUNING
     if (a.ts && ++ts_launch == 30) {
-        unsigned long long t[128 + 32];
+        unsigned long long t[256 + 512];
         hipStreamSynchronize(h->stream);
         hipMemcpy(t, a.ts, sizeof(t), hipMemcpyDeviceToHost);
         fprintf(stderr, "PF_STAGE ticks: phi->T %lld | one-body %lld | Taylor", (long long)(t[129] - t[128]), (long long)(t[130] - t[129]));
@@ -1246,6 +1258,12 @@ int k_prop_fused(afq_handle *h) {
         }
         fprintf(stderr, "\n");
         fprintf(stderr, " | one-body + store %lld | total %lld\n", (long long)(t[137] - t[130 + h->exp_order]), (long long)(t[137] - t[128]));
+        for (int wv = 0; wv < 8; ++wv) {
+            const unsigned long long *o = t + 256 + (wv * 16 + 5) * 4, *o0 = t + 256 + 5 * 4, *o6 = t + 256 + (wv * 16 + 6) * 4;
+            fprintf(stderr, "PF_ALL wave %d (product 3, chunk 5): start %+5lld  halfA %5lld  sync %5lld (released at %+5lld)  halfB %5lld  | chunk period %lld\n",
+                    wv, (long long)(o[0] - o0[0]), (long long)(o[1] - o[0]), (long long)(o[2] - o[1]), (long long)(o[2] - o0[0]),
+                    (long long)(o[3] - o[2]), (long long)(o6[0] - o[0]));
+        }
         for (int wv = 0; wv < 2; ++wv)
             for (int c = 0; c < (h->M + 7) / 8; ++c) {
                 const unsigned long long *o = t + (wv * 16 + c) * 4;
