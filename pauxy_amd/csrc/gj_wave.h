@@ -210,6 +210,117 @@ __device__ __attribute__((always_inline)) inline void gj_wave16(cplx *O, int n, 
     gj_wave_det(n, lane, piv, prow, ph, la);
 }
 
+// --------------------------------------------------------------------------
+// The same inversion for n <= 16 with every lane busy: lane (q = lane >> 4, r = lane & 15) keeps columns 4 q .. 4 q + 3 of
+// row r (8 VGPRs).  Per pivot step: column k goes from its quad of lanes to the other three by one v_permlane16_swap and
+// one v_permlane32_swap per dword, the pivot search is a DPP maximum over ONE row of 16 lanes (the four rows hold the same
+// column), the pivot row crosses through 16 x 16 bytes of LDS (four stores, four loads) and every lane updates four
+// entries: about half the instructions of gj_wave_rj<8>, whose step is bound by the instruction issue of its one wave.
+// Used by the blocked Gauss-Jordan of k_bigdet.hip, where the pivot tile's inversion is the longest chain of a block step.
+template <int QK>
+__device__ __attribute__((always_inline)) inline double gj_bcast_quad(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const unsigned lo2 = a1[QK & 1], hi2 = b1[QK & 1];
+    const auto a2 = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    const auto b2 = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return __hiloint2double((int)b2[QK >> 1], (int)a2[QK >> 1]);
+}
+
+__device__ inline unsigned gj_row16_max_u32(unsigned v) {
+#define AFQ_DPP_MAX(ctrl, rmask)                                                                         \
+    { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);      \
+      v = v > t ? v : t; }
+    AFQ_DPP_MAX(0x111, 0xf) AFQ_DPP_MAX(0x112, 0xf) AFQ_DPP_MAX(0x114, 0xf) AFQ_DPP_MAX(0x118, 0xf)
+#undef AFQ_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+template <int K>
+__device__ __attribute__((always_inline)) inline void gj_quad_step(double (&vr)[4], double (&vi)[4], int n, int lane, bool &used,
+                                 double &sx, double &sy, double &pdx, double &pdy, int &mystep, cplx *rowk) {
+    constexpr int QK = K >> 2, U = K & 3;
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 64u * q;
+    const double fx = gj_bcast_quad<QK>(vr[U]), fy = gj_bcast_quad<QK>(vi[U]);
+    const unsigned mb = (unsigned)__double2hiint(fabs(fx) + fabs(fy));
+    const unsigned key = used ? 0u : ((((mb >> 5) + 1u) << 5) | (unsigned)(31 - r));
+    const double nnl = fx * fx + fy * fy;
+    double dnl = __builtin_amdgcn_rcp(nnl);
+    dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
+    dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
+    const double ixl = fx * dnl, iyl = -fy * dnl;
+    const int p = 31 - (int)(gj_row16_max_u32(key) & 31u);
+    const bool isp = r == p;
+    used = used || isp;
+    const double fxz = isp ? 0.0 : fx, fyz = isp ? 0.0 : fy;
+    if (q == QK) { vr[U] = isp ? 1.0 : 0.0; vi[U] = 0.0; }
+    if (isp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    cplx rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rk[j] = rowk[4 * q + j];
+    __builtin_amdgcn_sched_barrier(0);
+    const double ix = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ixl), p),
+                                       __builtin_amdgcn_readlane(__double2loint(ixl), p));
+    const double iy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(iyl), p),
+                                       __builtin_amdgcn_readlane(__double2loint(iyl), p));
+    if (isp) { sx = ix; sy = iy; pdx = fx; pdy = fy; mystep = K; }
+    const double mx = fxz * ix - fyz * iy, my = fxz * iy + fyz * ix;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vr[j] = fma(-mx, rk[j].x, vr[j]); vr[j] = fma(my, rk[j].y, vr[j]);
+        vi[j] = fma(-mx, rk[j].y, vi[j]); vi[j] = fma(-my, rk[j].x, vi[j]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// O: n x n row-major in LDS, n <= 16, overwritten with the inverse; piv16[k], prow16[k] = pivot and pivot row of step k
+// afterwards (1 and k for k >= n): the determinant is the caller's business (gj_wave_det below, or all the pivot tiles of a
+// blocked inversion at once)
+__device__ __attribute__((always_inline)) inline void gj_wave16q_inv(cplx *O, int n, int lane, cplx *rowk, cplx *piv16, int *prow16) {
+    if (lane < 16) { piv16[lane] = cmake(1.0, 0.0); prow16[lane] = lane; }
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int q = lane >> 4, r = lane & 15;
+    double vr[4], vi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        const cplx t = (r < n && c < n) ? O[r * n + c] : cmake(0.0, 0.0);
+        vr[j] = t.x; vi[j] = t.y;
+    }
+    bool used = r >= n;
+    double sx = 1.0, sy = 0.0, pdx = 1.0, pdy = 0.0;
+    int mystep = r;
+    __builtin_amdgcn_wave_barrier();
+#define AFQ_GJ_QS(K) if (K < n) gj_quad_step<K>(vr, vi, n, lane, used, sx, sy, pdx, pdy, mystep, rowk);
+    AFQ_GJ_QS(0) AFQ_GJ_QS(1) AFQ_GJ_QS(2) AFQ_GJ_QS(3) AFQ_GJ_QS(4) AFQ_GJ_QS(5) AFQ_GJ_QS(6) AFQ_GJ_QS(7)
+    AFQ_GJ_QS(8) AFQ_GJ_QS(9) AFQ_GJ_QS(10) AFQ_GJ_QS(11) AFQ_GJ_QS(12) AFQ_GJ_QS(13) AFQ_GJ_QS(14) AFQ_GJ_QS(15)
+#undef AFQ_GJ_QS
+    if (q == 0 && r < n) { piv16[mystep] = cmake(pdx, pdy); prow16[mystep] = r; }
+    __builtin_amdgcn_wave_barrier();
+    if (r < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            if (c < n) O[mystep * n + prow16[c]] = cmake(vr[j] * sx - vi[j] * sy, vr[j] * sy + vi[j] * sx);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the same with the determinant (piv, prow: 32 entries each, as gj_wave32)
+__device__ __attribute__((always_inline)) inline void gj_wave16q(cplx *O, int n, int lane, bool write_inverse, cplx *rowk, cplx *piv, int *prow,
+                                  cplx &ph, int &la) {
+    if (lane < 32) { piv[lane] = cmake(1.0, 0.0); prow[lane] = lane; }
+    gj_wave16q_inv(O, n, lane, rowk, piv, prow);
+    gj_wave_det(__builtin_amdgcn_readfirstlane(n), lane, piv, prow, ph, la);
+}
 
 // --------------------------------------------------------------------------
 // Inverse Cholesky factor of a Hermitian positive definite n x n matrix, n <= 32, by ONE wave; same

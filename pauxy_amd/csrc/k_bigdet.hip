@@ -112,8 +112,10 @@ struct GjArgs {
     cplx *detm;                      // [2 nw] mantissa of det O_s
     int *dete;                       // [2 nw] binary exponent
     const int *only = nullptr;       // when set: only the matrices with a non-zero entry are processed
+    unsigned long long *ts = nullptr;   // tuning builds (AFQ_GJ_TS): s_memtime stamps of work-group 0, [wave][block step][point]
     int dbg = 0;                     // tuning builds: timing ablations of gj_mfma_kernel (WRONG results): 1 no inversion of the
-                                     // pivot tile, 2 no rank-16 update, 4 no parking, 8 no row scaling
+                                     // pivot tile, 2 no rank-16 update of the register tiles, 4 none of the diagonal tiles,
+                                     // 8 no block steps at all (load and store only), 16 the halves-layout pivot inversion
 };
 
 // wave-wide maximum of a 32-bit key by DPP row shifts / row broadcasts (no LDS traffic)
@@ -326,10 +328,54 @@ __global__ __launch_bounds__(512) void gj_big_kernel(GjArgs a) {
 // (B-fragment order: 32 KB) and the pivot tile (row-major for the inverting wave, then A-fragment order: 4 KB) pass
 // through LDS.
 struct GjMfmaLds {
-    static constexpr int FP = 0, RP = 32768, PL = 65536, SMALL = 69632;         // byte offsets
-    static constexpr int PARK = SMALL + 512 + 512 + 128 + 64;                   // (rowk, piv, prow, scalars in between)
-    static constexpr int BYTES = PARK + 32768;                                  // the parked tiles of wave 0
+    // byte offsets: block column panels (two: the tiles of the next block column are published as soon as they are up to
+    // date, while the current one is still being read), block row panel, the diagonal tiles (their home), the pivot tile
+    // row-major for the inverting wave, its inverse in A-fragment order (double-buffered: written for step k + 1 while
+    // step k reads its own), pivots and pivot rows of all eight pivot tiles (the determinant is evaluated once, at the end)
+    static constexpr int FP = 0, RP = 65536, DG = 98304, PL = 131072, PA = 135168, PIV = 143360, PROW = 145408, SMALL = 145920;
+    static constexpr int BYTES = SMALL + 512 + 64;                              // + rowk, the flag
 };
+
+// rank-16 product of one tile: acc += A-fragments (4 k-steps of `ap`) x B-fragments (`bp`); complex by THREE real MFMAs per
+// k-step (the phase is bound by the matrix pipe: two waves per SIMD): p1 = sum ar br, p2 = sum ai bi,
+// p3 = acc_i + sum (ar + ai)(br + bi); then acc_r += p1 - p2, acc_i = p3 - p1 - p2.  The fragments of two k-steps at a time
+// (four LDS reads in flight, then six MFMAs).
+__device__ __attribute__((always_inline)) inline void gj_tile_mac(const d2_t *ap, const d2_t *bp, int lane, int nks, d4_t &accr, d4_t &acci) {
+    d4_t p1 = (d4_t){0, 0, 0, 0}, p2 = (d4_t){0, 0, 0, 0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { av[q] = ap[(2 * half + q) * 64 + lane]; bv[q] = bp[(2 * half + q) * 64 + lane]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (2 * half + q < nks) {
+                p1 = mfma16(av[q][0], bv[q][0], p1);
+                p2 = mfma16(av[q][1], bv[q][1], p2);
+                acci = mfma16(av[q][0] + av[q][1], bv[q][0] + bv[q][1], acci);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accr[r] += p1[r] - p2[r]; acci[r] -= p1[r] + p2[r]; }
+}
+
+// Work split (round 4, second version): wave 0 is the PIVOT wave -- it owns the eight diagonal tiles, which live in LDS,
+// and does nothing but bring the next pivot tile up to date, invert it (register Gauss-Jordan, one wave) and publish the
+// inverse, one block step AHEAD of the other seven waves, whose rank-16 update of step k runs meanwhile (look-ahead: the
+// inversion is the longest dependent chain of a step and nothing else waits for it any more).  Waves 1..7 own the tiles
+// (I, (I + w) mod 8) in registers -- one per tile row and tile column -- and share the updates of the diagonal tiles that
+// are not the next pivot.  Two barriers per block step: the row scaling of a wave's tile of the block row needs nothing
+// but P^-1 (published a step ahead) and the wave's own registers.  Global traffic overlaps the first and the last block
+// step: step 0 starts when its block row and column have arrived and takes the other tiles in the order they were
+// requested; every tile is stored right after its last update.
+typedef unsigned int gj_u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int gj_u2_t __attribute__((ext_vector_type(2)));
+
+__device__ inline void gj_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
     extern __shared__ __align__(16) unsigned char gsm[];
@@ -338,184 +384,280 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
     const int lk = lane >> 4, lr = lane & 15;
     const int n = (b & 1) ? a.nb : a.na;
     const int nt16 = (n + 15) >> 4;                                    // tile rows / columns that exist
+    const int nsteps = (a.dbg & 8) ? 0 : nt16;
     cplx *O = a.O + (long)b * a.ld * a.ld;
-    d2_t *Fp = (d2_t *)(gsm + GjMfmaLds::FP), *Rp = (d2_t *)(gsm + GjMfmaLds::RP);
+    d2_t *Fp = (d2_t *)(gsm + GjMfmaLds::FP), *Rp = (d2_t *)(gsm + GjMfmaLds::RP), *Dg = (d2_t *)(gsm + GjMfmaLds::DG);
     cplx *Pl = (cplx *)(gsm + GjMfmaLds::PL);
-    d2_t *Pa = (d2_t *)(gsm + GjMfmaLds::PL);                          // P^-1 in A-fragment order, after the leaf
+    d2_t *Pa = (d2_t *)(gsm + GjMfmaLds::PA);                          // [2][4 k-steps][64]
+    cplx *piv_all = (cplx *)(gsm + GjMfmaLds::PIV);                    // [8 pivot tiles][16]
+    int *prow_all = (int *)(gsm + GjMfmaLds::PROW);
     cplx *rowk = (cplx *)(gsm + GjMfmaLds::SMALL);
-    cplx *piv = rowk + 32;
-    int *prow = (int *)(piv + 32);
-    double *scal = (double *)(prow + 32);                              // [0..1] running mantissa, [2] exponent, [3] worst pivot ratio
-    // ---- load: tile i of this wave is (I = i, J = (i + wave) & 7)
-    d4_t Cr[8], Ci[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int J = (i + wave) & 7;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + 4 * r + lk, col = 16 * J + lr;
-            const cplx t = (row < n && col < n) ? O[(long)row * a.ld + col] : cmake(0.0, 0.0);
-            Cr[i][r] = t.x; Ci[i][r] = t.y;
+    int *s_bad = (int *)(rowk + 32);
+#ifdef AFQ_TUNING
+    auto stamp = [&](int kb, int pt) {
+        if (a.ts && b == 0) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+            if (lane == 0) a.ts[(wave * 8 + kb) * 8 + pt] = t;
         }
-    }
-    if (tid == 0) { scal[0] = 1.0; scal[1] = 0.0; scal[2] = 0.0; scal[3] = 1.0; }
-    for (int kb = 0; kb < nt16; ++kb) {
-        const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
-        const int Jk = (kb + wave) & 7;                                // this wave's tile of the block row is (kb, Jk)
-        // ---- S1: block column (negated) -> Fp, block row -> Rp, pivot tile -> Pl
+    };
+#define GJ_STAMP(kb, pt) stamp(kb, pt)
+#else
+#define GJ_STAMP(kb, pt)
+#endif
+    // B-fragments of block column J in step kb: the scaled block row, or P^-1 itself (its home) for the pivot's own column
+    // (the update then turns O[i, k] into -O[i, k] P^-1)
+    auto bpanel = [&](int J, int kb) { return J == kb ? Dg + kb * 256 : Rp + J * 256; };
+    auto apanel = [&](int I, int kb) { return Fp + (kb & 1) * 2048 + I * 256; };       // A-fragments of tile row I in step kb
+
+    if (wave == 0) {
+        // ================================================================= pivot wave
+        __builtin_amdgcn_s_setprio(3);                                 // its chain is the block step's critical path
+        // inverts the pivot tile `t` (row-major in Pl, compact nb x nb), leaves P^-1 in A-fragment order in Pa[t & 1] and
+        // in accumulator (= B-fragment) layout in Dg[t]; pivots and pivot rows stay in piv_all / prow_all
+        auto invert = [&](const int t, const int nb) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(a.dbg & 1)) gj_wave16q_inv(Pl, nb, lane, rowk, piv_all + 16 * t, prow_all + 16 * t);
+            GJ_STAMP(t ? t - 1 : 0, t ? 4 : 7);
+            d2_t *pa = Pa + (t & 1) * 256;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int J = (i + wave) & 7;
-            if (i < nt16 && J == kb) {                                 // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Fp[(i * 4 + (lr >> 2)) * 64 + (lr & 3) * 16 + 4 * r + lk] = (d2_t){-Cr[i][r], -Ci[i][r]};
+            for (int q = 0; q < 4; ++q) {
+                const int e = lane + 64 * q, row = e >> 4, col = e & 15;
+                const cplx v = (row < nb && col < nb) ? Pl[row * nb + col] : cmake(0.0, 0.0);
+                pa[(col >> 2) * 64 + (col & 3) * 16 + row] = (d2_t){v.x, v.y};
+                Dg[(t * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col] = (d2_t){v.x, v.y};
             }
-            if (i == kb && J < nt16) {
+        };
+        // after the last pivot tile: determinant = product of all pivots x parity of every tile's pivot order; a tile whose
+        // pivots span more than ten decades flags the matrix (redone by the step-by-step kernel, nothing stored here)
+        auto finish = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double px = 1.0, py = 0.0, worst = 1.0;
+            int ex = 0, odd = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = (lane >> 4) + 4 * h, k = lane & 15;
+                const int nb = n - 16 * t < 16 ? n - 16 * t : 16;          // (<= 0 for tiles that do not exist)
+                const bool ok = k < nb && !(a.dbg & 1);
+                const cplx d = ok ? piv_all[16 * t + k] : cmake(1.0, 0.0);
+                const double pm = fabs(d.x) + fabs(d.y);
+                double pmin = ok ? pm : 1e300, pmax = ok ? pm : 0.0;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    pmin = fmin(pmin, __shfl_xor(pmin, off));
+                    pmax = fmax(pmax, __shfl_xor(pmax, off));
+                }
+                const double ratio = nb > 0 ? (pmax > 0.0 ? pmin / pmax : 0.0) : 1.0;
+                worst = ratio < worst ? ratio : worst;
+                int inv = 0;
+                if (ok) {
+                    const int pr = prow_all[16 * t + k];
+                    for (int j = k + 1; j < nb; ++j) inv += prow_all[16 * t + j] < pr ? 1 : 0;
+                }
+                odd ^= inv & 1;
+                const double tx = px * d.x - py * d.y, ty = px * d.y + py * d.x;
+                int e2;
+                (void)frexp(fmax(fabs(tx), fabs(ty)), &e2);
+                px = ldexp(tx, -e2); py = ldexp(ty, -e2); ex += e2;
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double qx = __shfl_xor(px, off), qy = __shfl_xor(py, off);
+                const int qe = __shfl_xor(ex, off);
+                const double tx = px * qx - py * qy, ty = px * qy + py * qx;
+                int e2;
+                (void)frexp(fmax(fabs(tx), fabs(ty)), &e2);
+                px = ldexp(tx, -e2); py = ldexp(ty, -e2);
+                ex += qe + e2;
+                worst = fmin(worst, __shfl_xor(worst, off));
+            }
+            const double sg = (__popcll(__ballot(odd != 0)) & 1) ? -1.0 : 1.0;
+            const bool bad = !(worst >= 1e-10);
+            if (lane == 0) { *s_bad = bad ? 1 : 0; a.detm[b] = cmake(sg * px, sg * py); a.dete[b] = ex; flag[b] = bad ? 1 : 0; }
+        };
+        // prologue: the diagonal tiles to their home, the first pivot tile inverted while the others arrive
+        {
+            cplx dt[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    Rp[(J * 4 + r) * 64 + lane] = (d2_t){Cr[i][r], Ci[i][r]};
-                    if (J == kb && 4 * r + lk < nblk && lr < nblk) Pl[(4 * r + lk) * nblk + lr] = cmake(Cr[i][r], Ci[i][r]);
+                    const int row = 16 * i + 4 * r + lk, col = 16 * i + lr;
+                    dt[i][r] = (row < n && col < n) ? O[(long)row * a.ld + col] : cmake(0.0, 0.0);
+                }
+            const int nb0 = n < 16 ? n : 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + lk < nb0 && lr < nb0) Pl[(4 * r + lk) * nb0 + lr] = dt[0][r];
+            invert(0, nb0);
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dg[(i * 4 + r) * 64 + lane] = (d2_t){dt[i][r].x, dt[i][r].y};
+            if (nt16 == 1) finish();
+        }
+        gj_lds_barrier();                                              // P
+        for (int kb = 0; kb < nsteps; ++kb) {
+            const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
+            const int nks = (nblk + 3) >> 2;
+            GJ_STAMP(kb, 0);
+            GJ_STAMP(kb, 1);
+            gj_lds_barrier();                                          // B1
+            GJ_STAMP(kb, 2);
+            // the next pivot tile up to date, inverted, published -- while the other waves update everything else
+            const int nx = kb + 1;
+            if (nx < nt16) {
+                const int nbx = n - 16 * nx < 16 ? n - 16 * nx : 16;
+                d4_t accr, acci;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const d2_t v = Dg[(nx * 4 + r) * 64 + lane]; accr[r] = v[0]; acci[r] = v[1]; }
+                gj_tile_mac(apanel(nx, kb), Rp + nx * 256, lane, nks, accr, acci);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + lk < nbx && lr < nbx) Pl[(4 * r + lk) * nbx + lr] = cmake(accr[r], acci[r]);
+                GJ_STAMP(kb, 3);
+                invert(nx, nbx);
+                if (nx == nt16 - 1) finish();
+            } else if (a.write_inverse && !*s_bad) {                   // last step: this pivot's inverse is final
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * kb + 4 * r + lk, col = 16 * kb + lr;
+                    const d2_t v = Dg[(kb * 4 + r) * 64 + lane];
+                    if (row < n && col < n) O[(long)row * a.ld + col] = cmake(v[0], v[1]);
                 }
             }
+            GJ_STAMP(kb, 5);
+            gj_lds_barrier();                                          // B4
+            GJ_STAMP(kb, 6);
         }
-        __syncthreads();
-        // ---- S2: one wave inverts the pivot tile
-        if (wave == 0) {
-            // (wave 0 parks its tiles in LDS around the inversion: the register Gauss-Jordan needs ~100 registers on
-            //  top of the 128 the matrix takes, and the kernel has 256 per lane)
-            d2_t *park = (d2_t *)(gsm + GjMfmaLds::PARK);
-            if (!(a.dbg & 4)) {
+        return;
+    }
+    // ===================================================================== tile waves 1..7: tile i is (I = i, J = (i + wave) & 7)
+    d4_t Cr[8], Ci[8];
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(O, 0, a.ld * a.ld * (int)sizeof(cplx), 0x00020000);
+    const int lane_off = (lk * a.ld + lr) * (int)sizeof(cplx);
+    // (buffer loads: lanes outside the matrix ask for an offset beyond the descriptor's range and get zeros -- no branch
+    //  around a load, so the loads retire in the order they were requested and step 0 waits only for what it uses)
+    auto load_tile = [&](int I, int J, d4_t &tr, d4_t &ti) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) park[(i * 4 + r) * 64 + lane] = (d2_t){Cr[i][r], Ci[i][r]};
-            }
-            cplx ph = cmake(1.0, 0.0); int la = 0;
-            if (!(a.dbg & 1)) gj_wave16(Pl, nblk, lane, true, rowk, piv, prow, ph, la);
-            if (!(a.dbg & 4)) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const d2_t v = park[(i * 4 + r) * 64 + lane]; Cr[i][r] = v[0]; Ci[i][r] = v[1]; }
-            }
-            // pivots of the block: smallest against largest modulus (a poorly conditioned leading block is flagged)
-            const double pm = lane < nblk ? fabs(piv[lane & 31].x) + fabs(piv[lane & 31].y) : 0.0;
-            double pmin = lane < nblk ? pm : 1e300, pmax = pm;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                pmin = fmin(pmin, __shfl_xor(pmin, off));
-                pmax = fmax(pmax, __shfl_xor(pmax, off));
-            }
-            if (lane == 0) {
-                const double mx = scal[0] * ph.x - scal[1] * ph.y, my = scal[0] * ph.y + scal[1] * ph.x;
-                int e2;
-                (void)frexp(fmax(fabs(mx), fabs(my)), &e2);
-                scal[0] = ldexp(mx, -e2); scal[1] = ldexp(my, -e2); scal[2] += (double)(la + e2);
-                const double ratio = pmax > 0.0 ? pmin / pmax : 0.0;
-                if (ratio < scal[3]) scal[3] = ratio;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + 4 * r + lk, col = 16 * J + lr;
+            const int uo = ((16 * I + 4 * r) * a.ld + 16 * J) * (int)sizeof(cplx);
+            // (real and imaginary part by separate 8-byte loads, straight into the accumulator registers: a 16-byte load
+            //  needs two moves per row that the compiler places in front of the block-step loop, behind a wait for all loads)
+            const int vo = (row < n && col < n) ? lane_off : 0x7fffffff;
+            tr[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(orsrc, vo, uo, 0));
+            ti[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(orsrc, vo, uo + 8, 0));   // (+ 8 in the scalar
+                                                                   // offset: as an immediate the two loads are merged again)
         }
-        __syncthreads();
-        // ---- S3: P^-1 out of Pl: one element per thread of the first four waves for the re-layout; wave 0's pivot tile
-        cplx pe = cmake(0.0, 0.0);
-        if (tid < 256) {
-            const int row = tid >> 4, col = tid & 15;
-            if (row < nblk && col < nblk) pe = Pl[row * nblk + col];
-        }
-        d4_t Nr = (d4_t){0, 0, 0, 0}, Ni = (d4_t){0, 0, 0, 0};         // new value of this wave's tile of the block row
-        if (wave == 0) {
+    };
+    // (buffer stores: descriptor + one 32-bit lane offset + a scalar offset per row of a tile; as 64-bit addresses the 32
+    //  rows of a wave's tiles are hoisted out of the block-step loop into 64 VGPRs that the loop does not have)
+    auto store_tile = [&](int I, int J, const d4_t &tr, const d4_t &ti) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const cplx t = (4 * r + lk < nblk && lr < nblk) ? Pl[(4 * r + lk) * nblk + lr] : cmake(0.0, 0.0);
-                Nr[r] = t.x; Ni[r] = t.y;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + 4 * r + lk, col = 16 * J + lr;
+            const int uo = ((16 * I + 4 * r) * a.ld + 16 * J) * (int)sizeof(cplx);
+            if (row < n && col < n)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gj_u4_t, (d2_t){tr[r], ti[r]}), orsrc, lane_off, uo, 0);
         }
-        __syncthreads();
-        // ---- S4: P^-1 in A-fragment order (lane (k, row) of fragment ks = P^-1[row][4 ks + k])
-        if (tid < 256) {
-            const int row = tid >> 4, col = tid & 15;
-            Pa[(col >> 2) * 64 + (col & 3) * 16 + row] = (d2_t){pe.x, pe.y};
-        }
-        __syncthreads();
-        // ---- S5: row scaling R' = P^-1 R for this wave's tile of the block row (wave 0: P^-1 itself, above)
+    };
+    // block column tile (negated) -> Fp in A-fragment order
+    auto publish_col = [&](int I, int kb, const d4_t &tr, const d4_t &ti) {
+        d2_t *fp = apanel(I, kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fp[(lr >> 2) * 64 + (lr & 3) * 16 + 4 * r + lk] = (d2_t){-tr[r], -ti[r]};
+    };
+    // requests in the order of first use: step 0's tile of the block row, its tile of the block column (a second copy, so
+    // that nothing else has to have arrived when it is published), then the tiles in the order step 0 updates them
+    {
+        const int i0 = (8 - wave) & 7;                                 // tile (i0, 0) is this wave's
+        load_tile(0, wave, Cr[0], Ci[0]);
+        d4_t f0r, f0i;
+        load_tile(i0, 0, f0r, f0i);
+        __builtin_amdgcn_sched_barrier(0);                             // (the scheduler would request these two last)
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { load_tile(i, (i + wave) & 7, Cr[i], Ci[i]); __builtin_amdgcn_sched_barrier(0); }
+        if (i0 < nt16) publish_col(i0, 0, f0r, f0i);
+    }
+    gj_lds_barrier();                                                  // P
+    for (int kb = 0; kb < nsteps; ++kb) {
+        const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
         const int nks = (nblk + 3) >> 2;                               // k-steps of 4 that hold anything
-        if (wave != 0 && Jk < nt16 && !(a.dbg & 8)) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                d2_t av[2], bv[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { av[q] = Pa[(2 * half + q) * 64 + lane]; bv[q] = Rp[(Jk * 4 + 2 * half + q) * 64 + lane]; }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (2 * half + q < nks) {
-                        Nr = mfma16(av[q][0], bv[q][0], Nr); Nr = mfma16(-av[q][1], bv[q][1], Nr);
-                        Ni = mfma16(av[q][0], bv[q][1], Ni); Ni = mfma16(av[q][1], bv[q][0], Ni);
-                    }
-                }
-            }
-        }
-        __syncthreads();                                               // every read of the old block row is done
-        // ---- S6: the new block row into this wave's registers and into Rp
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i == kb) {                                             // wave-uniform; static register index
-                Cr[i] = Nr; Ci[i] = Ni;
-            }
-        }
+        const int Jk = (kb + wave) & 7;                                // this wave's tile of the block row is (kb, Jk)
+        const bool st = kb == nt16 - 1 && a.write_inverse && !*s_bad; // last step: every tile is final after its update
+        GJ_STAMP(kb, 0);
+        // ---- row scaling R' = P^-1 R of this wave's tile of the block row, straight from its registers (the accumulator
+        //      layout IS the B-fragment order: register ks = k-step ks) -> Rp and back into the registers
         if (Jk < nt16) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Rp[(Jk * 4 + r) * 64 + lane] = (d2_t){Nr[r], Ni[r]};
+            for (int i = 0; i < 8; ++i) {
+                if (i == kb) {                                         // wave-uniform; static register index
+                    const d2_t *pa = Pa + (kb & 1) * 256;
+                    d2_t av[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) av[ks] = pa[ks * 64 + lane];
+                    d4_t Nr = (d4_t){0, 0, 0, 0}, Ni = (d4_t){0, 0, 0, 0}, p2 = (d4_t){0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (ks < nks) {                                // three products per k-step, as in gj_tile_mac
+                            Nr = mfma16(av[ks][0], Cr[i][ks], Nr);
+                            p2 = mfma16(av[ks][1], Ci[i][ks], p2);
+                            Ni = mfma16(av[ks][0] + av[ks][1], Cr[i][ks] + Ci[i][ks], Ni);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { Ni[r] -= Nr[r] + p2[r]; Nr[r] -= p2[r]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Rp[(Jk * 4 + r) * 64 + lane] = (d2_t){Nr[r], Ni[r]};
+                    Cr[i] = Nr; Ci[i] = Ni;
+                    if (st) store_tile(i, Jk, Nr, Ni);
+                    if (Jk == kb + 1) publish_col(i, kb + 1, Nr, Ni);  // (wave 1: row kb of the next step's block column)
+                }
+            }
         }
-        __syncthreads();
-        // ---- S7: rank-16 update of every tile outside the block row: C <- (J == kb ? 0 : C) + (-F) R'
+        GJ_STAMP(kb, 1);
+        gj_lds_barrier();                                              // B1
+        GJ_STAMP(kb, 2);
+        // ---- rank-16 update of every tile outside the block row: C <- (J == kb ? 0 : C) + (-F) R'
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int J = (i + wave) & 7;
             if (i < nt16 && J < nt16 && i != kb && !(a.dbg & 2)) {
                 d4_t accr = Cr[i], acci = Ci[i];
                 if (J == kb) { accr = (d4_t){0, 0, 0, 0}; acci = (d4_t){0, 0, 0, 0}; }
-                // the fragments of two k-steps at a time (four LDS reads in flight, then eight MFMAs): two LDS latencies per
-                // tile instead of four (fragments beyond nblk hold zeros or stale finite numbers times zeros:
-                // the block column beyond nblk is the matrix's zero padding)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    d2_t av[2], bv[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        av[q] = Fp[(i * 4 + 2 * half + q) * 64 + lane]; bv[q] = Rp[(J * 4 + 2 * half + q) * 64 + lane];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        if (2 * half + q < nks) {
-                            accr = mfma16(av[q][0], bv[q][0], accr); accr = mfma16(-av[q][1], bv[q][1], accr);
-                            acci = mfma16(av[q][0], bv[q][1], acci); acci = mfma16(av[q][1], bv[q][0], acci);
-                        }
-                    }
-                }
+                gj_tile_mac(apanel(i, kb), bpanel(J, kb), lane, nks, accr, acci);
                 Cr[i] = accr; Ci[i] = acci;
+                if (st) store_tile(i, J, accr, acci);
+                if (J == kb + 1) publish_col(i, kb + 1, accr, acci);   // wave-uniform: the next step's block column
             }
         }
-        __syncthreads();                                               // panels free for the next block step
-    }
-    // ---- the inverse back in place, the determinant, the conditioning flag (a flagged matrix is left as it came: the
-    //      step-by-step kernel redoes it)
-    const bool bad = scal[3] < 1e-10;
-    if (a.write_inverse && !bad) {
+        GJ_STAMP(kb, 3);
+        // ... and the diagonal tiles that are neither this pivot nor the next one (that is wave 0's): one each for waves
+        // 1, 2, 3, 5, 6, 7 -- not wave 4, the pivot wave's neighbour on its SIMD: the register Gauss-Jordan runs 17 k cycles
+        // beside 12 k cycles of fp64 MFMAs and 21.5 k beside 23 k (all six tiles on wave 4), 12.5 k alone
+        // (a load inside the loop whose value the loop uses -- an out-of-range buffer load: zero, no memory access: in front
+        //  of a loop that stores, loads nothing and uses registers with loads in flight the compiler waits for ALL
+        //  outstanding loads, which is exactly the wait step 0 is arranged to avoid.  Here, behind the last use of a tile,
+        //  because loads retire in order.)
+        const int zero = __builtin_amdgcn_raw_buffer_load_b32(orsrc, 0x7fffffff, 0, 0);
+        for (int i = 0; i < nt16; ++i) {
+            const int rank = i - (i > kb ? 1 : 0) - (i > kb + 1 ? 1 : 0);      // 0..5 among the tiles that are updated here
+            const int owner = rank < 3 ? rank + 1 : rank < 6 ? rank + 2 : 4;   // (0..6 in the last step: there is no next pivot)
+            if (i == kb || i == kb + 1 || wave != owner + zero || (a.dbg & 4)) continue;
+            d4_t accr, acci;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int J = (i + wave) & 7;
+            for (int r = 0; r < 4; ++r) { const d2_t v = Dg[(i * 4 + r) * 64 + lane]; accr[r] = v[0]; acci[r] = v[1]; }
+            gj_tile_mac(apanel(i, kb), Rp + i * 256, lane, nks, accr, acci);
+            if (st) store_tile(i, i, accr, acci);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * i + 4 * r + lk, col = 16 * J + lr;
-                if (row < n && col < n) O[(long)row * a.ld + col] = cmake(Cr[i][r], Ci[i][r]);
+                for (int r = 0; r < 4; ++r) Dg[(i * 4 + r) * 64 + lane] = (d2_t){accr[r], acci[r]};
             }
         }
-    }
-    if (tid == 0) {
-        a.detm[b] = cmake(scal[0], scal[1]);
-        a.dete[b] = (int)scal[2];
-        flag[b] = bad ? 1 : 0;
+        GJ_STAMP(kb, 5);
+        gj_lds_barrier();                                              // B4: panels free for the next block step
+        GJ_STAMP(kb, 6);
     }
 }
 
@@ -565,7 +707,6 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
         GjArgs a;
         a.na = h->na; a.nb = h->nb; a.ld = nmax; a.write_inverse = ghalf != nullptr || oinv != nullptr;
         a.O = h->big_ws; a.detm = h->detm; a.dete = h->dete;
-        a.dbg = afq_knob("AFQ_GJ_DBG") ? atoi(afq_knob("AFQ_GJ_DBG")) : 0;
         // blocked Gauss-Jordan on the matrix pipe for more than one block of 32; the step-by-step kernel for matrices it flags
         // as poorly conditioned block-wise (none in any test or benchmark so far) and for tuning builds that ask for it
         const bool blocked = nmax > 32 && !afq_knob("AFQ_GJ_STEPWISE");     // (up to 32: one leaf would do all the work)
@@ -573,8 +714,34 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
             static size_t lds_set[AFQ_MAX_DEVICES] = {0};
             AFQ_HIP(h, afq_raise_lds((const void *)gj_mfma_kernel, GjMfmaLds::BYTES, lds_set));
             if (!h->gj_flag) AFQ_HIP(h, hipMalloc(&h->gj_flag, sizeof(int) * nb2));
+            a.dbg = afq_knob("AFQ_GJ_DBG") ? atoi(afq_knob("AFQ_GJ_DBG")) : 0;
+#ifdef AFQ_TUNING
+            static unsigned long long *ts_dev = nullptr;
+            static int ts_launch = 0;
+            if (afq_knob("AFQ_GJ_TS")) {
+                if (!ts_dev) { hipMalloc(&ts_dev, 512 * 8); hipMemset(ts_dev, 0, 512 * 8); }
+                a.ts = ts_dev;
+            }
+#endif
             AFQ_LAUNCH(h, gj_mfma_kernel, dim3(nb2), dim3(512), GjMfmaLds::BYTES, h->stream, a, h->gj_flag);
             AFQ_POST(h);
+#ifdef AFQ_TUNING
+            if (a.ts && ++ts_launch == 30) {
+                unsigned long long t[512];
+                hipStreamSynchronize(h->stream);
+                hipMemcpy(t, a.ts, sizeof(t), hipMemcpyDeviceToHost);
+                const unsigned long long t0 = t[0];
+                for (int kb = 0; kb < 8; ++kb)
+                    for (int wv = 0; wv < 8; ++wv) {
+                        const unsigned long long *o = t + (wv * 8 + kb) * 8;
+                        fprintf(stderr, "GJ_TS step %d wave %d: start %+7lld | to B1 %5lld | in B1 %5lld | %s %5lld | %s %5lld | %s %5lld | in B4 %5lld\n", kb, wv,
+                                (long long)(o[0] - t0), (long long)(o[1] - o[0]), (long long)(o[2] - o[1]),
+                                wv ? "tiles" : "upd next", (long long)(o[3] - o[2]),
+                                wv ? "-" : "leaf", wv ? 0ll : (long long)(o[4] - o[3]),
+                                wv ? "diag share" : "conv", (long long)(o[5] - (wv ? o[3] : o[4])), (long long)(o[6] - o[5]));
+                    }
+            }
+#endif
             a.only = h->gj_flag;                                      // (work-groups of unflagged matrices return at once)
             AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
         } else {
