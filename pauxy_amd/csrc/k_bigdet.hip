@@ -333,7 +333,10 @@ struct GjMfmaLds {
     // row-major for the inverting wave, its inverse in A-fragment order (double-buffered: written for step k + 1 while
     // step k reads its own), pivots and pivot rows of all eight pivot tiles (the determinant is evaluated once, at the end)
     static constexpr int FP = 0, RP = 65536, DG = 98304, PL = 131072, PA = 135168, PIV = 143360, PROW = 145408, SMALL = 145920;
-    static constexpr int BYTES = SMALL + 512 + 64;                              // + rowk, the flag
+    // + rowk, the flag, the growth guard: largest |entry| of block row / block column k by wave [2][8][8], lane maxima of
+    // |P_k^-1| [8][64]
+    static constexpr int BMAX = SMALL + 512 + 64, PMAX = BMAX + 512;
+    static constexpr int BYTES = PMAX + 2048;
 };
 
 // rank-16 product of one tile: acc += A-fragments (4 k-steps of `ap`) x B-fragments (`bp`); complex by THREE real MFMAs per
@@ -393,6 +396,19 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
     int *prow_all = (int *)(gsm + GjMfmaLds::PROW);
     cplx *rowk = (cplx *)(gsm + GjMfmaLds::SMALL);
     int *s_bad = (int *)(rowk + 32);
+    unsigned *bmax = (unsigned *)(gsm + GjMfmaLds::BMAX), *pmaxp = (unsigned *)(gsm + GjMfmaLds::PMAX);
+    // largest |re|, |im| of a tile as the high word of the double (positive doubles order like their bit patterns: integer
+    // maxima of the sign-stripped high words, no fp64 operation), wave-wide.  A NaN counts as larger than everything.
+    auto tile_max = [&](const d4_t &tr, const d4_t &ti) {
+        unsigned key = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned hr = (unsigned)__double2hiint(tr[r]) & 0x7fffffffu, hi = (unsigned)__double2hiint(ti[r]) & 0x7fffffffu;
+            key = key > hr ? key : hr;
+            key = key > hi ? key : hi;
+        }
+        return gj_wave_max_u32(key);
+    };
 #ifdef AFQ_TUNING
     auto stamp = [&](int kb, int pt) {
         if (a.ts && b == 0) {
@@ -420,20 +436,36 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
             if (!(a.dbg & 1)) gj_wave16q_inv(Pl, nb, lane, rowk, piv_all + 16 * t, prow_all + 16 * t);
             GJ_STAMP(t ? t - 1 : 0, t ? 4 : 7);
             d2_t *pa = Pa + (t & 1) * 256;
+            double m = 0.0;
+            bool isnan = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = lane + 64 * q, row = e >> 4, col = e & 15;
                 const cplx v = (row < nb && col < nb) ? Pl[row * nb + col] : cmake(0.0, 0.0);
                 pa[(col >> 2) * 64 + (col & 3) * 16 + row] = (d2_t){v.x, v.y};
                 Dg[(t * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col] = (d2_t){v.x, v.y};
+                m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+                isnan = isnan || v.x != v.x || v.y != v.y;
             }
+            pmaxp[t * 64 + lane] = isnan ? 0x7ff80000u : (unsigned)__double2hiint(m);   // (reduced once, in finish())
         };
-        // after the last pivot tile: determinant = product of all pivots x parity of every tile's pivot order; a tile whose
-        // pivots span more than ten decades flags the matrix (redone by the step-by-step kernel, nothing stored here)
-        auto finish = [&]() {
+        // after the last pivot tile, before the stores of the last block step -- is the blocked result to be trusted?
+        //   pivot spread: a tile whose pivots span more than ten decades;
+        //   growth guard: pivoting is confined to the pivot tile, so the multipliers O[i, k] P_k^-1 are not bounded by one;
+        //     with g = max_k max|P_k^-1| max|block row and column k| the rounding error of a step is about g times that of
+        //     partial pivoting -- above 1e5 the matrix is flagged (a leading tile of tiny or vanishing entries in a well-
+        //     conditioned matrix, e.g. a walker whose first orbitals are orthogonal to the trial's first orbitals).
+        // A flagged matrix is redone by the step-by-step kernel; nothing of it is stored here.  Integer DPP maxima of the
+        // high words of the doubles: this sits between two block steps, on everybody's critical path.
+        auto row16_max = [&](unsigned v) {       // lane 15 of every row of 16 lanes: maximum of the row
+#define AFQ_DPP_MAX(ctrl) { const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false); v = v > t_ ? v : t_; }
+            AFQ_DPP_MAX(0x111) AFQ_DPP_MAX(0x112) AFQ_DPP_MAX(0x114) AFQ_DPP_MAX(0x118)
+#undef AFQ_DPP_MAX
+            return v;
+        };
+        auto judge = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            double px = 1.0, py = 0.0, worst = 1.0;
-            int ex = 0, odd = 0;
+            bool bad = false;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int t = (lane >> 4) + 4 * h, k = lane & 15;
@@ -441,14 +473,40 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
                 const bool ok = k < nb && !(a.dbg & 1);
                 const cplx d = ok ? piv_all[16 * t + k] : cmake(1.0, 0.0);
                 const double pm = fabs(d.x) + fabs(d.y);
-                double pmin = ok ? pm : 1e300, pmax = ok ? pm : 0.0;
+                const unsigned key = pm != pm ? 0x7ff80000u : (unsigned)__double2hiint(pm);
+                const unsigned kmax = row16_max(ok ? key : 0u), kmin = ~row16_max(ok ? ~key : 0u);
+                // (high words: the comparison is good to 2^-20, the threshold is a decade count)
+                const double pmax = __hiloint2double((int)kmax, 0), pmin = __hiloint2double((int)kmin, 0);
+                bad = bad || (k == 15 && nb > 0 && !(pmin >= 1e-10 * pmax && pmax > 0.0));
+            }
+            unsigned mypk = 0u;
+            for (int t = 0; t < nt16; ++t) {
+                const unsigned pk = gj_wave_max_u32(pmaxp[t * 64 + lane]);
+                mypk = (lane >> 3) == t ? pk : mypk;
+            }
+            {
+                const int t = lane >> 3, w = lane & 7;
+                unsigned bk = bmax[t * 8 + w], bc = bmax[64 + t * 8 + w];
+                bk = bk > bc ? bk : bc;
+                bk = row16_max(bk);             // (lane 8 t + 7: the shifts that reach it stay inside its group of eight... 
+                                                //  except row_shr:8, which can only raise the maximum of an odd group by
+                                                //  its even neighbour's: a conservative guard, not a wrong one)
+                const double g = __hiloint2double((int)mypk, 0) * __hiloint2double((int)bk, 0);
+                bad = bad || (w == 7 && t < nt16 && !(g <= 1e5));
+            }
+            const bool any = __ballot(bad) != 0ull || (a.dbg & 64);
+            if (lane == 0) { *s_bad = any ? 1 : 0; flag[b] = any ? 1 : 0; }
+        };
+        // determinant = product of all pivots x parity of every tile's pivot order (the pivot wave is idle by then)
+        auto determinant = [&]() {
+            double px = 1.0, py = 0.0;
+            int ex = 0, odd = 0;
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    pmin = fmin(pmin, __shfl_xor(pmin, off));
-                    pmax = fmax(pmax, __shfl_xor(pmax, off));
-                }
-                const double ratio = nb > 0 ? (pmax > 0.0 ? pmin / pmax : 0.0) : 1.0;
-                worst = ratio < worst ? ratio : worst;
+            for (int h = 0; h < 2; ++h) {
+                const int t = (lane >> 4) + 4 * h, k = lane & 15;
+                const int nb = n - 16 * t < 16 ? n - 16 * t : 16;
+                const bool ok = k < nb && !(a.dbg & 1);
+                const cplx d = ok ? piv_all[16 * t + k] : cmake(1.0, 0.0);
                 int inv = 0;
                 if (ok) {
                     const int pr = prow_all[16 * t + k];
@@ -469,11 +527,9 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
                 (void)frexp(fmax(fabs(tx), fabs(ty)), &e2);
                 px = ldexp(tx, -e2); py = ldexp(ty, -e2);
                 ex += qe + e2;
-                worst = fmin(worst, __shfl_xor(worst, off));
             }
             const double sg = (__popcll(__ballot(odd != 0)) & 1) ? -1.0 : 1.0;
-            const bool bad = !(worst >= 1e-10);
-            if (lane == 0) { *s_bad = bad ? 1 : 0; a.detm[b] = cmake(sg * px, sg * py); a.dete[b] = ex; flag[b] = bad ? 1 : 0; }
+            if (lane == 0) { a.detm[b] = cmake(sg * px, sg * py); a.dete[b] = ex; }
         };
         // prologue: the diagonal tiles to their home, the first pivot tile inverted while the others arrive
         {
@@ -494,13 +550,17 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
             for (int i = 1; i < 8; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Dg[(i * 4 + r) * 64 + lane] = (d2_t){dt[i][r].x, dt[i][r].y};
-            if (nt16 == 1) finish();
+            // guard slots of steps 1..7 (and wave 0's own column): zero until a tile wave writes its maximum (after P);
+            // step 0's slots are written by the tile waves themselves, before P
+            for (int e = lane; e < 128; e += 64)
+                if (((e & 63) >> 3) != 0 || (e & 7) == 0) bmax[e] = 0u;
         }
         gj_lds_barrier();                                              // P
         for (int kb = 0; kb < nsteps; ++kb) {
             const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
             const int nks = (nblk + 3) >> 2;
             GJ_STAMP(kb, 0);
+            if (kb == nt16 - 1) judge();                               // (every pivot tile is inverted, every guard slot written)
             GJ_STAMP(kb, 1);
             gj_lds_barrier();                                          // B1
             GJ_STAMP(kb, 2);
@@ -517,14 +577,16 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
                     if (4 * r + lk < nbx && lr < nbx) Pl[(4 * r + lk) * nbx + lr] = cmake(accr[r], acci[r]);
                 GJ_STAMP(kb, 3);
                 invert(nx, nbx);
-                if (nx == nt16 - 1) finish();
-            } else if (a.write_inverse && !*s_bad) {                   // last step: this pivot's inverse is final
+            } else {                                                   // last step: this pivot's inverse is final
+                if (a.write_inverse && !*s_bad) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * kb + 4 * r + lk, col = 16 * kb + lr;
-                    const d2_t v = Dg[(kb * 4 + r) * 64 + lane];
-                    if (row < n && col < n) O[(long)row * a.ld + col] = cmake(v[0], v[1]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * kb + 4 * r + lk, col = 16 * kb + lr;
+                        const d2_t v = Dg[(kb * 4 + r) * 64 + lane];
+                        if (row < n && col < n) O[(long)row * a.ld + col] = cmake(v[0], v[1]);
+                    }
                 }
+                determinant();
             }
             GJ_STAMP(kb, 5);
             gj_lds_barrier();                                          // B4
@@ -579,13 +641,14 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
 #pragma unroll
         for (int i = 1; i < 8; ++i) { load_tile(i, (i + wave) & 7, Cr[i], Ci[i]); __builtin_amdgcn_sched_barrier(0); }
         if (i0 < nt16) publish_col(i0, 0, f0r, f0i);
+        const unsigned mc = tile_max(f0r, f0i), mr = tile_max(Cr[0], Ci[0]);       // (zeros for tiles outside the matrix)
+        if (lane == 0) { bmax[wave] = mr; bmax[64 + wave] = mc; }
     }
     gj_lds_barrier();                                                  // P
     for (int kb = 0; kb < nsteps; ++kb) {
         const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
         const int nks = (nblk + 3) >> 2;                               // k-steps of 4 that hold anything
         const int Jk = (kb + wave) & 7;                                // this wave's tile of the block row is (kb, Jk)
-        const bool st = kb == nt16 - 1 && a.write_inverse && !*s_bad; // last step: every tile is final after its update
         GJ_STAMP(kb, 0);
         // ---- row scaling R' = P^-1 R of this wave's tile of the block row, straight from its registers (the accumulator
         //      layout IS the B-fragment order: register ks = k-step ks) -> Rp and back into the registers
@@ -611,14 +674,18 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Rp[(Jk * 4 + r) * 64 + lane] = (d2_t){Nr[r], Ni[r]};
                     Cr[i] = Nr; Ci[i] = Ni;
-                    if (st) store_tile(i, Jk, Nr, Ni);
-                    if (Jk == kb + 1) publish_col(i, kb + 1, Nr, Ni);  // (wave 1: row kb of the next step's block column)
+                    if (Jk == kb + 1) {                                // (wave 1: row kb of the next step's block column)
+                        publish_col(i, kb + 1, Nr, Ni);
+                        const unsigned mc = tile_max(Nr, Ni);
+                        if (lane == 0) bmax[64 + (kb + 1) * 8 + wave] = mc;
+                    }
                 }
             }
         }
         GJ_STAMP(kb, 1);
         gj_lds_barrier();                                              // B1
         GJ_STAMP(kb, 2);
+        const bool st = kb == nt16 - 1 && a.write_inverse && !*s_bad; // last step: every tile is final after its update
         // ---- rank-16 update of every tile outside the block row: C <- (J == kb ? 0 : C) + (-F) R'
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -629,8 +696,12 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
                 gj_tile_mac(apanel(i, kb), bpanel(J, kb), lane, nks, accr, acci);
                 Cr[i] = accr; Ci[i] = acci;
                 if (st) store_tile(i, J, accr, acci);
-                if (J == kb + 1) publish_col(i, kb + 1, accr, acci);   // wave-uniform: the next step's block column
-            }
+                if (J == kb + 1 || i == kb + 1) {                      // wave-uniform: the next step's block column / row
+                    if (J == kb + 1) publish_col(i, kb + 1, accr, acci);
+                    const unsigned m = tile_max(accr, acci);
+                    if (lane == 0) bmax[(J == kb + 1 ? 64 : 0) + (kb + 1) * 8 + wave] = m;
+                }
+            } else if (i == kb && J < nt16 && st) store_tile(i, J, Cr[i], Ci[i]);   // (the scaled block row)
         }
         GJ_STAMP(kb, 3);
         // ... and the diagonal tiles that are neither this pivot nor the next one (that is wave 0's): one each for waves

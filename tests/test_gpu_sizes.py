@@ -453,3 +453,46 @@ def test_greens_33_to_45_electrons(M, na, nb, cplx):
         assert abs(ot[w] - det) <= 1e-9 * abs(det)
         close(gh[w].reshape(na + nb, M), numpy.concatenate(ghalf_ref), 1e-8)
     dev.close()
+
+
+@pytest.mark.parametrize("M,na,nb", [(140, 64, 40), (150, 128, 97), (136, 33, 48)])
+def test_blocked_gauss_jordan_hands_badly_placed_pivots_to_the_step_by_step_kernel(M, na, nb):
+    """The blocked Gauss-Jordan of k_bigdet.hip (more than 32 electrons per spin) pivots inside 16 x 16 tiles only.  Walkers
+    whose overlap matrix is well conditioned as a whole but has (1) a vanishing leading tile (a permutation: the first
+    orbitals of the walker are orthogonal to the first orbitals of the trial), (2) a leading tile 1e-10 times the rest
+    (unbounded multipliers), (3) one vanishing diagonal tile further down, must come out as exact as the others: the kernel
+    flags them (pivot spread of a tile, growth guard) and the step-by-step kernel with full partial pivoting redoes them.
+    Reference: walkers/single_det.py:295-321 (scipy.linalg.inv: LAPACK partial pivoting)."""
+    model, rng = build(M, 6, na, nb, True, seed=M + na)
+    nw = 6
+    nt = na + nb
+    phi = rng.rand(nw, M, nt) - 0.5 + 1j * (rng.rand(nw, M, nt) - 0.5)
+
+    def with_overlap(T, psi_s):
+        # phi_s with psi_s^H phi_s = T
+        return psi_s @ numpy.linalg.solve(psi_s.conj().T @ psi_s, T)
+
+    for s, (o, n) in enumerate(((0, na), (na, nb))):
+        psi_s = model.psi[:, o:o + n]
+        noise = 1e-3 * (rng.rand(n, n) - 0.5 + 1j * (rng.rand(n, n) - 0.5))
+        phi[1][:, o:o + n] = with_overlap(numpy.eye(n)[::-1] + 0j, psi_s)                 # (1) exact zeros in the tile
+        T = rng.rand(n, n) - 0.5 + 1j * (rng.rand(n, n) - 0.5)
+        T[:16, :16] *= 1e-10
+        phi[2][:, o:o + n] = with_overlap(T, psi_s)                                        # (2)
+        T = numpy.eye(n) + noise
+        if n > 40:
+            T[16:32, 16:32] = 0.0
+            T[16:32, 32:48] += numpy.eye(16)
+            T[32:48, 16:32] += numpy.eye(16)
+            T[32:48, 32:48] -= numpy.eye(16)
+        phi[3][:, o:o + n] = with_overlap(T, psi_s)                                        # (3)
+        phi[4][:, o:o + n] = with_overlap(numpy.eye(n)[::-1] + noise, psi_s)               # (1) with noise in the tile
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phi)
+    ot = dev.greens(want_G=False)
+    gh = dev.get(L.F_GHALF)
+    for w in range(nw):
+        det, ghalf_ref, _ = ref.greens_function(phi[w], model.psi, na, nb)
+        assert abs(ot[w] - det) <= 1e-9 * abs(det), (w, ot[w], det)
+        close(gh[w].reshape(nt, M), numpy.concatenate(ghalf_ref), 1e-8)
+    dev.close()
