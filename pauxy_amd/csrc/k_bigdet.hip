@@ -115,7 +115,8 @@ struct GjArgs {
     unsigned long long *ts = nullptr;   // tuning builds (AFQ_GJ_TS): s_memtime stamps of work-group 0, [wave][block step][point]
     int dbg = 0;                     // tuning builds: timing ablations of gj_mfma_kernel (WRONG results): 1 no inversion of the
                                      // pivot tile, 2 no rank-16 update of the register tiles, 4 none of the diagonal tiles,
-                                     // 8 no block steps at all (load and store only), 16 the halves-layout pivot inversion
+                                     // 8 no block steps at all (loads only); 64 flags every matrix (right results: everything
+                                     // through the step-by-step kernel)
 };
 
 // wave-wide maximum of a 32-bit key by DPP row shifts / row broadcasts (no LDS traffic)
