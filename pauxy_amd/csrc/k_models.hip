@@ -86,37 +86,69 @@ int k_exp_diag_factors(afq_handle *h, const cplx *vd, cplx *out) {
 }
 
 // ke = sum_s sum_{i,q} rT[i,q] Ghalf_s[i,q];  pe = U sum_n G_up[n,n] G_dn[n,n]
-__global__ __launch_bounds__(256) void energy_hubbard_kernel(const cplx *rH1, const cplx *ghalf, const cplx *psi,
-                                                             cplx *energy, int M, int na, int nb, int nt,
-                                                             double U) {
-    __shared__ double red[8];
+// (1024 threads per walker, four independent 16-byte loads in flight per thread: the kernel streams the walker's 1 MB
+//  Ghalf once -- 268 MB at C4 -- and was latency bound at 256 threads with one load in flight: 255 us, 1 TB/s)
+constexpr int EH_THR = 1024;
+__global__ __launch_bounds__(EH_THR) void energy_hubbard_kernel(const cplx *rH1, const cplx *ghalf, const cplx *psi,
+                                                                cplx *energy, int M, int na, int nb, int nt,
+                                                                double U) {
+    __shared__ double red[4][EH_THR / 64];
     const int w = blockIdx.x, tid = threadIdx.x;
     const cplx *gh = ghalf + (long)w * nt * M;
     double kr = 0, ki = 0, pr = 0, pi = 0;
-    for (long q = tid; q < (long)nt * M; q += 256) {
+    const long total = (long)nt * M;
+    long q = tid;
+    for (; q + 3 * EH_THR < total; q += 4 * EH_THR) {
+        cplx a[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = rH1[q + u * EH_THR]; g[u] = gh[q + u * EH_THR]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kr += a[u].x * g[u].x - a[u].y * g[u].y;
+            ki += a[u].x * g[u].y + a[u].y * g[u].x;
+        }
+    }
+    for (; q < total; q += EH_THR) {
         const cplx a = rH1[q], g = gh[q];
         kr += a.x * g.x - a.y * g.y;
         ki += a.x * g.y + a.y * g.x;
     }
-    for (int n = tid; n < M; n += 256) {
+    // G_s[n, n] = sum_i conj(psi_s[n, i]) Ghalf_s[i, n]: four threads per site, each a quarter of the orbitals of both spins
+    {
+        const int n = tid >> 2, part = tid & 3;
         cplx g[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
-        for (int s = 0; s < 2; ++s) {
-            const int ns = s == 0 ? na : nb, off = s == 0 ? 0 : na;
-            for (int i = 0; i < ns; ++i) cfma(g[s], cconj(psi[(long)n * nt + off + i]), gh[(long)(off + i) * M + n]);
+        for (int nn = n; nn < M; nn += EH_THR / 4) {
+            g[0] = cmake(0.0, 0.0); g[1] = cmake(0.0, 0.0);
+            for (int s = 0; s < 2; ++s) {
+                const int ns = s == 0 ? na : nb, off = s == 0 ? 0 : na;
+                for (int i = part; i < ns; i += 4) cfma(g[s], cconj(psi[(long)nn * nt + off + i]), gh[(long)(off + i) * M + nn]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                g[s].x += __shfl_xor(g[s].x, 1); g[s].y += __shfl_xor(g[s].y, 1);
+                g[s].x += __shfl_xor(g[s].x, 2); g[s].y += __shfl_xor(g[s].y, 2);
+            }
+            if (part == 0) {
+                const cplx t = cmul(g[0], g[1]);
+                pr += U * t.x; pi += U * t.y;
+            }
         }
-        const cplx t = cmul(g[0], g[1]);
-        pr += U * t.x; pi += U * t.y;
     }
     double v[4] = {kr, ki, pr, pi};
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         double x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = x;
-        __syncthreads();
-        v[k] = red[0] + red[1] + red[2] + red[3];
+        if ((tid & 63) == 0) red[k][tid >> 6] = x;
     }
+    __syncthreads();
     if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double x = 0.0;
+            for (int i = 0; i < EH_THR / 64; ++i) x += red[k][i];
+            v[k] = x;
+        }
         energy[3 * w + 0] = cmake(v[0] + v[2], v[1] + v[3]);
         energy[3 * w + 1] = cmake(v[0], v[1]);
         energy[3 * w + 2] = cmake(v[2], v[3]);
@@ -124,7 +156,7 @@ __global__ __launch_bounds__(256) void energy_hubbard_kernel(const cplx *rH1, co
 }
 
 int k_energy_hubbard(afq_handle *h) {
-    AFQ_LAUNCH(h, energy_hubbard_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->rH1, h->ghalf, h->psi,
+    AFQ_LAUNCH(h, energy_hubbard_kernel, dim3(h->nw), dim3(EH_THR), 0, h->stream, h->rH1, h->ghalf, h->psi,
                        h->energy, h->M, h->na, h->nb, h->nt, h->U);
     AFQ_POST(h);
     return AFQ_OK;
