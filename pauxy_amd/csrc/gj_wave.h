@@ -421,3 +421,75 @@ __device__ __attribute__((always_inline)) inline void chol_wave32(const cplx *S,
     else if (n <= 26) chol_wave_rj<13>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
     else chol_wave_rj<16>(S, ld, Tt, ldt, n, lane, rowk, piv, bad);
 }
+
+// --------------------------------------------------------------------------
+// Inverse Cholesky factor of an n x n tile, n <= 16, in the quad layout of gj_wave16q_inv (lane (q, r) keeps columns
+// 4 q .. 4 q + 3 of row r: every lane busy, a quarter of the FMAs and LDS operations of chol_wave_rj<8> per lane).
+// S row-major with leading dimension ld (LDS); Tt as chol_wave_rj: conj(Ltilde^-1[r][c]) / sqrt(D_r) below the diagonal,
+// 1 / sqrt(D_r) on it, zero above; piv[k] = D_k (16 doubles, 1 for k >= n).
+template <int K>
+__device__ __attribute__((always_inline)) inline void chol_quad_step(double (&vr)[4], double (&vi)[4], int lane, cplx *rowk, double *piv, bool &bad) {
+    constexpr int QK = K >> 2, U = K & 3;
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned rowk_l = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)rowk + 64u * q;
+    const double fx = gj_bcast_quad<QK>(vr[U]), fy = gj_bcast_quad<QK>(vi[U]);
+    const bool isp = r == K;
+    if (q == QK) { vr[U] = isp ? 1.0 : 0.0; vi[U] = 0.0; }
+    if (isp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gj_store_pair(rowk_l, 2 * j, vr[j], vi[j]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    cplx rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rk[j] = rowk[4 * q + j];
+    __builtin_amdgcn_sched_barrier(0);
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), K),
+                                      __builtin_amdgcn_readlane(__double2loint(fx), K));
+    bad = bad || !(d > 0.0);
+    double dinv = __builtin_amdgcn_rcp(d);
+    dinv = fma(fma(-d, dinv, 1.0), dinv, dinv);
+    dinv = fma(fma(-d, dinv, 1.0), dinv, dinv);
+    if (lane == 0) piv[K] = d;
+    const double mx = r > K ? fx * dinv : 0.0, my = r > K ? fy * dinv : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vr[j] = fma(-mx, rk[j].x, vr[j]); vr[j] = fma(my, rk[j].y, vr[j]);
+        vi[j] = fma(-mx, rk[j].y, vi[j]); vi[j] = fma(-my, rk[j].x, vi[j]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __attribute__((always_inline)) inline void chol_wave16q(const cplx *S, int ld, cplx *Tt, int ldt, int n, int lane,
+                                                                   cplx *rowk, double *piv, bool &bad) {
+    if (lane < 16) piv[lane] = 1.0;
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int q = lane >> 4, r = lane & 15;
+    double vr[4], vi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        const cplx t = (r < n && c < n) ? S[r * ld + c] : cmake(0.0, 0.0);
+        vr[j] = t.x; vi[j] = t.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+#define AFQ_CH_QS(K) if (K < n) chol_quad_step<K>(vr, vi, lane, rowk, piv, bad);
+    AFQ_CH_QS(0) AFQ_CH_QS(1) AFQ_CH_QS(2) AFQ_CH_QS(3) AFQ_CH_QS(4) AFQ_CH_QS(5) AFQ_CH_QS(6) AFQ_CH_QS(7)
+    AFQ_CH_QS(8) AFQ_CH_QS(9) AFQ_CH_QS(10) AFQ_CH_QS(11) AFQ_CH_QS(12) AFQ_CH_QS(13) AFQ_CH_QS(14) AFQ_CH_QS(15)
+#undef AFQ_CH_QS
+    __builtin_amdgcn_wave_barrier();
+    if (r < n) {
+        const double rs = 1.0 / sqrt(piv[r]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            if (c >= n) continue;
+            cplx t = cmake(0.0, 0.0);
+            if (c < r) t = cmake(vr[j] * rs, -vi[j] * rs);
+            else if (c == r) t = cmake(rs, 0.0);
+            Tt[r * ldt + c] = t;
+        }
+    }
+}
+

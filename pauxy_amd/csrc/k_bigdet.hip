@@ -1049,6 +1049,224 @@ __global__ __launch_bounds__(512) void chol_linv_kernel(CholArgs a) {
     }
 }
 
+// Blocked version of chol_linv_kernel on the matrix pipe (round 4; the structure of gj_mfma_kernel: eight waves per matrix,
+// 16 x 16 tiles in MFMA accumulator layout, wave w > 0 owns the tiles (I, (I + w) mod 8), the pivot wave 0 keeps the
+// diagonal tiles in LDS and works one block step ahead).  Block forward elimination of [S | I] with S = L L^H:
+//   block step k:  C = L_kk^-1 (inverse Cholesky factor of the pivot tile, one wave in registers);
+//                  Y_j = C x (block row k, tile j)    -- the remaining S for j > k, the accumulated right-hand side W for
+//                                                        j < k, the identity for j = k (Y_k = C);  X_kj = Y_j (j <= k) is
+//                                                        row block k of L^-1, final;
+//                  tile (i, j) -= Y_i^H Y_j  for i > k and (j <= k: right-hand side | j >= i: upper triangle of S)
+// S is Hermitian, so the block column is the conjugate transpose of the block row and never read: the accumulator layout
+// of Y_i IS the A-fragment order of Y_i^H (conjugated on the way), both operands of the update come from the one published
+// panel.  About half the tile products of the Gauss-Jordan.  No pivoting (positive definite); a non-positive pivot sets the
+// walker's breakdown flag as in chol_linv_kernel.  Output: Tt = conj(L^-1) (zeros above the diagonal), logd = log det L.
+struct CholMfmaLds {
+    static constexpr int RP = 0, DG = 32768, PL = 65536, PT = 69632, CA = 73728, DALL = 81920, SMALL = 82944;
+    static constexpr int BYTES = SMALL + 512 + 256 + 64;                        // + rowk, piv of one tile, the flag
+};
+
+// acc += A B with A = -Y_i^H, B = Y_j: fragments of both from panels in accumulator layout (register ks = k-step ks);
+// complex by three real MFMAs per k-step
+__device__ __attribute__((always_inline)) inline void chol_tile_mac(const d2_t *yi, const d2_t *yj, int lane, int nks, d4_t &accr, d4_t &acci) {
+    d4_t p1 = (d4_t){0, 0, 0, 0}, p2 = (d4_t){0, 0, 0, 0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { av[q] = yi[(2 * half + q) * 64 + lane]; bv[q] = yj[(2 * half + q) * 64 + lane]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (2 * half + q < nks) {
+                const double ar = -av[q][0], ai = av[q][1];            // -conj(y)
+                p1 = mfma16(ar, bv[q][0], p1);
+                p2 = mfma16(ai, bv[q][1], p2);
+                acci = mfma16(ar + ai, bv[q][0] + bv[q][1], acci);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accr[r] += p1[r] - p2[r]; acci[r] -= p1[r] + p2[r]; }
+}
+
+__global__ __launch_bounds__(512) void chol_mfma_kernel(CholArgs a) {
+    extern __shared__ __align__(16) unsigned char gsm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, lr = lane & 15;
+    const int n = (b & 1) ? a.nb : a.na;
+    const int nt16 = (n + 15) >> 4;
+    const cplx *S = a.S + (long)b * a.ld * a.ld;
+    cplx *Tt = a.Tt + (long)b * a.ld * a.ld;
+    d2_t *Rp = (d2_t *)(gsm + CholMfmaLds::RP), *Dg = (d2_t *)(gsm + CholMfmaLds::DG);
+    cplx *Pl = (cplx *)(gsm + CholMfmaLds::PL), *Pt = (cplx *)(gsm + CholMfmaLds::PT);
+    d2_t *Ca = (d2_t *)(gsm + CholMfmaLds::CA);                        // [2][4 k-steps][64]: C in A-fragment order
+    double *dall = (double *)(gsm + CholMfmaLds::DALL);                // [128] pivots D_k (1 beyond n)
+    cplx *rowk = (cplx *)(gsm + CholMfmaLds::SMALL);
+    double *piv = (double *)(rowk + 32);
+    int *s_bad = (int *)(piv + 32);
+    // Tt rows / columns of tile (I, J), conjugated (buffer stores: one 32-bit lane offset, see gj_mfma_kernel)
+    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(Tt, 0, a.ld * a.ld * (int)sizeof(cplx), 0x00020000);
+    const int lane_off = (lk * a.ld + lr) * (int)sizeof(cplx);
+    auto store_conj = [&](int I, int J, const d4_t &tr, const d4_t &ti) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + 4 * r + lk, col = 16 * J + lr;
+            const int uo = ((16 * I + 4 * r) * a.ld + 16 * J) * (int)sizeof(cplx);
+            if (row < n && col < n)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gj_u4_t, (d2_t){tr[r], -ti[r]}), trsrc, lane_off, uo, 0);
+        }
+    };
+    if (wave == 0) {
+        // ================================================================= pivot wave
+        __builtin_amdgcn_s_setprio(3);
+        bool bad = false;
+        // pivot tile t (row-major in Pl, compact nb x nb) -> C = L_tt^-1: A-fragment order in Ca[t & 1], accumulator layout
+        // in Dg[t] (its final value: X_tt), conjugated to Tt; pivots to dall
+        auto factor = [&](const int t, const int nb) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            chol_wave16q(Pl, nb, Pt, nb, nb, lane, rowk, piv, bad);          // Pt = conj(C), zeros above the diagonal
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 16) dall[16 * t + lane] = lane < nb ? piv[lane] : 1.0;
+            d2_t *ca = Ca + (t & 1) * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = lane + 64 * q, row = e >> 4, col = e & 15;
+                const cplx v = (row < nb && col <= row) ? Pt[row * nb + col] : cmake(0.0, 0.0);
+                ca[(col >> 2) * 64 + (col & 3) * 16 + row] = (d2_t){v.x, -v.y};
+                Dg[(t * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col] = (d2_t){v.x, -v.y};
+                const int gr = 16 * t + row, gc = 16 * t + col;
+                if (gr < n && gc < n) Tt[(long)gr * a.ld + gc] = v;
+            }
+        };
+        for (int e = lane; e < 128; e += 64) dall[e] = 1.0;
+        {
+            cplx dt[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * r + lk, col = 16 * i + lr;
+                    dt[i][r] = (row < n && col < n) ? S[(long)row * a.ld + col] : cmake(0.0, 0.0);
+                }
+            const int nb0 = n < 16 ? n : 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + lk < nb0 && lr < nb0) Pl[(4 * r + lk) * nb0 + lr] = dt[0][r];
+            factor(0, nb0);
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dg[(i * 4 + r) * 64 + lane] = (d2_t){dt[i][r].x, dt[i][r].y};
+        }
+        gj_lds_barrier();                                              // P
+        for (int kb = 0; kb < nt16; ++kb) {
+            const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
+            const int nks = (nblk + 3) >> 2;
+            gj_lds_barrier();                                          // B1
+            const int nx = kb + 1;
+            if (nx < nt16) {
+                const int nbx = n - 16 * nx < 16 ? n - 16 * nx : 16;
+                d4_t accr, acci;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const d2_t v = Dg[(nx * 4 + r) * 64 + lane]; accr[r] = v[0]; acci[r] = v[1]; }
+                chol_tile_mac(Rp + nx * 256, Rp + nx * 256, lane, nks, accr, acci);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + lk < nbx && lr < nbx) Pl[(4 * r + lk) * nbx + lr] = cmake(accr[r], acci[r]);
+                factor(nx, nbx);
+            }
+            gj_lds_barrier();                                          // B4
+        }
+        // log det L = 1/2 sum log D_k; breakdown flag
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double l = log(dall[lane]) + log(dall[lane + 64]);
+        bad = bad || !(dall[lane] > 0.0) || !(dall[lane + 64] > 0.0);
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o);
+        const bool anybad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+            a.logd[b] = 0.5 * l;
+            if (anybad) a.fail[b >> 1] = 1;
+        }
+        return;
+    }
+    // ===================================================================== tile waves 1..7: tile i is (I = i, J = (i + wave) & 7)
+    d4_t Cr[8], Ci[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int J = (i + wave) & 7;
+        Cr[i] = (d4_t){0, 0, 0, 0}; Ci[i] = (d4_t){0, 0, 0, 0};
+        if (J > i) {                                                   // upper triangle of S; Tt is zero there
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * r + lk, col = 16 * J + lr;
+                if (row < n && col < n) {
+                    const cplx t = S[(long)row * a.ld + col];
+                    Cr[i][r] = t.x; Ci[i][r] = t.y;
+                    Tt[(long)row * a.ld + col] = cmake(0.0, 0.0);
+                }
+            }
+        }
+    }
+    gj_lds_barrier();                                                  // P
+    for (int kb = 0; kb < nt16; ++kb) {
+        const int nblk = n - 16 * kb < 16 ? n - 16 * kb : 16;
+        const int nks = (nblk + 3) >> 2;
+        const int Jk = (kb + wave) & 7;                                // this wave's tile of block row kb is (kb, Jk)
+        // ---- Y = C x tile of the block row, from the registers -> Rp; a right-hand-side tile (Jk < kb) is final: row block
+        //      kb of L^-1
+        if (Jk < nt16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i == kb) {                                         // wave-uniform; static register index
+                    const d2_t *ca = Ca + (kb & 1) * 256;
+                    d2_t av[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) av[ks] = ca[ks * 64 + lane];
+                    d4_t Nr = (d4_t){0, 0, 0, 0}, Ni = (d4_t){0, 0, 0, 0}, p2 = (d4_t){0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (ks < nks) {
+                            Nr = mfma16(av[ks][0], Cr[i][ks], Nr);
+                            p2 = mfma16(av[ks][1], Ci[i][ks], p2);
+                            Ni = mfma16(av[ks][0] + av[ks][1], Cr[i][ks] + Ci[i][ks], Ni);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { Ni[r] -= Nr[r] + p2[r]; Nr[r] -= p2[r]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Rp[(Jk * 4 + r) * 64 + lane] = (d2_t){Nr[r], Ni[r]};
+                    if (Jk < kb) store_conj(kb, Jk, Nr, Ni);
+                }
+            }
+        }
+        gj_lds_barrier();                                              // B1
+        // ---- tile (i, J) -= Y_i^H Y_J for i > kb, J <= kb (right-hand side) or J > i (upper triangle of S)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int J = (i + wave) & 7;
+            if (i > kb && i < nt16 && J < nt16 && (J <= kb || J > i)) {
+                const d2_t *yj = J == kb ? Dg + kb * 256 : Rp + J * 256;    // (Y_kb = C itself: the identity block of the right-hand side)
+                chol_tile_mac(Rp + i * 256, yj, lane, nks, Cr[i], Ci[i]);
+            }
+        }
+        // ... and the diagonal tiles below the next pivot (that one is wave 0's), one each for waves 1, 2, 3, 5, 6, 7
+        for (int i = kb + 2; i < nt16; ++i) {
+            const int rank = i - kb - 2;
+            const int owner = rank < 3 ? rank + 1 : rank + 2;
+            if (wave != owner) continue;
+            d4_t accr, acci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const d2_t v = Dg[(i * 4 + r) * 64 + lane]; accr[r] = v[0]; acci[r] = v[1]; }
+            chol_tile_mac(Rp + i * 256, Rp + i * 256, lane, nks, accr, acci);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dg[(i * 4 + r) * 64 + lane] = (d2_t){accr[r], acci[r]};
+        }
+        gj_lds_barrier();                                              // B4
+    }
+}
+
 // n <= 32: one wave per matrix, four matrices per work-group, everything in registers (gj_wave.h)
 __global__ __launch_bounds__(256) void chol_small_kernel(CholArgs a, int nmat) {
     __shared__ cplx rowk_s[4][32];
@@ -1108,7 +1326,12 @@ int k_reortho_big(afq_handle *h) {
             a.na = h->na; a.nb = h->nb; a.ld = nmax;
             a.S = h->big_ws; a.Tt = h->big_ws2; a.logd = h->qr_logd + (size_t)pass * nb2; a.fail = h->qr_fail;
             if (nmax <= 32) AFQ_LAUNCH(h, chol_small_kernel, dim3((nb2 + 3) / 4), dim3(256), 0, h->stream, a, nb2);
-            else AFQ_LAUNCH(h, chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            else if (afq_knob("AFQ_CHOL_STEPWISE")) AFQ_LAUNCH(h, chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            else {
+                static size_t lds_set[AFQ_MAX_DEVICES] = {0};
+                AFQ_HIP(h, afq_raise_lds((const void *)chol_mfma_kernel, CholMfmaLds::BYTES, lds_set));
+                AFQ_LAUNCH(h, chol_mfma_kernel, dim3(nb2), dim3(512), CholMfmaLds::BYTES, h->stream, a);
+            }
             AFQ_POST(h);
         }
         {
