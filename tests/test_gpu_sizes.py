@@ -496,3 +496,27 @@ def test_blocked_gauss_jordan_hands_badly_placed_pivots_to_the_step_by_step_kern
         assert abs(ot[w] - det) <= 1e-9 * abs(det), (w, ot[w], det)
         close(gh[w].reshape(nt, M), numpy.concatenate(ghalf_ref), 1e-8)
     dev.close()
+
+
+@pytest.mark.parametrize("M,na,nb", [(140, 64, 40), (150, 128, 97), (136, 33, 48), (130, 113, 17)])
+def test_blocked_cholesky_reortho_every_tile_count(M, na, nb):
+    """Re-orthogonalisation above 32 electrons per spin: Gram GEMM + blocked inverse Cholesky factor (chol_mfma_kernel:
+    16 x 16 tiles, 3 to 8 of them per spin, ragged last tile, unequal spins, one spin below 32) + Q GEMM, twice; every
+    walker against the oracle's QR with the diagonal of R made positive (walkers/single_det.py:215-255), detR included."""
+    model, rng = build(M, 6, na, nb, True, seed=M + nb)
+    nw = 5
+    nt = na + nb
+    phi = model.psi[None] + 0.3 * (rng.rand(nw, M, nt) - 0.5 + 1j * (rng.rand(nw, M, nt) - 0.5))
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phi)
+    dev.set(L.F_OT, numpy.ones(nw, dtype=complex))
+    detR = dev.reortho()
+    q = dev.get(L.F_PHI)
+    for w in range(nw):
+        p = phi[w].copy()
+        d = ref.reortho(p, na, nb)
+        close(q[w], p, 1e-9)
+        close(detR[w], d, 1e-9)
+        for sl in (slice(0, na), slice(na, nt)):
+            close(q[w][:, sl].conj().T @ q[w][:, sl], numpy.eye(sl.stop - sl.start), 1e-11)
+    dev.close()
