@@ -855,7 +855,7 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     if (xi) {
         if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
-    } else if (k_prop_fused_supported(h) || k_ueg_fast_supported(h)) {
+    } else if (k_prop_fused_supported(h) || k_ueg_fast_supported(h) || (h->vhs_diag && !h->no_fused && h->K == h->M)) {
         // nothing ahead of fields_kernel reads the fields or the alive flags on this path (the Green's function is
         // evaluated for every walker, the one-body product sits inside the fused propagator): fields_kernel draws
         // the same Philox stream itself and sets the flags
@@ -906,14 +906,19 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
         // the un-propagated walker, so fields, potential and the scaling factors are made FIRST and the factors ride on
         // the store of the first one-body product: phi <- B [exp(V) (B phi)] in two GEMM launches, the walkers pass
         // through memory twice instead of three times (exp_diag_kernel: 537 MB of traffic at C4).
+        cplx *fac = h->vhs + (size_t)h->nw * h->nv * h->M;                              // second half of the vhs buffer
+        const bool fields_make_factors = h->K == h->M;                                  // (one field per site)
         {
             PhaseTimer t(h, T_FB);                                                      // :133-158
             if ((rc = force_bias(h, false))) return rc;
-            if ((rc = k_xbar_fields(h))) return rc;
+            // ... and with the fields the diagonal HS potential (:161) and its Taylor factors (:162-171): the same
+            // arithmetic as vhs_hubbard_kernel + exp_diag_factor_kernel, two launches less
+            if ((rc = k_xbar_fields(h, fields_make_factors ? fac : nullptr))) return rc;
         }
-        { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }                 // :161
-        cplx *fac = h->vhs + (size_t)h->nw * h->nv * h->M;                              // second half of the vhs buffer
-        { PhaseTimer t(h, T_EXP); if ((rc = k_exp_diag_factors(h, h->vhs, fac))) return rc; }   // :162-171
+        if (!fields_make_factors) {
+            { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }             // :161
+            { PhaseTimer t(h, T_EXP); if ((rc = k_exp_diag_factors(h, h->vhs, fac))) return rc; }   // :162-171
+        }
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h, fac))) return rc; }        // :251 + the row scaling
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }             // :258
         h->prop_pending = true;

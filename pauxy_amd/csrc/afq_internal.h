@@ -407,7 +407,7 @@ int k_conj_transpose(afq_handle *h, const cplx *A, cplx *At);
 int k_bp_accumulate(afq_handle *h, int restore, int with_energy);
 int k_bp_reset(afq_handle *h, bool first);
 int k_bp_hirsch_step(afq_handle *h, int i);                 // B(x)^H of the i-th most recent discrete configuration
-int k_xbar_fields(afq_handle *h);                           // xbar + clip + shift in one launch
+int k_xbar_fields(afq_handle *h, cplx *hubbard_factors = nullptr);   // + the Hubbard row-scaling factors (continuous fields)
 int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch
 int k_update_weight(afq_handle *h, cplx eshift);

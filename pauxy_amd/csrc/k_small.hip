@@ -809,6 +809,12 @@ struct XbarArgs {
     int ndet;               // > 1: vbias holds ndet slices of det_stride elements, combined with detw
     long det_stride;
     const cplx *detw;       // [nw, ndet]
+    // Hubbard with continuous fields: the kernel that makes the shifted fields also makes the HS potential's diagonal and
+    // its degree-n Taylor factor per site (vhs_hubbard_kernel + exp_diag_factor_kernel of k_models.hip: two launches of
+    // M nw elements each), hub_fac [nw, nv, M]; null otherwise
+    cplx *hub_fac = nullptr;
+    double hub_f = 0.0;     // sqrt(dt) sqrt(U) (charge decomposition: d = i f x) or sqrt(dt U) (spin: d = -+ f x)
+    int hub_spin = 0, hub_order = 0;
 };
 
 __device__ inline cplx xbar_value(const XbarArgs &a, int w, int n) {
@@ -992,6 +998,23 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
         const cplx sft = cmake(x - b.x, -b.y);
         xbar[e] = b;
         xs[e] = sft;
+        if (FUSED && xa.hub_fac) {
+            // propagation/hubbard.py:409-413 / :475-480, continuous.py:104-107 with a diagonal potential: one factor per site
+            auto taylor = [&](const cplx d) {
+                cplx acc = cmake(1.0, 0.0), t = acc;
+                for (int k = 1; k <= xa.hub_order; ++k) {
+                    t = cmul(d, t);
+                    t = cmake(t.x / k, t.y / k);
+                    acc = cadd(acc, t);
+                }
+                return acc;
+            };
+            if (!xa.hub_spin) xa.hub_fac[(long)w * K + n] = taylor(cmake(-xa.hub_f * sft.y, xa.hub_f * sft.x));
+            else {
+                xa.hub_fac[((long)w * 2 + 0) * K + n] = taylor(cmake(-xa.hub_f * sft.x, -xa.hub_f * sft.y));
+                xa.hub_fac[((long)w * 2 + 1) * K + n] = taylor(cmake(xa.hub_f * sft.x, xa.hub_f * sft.y));
+            }
+        }
         const cplx mm = mf[n];
         acc[0] += sft.x * mm.x - sft.y * mm.y;
         acc[1] += sft.x * mm.y + sft.y * mm.x;
@@ -1054,15 +1077,21 @@ int k_fields(afq_handle *h) {
 }
 
 // force bias from the contraction output + clip + shift in one launch (the step's hot path)
-int k_xbar_fields(afq_handle *h) {
+int k_xbar_fields(afq_handle *h, cplx *hubbard_factors) {
     FieldRng rng = FieldRng();
     if (h->rng_inline) {
         rng.on = 1; rng.seed = h->rng_seed; rng.stream = h->rng_stream; rng.counter = h->rng_inline_counter;
         rng.weight = h->weight; rng.alive_out = h->alive;
         h->rng_inline = false;
     }
+    XbarArgs xa = xbar_args(h);
+    if (hubbard_factors) {
+        const bool spin = (h->flags & AFQ_PROP_HUBBARD_SPIN) != 0;
+        xa.hub_fac = hubbard_factors; xa.hub_spin = spin ? 1 : 0; xa.hub_order = h->exp_order;
+        xa.hub_f = spin ? sqrt(h->dt * h->U) : h->sqrt_dt * sqrt(h->U);
+    }
     AFQ_LAUNCH(h, fields_kernel<true>, dim3(h->nw), dim3(NTHR), 0, h->stream, h->K, h->sqrt_dt, h->xi, h->xbar,
-                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xbar_args(h), rng);
+                       h->mf_shift, h->xs, h->cmf, h->cfb, h->counters, h->alive, xa, rng);
     AFQ_POST(h);
     return AFQ_OK;
 }
