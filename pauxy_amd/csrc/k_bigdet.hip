@@ -1104,7 +1104,6 @@ __global__ __launch_bounds__(512) void chol_mfma_kernel(CholArgs a) {
     double *dall = (double *)(gsm + CholMfmaLds::DALL);                // [128] pivots D_k (1 beyond n)
     cplx *rowk = (cplx *)(gsm + CholMfmaLds::SMALL);
     double *piv = (double *)(rowk + 32);
-    int *s_bad = (int *)(piv + 32);
     // Tt rows / columns of tile (I, J), conjugated (buffer stores: one 32-bit lane offset, see gj_mfma_kernel)
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(Tt, 0, a.ld * a.ld * (int)sizeof(cplx), 0x00020000);
     const int lane_off = (lk * a.ld + lr) * (int)sizeof(cplx);

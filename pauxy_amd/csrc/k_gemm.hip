@@ -56,6 +56,18 @@ struct OneBodyProbT {
     const cplx *rowscale;
     long rs_stride;
     __device__ bool active(int b) const { return alive[b] != 0; }
+    // dead walkers are not propagated (qmc/afqmc.py:232) but source and destination are ping-pong buffers: their columns
+    // are copied through by the work-groups / waves that would have multiplied them (a separate copy launch before)
+    static constexpr bool INACTIVE_COPY = true;
+    __device__ void inactive_tile(int b, int row0, int nr, int col0, int nc, int t, int nthr) const {
+        for (int e = t; e < nr * nc; e += nthr) {
+            const int r = row0 + e / nc, c = col0 + e % nc;
+            if (r < rows && c < cols) {
+                const long idx = ((long)b * rows + r) * nt + off + c;
+                dst[idx] = src[idx];
+            }
+        }
+    }
     __device__ cplx loadA(int, int row, int k) const { return B1[(long)row * kdim + k]; }
     __device__ cplx loadB(int b, int k, int col) const {
         return src[((long)b * kdim + k) * nt + off + col];
@@ -78,13 +90,6 @@ struct OneBodyProbT {
 };
 
 typedef OneBodyProbT<false> OneBodyProb;
-
-__global__ void copy_dead_kernel(const cplx *src, cplx *dst, const int *alive, long per) {
-    const int w = blockIdx.y;
-    if (alive[w]) return;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x)
-        dst[w * per + i] = src[w * per + i];
-}
 
 // s = 0 / 1: the columns of one spin; s = 2: both spins in one launch (BH1[0] == BH1[1], one row-scale set)
 template <bool AR>
@@ -148,10 +153,7 @@ int k_onebody(afq_handle *h, const cplx *rowscale) {
         const int rc = h->bh1_real ? onebody_spin<true>(h, s, rowscale) : onebody_spin<false>(h, s, rowscale);
         if (rc) return rc;
     }
-    // dead walkers are not propagated (qmc/afqmc.py:232): carry their phi over
-    AFQ_LAUNCH(h, copy_dead_kernel, dim3(8, h->nw), dim3(256), 0, h->stream, h->phi, h->phi_t,
-                       h->alive, (long)M * h->nt);
-    AFQ_POST(h);
+    // (dead walkers are not propagated, qmc/afqmc.py:232: the products above copied their phi through)
     cplx *t = h->phi; h->phi = h->phi_t; h->phi_t = t;
     return AFQ_OK;
 }

@@ -59,6 +59,10 @@ struct FragSet {
 //   MAP_BATCH_XCD_ROWS  (work-group engine) as MAP_BATCH_XCD, tile rows fastest inside a batch: the row tiles of one
 //                       B column panel run back to back on one XCD
 enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3, MAP_BATCH_XCD_ROWS = 4 };
+// optional problem trait: static constexpr bool INACTIVE_COPY = true -- inactive_tile(b, row0, nrows, col0, ncols, t, nthr)
+// is called by the nthr threads that would have computed the tile of an inactive batch (both GEMM engines)
+template <class P, class = void> struct gemm_inactive_copy { static constexpr bool value = false; };
+template <class P> struct gemm_inactive_copy<P, decltype((void)P::INACTIVE_COPY)> { static constexpr bool value = P::INACTIVE_COPY; };
 
 template <int TM, int TN, class P, int MAP = MAP_COLS_FAST>
 __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {
@@ -92,7 +96,12 @@ __global__ __launch_bounds__(512) void mfma_gemm_kernel(P p) {
         if (MAP == MAP_ROWS_FAST) { tn = rem / tiles_m; tm = rem % tiles_m; }
         else { tm = rem / tiles_n; tn = rem % tiles_n; }
     }
-    if (!p.active(b)) return;
+    if (!p.active(b)) {
+        // optional problem trait INACTIVE_COPY: the output tile of an inactive batch is not left alone but copied through
+        // (ping-pong buffers: a dead walker's columns have to arrive in the destination too)
+        if constexpr (gemm_inactive_copy<P>::value) p.inactive_tile(b, tm * 16 * TM, 16 * TM, tn * 16 * TN, 16 * TN, lane, 64);
+        return;
+    }
     const int row0 = tm * 16 * TM, col0 = tn * 16 * TN;
     const int lr = lane & 15, lk = lane >> 4;
     constexpr bool OUT_CPLX = P::A_CPLX || P::B_CPLX;

@@ -145,7 +145,10 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
         if (MAP == MAP_ROWS_FAST) { tn = rem / tiles_m; tm = rem % tiles_m; }
         else { tm = rem / tiles_n; tn = rem % tiles_n; }
     }
-    if (!p.active(b)) return;                              // uniform over the work-group
+    if (!p.active(b)) {                                    // uniform over the work-group
+        if constexpr (gemm_inactive_copy<P>::value) p.inactive_tile(b, tm * 16 * RT, 16 * RT, tn * 16 * CT, 16 * CT, (int)threadIdx.x, (int)blockDim.x);
+        return;
+    }
     const int row0 = tm * 16 * RT, col0 = tn * 16 * CT;
     const int lr = lane & 15, lk = lane >> 4;
     unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
