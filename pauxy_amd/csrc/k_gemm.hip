@@ -146,8 +146,9 @@ int k_onebody(afq_handle *h, const cplx *rowscale) {
     const int M = h->M;
     // both spins share the matrix (and the row-scale set, if any): one launch over all na + nb columns pads the column
     // tiles once instead of twice (M = 400, 50 + 50 columns: 448 x 128 against 2 x 512 x 64)
-    const bool merged = h->bh1_same && h->na > 0 && h->nb > 0 && (!rowscale || h->nv == 1) && M > 128 && h->nt > 32 &&
-                        h->nw >= 64 && !h->no_ring;
+    // ... and on small systems (M <= 64: the register engine, launch-latency bound) one launch instead of two
+    const bool merged = h->bh1_same && h->na > 0 && h->nb > 0 && (!rowscale || h->nv == 1) &&
+                        ((M > 128 && h->nt > 32 && h->nw >= 64 && !h->no_ring) || M <= 64);
     for (int s = merged ? 2 : 0; s < (merged ? 3 : 2); ++s) {
         if (s < 2 && (s == 0 ? h->na : h->nb) == 0) continue;
         const int rc = h->bh1_real ? onebody_spin<true>(h, s, rowscale) : onebody_spin<false>(h, s, rowscale);
