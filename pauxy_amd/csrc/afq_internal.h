@@ -389,7 +389,9 @@ int k_rng_uniform(afq_handle *h, double *u, long n);
 int k_energy_full_g(afq_handle *h, const cplx *G_dev, int ng, cplx *E_dev);   // estimators/generic.py:398-434
 // k_bigdet.hip
 int k_greens_big_supported(afq_handle *h);
-int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv = nullptr);   // ghalf may be null (overlap only)
+struct WeightArgs;
+int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv = nullptr, const WeightArgs *wa = nullptr);   // ghalf may be null
+                                // (overlap only); wa: the step's weight update rides on the determinant kernel
 int k_reortho_big(afq_handle *h);                           // Cholesky-QR2; sets qr_fail for breakdowns
 // k_small.hip
 int k_alive(afq_handle *h);

@@ -13,6 +13,8 @@
 // on global memory (14.7 ms per call at C4); the pieces above take ~0.1 + 0.3 + 0.15 ms.
 #include "mfma_gemm_wg.h"
 #include "gj_wave.h"
+#include "weight_update.h"
+#include <cstring>
 
 #define GJ_N 128
 
@@ -733,12 +735,15 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
     }
 }
 
-__global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det, int nw) {
+// (wa.weight != null: det IS wa.ovlp_new and the walker's weight update, weight cap and estimator terms run right behind
+//  its determinant, as in greens_small_kernel: no separate weight_kernel launch)
+__global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det, int nw, WeightArgs wa) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
     const cplx p = cmul(detm[2 * w], detm[2 * w + 1]);
     const int e = dete[2 * w] + dete[2 * w + 1];
     det[w] = cmake(ldexp(p.x, e), ldexp(p.y, e));
+    if (wa.weight) weight_update_and_cap(wa, w);
 }
 
 // N > 45, or a smaller determinant whose walker does not fit the one-work-group kernel of k_small.hip (M > 128, or walker +
@@ -750,7 +755,7 @@ int k_greens_big_supported(afq_handle *h) {
     return !small_fits && nmax > 16 && nmax <= GJ_N && h->nb > 0 && !h->no_ring;
 }
 
-int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
+int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const WeightArgs *wa_in) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
     const int nb2 = 2 * h->nw;
     const size_t wsn = (size_t)nb2 * nmax * nmax;
@@ -820,8 +825,11 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv) {
             AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
         }
         AFQ_POST(h);
+        WeightArgs wa;
+        if (wa_in) wa = *wa_in;
+        else std::memset(&wa, 0, sizeof(wa));
         AFQ_LAUNCH(h, det_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detm,
-                           h->dete, det, h->nw);
+                           h->dete, det, h->nw, wa);
         AFQ_POST(h);
     }
     if (oinv)    // [nw, 2, nmax, nmax]: the layout of the workspace (batch = 2 w + spin)
