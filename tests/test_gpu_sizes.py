@@ -520,3 +520,41 @@ def test_blocked_cholesky_reortho_every_tile_count(M, na, nb):
         for sl in (slice(0, na), slice(na, nt)):
             close(q[w][:, sl].conj().T @ q[w][:, sl], numpy.eye(sl.stop - sl.start), 1e-11)
     dev.close()
+
+
+def test_dead_walkers_pass_through_the_large_one_body_products_untouched():
+    """Dead walkers are not propagated (qmc/afqmc.py:232) but the one-body product writes into the other buffer of a
+    ping-pong pair: the work-groups of the ring GEMM engine (M > 128, 64 walkers and more) copy a dead walker's columns
+    through instead of multiplying them (INACTIVE_COPY), here on the un-fused generic step -- B, Taylor products, B -- and
+    on the Hubbard step whose field kernel makes the diagonal potential's Taylor factors.  Dead walkers bit-equal, live ones
+    against the oracle."""
+    from pauxy_amd.propagation import setup as psetup
+    nw = 64
+    # generic, M = 140, 40 + 37 electrons
+    model, rng = build(140, 12, 40, 37, True, seed=5)
+    s = systems.Hubbard(12, 12, 60, 57, 4.0)
+    th = trial_mod.uhf_trial_hubbard(s, ueff=0.4)
+    BH1, mf = psetup.hubbard_propagator_arrays(s, th, 0.01, True)
+    hub = ref.RefModel('hubbard', 144, 60, 57, th.psi, BH1, mf, 0.01, U=4.0, H1=s.T.astype(complex))
+    for m in (model, hub):
+        M, nt, K = m.M, m.na + m.nb, m.nfields
+        r = numpy.random.RandomState(9)
+        dev = make_device(m, nw)
+        phis = m.psi[None] + 0.05 * (r.rand(nw, M, nt) + 1j * r.rand(nw, M, nt))
+        dev.set(L.F_PHI, phis)
+        w0 = numpy.ones(nw)
+        w0[1::5] = 0.0
+        dev.set(L.F_WEIGHT, w0)
+        dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, m.psi, m.na, m.nb) for p in phis]))
+        xi = r.normal(size=(nw, K))
+        dev.propagate(xi, 0.1)
+        out_phi, out_w = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+        for i in range(nw):
+            if w0[i] == 0.0:
+                assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+        for i in (0, 2, 33, 63):
+            w = ref.new_walker(m, phis[i])
+            ref.propagate_walker_phaseless(m, w, xi[i], 0.1)
+            close(out_phi[i], w['phi'], 1e-9)
+            close(out_w[i], w['weight'], 1e-9)
+        dev.close()
