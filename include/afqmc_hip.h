@@ -256,6 +256,18 @@ int afq_local_energy(afq_handle *h, double *E_out);
 int afq_set_exchange_algorithm(afq_handle *h, int mode);
 int afq_exchange_algorithm(afq_handle *h, int *mode_out);
 
+/* Force bias of a multi-determinant trial (propagation/generic.py:154-157, walkers/multi_det.py:283-290) has two
+ * device algorithms with the same result:
+ *   1  one half-rotated contraction per determinant, rchol_d^T vec(Ghalf_d), averaged with the weights
+ *      conj(c_d) <D_d|phi> afterwards (ndet, or 2 ndet for complex vectors, times K (Na + Nb) M products)
+ *   2  the reference's own formulation: the weights go into ONE determinant-averaged Green's function
+ *      Gbar = sum_d w_d conj(psi_d) Ghalf_d / sum_d w_d, contracted once with the symmetric-packed hs_pot
+ *      (K M (M + 1) / 2 products + the build of Gbar); needs symmetric L_n
+ * mode 0 (default) picks 2 when it is the cheaper one for more than 32 walkers.  afq_msd_force_bias: what the next
+ * force bias will use (0 for a single-determinant trial).                                                          */
+int afq_set_msd_force_bias(afq_handle *h, int mode);
+int afq_msd_force_bias(afq_handle *h, int *mode_out);
+
 /* unit-test hooks (reference: <system propagator>.construct_force_bias /
  * construct_VHS, Continuous.apply_exponential, operations.kinetic_real)       */
 int afq_force_bias(afq_handle *h, double *xbar_out);                 /* c128[nw,K] */

@@ -117,6 +117,8 @@ SIGNATURES = {
     "afq_estimates_allreduce_local": [POINTER(_h), c_int],
     "afq_set_exchange_algorithm": [_h, c_int],
     "afq_exchange_algorithm": [_h, POINTER(c_int)],
+    "afq_set_msd_force_bias": [_h, c_int],
+    "afq_msd_force_bias": [_h, POINTER(c_int)],
     "afq_kernel_trace": [_h, c_int],
     "afq_kernel_trace_stride": [_h, c_int, c_int],
     "afq_kernel_trace_get": [_h, c_int, _dp, c_int, POINTER(c_int)],

@@ -72,11 +72,12 @@ void free_dets(afq_handle *h) {
     h->dets.clear();
     h->ndet = 1; h->cur_det = 0;
     if (h->coeffs) { hipFree(h->coeffs); h->coeffs = nullptr; }
+    dev_free(h->msd_psicT); h->msd_fb_gbar = false;
 }
 
 void free_system(afq_handle *h) {
     free_dets(h);
-    dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
+    dev_free(h->hs_pot); dev_free(h->hs_pair); dev_free(h->hs_pk); dev_free(h->L_full); dev_free(h->rchol_re); dev_free(h->rchol_im);
     for (int s = 0; s < 2; ++s) { dev_free(h->rchol_frag[s]); dev_free(h->rchol_frag_im[s]); }
     k_free_atil(h->atil);
     dev_free(h->H1); dev_free(h->rH1);
@@ -100,6 +101,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0; h->vbias_version = 0;
     dev_free(h->gdiag); h->gdiag_version = 0; h->gdiag_parts = 0;
     dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
+    dev_free(h->msd_gs); dev_free(h->msd_S); h->msd_fb_gbar = false;
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->hs_fbfac);
     dev_free(h->bp_hist); dev_free(h->bp_n); dev_free(h->bp_flag); dev_free(h->bp_cos); dev_free(h->bp_ph);
@@ -532,6 +534,21 @@ int afq_set_trial_multi(afq_handle *h, int ndet, const double *psi, const double
     }
     select_det(h, 0);
     if ((rc = dev_upload(h, &h->coeffs, coeffs, (size_t)ndet))) return rc;
+    if (ndet > 1) {
+        // conj(psi_d)^T of every determinant stacked, [ndet nt, M]: both operands of the averaged Green's function
+        // (k_force_bias_msd_gbar) read it along the orbital index
+        const int M = h->M, nt = h->nt;
+        const size_t kkp = ((size_t)ndet * nt + 7) & ~(size_t)7;               // zero rows up to a whole chunk of 8
+        std::vector<double> pt(2 * kkp * M, 0.0);
+        for (int d = 0; d < ndet; ++d)
+            for (int p_ = 0; p_ < M; ++p_)
+                for (int i = 0; i < nt; ++i) {
+                    const double *src = psi + 2 * (npsi * d + (size_t)p_ * nt + i);
+                    double *dst = &pt[2 * (((size_t)d * nt + i) * M + p_)];
+                    dst[0] = src[0]; dst[1] = -src[1];
+                }
+        if ((rc = dev_upload(h, &h->msd_psicT, pt.data(), kkp * M))) return rc;
+    }
     return AFQ_OK;
 }
 
@@ -816,11 +833,20 @@ static int force_bias(afq_handle *h, bool with_xbar = true) {
     int rc;
     if (h->flags & AFQ_PROP_FORCE_BIAS) {
         if (h->kind == AFQ_SYS_GENERIC) {
-            for (int d = 0; d < h->ndet; ++d) {
-                select_det(h, d);
-                if ((rc = k_force_bias_generic(h))) { select_det(h, 0); return rc; }
+            h->msd_fb_gbar = false;
+            // (automatic mode: when every determinant's own contraction is current -- the Coulomb vectors of the energy
+            //  evaluation that has just run on these Green's functions -- their weighted average costs nothing)
+            if (k_msd_gbar_wanted(h) && !(h->msd_fb_mode == 0 && k_msd_vbias_current(h))) {
+                // the reference's own formulation: ONE contraction with the determinant-averaged G (generic.py:154-157)
+                if ((rc = k_force_bias_msd_gbar(h))) return rc;
+                h->msd_fb_gbar = true;
+            } else {
+                for (int d = 0; d < h->ndet; ++d) {
+                    select_det(h, d);
+                    if ((rc = k_force_bias_generic(h))) { select_det(h, 0); return rc; }
+                }
+                select_det(h, 0);
             }
-            select_det(h, 0);
         }
         else if (h->kind == AFQ_SYS_UEG) { if ((rc = k_vbias_ueg(h))) return rc; }
     }
@@ -1105,6 +1131,19 @@ int afq_set_exchange_algorithm(afq_handle *h, int mode) {
     return AFQ_OK;
 }
 
+int afq_set_msd_force_bias(afq_handle *h, int mode) {
+    if (!h || mode < 0 || mode > 2) return AFQ_EINVAL;
+    h->msd_fb_mode = mode;
+    return AFQ_OK;
+}
+
+int afq_msd_force_bias(afq_handle *h, int *mode) {
+    if (!h || !mode) return AFQ_EINVAL;
+    if (h->kind != AFQ_SYS_GENERIC || !h->have_trial || !h->nw) AFQ_FAIL(h, AFQ_ESTATE, "generic system, trial and walkers must be set");
+    *mode = h->ndet <= 1 ? 0 : k_msd_gbar_wanted(h) ? 2 : 1;
+    return AFQ_OK;
+}
+
 int afq_exchange_algorithm(afq_handle *h, int *mode) {
     if (!h || !mode) return AFQ_EINVAL;
     if (h->kind != AFQ_SYS_GENERIC || !h->have_trial) AFQ_FAIL(h, AFQ_ESTATE, "generic system and trial must be set");
@@ -1339,7 +1378,14 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
     if (eval_energy) {
         {
             PhaseTimer t(h, T_GREENS);
-            if (!h->greens_valid && (rc = greens_any(h, h->ovlp_old, true))) return rc;
+            if (!h->greens_valid) {
+                // (e.g. behind a comb that did not carry the Green's functions along: multi-determinant trials.)  It is
+                // the Green's function of the CURRENT walkers, so it also is what the next step starts from: the overlaps go
+                // where the end-of-step evaluation leaves them and the evaluation is kept -- with it the Coulomb vectors the
+                // energy contracts below, which are the next step's force bias
+                if ((rc = greens_any(h, h->ovlp_new, true))) return rc;
+                if (h->greens_cache && !(h->flags & AFQ_PROP_FREE_PROJECTION) && h->psi_stride == 0) { h->greens_valid = true; h->gsum_only = false; }
+            }
             if (h->kind == AFQ_SYS_UEG || h->rdm_on) {       // (one_rdm: w.greens_function(trial) refreshes walker.G, mixed.py:212)
                 if ((rc = ensure_G(h))) return rc;
                 if ((rc = k_full_G(h))) return rc;

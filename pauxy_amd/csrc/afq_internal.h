@@ -104,6 +104,7 @@ struct afq_handle {
         double *rchol_frag[2] = {nullptr, nullptr}, *rchol_frag_im[2] = {nullptr, nullptr};
         void *atil[2] = {nullptr, nullptr};
         bool rchol_same = false;
+        unsigned long long vbias_version = 0;   // ghalf_version this determinant's force-bias partials were contracted from
     };
     int ndet = 1, cur_det = 0;
     std::vector<DetOps> dets;       // size ndet when ndet > 1
@@ -113,6 +114,14 @@ struct afq_handle {
     cplx *ghalf_all = nullptr;      // owning pointers of the per-determinant slices
     cplx *vbias_all = nullptr;
     cplx *energy_all = nullptr;     // [ndet, nw, 3] per-determinant local energies
+    // force bias of a multi-determinant trial through the determinant-averaged Green's function (the reference's own
+    // formulation, propagation/generic.py:154-157 + walkers/multi_det.py:283-290; k_gemm.hip: k_force_bias_msd_gbar)
+    int msd_fb_mode = 0;            // afq_set_msd_force_bias: 0 auto, 1 one contraction per determinant, 2 averaged G
+    bool msd_fb_gbar = false;       // the last force_bias() left ONE already-averaged set of partials in vbias_all
+    cplx *msd_psicT = nullptr;      // [ndet nt, M] conj(psi_d)^T of every determinant, stacked
+    cplx *msd_gs = nullptr;         // [nw, ndet nt, M] Ghalf_d scaled by w_d / sum_d w_d
+    cplx *msd_S = nullptr;          // [nw, ld_hs] (Gbar + Gbar^T) on the packed columns p <= q (the diagonal: Gbar[p,p])
+    double *hs_pk = nullptr;        // [M (M + 1) / 2, ld_rc] packed hs_pot with the field index contiguous
 
     // ---- back-propagation (estimators/back_propagation.py, walkers/stack.py FieldConfig)
     int nbp = 0;                    // field configurations kept per walker (0 = off)
@@ -371,6 +380,9 @@ struct KernelTrace {
 // k_gemm.hip
 int k_onebody(afq_handle *h, const cplx *rowscale = nullptr);   // phi <- [diag(rowscale_w)] BH1 phi (all live walkers)
 int k_force_bias_generic(afq_handle *h);                    // ghalf -> vbias[2,nw,K]
+bool k_msd_vbias_current(afq_handle *h);                    // every determinant's force-bias partials match ghalf_version
+bool k_msd_gbar_wanted(afq_handle *h);                      // multi-determinant force bias through the averaged G
+int k_force_bias_msd_gbar(afq_handle *h);                   // ghalf_all, detw -> averaged partials in vbias_all
 bool k_fb_use_sum(afq_handle *h);                           // force bias runs once over Ghalf_a + Ghalf_b
 int k_vhs_generic(afq_handle *h);                           // xs -> vhs
 int k_apply_exponential(afq_handle *h, const cplx *vhs);    // phi <- sum_n vhs^n/n! phi

@@ -254,10 +254,20 @@ static int force_bias_generic_impl(afq_handle *h);
 // The Coulomb vectors of the energy evaluation at the end of step n and the force bias at the start of step n + 1 are
 // the same contraction of the same (cached) Ghalf: the second call is skipped while ghalf_version has not moved.
 int k_force_bias_generic(afq_handle *h) {
-    if (h->ndet == 1 && h->vbias_version == h->ghalf_version && !afq_knob("AFQ_FB_NOREUSE")) return AFQ_OK;
+    // (multi-determinant trial: one set of partials, and one version, per determinant -- the Coulomb vectors of an energy
+    //  evaluation serve the force bias of the next step as they do for one determinant)
+    unsigned long long &ver = h->ndet == 1 ? h->vbias_version : h->dets[h->cur_det].vbias_version;
+    if (ver == h->ghalf_version && !afq_knob("AFQ_FB_NOREUSE")) return AFQ_OK;
     const int rc = force_bias_generic_impl(h);
-    h->vbias_version = rc == AFQ_OK && h->ndet == 1 ? h->ghalf_version : 0;
+    ver = rc == AFQ_OK ? h->ghalf_version : 0;
     return rc;
+}
+
+// every determinant's partials are current (left behind by the energy evaluation on the same Green's functions)
+bool k_msd_vbias_current(afq_handle *h) {
+    if (h->ndet <= 1 || afq_knob("AFQ_FB_NOREUSE")) return false;
+    for (int d = 0; d < h->ndet; ++d) if (h->dets[d].vbias_version != h->ghalf_version) return false;
+    return true;
 }
 
 static int force_bias_generic_impl(afq_handle *h) {
@@ -336,6 +346,164 @@ static int force_bias_generic_impl(afq_handle *h) {
         fill_force_bias(p, h);
         const TileChoice tc = pick_tiles(p.batch, p.rows, p.cols, kCplxTiles, 4);
         DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
+    }
+    return AFQ_OK;
+}
+
+// ------------------------------------------ multi-determinant force bias through the determinant-averaged G
+// The reference contracts the Cholesky vectors with ONE matrix per walker (propagation/generic.py:154-157,
+// walkers/multi_det.py:283-290):  vbias_n = sum_pq L_n[p,q] Gbar[p,q],  Gbar = sum_d w_d (G_d,a + G_d,b) / sum_d w_d,
+// G_d = conj(psi_d) Ghalf_d.  One contraction per determinant with its half-rotated vectors (k_force_bias_generic) costs
+// ndet (x 2 for complex vectors) x K nt M products; through Gbar it is K M (M + 1) / 2 for symmetric L_n -- the mirror image
+// of the HS-potential GEMM, on the same packed columns -- plus the build of Gbar:
+//   1. msd_scale_ghalf_kernel: gs[w] = [ (w_d / sum w) Ghalf_d[w] ]_d stacked over the determinants, [ndet nt, M]
+//   2. GbarSymProb: S = Gbar + Gbar^T on the upper triangle only, as ONE product with a doubled contraction,
+//        S[p,q] = sum_k X[k,p] Y[k,q],  X = [conj(psi)^T ; gs],  Y = [gs ; conj(psi)^T]   (k over 2 ndet nt),
+//      strictly lower work-group tiles skipped, the diagonal halved, stored straight into the packed columns
+//   3. ForceBiasProb with A = S [nw, P] and B = the packed hs_pot with the field index contiguous [P, K]
+__global__ void msd_scale_ghalf_kernel(const cplx *__restrict__ ghalf_all, const cplx *__restrict__ detw,
+                                       cplx *__restrict__ gs, int nw, int ndet, long per, long wstride) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int w = blockIdx.y, d = blockIdx.z;
+    if (e >= per) return;
+    cplx tot = cmake(0.0, 0.0);
+    for (int dd = 0; dd < ndet; ++dd) tot = cadd(tot, detw[(long)w * ndet + dd]);
+    const cplx sc = cdiv(detw[(long)w * ndet + d], tot);
+    gs[(long)w * wstride + (long)d * per + e] = cmul(sc, ghalf_all[((long)d * nw + w) * per + e]);
+}
+
+// out[c][n] = in[n][c]: the packed hs_pot^T [K, ld_in] -> [P, ld_out]
+__global__ void transpose_f64_kernel(const double *__restrict__ in, double *__restrict__ out, int nrow_in, long ncol_in,
+                                     long ld_in, long ld_out) {
+    __shared__ double t[32][33];
+    const long c0 = (long)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const long c = c0 + threadIdx.x; const int r = r0 + j;
+        t[j][threadIdx.x] = (r < nrow_in && c < ncol_in) ? in[(long)r * ld_in + c] : 0.0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const long c = c0 + j; const int r = r0 + threadIdx.x;
+        if (c < ncol_in && r < nrow_in) out[c * ld_out + r] = t[threadIdx.x][j];
+    }
+}
+
+struct GbarSymProb {
+    static constexpr bool A_CPLX = true, B_CPLX = true, TILE_SKIP = true;
+    int batch, rows, cols, kdim;     // nw, M, M, 2 KK
+    int KK, M;
+    long ldS;
+    const cplx *psicT;               // [KK, M]
+    const cplx *gs;                  // [nw, KK, M]
+    cplx *S;                         // [nw, ldS]
+    __device__ bool active(int) const { return true; }
+    __device__ bool skip_tile(int row0, int col0) const { return row0 > col0; }
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        return k < KK ? psicT + (long)k * M + row : gs + ((long)b * KK + (k - KK)) * M + row;
+    }
+    __device__ const cplx *ptrB(int b, int k, int col) const {
+        return k < KK ? gs + ((long)b * KK + k) * M + col : psicT + (long)(k - KK) * M + col;
+    }
+    __device__ cplx loadA(int b, int row, int k) const { return *ptrA(b, row, k); }
+    __device__ cplx loadB(int b, int k, int col) const { return *ptrB(b, k, col); }
+    // incremental refill of the ring engine: two affine segments, [0, KK) and [KK, 2 KK) (KK is a multiple of 8:
+    // the stacks are zero-padded to it)
+    static constexpr bool INCR = true, INCR_SEG = true;
+    __device__ int klimit(int) const { return kdim; }
+    __device__ int kseg() const { return KK; }
+    __device__ const cplx *baseA(int, int row) const { return psicT + row; }
+    __device__ const cplx *baseB(int b, int col) const { return gs + (long)b * KK * M + col; }
+    __device__ const cplx *baseA2(int b, int row) const { return gs + (long)b * KK * M + row; }
+    __device__ const cplx *baseB2(int, int col) const { return psicT + col; }
+    __device__ long kstepA() const { return M; }
+    __device__ long kstepB(int) const { return M; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int, int) const { return true; }
+    __device__ void store(int b, int row, int col, double re, double im) const {
+        if (row > col) return;
+        const double f = row == col ? 0.5 : 1.0;
+        S[(long)b * ldS + (long)row * M - (long)row * (row - 1) / 2 + (col - row)] = cmake(f * re, f * im);
+    }
+};
+
+static double msd_fb_cost_per_det(const afq_handle *h) {
+    return (double)h->ndet * (h->rchol_real ? 1.0 : 2.0) * h->K * (double)h->nt * h->M;
+}
+static double msd_fb_cost_gbar(const afq_handle *h) {
+    // real-by-complex products; a 3-multiplication complex product counts 1.5
+    return (double)h->K * h->M * (h->M + 1) / 2.0 + 1.5 * (double)h->M * h->M * h->ndet * h->nt;
+}
+
+bool k_msd_gbar_wanted(afq_handle *h) {
+    if (h->ndet <= 1 || h->kind != AFQ_SYS_GENERIC || !h->hs_sym || h->no_ring || !h->msd_psicT) return false;
+    if (2 * h->fb_split > FB_MAX_BATCH) return false;
+    if (h->msd_fb_mode == 1) return false;
+    if (h->msd_fb_mode == 2) return true;
+    return h->nw > 32 && 1.2 * msd_fb_cost_gbar(h) < msd_fb_cost_per_det(h);
+}
+
+int k_force_bias_msd_gbar(afq_handle *h) {
+    const int M = h->M, KK = (h->ndet * h->nt + 7) & ~7, nw = h->nw;     // (stacks zero-padded to whole chunks of 8)
+    const long P = (long)M * (M + 1) / 2, per = (long)h->nt * M;
+    h->dets[0].vbias_version = 0;                  // the averaged partials go where determinant 0 keeps its own
+    if (!h->hs_pk) {
+        AFQ_HIP(h, hipMalloc(&h->hs_pk, sizeof(double) * (size_t)P * h->ld_rc));
+        AFQ_HIP(h, hipMemsetAsync(h->hs_pk, 0, sizeof(double) * (size_t)P * h->ld_rc, h->stream));
+        AFQ_LAUNCH(h, transpose_f64_kernel, dim3((unsigned)((P + 31) / 32), (unsigned)((h->K + 31) / 32)), dim3(32, 8), 0,
+                   h->stream, h->hs_pot, h->hs_pk, h->K, P, h->ld_hs, h->ld_rc);
+        AFQ_POST(h);
+    }
+    if (!h->msd_gs) {
+        AFQ_HIP(h, hipMalloc(&h->msd_gs, sizeof(cplx) * (size_t)nw * KK * M));
+        AFQ_HIP(h, hipMemsetAsync(h->msd_gs, 0, sizeof(cplx) * (size_t)nw * KK * M, h->stream));             // (the pad rows)
+    }
+    if (!h->msd_S) {
+        AFQ_HIP(h, hipMalloc(&h->msd_S, sizeof(cplx) * (size_t)nw * h->ld_hs));
+        AFQ_HIP(h, hipMemsetAsync(h->msd_S, 0, sizeof(cplx) * (size_t)nw * h->ld_hs, h->stream));   // (the pad column)
+    }
+    AFQ_LAUNCH(h, msd_scale_ghalf_kernel, dim3((unsigned)((per + 255) / 256), nw, h->ndet), dim3(256), 0, h->stream,
+               h->ghalf_all, h->detw, h->msd_gs, nw, h->ndet, per, (long)KK * M);
+    AFQ_POST(h);
+    {
+        GbarSymProb p;
+        p.batch = nw; p.rows = M; p.cols = M; p.kdim = 2 * KK; p.KK = KK; p.M = M; p.ldS = h->ld_hs;
+        p.psicT = h->msd_psicT; p.gs = h->msd_gs; p.S = h->msd_S;
+#ifdef AFQ_TUNING
+        const int gcfg = afq_knob("AFQ_GBAR_CFG") ? atoi(afq_knob("AFQ_GBAR_CFG")) : 0;
+        if (gcfg == 1) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 2) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD_ROWS, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 3) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 4, GbarSymProb, MAP_BATCH_XCD, true>(p, h->stream, h->zero_page)));
+        else if (gcfg == 4) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
+        else if (gcfg == 5) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 6) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else if (gcfg == 7) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 8) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 8, GbarSymProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
+        else
+#endif
+        if (M > 64)
+            // 64 x 64 tiles, four waves of 2 x 2, 3-multiplication products, the half-chunk pipelined loop with the waves'
+            // own refill (STAG = 2).  Measured at C5 sizes (400 x 400, contraction 2 x 400, 256 walkers;
+            // profiles/r05_c5_gbar_variants.txt): 2.37-2.39 ms; one walker per XCD at a time 2.42-2.48; with loader waves
+            // 2.63 (2.75 on the batch map); 4-multiplication products under loader waves 2.88; ring depth 8: 2.97;
+            // before the incremental refill (per-fragment address arithmetic every chunk) 3.14
+            AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else
+            AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 1, 1, 4, GbarSymProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+    }
+    {
+        ForceBiasProb<false> p;
+        fill_force_bias(p, h);
+        const int ns2 = 2 * h->fb_split;
+        const long slice = (P + ns2 - 1) / ns2;
+        int kmax = 0;
+        for (int b = 0; b < ns2; ++b) {
+            long l = P - b * slice; if (l > slice) l = slice; if (l < 0) l = 0;
+            p.q0[b] = b * slice; p.len[b] = (int)l;
+            if (l > kmax) kmax = (int)l;
+        }
+        p.kdim = kmax; p.ghalf = h->msd_S; p.astride = h->ld_hs; p.rre = h->hs_pk; p.rim = nullptr; p.out = h->vbias_all;
+        AFQ_GEMM_AS(h, "msd_gbar_contract GEMM", (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
     }
     return AFQ_OK;
 }
@@ -570,6 +738,9 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                         else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                     }
                     // round 4: 64 x 64 tiles, four compute + four loader waves (STAG = 3; see k_vhs_generic): C5 sizes 689 -> 627 us
+                    else if (afq_knob("AFQ_TAYLOR_S2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_S2C")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_XCD")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
                     else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                 }
                 continue;

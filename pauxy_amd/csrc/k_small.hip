@@ -791,6 +791,8 @@ static XbarArgs xbar_args(afq_handle *h) {
     a.gparts = h->gdiag_parts;
     a.ndet = h->ndet; a.detw = h->detw; a.det_stride = (long)2 * h->fb_split * h->nw * h->K;
     if (h->ndet > 1) a.vbias = h->vbias_all;
+    // (the contraction with the determinant-averaged G left ONE set of partials, already weighted: k_force_bias_msd_gbar)
+    if (h->ndet > 1 && h->msd_fb_gbar && h->kind == AFQ_SYS_GENERIC) a.ndet = 1;
     return a;
 }
 

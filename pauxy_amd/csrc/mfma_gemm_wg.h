@@ -82,6 +82,15 @@ template <class P> struct gemm_areal<P, decltype((void)P::A_REAL)> { static cons
 // ... and the same for B: static constexpr bool B_REAL = true on a problem with B_CPLX (complex storage, zero imaginary parts)
 template <class P, class = void> struct gemm_breal { static constexpr bool value = false; };
 template <class P> struct gemm_breal<P, decltype((void)P::B_REAL)> { static constexpr bool value = P::B_REAL; };
+// optional problem trait: static constexpr bool TILE_SKIP = true -- skip_tile(row0, col0) is true for work-group tiles whose
+// output nobody wants (the strictly lower tiles of a symmetric result): such a work-group returns before its first barrier
+template <class P, class = void> struct gemm_tileskip { static constexpr bool value = false; };
+template <class P> struct gemm_tileskip<P, decltype((void)P::TILE_SKIP)> { static constexpr bool value = P::TILE_SKIP; };
+// optional problem trait (with INCR): static constexpr bool INCR_SEG = true -- the operands are affine in the contraction
+// index on [0, kseg()) and again on [kseg(), klimit): the refill re-bases its pointers from baseA2(b, row) / baseB2(b, col)
+// (the sources of index kseg()) when it reaches kseg(), a multiple of 8
+template <class P, class = void> struct gemm_incr_seg { static constexpr bool value = false; };
+template <class P> struct gemm_incr_seg<P, decltype((void)P::INCR_SEG)> { static constexpr bool value = P::INCR_SEG; };
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
         return;
     }
     const int row0 = tm * 16 * RT, col0 = tn * 16 * CT;
+    if constexpr (gemm_tileskip<P>::value) { if (p.skip_tile(row0, col0)) return; }   // uniform over the work-group
     const int lr = lane & 15, lk = lane >> 4;
     unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
     const unsigned ring_l = lds_addr(smem);
@@ -190,6 +200,22 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
 #pragma unroll
             for (int sub = 0; sub < KC; ++sub) {
                 unsigned char *dst = smem + (size_t)slot * CHUNK + (size_t)sub * SUB;
+                if constexpr (gemm_incr_seg<P>::value) {
+                    if (kcur == p.kseg()) {                    // uniform: second affine segment of both operands
+#pragma unroll
+                        for (int t = 0; t < LPA; ++t) {
+                            const int f = wave + t * NW, row = row0 + (f >> 1) * 16 + lr;
+                            curA[t] = p.baseA2(b, okA[t] ? row : row0) + (long)(2 * lk + (f & 1)) * p.kstepA();
+                        }
+#pragma unroll
+                        for (int t = 0; t < LPB; ++t) {
+                            const int f = wave + t * NW;
+                            const int col = P::B_CPLX ? col0 + (f >> 1) * 16 + lr : col0 + f * 16 + b_cc;
+                            const int kl = P::B_CPLX ? 2 * lk + (f & 1) : 2 * b_kk + b_half;
+                            curB[t] = p.baseB2(b, okB[t] ? col : col0) + (long)kl * p.kstepB(b);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < LPA; ++t) {
                     const int f = wave + t * NW;

@@ -548,6 +548,15 @@ class AfqDevice(object):
         self._ck(self.lib.afq_exchange_algorithm(self.h, ctypes.byref(m)))
         return m.value
 
+    def set_msd_force_bias(self, mode):
+        """0 automatic, 1 one contraction per determinant, 2 determinant-averaged G (see afq_set_msd_force_bias)."""
+        self._ck(self.lib.afq_set_msd_force_bias(self.h, int(mode)))
+
+    def msd_force_bias(self):
+        m = ctypes.c_int()
+        self._ck(self.lib.afq_msd_force_bias(self.h, ctypes.byref(m)))
+        return m.value
+
 
 # -- in-process communicator: several AfqDevice objects driven by one host thread -----------------------------
 def _handle_array(devs):

@@ -377,6 +377,15 @@ def test_c5_sizes_distinct_complex_determinants(nw):
         tot = dev.greens()
         wts = dev.det_weights()
         xbar = dev.force_bias()
+        # (256 walkers: the automatic choice is the contraction with the determinant-averaged G, propagation/generic.py:154-157;
+        #  8 walkers: one contraction per determinant) -- both algorithms against each other
+        assert dev.msd_force_bias() == (2 if nw > 32 else 1)
+        xb = {}
+        for fbm in (1, 2):
+            dev.set_msd_force_bias(fbm)
+            xb[fbm] = dev.force_bias()
+        close(xb[1], xb[2], 1e-11)
+        dev.set_msd_force_bias(0)
         dev.greens()
         E[mode] = dev.local_energy()
         assert dev.exchange_algorithm() == mode

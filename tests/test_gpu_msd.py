@@ -19,11 +19,18 @@ def close(a, b, tol=TOL):
     assert err <= tol, err
 
 
-def run_steps(d, tag, hybrid, nw=3):
+def run_steps(d, tag, hybrid, nw=3, fb_mode=0):
     """Walker 0 replays the reference's run; the other walkers start from perturbed states and are
-    checked against the oracle."""
+    checked against the oracle.  fb_mode: afq_set_msd_force_bias (1 one contraction per determinant, 2 through the
+    determinant-averaged Green's function, propagation/generic.py:154-157)."""
     m = msd_model(d, tag)
     dev = make_device(m, nw, hybrid=hybrid)
+    dev.set_msd_force_bias(fb_mode)
+    if fb_mode:
+        # (the averaged-G contraction runs on the symmetric-packed hs_pot: non-symmetric L_n keep algorithm 1)
+        hs = numpy.asarray(m.hs_pot).reshape(m.M, m.M, -1)
+        sym = bool(numpy.array_equal(hs, hs.transpose(1, 0, 2)))
+        assert dev.msd_force_bias() == (fb_mode if (fb_mode == 1 or sym) else 1)
     rng = numpy.random.RandomState(3)
     phi0 = numpy.array([d[tag + 'phi0']] + [d[tag + 'phi0'] + 0.05 * (rng.rand(m.M, m.na + m.nb) +
                                                                        1j * rng.rand(m.M, m.na + m.nb))
@@ -73,15 +80,24 @@ def run_steps(d, tag, hybrid, nw=3):
     return wfinal
 
 
-def test_phmsd_local_energy_weights(golden):
-    w = run_steps(golden('msd_ops.npz'), 'PL_', False)
+@pytest.mark.parametrize("fb_mode", [0, 1, 2])
+def test_phmsd_local_energy_weights(golden, fb_mode):
+    w = run_steps(golden('msd_ops.npz'), 'PL_', False, fb_mode=fb_mode)
     assert w == pytest.approx(0.68797524675701, rel=1e-9)           # propagation/tests/test_generic.py:72
 
 
-def test_phmsd_hybrid(golden):
-    w = run_steps(golden('msd_ops.npz'), 'PH_', True)
+@pytest.mark.parametrize("fb_mode", [0, 1, 2])
+def test_phmsd_hybrid(golden, fb_mode):
+    w = run_steps(golden('msd_ops.npz'), 'PH_', True, fb_mode=fb_mode)
     assert w == pytest.approx(0.7430443466368197, rel=1e-9)         # propagation/tests/test_generic.py:92
 
 
-def test_nomsd(golden):
-    run_steps(golden('msd_ops.npz'), 'N_', True)
+@pytest.mark.parametrize("fb_mode", [0, 1, 2])
+def test_nomsd(golden, fb_mode):
+    run_steps(golden('msd_ops.npz'), 'N_', True, fb_mode=fb_mode)
+
+
+def test_nomsd_many_walkers_averaged_g(golden):
+    """40 walkers: the automatic choice (more than 32 walkers, cost model) and both forced algorithms agree."""
+    run_steps(golden('msd_ops.npz'), 'N_', True, nw=40, fb_mode=0)
+    run_steps(golden('msd_ops.npz'), 'N_', True, nw=40, fb_mode=2)

@@ -96,6 +96,16 @@ def test_distinct_complex_determinants_on_boundary_shapes(M, K, na, nb, ndet, nw
         tot = dev.greens()
         wts = dev.det_weights()
         xbar = dev.force_bias()
+        # both force-bias algorithms (afq_set_msd_force_bias): one contraction per determinant, and the reference's own
+        # formulation through the determinant-averaged Green's function
+        xb = {}
+        for fbm in (1, 2):
+            dev.set_msd_force_bias(fbm)
+            assert dev.msd_force_bias() == fbm
+            xb[fbm] = dev.force_bias()
+        close(xb[1], xb[2], 1e-11)
+        close(xbar, xb[2], 1e-11)
+        dev.set_msd_force_bias(0)
         dev.greens()
         E[mode] = dev.local_energy()
         dev.close()
