@@ -89,40 +89,72 @@ def build_config(name):
     return s, trial_mod.MultiDetTrial(s, (numpy.array([0.8, 0.3, 0.2, 0.1], dtype=complex), dets), init=t0.psi)
 
 
-def launch_work(name, c, b_real=False, psi_real=False):
-    """(bound, algorithmic work of ONE launch, note) of the launches afq_launch_trace names (kernel names for plain
-    launches, the launching function for the GEMM engines); SURVEY 8d conventions: 8 flops per complex MAC, 4 per
-    real-by-complex MAC, no padding.  None for launches that are bookkeeping."""
+def work_table(c, b_real=False, psi_real=False, rchol_same=False):
+    """The ONE work model of both bench modes (the headline line and --config): for every launch afq_launch_trace can
+    name (kernel names for plain launches, the launching function for the GEMM engines) the algorithmic work of ONE
+    launch, SURVEY 8d conventions -- 8 flops per complex MAC, 4 per real-by-complex MAC, no padding.
+      survey         SURVEY 8d's own count for the operation (operands priced as complex even where they happen to be real)
+      real_operands  the same with 4 flops per MAC wherever one operand is real in THIS run (real BH1, real trial)
+      cmac           flops one complex-by-complex MAC is priced at in both: 8, or 6 for a launch that executes
+                     3-multiplication products AND would otherwise be priced above the peak (stated in its note)
+    Launches that are bookkeeping have no entry."""
     M, na, nb, K, nw = c["M"], c["na"], c["nb"], c["K"], c["nw"]
     nt, ndet = na + nb, c.get("ndet", 1)
-    cx = 2.0 if ndet > 1 else 1.0                       # perturbed determinants make the half-rotated vectors complex
-    ob = 4.0 if b_real else 8.0                         # a real one-body matrix times a complex walker: 4 flops per MAC
-    ov = 4.0 if psi_real else 8.0                       # a real trial in the overlap / Gram products likewise
-    table = (
-        ("prop_fused_kernel", "mfma", M * M * nt * (8.0 * 6 + ob * 2) * nw, "B exp(V) B: 2 + 6 products of M x M by M x (na+nb)"),
-        ("prop_ueg_kernel", "mfma", 8.0 * M * M * nt * 6 * nw, "exp(V) phi from per-walker coefficients: 6 products"),
-        ("k_apply_exponential", "mfma", 8.0 * M * M * nt * nw, "one Taylor product V T, both spins"),
-        # (one launch for both spins when they share one real matrix, else one per spin: run_config divides by the count)
-        ("onebody_spin", "mfma", ob * M * M * nt * nw,
-         "BH1 phi: one application to both spins = %d M^2 (na+nb) flops per walker%s" % (ob, " (real BH1)" if b_real else "")),
-        ("k_vhs_generic", "mfma", 4.0 * (M * (M + 1) // 2) * K * nw, "HS potential, packed symmetric columns"),
-        ("force_bias_generic_impl", "mfma",
-         4.0 * K * (na if (ndet == 1 and na == nb) else nt) * M * nw, "force bias / Coulomb vectors, one real-B pass"),
-        ("launch_exx_quadratic", "mfma", 4.0 * cx * (na * M * (na * M + 1) / 2.0 + nb * M * (nb * M + 1) / 2.0) * nw,
-         "exchange energy as the quadratic form on the upper triangle of Atil (one determinant)"),
-        ("exx_kernel", "mfma", 4.0 * cx * K * M * (na * na + nb * nb) * nw, "exchange energy, T intermediate"),
-        ("OvlpProb GEMM", "mfma", ov * na * na * M * nw * 2, "phi^T conj(psi), both spins%s" % (" (real trial)" if psi_real else "")),
-        ("GhalfProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "O^-1 phi^T, both spins"),
-        ("GramProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "Cholesky-QR Gram matrix, both spins"),
-        ("QProb GEMM", "mfma", 8.0 * na * na * M * nw * 2, "Cholesky-QR Q = phi T, both spins"),
-        ("gj_big_kernel", "valu", 8.0 * na ** 3 * nw * 2, "register-resident Gauss-Jordan, 8 N^3 flops per matrix"),
-        ("greens_small_kernel", "hbm", 2.0 * M * nt * 16 * nw, "reads phi, writes Ghalf (latency bound: Gauss-Jordan chain)"),
-        ("ueg_fields_kernel", "hbm", (nt * M * 16 + 2 * K * 16 + 600 * 16) * nw,
-         "reads Ghalf, writes xbar, xs and the HS coefficients (latency bound: RNG chain, dependent gathers)"),
-    )
-    for key, bound, work, note in table:
+    cx = ndet > 1                                       # perturbed determinants make the half-rotated vectors complex
+    ob = 4.0 if b_real else 8.0
+    ov = 4.0 if psi_real else 8.0
+    nn2 = na * na + nb * nb
+    n3 = float(na ** 3 + nb ** 3)
+    P = M * (M + 1) // 2
+    fb_len = na if (ndet == 1 and na == nb and rchol_same) else nt
+    exq_pairs = na * M * (na * M + 1) / 2.0 + nb * M * (nb * M + 1) / 2.0
+    t = {
+        "prop_fused_kernel": ("mfma", 8.0 * M * M * nt * 8 * nw, M * M * nt * (8.0 * 6 + ob * 2) * nw,
+                              "B exp(V) B: 2 one-body + 6 Taylor products of M x M by M x (na+nb) per walker"),
+        "prop_ueg_kernel": ("mfma", 8.0 * M * M * nt * 6 * nw, None, "exp(V) phi from per-walker coefficients: 6 products"),
+        "k_apply_exponential": ("mfma", 8.0 * M * M * nt * nw, None, "one Taylor product V T, both spins"),
+        # (one launch for both spins when they share one real matrix, else one per spin: the caller divides by the count)
+        "onebody_spin": ("mfma", 8.0 * M * M * nt * nw, ob * M * M * nt * nw, "BH1 phi: one application to both spins"),
+        "k_vhs_generic": ("mfma", 4.0 * P * K * nw, None, "HS potential, packed symmetric columns"),
+        "force_bias_generic_impl": ("mfma", 4.0 * K * fb_len * M * nw, None,
+                                    "force bias / Coulomb vectors, one real-B pass over %s" %
+                                    ("Ghalf_a + Ghalf_b" if fb_len == na and na == nb else "both spins")),
+        # multi-determinant force bias through the determinant-averaged G (k_force_bias_msd_gbar)
+        "msd_gbar_fold GEMM": ("mfma", 8.0 * M * M * ndet * nt * nw, None,
+                               "Gbar + Gbar^T on the upper triangle = M^2 ndet (na+nb) complex MACs per walker"),
+        "msd_gbar_contract GEMM": ("mfma", 4.0 * K * P * nw, None, "packed hs_pot times the folded averaged G"),
+        "msd_scale_ghalf_kernel": ("hbm", 2.0 * 16 * ndet * nt * M * nw, None, "reads every Ghalf_d, writes it scaled"),
+        # complex Atil (complex half-rotated vectors) and a complex Ghalf: the kernel multiplies with 3-multiplication
+        # products, priced at 6 flops per complex MAC (8 would put the launch above the peak)
+        "launch_exx_quadratic": ("mfma", (6.0 if cx else 4.0) * exq_pairs * nw, None,
+                                 "exchange energy as the quadratic form on the upper triangle of Atil (one determinant)%s" %
+                                 ("; complex Atil: 3-multiplication products priced at 6 flops per complex MAC" if cx else "")),
+        "exx_kernel": ("mfma", (8.0 if cx else 4.0) * K * M * nn2 * nw, None, "exchange energy, T intermediate"),
+        "OvlpProb GEMM": ("mfma", 8.0 * nn2 * M * nw, ov * nn2 * M * nw, "phi^T conj(psi), both spins"),
+        "GhalfProb GEMM": ("mfma", 8.0 * nn2 * M * nw, None, "O^-1 phi^T, both spins"),
+        "GdiagProb GEMM": ("mfma", 8.0 * nn2 * M * nw, ov * nn2 * M * nw, "(psi O^-1) rowdot phi = diag G, both spins"),
+        "GramProb GEMM": ("mfma", 8.0 * nn2 * M * nw, None, "Cholesky-QR Gram matrix, both spins"),
+        "QProb GEMM": ("mfma", 8.0 * nn2 * M * nw, None, "Cholesky-QR Q = phi T, both spins"),
+        "gj_mfma_kernel": ("mfma", 8.0 * n3 * nw, None, "blocked Gauss-Jordan inverse + determinant, 8 N^3 flops per matrix"),
+        "gj_big_kernel (fallback pass)": ("valu", 8.0 * n3 * nw, None,
+                                          "step-by-step Gauss-Jordan of the matrices the blocked kernel flagged"),
+        "gj_big_kernel": ("valu", 8.0 * n3 * nw, None, "register-resident Gauss-Jordan, 8 N^3 flops per matrix"),
+        "chol_mfma_kernel": ("mfma", 8.0 / 3.0 * n3 * nw, None,
+                             "blocked Cholesky + inverse of the factor, (4/3 + 4/3) N^3 flops per Gram matrix"),
+        "chol_linv_kernel": ("valu", 8.0 / 3.0 * n3 * nw, None, "Cholesky + inverse of the factor, one pivot at a time"),
+        "greens_small_kernel": ("hbm", 2.0 * M * nt * 16 * nw, None, "reads phi, writes Ghalf (latency bound: Gauss-Jordan chain)"),
+        "ueg_fields_kernel": ("hbm", (nt * M * 16 + 2 * K * 16 + 600 * 16) * nw, None,
+                              "reads Ghalf, writes xbar, xs and the HS coefficients"),
+    }
+    return t
+
+
+def launch_work(name, c, b_real=False, psi_real=False, rchol_same=False):
+    """(bound, survey work, real-operand work or None, note) of the launch `name`, or None (bookkeeping)."""
+    table = work_table(c, b_real, psi_real, rchol_same)
+    for key in sorted(table, key=len, reverse=True):      # longest key first: "gj_big_kernel (fallback pass)" before "gj_big_kernel"
         if key in name:
-            return bound, work, note
+            return table[key]
     return None
 
 
@@ -184,11 +216,15 @@ def config_cpu_baseline(name, system, trial, budget_s=15.0):
         while time.time() - t0 < budget_s:
             done += block(nw_)
         el = time.time() - t0
-    return {"value": done / el, "unit": "walker-steps/s", "cores": socket_cores, "kind": "port",
-            "cpu": "%s, %d cores/socket x %d sockets" % (cpu_model, socket_cores, sockets),
-            "sample": "%d walker-steps (blocks of %d walkers x %d steps in the bench cadence incl. the per-block energy "
-                      "evaluation), numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s wall, BLAS threads of one socket"
-                      % (done, nw_, NSTEPS_BLOCK, el)}
+    out = {"value": done / el, "unit": "walker-steps/s", "cores": socket_cores, "kind": "port",
+           "cpu": "%s, %d cores/socket x %d sockets" % (cpu_model, socket_cores, sockets), "dt": dt,
+           "sample": "%d walker-steps (blocks of %d walkers x %d steps in the bench cadence incl. the per-block energy "
+                     "evaluation), numpy/scipy per-walker loop of oracle/afqmc_ref.py, %.1f s wall, BLAS threads of one socket"
+                     % (done, nw_, NSTEPS_BLOCK, el)}
+    if dt != c["dt"]:
+        out["sample"] += ("; time step %g instead of the configured %g (same arithmetic per step; at the configured step the "
+                          "weights of a two-walker sample fall below the comb's 1e-8 threshold within the first block)" % (dt, c["dt"]))
+    return out
 
 
 def run_config(args, name, state):
@@ -229,31 +265,57 @@ def run_config(args, name, state):
     elapsed = sorted(regions)[(repeats - 1) // 2]
     state["phase"] = "launch trace"
     extra = 2 * NSTEPS_BLOCK
+    flagged0 = int(dev.counters()[2])
     dev.launch_trace(True)
     afqmc.run_batched(extra, first_step=first, eshift=eshift)
     dev.sync()
     dev.launch_trace(False)
     trace = dev.launch_trace_get()
+    flagged = int(dev.counters()[2]) - flagged0     # matrices the blocked Gauss-Jordan handed to the step-by-step kernel
     b_real = bool(numpy.abs(numpy.imag(afqmc.propagators.propagator.BH1)).max() == 0.0)
     psi_real = bool(numpy.abs(numpy.imag(numpy.asarray(trial.psi))).max() == 0.0)
+    rc_ = numpy.asarray(getattr(trial, '_rchol', numpy.zeros((0, 1))))
+    half = c["na"] * c["M"]
+    rchol_same = bool(c["kind"] == "generic" and c.get("ndet", 1) == 1 and c["na"] == c["nb"] and
+                      numpy.array_equal(rc_[:half], rc_[half:2 * half]))
+    traffic_table, traffic_source = committed_traffic(name)
     rows = []
     for lname, (count, ms) in sorted(trace.items(), key=lambda kv: -kv[1][1]):
         row = {"launch": lname, "launches": count, "avg_ms": ms / count, "ms_per_step": ms / extra}
-        w = launch_work(lname, c, b_real=b_real, psi_real=psi_real)
+        w = launch_work(lname, c, b_real=b_real, psi_real=psi_real, rchol_same=rchol_same)
+        if w and "fallback pass" in lname:
+            # priced by the matrices it actually processed: every other work-group of the launch returns at once
+            nmat = 2 * c["nw"] * count
+            if flagged == 0:
+                row["note"] = "second pass behind the blocked Gauss-Jordan: 0 of %d matrices flagged, nothing to price" % nmat
+                w = None
+            else:
+                w = (w[0], w[1] * flagged / nmat, None, w[3] + " (%d of %d matrices)" % (flagged, nmat))
         if w:
-            bound, work, note = w
+            bound, work, work_real, note = w
             if lname == "onebody_spin":          # two applications per step, in `count / extra` launches per step
                 work = work * 2.0 * extra / count
+                work_real = work_real * 2.0 * extra / count if work_real else None
             t = ms / count * 1e-3
             if bound == "hbm":
                 row.update(bound="hbm", achieved=work / t / 1e9, peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                            frac=work / t / 1e12 / PEAK_HBM_TBS, bytes_per_launch=work, note=note)
             else:
-                # algorithmic fraction (SURVEY 8d count: 4 multiplications per complex product, no padding) -- comparable
-                # across implementations; a kernel with 3-multiplication products or real operands can exceed the share of
-                # the pipe it keeps busy, and 1
-                row.update(bound=bound, achieved=work / t / 1e12, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
-                           frac=work / t / 1e12 / PEAK_F64_MFMA_TFLOPS, flops_per_launch=work, note=note)
+                # frac: the work THIS run needs -- 4 flops per MAC wherever an operand is real here (a real one-body matrix, a
+                # real trial), 8 per complex MAC: a utilisation, never above 1.  frac_survey: SURVEY 8d's own count for the
+                # operation, which prices those operands as complex -- an effective rate against that formulation (it may
+                # exceed 1 where the kernel uses the real operand)
+                need = work_real if work_real is not None else work
+                row.update(bound=bound, achieved=need / t / 1e12, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
+                           frac=need / t / 1e12 / PEAK_F64_MFMA_TFLOPS, flops_per_launch=need, note=note)
+                if need != work:
+                    row.update(frac_survey=work / t / 1e12 / PEAK_F64_MFMA_TFLOPS, flops_per_launch_survey=work)
+            tr = traffic_for(traffic_table, lname)
+            if tr is not None:
+                row["traffic"] = tr
+            if not row["frac"] <= 1.0:
+                raise RuntimeError("launch %r priced above its peak (frac %.3f): the timed launch cannot be doing the counted "
+                                   "work -- fix its work model" % (lname, row["frac"]))
         rows.append(row)
     priced = [r for r in rows if "frac" in r]
     if not priced:
@@ -273,9 +335,12 @@ def run_config(args, name, state):
         "last_block_ETotal": float(numpy.real(mixed.blocks[-1][6])) if mixed.blocks else None,
         "roofline": {"bound": "hbm" if dom["bound"] == "hbm" else "mfma", "kernel": dom["launch"] + " (" + dom["note"] + ")",
                      "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                     "traffic": None, "kernel_ms": dom["avg_ms"], "launches": dom["launches"],
+                     "frac_survey": dom.get("frac_survey"),
+                     "traffic": dom.get("traffic"), "traffic_source": traffic_source if dom.get("traffic") is not None else None,
+                     "kernel_ms": dom["avg_ms"], "launches": dom["launches"],
                      "measured": "extra pass of %d steps under afq_launch_trace right behind the timed regions" % extra,
-                     "frac_is": "algorithmic work of SURVEY 8d (4-multiplication complex products, no padding) over the time",
+                     "frac_is": "algorithmic work this run needs (8 flops per complex MAC, 4 where an operand is real in this "
+                                "run, no padding) over the time; frac_survey: SURVEY 8d's count with every operand priced as complex",
                      "pipe": "fp64 vector ALU (same peak as the matrix pipe on gfx950)" if dom["bound"] == "valu" else None},
         "roofline_all": rows[:16],
         "step_ms_in_traced_launches": sum(r["ms_per_step"] for r in rows),
@@ -288,6 +353,42 @@ def run_config(args, name, state):
     state["dev"] = None
     release_context(system, trial)
     return out
+
+
+# rocprofv3 names of the launches afq_launch_trace names by their launching function (GEMM engines)
+ROCPROF_NAME = {"onebody_spin": "mfma_gemm_wg_kernel<OneBodyProbT>", "k_apply_exponential": "mfma_gemm_wg_kernel<TaylorProb>",
+                "k_vhs_generic": "mfma_gemm_wg_kernel<VhsProb>", "launch_exx_quadratic": "mfma_gemm_wg_kernel<ExxQProb>",
+                "msd_gbar_fold GEMM": "mfma_gemm_wg_kernel<GbarSymProb>", "OvlpProb GEMM": "mfma_gemm_wg_kernel<OvlpProbT>",
+                "GhalfProb GEMM": "mfma_gemm_wg_kernel<GhalfProbT>", "GdiagProb GEMM": "mfma_gemm_wg_kernel<GdiagProbT>",
+                "GramProb GEMM": "mfma_gemm_wg_kernel<GramProb>", "QProb GEMM": "mfma_gemm_wg_kernel<QProb>"}
+
+
+def committed_traffic(config_name):
+    """HBM-side bytes per launch of this configuration's kernels from the newest committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_traffic.json, tools/profile_round.sh + tools/publish_profiles.py: separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command, FETCH_SIZE doubled on gfx950) -- ({kernel: bytes}, source) or ({}, None)."""
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        table = d if config_name == "C3" else d.get("configs", {}).get(config_name)
+        if table:
+            return ({k: v["traffic_bytes_per_launch"] for k, v in table.items() if isinstance(v, dict) and
+                     "traffic_bytes_per_launch" in v},
+                    "%s: rocprofv3 --pmc passes of this command (not collected in this run)" % os.path.relpath(path, ROOT))
+    return {}, None
+
+
+def traffic_for(table, launch):
+    if not table:
+        return None
+    for key, kname in ROCPROF_NAME.items():
+        if key in launch:
+            return table.get(kname)
+    base = launch.split("<")[0].split(" ")[0]
+    return table.get(launch, table.get(base))
 
 
 def host_cpu():
@@ -611,8 +712,9 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     }
     if os.environ.get("AFQ_BENCH_DEVICE_COMM"):
         # 'rccl' | 'sendrecv' | 'ipc' | '0': pin one communicator ('ipc' also works with every rank on one GPU over gloo)
+        # ('auto': the whole candidate chain rccl -> sendrecv -> ipc -> host, also when the ranks' own process group is gloo)
         v = os.environ["AFQ_BENCH_DEVICE_COMM"]
-        options['walkers'] = {'device_comm': False if v == '0' else v}
+        options['walkers'] = {'device_comm': False if v == '0' else True if v == 'auto' else v}
     state["phase"] = "set-up"
     afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
@@ -709,27 +811,29 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     nt = 2 * N
     rc = numpy.asarray(trial._rchol)
     fb_same_spin_block = bool(numpy.array_equal(rc[:N * M], rc[N * M:2 * N * M]))
+    b_real = bool(numpy.abs(numpy.imag(afqmc.propagators.propagator.BH1)).max() == 0.0)
+    psi_real = bool(numpy.abs(numpy.imag(numpy.asarray(trial.psi))).max() == 0.0)
+    # the same work model as the --config lines (work_table): SURVEY 8d count, and the count with real operands at 4 flops
+    wt = work_table(dict(M=M, na=N, nb=N, K=K, nw=nw), b_real=b_real, psi_real=psi_real, rchol_same=fb_same_spin_block)
+    quad = dev.exchange_algorithm() == 2
     kernels = [
-        ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR,
-         8.0 * M * M * nt * (6 + 2) * nw),
+        ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
         # GEMM per spin) executes 4 (N M)^2 flops per spin and walker -- K / M = 5 times fewer than the
         # T-intermediate formulation of the reference (4 K M N^2); both counts are reported
         # (Atil is symmetric: the library stores its upper triangle and contracts only that -- NM (NM + 1) / 2 pairs)
         (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g, upper triangle)",
-          L.K_EXCHANGE, 4.0 * 2 * (N * M) * (N * M + 1) / 2 * nw) if dev.exchange_algorithm() == 2 else
-         ("exx_kernel (Cholesky exchange energy, T intermediate)", L.K_EXCHANGE, exchange_flops_per_walker(M, K, N, N) * nw)),
+          L.K_EXCHANGE, wt["launch_exx_quadratic"]) if quad else
+         ("exx_kernel (Cholesky exchange energy, T intermediate)", L.K_EXCHANGE, wt["exx_kernel"])),
         # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted
-        ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS,
-         4.0 * (M * (M + 1) // 2) * K * nw),
+        ("mfma_gemm_wg_kernel<VhsProb> (HS potential, packed symmetric columns)", L.K_VHS, wt["k_vhs_generic"]),
         # force bias: both spins of an RHF-type trial contract with the same half-rotated Cholesky block, so the library
         # contracts Ghalf_a + Ghalf_b once (distributivity: half the flops of the two-spin contraction the reference
         # does, SURVEY 8d: 4 K (Na + Nb) M); the executed count is reported
-        ("mfma_gemm_wg_kernel<ForceBiasProb> (force bias)", L.K_FORCE_BIAS,
-         4.0 * K * (N if fb_same_spin_block else nt) * M * nw),
+        ("mfma_gemm_wg_kernel<ForceBiasProb> (force bias)", L.K_FORCE_BIAS, wt["force_bias_generic_impl"]),
     ]
     rows = []
-    for name, kind, flops in kernels:
+    for name, kind, (_bound, flops, flops_real, _note) in kernels:
         live = kind in traced
         ms = traced[kind] if live else dev.kernel_trace_get(kind)
         if len(ms) == 0:
@@ -750,6 +854,12 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         if issued > 0:
             extra["issued_flops_per_launch"] = issued
             extra["frac_issued"] = issued / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
+        if flops_real is not None and flops_real != flops:
+            # SURVEY 8d prices the two B phi products as complex by complex; BH1 is real in this run (real trial, real L_n) and
+            # the kernel multiplies it as such: `frac` counts 4 flops per MAC there, frac_survey keeps SURVEY's count
+            extra["flops_per_launch_survey"] = flops
+            extra["frac_survey"] = flops / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
+            flops = flops_real
         rows.append({"kernel": name, "launches": int(len(ms)), "avg_ms": avg, **extra,
                      "measured": (("timed regions, every %d-th launch" % trace_stride if kind == L.K_PROPAGATOR
                                    else "timed regions") if live
@@ -765,17 +875,44 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     dom = max(rows, key=lambda r: r["ms_per_step"])
     if not dom["measured"].startswith("timed region"):
         raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
-    traffic = None
-    traffic_source = None
-    tfile = next((os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
-                                                              "r01_pmc_traffic.json")
-                  if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
-    if tfile:
-        traffic_source = "%s: rocprofv3 --pmc passes of this command (not collected in this run)" % os.path.relpath(tfile, ROOT)
-        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        with open(tfile) as f:
-            traffic = json.load(f).get(dom["kernel"].split(" ")[0], {}).get("traffic_bytes_per_launch")
+    for r in rows:
+        if not (r["frac"] <= 1.0 and r.get("frac_issued", 0.0) <= 1.0):
+            raise RuntimeError("kernel %r priced above the peak (frac %.3f, issued %.3f): the timed launch cannot be doing the "
+                               "counted work" % (r["kernel"], r["frac"], r.get("frac_issued", 0.0)))
+    # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    traffic_table, traffic_source = committed_traffic("C3")
+    traffic = traffic_table.get(dom["kernel"].split(" ")[0])
+    if traffic is None:
+        traffic_source = None
 
+    # Device-timed cost of the exchange steps (what the strong-scaling leg pays): two more blocks under
+    # afq_launch_trace (an event pair around every launch, on the library's stream), every launch that belongs to a
+    # population-control event or to the block reduction, averaged per event, on every rank.  A kernel that waits for a
+    # peer's flag (the plan kernel on the window collectives, the unpack kernel) is timed WITH that wait.
+    state["phase"] = "exchange-step timing"
+    pc_steps = 2 * NSTEPS_BLOCK
+    dev.launch_trace(True)
+    afqmc.run_batched(pc_steps, first_step=first + extra_steps, eshift=eshift)
+    dev.sync()
+    dev.launch_trace(False)
+    ltrace = dev.launch_trace_get()
+    pc_names = ("comm_prep_kernel", "ncclAllGather", "comb_plan_global_kernel", "comb_plan_kernel", "clone_kernel",
+                "comm_pack_kernel<true>", "ncclSend/Recv", "comm_pack_kernel<false>", "reset_kernel")
+    red_names = ("ncclAllReduce", "est_put_kernel", "est_sum_kernel")
+    n_events, n_blocks = pc_steps // NPOP, pc_steps // NSTEPS_BLOCK
+    pc_us = {k: 1e3 * ms / n_events for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in pc_names)}
+    red_us = {k: 1e3 * ms / n_blocks for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in red_names)}
+    exchange_timing = {"per_popcontrol_event_us": pc_us, "popcontrol_event_us": sum(pc_us.values()),
+                       "per_block_reduction_us": red_us, "block_reduction_us": sum(red_us.values()),
+                       "ms_per_step_share": (sum(pc_us.values()) / NPOP + sum(red_us.values()) / NSTEPS_BLOCK) * 1e-3,
+                       "measured": "extra pass of %d steps under afq_launch_trace after the timed regions; device time of the "
+                                   "launches of one comb event (every %d steps) / one block reduction (every %d steps), "
+                                   "waits for peers' flags included" % (pc_steps, NPOP, NSTEPS_BLOCK)}
+    if comm is not None:
+        tot = numpy.zeros(2 * world)
+        comm.Allgather(numpy.array([exchange_timing["popcontrol_event_us"], exchange_timing["block_reduction_us"]]), tot)
+        exchange_timing["popcontrol_event_us_per_rank"] = tot[0::2].tolist()
+        exchange_timing["block_reduction_us_per_rank"] = tot[1::2].tolist()
     comm_stats = dev.comm_stats() if device_comm else None
     comm_per_rank = None
     if device_comm and comm is not None:
@@ -817,10 +954,17 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
             # full slot to and from every peer on the chosen transport, all-reduce) passed on EVERY rank
             "comm_probe": ("passed on every rank (%s)" % comm_kind) if device_comm else
                           (None if world == 1 else "no device communicator: " + (comm_note or "not requested")),
+            "exchange_timing": exchange_timing,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-                         "frac_issued": dom.get("frac_issued"), "traffic": traffic,
+                         "frac_survey": dom.get("frac_survey"),
+                         "frac_issued": dom.get("frac_issued"),
+                         "frac_is": "frac: the algorithmic work this run needs (8 flops per complex MAC; the real one-body "
+                                    "propagator at 4 flops per MAC) over the time; frac_survey: SURVEY 8d's count (BH1 priced as "
+                                    "complex: 8 x 16 M^2 N per walker); frac_issued: MFMA instructions x their flops, padding "
+                                    "included, 3-multiplication products counted as 3 -- the share of the matrix pipe that is busy",
+                         "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
                          "flops_per_launch": dom["flops_per_launch"],

@@ -130,6 +130,15 @@ def release_context(system, trial):
 _scratch = {}
 
 
+def release_scratch(system):
+    """Closes the scratch handle of ``system`` (its second copy of the Hamiltonian on the device); the next
+    ``local_energy(system, ...)`` without a device builds a new one.  ``trial.calculate_energy`` -- the one call the
+    driver makes through it, at set-up -- releases it again, so a run does not carry two copies of hs_pot / rchol."""
+    ent = _scratch.pop(id(system), None)
+    if ent is not None:
+        ent[1].close()
+
+
 def scratch_device(system):
     """One-walker handle holding ``system`` for the reference's free functions that name no walker
     (``pauxy.estimators.mixed.local_energy(system, G, Ghalf)``, mixed.py:383-437): a second handle with the same
@@ -138,6 +147,8 @@ def scratch_device(system):
     ent = _scratch.get(id(system))
     if ent is not None and ent[0] is system:
         return ent[1].dev
+    if ent is not None:                 # id() of a dead system object reused by this one: the old handle is nobody's
+        _scratch.pop(id(system))[1].close()
     for ctx in list(_contexts.values()):
         if ctx.system is system:
             scratch = Context(system, ctx.trial, ctx.dev.device_id)

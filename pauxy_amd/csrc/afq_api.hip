@@ -878,10 +878,14 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     int rc = need_ready(h, true);
     if (rc) return rc;
     if (h->hirsch) AFQ_FAIL(h, AFQ_ESTATE, "discrete Hirsch propagator set: use afq_propagate_hirsch");
+    // Hubbard, continuous fields, one field per site: fields_kernel makes the fields (and draws them), the diagonal HS
+    // potential and its Taylor factors.  ONE flag decides the inline draw, the branch below and who writes the factors.
+    const bool hubbard_fused = h->vhs_diag && !h->no_fused;
+    const bool hubbard_fused_fields = hubbard_fused && h->K == h->M;
     if (xi) {
         if ((rc = k_alive(h))) return rc;
         AFQ_HIP(h, hipMemcpyAsync(h->xi, xi, sizeof(double) * (size_t)h->nw * h->K, hipMemcpyHostToDevice, h->stream));
-    } else if (k_prop_fused_supported(h) || k_ueg_fast_supported(h) || (h->vhs_diag && !h->no_fused && h->K == h->M)) {
+    } else if (k_prop_fused_supported(h) || k_ueg_fast_supported(h) || hubbard_fused_fields) {
         // nothing ahead of fields_kernel reads the fields or the alive flags on this path (the Green's function is
         // evaluated for every walker, the one-body product sits inside the fused propagator): fields_kernel draws
         // the same Philox stream itself and sets the flags
@@ -927,13 +931,13 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
         h->prop_pending = true;
         return AFQ_OK;
     }
-    if (h->vhs_diag && !h->no_fused) {
+    if (hubbard_fused) {
         // Hubbard, continuous fields: the HS potential is diagonal, exp(V) a row scaling.  The force bias reads Ghalf of
         // the un-propagated walker, so fields, potential and the scaling factors are made FIRST and the factors ride on
         // the store of the first one-body product: phi <- B [exp(V) (B phi)] in two GEMM launches, the walkers pass
         // through memory twice instead of three times (exp_diag_kernel: 537 MB of traffic at C4).
         cplx *fac = h->vhs + (size_t)h->nw * h->nv * h->M;                              // second half of the vhs buffer
-        const bool fields_make_factors = h->K == h->M;                                  // (one field per site)
+        const bool fields_make_factors = hubbard_fused_fields;                          // (one field per site)
         {
             PhaseTimer t(h, T_FB);                                                      // :133-158
             if ((rc = force_bias(h, false))) return rc;
@@ -945,6 +949,7 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
             { PhaseTimer t(h, T_VHS); if ((rc = build_vhs(h))) return rc; }             // :161
             { PhaseTimer t(h, T_EXP); if ((rc = k_exp_diag_factors(h, h->vhs, fac))) return rc; }   // :162-171
         }
+        if (h->rng_inline) AFQ_FAIL(h, AFQ_ESTATE, "internal: the inline field draw of this step was not consumed by the field kernel");
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h, fac))) return rc; }        // :251 + the row scaling
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }             // :258
         h->prop_pending = true;

@@ -107,6 +107,50 @@ struct GhalfProbT {
 
 typedef GhalfProbT<false> GhalfProb;
 
+// Hubbard, continuous fields, REAL trial, a step whose Green's function only feeds the next force bias
+// (propagation/hubbard.py:404-407 reads diag G alone): diag G_s[q] = sum_j W[q,j] phi[q,j] with W = conj(psi_s) O_s^-1 --
+// a real-by-complex M x N x N product (two multiplications per element pair where O^-1 phi^T above takes three), its
+// output never stored: every element meets phi[q,j] in the epilogue and the sums over 16 columns go to gdiag
+// (rows = sites, cols = electrons, contraction = electrons; gdiag [2 nw, ceil(N / 16), M])
+struct GdiagProbT {
+    static constexpr bool A_CPLX = true, B_CPLX = true, A_REAL = true, ROWDOT = true;
+    int batch, rows, cols, kdim;     // 2 nw, M, nmax, nmax
+    int nt, na, nb, ld, M;
+    const cplx *psic;                // conj(psi) [M, nt], imaginary parts exactly zero
+    const cplx *Oinv;                // [2 nw, ld * ld]
+    const cplx *phi;                 // [nw, M, nt]
+    cplx *gdiag;                     // [2 nw, nparts, M]
+    int nparts;
+    const cplx *zero;
+    __device__ bool active(int) const { return true; }
+    __device__ cplx loadA(int, int, int) const { return cmake(0, 0); }
+    __device__ cplx loadB(int, int, int) const { return cmake(0, 0); }
+    __device__ const cplx *ptrA(int b, int row, int k) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return k < ns ? psic + (long)row * nt + (s ? na : 0) + k : zero;
+    }
+    __device__ const cplx *ptrB(int b, int k, int col) const {
+        const int ns = (b & 1) ? nb : na;
+        return (k < ns && col < ns) ? Oinv + (long)b * ld * ld + (long)k * ld + col : zero;
+    }
+    static constexpr bool INCR = true;       // incremental refill of the ring engine
+    __device__ int klimit(int b) const { return (b & 1) ? nb : na; }
+    __device__ const cplx *baseA(int b, int row) const { return psic + (long)row * nt + ((b & 1) ? na : 0); }
+    __device__ const cplx *baseB(int b, int col) const { return Oinv + (long)b * ld * ld + col; }
+    __device__ long kstepA() const { return 1; }
+    __device__ long kstepB(int) const { return ld; }
+    __device__ bool rowok(int, int) const { return true; }
+    __device__ bool colok(int b, int col) const { return col < ((b & 1) ? nb : na); }
+    __device__ cplx dot_operand(int b, int row, int col) const {
+        const int s = b & 1, ns = s ? nb : na;
+        return col < ns ? phi[((long)(b >> 1) * M + row) * nt + (s ? na : 0) + col] : cmake(0.0, 0.0);
+    }
+    __device__ void store_dot(int b, int row, int tile, double re, double im) const {
+        gdiag[((long)b * nparts + tile) * M + row] = cmake(re, im);
+    }
+    __device__ void store(int, int, int, double, double) const {}
+};
+
 // ------------------------------------------------------------------ 2. register-resident Gauss-Jordan
 struct GjArgs {
     int na, nb, ld, write_inverse;
@@ -114,6 +158,7 @@ struct GjArgs {
     cplx *detm;                      // [2 nw] mantissa of det O_s
     int *dete;                       // [2 nw] binary exponent
     const int *only = nullptr;       // when set: only the matrices with a non-zero entry are processed
+    unsigned long long *nflagged = nullptr;   // ... and counted here (afq_counters [2])
     unsigned long long *ts = nullptr;   // tuning builds (AFQ_GJ_TS): s_memtime stamps of work-group 0, [wave][block step][point]
     int dbg = 0;                     // tuning builds: timing ablations of gj_mfma_kernel (WRONG results): 1 no inversion of the
                                      // pivot tile, 2 no rank-16 update of the register tiles, 4 none of the diagonal tiles,
@@ -147,7 +192,10 @@ __device__ inline unsigned wave_max_u32(unsigned v) {
 // unused rows (ties -> lowest row), which differs from LAPACK's choice only in exact-tie/rounding
 // cases; determinant and inverse do not depend on the pivot order beyond rounding.
 __global__ __launch_bounds__(512) void gj_big_kernel(GjArgs a) {
-    if (a.only && !a.only[blockIdx.x]) return;           // (second pass behind the blocked kernel: flagged matrices only)
+    if (a.only) {                                        // (second pass behind the blocked kernel: flagged matrices only)
+        if (!a.only[blockIdx.x]) return;
+        if (threadIdx.x == 0 && a.nflagged) atomicAdd(a.nflagged, 1ull);
+    }
     __shared__ cplx colk[2][GJ_N], rowk[2][GJ_N], piv[GJ_N];
     __shared__ int prow[GJ_N], invp[GJ_N], s_par;
     __shared__ cplx stage[16][GJ_N];
@@ -772,7 +820,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
         if (afq_knob("AFQ_OVLP_CFG")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else
 #endif
-        if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+        if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+        else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         return AFQ_OK;
     };
@@ -820,7 +869,9 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
             }
 #endif
             a.only = h->gj_flag;                                      // (work-groups of unflagged matrices return at once)
-            AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+            a.nflagged = h->counters ? h->counters + 2 : nullptr;
+            afq_note_launch(h, "gj_big_kernel (fallback pass)");      // (its own name in launch traces: priced by the matrices it processes)
+            hipLaunchKernelGGL(gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
         } else {
             AFQ_LAUNCH(h, gj_big_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
         }
@@ -846,21 +897,48 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
             if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else
 #endif
-            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
             return AFQ_OK;
         };
         // Hubbard, the walkers' own Ghalf, shared single-determinant trial: the diagonal of G comes along
         const bool want_diag = h->kind == AFQ_SYS_HUBBARD && ghalf == h->ghalf && h->ndet == 1 && h->psi_stride == 0 && h->psicT;
         if (want_diag) {
-            // a wave block covers 16 TM rows: 32 with the 2 x 2 waves of 2 x 2 tiles
-            const int parts = afq_knob("AFQ_GHALF_CFG") ? (nmax + 15) / 16 : (nmax + 31) / 32;
-            if (!h->gdiag || h->gdiag_parts != parts) {
-                if (h->gdiag) hipFree(h->gdiag);
-                h->gdiag = nullptr;
-                AFQ_HIP(h, hipMalloc(&h->gdiag, sizeof(cplx) * (size_t)nb2 * parts * h->M));
-                h->gdiag_parts = parts;
+            // partial sums per row block of Ghalf (a wave block covers 16 TM rows: 32 with the 2 x 2 waves of 2 x 2 tiles) or,
+            // from the real-trial product below, per 16 columns of W: the buffer holds the larger count, gdiag_parts is what
+            // the last writer used
+            const int parts16 = (nmax + 15) / 16;
+            if (!h->gdiag) AFQ_HIP(h, hipMalloc(&h->gdiag, sizeof(cplx) * (size_t)nb2 * parts16 * h->M));
+            if (h->ghalf_skip_store && h->psi_real && !afq_knob("AFQ_NO_GDIAG_REAL")) {
+                // only diag G is wanted and the trial is real: W = conj(psi) O^-1 (real by complex), rowdot with phi
+                GdiagProbT p;
+                p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
+                p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax; p.M = h->M;
+                p.psic = h->psic; p.Oinv = h->big_ws; p.phi = h->phi; p.gdiag = h->gdiag; p.nparts = parts16;
+                p.zero = (const cplx *)h->zero_page;
+                h->gdiag_parts = parts16;
+                h->ghalf_skipped = true;
+#ifdef AFQ_TUNING
+                const int gc = afq_knob("AFQ_GDIAG_CFG") ? atoi(afq_knob("AFQ_GDIAG_CFG")) : 0;
+                if (gc == 1) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 2) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 3) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+                else if (gc == 4) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+                else if (gc == 5) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 2, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 6) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+                else if (gc == 8) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GdiagProbT, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 9) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GdiagProbT, MAP_BATCH_XCD_ROWS, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 10) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 2, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 11) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 8, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (gc == 7) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+                else
+#endif
+                AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                h->gdiag_version = h->ghalf_version;
+                return AFQ_OK;
             }
+            h->gdiag_parts = afq_knob("AFQ_GHALF_CFG") ? parts16 : (nmax + 31) / 32;
             const int rc = run(GhalfProbT<true>());
             if (rc) return rc;
             h->gdiag_version = h->ghalf_version;
@@ -1325,7 +1403,8 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         }
         {
@@ -1346,7 +1425,8 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         }
     }

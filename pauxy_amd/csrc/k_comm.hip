@@ -30,8 +30,10 @@
 // number (monotonic), a waiting kernel gives up after the wait budget (afq_comm_set_timeout, 300 s by default) and raises the sticky error scal[6] (AFQ_ECOMM at the next
 // host synchronisation) instead of hanging the device.
 // More pairs between two ranks than `cap` slots raise the sticky flag scal[3] (AFQ_EOVERFLOW at the next
-// afq_estimates_get); scal[4] keeps the largest run seen.  The window transport sizes cap = nw (a rank owns nw
-// walkers: it can neither send nor receive more), so it cannot overflow.
+// afq_estimates_get); scal[4] keeps the largest run seen.  Up to 512 walkers per rank the window transport sizes
+// cap = nw (a rank owns nw walkers: it can neither send nor receive more) and cannot overflow; above, cap =
+// max(512, nw / 4) slots per peer (default_cap) with the overflow flag as the guard, and the driver grows the windows at
+// block boundaries when the largest transfer seen comes near the capacity (Walkers.tune_exchange_capacity).
 //
 // Three communicators over the same kernels:
 //   RCCL   (afq_comm_init: one process per GPU) -- ncclAllGather / ncclAllReduce for the two collectives, windows
@@ -824,12 +826,27 @@ static void clear_comm_scalars(afq_handle *h) {
     if (h->scal) { (void)hipMemset(h->scal + 3, 0, 6 * sizeof(double)); h->scal_cache_valid = false; }
 }
 
-static double g_wait_seconds_host = WAIT_SECONDS_DEFAULT;    // what the device symbol currently holds (per process)
-static int set_wait_budget(double seconds) {
+// g_wait_ticks is one symbol PER DEVICE (one code object instance each): the host mirror is kept per device too, so that
+// with several GPUs in one process (afq_comm_init_local) a probe restores the budget of the device it shortened, and a
+// budget set through one handle is never reported for -- or "restored" onto -- another device
+static double g_wait_seconds_host[AFQ_MAX_DEVICES];
+static bool g_wait_seconds_known[AFQ_MAX_DEVICES];
+static int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= AFQ_MAX_DEVICES) d = 0;
+    return d;
+}
+static double wait_budget_of_current_device() {
+    const int d = current_device_slot();
+    return g_wait_seconds_known[d] ? g_wait_seconds_host[d] : WAIT_SECONDS_DEFAULT;
+}
+static int set_wait_budget(double seconds) {          // for the CURRENT device (callers hipSetDevice(h->device) first)
     if (!(seconds > 0.0)) return AFQ_EINVAL;
-    g_wait_seconds_host = seconds;
     const unsigned long long ticks = (unsigned long long)std::min(seconds * 1e8, 9.0e17);
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks)) == hipSuccess ? AFQ_OK : AFQ_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks)) != hipSuccess) return AFQ_EHIP;
+    const int d = current_device_slot();
+    g_wait_seconds_host[d] = seconds; g_wait_seconds_known[d] = true;
+    return AFQ_OK;
 }
 
 void k_comm_destroy(afq_handle *h) {
@@ -1182,7 +1199,7 @@ int afq_comm_probe(afq_handle *h, int64_t *mismatch_out) {
     // the step loop (three candidates x 300 s would outlast a benchmark's time limit).  Restored on every way out.
     struct ProbeBudget {
         double keep; afq_handle *h;
-        ProbeBudget(afq_handle *h_) : keep(g_wait_seconds_host), h(h_) {
+        ProbeBudget(afq_handle *h_) : keep(wait_budget_of_current_device()), h(h_) {
             if (keep > 20.0) { hipStreamSynchronize(h->stream); set_wait_budget(20.0); }
         }
         ~ProbeBudget() { if (keep > 20.0) { hipStreamSynchronize(h->stream); set_wait_budget(keep); } }

@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         }
     };
 
-    // Measured negative result (round 2, profiles/r02_pmc_prop_fused_t4_vs_t16.txt): the same products on
+    // Measured negative result (round 2, profiles/archive/r02_pmc_prop_fused_t4_vs_t16.txt): the same products on
     // v_mfma_f64_4x4x4 (16 x 4 and 4 x 16 units, 79 % of the MFMA cycles of the padded 16x16x4 grid) are CORRECT but
     // not faster -- 183 us against 177 us: MFMA-busy cycles drop 18 %, wave-parked cycles (s_waitcnt / barrier) rise
     // from 23 % to 35 % of the wave cycles, 1.6 x the instructions, and the broadcast read of a 4-column group of T

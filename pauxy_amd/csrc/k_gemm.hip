@@ -478,6 +478,8 @@ int k_force_bias_msd_gbar(afq_handle *h) {
         else if (gcfg == 5) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
         else if (gcfg == 6) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else if (gcfg == 7) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 9) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
+        else if (gcfg == 10) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (gcfg == 8) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 8, GbarSymProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
         else
 #endif
@@ -738,10 +740,16 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                         else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                     }
                     // round 4: 64 x 64 tiles, four compute + four loader waves (STAG = 3; see k_vhs_generic): C5 sizes 689 -> 627 us
+                    else if (afq_knob("AFQ_TAYLOR_WPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_WPE2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_S2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_S2C")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_XCD")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
-                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+                    // round 5: the same 64 x 64 tiles from four waves that refill the ring themselves inside the half-chunk
+                    // pipelined loop (STAG = 2): 627-633 -> 612-616 us (C5 sizes).  Forcing two work-groups per CU
+                    // (128 VGPRs, WPE = 4) spills 65-98 registers into the chunk loop: 2102 us
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                 }
                 continue;
             }

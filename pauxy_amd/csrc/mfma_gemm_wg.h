@@ -99,8 +99,11 @@ template <class P> struct gemm_incr_types<P, true> {
 
 // KC: k-chunks of 8 per ring slot / barrier (1 or 2).  With KC = 2 the fragments of the second half are
 // read from LDS while the MFMAs of the first half run, and the barrier cost is paid once per 16 indices.
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
-__global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_wg_kernel(P p, const void *zero16) {
+// WPE: waves per SIMD the register allocation must leave room for (amdgpu_waves_per_eu).  A work-group of 4 + 4 or 8 waves puts
+// two waves on every SIMD; with WPE = 4 (at most 128 VGPRs) a second work-group is co-resident on the CU, whose MFMAs run
+// while the first sits at its chunk barrier or in its epilogue.
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0, int WPE = 1>
+__global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_gemm_wg_kernel(P p, const void *zero16) {
 #ifdef AFQ_TUNING
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1)) void mfma_gemm_w
     // fragment and chunk in flight -- and only ONE chunk of latency tolerance (the loads of chunk c + D are waited for one
     // iteration later, in program order ahead of half the MFMAs).  MEASURED NEGATIVE (round 3, VhsProb at C3, tuning knob
     // AFQ_VHS_RREG): correct, 67.9 us against 61.5 us with the DMA ring; 63 % of that kernel's L2 accesses miss
-    // (TCC_MISS / (HIT + MISS), profiles/r03_pmc_sq_tcp_bench_kernels.txt), so the three chunks the DMA ring keeps in
+    // (TCC_MISS / (HIT + MISS), profiles/archive/r03_pmc_sq_tcp_bench_kernels.txt), so the three chunks the DMA ring keeps in
     // flight matter more than the issue slots it costs.  Kept for tuning builds only.
     if constexpr (STAG == 4) {
         static_assert(KC == 1 && gemm_incr<P>::value, "register-staged refill: incremental problems, one sub-chunk per slot");
@@ -665,7 +668,7 @@ inline double mfma_gemm_wg_issued_flops(const P &p, KLen klen) {
     return f;
 }
 
-template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0>
+template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0, int WPE = 1>
 inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void *zero16) {
     constexpr int RT = WM * TM, CT = WN * TN;
     constexpr int NA = RT * 2, NB = P::B_CPLX ? CT * 2 : CT;
@@ -681,7 +684,7 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
     const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
     static_assert(STAG != 3 || WM * WN <= 8, "compute + loader waves must fit one work-group");
-    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC, STAG>;
+    auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC, STAG, WPE>;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};   // one per template instantiation and device: set the cap once
     {
         hipError_t e = afq_raise_lds((const void *)kern, lds, lds_set);

@@ -117,7 +117,11 @@ class Mixed(object):
         everywhere = getattr(comm, 'reduce_is_allreduce', False)
         if comm.rank == 0 or everywhere:
             gs[ns.eproj] = gs[ns.enumer]
-            gs[ns.eproj:ns.e2b + 1] = gs[ns.eproj:ns.e2b + 1] / gs[ns.edenom]
+            # A block without an energy evaluation (energy_eval_freq larger than the block) has edenom = 0: the reference
+            # divides all the same (mixed.py:268: a RuntimeWarning and a NaN row).  The row is the same NaN here -- the
+            # file stays comparable with the reference's -- without the warning
+            with numpy.errstate(divide='ignore', invalid='ignore'):
+                gs[ns.eproj:ns.e2b + 1] = gs[ns.eproj:ns.e2b + 1] / gs[ns.edenom]
             gs[ns.ehyb] /= gs[ns.weight]
             gs[ns.ovlp] /= gs[ns.weight]
             eshift = numpy.array([gs[ns.ehyb], gs[ns.eproj]])

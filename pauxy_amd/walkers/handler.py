@@ -491,6 +491,19 @@ class Walkers(object):
             except L.AfqError:
                 pass
 
+        # Fault injection for the bring-up tests (tests/test_gpu_bench.py): AFQ_COMM_FAULT="rccl:avail:3,ipc:probe:3" makes
+        # rank 3 report that it cannot load librccl, and fail the probe of the IPC candidate.  Stages: avail (rccl /
+        # sendrecv only), init, probe.  The injected failure is raised where a real one would be -- AFTER the collective
+        # calls of the stage, so the other ranks are never left inside one.
+        faults = set()
+        for item in os.environ.get('AFQ_COMM_FAULT', '').split(','):
+            part = item.strip().split(':')
+            if len(part) == 3 and part[2].lstrip('-').isdigit():
+                faults.add((part[0], part[1], int(part[2])))
+
+        def fault(kind, stage):
+            return 'injected fault (AFQ_COMM_FAULT %s:%s:%d)' % (kind, stage, comm.rank) if (kind, stage, comm.rank) in faults else ''
+
         candidates = [want] if want in ('rccl', 'sendrecv', 'ipc') else ['rccl', 'sendrecv', 'ipc']
         errors = []
         rccl_up = rccl_failed = False
@@ -502,7 +515,7 @@ class Walkers(object):
                 if not rccl_up:
                     rccl_failed = True            # until ncclCommInitRank has succeeded everywhere
                     # 1. can every rank load librccl?  (local question, then agreement)
-                    if not agree(dev.comm_available()):
+                    if not agree(dev.comm_available() and not fault(kind, 'avail')):
                         errors.append(kind + ': librccl is not loadable on every rank')
                         continue
                     # 2. rank 0's id to everybody; ncclCommInitRank is a blocking collective, entered by all or none
@@ -518,6 +531,7 @@ class Walkers(object):
                         dev.comm_init(uid, comm.rank, comm.size)
                     except L.AfqError as e:
                         err = str(e)
+                    err = err or fault(kind, 'init')
                     if not agree(not err):
                         teardown()
                         errors.append(kind + ': ' + (err or 'ncclCommInitRank failed on another rank'))
@@ -535,6 +549,7 @@ class Walkers(object):
                     dev.comm_init_ipc(comm.rank, comm.size, allgather_bytes)
                 except L.AfqError as e:
                     err = str(e)
+                err = err or fault(kind, 'init')
             if not agree(not err):
                 errors.append(kind + ': ' + (err or 'set-up failed on another rank'))
                 if kind == 'ipc':
@@ -547,6 +562,7 @@ class Walkers(object):
                     err = 'peer windows could not be exported / mapped on every rank'     # (agreed inside the library)
             except L.AfqError as e:
                 err = str(e)
+            err = err or fault(kind, 'probe')
             if agree(not err):
                 self.device_comm_kind = kind
                 return True, '; '.join(errors)
@@ -581,9 +597,10 @@ class Walkers(object):
         self.dev.set_log_shift(True, self.log_shift, self.detR_shift)
 
     def tune_exchange_capacity(self):
-        """Device communicator with the fixed-size ncclSend / ncclRecv transport only (the window transport moves live
-        slots and keeps the capacity that cannot overflow): size the per-peer exchange slots from the largest transfer
-        seen so far -- four times that + 8, at least 32, at most nw.  The capacity STARTS at nw (what a rank owns: no
+        """Device communicator.  Window transport (live slots only): grow the windows when the largest transfer seen
+        reaches half their capacity (they start at nw slots per peer up to 512 walkers per rank -- no overflow possible --
+        and at max(512, nw / 4) above).  Fixed-size ncclSend / ncclRecv transport: size the per-peer exchange slots from
+        the largest transfer seen so far -- four times that + 8, at least 32, at most nw.  The capacity STARTS at nw (what a rank owns: no
         overflow before there is history) and shrinks only after 20 events (every slot of the capacity crosses the link at
         every event on this transport: nw slots of 160 KB to each of 7 peers are 290 MB per event at the bench sizes); an
         overflow aborts the run, spare slots only cost link time.  Called at block boundaries, right behind the block's host sync; every rank computes the same
@@ -592,6 +609,11 @@ class Walkers(object):
             return
         st = self.dev.comm_stats()
         if st['window']:
+            # live slots only cross the link, so spare capacity costs memory, not time: the windows never shrink, and
+            # they grow (to at most nw slots per peer, which cannot overflow) as soon as the largest transfer seen
+            # reaches half the capacity -- above 512 walkers per rank they start at max(512, nw / 4) slots
+            if st['capacity'] < self.nw and 2 * st['max_transfer'] >= st['capacity']:
+                self.dev.comm_set_capacity(min(self.nw, max(4 * st['max_transfer'] + 8, 2 * st['capacity'])))
             return
         want = min(self.nw, max(32, 4 * st['max_transfer'] + 8))
         if want > st['capacity'] or (st['events'] >= 20 and want < 0.6 * st['capacity']):

@@ -36,6 +36,12 @@ def check_line(out, n_gpus, steps, walkers_total):
     for row in out["roofline_all"]:
         assert 0.0 < row["frac_issued"] < 1.0, row["kernel"]
     assert len(out["rank_ms_per_step"]["per_rank"]) == n_gpus
+    # device-timed cost of one population-control event and one block reduction
+    et = out["exchange_timing"]
+    assert et["popcontrol_event_us"] > 0.0 and et["per_popcontrol_event_us"]
+    assert 0.0 < et["ms_per_step_share"] < out["ms_per_step"]
+    if n_gpus > 1:
+        assert len(et["popcontrol_event_us_per_rank"]) == n_gpus
 
 
 def test_bench_one_gpu_short_region_is_repeated():
@@ -60,3 +66,31 @@ def test_bench_weak_and_strong_lines():
     assert [o["scaling"] for o in outs] == ["weak", "strong"]
     check_line(outs[0], 2, 10, 512)
     check_line(outs[1], 2, 10, 2048)
+
+
+def test_bench_eight_ranks_print_their_line_when_one_rank_cannot_bring_rccl_up():
+    """`python bench.py --gpus 8` on the whole candidate chain (walkers/handler.py:225-338 on the device, with agreed
+    fall-backs) when rank 3 of 8 reports that it cannot load librccl (AFQ_COMM_FAULT): nobody enters ncclCommInitRank,
+    every rank moves on to the peer-window communicator, the probe passes and rank 0 prints the line -- saying which
+    communicator ran and why the preferred one was dropped.  (The eight ranks share this box's one GPU over gloo.)"""
+    (out,) = run_bench(["--gpus", "8", "--steps", "10", "--warmup", "10", "--walkers-per-gpu", "64"],
+                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "auto", "AFQ_COMM_FAULT": "rccl:avail:3"})
+    check_line(out, 8, 10, 512)
+    assert out["population_control"].startswith("device comb over mapped peer windows")
+    assert "fell through: rccl: librccl is not loadable on every rank" in out["population_control"]
+    assert out["comm_probe"].startswith("passed on every rank (ipc)")
+    assert out["comm_stats_per_rank"]["error"] == [0] * 8 and out["comm_stats_per_rank"]["overflow"] == [0] * 8
+    assert "comb_plan_global_kernel" in out["exchange_timing"]["per_popcontrol_event_us"]
+
+
+def test_bench_eight_ranks_reach_the_host_path_when_every_candidate_fails_on_one_rank():
+    """... and when rank 3 also fails the probe of the peer-window communicator: every rank tears it down, the population
+    control goes through the host (pop_control_distributed), rank 0 still prints its line with the reasons."""
+    (out,) = run_bench(["--gpus", "8", "--steps", "10", "--warmup", "10", "--walkers-per-gpu", "64"],
+                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "auto",
+                        "AFQ_COMM_FAULT": "rccl:avail:3,ipc:probe:3"})
+    check_line(out, 8, 10, 512)
+    assert out["population_control"].startswith("host-mediated")
+    assert "rccl: librccl is not loadable on every rank" in out["population_control"]
+    assert "ipc: probe failed on another rank" in out["population_control"] or "injected fault" in out["population_control"]
+    assert out["comm_stats"] is None and out["comm_probe"].startswith("no device communicator")

@@ -489,12 +489,21 @@ def test_blocked_gauss_jordan_hands_badly_placed_pivots_to_the_step_by_step_kern
         phi[4][:, o:o + n] = with_overlap(numpy.eye(n)[::-1] + noise, psi_s)               # (1) with noise in the tile
     dev = make_device(model, nw)
     dev.set(L.F_PHI, phi)
+    dev.counters(reset=True)
     ot = dev.greens(want_G=False)
     gh = dev.get(L.F_GHALF)
+    # afq_counters [2]: matrices the fallback pass actually processed (bench.py prices that launch by it): the
+    # constructed walkers with more than 32 electrons in the spin, and none of the two ordinary ones
+    flagged = int(dev.counters()[2])
+    assert 1 <= flagged <= 8, flagged
     for w in range(nw):
         det, ghalf_ref, _ = ref.greens_function(phi[w], model.psi, na, nb)
         assert abs(ot[w] - det) <= 1e-9 * abs(det), (w, ot[w], det)
         close(gh[w].reshape(nt, M), numpy.concatenate(ghalf_ref), 1e-8)
+    dev.set(L.F_PHI, numpy.array([phi[0]] * nw))
+    dev.counters(reset=True)
+    dev.greens(want_G=False)
+    assert int(dev.counters()[2]) == 0
     dev.close()
 
 

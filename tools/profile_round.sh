@@ -21,6 +21,6 @@ run_stats bench_c3 python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline
 for c in C1 C2 C4 C5sd C5; do run_stats cfg_$c python3 bench.py --config $c --no-cpu-baseline; done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   run_pmc bench_c3 $ctr python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
-  run_pmc cfg_C2 $ctr python3 bench.py --config C2 --no-cpu-baseline
+  for c in C2 C4 C5; do run_pmc cfg_$c $ctr python3 bench.py --config $c --no-cpu-baseline --repeats 1; done
 done
 ls $out

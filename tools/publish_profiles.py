@@ -51,26 +51,39 @@ def main():
             open(os.path.join(prof, rnd + '_bench_c3.json'), 'w').write(ln)
     with open(os.path.join(prof, rnd + '_configs_roofline.json'), 'w') as out:
         subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'roofline_configs.py'), src], stdout=out)
-    # ---- traffic per launch of the bench kernels
-    pmc = {}
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-        for ln in open(os.path.join(src, 'bench_c3_pmc_%s.txt' % ctr)):
-            m = re.match(r'(.*\S)\s+%s\s+n=\s*\d+ mean=(\S+)' % ctr, ln)
-            if m:
-                pmc.setdefault(m.group(1)[:60], {})[ctr] = float(m.group(2))
+    # ---- traffic per launch of the bench kernels, and of the kernels of the other configurations
+    def traffic_of(name):
+        pmc = {}
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            path = os.path.join(src, '%s_pmc_%s.txt' % (name, ctr))
+            if not os.path.exists(path):
+                return {}
+            for ln in open(path):
+                m = re.match(r'(.*\S)\s+%s\s+n=\s*\d+ mean=(\S+)' % ctr, ln)
+                if m:
+                    pmc.setdefault(m.group(1)[:60], {})[ctr] = float(m.group(2))
+        out = {}
+        stats = os.path.join(src, '%s_kernel_stats.csv' % name)
+        if not os.path.exists(stats):
+            return {}
+        for r in csv.DictReader(open(stats)):
+            t = pmc.get(r['Name'][:60])
+            if t and 'FETCH_SIZE' in t and 'WRITE_SIZE' in t and not r['Name'].startswith('__amd'):
+                out.setdefault(short(r['Name']), {
+                    "traffic_bytes_per_launch": (2.0 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024.0,
+                    "avg_us_in_that_run": float(r['AverageNs']) / 1e3})
+        return out
     tag = os.path.basename(os.path.normpath(src))
     traffic = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 "
-                  "--no-cpu-baseline (tools/profile_round.sh %s); per-kernel means in profiles/%s_bench_c3_pmc_FETCH_SIZE.txt / "
+                  "--no-cpu-baseline, and -- python3 bench.py --config C2 | C4 | C5 --no-cpu-baseline --repeats 1 under "
+                  "'configs' (tools/profile_round.sh %s); per-kernel means in profiles/%s_*_pmc_FETCH_SIZE.txt / "
                   "_WRITE_SIZE.txt" % (tag, rnd),
         "note": "FETCH_SIZE / WRITE_SIZE are KB of L2 memory-side requests (Infinity-Cache hits included); FETCH_SIZE is doubled "
-                "on gfx950 as MI355X_MICROARCH.md prescribes"}
-    for r in csv.DictReader(open(os.path.join(src, 'bench_c3_kernel_stats.csv'))):
-        t = pmc.get(r['Name'][:60])
-        if t and 'FETCH_SIZE' in t and 'WRITE_SIZE' in t and not r['Name'].startswith('__amd'):
-            traffic.setdefault(short(r['Name']), {
-                "traffic_bytes_per_launch": (2.0 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024.0,
-                "avg_us_in_that_run": float(r['AverageNs']) / 1e3})
+                "on gfx950 as MI355X_MICROARCH.md prescribes.  One name = one kernel template: a mean over every launch of "
+                "that template in the run (the per-determinant and the averaged-G force-bias contractions of C5 share one)"}
+    traffic.update(traffic_of('bench_c3'))
+    traffic["configs"] = {c: traffic_of('cfg_' + c) for c in ('C2', 'C4', 'C5') if traffic_of('cfg_' + c)}
     json.dump(traffic, open(os.path.join(prof, rnd + '_pmc_traffic.json'), 'w'), indent=1)
     print("published", src, "->", prof, "as", rnd)
 
