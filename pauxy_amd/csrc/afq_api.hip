@@ -826,7 +826,7 @@ static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf) {
         if ((rc = with_ghalf ? k_greens(h, dd) : k_overlap(h, dd))) { select_det(h, 0); return rc; }
     }
     select_det(h, 0);
-    return k_msd_combine(h, det_out);
+    return k_msd_combine(h, det_out, with_ghalf);       // (multi_det.py:209,218 skip; calc_overlap :135-162 does not)
 }
 
 static int force_bias(afq_handle *h, bool with_xbar = true) {

@@ -422,7 +422,7 @@ int k_bp_accumulate(afq_handle *h, int restore, int with_energy);
 int k_bp_reset(afq_handle *h, bool first);
 int k_bp_hirsch_step(afq_handle *h, int i);                 // B(x)^H of the i-th most recent discrete configuration
 int k_xbar_fields(afq_handle *h, cplx *hubbard_factors = nullptr);   // + the Hubbard row-scaling factors (continuous fields)
-int k_msd_combine(afq_handle *h, cplx *det_out);          // detd -> detw, det_out = sum_d detw
+int k_msd_combine(afq_handle *h, cplx *det_out, bool skip_small);          // detd -> detw, det_out = sum_d detw
 int k_msd_energy_combine(afq_handle *h);                   // energy_all, detw -> energy                                  // vbias / G -> xbar (unclipped), system dispatch
 int k_update_weight(afq_handle *h, cplx eshift);
 int k_reortho(afq_handle *h, cplx *keep = nullptr, bool *keep_done = nullptr);

@@ -368,8 +368,10 @@ __global__ void msd_scale_ghalf_kernel(const cplx *__restrict__ ghalf_all, const
     if (e >= per) return;
     cplx tot = cmake(0.0, 0.0);
     for (int dd = 0; dd < ndet; ++dd) tot = cadd(tot, detw[(long)w * ndet + dd]);
-    const cplx sc = cdiv(detw[(long)w * ndet + d], tot);
-    gs[(long)w * wstride + (long)d * per + e] = cmul(sc, ghalf_all[((long)d * nw + w) * per + e]);
+    const cplx wd = detw[(long)w * ndet + d];
+    // (a skipped determinant -- weight exactly 0, msd_combine_kernel -- contributes zeros, whatever its Ghalf holds)
+    const bool dead = wd.x == 0.0 && wd.y == 0.0;
+    gs[(long)w * wstride + (long)d * per + e] = dead ? cmake(0.0, 0.0) : cmul(cdiv(wd, tot), ghalf_all[((long)d * nw + w) * per + e]);
 }
 
 // out[c][n] = in[n][c]: the packed hs_pot^T [K, ld_in] -> [P, ld_out]

@@ -717,10 +717,11 @@ __device__ inline cplx xbar_value(const XbarArgs &a, int w, int n) {
                 // vbias_n = sum_d w_d <V_n G_d> / sum_d w_d; <V_n G_d> = rchol_d^T vec(Ghalf_d)
                 cplx num = cmake(0.0, 0.0), den = cmake(0.0, 0.0);
                 for (int d = 0; d < a.ndet; ++d) {
+                    const cplx wd = a.detw[(long)w * a.ndet + d];
+                    if (wd.x == 0.0 && wd.y == 0.0) continue;     // skipped determinant (msd_combine_kernel): its Ghalf may hold anything
                     cplx x = cmake(0.0, 0.0);
                     const cplx *vb = a.vbias + (long)d * a.det_stride;
                     for (int b = 0; b < 2 * a.nsplit; ++b) x = cadd(x, vb[((long)b * a.nw + w) * a.K + n]);
-                    const cplx wd = a.detw[(long)w * a.ndet + d];
                     cfma(num, wd, x);
                     den = cadd(den, wd);
                 }
@@ -805,22 +806,30 @@ int k_xbar(afq_handle *h) {
 
 // --------------------------------------------------------------------------
 // multi-determinant trial: weights and weighted averages (walkers/multi_det.py:194-229,135-162)
+// skip_small (Green's function, walkers/multi_det.py:209,218): a determinant whose overlap with the walker is below 1e-16 is
+// left out -- the reference `continue`s past it, keeping whatever Gi / weight the walker object held before (zeros for a fresh
+// walker); here it gets the weight 0 and every consumer of the weights (force bias, energy) passes over it, i.e. the
+// reference's result for a fresh walker.  A singular overlap matrix may leave NaN as its determinant (0 x inf behind a zero
+// pivot): that IS a zero overlap, in the Green's function and in calc_overlap (multi_det.py:135-162, which skips nothing).
 __global__ void msd_combine_kernel(const cplx *detd, const cplx *coeffs, cplx *detw, cplx *det_out, int nw,
-                                   int ndet) {
+                                   int ndet, int skip_small) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
     cplx tot = cmake(0.0, 0.0);
     for (int d = 0; d < ndet; ++d) {
-        const cplx wd = cmul(cconj(coeffs[d]), detd[(long)d * nw + w]);
+        cplx dd = detd[(long)d * nw + w];
+        const double mag = hypot(dd.x, dd.y);
+        if (!(mag == mag) || (skip_small && mag < 1e-16)) dd = cmake(0.0, 0.0);
+        const cplx wd = cmul(cconj(coeffs[d]), dd);
         detw[(long)w * ndet + d] = wd;
         tot = cadd(tot, wd);
     }
     det_out[w] = tot;
 }
 
-int k_msd_combine(afq_handle *h, cplx *det_out) {
+int k_msd_combine(afq_handle *h, cplx *det_out, bool skip_small) {
     AFQ_LAUNCH(h, msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd, h->coeffs,
-                       h->detw, det_out, h->nw, h->ndet);
+                       h->detw, det_out, h->nw, h->ndet, skip_small ? 1 : 0);
     AFQ_POST(h);
     return AFQ_OK;
 }
@@ -833,6 +842,7 @@ __global__ void msd_energy_combine_kernel(const cplx *energy_all, const cplx *de
     cplx num[3] = {cmake(0.0, 0.0), cmake(0.0, 0.0), cmake(0.0, 0.0)}, den = cmake(0.0, 0.0);
     for (int d = 0; d < ndet; ++d) {
         const cplx wd = detw[(long)w * ndet + d];
+        if (wd.x == 0.0 && wd.y == 0.0) continue;              // skipped determinant: its energy may be anything
         for (int c = 0; c < 3; ++c) cfma(num[c], wd, energy_all[((long)d * nw + w) * 3 + c]);
         den = cadd(den, wd);
     }

@@ -101,3 +101,61 @@ def test_nomsd_many_walkers_averaged_g(golden):
     """40 walkers: the automatic choice (more than 32 walkers, cost model) and both forced algorithms agree."""
     run_steps(golden('msd_ops.npz'), 'N_', True, nw=40, fb_mode=0)
     run_steps(golden('msd_ops.npz'), 'N_', True, nw=40, fb_mode=2)
+
+
+@pytest.mark.parametrize("fb_mode,na,nb,M", [(1, 3, 3, 12), (2, 3, 3, 12), (1, 50, 50, 110), (2, 50, 50, 110)])
+def test_numerically_dead_determinant_is_skipped_like_the_reference(fb_mode, na, nb, M):
+    """walkers/multi_det.py:209,218: a determinant whose overlap with the walker is below 1e-16 is skipped by the
+    reference's Green's function -- no Gi, no weight, not in the total.  Here: a NOMSD trial of three determinants, one of
+    them EXACTLY orthogonal to some of the walkers (an orbital on a basis function those walkers do not occupy: its
+    overlap matrix has a zero row, the inverse does not exist).  Determinant weights, total overlap, force bias (both
+    algorithms) and energy against the oracle, which restates the skip (a fresh walker: zero weight, zero Gi); then one
+    full step.  calc_overlap (multi_det.py:135-162) skips nothing -- the zero overlap just adds zero."""
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.propagation import setup
+    K, dt, nw = 9, 0.005, 5
+    nt = na + nb
+    s = systems.synthetic_generic(M, K, (na, nb), seed=7)
+    t0 = trial_mod.rhf_trial_generic(s)
+    rng = numpy.random.RandomState(5)
+    dets = numpy.array([t0.psi + 0.05 * (rng.rand(M, nt) + 1j * rng.rand(M, nt)) for _ in range(3)])
+    dets[:, M - 1, :] = 0.0                                 # nobody occupies the last basis function ...
+    dets[1][:, 1] = 0.0
+    dets[1][M - 1, 1] = 1.0                                 # ... except one alpha orbital of determinant 1
+    coeffs = numpy.array([0.7 + 0.1j, 0.4 - 0.2j, 0.3 + 0.05j])
+    t = trial_mod.MultiDetTrial(s, (coeffs, dets), init=t0.psi)
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic_msd', M, na, nb, dets, BH1, mf, dt, coeffs=coeffs, hs_pot=s.hs_pot,
+                         H1=numpy.array([s.H1[0], s.H1[1]]).astype(complex), ecore=s.ecore)
+    phis = t0.psi[None] + 0.05 * (rng.rand(nw, M, nt) + 1j * rng.rand(nw, M, nt))
+    phis[:3, M - 1, :] = 0.0                                # walkers 0..2: <D_1|phi> = 0 exactly; 3, 4: ordinary
+    dev = make_device(model, nw)
+    dev.set_msd_force_bias(fb_mode)
+    dev.set(L.F_PHI, phis)
+    tot = dev.greens()
+    wts = dev.det_weights()
+    refs = [model.greens(p) for p in phis]
+    for w in range(3):
+        assert refs[w][1][1] == 0.0 and wts[w][1] == 0.0   # skipped by the oracle (as by the reference) and by the device
+    assert all(abs(refs[w][1][1]) > 0.0 for w in (3, 4))
+    close(wts, numpy.array([r[1] for r in refs]))
+    close(tot, numpy.array([r[0] for r in refs]))
+    close(dev.calc_overlap(), numpy.array([model.overlap(p) for p in phis]))
+    xbar = dev.force_bias()
+    assert numpy.all(numpy.isfinite(xbar))
+    close(xbar, numpy.array([model.force_bias(r[1], r[2]) for r in refs]))
+    dev.greens()
+    E = dev.local_energy()
+    assert numpy.all(numpy.isfinite(E))
+    close(E, numpy.array([model.local_energy(r[2], r[1]) for r in refs]), 1e-9)
+    # one full step; the propagated walkers occupy every basis function again
+    dev.set(L.F_OT, tot)
+    walkers = [ref.new_walker(model, p) for p in phis]
+    xi = rng.normal(size=(nw, K))
+    dev.propagate(xi, -0.3)
+    for w, x in zip(walkers, xi):
+        ref.propagate_walker_phaseless(model, w, x, -0.3)
+    close(dev.get(L.F_PHI), numpy.array([w['phi'] for w in walkers]), 1e-9)
+    close(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]), 1e-9)
+    close(dev.get(L.F_OT), numpy.array([w['ot'] for w in walkers]), 1e-9)
+    dev.close()

@@ -567,3 +567,66 @@ def test_dead_walkers_pass_through_the_large_one_body_products_untouched():
             close(out_phi[i], w['phi'], 1e-9)
             close(out_w[i], w['weight'], 1e-9)
         dev.close()
+
+
+def _component_errors(a, b):
+    """(normwise error, componentwise error over the significant components): real and imaginary parts are separate
+    components; one is significant when it is at least 1e-4 of the largest magnitude of the array."""
+    a, b = numpy.asarray(a, dtype=complex), numpy.asarray(b, dtype=complex)
+    scale = float(numpy.max(numpy.abs(b)))
+    norm = float(numpy.max(numpy.abs(a - b))) / scale
+    comp = 0.0
+    for part in (numpy.real, numpy.imag):
+        x, y = part(a), part(b)
+        sig = numpy.abs(y) >= 1e-4 * scale
+        if numpy.any(sig):
+            comp = max(comp, float(numpy.max(numpy.abs(x[sig] - y[sig]) / numpy.abs(y[sig]))))
+    return norm, comp
+
+
+@pytest.mark.parametrize("M,na,nb,cplx_trial", [(100, 25, 25, False), (100, 25, 25, True), (110, 50, 50, False), (110, 50, 50, True)])
+@pytest.mark.parametrize("scaling", ["re>>im", "im>>re", "real", "imaginary"])
+def test_badly_scaled_operands_through_the_three_multiplication_products(M, na, nb, cplx_trial, scaling):
+    """The complex products of the overlap / Ghalf GEMMs, the Taylor chain and the blocked Gauss-Jordan are
+    3-multiplication (Karatsuba) products: Im = (Ar + Ai)(Br + Bi) - Ar Br - Ai Bi.  Their error bound is NORMWISE
+    (~eps |A| |B|), not componentwise: a component 1e-8 of the other one is computed to 1e-8 of itself, which is 1e-16 of
+    the number.  All other tests draw Re ~ Im; here the walkers are badly scaled -- |Re| / |Im| = 1e8 and 1e-8, purely real,
+    purely imaginary -- through the Green's function (walkers/single_det.py:295-321), one propagation step
+    (continuous.py:232-262: B exp(V) B with the Taylor-6 chain) and the overlap of the propagated walker, for the one
+    work-group kernels (25 + 25 electrons, fused propagator) and the GEMM / blocked Gauss-Jordan path (50 + 50 electrons,
+    M = 110: un-fused Taylor GEMM chain), real and complex trial.  Pinned: 1e-13 NORMWISE on everything (measured on an
+    MI355X: 4e-16 ... 1e-14), and 1e-10 COMPONENTWISE on every real or imaginary part within four decades of the largest
+    number of its array (measured: up to 4e-12; a part of relative size s carries the absolute rounding error of the O(1)
+    terms it is the sum of, eps / s of itself, in the reference's LAPACK / BLAS arithmetic as much as here -- with six decades
+    the oracle-against-device difference is 1e-10 for that reason alone).  The small parts of the badly scaled numbers
+    themselves (1e-8 of their number) are below that line: the 3-multiplication product returns them to ~1e-8 of
+    themselves, i.e. 1e-16 of the number -- a phase error of 1e-16 rad in the importance function (continuous.py:264-292)."""
+    nt = na + nb
+    model, rng = build(M, 40, na, nb, cplx_trial, seed=M + na)
+    nw = 6
+    a, b = rng.rand(nw, M, nt) - 0.5, rng.rand(nw, M, nt) - 0.5
+    base = numpy.real(model.psi)[None] + 0.1 * a
+    other = numpy.real(model.psi)[None] + 0.1 * b
+    phis = {"re>>im": base + 1e-8j * other, "im>>re": 1e-8 * other + 1j * base, "real": base + 0j, "imaginary": 1j * base}[scaling]
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    det = dev.greens(want_G=False)
+    gh = dev.get(L.F_GHALF)
+    refs = [ref.greens_function(p, model.psi, na, nb) for p in phis]
+    checks = {"det": _component_errors(det, numpy.array([r[0] for r in refs])),
+              "ghalf": _component_errors(gh.reshape(nw, nt, M), numpy.array([numpy.concatenate(r[1]) for r in refs]))}
+    dev.set(L.F_OT, det)
+    walkers = [ref.new_walker(model, p) for p in phis]
+    xi = rng.normal(size=(nw, 40))
+    dev.propagate(xi, -0.2)
+    for w, x in zip(walkers, xi):
+        ref.propagate_walker_phaseless(model, w, x, -0.2)
+    checks["phi"] = _component_errors(dev.get(L.F_PHI), numpy.array([w['phi'] for w in walkers]))
+    checks["ot"] = _component_errors(dev.get(L.F_OT), numpy.array([w['ot'] for w in walkers]))
+    checks["weight"] = _component_errors(dev.get(L.F_WEIGHT), numpy.array([w['weight'] for w in walkers]))
+    dev.close()
+    print("badly scaled %s M=%d N=%d cplx=%s: " % (scaling, M, na, cplx_trial) +
+          "  ".join("%s %.1e/%.1e" % (k, v[0], v[1]) for k, v in checks.items()))
+    for k, (norm, comp) in checks.items():
+        assert norm <= 1e-13, (k, norm)
+        assert comp <= 1e-10, (k, comp)
