@@ -14,6 +14,10 @@
 // pivot is deferred: row p is only scaled once, at the end.  No barrier, no atomics; the matrix never
 // returns to LDS until the inverse is stored un-permuted (A^-1[step(i)][prow[j]] = W[i][j]).
 // det A = sign(prow) prod_k d_k is returned as mantissa / binary exponent.
+#ifdef AFQ_TUNING
+// tuning builds, timing ablation only (WRONG results unless no pivoting is needed): the pivot of step k is row k, no search
+static __device__ int afq_gj_nopiv = 0;
+#endif
 __device__ inline unsigned gj_wave_max_u32(unsigned v) {
 #define AFQ_DPP_MAX(ctrl, rmask)                                                                         \
     { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);      \
@@ -81,7 +85,11 @@ __device__ inline void gj_block8(double (&vr)[RJ], double (&vi)[RJ], int it, int
             dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
             dnl = fma(fma(-nnl, dnl, 1.0), dnl, dnl);
             const double ixl = fx * dnl, iyl = -fy * dnl;
+#ifdef AFQ_TUNING
+            const int p = afq_gj_nopiv ? k : 31 - (int)(gj_wave_max_u32(key) & 31u);
+#else
             const int p = 31 - (int)(gj_wave_max_u32(key) & 31u);
+#endif
             const bool isp = r == p;
             used = used || isp;
             const double fxz = isp ? 0.0 : fx, fyz = isp ? 0.0 : fy;     // (the pivot row's own multiplier is zero)

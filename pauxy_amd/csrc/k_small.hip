@@ -571,6 +571,182 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     GS_STAMP(11);
 }
 
+// --------------------------------------------------------------------------
+// Green's function / overlap for AT MOST 8 ELECTRONS PER SPIN (round 5: the electron gas of BASELINE configs[1] has 7 + 7,
+// the 4 x 4 Hubbard lattice 8 + 8).  greens_small_kernel spends three dependent phases of 4-5 us each on such a walker --
+// two 16 x 16 MFMA tiles that are 80 % padding per phase and a 7-step register Gauss-Jordan built for n = 32 -- and the
+// kernel is one work-group per CU in a single round, i.e. pure latency.  Here, on the vector ALU, with every lane busy:
+//   phase 0  walker AND trial into LDS by LDS-DMA (one latency)
+//   phase 1  O_s[i, j] = sum_p phi[p, i] conj(psi[p, j]): thread = (spin, i, j, quarter of the p range), quad reduction
+//   phase 2  in-place Gauss-Jordan inverse with implicit row pivoting, one wave per spin, ONE LANE PER ELEMENT
+//            (lane = 8 row + column): per pivot step the column and the pivot row reach every lane by two lane
+//            permutes, the pivot row is found by the DPP maximum of gj_wave.h, and every lane does one complex FMA
+//   phase 3  Ghalf_s[i, q] = sum_j O^-1[i, j] phi[q, j]: thread per output element, stores along q
+// Same arguments, outputs and riders (weight update + cap behind the determinant, spin sum, per-walker trial of the
+// back-propagation, O^-1 for the Hirsch propagator) as greens_small_kernel; walkers/single_det.py:295-321, :170-199.
+template <bool INVERSE>
+__global__ __launch_bounds__(512) void greens_tiny_kernel(GreensArgs a, WeightArgs wa) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cplx O_l[2][64], oinv_l[2][64], piv_l[2][32];
+    __shared__ int prow_l[2][32];
+    __shared__ cplx ph_s[2];
+    __shared__ int la_s[2];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (a.only_alive && !a.alive[w]) return;
+    const int M = a.M, nt = a.nt, na = a.na, nb = a.nb;
+    cplx *phi_l = (cplx *)smem, *psi_l = phi_l + (long)M * nt;
+    const int lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {   // ---- phase 0
+        const unsigned total = (unsigned)(M * nt) * 16u;
+        const char *phi_g = (const char *)(a.phi + (long)w * M * nt), *psi_g = (const char *)(a.psi + w * a.psi_stride);
+        for (unsigned b0 = (unsigned)wave8 * 1024u; b0 < total; b0 += 8 * 1024u) {
+            const unsigned bo = b0 + (unsigned)lane * 16u;
+            if (bo < total) { glds16(phi_g + bo, (char *)phi_l + b0); glds16(psi_g + bo, (char *)psi_l + b0); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    {   // ---- phase 1: thread = (spin s, row i, column j, quarter c4 of the contraction)
+        const int o = tid >> 2, c4 = tid & 3;
+        const int s = o >> 6, i = (o >> 3) & 7, j = o & 7;
+        const int ns = s ? nb : na, off = s ? na : 0;
+        const bool live = i < ns && j < ns;
+        const int ic = off + (live ? i : 0), jc = off + (live ? j : 0);
+        double ar = 0.0, ai = 0.0;
+        // (eight terms per trip: sixteen LDS reads in flight ahead of the FMAs instead of a read -> wait -> FMA chain per term)
+        const int nterm = (M - c4 + 3) >> 2;
+        for (int t0 = 0; t0 < nterm; t0 += 8) {
+            cplx x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p_ = c4 + 4 * (t0 + u), pc = p_ < M ? p_ : c4;
+                x[u] = phi_l[pc * nt + ic]; y[u] = psi_l[pc * nt + jc];
+                if (p_ >= M) x[u] = cmake(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                          // x * conj(y)
+                ar = fma(x[u].x, y[u].x, ar); ar = fma(x[u].y, y[u].y, ar);
+                ai = fma(x[u].y, y[u].x, ai); ai = fma(-x[u].x, y[u].y, ai);
+            }
+        }
+        ar += __shfl_xor(ar, 1); ai += __shfl_xor(ai, 1);
+        ar += __shfl_xor(ar, 2); ai += __shfl_xor(ai, 2);
+        // (rows and columns past the electron count: the identity, so that the padded matrix has the same determinant)
+        if (c4 == 0) O_l[s][i * 8 + j] = live ? cmake(ar, ai) : cmake(i == j ? 1.0 : 0.0, 0.0);
+        if (tid < 64) { piv_l[tid >> 5][tid & 31] = cmake(1.0, 0.0); prow_l[tid >> 5][tid & 31] = tid & 31; }
+    }
+    __syncthreads();
+    // ---- phase 2: waves 0 and 1 (different SIMDs), spin = wave
+    if (wave8 < 2) {
+        const int s = wave8, n = s ? nb : na;
+        const int r = lane >> 3, c = lane & 7;
+        cplx v = O_l[s][lane];
+        double wx = v.x, wy = v.y;
+        bool used = r >= n;
+        int mystep = r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < n) {
+                // column k to every lane of its row
+                const int src = (lane & 0x38) | k;
+                const double fx = __shfl(wx, src), fy = __shfl(wy, src);
+                // pivot row: largest |re| + |im| among the rows not used yet (LAPACK's izamax metric on the top 26 bits of the
+                // double, ties -> lowest row), as in gj_wave.h
+                const unsigned mb = (unsigned)__double2hiint(fabs(fx) + fabs(fy));
+                const unsigned key = used ? 0u : ((((mb >> 5) + 1u) << 5) | (unsigned)(31 - r));
+                const int p_ = 31 - (int)(gj_wave_max_u32(key) & 31u);
+                const bool isp = r == p_;
+                // the pivot (uniform) and its reciprocal: v_rcp_f64 + two Newton steps
+                const double dx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fx), p_ * 8),
+                                                   __builtin_amdgcn_readlane(__double2loint(fx), p_ * 8));
+                const double dy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fy), p_ * 8),
+                                                   __builtin_amdgcn_readlane(__double2loint(fy), p_ * 8));
+                // (every product-sum below is an explicit fma: the two instantiations of this kernel -- determinant only, and
+                //  with the inverse -- must round alike, whatever the compiler would contract where)
+                const double nn = fma(dx, dx, dy * dy);
+                double dn = __builtin_amdgcn_rcp(nn);
+                dn = fma(fma(-nn, dn, 1.0), dn, dn);
+                dn = fma(fma(-nn, dn, 1.0), dn, dn);
+                const double ix = dx * dn, iy = -dy * dn;
+                // the pivot row, column k replaced by the unit entry, scaled by 1 / d
+                const int psrc = p_ * 8 + c;
+                double px = __shfl(wx, psrc), py = __shfl(wy, psrc);
+                if (c == k) { px = 1.0; py = 0.0; }
+                const double qx = fma(px, ix, -(py * iy)), qy = fma(px, iy, py * ix);
+                if (isp) {
+                    wx = qx; wy = qy; mystep = k;
+                    if (c == 0) piv_l[s][k] = cmake(dx, dy);
+                } else {
+                    const double bx = c == k ? 0.0 : wx, by = c == k ? 0.0 : wy;
+                    wx = fma(-fx, qx, bx); wx = fma(fy, qy, wx);
+                    wy = fma(-fx, qy, by); wy = fma(-fy, qx, wy);
+                }
+                used = used || isp;
+            }
+        }
+        if (c == 0 && r < n) prow_l[s][mystep] = r;
+        __builtin_amdgcn_wave_barrier();
+        // un-permuted inverse: A^-1[step(r)][prow[c]] = W[r][c]
+        if (INVERSE && r < n && c < n) oinv_l[s][mystep * 8 + prow_l[s][c]] = cmake(wx, wy);
+        cplx ph;
+        int la;
+        gj_wave_det(n, lane, piv_l[s], prow_l[s], ph, la);
+        if (lane == 0) { ph_s[s] = ph; la_s[s] = la; }
+    }
+    __syncthreads();
+    if (tid == 448) {
+        const cplx p2 = cmul(ph_s[0], ph_s[1]);
+        const int e = la_s[0] + la_s[1];
+        a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
+        if (wa.weight) weight_update_and_cap(wa, w);
+    }
+    if (!INVERSE) return;
+    const int nmax = na > nb ? na : nb;
+    if (a.oinv) {
+        cplx *oo = a.oinv + (long)w * 2 * nmax * nmax;
+        for (int e = tid; e < 2 * nmax * nmax; e += 512) {
+            const int s = e / (nmax * nmax), rem = e - s * nmax * nmax, i = rem / nmax, j = rem - i * nmax;
+            const int ns = s ? nb : na;
+            if (i < ns && j < ns) oo[e] = oinv_l[s][i * 8 + j];
+        }
+    }
+    if (!a.ghalf) return;
+    // ---- phase 3
+    auto ghalf_of = [&](const int s, const int i, const int q) {
+        const int ns = s ? nb : na, off = s ? na : 0;
+        double gr = 0.0, gi = 0.0;
+        cplx x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                              // every read in flight before the first FMA
+            const int jc = j < ns ? j : 0;
+            x[j] = oinv_l[s][i * 8 + jc]; y[j] = phi_l[q * nt + off + jc];
+            if (j >= ns) x[j] = cmake(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gr = fma(x[j].x, y[j].x, gr); gr = fma(-x[j].y, y[j].y, gr);
+            gi = fma(x[j].x, y[j].y, gi); gi = fma(x[j].y, y[j].x, gi);
+        }
+        return cmake(gr, gi);
+    };
+    cplx *gh = a.ghalf + (long)w * nt * M;
+    if (a.gsum) {                                              // na == nb (host-checked): both spins of an element in one thread
+        cplx *gs = a.gsum + (long)w * na * M;
+        for (int e = tid; e < na * M; e += 512) {
+            const int i = e / M, q = e - i * M;
+            const cplx ga = ghalf_of(0, i, q), gb = ghalf_of(1, i, q);
+            if (!a.skip_spin) { gh[e] = ga; gh[(long)na * M + e] = gb; }
+            gs[e] = cmake(ga.x + gb.x, ga.y + gb.y);
+        }
+    } else {
+        for (int e = tid; e < nt * M; e += 512) {
+            const int ii = e / M, q = e - ii * M;
+            const int s = ii < na ? 0 : 1;
+            gh[e] = ghalf_of(s, ii - (s ? na : 0), q);
+        }
+    }
+}
+
 static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, cplx *oinv = nullptr) {
     GreensArgs a;
     a.oinv = oinv; a.gsum = nullptr;
@@ -606,6 +782,14 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         static const int dbg = afq_knob("AFQ_GREENS_DBG") ? atoi(afq_knob("AFQ_GREENS_DBG")) : 0;
         a.dbg = dbg;
 #ifdef AFQ_TUNING
+        static bool nopiv_set = false;
+        if (!nopiv_set && afq_knob("AFQ_GJ_NOPIV")) {
+            const int one = 1;
+            hipMemcpyToSymbol(HIP_SYMBOL(afq_gj_nopiv), &one, sizeof(int));
+            nopiv_set = true;
+        }
+#endif
+#ifdef AFQ_TUNING
         static unsigned long long *gsts = nullptr;
         static int gs_launch = 0;
         if (afq_knob("AFQ_GS_TS")) {
@@ -633,16 +817,23 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
 #else
         const bool wgj_on = wgj;
 #endif
+        // at most 8 electrons per spin, walker + trial in LDS: the vector-ALU kernel above
+        const size_t lds_tiny = sizeof(cplx) * 2 * (size_t)h->M * h->nt;
+        static size_t lds_set_tiny[2][AFQ_MAX_DEVICES] = {{0}};
+        const bool tiny = nmax <= 8 && h->nt >= 1 && lds_tiny <= 150 * 1024 && !dbg && !afq_knob("AFQ_NO_GREENS_TINY");
         if (ghalf || oinv) {
             // the spin sum the force bias contracts (every walker written: not on the only_alive path)
             const bool want_sum = ghalf && ghalf == h->ghalf && !only_alive && k_fb_use_sum(h) && h->psi_stride == 0;
             if (want_sum) {
                 if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)h->na * h->M * h->nw));
                 a.gsum = h->ghalf_sum;
-                if (h->ghalf_skip_store && wgj_on && !oinv) { a.skip_spin = 1; h->ghalf_skipped = true; }
+                if (h->ghalf_skip_store && (wgj_on || tiny) && !oinv) { a.skip_spin = 1; h->ghalf_skipped = true; }
             }
             KernelTrace kt(h, AFQ_K_GREENS);
-            if (wgj_on) {
+            if (tiny) {
+                AFQ_HIP(h, afq_raise_lds((const void *)greens_tiny_kernel<true>, lds_tiny, lds_set_tiny[0]));
+                AFQ_LAUNCH(h, (greens_tiny_kernel<true>), dim3(h->nw), dim3(512), lds_tiny, h->stream, a, wa);
+            } else if (wgj_on) {
                 AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<true, true>, lds, lds_set[0]));
                 AFQ_LAUNCH(h, (greens_small_kernel<true, true>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
             } else {
@@ -650,6 +841,9 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
                 AFQ_LAUNCH(h, (greens_small_kernel<true, false>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);
             }
             if (want_sum) h->gsum_version = h->ghalf_version;
+        } else if (tiny) {
+            AFQ_HIP(h, afq_raise_lds((const void *)greens_tiny_kernel<false>, lds_tiny, lds_set_tiny[1]));
+            AFQ_LAUNCH(h, (greens_tiny_kernel<false>), dim3(h->nw), dim3(512), lds_tiny, h->stream, a, wa);
         } else if (wgj_on) {
             AFQ_HIP(h, afq_raise_lds((const void *)greens_small_kernel<false, true>, lds, lds_set[2]));
             AFQ_LAUNCH(h, (greens_small_kernel<false, true>), dim3(h->nw), dim3(512), lds, h->stream, a, wa);

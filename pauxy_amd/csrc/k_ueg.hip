@@ -57,6 +57,7 @@ struct UegFast {
     int nrows = 0;
     cplx *psic_rows = nullptr;      // [nrows][nt] conj(psi[row, :])
     int *fb_off = nullptr;          // [K + 1] entries of field n: fb_off[n] .. fb_off[n + 1]  (1.7 on average at C2, at most 14)
+    int nfb = 0;                    // entries of the lists (fb_off[K])
     int *fb_idx = nullptr;          // index into the compact G (row slot * M + column)
     cplx *fb_val = nullptr;
     // walkers
@@ -94,12 +95,41 @@ struct UegFieldArgs {
     unsigned long long *counters;
     const int *alive;
     int force_bias;             // AFQ_PROP_FORCE_BIAS set
+    // round 5: the walker's Ghalf, the trial rows and the two gather tables go to LDS by LDS-DMA at kernel start
+    int nfb;                    // entries of the force-bias lists (fb_off[K])
+    int fb_lds, coef_lds;       // the force-bias lists / the coefficient lists are staged in LDS (they fit)
+    int abl;                    // tuning builds, timing ablations (WRONG results): 1 no Philox, 2 no gather + clip, 4 no G rows,
+                                // 8 no coefficients
 };
 
+// copy `bytes` (a multiple of 16, the source allocation padded accordingly) from memory to LDS with every wave's requests
+// in flight at once; the caller waits (s_waitcnt vmcnt(0)) and synchronises
+__device__ inline void uf_dma(const void *src, void *dst, unsigned bytes, int wave, int nwaves, int lane) {
+    for (unsigned b0 = (unsigned)wave * 1024u; b0 < bytes; b0 += (unsigned)nwaves * 1024u) {
+        const unsigned bo = b0 + (unsigned)lane * 16u;
+        if (bo < bytes) glds16((const char *)src + bo, (char *)dst + b0);
+    }
+}
+
+// One 1024-thread work-group per live walker (propagation/planewave.py:57-112, continuous.py:133-158): force bias from the
+// occupied rows of G_up + G_dn, fields (device Philox stream of fields_kernel, or the host's), clipping, shifts, and the
+// coefficients that ARE the plane-wave HS potential.  The kernel is one work-group per CU in a single round -- its time is
+// the latency of its dependent chain -- so (round 5) EVERYTHING it reads from memory is requested in its first
+// instructions: Ghalf of the walker, the trial rows, the force-bias lists and the coefficient lists by LDS-DMA into LDS
+// (20 + 2 + 50 + 25 KB at C2), the mean-field shift and the list offsets of the thread's own fields into registers; the
+// Philox / Box-Muller arithmetic runs under that one memory latency, and every later gather (14 dependent table reads
+// per occupied row, up to 14 per field, the terms of a coefficient) is an LDS read.  20.4 -> ~10 us at C2.
 __global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, FieldRng rng) {
     extern __shared__ __align__(16) unsigned char smem[];
     cplx *gc = (cplx *)smem;                                 // [nrows][M] rows of G_up + G_dn
     cplx *xl = gc + (size_t)a.nrows * a.M;                   // [K] shifted fields
+    cplx *ghl = xl + a.K;                                    // [nt][M] Ghalf of the walker
+    cplx *psr = ghl + (size_t)a.nt * a.M;                    // [nrows][nt] (+ pad to 16 bytes: complex, none needed)
+    const unsigned nfb4 = ((unsigned)a.nfb + 3u) & ~3u, ncq = (unsigned)a.ncoef * a.nterms, ncq4 = (ncq + 3u) & ~3u;
+    cplx *fbv = psr + (size_t)a.nrows * a.nt;                // [nfb] when fb_lds
+    int *fbi = (int *)(fbv + (a.fb_lds ? a.nfb : 0));        // [nfb4]
+    cplx *cvl = (cplx *)(fbi + (a.fb_lds ? nfb4 : 0));       // [ncoef * nterms] when coef_lds
+    int *cql = (int *)(cvl + (a.coef_lds ? ncq : 0));        // [ncq4]
     __shared__ double red[UF_NTF / 64][8];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (rng.on) {
@@ -107,51 +137,96 @@ __global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, Fiel
         if (tid == 0) rng.alive_out[w] = live ? 1 : 0;
         if (!live) return;
     } else if (a.alive && !a.alive[w]) return;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = UF_NTF / 64;
+    // ---- every memory request of the kernel, up front
+    uf_dma(a.ghalf + (long)w * a.nt * a.M, ghl, (unsigned)(a.nt * a.M) * 16u, wave, NWV, lane);
+    uf_dma(a.psic_rows, psr, (unsigned)(a.nrows * a.nt) * 16u, wave, NWV, lane);
+    if (a.fb_lds) {
+        uf_dma(a.fb_val, fbv, (unsigned)a.nfb * 16u, wave, NWV, lane);
+        uf_dma(a.fb_idx, fbi, nfb4 * 4u, wave, NWV, lane);
+    }
+    if (a.coef_lds) {
+        uf_dma(a.coef_v, cvl, ncq * 16u, wave, NWV, lane);
+        uf_dma(a.coef_q, cql, ncq4 * 4u, wave, NWV, lane);
+    }
+    const int K = a.K;
+    const long e0 = (long)w * K;
+    // a thread takes the two members of one Philox pair (the stream of fields_kernel: element e = w K + n is member e & 1
+    // of pair e >> 1); pairs beyond the first UF_NTF of a walker go round the loop below again
+    const long pr0 = (e0 >> 1) + tid, pr_last = (e0 + K - 1) >> 1;
+    int nA = (int)(2 * pr0 - e0), zA[3] = {0, 0, 0};
+    cplx mfA[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+    double xiA[2] = {0.0, 0.0};
+    if (pr0 <= pr_last) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { const int n = nA + m; zA[m] = a.fb_off[n < 0 ? 0 : (n > K ? K : n)]; }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int n = nA + m;
+            if (n >= 0 && n < K) { mfA[m] = a.mf[n]; if (!rng.on) xiA[m] = a.xi[e0 + n]; }
+        }
+    }
+    double xn0[2] = {0.0, 0.0};
+    if (rng.on && pr0 <= pr_last && !(a.abl & 1)) philox_normal_pair(pr0, rng.seed, rng.stream, rng.counter, xn0[0], xn0[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // rows of G_up + G_dn that are not identically zero: sum over ALL columns of the trial (both spins) of conj(psi[row, c]) Ghalf[c, :]
-    const cplx *gh = a.ghalf + (long)w * a.nt * a.M;
-    for (int e = tid; e < a.nrows * a.M; e += UF_NTF) {
+    for (int e = tid; e < ((a.abl & 4) ? 0 : a.nrows * a.M); e += UF_NTF) {
         const int rr = e / a.M, j = e - rr * a.M;
         cplx acc = cmake(0.0, 0.0);
-        for (int c = 0; c < a.nt; ++c) cfma(acc, a.psic_rows[rr * a.nt + c], gh[(long)c * a.M + j]);
+        for (int c0 = 0; c0 < a.nt; c0 += 8) {
+            cplx pc[8], gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < a.nt ? c0 + u : 0;
+                pc[u] = psr[rr * a.nt + c]; gv[u] = ghl[c * a.M + j];
+                if (c0 + u >= a.nt) pc[u] = cmake(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cfma(acc, pc[u], gv[u]);
+        }
         gc[e] = acc;
     }
     __syncthreads();
     // sums: mean-field shift (re, im), xi . xbar (re, im), xbar . xbar (re, im), clipped count  (continuous.py:140-158)
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    const int K = a.K;
-    const long e0 = (long)w * K;
-    auto element = [&](const long e, const int n, const double xdev) {
+    auto element = [&](const long e, const int n, const double x, const int z0, const int z1, const cplx mm) {
         cplx b = cmake(0.0, 0.0);
-        if (a.force_bias) {
+        if (a.force_bias && !(a.abl & 2)) {
             // propagation/planewave.py:70-76: vbias[n] = (G_up + G_dn) . column n of [iA | iB], xbar = -sqrt(dt) vbias
             cplx v = cmake(0.0, 0.0);
-            for (int z = a.fb_off[n], z1 = a.fb_off[n + 1]; z < z1; ++z) cfma(v, a.fb_val[z], gc[a.fb_idx[z]]);
+            if (a.fb_lds) { for (int z = z0; z < z1; ++z) cfma(v, fbv[z], gc[fbi[z]]); }
+            else { for (int z = z0; z < z1; ++z) cfma(v, a.fb_val[z], gc[a.fb_idx[z]]); }
             b = cmake(-a.sqrt_dt * v.x, -a.sqrt_dt * v.y);
         }
-        const double ab = hypot(b.x, b.y);
+        const double ab = (a.abl & 2) ? 0.0 : hypot(b.x, b.y);
         if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
-        const double x = rng.on ? xdev : a.xi[e];
         const cplx sft = cmake(x - b.x, -b.y);
         a.xbar[e] = b;
         a.xs[e] = sft;
         xl[n] = sft;
-        const cplx mm = a.mf[n];
         acc[0] += sft.x * mm.x - sft.y * mm.y;
         acc[1] += sft.x * mm.y + sft.y * mm.x;
         acc[2] += x * b.x; acc[3] += x * b.y;
         acc[4] += b.x * b.x - b.y * b.y;
         acc[5] += 2.0 * b.x * b.y;
     };
-    // a thread takes the two members of one Philox pair (the stream of fields_kernel: element e = w K + n is member e & 1
-    // of pair e >> 1)
-    for (long pr = (e0 >> 1) + tid; pr <= ((e0 + K - 1) >> 1); pr += UF_NTF) {
+    if (pr0 <= pr_last) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int n = nA + m;
+            if (n >= 0 && n < K) element(e0 + n, n, rng.on ? xn0[m] : xiA[m], zA[m], zA[m + 1], mfA[m]);
+        }
+    }
+    for (long pr = pr0 + UF_NTF; pr <= pr_last; pr += UF_NTF) {       // (more than 2 UF_NTF fields per walker)
         double xn[2] = {0.0, 0.0};
         if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const long e = 2 * pr + m;
             const int n = (int)(e - e0);
-            if (n >= 0 && n < K) element(e, n, xn[m]);
+            if (n >= 0 && n < K) element(e, n, rng.on ? xn[m] : a.xi[e], a.fb_off[n], a.fb_off[n + 1], a.mf[n]);
         }
     }
 #pragma unroll
@@ -177,10 +252,10 @@ __global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, Fiel
     cplx *vc = a.vcoef + (long)w * (a.ncoef + 1);
     for (int id = tid; id <= a.ncoef; id += UF_NTF) {
         cplx c = cmake(0.0, 0.0);
-        if (id < a.ncoef) {
+        if (id < a.ncoef && !(a.abl & 8)) {
             for (int t = 0; t < a.nterms; ++t) {
-                const int n = a.coef_q[id * a.nterms + t];
-                if (n >= 0) cfma(c, a.coef_v[id * a.nterms + t], xl[n]);
+                const int n = a.coef_lds ? cql[id * a.nterms + t] : a.coef_q[id * a.nterms + t];
+                if (n >= 0) cfma(c, a.coef_lds ? cvl[id * a.nterms + t] : a.coef_v[id * a.nterms + t], xl[n]);
             }
             c = cmake(a.sqrt_dt * c.x, a.sqrt_dt * c.y);
         }
@@ -405,6 +480,7 @@ int k_ueg_fast_system(afq_handle *h, int M, int nq, const int64_t *Acp, const in
             cq[id * nterms + t] = std::get<0>((*order[id])[t]);
             cv[id * nterms + t] = cmake(std::get<1>((*order[id])[t]), std::get<2>((*order[id])[t]));
         }
+    while (cq.size() % 4) cq.push_back(-1);                      // (whole 16-byte pieces for the LDS-DMA copy of the field kernel)
     f->nterms = nterms;
     f->ncoef = (int)ids.size(); f->Mp = Mp;
     for (short &s : eid) if (s < 0) s = (short)f->ncoef;            // the zero coefficient
@@ -456,6 +532,8 @@ int k_ueg_fast_trial(afq_handle *h, const double *psi) {
         }
         fo[n + 1] = (int)fi.size();
     }
+    f->nfb = (int)fi.size();
+    while (fi.size() % 4) fi.push_back(0);                       // (whole 16-byte pieces for the LDS-DMA copy of the field kernel)
     int rc;
     if ((rc = upload_vec(h, &f->psic_rows, pr))) return rc;
     if ((rc = upload_vec(h, &f->fb_off, fo))) return rc;
@@ -491,7 +569,7 @@ int k_ueg_fast_supported(afq_handle *h) {
     if (!f->elem_ok || !f->trial_ok || !f->bdiag_ok) return 0;
     if (h->ndet != 1 || h->rdm_on || h->psi_stride != 0 || h->nt > 16 || h->nb <= 0 || h->M > 112) return 0;
     if (!(h->flags & AFQ_PROP_HYBRID) || (h->flags & AFQ_PROP_FREE_PROJECTION)) return 0;
-    const size_t lds1 = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K);
+    const size_t lds1 = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K + (size_t)h->nt * h->M + (size_t)f->nrows * h->nt);
     return lds1 <= 150 * 1024;
 }
 
@@ -516,7 +594,25 @@ int k_ueg_fields(afq_handle *h) {
     a.nterms = f->nterms; a.coef_q = f->coef_q; a.coef_v = f->coef_v; a.xi = h->xi; a.mf = h->mf_shift; a.xbar = h->xbar; a.xs = h->xs;
     a.cmf = h->cmf; a.cfb = h->cfb; a.vcoef = f->vcoef; a.counters = h->counters; a.alive = h->alive;
     a.force_bias = (h->flags & AFQ_PROP_FORCE_BIAS) ? 1 : 0;
-    const size_t lds = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K);
+    // walker-independent tables into LDS as far as they fit beside the walker's own arrays: force-bias lists first
+    size_t lds = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K + (size_t)h->nt * h->M + (size_t)f->nrows * h->nt);
+    const size_t fb_bytes = (size_t)f->nfb * 16 + (((size_t)f->nfb + 3) & ~(size_t)3) * 4;
+    const size_t ncq = (size_t)f->ncoef * f->nterms, cq_bytes = ncq * 16 + ((ncq + 3) & ~(size_t)3) * 4;
+    a.nfb = f->nfb;
+    a.abl = afq_knob("AFQ_UEG_ABL") ? atoi(afq_knob("AFQ_UEG_ABL")) : 0;
+    // (the work-group is alone on its CU: everything but 2 KB of the 160 KB for the kernel's static arrays may be used)
+    const size_t cap = 158 * 1024;
+    a.fb_lds = lds + fb_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
+    if (a.fb_lds) lds += fb_bytes;
+    a.coef_lds = lds + cq_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
+    if (a.coef_lds) lds += cq_bytes;
+#ifdef AFQ_TUNING
+    static bool said = false;
+    if (!said && afq_knob("AFQ_UEG_SAY")) {
+        said = true;
+        fprintf(stderr, "ueg_fields: nrows %d nfb %d ncoef %d nterms %d lds %zu fb_lds %d coef_lds %d\n", f->nrows, f->nfb, f->ncoef, f->nterms, lds, a.fb_lds, a.coef_lds);
+    }
+#endif
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)ueg_fields_kernel, lds, lds_set));
     AFQ_LAUNCH(h, ueg_fields_kernel, dim3(h->nw), dim3(UF_NTF), lds, h->stream, a, rng);

@@ -164,13 +164,13 @@ def test_c2_c4_run_batched_equals_run(make):
     assert numpy.array_equal(phi_b, phi_c)
     for other, blocks, phi in ((b, blocks_b, phi_b), (c, blocks_c, phi_c)):
         for key in ('weight', 'ot', 'ehyb'):
-            if make is c2_afqmc:
-                assert numpy.array_equal(a[key], other[key]), key
-            elif make is c4_small_step_afqmc:
+            if make is c2_afqmc or make is c4_small_step_afqmc:
                 # every walker alive: Slater matrices and overlaps bit-equal over all 20 steps; the block sums of the two
                 # loops are the same terms in another association (the per-walker loop adds every step on the host), so
-                # the shift derived from block 1 differs in its last bit (E ~ +700) and with it, from step 11 on, the
-                # weights and the hybrid energies (one ulp)
+                # the shift derived from block 1 may differ in its last bit (E ~ +700 on the lattice) and with it, from step 11
+                # on, the weights and the hybrid energies (one ulp).  The electron gas was bit-equal
+                # throughout up to round 4 and differs by one ulp in three weights since the round-5 Green's function kernel
+                # for at most 8 electrons per spin (another summation order in the energies that make the shift)
                 assert numpy.array_equal(a[key][:10], other[key][:10]), key
                 if key == 'ot':
                     assert numpy.array_equal(a[key], other[key]), key

@@ -11,15 +11,22 @@ from pauxy_amd import systems, trial as tm, _lib as L      # noqa: E402
 from pauxy_amd.context import get_context, release_context  # noqa: E402
 from pauxy_amd.propagation import setup                    # noqa: E402
 
-s = systems.synthetic_generic(100, 500, (25, 25), seed=7)
-t = tm.rhf_trial_generic(s)
+if os.environ.get("PROBE_CONFIG", "C3") == "C2":       # UEG rs = 2, 7 + 7 electrons, M = 93 (BASELINE configs[1])
+    s = systems.UEG(2.0, 7, 7, 4.0)
+    t = tm.hartree_fock_ueg(s)
+    BH1, mf = setup.ueg_propagator_arrays(s, t, 0.005)
+    M_, nt_ = s.nbasis, 14
+else:
+    s = systems.synthetic_generic(100, 500, (25, 25), seed=7)
+    t = tm.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, 0.005)
+    M_, nt_ = 100, 50
 dev = get_context(s, t).dev
-BH1, mf = setup.generic_propagator_arrays(s, t, 0.005)
 nw = 256
 dev.walkers_alloc(nw)
 dev.set_propagator(BH1, mf, 0.005)
 rng = numpy.random.RandomState(1)
-dev.set(L.F_PHI, t.psi[None] + 0.05 * (rng.rand(nw, 100, 50) + 1j * rng.rand(nw, 100, 50)))
+dev.set(L.F_PHI, t.psi[None] + 0.05 * (rng.rand(nw, M_, nt_) + 1j * rng.rand(nw, M_, nt_)))
 for rep in range(3):
     for _ in range(50):
         dev.greens(want_G=False, fetch=False)
@@ -29,5 +36,5 @@ for rep in range(3):
         dev.greens(want_G=False, fetch=False)
     dev.sync()
     dt = (time.perf_counter() - t0) / 400
-print("AFQ_GREENS_DBG=%s: %.1f us per launch" % (os.environ.get("AFQ_GREENS_DBG", "0"), dt * 1e6))
+print("%s AFQ_GREENS_DBG=%s: %.1f us per launch" % (os.environ.get("PROBE_CONFIG", "C3"), os.environ.get("AFQ_GREENS_DBG", "0"), dt * 1e6))
 release_context(s, t)
