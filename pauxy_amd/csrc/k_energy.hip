@@ -584,6 +584,9 @@ static int launch_exx_quadratic(afq_handle *h) {
         else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 7) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
         else if (cfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        else if (cfg == 12) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        else if (cfg == 13) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+        else if (cfg == 14) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
         else if (cfg == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 11) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2, 4>(p, h->stream, h->zero_page)));
 #endif

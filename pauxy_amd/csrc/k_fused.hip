@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 }
 
 int k_prop_fused_supported(afq_handle *h) {
-    return !h->no_fused && !h->vhs_diag && h->nv == 1 && h->M <= 104 && h->na <= 32 && h->nb <= 32 && h->nb > 0;
+    return !h->no_fused && !h->vhs_diag && h->nv == 1 && h->M <= 104 && h->na <= 32 && h->nb <= 32 && (h->nb > 0 || afq_knob("AFQ_PF_NB0"));
 }
 
 int k_prop_fused(afq_handle *h) {

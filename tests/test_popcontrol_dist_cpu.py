@@ -209,3 +209,102 @@ def test_fake_comm_surface():
     c.Allgather(numpy.arange(3.0), buf)
     assert numpy.array_equal(buf, numpy.arange(3.0))
     assert c.bcast({'a': 1})['a'] == 1 and c.rank == 0 and c.size == 1
+
+
+# ---- bring-up of the library-owned communicator: the agreement protocol of Walkers._init_device_comm on CPU ranks -------
+class BringUpDevice(object):
+    """Records what Walkers._init_device_comm asks of the device (no GPU: every call succeeds)."""
+
+    def __init__(self):
+        self.calls, self.window = [], True
+
+    def comm_available(self):
+        self.calls.append('available')
+        return True
+
+    def comm_unique_id(self):
+        self.calls.append('unique_id')
+        return bytes(range(1, 129))
+
+    def comm_init(self, uid, rank, size):
+        assert uid == bytes(range(1, 129))
+        self.calls.append('init')
+
+    def comm_set_transport(self, window):
+        self.calls.append('transport:%d' % int(window))
+        self.window = bool(window)
+
+    def comm_init_ipc(self, rank, size, allgather):
+        got = allgather(bytes([rank]) * 4)                      # the bootstrap all-gather the library would ask for
+        assert got == b''.join(bytes([r]) * 4 for r in range(size))
+        self.calls.append('init_ipc')
+
+    def comm_probe(self):
+        self.calls.append('probe')
+
+    def comm_stats(self):
+        return {'window': self.window}
+
+    def comm_destroy(self):
+        self.calls.append('destroy')
+
+
+class BringUpHost(object):
+    def __init__(self):
+        self.dev, self.device_comm_kind = BringUpDevice(), ''
+
+
+BRINGUP_CASES = [
+    # AFQ_COMM_FAULT, expected (communicator up, kind), calls every rank must have made in this order
+    ('', (True, 'rccl'), ['available', 'unique_id?', 'init', 'transport:1', 'probe']),
+    ('rccl:avail:2', (True, 'ipc'), ['available', 'init_ipc', 'probe']),
+    ('rccl:probe:1', (True, 'sendrecv'), ['available', 'unique_id?', 'init', 'transport:1', 'probe', 'transport:0', 'probe']),
+    ('rccl:init:0,ipc:probe:2', (False, ''), ['available', 'unique_id?', 'init', 'destroy', 'init_ipc', 'probe', 'destroy']),
+    ('rccl:avail:1,ipc:init:0', (False, ''), ['available', 'init_ipc', 'destroy']),
+]
+
+
+def _bringup_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = TorchComm()
+        res = []
+        for fault, _, _ in BRINGUP_CASES:
+            os.environ['AFQ_COMM_FAULT'] = fault
+            host = BringUpHost()
+            ok, reason = Walkers._init_device_comm(host, comm, True)
+            res.append((ok, host.device_comm_kind, host.dev.calls, reason))
+        out.put((rank, res))
+    except Exception as e:
+        out.put((rank, repr(e)))
+        raise
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_comm_bring_up_is_agreed_by_all_ranks_whichever_rank_fails():
+    """Walkers._init_device_comm over three gloo ranks with faults injected on single ranks (AFQ_COMM_FAULT): every rank
+    ends on the same communicator (or on none), no rank enters ncclCommInitRank unless all can load the library, a
+    failed candidate is torn down everywhere before the next one is tried, and the reasons are kept."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_bringup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, per_case in res:
+        assert isinstance(per_case, list), per_case
+        for (fault, (ok_want, kind_want), calls_want), (ok, kind, calls, reason) in zip(BRINGUP_CASES, per_case):
+            assert (ok, kind) == (ok_want, kind_want), (rank, fault, ok, kind, reason)
+            want = [c for c in calls_want if not (c == 'unique_id?' and rank != 0)]
+            want = [c.rstrip('?') for c in want]
+            assert calls == want, (rank, fault, calls)
+            if fault:
+                assert fault.split(':')[0] in reason, (fault, reason)
