@@ -363,6 +363,19 @@ ROCPROF_NAME = {"onebody_spin": "mfma_gemm_wg_kernel<OneBodyProbT>", "k_apply_ex
                 "GramProb GEMM": "mfma_gemm_wg_kernel<GramProb>", "QProb GEMM": "mfma_gemm_wg_kernel<QProb>"}
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources (pauxy_amd/csrc/*.hip, *.h, *.inc): tools/publish_profiles.py stores it with the PMC
+    passes, so that a bench line can say whether the traffic it quotes was measured on THIS library's kernels."""
+    import hashlib
+    d = os.path.join(ROOT, "pauxy_amd", "csrc")
+    hsh = hashlib.sha256()
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h", ".inc")):
+            with open(os.path.join(d, n), "rb") as f:
+                hsh.update(n.encode() + b"\0" + f.read())
+    return hsh.hexdigest()[:16]
+
+
 def committed_traffic(config_name):
     """HBM-side bytes per launch of this configuration's kernels from the newest committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, tools/profile_round.sh + tools/publish_profiles.py: separate FETCH_SIZE / WRITE_SIZE
@@ -375,9 +388,13 @@ def committed_traffic(config_name):
             d = json.load(f)
         table = d if config_name == "C3" else d.get("configs", {}).get(config_name)
         if table:
+            sha = d.get("csrc_sha16")
+            state = ("kernel sources unchanged since those passes" if sha == csrc_sha16() else
+                     "STALE: the kernel sources have changed since those passes" if sha else "no source fingerprint recorded")
             return ({k: v["traffic_bytes_per_launch"] for k, v in table.items() if isinstance(v, dict) and
                      "traffic_bytes_per_launch" in v},
-                    "%s: rocprofv3 --pmc passes of this command (not collected in this run)" % os.path.relpath(path, ROOT))
+                    "%s: rocprofv3 --pmc passes of this command (not collected in this run; %s)"
+                    % (os.path.relpath(path, ROOT), state))
     return {}, None
 
 

@@ -1085,8 +1085,9 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
     } else if (alive && !alive[w]) return;
     // sums: mean-field shift (re, im), xi . xbar (re, im), xbar . xbar (re, im), clipped count
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    auto element = [&](const long e, const int n, const double xdev) {
-        cplx b = FUSED ? xbar_value(xa, w, n) : xbar[e];
+    // (the force bias and the mean-field shift of a field are REQUESTED before its Philox arithmetic and used behind it:
+    //  the kernel is one short latency chain per work-group, and the loads now fly under the ~1 us of integer / log / sincos)
+    auto element = [&](const long e, const int n, const double xdev, cplx b, const cplx mm) {
         const double ab = hypot(b.x, b.y);
         if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
         const double x = rng.on ? xdev : xi[e];
@@ -1110,7 +1111,6 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
                 xa.hub_fac[((long)w * 2 + 1) * K + n] = taylor(cmake(xa.hub_f * sft.x, xa.hub_f * sft.y));
             }
         }
-        const cplx mm = mf[n];
         acc[0] += sft.x * mm.x - sft.y * mm.y;
         acc[1] += sft.x * mm.y + sft.y * mm.x;
         acc[2] += x * b.x; acc[3] += x * b.y;
@@ -1123,22 +1123,31 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
         // force bias (xbar_value: a contraction per element for the lattice models) wants every thread of the work-group
         const int n = threadIdx.x;
         if (n < K) {
+            const cplx b = FUSED ? xbar_value(xa, w, n) : xbar[e0 + n];
+            const cplx mm = mf[n];
             double xn[2] = {0.0, 0.0};
             if (rng.on) philox_normal_pair((e0 + n) >> 1, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
-            element(e0 + n, n, xn[(e0 + n) & 1]);
+            element(e0 + n, n, xn[(e0 + n) & 1], b, mm);
         }
     } else {
         // a thread takes the two members of one Philox pair (elements 2 p, 2 p + 1 of the stream: consecutive fields of
         // this walker, or its first / last field alone when the walker's K fields start or end inside a pair), so that a
         // pair is generated once -- with a thread per field every pair was generated twice and one normal of each thrown away
         for (long pr = (e0 >> 1) + threadIdx.x; pr <= ((e0 + K - 1) >> 1); pr += NTHR) {
+            cplx bb[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)}, mm[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const long e = 2 * pr + m;
+                const int n = (int)(e - e0);
+                if (n >= 0 && n < K) { bb[m] = FUSED ? xbar_value(xa, w, n) : xbar[e]; mm[m] = mf[n]; }
+            }
             double xn[2] = {0.0, 0.0};
             if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const long e = 2 * pr + m;
                 const int n = (int)(e - e0);
-                if (n >= 0 && n < K) element(e, n, xn[m]);
+                if (n >= 0 && n < K) element(e, n, xn[m], bb[m], mm[m]);
             }
         }
     }

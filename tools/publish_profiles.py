@@ -82,6 +82,9 @@ def main():
         "note": "FETCH_SIZE / WRITE_SIZE are KB of L2 memory-side requests (Infinity-Cache hits included); FETCH_SIZE is doubled "
                 "on gfx950 as MI355X_MICROARCH.md prescribes.  One name = one kernel template: a mean over every launch of "
                 "that template in the run (the per-determinant and the averaged-G force-bias contractions of C5 share one)"}
+    sys.path.insert(0, ROOT)
+    import bench
+    traffic["csrc_sha16"] = bench.csrc_sha16()          # the library the passes ran on (the snapshot they were made from)
     traffic.update(traffic_of('bench_c3'))
     traffic["configs"] = {c: traffic_of('cfg_' + c) for c in ('C2', 'C4', 'C5') if traffic_of('cfg_' + c)}
     json.dump(traffic, open(os.path.join(prof, rnd + '_pmc_traffic.json'), 'w'), indent=1)
