@@ -356,10 +356,11 @@ def run_config(args, name, state):
 
 
 # rocprofv3 names of the launches afq_launch_trace names by their launching function (GEMM engines)
-ROCPROF_NAME = {"onebody_spin": "mfma_gemm_wg_kernel<OneBodyProbT>", "k_apply_exponential": "mfma_gemm_wg_kernel<TaylorProb>",
+# (tools/publish_profiles.py: short() keeps the problem's name up to "Prob")
+ROCPROF_NAME = {"onebody_spin": "mfma_gemm_wg_kernel<OneBodyProb>", "k_apply_exponential": "mfma_gemm_wg_kernel<TaylorProb>",
                 "k_vhs_generic": "mfma_gemm_wg_kernel<VhsProb>", "launch_exx_quadratic": "mfma_gemm_wg_kernel<ExxQProb>",
-                "msd_gbar_fold GEMM": "mfma_gemm_wg_kernel<GbarSymProb>", "OvlpProb GEMM": "mfma_gemm_wg_kernel<OvlpProbT>",
-                "GhalfProb GEMM": "mfma_gemm_wg_kernel<GhalfProbT>", "GdiagProb GEMM": "mfma_gemm_wg_kernel<GdiagProbT>",
+                "msd_gbar_fold GEMM": "mfma_gemm_wg_kernel<GbarSymProb>", "OvlpProb GEMM": "mfma_gemm_wg_kernel<OvlpProb>",
+                "GhalfProb GEMM": "mfma_gemm_wg_kernel<GhalfProb>", "GdiagProb GEMM": "mfma_gemm_wg_kernel<GdiagProb>",
                 "GramProb GEMM": "mfma_gemm_wg_kernel<GramProb>", "QProb GEMM": "mfma_gemm_wg_kernel<QProb>"}
 
 
@@ -387,14 +388,20 @@ def committed_traffic(config_name):
         with open(path) as f:
             d = json.load(f)
         table = d if config_name == "C3" else d.get("configs", {}).get(config_name)
+        borrowed = ""
+        if not table and config_name == "C5sd":
+            # the single-determinant run of the C5 sizes has no passes of its own; its Taylor / HS-potential GEMMs are the
+            # launches of the C5 run (same kernels, same operand sizes: the trial does not enter them)
+            table = {k: v for k, v in d.get("configs", {}).get("C5", {}).items() if "TaylorProb" in k or "VhsProb" in k}
+            borrowed = " of the C5 configuration: same kernel, same operand sizes"
         if table:
             sha = d.get("csrc_sha16")
             state = ("kernel sources unchanged since those passes" if sha == csrc_sha16() else
                      "STALE: the kernel sources have changed since those passes" if sha else "no source fingerprint recorded")
             return ({k: v["traffic_bytes_per_launch"] for k, v in table.items() if isinstance(v, dict) and
                      "traffic_bytes_per_launch" in v},
-                    "%s: rocprofv3 --pmc passes of this command (not collected in this run; %s)"
-                    % (os.path.relpath(path, ROOT), state))
+                    "%s: rocprofv3 --pmc passes of this command%s (not collected in this run; %s)"
+                    % (os.path.relpath(path, ROOT), borrowed, state))
     return {}, None
 
 
