@@ -112,6 +112,9 @@ def work_table(c, b_real=False, psi_real=False, rchol_same=False):
         "prop_fused_kernel": ("mfma", 8.0 * M * M * nt * 8 * nw, M * M * nt * (8.0 * 6 + ob * 2) * nw,
                               "B exp(V) B: 2 one-body + 6 Taylor products of M x M by M x (na+nb) per walker"),
         "prop_ueg_kernel": ("mfma", 8.0 * M * M * nt * 6 * nw, None, "exp(V) phi from per-walker coefficients: 6 products"),
+        "ueg_step_kernel": ("mfma", 8.0 * M * M * nt * 6 * nw, None,
+                            "force bias + fields + coefficients + B exp(V) B in one launch: the 6 products are the priced work, the "
+                            "field part (latency bound) is in the time"),
         "k_apply_exponential": ("mfma", 8.0 * M * M * nt * nw, None, "one Taylor product V T, both spins"),
         # (one launch for both spins when they share one real matrix, else one per spin: the caller divides by the count)
         "onebody_spin": ("mfma", 8.0 * M * M * nt * nw, ob * M * M * nt * nw, "BH1 phi: one application to both spins"),

@@ -926,8 +926,8 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     if (k_ueg_fast_supported(h)) {
         // plane waves: force bias from the occupied rows of G, fields, and the ~2 nq coefficients that ARE the HS
         // potential, in one launch; B exp(V) B from those coefficients in a second one (k_ueg.hip)
-        { PhaseTimer t(h, T_FB); if ((rc = k_ueg_fields(h))) return rc; }                        // :133-158, :161
-        { PhaseTimer t(h, T_EXP); if ((rc = k_prop_ueg(h))) return rc; }                         // :251, :162-171, :258
+        // (one launch -- ueg_step_kernel -- when the propagator's LDS arrays fit behind the field part's, else two)
+        { PhaseTimer t(h, T_EXP); if ((rc = k_ueg_step(h))) return rc; }                         // :133-171, :251, :258
         h->prop_pending = true;
         return AFQ_OK;
     }

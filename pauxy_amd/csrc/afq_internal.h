@@ -447,6 +447,7 @@ int k_ueg_fast_propagator(afq_handle *h, const double *BH1);
 int k_ueg_fast_supported(afq_handle *h);
 int k_ueg_fields(afq_handle *h);                            // force bias + fields + HS coefficients
 int k_prop_ueg(afq_handle *h);                              // phi <- B exp(V) B phi
+int k_ueg_step(afq_handle *h);                              // the two above in one launch when its LDS plan fits
 void k_ueg_fast_free(afq_handle *h);
 // k_comm.hip
 int k_comm_size(afq_handle *h);                             // ranks of the library-owned communicator (1 without)

@@ -33,7 +33,10 @@
 namespace {
 
 constexpr int UF_NT = 512;              // threads of the propagator
-constexpr int UF_NTF = 1024;            // threads of the field kernel: latency bound (dependent table / LDS gathers, the
+#ifndef UF_NTF_OVERRIDE
+#define UF_NTF_OVERRIDE 1024
+#endif
+constexpr int UF_NTF = UF_NTF_OVERRIDE; // threads of the field kernel: latency bound (dependent table / LDS gathers, the
                                         // Philox + Box-Muller chain), one work-group per CU -- 16 waves hide twice as much as 8
 constexpr int UF_MAX_COEF = 4095;       // coefficients per walker that fit the LDS budget with room to spare
 constexpr int UF_MAX_ROWS = 32;
@@ -119,8 +122,12 @@ __device__ inline void uf_dma(const void *src, void *dst, unsigned bytes, int wa
 // (20 + 2 + 50 + 25 KB at C2), the mean-field shift and the list offsets of the thread's own fields into registers; the
 // Philox / Box-Muller arithmetic runs under that one memory latency, and every later gather (14 dependent table reads
 // per occupied row, up to 14 per field, the terms of a coefficient) is an LDS read.  20.4 -> ~10 us at C2.
-__global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, FieldRng rng) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// (NT threads: 1024 as a kernel of its own, 512 as the head of ueg_step_kernel; coef_lds_out: the coefficients also go to
+//  this LDS array -- the propagator's operand -- and the function returns false for a dead walker)
+template <int NT>
+__device__ __attribute__((always_inline)) inline bool ueg_fields_body(const UegFieldArgs &a, const FieldRng &rng, unsigned char *smem,
+                                                                      cplx *coef_lds_out) {
+    constexpr int UF_NTF = NT;
     cplx *gc = (cplx *)smem;                                 // [nrows][M] rows of G_up + G_dn
     cplx *xl = gc + (size_t)a.nrows * a.M;                   // [K] shifted fields
     cplx *ghl = xl + a.K;                                    // [nt][M] Ghalf of the walker
@@ -135,8 +142,8 @@ __global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, Fiel
     if (rng.on) {
         const bool live = fabs(rng.weight[w]) > 1e-8;
         if (tid == 0) rng.alive_out[w] = live ? 1 : 0;
-        if (!live) return;
-    } else if (a.alive && !a.alive[w]) return;
+        if (!live) return false;
+    } else if (a.alive && !a.alive[w]) return false;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWV = UF_NTF / 64;
     // ---- every memory request of the kernel, up front
@@ -260,7 +267,14 @@ __global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, Fiel
             c = cmake(a.sqrt_dt * c.x, a.sqrt_dt * c.y);
         }
         vc[id] = c;
+        if (coef_lds_out) coef_lds_out[id] = c;
     }
+    return true;
+}
+
+__global__ __launch_bounds__(UF_NTF) void ueg_fields_kernel(UegFieldArgs a, FieldRng rng) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    (void)ueg_fields_body<UF_NTF>(a, rng, smem, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ propagator
@@ -283,11 +297,42 @@ struct PropUegArgs {
 // come from LDS.  The second-half units park their partial tile in LDS, the first-half unit of the same row tile adds it,
 // scales by 1 / n (Taylor term n), adds it to the running sum it keeps in registers and writes it back into T for the
 // next product: two barriers per product.  KSU = k-steps per unit (ceil(nks / 2), compile time: static register indices).
+// what the propagator part requests from memory before anything else: its rows of the walker and the coefficient ids of its
+// operand fragments.  ueg_step_kernel issues these loads ahead of the field part, so that they fly under it.
+template <int KSU> struct PropUegPrefetch { cplx phi[4]; int id0[KSU], id1[KSU]; };
+
 template <int KSU>
-__global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __attribute__((always_inline)) inline void prop_ueg_prefetch(const PropUegArgs &a, PropUegPrefetch<KSU> &pf) {
     const int w = blockIdx.x;
-    if (!a.alive[w]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int M = a.M, nt = a.nt, nrt = a.nrt, nks = a.nks;
+    const int nunits = 2 * nrt, u0 = wave, u1 = wave + 8;
+    const bool has0 = u0 < nunits, has1 = u1 < nunits;
+    const int rt0 = has0 ? u0 % nrt : 0, kh0 = has0 ? u0 / nrt : 0;
+    const int rt1 = has1 ? u1 % nrt : 0, kh1 = has1 ? u1 / nrt : 0;
+    const int ksplit = (nks + 1) >> 1;
+    const int k00 = kh0 ? ksplit : 0, n0 = has0 ? (kh0 ? nks - ksplit : ksplit) : 0;
+    const int k10 = kh1 ? ksplit : 0, n1 = has1 ? (kh1 ? nks - ksplit : ksplit) : 0;
+    const cplx *phi = a.phi + (long)w * M * nt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = rt0 * 16 + 4 * r + lk;
+        pf.phi[r] = (has0 && kh0 == 0 && k < M && lr < nt) ? phi[(long)k * nt + lr] : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < KSU; ++j) {
+        pf.id0[j] = j < n0 ? (int)a.elem_id[((long)rt0 * nks + k00 + j) * 64 + lane] : a.ncoef;
+        pf.id1[j] = j < n1 ? (int)a.elem_id[((long)rt1 * nks + k10 + j) * 64 + lane] : a.ncoef;
+    }
+}
+
+// (coef_ready: the coefficients are in LDS already -- written by ueg_fields_body in the same kernel, behind a barrier;
+//  pf: operands requested earlier by prop_ueg_prefetch, or null)
+template <int KSU, bool PRE>
+__device__ __attribute__((always_inline)) inline void prop_ueg_body(const PropUegArgs &a, unsigned char *smem, const bool coef_ready,
+                                                                    const PropUegPrefetch<KSU> &pf) {
+    const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int M = a.M, nt = a.nt, Mp = a.Mp, nrt = a.nrt, nks = a.nks;
@@ -295,8 +340,10 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
     cplx *coef = (cplx *)smem;                                                   // [ncoef + 1]
     unsigned char *Tb = smem + (((size_t)(a.ncoef + 1) * 16 + 15) & ~(size_t)15);   // [nks][1024]
     unsigned char *Pb = Tb + (size_t)nks * 1024;                                  // [nrt][2][4][64] doubles (re / im)
-    const cplx *vc = a.vcoef + (long)w * (a.ncoef + 1);
-    for (int i = tid; i <= a.ncoef; i += UF_NT) coef[i] = vc[i];
+    if (!coef_ready) {
+        const cplx *vc = a.vcoef + (long)w * (a.ncoef + 1);
+        for (int i = tid; i <= a.ncoef; i += UF_NT) coef[i] = vc[i];
+    }
     cplx *phi = a.phi + (long)w * M * nt;
     // ---- units of this wave: u = wave and wave + 8; unit u: half kh = u / nrt of the contraction, row tile rt = u % nrt.
     // The kh == 0 unit of a row tile owns that tile of the running sum S and of T.
@@ -318,7 +365,7 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int k = rt0 * 16 + 4 * r + lk;
             cplx v = cmake(0.0, 0.0);
-            if (k < M && col_ok) v = cmul(a.bdiag[spin * M + k], phi[(long)k * nt + lr]);
+            if (k < M && col_ok) v = cmul(a.bdiag[spin * M + k], PRE ? pf.phi[r] : phi[(long)k * nt + lr]);
             Sr[r] = v.x; Si[r] = v.y;
             *(d2_t *)(Tb + (size_t)(rt0 * 4 + r) * 1024 + lane * 16) = (d2_t){v.x, v.y};
         }
@@ -331,11 +378,14 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
     const int k00 = kh0 ? ksplit : 0, n0 = has0 ? (kh0 ? nks - ksplit : ksplit) : 0;
     const int k10 = kh1 ? ksplit : 0, n1 = has1 ? (kh1 ? nks - ksplit : ksplit) : 0;
     {
-        short id0[KSU], id1[KSU];
+        int id0[KSU], id1[KSU];
 #pragma unroll
         for (int j = 0; j < KSU; ++j) {
-            id0[j] = j < n0 ? a.elem_id[((long)rt0 * nks + k00 + j) * 64 + lane] : (short)a.ncoef;
-            id1[j] = j < n1 ? a.elem_id[((long)rt1 * nks + k10 + j) * 64 + lane] : (short)a.ncoef;
+            if constexpr (PRE) { id0[j] = pf.id0[j]; id1[j] = pf.id1[j]; }
+            else {
+                id0[j] = j < n0 ? (int)a.elem_id[((long)rt0 * nks + k00 + j) * 64 + lane] : a.ncoef;
+                id1[j] = j < n1 ? (int)a.elem_id[((long)rt1 * nks + k10 + j) * 64 + lane] : a.ncoef;
+            }
         }
 #pragma unroll
         for (int j = 0; j < KSU; ++j) {
@@ -415,6 +465,30 @@ __global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
             if (k < M && col_ok) phi[(long)k * nt + lr] = cmul(a.bdiag[spin * M + k], cmake(Sr[r], Si[r]));
         }
     }
+}
+
+template <int KSU>
+__global__ __launch_bounds__(UF_NT) void prop_ueg_kernel(PropUegArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (!a.alive[blockIdx.x]) return;
+    PropUegPrefetch<KSU> none;
+    prop_ueg_body<KSU, false>(a, smem, false, none);
+}
+
+// Round 5: force bias + fields + coefficients AND the propagator in ONE launch of 512 threads per live walker (the two
+// kernels above back to back in one work-group: the field part's arithmetic costs the same with 8 waves as with 16 -- it
+// is one memory latency + three barriers -- and what the second launch cost is gone: 4.6 us of launch floor, the
+// coefficients' trip through memory, the latency of the propagator's own first loads).  The propagator's LDS arrays
+// (coefficients | T | partial tiles) start where the field part's walker-dependent staging (Ghalf, trial rows, force-bias
+// lists) lies: all of it dead when the coefficients are written, behind the barrier that ends the field loop.
+template <int KSU>
+__global__ __launch_bounds__(UF_NT) void ueg_step_kernel(UegFieldArgs fa, FieldRng rng, PropUegArgs pa, unsigned prop_off) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    PropUegPrefetch<KSU> pf;
+    prop_ueg_prefetch<KSU>(pa, pf);                               // (in flight under the field part)
+    if (!ueg_fields_body<UF_NT>(fa, rng, smem, (cplx *)(smem + prop_off))) return;      // (dead walker: the whole work-group)
+    __syncthreads();                                              // coefficients in LDS; the field part's LDS is free
+    prop_ueg_body<KSU, true>(pa, smem + prop_off, true, pf);
 }
 
 }  // namespace
@@ -573,8 +647,8 @@ int k_ueg_fast_supported(afq_handle *h) {
     return lds1 <= 150 * 1024;
 }
 
-// force bias + fields + HS coefficients in one launch (replaces k_full_G, k_vbias_ueg, k_xbar_fields, k_vhs_ueg)
-int k_ueg_fields(afq_handle *h) {
+// argument blocks of the two halves of the plane-wave step; lds: the dynamic LDS either needs as a kernel of its own
+static int ueg_field_args(afq_handle *h, UegFieldArgs &a, FieldRng &rng, size_t &lds, size_t &live_end) {
     UegFast *f = uf_of(h);
     if (f->vcoef_nw != h->nw || !f->vcoef) {
         if (f->vcoef) hipFree(f->vcoef);
@@ -582,20 +656,19 @@ int k_ueg_fields(afq_handle *h) {
         AFQ_HIP(h, hipMalloc(&f->vcoef, sizeof(cplx) * (size_t)h->nw * (f->ncoef + 1)));
         f->vcoef_nw = h->nw;
     }
-    FieldRng rng = FieldRng();
+    rng = FieldRng();
     if (h->rng_inline) {
         rng.on = 1; rng.seed = h->rng_seed; rng.stream = h->rng_stream; rng.counter = h->rng_inline_counter;
         rng.weight = h->weight; rng.alive_out = h->alive;
         h->rng_inline = false;
     }
-    UegFieldArgs a;
     a.M = h->M; a.nt = h->nt; a.K = h->K; a.nq = h->nq; a.nrows = f->nrows; a.ncoef = f->ncoef;
     a.sqrt_dt = h->sqrt_dt; a.ghalf = h->ghalf; a.psic_rows = f->psic_rows; a.fb_off = f->fb_off; a.fb_idx = f->fb_idx; a.fb_val = f->fb_val;
     a.nterms = f->nterms; a.coef_q = f->coef_q; a.coef_v = f->coef_v; a.xi = h->xi; a.mf = h->mf_shift; a.xbar = h->xbar; a.xs = h->xs;
     a.cmf = h->cmf; a.cfb = h->cfb; a.vcoef = f->vcoef; a.counters = h->counters; a.alive = h->alive;
     a.force_bias = (h->flags & AFQ_PROP_FORCE_BIAS) ? 1 : 0;
     // walker-independent tables into LDS as far as they fit beside the walker's own arrays: force-bias lists first
-    size_t lds = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K + (size_t)h->nt * h->M + (size_t)f->nrows * h->nt);
+    lds = sizeof(cplx) * ((size_t)f->nrows * h->M + h->K + (size_t)h->nt * h->M + (size_t)f->nrows * h->nt);
     const size_t fb_bytes = (size_t)f->nfb * 16 + (((size_t)f->nfb + 3) & ~(size_t)3) * 4;
     const size_t ncq = (size_t)f->ncoef * f->nterms, cq_bytes = ncq * 16 + ((ncq + 3) & ~(size_t)3) * 4;
     a.nfb = f->nfb;
@@ -604,6 +677,7 @@ int k_ueg_fields(afq_handle *h) {
     const size_t cap = 158 * 1024;
     a.fb_lds = lds + fb_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
     if (a.fb_lds) lds += fb_bytes;
+    live_end = lds;                     // what lies beyond is still read while the coefficients are written
     a.coef_lds = lds + cq_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
     if (a.coef_lds) lds += cq_bytes;
 #ifdef AFQ_TUNING
@@ -613,6 +687,27 @@ int k_ueg_fields(afq_handle *h) {
         fprintf(stderr, "ueg_fields: nrows %d nfb %d ncoef %d nterms %d lds %zu fb_lds %d coef_lds %d\n", f->nrows, f->nfb, f->ncoef, f->nterms, lds, a.fb_lds, a.coef_lds);
     }
 #endif
+    return AFQ_OK;
+}
+
+static void ueg_prop_args(afq_handle *h, PropUegArgs &a, size_t &lds) {
+    UegFast *f = uf_of(h);
+    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order; a.ncoef = f->ncoef; a.Mp = f->Mp;
+    a.nrt = f->Mp / 16; a.nks = f->Mp / 4;
+    a.elem_id = f->elem_id; a.vcoef = f->vcoef; a.bdiag = f->bdiag; a.phi = h->phi; a.alive = h->alive;
+    lds = (((size_t)(f->ncoef + 1) * 16 + 15) & ~(size_t)15) + (size_t)a.nks * 1024 + (size_t)a.nrt * 4096;
+    // matrix-pipe flops: order products x 2 nrt units x KSU k-steps x 3 multiplications x 2048
+    const int ksu = (a.nks + 1) / 2;
+    h->issued_flops[AFQ_K_PROPAGATOR] = 3.0 * h->exp_order * 2.0 * a.nrt * ksu * 2048.0 * h->nw;
+}
+
+// force bias + fields + HS coefficients in one launch (replaces k_full_G, k_vbias_ueg, k_xbar_fields, k_vhs_ueg)
+int k_ueg_fields(afq_handle *h) {
+    UegFieldArgs a;
+    FieldRng rng;
+    size_t lds, live_end;
+    const int rc = ueg_field_args(h, a, rng, lds, live_end);
+    if (rc) return rc;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};
     AFQ_HIP(h, afq_raise_lds((const void *)ueg_fields_kernel, lds, lds_set));
     AFQ_LAUNCH(h, ueg_fields_kernel, dim3(h->nw), dim3(UF_NTF), lds, h->stream, a, rng);
@@ -621,16 +716,11 @@ int k_ueg_fields(afq_handle *h) {
 }
 
 int k_prop_ueg(afq_handle *h) {
-    UegFast *f = uf_of(h);
     PropUegArgs a;
-    a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order; a.ncoef = f->ncoef; a.Mp = f->Mp;
-    a.nrt = f->Mp / 16; a.nks = f->Mp / 4;
-    a.elem_id = f->elem_id; a.vcoef = f->vcoef; a.bdiag = f->bdiag; a.phi = h->phi; a.alive = h->alive;
-    const size_t lds = (((size_t)(f->ncoef + 1) * 16 + 15) & ~(size_t)15) + (size_t)a.nks * 1024 + (size_t)a.nrt * 4096;
+    size_t lds;
+    ueg_prop_args(h, a, lds);
     KernelTrace kt(h, AFQ_K_PROPAGATOR);
-    // matrix-pipe flops: order products x 2 nrt units x KSU k-steps x 3 multiplications x 2048
     const int ksu = (a.nks + 1) / 2;
-    h->issued_flops[AFQ_K_PROPAGATOR] = 3.0 * h->exp_order * 2.0 * a.nrt * ksu * 2048.0 * h->nw;
 #define PU_LAUNCH_(KSU_, SLOT_)                                                                                \
     do {                                                                                                      \
         static size_t lds_set_[AFQ_MAX_DEVICES] = {0};                                                        \
@@ -647,6 +737,50 @@ int k_prop_ueg(afq_handle *h) {
     default: PU_LAUNCH_(14, 6); break;
     }
 #undef PU_LAUNCH_
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
+// the whole head of a plane-wave step (continuous.py:133-171, :251, :258): ONE launch when the propagator's LDS arrays fit
+// where the field part's dead staging lies, else the two launches above
+int k_ueg_step(afq_handle *h) {
+    UegFieldArgs fa;
+    FieldRng rng;
+    PropUegArgs pa;
+    size_t lds_f, live_end, lds_p;
+    if (afq_knob("AFQ_UEG_NO_STEP_FUSION")) { const int rc = k_ueg_fields(h); return rc ? rc : k_prop_ueg(h); }
+    const bool was_inline = h->rng_inline;
+    int rc = ueg_field_args(h, fa, rng, lds_f, live_end);
+    if (rc) return rc;
+    ueg_prop_args(h, pa, lds_p);
+    // the propagator's arrays start at the field part's Ghalf copy: everything from there to live_end (Ghalf, trial rows,
+    // force-bias lists) is dead once the field loop is over; the coefficient lists beyond it are not
+    const size_t prop_off = sizeof(cplx) * ((size_t)fa.nrows * fa.M + fa.K);
+    const bool fits = fa.coef_lds ? prop_off + lds_p <= live_end : prop_off + lds_p <= 158 * 1024;
+    if (!fits) {
+        h->rng_inline = was_inline;                 // (ueg_field_args consumed the flag: the two-launch path reads it again)
+        rc = k_ueg_fields(h);
+        return rc ? rc : k_prop_ueg(h);
+    }
+    const size_t lds = std::max(lds_f, prop_off + lds_p);
+    KernelTrace kt(h, AFQ_K_PROPAGATOR);
+    const int ksu = (pa.nks + 1) / 2;
+#define US_LAUNCH_(KSU_)                                                                                       \
+    do {                                                                                                      \
+        static size_t lds_set_[AFQ_MAX_DEVICES] = {0};                                                        \
+        AFQ_HIP(h, afq_raise_lds((const void *)ueg_step_kernel<KSU_>, lds, lds_set_));                        \
+        AFQ_LAUNCH(h, ueg_step_kernel<KSU_>, dim3(h->nw), dim3(UF_NT), lds, h->stream, fa, rng, pa, (unsigned)prop_off); \
+    } while (0)
+    switch (ksu) {
+    case 2: US_LAUNCH_(2); break;
+    case 4: US_LAUNCH_(4); break;
+    case 6: US_LAUNCH_(6); break;
+    case 8: US_LAUNCH_(8); break;
+    case 10: US_LAUNCH_(10); break;
+    case 12: US_LAUNCH_(12); break;
+    default: US_LAUNCH_(14); break;
+    }
+#undef US_LAUNCH_
     AFQ_POST(h);
     return AFQ_OK;
 }
