@@ -330,3 +330,46 @@ def test_spin_summed_force_bias_after_an_exchange():
         same_population(one, ranks, exact=False)
     assert crossed
     close_all([one] + ranks)
+
+
+def test_windows_above_512_walkers_per_rank_start_smaller_than_the_population_and_grow(golden):
+    """More than 512 walkers per rank: the peer windows start at max(512, nw / 4) slots per peer (k_comm.hip: default_cap),
+    with the overflow flag as the guard; the driver grows them at a block boundary as soon as the largest transfer seen
+    reaches half the capacity (Walkers.tune_exchange_capacity).  600 walkers on each of two ranks: a skewed population
+    that moves 300 walkers stays within the initial 512 slots and equals the one-rank comb; the statistics make the driver
+    raise the capacity to the population size; then the extreme case -- every walker of rank 1 replaced by a clone from
+    rank 0, 600 transfers, which 512 slots could not hold -- goes through."""
+    from pauxy_amd.walkers.handler import Walkers
+    nranks, nw = 2, 600
+    model, one, ranks, rng = start(golden, nranks, nw)
+    assert ranks[0].comm_stats()['capacity'] == 512
+
+    class Host(object):                                    # what Walkers.tune_exchange_capacity touches
+        def __init__(self, dev):
+            self.dev, self.nw, self.device_comm = dev, nw, True
+
+    def comb_with(w, r):
+        one.set(L.F_WEIGHT, w)
+        for i, rk in enumerate(ranks):
+            rk.set(L.F_WEIGHT, w[i * nw:(i + 1) * nw])
+        pix_one, _ = one.popcontrol_comb(r, nranks * nw)
+        pix, _ = devmod.popcontrol_comb_local(ranks, r, nranks * nw)
+        assert numpy.array_equal(pix, pix_one)
+        same_population(one, ranks)
+        return pix
+
+    # half of rank 1's walkers die, rank 0's are heavy enough to fill the gaps: 300 walkers cross
+    w = numpy.concatenate([numpy.full(nw, 1.5), numpy.full(nw // 2, 1.0), numpy.full(nw // 2, 1e-6)])
+    comb_with(w, 0.41)
+    st = ranks[0].comm_stats()
+    assert st['overflow'] == 0 and 256 <= st['max_transfer'] <= 512, st
+    for rk in ranks:
+        Walkers.tune_exchange_capacity(Host(rk))
+    assert [rk.comm_stats()['capacity'] for rk in ranks] == [nw, nw]
+    # every walker of rank 1 dies, every walker of rank 0 is cloned once: nw transfers in one event
+    w = numpy.concatenate([numpy.full(nw, 3.0), numpy.full(nw, 1e-6)])
+    pix = comb_with(w, 0.37)
+    assert numpy.all(pix[nw:] == 0) and numpy.all(pix[:nw] == 2)
+    st = ranks[0].comm_stats()
+    assert st['overflow'] == 0 and st['max_transfer'] == nw and st['error'] == 0
+    close_all([one] + ranks)
