@@ -820,7 +820,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
         if (afq_knob("AFQ_OVLP_CFG")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else
 #endif
-        if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+        if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+        else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         return AFQ_OK;
@@ -897,7 +898,8 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
             if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else
 #endif
-            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
             return AFQ_OK;
@@ -1403,9 +1405,13 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            // round 5: the lean loop at two work-groups per CU (mfma_gemm_wg.h, STAG = 5): 238 -> 218 us at C4.  (The overlap
+            // and Ghalf GEMMs of the Green's function measured 2-3 % SLOWER that way and keep the pipelined loop.)
+            else AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         }
         {
             CholArgs a;
@@ -1425,9 +1431,11 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
             else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            else if (afq_knob("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));   // 253 -> 230 us
         }
     }
     AFQ_LAUNCH(h, qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,

@@ -576,7 +576,10 @@ static int launch_exx_quadratic(afq_handle *h) {
         // round 4: four compute waves with 2 x 2 tiles + four loader waves (STAG = 3: the ring refill kept out of the waves
         // that issue MFMAs; see the HS-potential GEMM in k_gemm.hip): 155 -> 139 us per evaluation at C3 against the eight
         // compute waves with 1 x 2 tiles that refill the ring themselves (cfg 9, the round-3 choice)
-        if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        // round 5: a complex Atil (3-multiplication products, 144 VGPRs) on the lean loop at two work-groups per CU
+        // (k_apply_exponential in k_gemm.hip): 9.95 -> 9.74 ms per determinant at C5; the real one (99 VGPRs) is two per CU anyway
+        if (cfg == 1 && RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
+        else if (cfg == 1 || cfg == 16) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
         else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
 #ifdef AFQ_TUNING
         else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
@@ -587,6 +590,7 @@ static int launch_exx_quadratic(afq_handle *h) {
         else if (cfg == 12) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
         else if (cfg == 13) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
         else if (cfg == 14) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+        else if (cfg == 15) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 11) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2, 4>(p, h->stream, h->zero_page)));
 #endif

@@ -131,6 +131,9 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // round 4: 64 x 64 tiles on four compute waves (2 x 2 MFMA tiles each) + four loader waves that do nothing but the
         // ring refill (STAG = 3): C4 (256 x 256 per walker, real BH1) 338 -> 300 us against the 128 x 128 tiles above, C5
         // sizes (400 x 100) 444 -> 384 us against 64 x 128; the small tile also pads least
+        // round 5: a complex BH1 (3-multiplication products: 142 VGPRs, one work-group per CU) runs the lean loop at 122 VGPRs
+        // so that two work-groups share a CU (see k_apply_exponential); the real one (97 VGPRs) is two per CU as it is
+        else if (!AR && !afq_knob("AFQ_OB_NOLEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
@@ -480,6 +483,7 @@ int k_force_bias_msd_gbar(afq_handle *h) {
         else if (gcfg == 5) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
         else if (gcfg == 6) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
         else if (gcfg == 7) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else if (gcfg == 11) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         else if (gcfg == 9) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
         else if (gcfg == 10) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (gcfg == 8) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 8, GbarSymProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
@@ -491,7 +495,8 @@ int k_force_bias_msd_gbar(afq_handle *h) {
             // profiles/r05_c5_gbar_variants.txt): 2.37-2.39 ms; one walker per XCD at a time 2.42-2.48; with loader waves
             // 2.63 (2.75 on the batch map); 4-multiplication products under loader waves 2.88; ring depth 8: 2.97;
             // before the incremental refill (per-fragment address arithmetic every chunk) 3.14
-            AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            // (the lean loop with two work-groups per CU, k_apply_exponential: 2.35 -> 2.31 ms)
+            AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         else
             AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 1, 1, 4, GbarSymProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
     }
@@ -742,6 +747,8 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                         else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                     }
                     // round 4: 64 x 64 tiles, four compute + four loader waves (STAG = 3; see k_vhs_generic): C5 sizes 689 -> 627 us
+                    else if (afq_knob("AFQ_TAYLOR_LEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_LEAN1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 1>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_WPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_WPE2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
                     else if (afq_knob("AFQ_TAYLOR_S2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
@@ -751,7 +758,13 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                     // round 5: the same 64 x 64 tiles from four waves that refill the ring themselves inside the half-chunk
                     // pipelined loop (STAG = 2): 627-633 -> 612-616 us (C5 sizes).  Forcing two work-groups per CU
                     // (128 VGPRs, WPE = 4) spills 65-98 registers into the chunk loop: 2102 us
-                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (afq_knob("AFQ_TAYLOR_S2DEF")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    // ... and TWO work-groups per CU: the 3-multiplication kernels of this engine hold 142-160 VGPRs, i.e. one
+                    // work-group of 4 + 4 waves per CU.  Forcing 128 registers on the pipelined loops spills (2102 us);
+                    // the lean loop of STAG = 5 -- loader waves, compute waves that read the fragments of ONE sub-step at a
+                    // time into one set of registers -- needs 122, and what its own waves no longer overlap the second
+                    // work-group does: 613 -> 589 us
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
                 }
                 continue;
             }

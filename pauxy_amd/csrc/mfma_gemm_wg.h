@@ -103,7 +103,7 @@ template <class P> struct gemm_incr_types<P, true> {
 // two waves on every SIMD; with WPE = 4 (at most 128 VGPRs) a second work-group is co-resident on the CU, whose MFMAs run
 // while the first sits at its chunk barrier or in its epilogue.
 template <int WM, int WN, int TM, int TN, int D, class P, int MAP, bool K3M = false, int KC = 1, int STAG = 0, int WPE = 1>
-__global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_gemm_wg_kernel(P p, const void *zero16) {
+__global__ __launch_bounds__(WM *WN * 64 * ((STAG == 3 || STAG == 5) ? 2 : 1), WPE) void mfma_gemm_wg_kernel(P p, const void *zero16) {
 #ifdef AFQ_TUNING
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -125,7 +125,10 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_g
     // its wave's instruction issue busy for 100+ cycles and only two or three MFMAs queue up ahead of it, so a compute
     // wave that refills the ring itself idles the matrix pipe of its SIMD for most of that time when it is alone there.
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS-DMA targets (M0) stay in SGPRs
-    const bool loader = STAG == 3 && wave_all >= WM * WN;
+    // (STAG == 5: the same loader waves; the compute waves run a lean loop with ONE set of operand fragments -- for kernels
+    //  that are to fit 128 VGPRs so that two work-groups share a CU, see the end of the chunk loops)
+    constexpr bool LOADERS = STAG == 3 || STAG == 5;
+    const bool loader = LOADERS && wave_all >= WM * WN;
     const int wave = loader ? wave_all - WM * WN : wave_all;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_m = (p.rows + 16 * RT - 1) / (16 * RT);
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_g
             mfma_step(0, 1);
         }
     } else
-    if (STAG != 3 || loader) {
+    if (!LOADERS || loader) {
 #pragma unroll
         for (int c = 0; c < D - 1; ++c) issue(c, c);
     }
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_g
     if (STAG == 3 && (abl & 32) && !loader) __builtin_amdgcn_s_setprio(3);       // experiment: compute waves first
     if (STAG == 3 && (abl & 64) && loader) __builtin_amdgcn_s_setprio(3);        // experiment: loader waves first
 #endif
-    if (STAG == 3 && loader) {
+    if (LOADERS && loader) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(D - 1, (D - 1) & (D - 1));
@@ -434,6 +437,38 @@ __global__ __launch_bounds__(WM *WN * 64 * (STAG == 3 ? 2 : 1), WPE) void mfma_g
     // does refill, reads and the wait for them in a block behind the barrier with the matrix pipe idle, which only
     // works out when several waves share a SIMD; the small-output contractions of this library run one wave per SIMD.
     if constexpr (STAG == 4) {
+    } else
+    if constexpr (STAG == 5) {
+        // lean compute loop behind loader waves: per sub-step read ITS fragments (one set of registers for both sub-steps),
+        // wait, multiply.  Nothing of the wave's own overlaps the LDS latency -- that is what the second work-group on the CU
+        // is for (launch with WPE = 4).
+        static_assert(KC == 1, "lean loop: one sub-chunk per slot");
+        for (int c = 0; c < nchunks; ++c) {
+            __builtin_amdgcn_s_barrier();
+            const unsigned sl = ring_l + (c & (D - 1)) * CHUNK;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (gemm_areal<P>::value) a[0][i][0][0] = lds_read_b64(sl + ((wm * TM + i) * 2 + s2) * 1024 + lane * 16);
+                    else a[0][i][0] = lds_read_b128(sl + ((wm * TM + i) * 2 + s2) * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (P::B_CPLX && gemm_breal<P>::value) bc[0][j][0][0] = lds_read_b64(sl + (NA + (wn * TN + j) * 2 + s2) * 1024 + lane * 16);
+                    else if (P::B_CPLX) bc[0][j][0] = lds_read_b128(sl + (NA + (wn * TN + j) * 2 + s2) * 1024 + lane * 16);
+                    else br[0][j][0] = lds_read_b64(sl + (NA + wn * TN + j) * 1024 + s2 * 512 + lane * 8);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (gemm_conj_a<P>::value) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[0][i][0][1] = -a[0][i][0][1];
+                }
+                mfma_step(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else
     if ((STAG == 2 || STAG == 3) && KC == 1) {
         constexpr bool own_refill = STAG == 2;
@@ -683,13 +718,13 @@ inline hipError_t launch_mfma_gemm_wg(const P &p, hipStream_t stream, const void
     }
     if (MAP == MAP_COLPANEL_XCD) nblk = 8 * tiles_m * ((tiles_n + 7) / 8);
     const size_t lds = (size_t)D * KC * (NA + NB) * 1024 + (size_t)WM * WN * 1024;
-    static_assert(STAG != 3 || WM * WN <= 8, "compute + loader waves must fit one work-group");
+    static_assert((STAG != 3 && STAG != 5) || WM * WN <= 8, "compute + loader waves must fit one work-group");
     auto kern = mfma_gemm_wg_kernel<WM, WN, TM, TN, D, P, MAP, K3M, KC, STAG, WPE>;
     static size_t lds_set[AFQ_MAX_DEVICES] = {0};   // one per template instantiation and device: set the cap once
     {
         hipError_t e = afq_raise_lds((const void *)kern, lds, lds_set);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN * (STAG == 3 ? 2 : 1)), lds, stream, p, zero16);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN * ((STAG == 3 || STAG == 5) ? 2 : 1)), lds, stream, p, zero16);
     return hipGetLastError();
 }
