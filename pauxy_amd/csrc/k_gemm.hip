@@ -626,6 +626,12 @@ int k_vhs_generic(afq_handle *h) {
                 else if (v == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (v == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (v == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 1, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 11) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 1, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 12) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 1, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 13) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+                else if (v == 14) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 4, 2, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (v == 7) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 5, 4>(p, h->stream, h->zero_page)));
                 else if (v == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 5, 4>(p, h->stream, h->zero_page)));
                 else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
