@@ -156,6 +156,9 @@ static int upload_psi(afq_handle *h, const double *psi) {
     cache_of(h)->psi.assign(psi, psi + 2 * n);
     h->psi_real = true;
     for (size_t i = 0; i < n && h->psi_real; ++i) h->psi_real = psi[2 * i + 1] == 0.0;
+    h->psi_closed = h->na == h->nb && h->na > 0;
+    for (int p_ = 0; p_ < h->M && h->psi_closed; ++p_)
+        h->psi_closed = memcmp(psi + 2 * (size_t)p_ * h->nt, psi + 2 * ((size_t)p_ * h->nt + h->na), sizeof(double) * 2 * h->na) == 0;
     std::vector<double> pc(psi, psi + 2 * n);
     for (size_t i = 0; i < n; ++i) pc[2 * i + 1] = -pc[2 * i + 1];
     if (h->ndet <= 1) {     // transposed copy (Hubbard force bias: diag of G from rows of conj(psi)^T and Ghalf)

@@ -95,6 +95,7 @@ struct afq_handle {
     cplx *psicT = nullptr;          // conj(psi)^T [nt, M]: coalesced reads of the Hubbard force bias (single-determinant upload only)
     long psi_stride = 0;            // elements between per-walker 'trials' (back-propagation only; 0 = shared psi)
     bool psi_real = false;          // every imaginary part of the uploaded trial is exactly zero
+    bool psi_closed = false;        // na == nb and the alpha and beta blocks of the (single, shared) trial are bitwise equal
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one

@@ -102,6 +102,7 @@ struct GreensArgs {
                         // 2 skip phase 3, 4 skip phase 1, 8 LDS Gauss-Jordan instead of the register one
     int psi_real;       // every imaginary part of the (single, shared) trial is exactly zero (checked at upload)
     int skip_spin;      // with gsum: do not store the per-spin Ghalf (nobody will read it: afq_propagate_finish)
+    int psi_closed;     // the alpha and beta blocks of the (single, shared) trial are bitwise equal, na == nb (checked at upload)
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     const bool yreal = WGJ && a.psi_real != 0;
     const char *psi_w = (const char *)(a.psi + w * a.psi_stride);
     const bool has_tile = wave < nt16 * nt16 && !(a.dbg & 4);
+    bool closed = false;                                     // (set in phase01, uniform over the work-group)
     auto phase01 = [&](auto yr_tag) __attribute__((always_inline)) {
         constexpr bool YR = decltype(yr_tag)::value;
         using y_t = typename std::conditional<YR, double, cplx>::type;
@@ -285,7 +287,21 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
         }
         GS_STAMP(1);
         __syncthreads();                                         // phi_l complete
-        for (int t = wave; t < ((a.dbg & 4) ? 0 : nt16 * nt16); t += 4) {
+        // Closed-shell walker (round 5): the trial's spin blocks are bitwise equal (host-checked) and so are THIS walker's
+        // -- an RHF run, where every operator of the step acts on both spins alike.  Checked here, on the copy in LDS, every
+        // time, for this walker alone: no state, nothing to invalidate.  Then O_b = O_a, det = det_a^2, Ghalf_b = Ghalf_a
+        // bit for bit, and the beta half of phases 1 - 3 is not computed (spin-sum mode only: that is the step's path).
+        if (WGJ && a.psi_closed && a.gsum && !a.oinv && INVERSE) {
+            int same = 1;
+            const int na_ = a.na;
+            for (int e = tid; e < M * na_; e += 512) {
+                const int p_ = e / na_, i_ = e - p_ * na_;
+                const cplx x = phi_l[p_ * nt + i_], y = phi_l[p_ * nt + na_ + i_];
+                same &= (__double_as_longlong(x.x) == __double_as_longlong(y.x)) & (__double_as_longlong(x.y) == __double_as_longlong(y.y));
+            }
+            closed = __syncthreads_and(same) != 0;
+        }
+        for (int t = wave; t < ((a.dbg & 4) || (closed && g == 1) ? 0 : nt16 * nt16); t += 4) {
             const int ti = t / nt16, tj = t % nt16;
             const int ia = ti * 16 + lr;
             const int iac = ia < n ? ia : n - 1;
@@ -352,11 +368,14 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
     __shared__ int gj_prow[2][32];
     // (the two single-wave inversions run on different SIMDs: spin up on wave 0, spin down on wave 1 of its group = wave 5)
     if (WGJ) {
-        if (wave == g && !(a.dbg & 1)) {
+        if (wave == g && !(a.dbg & 1) && !(closed && g == 1)) {
             cplx ph;
             int la;
             gj_wave32(O, n, lane, INVERSE, gj_row[g], gj_piv[g], gj_prow[g], ph, la);
-            if (lane == 0) { ph_s[g] = ph; la_s[g] = (double)la; }
+            if (lane == 0) {
+                ph_s[g] = ph; la_s[g] = (double)la;
+                if (closed) { ph_s[1] = ph; la_s[1] = (double)la; }         // det O_b = det O_a
+            }
         }
     } else if (wave == 0 && !(a.dbg & 1)) {
         // det = prod of pivots, kept as (mantissa, binary exponent) so that neither log, exp nor
@@ -512,7 +531,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
             const int c0 = tc0 * 16 + lr, c1 = tc1 * 16 + lr;
             const int c0c = c0 < M ? c0 : M - 1, c1c = c1 < M ? c1 : M - 1;
             d4_t sra = {0, 0, 0, 0}, sia = {0, 0, 0, 0}, srb = {0, 0, 0, 0}, sib = {0, 0, 0, 0};
-            for (int s = s_lo; s < s_hi; ++s) {
+            for (int s = s_lo; s < (closed ? 1 : s_hi); ++s) {
                 const int ns = s ? a.nb : a.na, offs = s ? a.na : 0;
                 const cplx *Os = (const cplx *)smem + (long)s * (nmax * nmax + 2 * nmax);
                 cplx *gh = a.ghalf + ((long)w * nt + offs) * M;
@@ -555,6 +574,13 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                     if (i < ns && c0 < M && !a.skip_spin) gh[(long)i * M + c0] = cmake(ra, ima);
                     if (two && i < ns && c1 < M && !a.skip_spin) gh[(long)i * M + c1] = cmake(rb, imb);
                     sra[r] += ra; sia[r] += ima; srb[r] += rb; sib[r] += imb;
+                    if (closed) {
+                        // Ghalf_b = Ghalf_a: the same values into the beta rows, and twice into the spin sum (x + x: exact)
+                        cplx *ghb = gh + (long)a.na * M;
+                        if (i < ns && c0 < M && !a.skip_spin) ghb[(long)i * M + c0] = cmake(ra, ima);
+                        if (two && i < ns && c1 < M && !a.skip_spin) ghb[(long)i * M + c1] = cmake(rb, imb);
+                        sra[r] += ra; sia[r] += ima; srb[r] += rb; sib[r] += imb;
+                    }
                 }
             }
             if (both) {
@@ -754,6 +780,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
+    a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !afq_knob("AFQ_NO_CLOSED_GREENS");
     a.skip_spin = 0;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");

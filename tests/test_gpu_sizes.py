@@ -630,3 +630,53 @@ def test_badly_scaled_operands_through_the_three_multiplication_products(M, na, 
     for k, (norm, comp) in checks.items():
         assert norm <= 1e-13, (k, norm)
         assert comp <= 1e-10, (k, comp)
+
+
+@pytest.mark.parametrize("M,N", [(100, 25), (40, 13), (64, 32)])
+def test_closed_shell_walkers_take_the_one_spin_path_of_the_greens_kernel(M, N):
+    """An RHF trial (alpha block == beta block) and walkers whose spin blocks are bitwise equal -- what an RHF run with a
+    spin-free propagator produces -- let greens_small_kernel compute ONE spin (checked per walker, in LDS, every call):
+    O_b = O_a, det = det_a^2, Ghalf_b = Ghalf_a.  A population that mixes such walkers with ordinary ones (beta block
+    different) against the oracle for both kinds (walkers/single_det.py:295-321), the closed ones with bitwise equal spin
+    blocks of Ghalf; then a step, re-orthogonalisation and a second step keep the closed walkers closed bit for bit
+    (propagation/continuous.py:232-262 acts on both spins alike) -- the invariant the fast path rests on."""
+    nt, K, nw = 2 * N, 30, 40
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    assert numpy.array_equal(t.psi[:, :N], t.psi[:, N:])
+    dt = 0.005
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=s.ecore)
+    rng = numpy.random.RandomState(M + N)
+    half = t.psi[None, :, :N] + 0.05 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    phis = numpy.concatenate([half, half], axis=2)
+    mixed = numpy.arange(nw) % 3 == 2                                   # every third walker: an ordinary (open) one
+    phis[mixed, :, N:] += 0.03 * (rng.rand(int(mixed.sum()), M, N) + 1j * rng.rand(int(mixed.sum()), M, N))
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    det = dev.greens(want_G=False)
+    gh = dev.get(L.F_GHALF).reshape(nw, nt, M)
+    for w in range(nw):
+        d_ref, gh_ref, _ = ref.greens_function(phis[w], model.psi, N, N)
+        assert abs(det[w] - d_ref) <= 1e-10 * abs(d_ref)
+        close(gh[w], numpy.concatenate(gh_ref), 1e-10)
+        if not mixed[w]:
+            assert numpy.array_equal(gh[w, :N], gh[w, N:])
+        else:
+            assert not numpy.array_equal(gh[w, :N], gh[w, N:])
+    # force bias (the spin sum the kernel leaves behind) for both kinds
+    xbar = dev.force_bias()
+    for w in (0, 1, 2, 5, nw - 1):
+        _, gh_ref, G_ref = ref.greens_function(phis[w], model.psi, N, N)
+        close(xbar[w], model.force_bias(gh_ref, G_ref), 1e-10)
+    # the invariant: closed walkers stay closed through steps and the re-orthogonalisation, bit for bit
+    dev.set(L.F_OT, det)
+    for step in range(2):
+        dev.propagate(rng.normal(size=(nw, K)), -0.1)
+        if step == 0:
+            dev.reortho()
+    out = dev.get(L.F_PHI)
+    for w in range(nw):
+        assert numpy.array_equal(out[w, :, :N], out[w, :, N:]) == (not mixed[w]), w
+    dev.close()

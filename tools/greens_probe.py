@@ -26,7 +26,10 @@ nw = 256
 dev.walkers_alloc(nw)
 dev.set_propagator(BH1, mf, 0.005)
 rng = numpy.random.RandomState(1)
-dev.set(L.F_PHI, t.psi[None] + 0.05 * (rng.rand(nw, M_, nt_) + 1j * rng.rand(nw, M_, nt_)))
+phi0 = t.psi[None] + 0.05 * (rng.rand(nw, M_, nt_) + 1j * rng.rand(nw, M_, nt_))
+if os.environ.get("PROBE_CLOSED"):                       # closed-shell walkers: beta block = alpha block, bit for bit
+    phi0[:, :, nt_ // 2:] = phi0[:, :, :nt_ // 2]
+dev.set(L.F_PHI, phi0)
 for rep in range(3):
     for _ in range(50):
         dev.greens(want_G=False, fetch=False)
