@@ -72,6 +72,10 @@ struct PropFusedArgs {
     int rem4;                   // M <= 100 in the full 7-row-tile deal: rows 96.. as one 4x4x4 unit (see taylor)
     int hyb;                    // > 0: a column slot with at most 4 * hyb <= 12 live columns is multiplied as hyb units of
                                 // 16 rows x 4 columns on v_mfma_f64_4x4x4 (see taylor_h)
+    int symcols;                // contig with na == nb (round 5): T holds the walker's columns in the order [a 0..15 | b 0..15 |
+                                // a 16..23, b 16..23 | a 24.., b 24..] so that a column and its twin of the other spin always go
+                                // through the same code and MFMA shape (slots 0, 1: taylor; slot 2: taylor_h's tile; slot 3:
+                                // 4x4x4 units): the spin blocks of a closed-shell walker stay bitwise equal through the step
     int contig;                 // the columns of T are the na + nb columns of the walker back to back (slot = column / 16)
                                 // instead of two slots per spin: every matrix of the chain acts on both spins alike
     const cplx *BH1;            // [2, M, M]
@@ -229,6 +233,20 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     };
     issueA(); issueA();                                          // PF_D - 1 chunks in flight
     prepare();
+    // T column -> walker column (identity unless a.symcols: see PropFusedArgs)
+    const int sym_n = a.symcols ? a.na : 0;
+    // (slots 0 and 1 are multiplied by the same code (taylor), slot 2 by taylor_h's full tile, slot 3 as 4x4x4 units -- three
+    //  summation orders: a column and its twin must sit in the same KIND of slot: [a 0..15 | b 0..15 | a 16..23, b 16..23 |
+    //  a 24.., b 24..])
+    auto wcol = [&](const int c) -> int {
+        if (!sym_n) return c;
+        if (c < 16) return c;
+        if (c < 32) return sym_n + (c - 16);
+        if (c < 40) return 16 + (c - 32);
+        if (c < 48) return sym_n + 16 + (c - 40);
+        const int e = c - 48, extra = sym_n - 24;
+        return e < extra ? 24 + e : sym_n + 24 + (e - extra);
+    };
 
     // ---- phi[w] -> T (B-fragment order), padding zeroed: one sweep over the ENTRIES of T (16 bytes each; entry index =
     // ((chunk * 4 + slot) * 2 + (p & 1)) * 64 + ((p & 7) >> 1) * 16 + column in the slot, i.e. shifts and masks only), each
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         const int p = ch * 8 + 2 * kk + pb, sp = a.contig ? 0 : slot >> 1, col = (a.contig ? slot : slot & 1) * 16 + j;
         const int ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
         const bool ok = p < M && col < ns_;
-        const cplx v = phi[ok ? p * nt + off_ + col : 0];
+        const cplx v = phi[ok ? p * nt + off_ + wcol(col) : 0];
         ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
     }
     __syncthreads();
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                     if (to_global) {
                         const int row = rt * 16 + lk_e + 4 * r, col = (a.contig ? cs : cs & 1) * 16 + lr_e;
                         PF_UNLESS(256)
-                        if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+                        if (row < M && col < ns_) phi[(long)row * nt + off_ + wcol(col)] = cmake(re, im);
                     } else if (t_ok(rt, r)) {
                         *(d2_t *)(Tf + t_addr(rt, r, cs)) = (d2_t){re, im};
                     }
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 const double im = BR ? P2[i][r] : P3[i][r] - P1[i][r] - P2[i][r];
                 if (to_global) {
                     const int row = (r0 + i) * 16 + lk_e + 4 * r, col = cb + lr_e;
-                    if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+                    if (row < M && col < ns_) phi[(long)row * nt + off_ + wcol(col)] = cmake(re, im);
                 } else if (t_ok(r0 + i, r)) {
                     *(d2_t *)(Tf + t_addr(r0 + i, r, c0)) = (d2_t){re, im};
                 }
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             const double re = BR ? Q1 : Q1 - Q2, im = BR ? Q2 : Q3 - Q1 - Q2;
             if (to_global) {
                 const int row = 96 + (ln_e >> 4), col = cb + (ln_e & 15);
-                if (row < M && col < ns_) phi[(long)row * nt + off_ + col] = cmake(re, im);
+                if (row < M && col < ns_) phi[(long)row * nt + off_ + wcol(col)] = cmake(re, im);
             } else {
                 *(d2_t *)(Tf + rem_t) = (d2_t){re, im};
             }
@@ -1204,12 +1222,13 @@ int k_prop_fused(afq_handle *h) {
         a.hyb = (h->na - 13) / 4;
     // contiguous columns: one one-body matrix for both spins (the HS potential never depends on the spin), 48 < na + nb <= 56
     // (a third unit per row tile would unbalance the deal and push wave 7 over 256 registers)
-    a.contig = 0;
+    a.contig = 0; a.symcols = 0;
     if (a.rem4 && a.same_b && h->na > 16 && h->nb > 16 && h->nt > 48 && h->nt <= 56 && PF_NW == 8 && !a.hyb &&
         !afq_knob("AFQ_PF_NOCONTIG")) {
         a.contig = 1;
         a.hyb = (h->nt - 48 + 3) / 4;
     }
+    a.symcols = (a.contig && h->na == h->nb && !afq_knob("AFQ_PF_NOSYM")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;

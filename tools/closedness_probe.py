@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """How long the C3 walkers of the benchmark stay closed-shell BIT FOR BIT (alpha block == beta block): the condition of the
 one-spin path of greens_small_kernel.  They start closed (RHF trial) and every operator of the step acts on both spins
-alike, but the fused propagator's contiguous-column deal multiplies columns 48, 49 (beta columns 23, 24) as 4x4x4 MFMA units
-and their alpha twins inside a 16x16x4 tile: last-bit differences appear in a few walkers per step (NEGATIVES.md)."""
+alike -- provided the fused propagator keeps a column and its twin of the other spin in column slots that are multiplied by
+the same code (PropFusedArgs::symcols; with the plain contiguous order 23 of 256 walkers lost the property in the first
+step: NEGATIVES.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy
@@ -23,3 +24,7 @@ for n in (1, 1, 3, 5, 10, 30):
     same = [numpy.array_equal(p[:, :25], p[:, 25:]) for p in phi]
     d = numpy.abs(phi[:, :, :25] - phi[:, :, 25:]).max()
     print("after step %d: %d of 256 walkers closed, max |alpha - beta| = %.3e" % (first - 1, sum(same), d))
+    if first - 1 <= 2:
+        diff = phi[:, :, :25] != phi[:, :, 25:]
+        print("   differing entries per column:", diff.sum(axis=(0, 1)).tolist())
+        print("   differing entries per row (first 12 / last 8):", diff.sum(axis=(0, 2))[:12].tolist(), diff.sum(axis=(0, 2))[-8:].tolist())
