@@ -853,13 +853,22 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     # the same work model as the --config lines (work_table): SURVEY 8d count, and the count with real operands at 4 flops
     wt = work_table(dict(M=M, na=N, nb=N, K=K, nw=nw), b_real=b_real, psi_real=psi_real, rchol_same=fb_same_spin_block)
     quad = dev.exchange_algorithm() == 2
+    # closed-shell population (every walker's spin blocks bitwise equal, RHF trial): the library evaluates the exchange energy
+    # of one spin and counts it twice (verified on the device per evaluation) -- the executed work is one spin's
+    phi_now = dev.get(L.F_PHI)
+    closed_pop = bool(quad and fb_same_spin_block and numpy.array_equal(numpy.asarray(trial.psi)[:, :N], numpy.asarray(trial.psi)[:, N:])
+                      and numpy.array_equal(phi_now[:, :, :N], phi_now[:, :, N:]))
+    if closed_pop:
+        b_, w_, wr_, n_ = wt["launch_exx_quadratic"]
+        wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice")
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
         # GEMM per spin) executes 4 (N M)^2 flops per spin and walker -- K / M = 5 times fewer than the
         # T-intermediate formulation of the reference (4 K M N^2); both counts are reported
         # (Atil is symmetric: the library stores its upper triangle and contracts only that -- NM (NM + 1) / 2 pairs)
-        (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g, upper triangle)",
+        (("mfma_gemm_wg_kernel<ExxQProb> (Cholesky exchange energy as the quadratic form g^T Atil g, upper triangle%s)"
+          % ("; closed-shell population: one spin evaluated, counted twice" if closed_pop else ""),
           L.K_EXCHANGE, wt["launch_exx_quadratic"]) if quad else
          ("exx_kernel (Cholesky exchange energy, T intermediate)", L.K_EXCHANGE, wt["exx_kernel"])),
         # symmetric Cholesky matrices: only the M(M+1)/2 columns p <= q are contracted

@@ -234,9 +234,11 @@ int afq_create(int device_id, afq_handle **out) {
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     if (hipMalloc(&h->estimates, sizeof(cplx) * AFQ_EST_COUNT_) != hipSuccess ||
         hipMalloc(&h->counters, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc(&h->closed_bad, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->scal, sizeof(double) * AFQ_NSCAL) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_);
     hipMemset(h->counters, 0, sizeof(unsigned long long) * 4);
+    hipMemset(h->closed_bad, 0, sizeof(unsigned long long));
     hipMemset(h->scal, 0, sizeof(double) * AFQ_NSCAL);
     if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->zero_page, 0, 256);
@@ -266,7 +268,7 @@ int afq_destroy(afq_handle *h) {
     free_walkers(h);
     free_system(h);
     dev_free(h->psi); dev_free(h->psic); dev_free(h->psicT); dev_free(h->BH1); dev_free(h->mf_shift);
-    dev_free(h->estimates); dev_free(h->counters); dev_free(h->scal);
+    dev_free(h->estimates); dev_free(h->counters); dev_free(h->closed_bad); dev_free(h->scal);
     if (h->zero_page) hipFree(h->zero_page);
     if (h->retired) hipHostFree((void *)h->retired);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);

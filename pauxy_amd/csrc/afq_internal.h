@@ -96,6 +96,13 @@ struct afq_handle {
     long psi_stride = 0;            // elements between per-walker 'trials' (back-propagation only; 0 = shared psi)
     bool psi_real = false;          // every imaginary part of the uploaded trial is exactly zero
     bool psi_closed = false;        // na == nb and the alpha and beta blocks of the (single, shared) trial are bitwise equal
+    // Closed-shell populations (round 5).  The Green's function kernel checks every walker's spin blocks for bitwise equality
+    // (greens_small_kernel); a walker that fails raises closed_bad to the epoch of that launch.  closed_checked_version is
+    // the ghalf_version whose Ghalf comes from such a checked launch (carried through the comb's clones, which copy whole
+    // walkers): while it equals ghalf_version, "*closed_bad < closed_epoch" ON THE DEVICE means Ghalf_b == Ghalf_a for every
+    // walker, and the exchange energy evaluates one spin (k_energy.hip).  The host never reads the flag.
+    unsigned long long *closed_bad = nullptr;
+    unsigned long long closed_epoch = 0, closed_checked_version = 0;
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one

@@ -222,6 +222,12 @@ struct PackArgs {
     cplx *phi, *ot, *ehyb, *phase, *eloc, *ghalf, *ovlp_new, *phi_old, *bp_hist, *bp_ph, *G;
     double *unscaled, *detR, *log_detR, *bp_cos;
     int *bp_n;
+    // unpack: a walker that arrives with a cached Ghalf whose spin blocks differ raises closed_bad to this rank's current
+    // epoch (afq_internal.h: the closed-shell verdict of the population must cover what other ranks send); closed_half =
+    // na * M elements per spin block, 0 = no check
+    unsigned long long *closed_bad;
+    unsigned long long closed_epoch;
+    long closed_half;
 };
 
 // grid (4, min(cap, COMM_GRID_Y), R): block (x, y, peer) moves quarter x of the slots y, y + gridDim.y, ... of that peer.
@@ -258,7 +264,18 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
         };
         long off = 0;
         mv(a.phi, per, off); off += per;
-        if (a.L.with_greens) { mv(a.ghalf, per, off); off += per; }
+        if (a.L.with_greens) {
+            mv(a.ghalf, per, off);
+            if (!PACK && a.closed_half) {
+                bool differ = false;
+                for (long i = t0; i < a.closed_half; i += stride) {
+                    const cplx x = s[off + i], y = s[off + a.closed_half + i];
+                    differ |= __double_as_longlong(x.x) != __double_as_longlong(y.x) || __double_as_longlong(x.y) != __double_as_longlong(y.y);
+                }
+                if (differ) atomicMax(a.closed_bad, a.closed_epoch);
+            }
+            off += per;
+        }
         if (a.L.with_bp) { mv(a.phi_old, per, off); off += per; mv(a.bp_hist, a.L.hist_per, off); off += a.L.hist_per; }
         if (a.L.with_rdm) { mv(a.G, a.L.gsz, off); off += a.L.gsz; }
         if (t0 == 0) {
@@ -630,6 +647,7 @@ void fill_pack(afq_handle *h, PackArgs &p, bool with_greens, bool send) {
     p.phi = h->phi; p.ot = h->ot; p.ehyb = h->ehyb; p.phase = h->phase; p.eloc = h->eloc; p.ghalf = h->ghalf;
     p.ovlp_new = h->ovlp_new; p.phi_old = h->phi_old; p.bp_hist = h->bp_hist; p.bp_ph = h->bp_ph; p.G = h->G;
     p.unscaled = h->unscaled; p.detR = h->detR; p.log_detR = h->log_detR; p.bp_cos = h->bp_cos; p.bp_n = h->bp_n;
+    p.closed_bad = h->closed_bad; p.closed_epoch = h->closed_epoch; p.closed_half = 0;
 }
 
 int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
@@ -659,11 +677,15 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
 }
 
 int stage_unpack(afq_handle *h, bool with_greens) {
+    // (the closed-shell verdict of this rank's population carries over when the walkers that arrive are checked too)
+    const bool closed_too = with_greens && h->closed_bad && h->closed_checked_version == h->ghalf_version && h->na == h->nb;
     ++h->ghalf_version;                 // cloned / received walkers bring their Ghalf along
+    if (closed_too) h->closed_checked_version = h->ghalf_version;
     afq_comm_state *c = cs_of(h);
     if (c->nranks > 1) {
         PackArgs p;
         fill_pack(h, p, with_greens, false);
+        if (closed_too) p.closed_half = (long)h->na * h->M;
         AFQ_LAUNCH(h, comm_pack_kernel<false>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
         AFQ_POST(h);
     }

@@ -238,7 +238,11 @@ struct ExxQProb {
     cplx *E;
     int ncb;
     const cplx *zero;
-    __device__ bool active(int) const { return true; }
+    // closed-shell populations (afq_internal.h: closed_bad): the launch that holds the beta spin's slices returns at once when
+    // every walker's Ghalf_b equals its Ghalf_a -- the finish kernel then takes the alpha sums twice
+    const unsigned long long *skip_flag;
+    unsigned long long skip_epoch;
+    __device__ bool active(int) const { return !(skip_flag && *skip_flag < skip_epoch); }
     __device__ const cplx *ptrA(int b, int row, int k) const {
         return k < len[b] ? ghalf + row * astride + goff[b] + k : zero;
     }
@@ -362,6 +366,11 @@ struct EFinArgs {
     // quadratic-form exchange: E[2 * qsplit, nw, ncb] partial sums of (g^T Atil)[q] g[q] (null: exx_kernel partials in `part`)
     const cplx *Eq;
     int qsplit, na, nb, ncb;
+    // closed_try: Eq holds two passes of 2 qsplit batches each -- alpha's slices, then beta's; the beta pass was skipped on the
+    // device, and the alpha sums count twice, when *closed_bad < closed_epoch (every walker's Ghalf_b == Ghalf_a)
+    int closed_try;
+    const unsigned long long *closed_bad;
+    unsigned long long closed_epoch;
 };
 
 // EF_THR threads per walker: the kernel streams Ghalf, rH1, the Coulomb partials and (quadratic-form exchange) the
@@ -381,12 +390,16 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
         e1i += h.x * g.y + h.y * g.x;
     }
     if (a.Eq) {          // exchange: the per-tile partial sums the GEMM epilogue left, in a fixed order
-        const int nb_ = a.qsplit * (a.nb > 0 ? 2 : 1);               // the batches of a spin without electrons are never written
-        for (int t = tid; t < nb_ * a.ncb; t += EF_THR) {
-            const int b = t / a.ncb, ct = t % a.ncb;
+        // (the batches of a spin without electrons are never written; two-pass scheme: qsplit IS the batches of a pass)
+        const int nb_ = a.closed_try ? a.qsplit : a.qsplit * (a.nb > 0 ? 2 : 1);
+        const bool closed = a.closed_try && *a.closed_bad < a.closed_epoch;
+        const int npass = a.closed_try && !closed ? 2 : 1;
+        for (int t = tid; t < npass * nb_ * a.ncb; t += EF_THR) {
+            const int b = t / a.ncb, ct = t % a.ncb;             // (the second pass's batches lie right behind the first's)
             const cplx v = a.Eq[((long)b * a.nw + w) * a.ncb + ct];
             exr += v.x; exi += v.y;
         }
+        if (closed) { exr *= 2.0; exi *= 2.0; }
     }
     // Coulomb
     double ecr = 0, eci = 0;
@@ -514,8 +527,9 @@ static int ensure_atil(afq_handle *h) {
     return AFQ_OK;
 }
 
+// (*S_out: contraction slices per spin of the un-split scheme; *two_pass: alpha and beta in two launches of 2 S slices each)
 template <bool RC>
-static int launch_exx_quadratic(afq_handle *h) {
+static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     const int M = h->M;
     const long nma = (long)h->na * M, nmb = (long)h->nb * M, nmax = nma > nmb ? nma : nmb;
     // contraction slices: enough 64 x 64 work-group tiles to fill the chip about twice
@@ -525,12 +539,30 @@ static int launch_exx_quadratic(afq_handle *h) {
     if (S > EXQ_MAX_BATCH / 2) S = EXQ_MAX_BATCH / 2;
     while (S > 1 && nmax / S < 64) --S;
     if (afq_knob("AFQ_EXQ_SPLIT")) S = atoi(afq_knob("AFQ_EXQ_SPLIT"));
+    // Closed-shell population (every walker's Ghalf_b == Ghalf_a, verified on the device by the Green's function launch this
+    // Ghalf comes from: closed_checked_version) and one Atil for both spins: the 2 S slices of the FIRST launch all belong to
+    // spin alpha (every XCD busy), the second launch holds spin beta's and returns at once on the device when the flag says
+    // closed; energy_finish_kernel then counts the alpha sums twice.  Nothing is decided on the host.
+    const bool closed_try = h->closed_bad && h->closed_checked_version == h->ghalf_version && h->closed_checked_version != 0 &&
+                            h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !afq_knob("AFQ_NO_CLOSED_EXX");
+    // (slices per spin: the same S as in the two-spin launch -- with 2 S the work-groups' contractions halve and the launch
+    //  loses a third of its rate: 88 against 68 us at C3)
+    int SL = closed_try ? 2 * S : S;
+    if (closed_try && afq_knob("AFQ_EXQ_CLOSED_SL")) SL = atoi(afq_knob("AFQ_EXQ_CLOSED_SL"));
+    if (SL > EXQ_MAX_BATCH) SL = EXQ_MAX_BATCH;
+    const int NB = closed_try ? SL : 2 * S;                      // batches of one launch
     ExxQProb<RC> p;
-    p.batch = 2 * S; p.rows = h->nw; p.cols = (int)nmax; p.astride = (long)h->nt * M;
+    p.batch = NB; p.rows = h->nw; p.cols = (int)nmax; p.astride = (long)h->nt * M;
     p.ghalf = h->ghalf; p.zero = (const cplx *)h->zero_page;
+    p.skip_flag = nullptr; p.skip_epoch = 0;
+    const int npass = closed_try ? 2 : 1;
+    // (ONE event pair around both launches: with a closed-shell population the second is a few microseconds of work-groups
+    //  that return at once, and the pair times what the evaluation costs)
+    KernelTrace kt(h, AFQ_K_EXCHANGE);
+    for (int pass = 0; pass < npass; ++pass) {
     int kmax = 0;
-    for (int b = 0; b < 2 * S; ++b) {
-        const int s = b / S, sl = b % S;
+    for (int b = 0; b < NB; ++b) {
+        const int s = closed_try ? pass : b / S, sl = closed_try ? b : b % S;
         const long tot = s == 0 ? nma : nmb;
         if (tot == 0) { p.goff[b] = 0; p.soff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; p.k0[b] = 0; continue; }
         const long ldq = (tot + 1) & ~1L;
@@ -538,8 +570,8 @@ static int launch_exx_quadratic(afq_handle *h) {
         // tot (1 - sqrt(1 - s / S)) (rounded to whole k-chunks); every slice is one batch = one XCD's share
         auto bound = [&](int x) -> long {
             if (x <= 0) return 0;
-            if (x >= S) return tot;
-            long r = (long)((double)tot * (1.0 - std::sqrt(1.0 - (double)x / S)));
+            if (x >= SL) return tot;
+            long r = (long)((double)tot * (1.0 - std::sqrt(1.0 - (double)x / SL)));
             r = (r + 7) & ~7L;
             return r > tot ? tot : r;
         };
@@ -553,20 +585,20 @@ static int launch_exx_quadratic(afq_handle *h) {
     }
     p.kdim = kmax;
     p.ncb = (int)((nmax + 15) / 16);
-    const size_t need = (size_t)2 * S * h->nw * p.ncb;
+    const size_t per_pass = (size_t)NB * h->nw * p.ncb, need = per_pass * npass;
     if (h->exq_y_len < need) {
         if (h->exq_y) hipFree(h->exq_y);
         AFQ_HIP(h, hipMalloc(&h->exq_y, sizeof(cplx) * need));
         h->exq_y_len = need;
     }
-    p.E = h->exq_y;
+    p.E = h->exq_y + per_pass * pass;
+    if (pass == 1) { p.skip_flag = h->closed_bad; p.skip_epoch = h->closed_epoch; }
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
     // (round 4: the loader-wave configuration for long contractions too: C5 sizes 6.63 -> 6.36 ms per evaluation)
     const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : 1;
     {
-        KernelTrace kt(h, AFQ_K_EXCHANGE);
-        {   // every configuration below multiplies 64 x 64 work-group tiles; the contraction of a tile is its KCUT length
+        if (pass == 0) {   // every configuration below multiplies 64 x 64 work-group tiles; the contraction of a tile is its KCUT length
             auto klen = [&](int b, int col0, int ncols) -> long {
                 const long need = (long)col0 + ncols - p.k0[b];
                 return need <= 0 ? 0 : (need < p.len[b] ? need : p.len[b]);
@@ -601,7 +633,9 @@ static int launch_exx_quadratic(afq_handle *h) {
 #endif
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
     }
-    return S;
+    }   // pass
+    *S_out = closed_try ? NB : S; *two_pass = closed_try;        // (two-pass: batches per pass)
+    return AFQ_OK;
 }
 
 int k_energy_generic(afq_handle *h) {
@@ -619,13 +653,16 @@ int k_energy_generic(afq_handle *h) {
         quadratic = false;
     }
     if (quadratic) {
-        const int S = h->rchol_real ? launch_exx_quadratic<false>(h) : launch_exx_quadratic<true>(h);
-        if (S < 0) return S;
+        int S = 0;
+        bool closed_try = false;
+        rc = h->rchol_real ? launch_exx_quadratic<false>(h, &S, &closed_try) : launch_exx_quadratic<true>(h, &S, &closed_try);
+        if (rc) return rc;
         EFinArgs f;
         f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
         f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = nullptr;
         f.energy = h->energy; f.Eq = h->exq_y; f.qsplit = S; f.na = h->na; f.nb = h->nb;
         f.ncb = (int)(((long)(h->na > h->nb ? h->na : h->nb) * M + 15) / 16);
+        f.closed_try = closed_try ? 1 : 0; f.closed_bad = h->closed_bad; f.closed_epoch = h->closed_epoch;
         AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
         AFQ_POST(h);
         return AFQ_OK;
@@ -668,6 +705,7 @@ int k_energy_generic(afq_handle *h) {
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
     f.energy = h->energy; f.Eq = nullptr; f.qsplit = 0; f.na = h->na; f.nb = h->nb; f.ncb = 0;
+    f.closed_try = 0; f.closed_bad = nullptr; f.closed_epoch = 0;
     AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
     AFQ_POST(h);
     return AFQ_OK;

@@ -103,6 +103,8 @@ struct GreensArgs {
     int psi_real;       // every imaginary part of the (single, shared) trial is exactly zero (checked at upload)
     int skip_spin;      // with gsum: do not store the per-spin Ghalf (nobody will read it: afq_propagate_finish)
     int psi_closed;     // the alpha and beta blocks of the (single, shared) trial are bitwise equal, na == nb (checked at upload)
+    unsigned long long *closed_bad;     // raised to closed_epoch by a walker whose spin blocks differ (afq_internal.h), or null
+    unsigned long long closed_epoch;
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
                 same &= (__double_as_longlong(x.x) == __double_as_longlong(y.x)) & (__double_as_longlong(x.y) == __double_as_longlong(y.y));
             }
             closed = __syncthreads_and(same) != 0;
+            if (!closed && tid == 0 && a.closed_bad) atomicMax(a.closed_bad, a.closed_epoch);
         }
         for (int t = wave; t < ((a.dbg & 4) || (closed && g == 1) ? 0 : nt16 * nt16); t += 4) {
             const int ti = t / nt16, tj = t % nt16;
@@ -781,6 +784,8 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
     a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !afq_knob("AFQ_NO_CLOSED_GREENS");
+    a.closed_bad = nullptr; a.closed_epoch = 0;
+    if (ghalf == h->ghalf) h->closed_checked_version = 0;       // (set again below when THIS launch checks every walker)
     a.skip_spin = 0;
     const int nmax = h->na > h->nb ? h->na : h->nb;
     if (nmax > 256) AFQ_FAIL(h, AFQ_EUNSUPPORTED, "more than 256 electrons per spin");
@@ -855,6 +860,11 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
                 if (!h->ghalf_sum) AFQ_HIP(h, hipMalloc(&h->ghalf_sum, sizeof(cplx) * (size_t)h->na * h->M * h->nw));
                 a.gsum = h->ghalf_sum;
                 if (h->ghalf_skip_store && (wgj_on || tiny) && !oinv) { a.skip_spin = 1; h->ghalf_skipped = true; }
+            }
+            if (want_sum && wgj_on && !tiny && a.psi_closed && !oinv) {
+                // this launch compares the spin blocks of EVERY walker: its verdict holds for the Ghalf it leaves behind
+                a.closed_bad = h->closed_bad; a.closed_epoch = ++h->closed_epoch;
+                h->closed_checked_version = h->ghalf_version;
             }
             KernelTrace kt(h, AFQ_K_GREENS);
             if (tiny) {
@@ -2007,7 +2017,9 @@ int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights) {
     // cloned walkers bring their Ghalf along, and its spin sum when that is current (it then stays current)
     const bool sum_too = with_greens && h->ghalf_sum && h->gsum_version == h->ghalf_version;
     const bool diag_too = with_greens && h->gdiag && h->gdiag_version == h->ghalf_version;
+    const bool closed_too = with_greens && h->closed_checked_version == h->ghalf_version;   // clones are whole walkers
     ++h->ghalf_version;
+    if (closed_too) h->closed_checked_version = h->ghalf_version;
     if (sum_too) h->gsum_version = h->ghalf_version;
     if (diag_too) h->gdiag_version = h->ghalf_version;
     CloneArgs a;

@@ -373,3 +373,56 @@ def test_windows_above_512_walkers_per_rank_start_smaller_than_the_population_an
     st = ranks[0].comm_stats()
     assert st['overflow'] == 0 and st['max_transfer'] == nw and st['error'] == 0
     close_all([one] + ranks)
+
+
+@pytest.mark.parametrize("open_walker", [False, True])
+def test_closed_shell_verdict_covers_walkers_received_from_another_rank(open_walker):
+    """The one-spin exchange energy (k_energy.hip: launch_exx_quadratic) rests on a device flag that says every walker's
+    cached Ghalf has equal spin blocks.  Walkers that arrive from another rank bring their Ghalf along, so the unpack kernel
+    checks them: rank 0 holds closed walkers only, rank 1 a heavy walker -- closed, or open (beta block different) -- whose
+    clones land on rank 0.  Energies after the exchange against the oracle on every walker of both ranks
+    (estimators/generic.py:49-83 through the walkers' own Green's functions)."""
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.propagation import setup
+    M, N, K, nw, nranks = 40, 13, 30, 36, 2
+    s = systems.synthetic_generic(M, K, (N, N), seed=7)
+    t = trial_mod.rhf_trial_generic(s)
+    dt = 0.005
+    BH1, mf = setup.generic_propagator_arrays(s, t, dt)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, dt, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=s.ecore)
+    rng = numpy.random.RandomState(91)
+    ntot = nranks * nw
+    half = t.psi[None, :, :N] + 0.05 * (rng.rand(ntot, M, N) + 1j * rng.rand(ntot, M, N))
+    phis = numpy.concatenate([half, half], axis=2)
+    heavy = nw + 5
+    if open_walker:
+        phis[heavy, :, N:] += 0.03 * (rng.rand(M, N) + 1j * rng.rand(M, N))
+    weights = numpy.ones(ntot)
+    weights[heavy] = 9.0
+    weights[:6] = 0.05                                                  # rank 0 loses walkers, rank 1's heavy one fills the slots
+    ots = numpy.array([ref.calc_overlap(p, model.psi, N, N) for p in phis])
+    ranks = [make_device(model, nw) for _ in range(nranks)]
+    for i, rk in enumerate(ranks):
+        sl = slice(i * nw, (i + 1) * nw)
+        rk.set(L.F_PHI, phis[sl]); rk.set(L.F_OT, ots[sl]); rk.set(L.F_WEIGHT, weights[sl])
+    devmod.comm_init_local(ranks)
+    xi = rng.normal(size=(ntot, K))
+    for i, rk in enumerate(ranks):
+        rk.propagate(xi[i * nw:(i + 1) * nw], -0.1)                     # leaves the end-of-step Green's functions behind
+        rk.set(L.F_WEIGHT, weights[i * nw:(i + 1) * nw])
+    pix, _ = devmod.popcontrol_comb_local(ranks, 0.37, ntot)
+    assert pix[heavy] > 1 and any(pix[w] == 0 for w in range(nw)), pix
+    for i, rk in enumerate(ranks):
+        E = rk.local_energy()
+        out = rk.get(L.F_PHI)
+        n_open = 0
+        for w in range(nw):
+            is_open = not numpy.array_equal(out[w, :, :N], out[w, :, N:])
+            n_open += is_open
+            _, gh_ref, G_ref = ref.greens_function(out[w], model.psi, N, N)
+            e_ref = numpy.array(model.local_energy(G_ref, gh_ref))
+            assert numpy.max(numpy.abs(E[w] - e_ref)) <= 1e-10 * max(1.0, numpy.max(numpy.abs(e_ref))), (i, w, is_open)
+        if i == 0:
+            assert (n_open > 0) == open_walker, n_open                  # the heavy walker's clones did land on rank 0
+    close_all(ranks)

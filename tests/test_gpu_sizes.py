@@ -670,6 +670,26 @@ def test_closed_shell_walkers_take_the_one_spin_path_of_the_greens_kernel(M, N):
     for w in (0, 1, 2, 5, nw - 1):
         _, gh_ref, G_ref = ref.greens_function(phis[w], model.psi, N, N)
         close(xbar[w], model.force_bias(gh_ref, G_ref), 1e-10)
+    # the exchange energy of a population that is NOT closed as a whole: the device flag sends the beta launch through
+    E = dev.local_energy()
+    for w in (0, 1, 2, 5, nw - 1):
+        _, gh_ref, G_ref = ref.greens_function(phis[w], model.psi, N, N)
+        close(E[w], numpy.array(model.local_energy(G_ref, gh_ref)), 1e-10)
+    # ... and of a closed one (every walker): one spin evaluated, counted twice -- against the oracle, and against the two-spin
+    # evaluation of the same walkers (the T-intermediate algorithm, which has no one-spin path)
+    closed_phis = numpy.concatenate([half, half], axis=2)
+    dev.set(L.F_PHI, closed_phis)
+    dev.greens(want_G=False)
+    E_closed = dev.local_energy()
+    for w in (0, 2, 7, nw - 1):
+        _, gh_ref, G_ref = ref.greens_function(closed_phis[w], model.psi, N, N)
+        close(E_closed[w], numpy.array(model.local_energy(G_ref, gh_ref)), 1e-10)
+    dev.set_exchange_algorithm(1)
+    dev.greens(want_G=False)
+    close(dev.local_energy(), E_closed, 1e-11)
+    dev.set_exchange_algorithm(0)
+    dev.set(L.F_PHI, phis)
+    det = dev.greens(want_G=False)
     # the invariant: closed walkers stay closed through steps and the re-orthogonalisation, bit for bit
     dev.set(L.F_OT, det)
     for step in range(2):
