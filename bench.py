@@ -860,7 +860,8 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                       and numpy.array_equal(phi_now[:, :, :N], phi_now[:, :, N:]))
     if closed_pop:
         b_, w_, wr_, n_ = wt["launch_exx_quadratic"]
-        wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice")
+        wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice "
+                                        "(kernel_ms = the alpha launch + the ExxQBetaProb launch that returns at once, ~3.4 us)")
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex

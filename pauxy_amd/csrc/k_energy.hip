@@ -276,6 +276,10 @@ struct ExxQProb {
     }
 };
 
+// The beta-spin launch of a closed-shell try (launch_exx_quadratic): the same problem under its own name, so that a kernel
+// trace separates the launches that return at once from the ones that multiply.
+template <bool RC> struct ExxQBetaProb : ExxQProb<RC> {};
+
 // A = R R^T (unconjugated) for one spin, stored permuted: out[(j,p),(i,q)] = A[(i,p),(j,q)].  One-time set-up
 // kernel: 64 x 64 tiles, 16 contraction indices per LDS stage, 4 x 4 outputs per thread on the fp64 vector ALU.
 template <bool RC>
@@ -545,8 +549,8 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     // closed; energy_finish_kernel then counts the alpha sums twice.  Nothing is decided on the host.
     const bool closed_try = h->closed_bad && h->closed_checked_version == h->ghalf_version && h->closed_checked_version != 0 &&
                             h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !afq_knob("AFQ_NO_CLOSED_EXX");
-    // (slices per spin: the same S as in the two-spin launch -- with 2 S the work-groups' contractions halve and the launch
-    //  loses a third of its rate: 88 against 68 us at C3)
+    // (slices of the one-spin launch: 2 S, as many work-groups as the two-spin launch has.  C3, us per evaluation: S = 4
+    //  slices 106.6, 5 100.9, 6 96.9, 7 91.4, 8 = 2 S 96.9, 10 139.8, 16 107.3; the two-spin launch 138.9)
     int SL = closed_try ? 2 * S : S;
     if (closed_try && afq_knob("AFQ_EXQ_CLOSED_SL")) SL = atoi(afq_knob("AFQ_EXQ_CLOSED_SL"));
     if (SL > EXQ_MAX_BATCH) SL = EXQ_MAX_BATCH;
@@ -610,7 +614,13 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
         // compute waves with 1 x 2 tiles that refill the ring themselves (cfg 9, the round-3 choice)
         // round 5: a complex Atil (3-multiplication products, 144 VGPRs) on the lean loop at two work-groups per CU
         // (k_apply_exponential in k_gemm.hip): 9.95 -> 9.74 ms per determinant at C5; the real one (99 VGPRs) is two per CU anyway
-        if (cfg == 1 && RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
+        if (cfg == 1 && pass == 1) {
+            ExxQBetaProb<RC> pb;
+            static_cast<ExxQProb<RC> &>(pb) = p;
+            if (RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(pb, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(pb, h->stream, h->zero_page)));
+        }
+        else if (cfg == 1 && RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 1 || cfg == 16) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
         else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
 #ifdef AFQ_TUNING
