@@ -920,8 +920,18 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     if not rows:
         raise RuntimeError("no traced kernel launches in the timed region")
     dom = max(rows, key=lambda r: r["ms_per_step"])
+    dominant_note = None
     if not dom["measured"].startswith("timed region"):
-        raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
+        if world > torch.cuda.device_count():
+            # several ranks share a GPU (AFQ_BENCH_BACKEND=gloo: the functional check of the multi-rank path): a rank's
+            # kernels run between those of the other ranks and their event-timed durations include the waiting -- which
+            # kernel looks longest is noise.  The roofline stays on the kernel traced inside the timed region, and says so.
+            dominant_note = ("ranks share a GPU: %s took longer per step in the extra pass (%.4f ms against %.4f), "
+                             "durations include other ranks' kernels" % (dom["kernel"].split(" ")[0], dom["ms_per_step"],
+                                                                        max(r["ms_per_step"] for r in rows if r["measured"].startswith("timed region"))))
+            dom = max((r for r in rows if r["measured"].startswith("timed region")), key=lambda r: r["ms_per_step"])
+        else:
+            raise RuntimeError("dominant kernel %s was not traced inside the timed region" % dom["kernel"])
     for r in rows:
         if not (r["frac"] <= 1.0 and r.get("frac_issued", 0.0) <= 1.0):
             raise RuntimeError("kernel %r priced above the peak (frac %.3f, issued %.3f): the timed launch cannot be doing the "
@@ -1014,6 +1024,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                          "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel_ms": dom["avg_ms"], "launches": dom["launches"], "measured": dom["measured"],
+                         "dominant_note": dominant_note,
                          "flops_per_launch": dom["flops_per_launch"],
                          "issued_flops_per_launch": dom.get("issued_flops_per_launch"),
                          # BASELINE's second figure: fp64 MFMA fraction of the Cholesky energy contraction
