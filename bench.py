@@ -728,6 +728,14 @@ def main():
         dist.destroy_process_group()
 
 
+def last_block_energy(afqmc):
+    try:
+        blocks = afqmc.estimators.estimators['mixed'].blocks
+        return float(numpy.real(blocks[-1][6])) if blocks else None
+    except Exception:
+        return None
+
+
 def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, with_cpu_baseline):
     import torch
     from pauxy_amd.qmc.afqmc import AFQMC
@@ -841,10 +849,14 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     # of 4 blocks right after it; algorithmic flops per launch as in DESIGN.md.
     traced = {kind: dev.kernel_trace_get(kind) for kind in in_region}
     extra_steps = 4 * NSTEPS_BLOCK
+    dev.counters(reset=True)
     dev.kernel_trace(True)
     afqmc.run_batched(extra_steps, first_step=first, eshift=eshift)
     dev.sync()
     dev.kernel_trace(False)
+    # walker steps the fused propagator took through its closed-shell deal (spin blocks bitwise equal, checked per walker in
+    # the kernel: column slot 1 = [beta 0..15], the twin of slot 0, left out of the Taylor products)
+    closed_prop = float(dev.counters()[3]) / (extra_steps * nw)
     nt = 2 * N
     rc = numpy.asarray(trial._rchol)
     fb_same_spin_block = bool(numpy.array_equal(rc[:N * M], rc[N * M:2 * N * M]))
@@ -862,8 +874,23 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         b_, w_, wr_, n_ = wt["launch_exx_quadratic"]
         wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice "
                                         "(kernel_ms = the alpha launch + the ExxQBetaProb launch that returns at once, ~3.4 us)")
+    prop_note = ""
+    prop_issued_scale = 0.0
+    if closed_prop > 0.0:
+        # executed work: the Taylor products of a closed-shell walker run on na + nb - 16 of its na + nb columns; SURVEY's
+        # count (frac_survey) stays what the reference does for the same walkers
+        b_, w_, wr_, n_ = wt["prop_fused_kernel"]
+        ob_ = 4.0 if b_real else 8.0
+        cols = nt - 16.0 * closed_prop
+        wt["prop_fused_kernel"] = (b_, w_, M * M * (8.0 * 6 * cols + ob_ * 2 * nt) * nw, n_)
+        prop_note = ("; closed-shell walkers (%.0f %% of the walker steps): Taylor products on %d of %d columns, `frac` prices "
+                     "the executed columns" % (100.0 * closed_prop, nt - 16, nt))
+        # matrix-pipe flops of the left-out slot: 6 full tiles + 1 remainder unit per k-step, 3 multiplications, 6 orders
+        nch = (M + 7) // 8
+        slot1 = 3.0 * 6 * (2.0 * nch) * (2048.0 * 6 + 512.0) * nw
+        prop_issued_scale = -closed_prop * slot1
     kernels = [
-        ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker)", L.K_PROPAGATOR, wt["prop_fused_kernel"]),
+        ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker%s)" % prop_note, L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
         # GEMM per spin) executes 4 (N M)^2 flops per spin and walker -- K / M = 5 times fewer than the
         # T-intermediate formulation of the reference (4 K M N^2); both counts are reported
@@ -898,6 +925,8 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         # flops the matrix pipe actually executes per launch (MFMA instructions x their flop count, padding
         # included, 3-multiplication complex products counted as 3): what `frac_issued` = pipe utilisation is priced on
         issued = dev.kernel_issued_flops(kind)
+        if kind == L.K_PROPAGATOR and closed_prop > 0.0:
+            issued += prop_issued_scale                   # (the library reports the full deal's count; see above)
         if issued > 0:
             extra["issued_flops_per_launch"] = issued
             extra["frac_issued"] = issued / (avg * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
@@ -1013,6 +1042,9 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                           (None if world == 1 else "no device communicator: " + (comm_note or "not requested")),
             "exchange_timing": exchange_timing,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+            # (device Philox streams: the same library gives the same number every run; kernel variants that claim
+            #  bit-equal results can be held against it)
+            "last_block_ETotal": last_block_energy(afqmc),
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "frac_survey": dom.get("frac_survey"),

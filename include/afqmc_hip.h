@@ -424,7 +424,8 @@ int afq_rng_philox4x32(afq_handle *h, const uint32_t *ctr_key, uint32_t *out, in
 int afq_debug(afq_handle *h, int sync_every_launch, int markers);
 int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_t *retired);
 /* counters: [0]=nfb_trig (continuous.py:150), [1]=nhe_trig (:210,213), [2]=overlap matrices the blocked
- * Gauss-Jordan flagged as poorly conditioned block-wise and handed to the step-by-step kernel (diagnostic)   */
+ * Gauss-Jordan flagged as poorly conditioned block-wise and handed to the step-by-step kernel (diagnostic),
+ * [3]=walker steps the fused propagator took through its closed-shell deal (spin blocks bitwise equal)       */
 int afq_counters(afq_handle *h, int64_t *out, int reset);
 /* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields
  * [3] vhs [4] exponential [5] overlap+weight [6] reortho [7] energy            */

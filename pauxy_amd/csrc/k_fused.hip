@@ -76,6 +76,8 @@ struct PropFusedArgs {
                                 // a 16..23, b 16..23 | a 24.., b 24..] so that a column and its twin of the other spin always go
                                 // through the same code and MFMA shape (slots 0, 1: taylor; slot 2: taylor_h's tile; slot 3:
                                 // 4x4x4 units): the spin blocks of a closed-shell walker stay bitwise equal through the step
+    int closed_try;             // symcols: a walker whose spin blocks are bitwise equal (checked on the LDS image, every launch)
+                                // skips column slot 1 -- the twin of slot 0 -- in the Taylor products (closed-shell deal below)
     int contig;                 // the columns of T are the na + nb columns of the walker back to back (slot = column / 16)
                                 // instead of two slots per spin: every matrix of the chain acts on both spins alike
     const cplx *BH1;            // [2, M, M]
@@ -83,6 +85,7 @@ struct PropFusedArgs {
     cplx *phi;                  // [nw, M, nt], updated in place
     const int *alive;
     const void *zero16;
+    unsigned long long *n_closed;   // afq_counters [3]: walkers that took the closed-shell deal
 };
 
 __device__ inline d2_t lds_read_c(unsigned addr) { return lds_read_b128(addr); }
@@ -262,6 +265,25 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
     }
     __syncthreads();
+    // Closed-shell walker (symcols layout: every alpha column has its beta twin at a fixed distance inside T): every matrix
+    // of the chain acts on both spins alike and twins go through the same code, so slot 1 = [b 0..15] would stay the bitwise
+    // copy of slot 0 = [a 0..15] through all the products -- the Taylor stage leaves it out and copies it back at the end.
+    bool closed = false;
+    if (a.closed_try) {
+        const int extra = a.na - 24;
+        bool same = true;
+        for (int e = tid; e < NCH * 512; e += PF_NT) {
+            const int j = e & 15, slot = (e >> 7) & 3;
+            const int tw = slot == 0 ? e + 128 : (slot == 2 && j < 8) ? e + 8 : (slot == 3 && j < extra) ? e + extra : -1;
+            if (tw >= 0) {
+                const d2_t x = ((const d2_t *)Tf)[e], y = ((const d2_t *)Tf)[tw];
+                same = same && __double_as_longlong(x[0]) == __double_as_longlong(y[0]) &&
+                       __double_as_longlong(x[1]) == __double_as_longlong(y[1]);
+            }
+        }
+        closed = __builtin_amdgcn_readfirstlane(__syncthreads_and(same ? 1 : 0)) != 0;
+        if (closed && tid == 0) atomicAdd(a.n_closed, 1ULL);
+    }
 
     // accumulator-layout address of element (row tile ti, reg r) of column slot cs for this lane
     auto t_ok = [&](int ti, int r) -> bool { return 2 * ti + (r >> 1) < NCH; };   // rows past the last chunk do not exist
@@ -1154,7 +1176,34 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 else if (wave == 5) taylor(I1{}, I2{}, std::true_type{}, 5, 0, 1, std::false_type{});
                 else taylor_h(std::true_type{}, std::true_type{}, nu, 4, 2, 3, 2);
             };
-            if (a.hyb == 2) deal(I2{});
+            // Closed-shell walker: slot 1 left out -- 12 full tiles, 6 NU units and 3 remainder units, per k-step:
+            //   waves 0, 1   row tiles (0,1) / (2,3) x [slot 2 | unit slot 3]                      384 + 96 NU
+            //   wave 2       row tiles (0,1) x slot 0                                              384
+            //   waves 6, 3, 5   row tile 2 / 3 / 5 x slot 0                                        192
+            //   wave 4       row tile 4 x slot 0 + remainder unit of slot 0                        240
+            //   wave 7       row tiles 4, 5 x [slot 2 | unit slot 3] + remainder units of 2, 3     384 + 96 NU + 96
+            // i.e. 720 / 672 / 576 / 768 cycles on the four SIMDs at NU = 1 instead of 1008 / 864 / 1008 / 1056.  Every tile
+            // goes through the code it goes through in the deal above (taylor for slot 0, taylor_h for slots 2, 3): the
+            // results are bit for bit the same.
+            auto closed_deal = [&](auto nu) __attribute__((always_inline)) {
+                if (wave == 0 || wave == 1) taylor_h(std::true_type{}, std::false_type{}, nu, 2 * wave, 2, 3, 0);
+                else if (wave == 2) taylor(I2{}, I1{}, std::false_type{}, 0, 0, 2, std::false_type{});
+                else if (wave == 4) taylor(I1{}, I1{}, std::true_type{}, 4, 0, 1, std::true_type{});
+                else if (wave == 7) taylor_h(std::true_type{}, std::true_type{}, nu, 4, 2, 3, 2);
+                else taylor(I1{}, I1{}, std::true_type{}, wave == 6 ? 2 : wave, 0, 1, std::false_type{});
+            };
+            if (closed) {
+                if (a.hyb == 2) closed_deal(I2{});
+                else closed_deal(I1{});
+                // T(slot 1) = T(slot 0) for the closing one-body pass, which multiplies all four slots
+                lds_barrier();
+                for (int e = tid; e < NCH * 128; e += PF_NT) {
+                    const int ch = e >> 7, i = e & 127;
+                    ((d2_t *)Tf)[ch * 512 + 128 + i] = ((const d2_t *)Tf)[ch * 512 + i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            else if (a.hyb == 2) deal(I2{});
             else deal(I1{});
         }
     }
@@ -1229,7 +1278,9 @@ int k_prop_fused(afq_handle *h) {
         a.hyb = (h->nt - 48 + 3) / 4;
     }
     a.symcols = (a.contig && h->na == h->nb && !afq_knob("AFQ_PF_NOSYM")) ? 1 : 0;
+    a.closed_try = (a.symcols && h->exp_order > 0 && !afq_knob("AFQ_PF_NOCLOSED")) ? 1 : 0;
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
+    a.n_closed = h->counters + 3;
     const int NCH = (h->M + 7) / 8;
     const size_t lds = (size_t)NCH * 8192 + (size_t)PF_D * 16384;
     static size_t lds_set[6][AFQ_MAX_DEVICES] = {{0}, {0}, {0}, {0}, {0}, {0}};

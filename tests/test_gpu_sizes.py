@@ -632,7 +632,7 @@ def test_badly_scaled_operands_through_the_three_multiplication_products(M, na, 
         assert comp <= 1e-10, (k, comp)
 
 
-@pytest.mark.parametrize("M,N", [(100, 25), (40, 13), (64, 32)])
+@pytest.mark.parametrize("M,N", [(100, 25), (100, 27), (98, 28), (40, 13), (64, 32)])
 def test_closed_shell_walkers_take_the_one_spin_path_of_the_greens_kernel(M, N):
     """An RHF trial (alpha block == beta block) and walkers whose spin blocks are bitwise equal -- what an RHF run with a
     spin-free propagator produces -- let greens_small_kernel compute ONE spin (checked per walker, in LDS, every call):
@@ -692,9 +692,21 @@ def test_closed_shell_walkers_take_the_one_spin_path_of_the_greens_kernel(M, N):
     det = dev.greens(want_G=False)
     # the invariant: closed walkers stay closed through steps and the re-orthogonalisation, bit for bit
     dev.set(L.F_OT, det)
+    dev.counters(reset=True)
     for step in range(2):
-        dev.propagate(rng.normal(size=(nw, K)), -0.1)
+        xi = rng.normal(size=(nw, K))
+        dev.propagate(xi, -0.1)
         if step == 0:
+            # (afq_counters [3]: the closed-shell deal exists for 96 < M <= 100, 48 < 2 N <= 56 and ran for exactly the closed walkers)
+            took = int(dev.counters()[3])
+            assert took == (int((~mixed).sum()) if (96 < M <= 100 and 48 < 2 * N <= 56) else 0), took
+            # the step itself against the oracle, closed walkers (the fused propagator's closed-shell deal at 48 < 2 N <= 56:
+            # column slot 1 left out of the Taylor products and copied back) and open ones (the full deal) alike
+            out = dev.get(L.F_PHI)
+            for w in (0, 1, 2, 3, 5, nw - 1):
+                wk = ref.new_walker(model, phis[w])
+                ref.propagate_walker_phaseless(model, wk, xi[w], -0.1)
+                close(out[w], wk['phi'], 1e-10)
             dev.reortho()
     out = dev.get(L.F_PHI)
     for w in range(nw):
