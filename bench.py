@@ -877,18 +877,21 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     prop_note = ""
     prop_issued_scale = 0.0
     if closed_prop > 0.0:
-        # executed work: the Taylor products of a closed-shell walker run on na + nb - 16 of its na + nb columns; SURVEY's
-        # count (frac_survey) stays what the reference does for the same walkers
+        # executed work: the Taylor products of a closed-shell walker run on its alpha half (na of the na + nb columns; the
+        # one-body passes multiply all of them); SURVEY's count (frac_survey) stays what the reference does for the same walkers
         b_, w_, wr_, n_ = wt["prop_fused_kernel"]
         ob_ = 4.0 if b_real else 8.0
-        cols = nt - 16.0 * closed_prop
+        cols = nt - N * closed_prop
         wt["prop_fused_kernel"] = (b_, w_, M * M * (8.0 * 6 * cols + ob_ * 2 * nt) * nw, n_)
-        prop_note = ("; closed-shell walkers (%.0f %% of the walker steps): Taylor products on %d of %d columns, `frac` prices "
-                     "the executed columns" % (100.0 * closed_prop, nt - 16, nt))
-        # matrix-pipe flops of the left-out slot: 6 full tiles + 1 remainder unit per k-step, 3 multiplications, 6 orders
+        prop_note = ("; closed-shell walkers (%.0f %% of the walker steps): Taylor products on the alpha half, %d of %d columns; "
+                     "`frac` prices the executed columns" % (100.0 * closed_prop, N, nt))
+        # matrix-pipe flops per k-step of 4: the library reports the full deal of this shape (contiguous columns: 18 tiles of
+        # 16 x 16, 6 + 4 units of 4 x 4 x 4 lanes), a closed-shell walker issues 12 tiles + 2 remainder units (two column
+        # slots of the alpha half x six row tiles + the 4-row remainder); 3 multiplications per complex product, 6 orders
         nch = (M + 7) // 8
-        slot1 = 3.0 * 6 * (2.0 * nch) * (2048.0 * 6 + 512.0) * nw
-        prop_issued_scale = -closed_prop * slot1
+        assert 96 < M <= 100 and 48 < nt <= 56 and N == nt // 2, "closed-shell issue count: the headline shape class"
+        per_kstep = (2048.0 * 18 + 512.0 * (6 * ((nt - 48 + 3) // 4) + 4)) - (2048.0 * 12 + 512.0 * 2)
+        prop_issued_scale = -closed_prop * 3.0 * 6 * (2.0 * nch) * per_kstep * nw
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker%s)" % prop_note, L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex

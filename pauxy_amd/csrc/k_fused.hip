@@ -76,8 +76,8 @@ struct PropFusedArgs {
                                 // a 16..23, b 16..23 | a 24.., b 24..] so that a column and its twin of the other spin always go
                                 // through the same code and MFMA shape (slots 0, 1: taylor; slot 2: taylor_h's tile; slot 3:
                                 // 4x4x4 units): the spin blocks of a closed-shell walker stay bitwise equal through the step
-    int closed_try;             // symcols: a walker whose spin blocks are bitwise equal (checked on the LDS image, every launch)
-                                // skips column slot 1 -- the twin of slot 0 -- in the Taylor products (closed-shell deal below)
+    int closed_try;             // one matrix for both spins, na == nb, a deal without holes: a walker whose spin blocks are bitwise
+                                // equal (checked in the kernel, every launch) takes the closed-shell deal of the Taylor products
     int contig;                 // the columns of T are the na + nb columns of the walker back to back (slot = column / 16)
                                 // instead of two slots per spin: every matrix of the chain acts on both spins alike
     const cplx *BH1;            // [2, M, M]
@@ -236,8 +236,31 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     };
     issueA(); issueA();                                          // PF_D - 1 chunks in flight
     prepare();
+    // ---- Closed-shell walker?  (spin blocks bitwise equal: checked on the walker itself, every launch, no state.)  Every
+    // matrix of the chain acts on both spins alike (closed_try: one one-body matrix, as many electrons of either spin), so the
+    // beta half would stay the bitwise copy of the alpha half through all the products: the Taylor stage multiplies the
+    // alpha half only (closed-shell deals below) and copies it into the beta half ahead of the closing one-body pass.
+    bool closed = false;
+    if (a.closed_try) {
+        bool same = true;
+        for (int p = tid >> 5; p < M; p += PF_NT / 32) {
+            const int c = tid & 31;
+            if (c < a.na) {
+                const cplx x = phi[p * nt + c], y = phi[p * nt + a.na + c];
+                same = same && __double_as_longlong(x.x) == __double_as_longlong(y.x) &&
+                       __double_as_longlong(x.y) == __double_as_longlong(y.y);
+            }
+        }
+        closed = __builtin_amdgcn_readfirstlane(__syncthreads_and(same ? 1 : 0)) != 0;
+        if (closed && tid == 0) atomicAdd(a.n_closed, 1ULL);
+    }
+    // Layout of T for THIS walker: the contiguous-column layout (a.contig) serves open-shell walkers; a closed-shell one takes
+    // the two-slots-per-spin layout [a0 a1 b0 b1], whose alpha half is three tiles per SIMD.  (Measured, C3, tuning build:
+    // 126.7 us; keeping the contiguous layout and leaving out its one wholly redundant slot [b 0..15] 145.3; neither 162.3.)
+    const bool relayout = closed && a.contig;
+    const int contig = relayout ? 0 : a.contig, hyb = relayout ? 0 : a.hyb;
     // T column -> walker column (identity unless a.symcols: see PropFusedArgs)
-    const int sym_n = a.symcols ? a.na : 0;
+    const int sym_n = (a.symcols && !relayout) ? a.na : 0;
     // (slots 0 and 1 are multiplied by the same code (taylor), slot 2 by taylor_h's full tile, slot 3 as 4x4x4 units -- three
     //  summation orders: a column and its twin must sit in the same KIND of slot: [a 0..15 | b 0..15 | a 16..23, b 16..23 |
     //  a 24.., b 24..])
@@ -258,32 +281,13 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     PF_UNLESS((32 | 128))
     for (int e = tid; e < NCH * 512; e += PF_NT) {
         const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
-        const int p = ch * 8 + 2 * kk + pb, sp = a.contig ? 0 : slot >> 1, col = (a.contig ? slot : slot & 1) * 16 + j;
-        const int ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const int p = ch * 8 + 2 * kk + pb, sp = contig ? 0 : slot >> 1, col = (contig ? slot : slot & 1) * 16 + j;
+        const int ns_ = contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
         const bool ok = p < M && col < ns_;
         const cplx v = phi[ok ? p * nt + off_ + wcol(col) : 0];
         ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
     }
     __syncthreads();
-    // Closed-shell walker (symcols layout: every alpha column has its beta twin at a fixed distance inside T): every matrix
-    // of the chain acts on both spins alike and twins go through the same code, so slot 1 = [b 0..15] would stay the bitwise
-    // copy of slot 0 = [a 0..15] through all the products -- the Taylor stage leaves it out and copies it back at the end.
-    bool closed = false;
-    if (a.closed_try) {
-        const int extra = a.na - 24;
-        bool same = true;
-        for (int e = tid; e < NCH * 512; e += PF_NT) {
-            const int j = e & 15, slot = (e >> 7) & 3;
-            const int tw = slot == 0 ? e + 128 : (slot == 2 && j < 8) ? e + 8 : (slot == 3 && j < extra) ? e + extra : -1;
-            if (tw >= 0) {
-                const d2_t x = ((const d2_t *)Tf)[e], y = ((const d2_t *)Tf)[tw];
-                same = same && __double_as_longlong(x[0]) == __double_as_longlong(y[0]) &&
-                       __double_as_longlong(x[1]) == __double_as_longlong(y[1]);
-            }
-        }
-        closed = __builtin_amdgcn_readfirstlane(__syncthreads_and(same ? 1 : 0)) != 0;
-        if (closed && tid == 0) atomicAdd(a.n_closed, 1ULL);
-    }
 
     // accumulator-layout address of element (row tile ti, reg r) of column slot cs for this lane
     auto t_ok = [&](int ti, int r) -> bool { return 2 * ti + (r >> 1) < NCH; };   // rows past the last chunk do not exist
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
             // the half-chunk pipeline of the Taylor products below (see there): refill, fragment reads and address
             // arithmetic between the MFMA groups of the sub-step in flight
             constexpr int NR = 1 + NSL;
-            constexpr int RPG = NSL > 1 ? (NR + NSL - 2) / (NSL - 1) : NR;
+            constexpr int RPG = NSL > 1 ? (NR + NSL - 2) / (NSL > 1 ? NSL - 1 : 1) : NR;
             d2_t a0, a1, b0[NSL], b1[NSL];
             auto half = [&](d2_t &ax, d2_t (&bx)[NSL], d2_t &ay, d2_t (&by)[NSL], const unsigned abase, const unsigned bbase,
                             const int ys, const bool fetch, const bool refill) __attribute__((always_inline)) {
@@ -456,14 +460,14 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NSL; ++j)
             if (cv[j]) {
-                const int cs = slot0 + j * SS, sp = a.contig ? 0 : cs >> 1;
-                const int ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+                const int cs = slot0 + j * SS, sp = contig ? 0 : cs >> 1;
+                const int ns_ = contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double re = BR ? P1[j][r] : P1[j][r] - P2[j][r];
                     const double im = BR ? P2[j][r] : P3[j][r] - P1[j][r] - P2[j][r];
                     if (to_global) {
-                        const int row = rt * 16 + lk_e + 4 * r, col = (a.contig ? cs : cs & 1) * 16 + lr_e;
+                        const int row = rt * 16 + lk_e + 4 * r, col = (contig ? cs : cs & 1) * 16 + lr_e;
                         PF_UNLESS(256)
                         if (row < M && col < ns_) phi[(long)row * nt + off_ + wcol(col)] = cmake(re, im);
                     } else if (t_ok(rt, r)) {
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // and needs no barrier at all
         int lk_e = lk, lr_e = lr, ln_e = lane;                   // laundered (see one_body)
         asm volatile("" : "+v"(lk_e), "+v"(lr_e), "+v"(ln_e));
-        const int sp = a.contig ? 0 : c0 >> 1, ns_ = a.contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
-        const int cb = (a.contig ? c0 : c0 & 1) * 16;            // first walker column of the slot (within the spin block)
+        const int sp = contig ? 0 : c0 >> 1, ns_ = contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const int cb = (contig ? c0 : c0 & 1) * 16;            // first walker column of the slot (within the spin block)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 // instead of two per chunk (the 2 x 2 deal needs every register it can get: 96 product + 64 sum).
                 constexpr int NG = NI * NJ + (REM ? 1 : 0);       // MFMA groups (one tile or unit: 3 MFMAs) per sub-step
                 constexpr int NR = NI + NJ + (REM ? 1 : 0);       // fragment reads per sub-step
-                constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG - 1) : NR;   // reads behind each group but the last
+                constexpr int RPG = NG > 1 ? (NR + NG - 2) / (NG > 1 ? NG - 1 : 1) : NR;   // reads behind each group but the last
                 d2_t a0[NI], b0[NJ], a1[NI], b1[NJ];              // sub-step 0 / sub-step 1 fragments
                 d2_t q0 = (d2_t){0.0, 0.0}, q1 = (d2_t){0.0, 0.0};   // remainder rows of the A operand, sub-step 0 / 1
                 auto half = [&](d2_t (&ax)[NI], d2_t (&bx)[NJ], d2_t &qx, d2_t (&ay)[NI], d2_t (&by)[NJ], d2_t &qy,
@@ -1127,6 +1131,16 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 #ifdef AFQ_TUNING
 #include "k_fused_t4.inc"      // taylor4(): the same products on v_mfma_f64_4x4x4 (tuning builds only)
 #endif
+    // closed-shell walker in the two-slots-per-spin layout: T(b0, b1) = T(a0, a1) behind the Taylor stage, for the closing
+    // one-body pass (which multiplies every slot)
+    auto mirror_spin = [&]() __attribute__((always_inline)) {
+        lds_barrier();
+        for (int e = tid; e < NCH * 256; e += PF_NT) {
+            const int ch = e >> 8, i = e & 255;
+            ((d2_t *)Tf)[ch * 512 + 256 + i] = ((const d2_t *)Tf)[ch * 512 + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 #if PF_NW == 16
     {
         // SIMD s (waves s, s + 4, s + 8, s + 12) owns column tile s: row tiles (0,1) (2,3) (4,5) (6); 7 tiles per SIMD
@@ -1142,7 +1156,14 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         // six row tiles, one column tile per spin: waves 0-3 a pair of the row tiles 0-3, waves 4-7 one of the tiles 4, 5
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2, std::false_type{});
+        if (closed) {
+            // closed-shell walker: the six tiles of slot a0, one per wave (waves 6, 7 repeat the row tiles 0, 1 -- the same
+            // bits to the same addresses -- so that every wave runs the chunk loop with its barriers and refills): two tiles
+            // per SIMD instead of three
+            taylor(I1{}, I1{}, std::false_type{}, wave < 6 ? wave : wave - 6, 0, 1, std::false_type{});
+            mirror_spin();
+        }
+        else if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave & 1), 2 * (wave >> 1), 2, std::false_type{});
         else taylor(I1{}, I1{}, std::false_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1, std::false_type{});
     }
     else if (NARROW) {
@@ -1155,9 +1176,9 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         else if (nrt <= 6) taylor(I2{}, I1{}, std::true_type{}, 4 + (wave & 1), 2 * ((wave - 4) >> 1), 1, std::false_type{});
         else taylor(I2{}, I1{}, std::true_type{}, (wave & 1) ? 6 : 4, 2 * ((wave - 4) >> 1), (wave & 1) ? 1 : 2, std::false_type{});
     }
-    else if (FULL == 7 && a.contig) {
+    else if (FULL == 7 && contig) {
         // Contiguous columns (one matrix for both spins, 48 < na + nb <= 56): three full column slots and a fourth with
-        // na + nb - 48 live columns, multiplied as NU = a.hyb units of 16 rows x 4 columns (taylor_h).  The 18 full tiles,
+        // na + nb - 48 live columns, multiplied as NU = hyb units of 16 rows x 4 columns (taylor_h).  The 18 full tiles,
         // 6 NU units and 4 remainder units are dealt so that no SIMD (waves w, w + 4) carries more than 1056 MFMA cycles
         // per k-step at NU = 1 (1200 in the two-slots-per-spin layout):
         //   waves 0, 2   row tiles (0,1) / (2,3) x slots 0, 1                                  768
@@ -1176,38 +1197,11 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 else if (wave == 5) taylor(I1{}, I2{}, std::true_type{}, 5, 0, 1, std::false_type{});
                 else taylor_h(std::true_type{}, std::true_type{}, nu, 4, 2, 3, 2);
             };
-            // Closed-shell walker: slot 1 left out -- 12 full tiles, 6 NU units and 3 remainder units, per k-step:
-            //   waves 0, 1   row tiles (0,1) / (2,3) x [slot 2 | unit slot 3]                      384 + 96 NU
-            //   wave 2       row tiles (0,1) x slot 0                                              384
-            //   waves 6, 3, 5   row tile 2 / 3 / 5 x slot 0                                        192
-            //   wave 4       row tile 4 x slot 0 + remainder unit of slot 0                        240
-            //   wave 7       row tiles 4, 5 x [slot 2 | unit slot 3] + remainder units of 2, 3     384 + 96 NU + 96
-            // i.e. 720 / 672 / 576 / 768 cycles on the four SIMDs at NU = 1 instead of 1008 / 864 / 1008 / 1056.  Every tile
-            // goes through the code it goes through in the deal above (taylor for slot 0, taylor_h for slots 2, 3): the
-            // results are bit for bit the same.
-            auto closed_deal = [&](auto nu) __attribute__((always_inline)) {
-                if (wave == 0 || wave == 1) taylor_h(std::true_type{}, std::false_type{}, nu, 2 * wave, 2, 3, 0);
-                else if (wave == 2) taylor(I2{}, I1{}, std::false_type{}, 0, 0, 2, std::false_type{});
-                else if (wave == 4) taylor(I1{}, I1{}, std::true_type{}, 4, 0, 1, std::true_type{});
-                else if (wave == 7) taylor_h(std::true_type{}, std::true_type{}, nu, 4, 2, 3, 2);
-                else taylor(I1{}, I1{}, std::true_type{}, wave == 6 ? 2 : wave, 0, 1, std::false_type{});
-            };
-            if (closed) {
-                if (a.hyb == 2) closed_deal(I2{});
-                else closed_deal(I1{});
-                // T(slot 1) = T(slot 0) for the closing one-body pass, which multiplies all four slots
-                lds_barrier();
-                for (int e = tid; e < NCH * 128; e += PF_NT) {
-                    const int ch = e >> 7, i = e & 127;
-                    ((d2_t *)Tf)[ch * 512 + 128 + i] = ((const d2_t *)Tf)[ch * 512 + i];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            else if (a.hyb == 2) deal(I2{});
+            if (hyb == 2) deal(I2{});
             else deal(I1{});
         }
     }
-    else if (FULL == 7 && a.hyb) {
+    else if (FULL == 7 && hyb) {
         if constexpr (FULL == 7) {
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
@@ -1217,10 +1211,32 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
                 else if (wave < 6) taylor(I2{}, I1{}, std::true_type{}, 4, 2 * (wave - 4), 2, std::false_type{});
                 else taylor_h(std::false_type{}, std::true_type{}, nu, 4, 0, 2 * (wave - 6) + 1, 2 * (wave - 6));
             };
-            if (a.hyb == 3) deal(I3{});
-            else if (a.hyb == 2) deal(I2{});
+            if (hyb == 3) deal(I3{});
+            else if (hyb == 2) deal(I2{});
             else deal(I1{});
         }
+    }
+    else if (FULL >= 5 && closed) {
+        // Closed-shell walker, two slots per spin: the alpha half only -- waves 0-3 two row tiles of one slot each (rows (0,1) /
+        // (2,3) x slot a0 / a1), waves 4-7 one row tile each (row 4 and, where it exists, row 5 x a0 / a1; with seven full row
+        // tiles waves 4, 5 take the rows (4,5) and waves 6, 7 row 6; with five, waves 6, 7 repeat waves 4, 5), the remainder
+        // units of the M <= 100 deal with row tile 4: three tiles per SIMD instead of seven.  Same code per tile as in the
+        // deals below (taylor), so the alpha results are theirs bit for bit.
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        const int cs = wave & 1;
+        if (wave < 4) taylor(I2{}, I1{}, std::false_type{}, 2 * (wave >> 1), cs, 2, std::false_type{});
+        else if constexpr (FULL == 7) {
+            if (a.rem4) {
+                if (wave < 6) taylor(I1{}, I1{}, std::true_type{}, 4, cs, 1, std::true_type{});
+                else taylor(I1{}, I1{}, std::true_type{}, 5, cs, 1, std::false_type{});
+            } else {
+                if (wave < 6) taylor(I2{}, I1{}, std::true_type{}, 4, cs, 2, std::false_type{});
+                else taylor(I1{}, I1{}, std::true_type{}, 6, cs, 1, std::false_type{});
+            }
+        }
+        else taylor(I1{}, I1{}, std::true_type{}, (FULL == 6 && wave >= 6) ? 5 : 4, cs, 1, std::false_type{});
+        mirror_spin();
     }
     else if (wave < 4) taylor(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::false_type{}, 2 * (wave >> 1), 2 * (wave & 1), 2, std::false_type{});
     else if constexpr (FULL == 7) {
@@ -1278,7 +1294,7 @@ int k_prop_fused(afq_handle *h) {
         a.hyb = (h->nt - 48 + 3) / 4;
     }
     a.symcols = (a.contig && h->na == h->nb && !afq_knob("AFQ_PF_NOSYM")) ? 1 : 0;
-    a.closed_try = (a.symcols && h->exp_order > 0 && !afq_knob("AFQ_PF_NOCLOSED")) ? 1 : 0;
+    a.closed_try = 0;           // (set below, once the deal is known)
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     a.n_closed = h->counters + 3;
     const int NCH = (h->M + 7) / 8;
@@ -1301,6 +1317,10 @@ int k_prop_fused(afq_handle *h) {
     const int nrt = (h->M + 15) / 16;
     const bool nofull = PF_NW != 8 || afq_knob("AFQ_PF_NOFULL");
     const int full = nofull ? 0 : narrow ? (nrt == 6 ? 6 : 0) : (nrt >= 5 && h->na > 16 && h->nb > 16 ? nrt : 0);
+    // closed-shell deals: one matrix for both spins (the chain then acts on the spin blocks alike), as many electrons of
+    // either spin, and a deal without holes: the contiguous-column deal with twins in like slots (symcols), or two slots per spin
+    a.closed_try = (a.same_b && h->na == h->nb && h->exp_order > 0 && full != 0 && PF_NW == 8 && !a.t4 &&
+                    (a.contig ? a.symcols != 0 : a.hyb == 0) && !afq_knob("AFQ_PF_NOCLOSED")) ? 1 : 0;
 #define PF_LAUNCH_(NARROW_, FULL_, SLOT_)                                                                     \
     do {                                                                                                      \
         AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<NARROW_, FULL_>, lds, lds_set[SLOT_]));      \

@@ -712,3 +712,52 @@ def test_closed_shell_walkers_take_the_one_spin_path_of_the_greens_kernel(M, N):
     for w in range(nw):
         assert numpy.array_equal(out[w, :, :N], out[w, :, N:]) == (not mixed[w]), w
     dev.close()
+
+
+@pytest.mark.parametrize("M,N,deal", [
+    (100, 25, True),     # contiguous columns, twins in like slots: column slot 1 left out
+    (100, 30, True),     # two slots per spin, seven row tiles with the 4-row remainder unit: the alpha half only
+    (100, 20, True),     # ... 40 columns
+    (104, 20, True),     # ... seven full row tiles
+    (90, 20, True),      # six row tiles (prop_fused_kernel<false, 6>)
+    (70, 18, True),      # five row tiles (prop_fused_kernel<false, 5>)
+    (93, 7, True),       # one column tile per spin, six row tiles (prop_fused_kernel<true, 6>)
+    (70, 7, False),      # narrow, generic tile tests: no closed-shell deal
+    (60, 20, False),     # wide, generic tile tests: no closed-shell deal
+])
+def test_fused_propagator_closed_shell_deals(M, N, deal):
+    """Walkers whose spin blocks are bitwise equal take the fused propagator's closed-shell deal (the kernel checks every walker
+    on its LDS image): the Taylor products of the alpha half only -- of everything but the redundant slot in the
+    contiguous-column layout -- copied into the beta half ahead of the closing one-body pass.  A population of closed, open and
+    dead walkers, two steps against the oracle (propagation/continuous.py:232-262); afq_counters [3] counts exactly the live
+    closed walkers; closed walkers stay closed bit for bit."""
+    K, nw = 24, 21
+    model, rng = build(M, K, N, N, False, seed=31)
+    assert numpy.array_equal(model.BH1[0], model.BH1[1])
+    half = model.psi[None, :, :N] + 0.1 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    phis = numpy.concatenate([half, half], axis=2)
+    is_open = numpy.arange(nw) % 3 == 1
+    phis[is_open, :, N:] += 0.05 * (rng.rand(int(is_open.sum()), M, N) + 1j * rng.rand(int(is_open.sum()), M, N))
+    w0 = numpy.ones(nw)
+    w0[4::7] = 0.0
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, N, N) for p in phis]))
+    walkers = [ref.new_walker(model, phis[i]) for i in range(nw)]
+    dev.counters(reset=True)
+    live_closed = int(((w0 > 0) & ~is_open).sum())
+    for step in range(2):
+        xi = rng.normal(size=(nw, K))
+        dev.propagate(xi, 0.2)
+        out_phi, out_w = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+        for i in range(nw):
+            if w0[i] == 0.0:
+                assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+                continue
+            ref.propagate_walker_phaseless(model, walkers[i], xi[i], 0.2)
+            close(out_phi[i], walkers[i]['phi'], 1e-10 * (step + 1))
+            close(out_w[i], walkers[i]['weight'], 1e-10 * (step + 1))
+            assert numpy.array_equal(out_phi[i, :, :N], out_phi[i, :, N:]) == (not is_open[i]), (step, i)
+        assert int(dev.counters()[3]) == (live_closed * (step + 1) if deal else 0)
+    dev.close()
