@@ -49,6 +49,14 @@ def test_bench_one_gpu_short_region_is_repeated():
     check_line(out, 1, 20, 256)
     assert out["repeats"] == 5 and out["scaling"] == "weak"
     assert out["population_control"] == "device comb (one rank)"
+    # the benchmark's RHF population is closed-shell: the propagator says so from the device's count (afq_counters [3]) and
+    # prices the executed columns; the exchange energy evaluates one spin; the block energy is there to hold variants against
+    r = out["roofline"]
+    assert "closed-shell walkers (100 % of the walker steps)" in r["kernel"]
+    assert r["frac"] < r["frac_issued"] < r["frac_survey"] < 1.1
+    assert r["flops_per_launch"] == pytest.approx(100 * 100 * (8.0 * 6 * 25 + 4.0 * 2 * 50) * 256)
+    assert "one spin evaluated" in r["cholesky_energy"]["kernel"]
+    assert out["last_block_ETotal"] is not None and abs(out["last_block_ETotal"]) < 1e4
 
 
 def test_bench_two_ranks_self_launched_strong():
