@@ -606,8 +606,13 @@ def launch_ranks(ngpus, argv):
             if st != 0 and rc == 0:
                 rc = st if st > 0 else 128 - st
                 sys.stderr.write("bench.py: rank %d exited with status %d; ending the other ranks\n" % (r, st))
+                # a rank that is failing for the same reason gets a moment to say so itself before it is ended
+                grace = time.time() + 10.0
+                while time.time() < grace and any(procs[q].poll() is None for q in live):
+                    time.sleep(0.05)
                 for q in live:
-                    procs[q].terminate()
+                    if procs[q].poll() is None:
+                        procs[q].terminate()
         time.sleep(0.05)
     for t in threads:
         t.join(timeout=5.0)

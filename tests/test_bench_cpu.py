@@ -23,7 +23,10 @@ def test_bench_self_launch_relays_rank_failure():
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert p.stdout.strip() == ""                                     # no result line is invented
-    assert p.stderr.count("no GPU visible") == 2                      # both ranks ran and both refused
+    # both ranks ran and both refused (a rank still paging torch in when the other one has already failed is ended
+    # by the parent after its grace period: then the parent says so)
+    n = p.stderr.count("no GPU visible")
+    assert n == 2 or (n == 1 and "ending the other ranks" in p.stderr), p.stderr
     assert "ending the other ranks" in p.stderr or "exited with status" in p.stderr
 
 
