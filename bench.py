@@ -342,7 +342,7 @@ def run_config(args, name, state):
         "config": {"workload": c["label"] + ", dt=%g, reortho/10, comb/5, energy/10" % c["dt"], "name": name,
                    "walkers_total": c["nw"], "rng": "device-philox",
                    "sizes": {k: c[k] for k in ("M", "na", "nb", "K", "nw")}},
-        "last_block_ETotal": float(numpy.real(mixed.blocks[-1][6])) if mixed.blocks else None,
+        "last_block_ETotal": float(numpy.real(mixed.blocks[-1][5])) if mixed.blocks else None,
         "roofline": {"bound": "hbm" if dom["bound"] == "hbm" else "mfma", "kernel": dom["launch"] + " (" + dom["note"] + ")",
                      "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                      "frac_survey": dom.get("frac_survey"),
@@ -736,7 +736,10 @@ def main():
 def last_block_energy(afqmc):
     try:
         blocks = afqmc.estimators.estimators['mixed'].blocks
-        return float(numpy.real(blocks[-1][6])) if blocks else None
+        # block row = [step, WeightFactor, Weight, ENumer, EDenom, ETotal, E1Body, E2Body, EHybrid, Overlap, Time]
+        # (rounds 1-5 printed column 6 under this name: E1Body, which is the same number for every walker of a trial
+        #  built from the eigenvectors of h1)
+        return float(numpy.real(blocks[-1][5])) if blocks else None
     except Exception:
         return None
 

@@ -427,6 +427,10 @@ int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_
  * Gauss-Jordan flagged as poorly conditioned block-wise and handed to the step-by-step kernel (diagnostic),
  * [3]=walker steps the fused propagator took through its closed-shell deal (spin blocks bitwise equal)       */
 int afq_counters(afq_handle *h, int64_t *out, int reset);
+/* the same, first n counters (n <= 8): [4]=walker energy evaluations whose exchange energy was evaluated for one spin and
+ * counted twice (closed-shell population, decided on the device: energy_finish_kernel), [5]=walker Green's functions
+ * computed for one spin (closed-shell walker, greens_small_kernel), [6], [7] reserved (0)                          */
+int afq_counters_ext(afq_handle *h, int64_t *out, int n, int reset);
 /* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields
  * [3] vhs [4] exponential [5] overlap+weight [6] reortho [7] energy            */
 int afq_timers(afq_handle *h, double *out_ms, int reset);

@@ -233,11 +233,11 @@ int afq_create(int device_id, afq_handle **out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return AFQ_EHIP; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     if (hipMalloc(&h->estimates, sizeof(cplx) * AFQ_EST_COUNT_) != hipSuccess ||
-        hipMalloc(&h->counters, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc(&h->counters, sizeof(unsigned long long) * AFQ_NCOUNTERS) != hipSuccess ||
         hipMalloc(&h->closed_bad, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&h->scal, sizeof(double) * AFQ_NSCAL) != hipSuccess) { delete h; return AFQ_ENOMEM; }
     hipMemset(h->estimates, 0, sizeof(cplx) * AFQ_EST_COUNT_);
-    hipMemset(h->counters, 0, sizeof(unsigned long long) * 4);
+    hipMemset(h->counters, 0, sizeof(unsigned long long) * AFQ_NCOUNTERS);
     hipMemset(h->closed_bad, 0, sizeof(unsigned long long));
     hipMemset(h->scal, 0, sizeof(double) * AFQ_NSCAL);
     if (hipMalloc(&h->zero_page, 256) != hipSuccess) { delete h; return AFQ_ENOMEM; }
@@ -1574,16 +1574,18 @@ int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_
     return AFQ_OK;
 }
 
-int afq_counters(afq_handle *h, int64_t *out, int reset) {
-    if (!h || !out) return AFQ_EINVAL;
+int afq_counters_ext(afq_handle *h, int64_t *out, int n, int reset) {
+    if (!h || !out || n < 0) return AFQ_EINVAL;
     hipSetDevice(h->device);
-    unsigned long long c[4];
+    unsigned long long c[AFQ_NCOUNTERS];
     int rc = copy_out(h, c, h->counters, sizeof(c));
     if (rc) return rc;
-    for (int i = 0; i < 4; ++i) out[i] = (int64_t)c[i];
+    for (int i = 0; i < n; ++i) out[i] = i < AFQ_NCOUNTERS ? (int64_t)c[i] : 0;
     if (reset) AFQ_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(c), h->stream));
     return AFQ_OK;
 }
+
+int afq_counters(afq_handle *h, int64_t *out, int reset) { return afq_counters_ext(h, out, 4, reset); }
 
 int afq_enable_timers(afq_handle *h, int on) {
     if (!h) return AFQ_EINVAL;

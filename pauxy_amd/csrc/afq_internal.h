@@ -37,6 +37,8 @@ __device__ inline cplx cdiv(cplx a, cplx b) {
 #define AFQ_NSCAL 12
 enum { T_GREENS = 0, T_ONEBODY, T_FB, T_VHS, T_EXP, T_OVLP, T_QR, T_ENERGY, T_COUNT };
 
+#define AFQ_NCOUNTERS 8     // afq_counters_ext (include/afqmc_hip.h)
+
 struct afq_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -238,7 +240,7 @@ struct afq_handle {
     // cloned by the comb, and rdm_acc += sum_w weight_w Re G_w with every afq_estimates_update
     bool rdm_on = false;
     double *rdm_acc = nullptr;      // [2, M, M]
-    unsigned long long *counters = nullptr;   // [4]
+    unsigned long long *counters = nullptr;   // [AFQ_NCOUNTERS]
     int *alive = nullptr;           // [nw]
     int *parent_ix = nullptr;       // [nw]
     // [AFQ_NSCAL] device scalars: 0 total weight of the last comb, 1 local pairs (< 0: collapsed), 2 collapse flag (sticky),

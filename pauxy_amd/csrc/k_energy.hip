@@ -375,6 +375,7 @@ struct EFinArgs {
     int closed_try;
     const unsigned long long *closed_bad;
     unsigned long long closed_epoch;
+    unsigned long long *counters;       // afq_counters_ext [4]
 };
 
 // EF_THR threads per walker: the kernel streams Ghalf, rH1, the Coulomb partials and (quadratic-form exchange) the
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
             const cplx v = a.Eq[((long)b * a.nw + w) * a.ncb + ct];
             exr += v.x; exi += v.y;
         }
-        if (closed) { exr *= 2.0; exi *= 2.0; }
+        if (closed) { exr *= 2.0; exi *= 2.0; if (tid == 0 && a.counters) atomicAdd(&a.counters[4], 1ull); }
     }
     // Coulomb
     double ecr = 0, eci = 0;
@@ -673,6 +674,7 @@ int k_energy_generic(afq_handle *h) {
         f.energy = h->energy; f.Eq = h->exq_y; f.qsplit = S; f.na = h->na; f.nb = h->nb;
         f.ncb = (int)(((long)(h->na > h->nb ? h->na : h->nb) * M + 15) / 16);
         f.closed_try = closed_try ? 1 : 0; f.closed_bad = h->closed_bad; f.closed_epoch = h->closed_epoch;
+        f.counters = h->counters;
         AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
         AFQ_POST(h);
         return AFQ_OK;
@@ -715,7 +717,7 @@ int k_energy_generic(afq_handle *h) {
     f.M = M; f.K = K; f.nw = h->nw; f.nt = h->nt; f.nsplit = h->fb_split; f.nxt = nxt; f.nwt = nwt;
     f.ecore = h->ecore; f.rH1 = h->rH1; f.ghalf = h->ghalf; f.vbias = h->vbias; f.part = h->exx_part;
     f.energy = h->energy; f.Eq = nullptr; f.qsplit = 0; f.na = h->na; f.nb = h->nb; f.ncb = 0;
-    f.closed_try = 0; f.closed_bad = nullptr; f.closed_epoch = 0;
+    f.closed_try = 0; f.closed_bad = nullptr; f.closed_epoch = 0; f.counters = nullptr;
     AFQ_LAUNCH(h, energy_finish_kernel, dim3(h->nw), dim3(EF_THR), 0, h->stream, f);
     AFQ_POST(h);
     return AFQ_OK;

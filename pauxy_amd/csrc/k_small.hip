@@ -105,6 +105,7 @@ struct GreensArgs {
     int psi_closed;     // the alpha and beta blocks of the (single, shared) trial are bitwise equal, na == nb (checked at upload)
     unsigned long long *closed_bad;     // raised to closed_epoch by a walker whose spin blocks differ (afq_internal.h), or null
     unsigned long long closed_epoch;
+    unsigned long long *counters;       // afq_counters_ext [5]: walkers that took the one-spin path
 };
 
 // One workgroup per walker, spins in sequence.  O = phi_s^T conj(psi_s)
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
             }
             closed = __syncthreads_and(same) != 0;
             if (!closed && tid == 0 && a.closed_bad) atomicMax(a.closed_bad, a.closed_epoch);
+            if (closed && tid == 0 && a.counters) atomicAdd(&a.counters[5], 1ull);
         }
         for (int t = wave; t < ((a.dbg & 4) || (closed && g == 1) ? 0 : nt16 * nt16); t += 4) {
             const int ti = t / nt16, tj = t % nt16;
@@ -784,7 +786,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
     a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !afq_knob("AFQ_NO_CLOSED_GREENS");
-    a.closed_bad = nullptr; a.closed_epoch = 0;
+    a.closed_bad = nullptr; a.closed_epoch = 0; a.counters = h->counters;
     if (ghalf == h->ghalf) h->closed_checked_version = 0;       // (set again below when THIS launch checks every walker)
     a.skip_spin = 0;
     const int nmax = h->na > h->nb ? h->na : h->nb;

@@ -481,9 +481,11 @@ class AfqDevice(object):
     def rng_seed(self, seed, stream=0):
         self._ck(self.lib.afq_rng_seed(self.h, int(seed), int(stream)))
 
-    def counters(self, reset=False):
-        out = numpy.zeros(4, dtype=numpy.int64)
-        self._ck(self.lib.afq_counters(self.h, _p(out), int(reset)))
+    def counters(self, reset=False, n=4):
+        """[nfb_trig, nhe_trig, flagged overlap matrices, closed-deal propagator walker steps] and with n = 8 also
+        [.., one-spin exchange-energy walker evaluations, one-spin Green's functions, 0, 0] (afq_counters_ext)."""
+        out = numpy.zeros(max(4, n), dtype=numpy.int64)
+        self._ck(self.lib.afq_counters_ext(self.h, _p(out), int(max(4, n)), int(reset)))
         return out
 
     def enable_timers(self, on=True):

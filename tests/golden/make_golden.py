@@ -417,9 +417,11 @@ def make_ueg_ops():
     save('ueg_ops.npz', out)
 
 
-def record_trajectory(afqmc, comm, out):
+def record_trajectory(afqmc, comm, out, r_override=None):
     """Run AFQMC.run while recording the random numbers it draws and the
-    walker scalars after every step."""
+    walker scalars after every step.  ``r_override`` {step: value}: the comb of that step is handed this uniform instead of
+    the one it drew (the draw still happens: the generator's state advances as in any run) -- the comb's r is an input, and
+    at the benchmark's time step an unforced r hardly ever lands where a walker is cloned."""
     psi = afqmc.psi
     nw = len(psi.walkers)
     K = afqmc.system.nfields
@@ -440,6 +442,8 @@ def record_trajectory(afqmc, comm, out):
 
     def random(*a, **k):
         x = _random(*a, **k)
+        if r_override and state['step'] in r_override:
+            x = r_override[state['step']]
         rr[state['step']] = x
         return x
 
@@ -525,6 +529,92 @@ def make_traj_generic():
     numer = out['final_estimates'][2]
     assert abs(numer.real - 3.8763193646854273) < 1e-9, numer
     save('traj_generic.npz', out)
+
+
+def c3_inputs(M=100, K=500, seed=7):
+    """The synthetic generic Hamiltonian of SURVEY 8(d) / BASELINE configs[2], restated here with numpy only (the package's
+    own pauxy_amd.systems.synthetic_generic is held to the checksums this generator stores, not used to make them):
+    h1 = (R + R^T) / 2, R ~ U(0, 1); L_n = (A_n + A_n^T) / 2, A_n ~ N(0, (0.1 / M)^2); RandomState(seed)."""
+    rng = numpy.random.RandomState(seed)
+    R = rng.random_sample((M, M))
+    h1 = 0.5 * (R + R.T)
+    A = rng.normal(scale=0.1 / M, size=(K, M, M))
+    L = 0.5 * (A + A.transpose(0, 2, 1))
+    chol = numpy.ascontiguousarray(L.reshape(K, M * M).T)
+    return h1, chol
+
+
+def c3_open_walkers(phi, nopen, seed, na, eps=1e-3):
+    """Walkers 0, 3, 6, ... (``nopen`` of them) get their beta block perturbed: open-shell walkers beside closed ones."""
+    rng = numpy.random.RandomState(seed)
+    ix = [3 * i for i in range(nopen)]
+    for i in ix:
+        phi[i][:, na:] += eps * (rng.rand(*phi[i][:, na:].shape) + 1j * rng.rand(*phi[i][:, na:].shape))
+    return ix
+
+
+def make_traj_generic_c3(name='traj_generic_c3.npz', nwalkers=36, nopen=0, blocks=3, r_override=None):
+    """BASELINE configs[2] at its own size through the GENUINE driver: M = 100, K = 500, 25 + 25 electrons, RHF trial,
+    walkers starting at the trial (closed-shell: spin blocks bitwise equal), 10 steps per block, re-orthogonalisation every
+    10, comb every 5, energy every 10 -- the cadence bench.py times.  The inputs regenerate from seed 7 and the fields from
+    the recorded MT19937 state, so the fixture holds seeds, checksums and the reference's outputs only.
+    ``nopen`` > 0: every third walker starts with a perturbed beta block (c3_open_walkers)."""
+    out = {}
+    M, K, nelec = 100, 500, (25, 25)
+    h1, chol = c3_inputs(M, K, 7)
+    system = Generic(nelec=nelec, h1e=numpy.array([h1, h1]), chol=chol, ecore=0.0)
+    e, v = numpy.linalg.eigh(h1)
+    psi = numpy.zeros((M, 50), dtype=numpy.complex128)
+    psi[:, :25] = v[:, :25]
+    psi[:, 25:] = v[:, :25]
+    trial = MultiSlater(system, (numpy.array([1.0 + 0j]), psi[None].copy()))
+    trial.half_rotate(system, None)                    # trial_wavefunction/utils.py:76-77
+    options = {'verbosity': 0, 'get_sha1': False,
+               'qmc': {'timestep': 0.005, 'steps': 10, 'blocks': blocks, 'rng_seed': 8, 'nwalkers': nwalkers,
+                       'pop_control_freq': 5, 'stabilise_freq': 10},
+               'estimates': {'mixed': {}},
+               }
+    comm = MPI.COMM_WORLD
+    afqmc = AFQMC(comm=comm, system=system, trial=trial, options=options)
+    assert len(afqmc.psi.walkers) == nwalkers
+    if nopen:
+        phis = [w.phi for w in afqmc.psi.walkers]
+        out['open_ix'] = numpy.array(c3_open_walkers(phis, nopen, 21, 25), dtype=numpy.int32)
+        out['open_seed'] = 21
+        for i in out['open_ix']:
+            w = afqmc.psi.walkers[i]
+            w.inverse_overlap(afqmc.trial)
+            w.ot = w.calc_otrial(afqmc.trial)
+            w.ovlp = w.ot
+            w.greens_function(afqmc.trial)
+            w.le_oratio = 1.0
+    out['rng_state_keys'] = numpy.array(numpy.random.get_state()[1], dtype=numpy.uint32)
+    st = numpy.random.get_state()
+    out['rng_state_rest'] = numpy.array([st[2], st[3]], dtype=numpy.int64)
+    out['rng_state_gauss'] = float(st[4])
+    record_trajectory(afqmc, comm, out, r_override)
+    out['r_override_steps'] = numpy.array(sorted(r_override or {}), dtype=numpy.int64)
+    xi = out.pop('xi')
+    out['xi_sum'] = xi.sum(axis=2)                     # [step, walker]: holds the regenerated stream to the recorded one
+    out['xi_first'] = xi[:, :, 0].copy()
+    out['seed'] = 7
+    out['M'], out['K'] = M, K
+    phi0 = out.pop('phi0')
+    out['phi0_sum'] = phi0.sum(axis=(1, 2))
+    out['nwalkers'] = nwalkers
+    fp = out.pop('final_phi')
+    out['final_phi_colnorm'] = numpy.linalg.norm(fp, axis=1)      # [walker, column]
+    out['final_phi_sum'] = fp.sum(axis=1)
+    # checksums of what the test regenerates with the package's own set-up code
+    for key, arr in (('psi', out.pop('psi')), ('BH1', out.pop('BH1')), ('mf_shift', out.pop('mf_shift'))):
+        arr = numpy.asarray(arr)
+        out[key + '_abs_sum'] = numpy.abs(arr).sum()
+        out[key + '_sum'] = arr.sum()
+    rchol = numpy.asarray(afqmc.trial._rchol)
+    out['rchol_abs_sum'] = numpy.abs(rchol).sum()
+    out['rchol_shape'] = numpy.array(rchol.shape)
+    out['h1_sum'], out['chol_abs_sum'] = h1.sum(), numpy.abs(chol).sum()
+    save(name, out)
 
 
 def make_traj_hubbard(name, nup, pin=None, nwalkers=10, npop=1, blocks=10, prop_extra=None):
@@ -1290,11 +1380,17 @@ def make_dropin():
 # Every committed fixture and the ONE call that makes it.  `python make_golden.py` (or `all`) regenerates all of them,
 # `python make_golden.py <file or group> ...` some, `--check` regenerates into a scratch directory and compares with the
 # committed files array by array (exit status 1 on any difference).
+# comb uniforms that make the C3-size trajectories clone walkers (weights differ by 1e-3 there: see record_trajectory)
+C3_R = {15: 0.9999, 20: 0.0001, 25: 0.9999, 30: 0.0001}
+
 FIXTURES = [
     ('ops', 'generic_ops.npz', lambda: make_generic_ops()),
     ('ops', 'hubbard_ops.npz', lambda: make_hubbard_ops()),
     ('ops', 'ueg_ops.npz', lambda: make_ueg_ops()),
     ('traj', 'traj_generic.npz', lambda: make_traj_generic()),
+    # BASELINE configs[2] at its own size and cadence (closed-shell walkers; and a third of them opened)
+    ('traj', 'traj_generic_c3.npz', lambda: make_traj_generic_c3(r_override=C3_R)),
+    ('traj', 'traj_generic_c3_open.npz', lambda: make_traj_generic_c3('traj_generic_c3_open.npz', nopen=12, r_override=C3_R)),
     ('traj', 'traj_hubbard.npz', lambda: make_traj_hubbard('traj_hubbard.npz', 7, pin=-152.91937839611)),
     # BASELINE configs[0]: 4x4 U=4 half filling, 10 walkers, comb every 5 steps
     ('traj', 'traj_hubbard_c1.npz', lambda: make_traj_hubbard('traj_hubbard_c1.npz', 8, nwalkers=10, npop=5, blocks=10)),

@@ -451,3 +451,39 @@ def test_comb_truncation_quirk():
     pix = ref.comb_parent_ix(w / (w.sum() / 4), 4, 0.5)
     assert list(pix) == [3, 0, 0, 1]
     assert ref.comb_pairs(pix) == [(0, 1)]
+
+
+@pytest.mark.parametrize("name", ['traj_generic_c3.npz', 'traj_generic_c3_open.npz'])
+def test_traj_generic_at_the_benchmark_size(golden, name):
+    """BASELINE configs[2] at its own size and cadence (M = 100, K = 500, 25 + 25 electrons, RHF trial, re-orthogonalisation
+    every 10 steps, comb every 5, energy every 10; 36 walkers -- above the 32 from which the device takes its spin-summed / one-spin paths -- 30 steps, four forced comb events that clone and kill) through the genuine
+    driver (qmc/afqmc.py:223-255, estimators/mixed.py:133-289, walkers/handler.py:225-338): the oracle against it.  The
+    second fixture starts every third walker with a perturbed beta block (open-shell walkers beside closed ones)."""
+    from tests import c3_traj
+    d = golden(name)
+    system, trial, BH1, mf_shift = c3_traj.inputs(d)
+    na, nb = system.nup, system.ndown
+    model = ref.RefModel('generic', system.nbasis, na, nb, trial.psi, BH1, mf_shift, float(d['dt']), hs_pot=system.hs_pot,
+                         rchol=trial._rchol, H1=system.H1.astype(complex), ecore=system.ecore)
+    phi0 = c3_traj.initial_walkers(d, trial)
+    close(phi0.sum(axis=(1, 2)), d['phi0_sum'], 1e-10)
+    walkers = [ref.new_walker(model, p) for p in phi0]
+    rp = c3_traj.StateReplay(d)
+    rec = []
+    blocks = ref.run_afqmc(model, walkers, lambda step, iw: rp.normal(0.0, 1.0, model.nfields), lambda step: rp.random(),
+                           int(d['nsteps']), int(d['nblocks']), nstblz=int(d['nstblz']),
+                           npop_control=int(d['npop_control']), energy_eval_freq=int(d['energy_eval_freq']), record=rec)
+    tol = 1e-8
+    for key, gold in (('weight', 'weight'), ('unscaled_weight', 'unscaled_weight'), ('ot', 'ot'), ('hybrid_energy', 'ehyb'),
+                      ('phase', 'phase'), ('eloc', 'eloc')):
+        close(numpy.array([x[key] for x in rec]), d[gold], tol)
+    pix = numpy.array([x['parent_ix'] for x in rec if x['parent_ix'] is not None])
+    assert numpy.array_equal(pix, d['parent_ix'])
+    assert (pix != 1).any()                                     # walkers were cloned and killed
+    close(numpy.array(blocks)[:, :9], d['blocks'][:, 1:10], tol)
+    fp = numpy.array([w['phi'] for w in walkers])
+    close(numpy.linalg.norm(fp, axis=1), d['final_phi_colnorm'], tol)
+    close(fp.sum(axis=1), d['final_phi_sum'], tol)
+    est = numpy.zeros(10, dtype=numpy.complex128)
+    ref.mixed_update(model, est, walkers, 0, 1, False)
+    close(est[:9], d['final_estimates'][:9], tol)
