@@ -663,6 +663,9 @@ def main():
                          "the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
+    ap.add_argument("--open-shell", action="store_true",
+                    help="C3: start every walker with its beta block perturbed by 1e-3 (open-shell walkers: none of the "
+                         "closed-shell paths of the Green's function, the exchange energy and the fused propagator applies)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-window", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -772,6 +775,15 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
     state["dev"] = dev
+    if getattr(args, "open_shell", False):
+        from pauxy_amd import _lib as L_
+        rng_o = numpy.random.RandomState(1000 + rank)
+        phi_o = dev.get(L_.F_PHI)
+        phi_o[:, :, N:] += 1e-3 * (rng_o.rand(*phi_o[:, :, N:].shape) + 1j * rng_o.rand(*phi_o[:, :, N:].shape))
+        dev.set(L_.F_PHI, phi_o)
+        afqmc.psi.phi_version += 1
+        dev.set(L_.F_OT, dev.calc_overlap())
+        afqmc.psi._invalidate()
     device_comm = bool(getattr(afqmc.psi, 'device_comm', False))
     comm_kind = getattr(afqmc.psi, 'device_comm_kind', '')
     comm_note = getattr(afqmc.psi, 'device_comm_error', '') or ''
@@ -893,13 +905,10 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
         wt["prop_fused_kernel"] = (b_, w_, M * M * (8.0 * 6 * cols + ob_ * 2 * nt) * nw, n_)
         prop_note = ("; closed-shell walkers (%.0f %% of the walker steps): Taylor products on the alpha half, %d of %d columns; "
                      "`frac` prices the executed columns" % (100.0 * closed_prop, N, nt))
-        # matrix-pipe flops per k-step of 4: the library reports the full deal of this shape (contiguous columns: 18 tiles of
-        # 16 x 16, 6 + 4 units of 4 x 4 x 4 lanes), a closed-shell walker issues 12 tiles + 2 remainder units (two column
-        # slots of the alpha half x six row tiles + the 4-row remainder); 3 multiplications per complex product, 6 orders
-        nch = (M + 7) // 8
-        assert 96 < M <= 100 and 48 < nt <= 56 and N == nt // 2, "closed-shell issue count: the headline shape class"
-        per_kstep = (2048.0 * 18 + 512.0 * (6 * ((nt - 48 + 3) // 4) + 4)) - (2048.0 * 12 + 512.0 * 2)
-        prop_issued_scale = -closed_prop * 3.0 * 6 * (2.0 * nch) * per_kstep * nw
+        # matrix-pipe flops: the library's own count per walker for either deal (afq_propagator_issued_flops), mixed by the
+        # device's count of the walkers that took the closed-shell deal
+        open_w, closed_w = dev.propagator_issued_flops()
+        prop_issued_scale = closed_prop * (closed_w - open_w) * nw
     kernels = [
         ("prop_fused_kernel (B exp(V) B, 2 one-body + 6 Taylor products per walker%s)" % prop_note, L.K_PROPAGATOR, wt["prop_fused_kernel"]),
         # Cholesky exchange energy.  Algorithm 2 (quadratic form g^T Atil g, one [nw x NM] x [NM x NM] real-by-complex
@@ -1040,7 +1049,8 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "generic Cholesky AFQMC: Nbasis=100, Nchol=500, RHF trial 25+25 electrons, "
                                    "%d walkers/GPU, dt=0.005, reortho/10, comb/5, energy/10 "
-                                   "(BASELINE configs[2])" % nw,
+                                   "(BASELINE configs[2])%s" % (nw, "; OPEN-SHELL walkers (--open-shell: beta blocks perturbed by 1e-3)"
+                                                                if getattr(args, "open_shell", False) else ""),
                        "walkers_total": total_walkers, "rng": "host-numpy" if args.host_rng else "device-philox",
                        "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "population_control": pc_label},

@@ -471,6 +471,10 @@ int afq_launch_trace_get(afq_handle *h, char *names_out, int names_len, double *
  * 0 for kinds that have not been launched or do not run on the matrix pipe.  (measurement hook, no reference
  * counterpart)                                                                                                    */
 int afq_kernel_issued_flops(afq_handle *h, int kind, double *flops_out);
+/* fused propagator (AFQ_K_PROPAGATOR): matrix-pipe flops ONE walker issues in the last launch's shape through the open-shell
+ * deal and through the closed-shell deal (alpha slots only); afq_kernel_issued_flops reports nw x the open-shell count, the
+ * count of a launch is (nw_live - n_closed) x open + n_closed x closed with n_closed from afq_counters [3]            */
+int afq_propagator_issued_flops(afq_handle *h, double *open_per_walker, double *closed_per_walker);
 
 #ifdef __cplusplus
 }

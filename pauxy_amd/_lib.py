@@ -77,6 +77,7 @@ SIGNATURES = {
     "afq_rng_seed": [_h, c_uint64, c_uint64],
     "afq_counters": [_h, c_void_p, c_int],
     "afq_counters_ext": [_h, c_void_p, c_int, c_int],
+    "afq_propagator_issued_flops": [_h, POINTER(c_double), POINTER(c_double)],
     "afq_timers": [_h, _dp, c_int],
     "afq_enable_timers": [_h, c_int],
     "afq_stream": [_h, POINTER(c_void_p)],

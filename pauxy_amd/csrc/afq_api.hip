@@ -1953,6 +1953,13 @@ int afq_launch_trace_get(afq_handle *h, char *names_out, int names_len, double *
     return AFQ_OK;
 }
 
+int afq_propagator_issued_flops(afq_handle *h, double *open_per_walker, double *closed_per_walker) {
+    if (!h || !open_per_walker || !closed_per_walker) return AFQ_EINVAL;
+    *open_per_walker = h->prop_issued_open;
+    *closed_per_walker = h->prop_issued_closed;
+    return AFQ_OK;
+}
+
 int afq_kernel_issued_flops(afq_handle *h, int kind, double *flops_out) {
     if (!h || !flops_out || kind < 0 || kind >= AFQ_K_COUNT) return AFQ_EINVAL;
     *flops_out = h->issued_flops[kind];

@@ -226,6 +226,7 @@ struct afq_handle {
     unsigned ktrace_mask = 0;          // bit k: event pairs around the launches of kernel kind k
     std::vector<hipEvent_t> ktrace_ev[AFQ_K_COUNT];   // start/stop pairs
     double issued_flops[AFQ_K_COUNT] = {0, 0, 0, 0, 0};   // matrix-pipe flops of the last launch of each kind (afq_kernel_issued_flops)
+    double prop_issued_open = 0.0, prop_issued_closed = 0.0;   // per walker, last fused-propagator launch (afq_propagator_issued_flops)
     int ktrace_used[AFQ_K_COUNT] = {0, 0, 0, 0, 0};
     int ktrace_stride[AFQ_K_COUNT] = {1, 1, 1, 1, 1}, ktrace_seen[AFQ_K_COUNT] = {0, 0, 0, 0, 0};   // every n-th launch of a kind is timed
     // afq_launch_trace: an event pair around EVERY launch, keyed by the launch's breadcrumb name (a profile pass, not

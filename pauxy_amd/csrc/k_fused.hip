@@ -1311,6 +1311,13 @@ int k_prop_fused(afq_handle *h) {
         const double taylor_pass = a.contig ? ksteps * (2048.0 * (nrt_ - 1) * 3 + 512.0 * (nrt_ - 1) * a.hyb + 512.0 * 4)
                                    : a.hyb ? ksteps * (2048.0 * (nrt_ - 1) * 2 + 512.0 * (nrt_ - 1) * 2 * a.hyb + 512.0 * 4) : per_pass;
         h->issued_flops[AFQ_K_PROPAGATOR] = (3.0 * h->exp_order * taylor_pass + 2.0 * (a.b_real ? 2.0 : 3.0) * per_pass) * h->nw;
+        h->prop_issued_open = h->issued_flops[AFQ_K_PROPAGATOR] / h->nw;
+        // a closed-shell walker (afq_counters [3]) issues the alpha slots only in its Taylor products: two column slots x the
+        // row tiles (+ two remainder units in the M <= 100 deal), one slot when narrow; its one-body passes multiply every slot.
+        // Waves that repeat a tile (five row tiles, narrow) and row tiles that do not exist are not counted, as above
+        const int cta = (h->na + 15) / 16;
+        const double closed_pass = ksteps * (2048.0 * (a.rem4 ? nrt_ - 1 : nrt_) * cta + 512.0 * (a.rem4 ? cta : 0));
+        h->prop_issued_closed = 3.0 * h->exp_order * closed_pass + 2.0 * (a.b_real ? 2.0 : 3.0) * per_pass;
     }
     // every tile of the deal present: wide with 5-7 row tiles (waves 4-7 own the tiles from 4 on) and two column tiles
     // per spin, or narrow with six row tiles

@@ -541,6 +541,12 @@ class AfqDevice(object):
         self._ck(self.lib.afq_kernel_issued_flops(self.h, int(kind), ctypes.byref(out)))
         return float(out.value)
 
+    def propagator_issued_flops(self):
+        """(open, closed): matrix-pipe flops ONE walker issues in the fused propagator's open-shell / closed-shell deal."""
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._ck(self.lib.afq_propagator_issued_flops(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return float(a.value), float(b.value)
+
     def set_exchange_algorithm(self, mode):
         """0 automatic, 1 T-intermediate (exx_kernel), 2 quadratic form (see afq_set_exchange_algorithm)."""
         self._ck(self.lib.afq_set_exchange_algorithm(self.h, int(mode)))
