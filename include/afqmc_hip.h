@@ -429,7 +429,9 @@ int afq_last_launch(afq_handle *h, char *buf, int len, uint64_t *queued, uint64_
 int afq_counters(afq_handle *h, int64_t *out, int reset);
 /* the same, first n counters (n <= 8): [4]=walker energy evaluations whose exchange energy was evaluated for one spin and
  * counted twice (closed-shell population, decided on the device: energy_finish_kernel), [5]=walker Green's functions
- * computed for one spin (closed-shell walker, greens_small_kernel), [6], [7] reserved (0)                          */
+ * computed for one spin (closed-shell walker, greens_small_kernel), [6]=per-determinant overlaps of a multi-determinant
+ * trial that came out as NaN (0 x inf behind a zero pivot of a singular overlap matrix) and were taken as zero overlaps,
+ * [7] reserved (0)                                                                                                  */
 int afq_counters_ext(afq_handle *h, int64_t *out, int n, int reset);
 /* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields
  * [3] vhs [4] exponential [5] overlap+weight [6] reortho [7] energy            */

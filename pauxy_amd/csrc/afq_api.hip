@@ -100,7 +100,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->ghalf_all); h->ghalf = nullptr; dev_free(h->G); dev_free(h->ovlp_old); dev_free(h->ovlp_new);
     dev_free(h->xi); dev_free(h->vbias_all); h->vbias = nullptr; dev_free(h->ghalf_sum); h->gsum_version = 0; h->vbias_version = 0;
     dev_free(h->gdiag); h->gdiag_version = 0; h->gdiag_parts = 0;
-    dev_free(h->detd); dev_free(h->detw); dev_free(h->energy_all);
+    dev_free(h->detd); dev_free(h->detd_a); dev_free(h->detw); dev_free(h->energy_all);
     dev_free(h->msd_gs); dev_free(h->msd_S); h->msd_fb_gbar = false;
     dev_free(h->hs_oinv); dev_free(h->hs_u); dev_free(h->hs_fields); dev_free(h->hs_used); dev_free(h->hs_alive0);
     dev_free(h->hs_fbfac);
@@ -600,7 +600,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
     A_(h->ot, n) A_(h->ehyb, n) A_(h->phase, n) A_(h->eloc, n)
     A_(h->ghalf_all, per * n * h->ndet) A_(h->ovlp_old, n) A_(h->ovlp_new, n)
     h->ghalf = h->ghalf_all + (size_t)h->cur_det * n * per;
-    if (h->ndet > 1) { A_(h->detd, n * h->ndet) A_(h->detw, n * h->ndet) A_(h->energy_all, 3 * n * h->ndet) }
+    if (h->ndet > 1) { A_(h->detd, n * h->ndet) A_(h->detd_a, n * h->ndet) A_(h->detw, n * h->ndet) A_(h->energy_all, 3 * n * h->ndet) }
     A_(h->xi, K * n) A_(h->xbar, K * n) A_(h->xs, K * n) A_(h->cmf, n) A_(h->cfb, n)
     A_(h->energy, 3 * n) A_(h->alive, n) A_(h->parent_ix, n)
     // force-bias contraction slices: enough wave-tasks to fill 1024 SIMDs
@@ -828,7 +828,10 @@ static int greens_any(afq_handle *h, cplx *det_out, bool with_ghalf) {
     for (int d = 0; d < h->ndet; ++d) {
         select_det(h, d);
         cplx *dd = h->detd + (size_t)d * h->nw;
-        if ((rc = with_ghalf ? k_greens(h, dd) : k_overlap(h, dd))) { select_det(h, 0); return rc; }
+        h->det_a_out = with_ghalf ? h->detd_a + (size_t)d * h->nw : nullptr;
+        rc = with_ghalf ? k_greens(h, dd) : k_overlap(h, dd);
+        h->det_a_out = nullptr;
+        if (rc) { select_det(h, 0); return rc; }
     }
     select_det(h, 0);
     return k_msd_combine(h, det_out, with_ghalf);       // (multi_det.py:209,218 skip; calc_overlap :135-162 does not)

@@ -120,6 +120,8 @@ struct afq_handle {
     std::vector<DetOps> dets;       // size ndet when ndet > 1
     cplx *coeffs = nullptr;         // [ndet] device copy of the CI coefficients
     cplx *detd = nullptr;           // [ndet, nw] per-determinant overlaps <D_d|phi_w>
+    cplx *detd_a = nullptr;         // [ndet, nw] their alpha factors det(phi_a^T conj(D_d,a)) (multi_det.py:209 tests it first)
+    cplx *det_a_out = nullptr;      // where the Green's function launch in flight leaves the alpha determinants (or null)
     cplx *detw = nullptr;           // [nw, ndet] weights conj(c_d) <D_d|phi_w> of the last evaluation
     cplx *ghalf_all = nullptr;      // owning pointers of the per-determinant slices
     cplx *vbias_all = nullptr;

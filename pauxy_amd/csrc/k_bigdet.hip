@@ -785,12 +785,13 @@ __global__ __launch_bounds__(512) void gj_mfma_kernel(GjArgs a, int *flag) {
 
 // (wa.weight != null: det IS wa.ovlp_new and the walker's weight update, weight cap and estimator terms run right behind
 //  its determinant, as in greens_small_kernel: no separate weight_kernel launch)
-__global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det, int nw, WeightArgs wa) {
+__global__ void det_combine_kernel(const cplx *detm, const int *dete, cplx *det, cplx *det_a, int nw, WeightArgs wa) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
     const cplx p = cmul(detm[2 * w], detm[2 * w + 1]);
     const int e = dete[2 * w] + dete[2 * w + 1];
     det[w] = cmake(ldexp(p.x, e), ldexp(p.y, e));
+    if (det_a) det_a[w] = cmake(ldexp(detm[2 * w].x, dete[2 * w]), ldexp(detm[2 * w].y, dete[2 * w]));
     if (wa.weight) weight_update_and_cap(wa, w);
 }
 
@@ -881,7 +882,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
         if (wa_in) wa = *wa_in;
         else std::memset(&wa, 0, sizeof(wa));
         AFQ_LAUNCH(h, det_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detm,
-                           h->dete, det, h->nw, wa);
+                           h->dete, det, h->det_a_out, h->nw, wa);
         AFQ_POST(h);
     }
     if (oinv)    // [nw, 2, nmax, nmax]: the layout of the workspace (batch = 2 w + spin)

@@ -94,6 +94,7 @@ struct GreensArgs {
     cplx *gsum;         // optional [nw, na*M]: Ghalf_a + Ghalf_b (na == nb), see k_force_bias_generic
     cplx *oinv;         // optional [nw, 2, nmax, nmax]: O^-1 (O = phi^T conj(psi)), row-major, leading dim nmax
     cplx *det;          // [nw]
+    cplx *det_a;        // optional [nw]: the alpha spin's determinant alone (multi-determinant trials: walkers/multi_det.py:209)
     cplx *ws;           // global workspace [nw, nmax*nmax] when O does not fit LDS
     int o_in_lds;
     int only_alive;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(NTHR) void greens_kernel(GreensArgs a) {
         __syncthreads();
         lu_factor(O, n, perm, &piv_s, &ph_s, &la_s);
         if (tid == 0) { phase = cmul(phase, ph_s); logabs += la_s; }
+        if (tid == 0 && s == 0 && a.det_a) { const double e0 = exp(logabs); a.det_a[w] = cmake(phase.x * e0, phase.y * e0); }
         if (a.ghalf) {
             // column c of Ghalf_s: solve L U x = P phi_s^T[:, c]
             cplx *gh = a.ghalf + ((long)w * nt + off) * M;
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(512) void greens_small_kernel(GreensArgs a, WeightA
         const cplx p2 = (a.dbg & 1) ? cmake(1.0, 0.0) : cmul(ph_s[0], ph_s[1]);
         const int e = (a.dbg & 1) ? 0 : (int)(la_s[0] + la_s[1]);
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
+        if (a.det_a) a.det_a[w] = cmake(ldexp(ph_s[0].x, (int)la_s[0]), ldexp(ph_s[0].y, (int)la_s[0]));
         if (wa.weight) weight_update_and_cap(wa, w);
     }
     GS_STAMP(6);
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(512) void greens_tiny_kernel(GreensArgs a, WeightAr
         const cplx p2 = cmul(ph_s[0], ph_s[1]);
         const int e = la_s[0] + la_s[1];
         a.det[w] = cmake(ldexp(p2.x, e), ldexp(p2.y, e));
+        if (a.det_a) a.det_a[w] = cmake(ldexp(ph_s[0].x, la_s[0]), ldexp(ph_s[0].y, la_s[0]));
         if (wa.weight) weight_update_and_cap(wa, w);
     }
     if (!INVERSE) return;
@@ -784,6 +788,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     if (ghalf) ++h->ghalf_version;
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.nw = h->nw;
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
+    a.det_a = h->det_a_out;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
     a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !afq_knob("AFQ_NO_CLOSED_GREENS");
     a.closed_bad = nullptr; a.closed_epoch = 0; a.counters = h->counters;
@@ -1043,16 +1048,26 @@ int k_xbar(afq_handle *h) {
 // left out -- the reference `continue`s past it, keeping whatever Gi / weight the walker object held before (zeros for a fresh
 // walker); here it gets the weight 0 and every consumer of the weights (force bias, energy) passes over it, i.e. the
 // reference's result for a fresh walker.  A singular overlap matrix may leave NaN as its determinant (0 x inf behind a zero
-// pivot): that IS a zero overlap, in the Green's function and in calc_overlap (multi_det.py:135-162, which skips nothing).
-__global__ void msd_combine_kernel(const cplx *detd, const cplx *coeffs, cplx *detw, cplx *det_out, int nw,
-                                   int ndet, int skip_small) {
+// pivot): that IS a zero overlap, in the Green's function and in calc_overlap (multi_det.py:135-162, which skips nothing);
+// every such event is counted (afq_counters_ext [6]) so that a NaN from a genuine numerical failure does not pass unseen.
+// The reference tests the alpha determinant first (:209) and the product of both second (:218): both tests are applied, the
+// first on detd_a (the alpha determinant alone, written by the Green's function kernels beside the product).
+__global__ void msd_combine_kernel(const cplx *detd, const cplx *detd_a, const cplx *coeffs, cplx *detw, cplx *det_out, int nw,
+                                   int ndet, int skip_small, unsigned long long *counters) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
     cplx tot = cmake(0.0, 0.0);
     for (int d = 0; d < ndet; ++d) {
         cplx dd = detd[(long)d * nw + w];
         const double mag = hypot(dd.x, dd.y);
-        if (!(mag == mag) || (skip_small && mag < 1e-16)) dd = cmake(0.0, 0.0);
+        bool skip = skip_small && mag < 1e-16;
+        if (skip_small && detd_a) {
+            const cplx da = detd_a[(long)d * nw + w];
+            const double ma = hypot(da.x, da.y);
+            skip = skip || ma < 1e-16;
+        }
+        if (!(mag == mag)) { skip = true; if (counters) atomicAdd(&counters[6], 1ull); }
+        if (skip) dd = cmake(0.0, 0.0);
         const cplx wd = cmul(cconj(coeffs[d]), dd);
         detw[(long)w * ndet + d] = wd;
         tot = cadd(tot, wd);
@@ -1061,8 +1076,8 @@ __global__ void msd_combine_kernel(const cplx *detd, const cplx *coeffs, cplx *d
 }
 
 int k_msd_combine(afq_handle *h, cplx *det_out, bool skip_small) {
-    AFQ_LAUNCH(h, msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd, h->coeffs,
-                       h->detw, det_out, h->nw, h->ndet, skip_small ? 1 : 0);
+    AFQ_LAUNCH(h, msd_combine_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->detd,
+                       skip_small ? h->detd_a : nullptr, h->coeffs, h->detw, det_out, h->nw, h->ndet, skip_small ? 1 : 0, h->counters);
     AFQ_POST(h);
     return AFQ_OK;
 }

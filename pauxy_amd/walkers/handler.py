@@ -227,6 +227,7 @@ class Walkers(object):
         # host-mediated path (pop_control_distributed) stays for CPU process groups (gloo) and as the last resort.
         # walkers: {device_comm: True / 'rccl' / 'ipc' / 'sendrecv' / False}; AFQ_DEVICE_COMM=0 forces the host path.
         self.device_comm, self.device_comm_error, self.device_comm_kind = False, '', ''
+        self._device_comm_fault = walker_opts.get('device_comm_fault', None)
         opt = walker_opts.get('device_comm', None)
         want = opt if opt is not None else os.environ.get('AFQ_DEVICE_COMM', '1') != '0'
         forced = opt is not None and opt is not False        # tried whatever the driver's communicator sits on
@@ -495,8 +496,16 @@ class Walkers(object):
         # rank 3 report that it cannot load librccl, and fail the probe of the IPC candidate.  Stages: avail (rccl /
         # sendrecv only), init, probe.  The injected failure is raised where a real one would be -- AFTER the collective
         # calls of the stage, so the other ranks are never left inside one.
+        # The hook is test infrastructure: it is honoured only on request -- walkers: {device_comm_fault: "..."} or the
+        # environment variable TOGETHER with AFQ_ALLOW_FAULT_INJECTION=1 (a stray AFQ_COMM_FAULT alone changes nothing) -- and
+        # rank 0 says on stderr that failures are being injected.
         faults = set()
-        for item in os.environ.get('AFQ_COMM_FAULT', '').split(','):
+        spec = getattr(self, '_device_comm_fault', None)
+        if spec is None and os.environ.get('AFQ_ALLOW_FAULT_INJECTION', '0') == '1':
+            spec = os.environ.get('AFQ_COMM_FAULT', '')
+        if spec and comm.rank == 0:
+            sys.stderr.write("pauxy_amd: communicator bring-up with INJECTED failures (%s): test mode\n" % spec)
+        for item in (spec or '').split(','):
             part = item.strip().split(':')
             if len(part) == 3 and part[2].lstrip('-').isdigit():
                 faults.add((part[0], part[1], int(part[2])))

@@ -84,7 +84,7 @@ def test_bench_eight_ranks_print_their_line_when_one_rank_cannot_bring_rccl_up()
     every rank moves on to the peer-window communicator, the probe passes and rank 0 prints the line -- saying which
     communicator ran and why the preferred one was dropped.  (The eight ranks share this box's one GPU over gloo.)"""
     (out,) = run_bench(["--gpus", "8", "--steps", "10", "--warmup", "10", "--walkers-per-gpu", "64"],
-                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "auto", "AFQ_COMM_FAULT": "rccl:avail:3"})
+                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "auto", "AFQ_COMM_FAULT": "rccl:avail:3", "AFQ_ALLOW_FAULT_INJECTION": "1"})
     check_line(out, 8, 10, 512)
     assert out["population_control"].startswith("device comb over mapped peer windows")
     assert "fell through: rccl: librccl is not loadable on every rank" in out["population_control"]
@@ -98,7 +98,7 @@ def test_bench_eight_ranks_reach_the_host_path_when_every_candidate_fails_on_one
     control goes through the host (pop_control_distributed), rank 0 still prints its line with the reasons."""
     (out,) = run_bench(["--gpus", "8", "--steps", "10", "--warmup", "10", "--walkers-per-gpu", "64"],
                        {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "auto",
-                        "AFQ_COMM_FAULT": "rccl:avail:3,ipc:probe:3"})
+                        "AFQ_COMM_FAULT": "rccl:avail:3,ipc:probe:3", "AFQ_ALLOW_FAULT_INJECTION": "1"})
     check_line(out, 8, 10, 512)
     assert out["population_control"].startswith("host-mediated")
     assert "rccl: librccl is not loadable on every rank" in out["population_control"]

@@ -128,16 +128,24 @@ def test_numerically_dead_determinant_is_skipped_like_the_reference(fb_mode, na,
     model = ref.RefModel('generic_msd', M, na, nb, dets, BH1, mf, dt, coeffs=coeffs, hs_pot=s.hs_pot,
                          H1=numpy.array([s.H1[0], s.H1[1]]).astype(complex), ecore=s.ecore)
     phis = t0.psi[None] + 0.05 * (rng.rand(nw, M, nt) + 1j * rng.rand(nw, M, nt))
-    phis[:3, M - 1, :] = 0.0                                # walkers 0..2: <D_1|phi> = 0 exactly; 3, 4: ordinary
+    phis[:3, M - 1, :] = 0.0                                # walkers 0..2: <D_1|phi> = 0 exactly; 4: ordinary
+    # walker 3: the ALPHA determinant with D_1 alone is below the threshold (1e-17 times a minor of order one) while the
+    # product of both spins is far above it (beta columns scaled up): the reference tests the alpha factor first (:209)
+    phis[3, M - 1, :na] = 0.0
+    phis[3, M - 1, 0] = 1e-17
+    phis[3, :, na:] *= 1e3
     dev = make_device(model, nw)
     dev.set_msd_force_bias(fb_mode)
     dev.set(L.F_PHI, phis)
     tot = dev.greens()
     wts = dev.det_weights()
     refs = [model.greens(p) for p in phis]
-    for w in range(3):
+    for w in range(4):
         assert refs[w][1][1] == 0.0 and wts[w][1] == 0.0   # skipped by the oracle (as by the reference) and by the device
-    assert all(abs(refs[w][1][1]) > 0.0 for w in (3, 4))
+    assert abs(refs[4][1][1]) > 0.0
+    da = numpy.linalg.det(phis[3][:, :na].T @ dets[1][:, :na].conj())
+    db = numpy.linalg.det(phis[3][:, na:].T @ dets[1][:, na:].conj())
+    assert abs(da) < 1e-16 and abs(da * db) > 1e-12        # the alpha test, not the product test, is what skips walker 3
     close(wts, numpy.array([r[1] for r in refs]))
     close(tot, numpy.array([r[0] for r in refs]))
     close(dev.calc_overlap(), numpy.array([model.overlap(p) for p in phis]))

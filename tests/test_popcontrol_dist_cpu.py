@@ -272,8 +272,9 @@ def _bringup_worker(rank, world, port, out):
         comm = TorchComm()
         res = []
         for fault, _, _ in BRINGUP_CASES:
-            os.environ['AFQ_COMM_FAULT'] = fault
+            os.environ.pop('AFQ_COMM_FAULT', None)
             host = BringUpHost()
+            host._device_comm_fault = fault              # (what walkers: {device_comm_fault: ...} sets)
             ok, reason = Walkers._init_device_comm(host, comm, True)
             res.append((ok, host.device_comm_kind, host.dev.calls, reason))
         out.put((rank, res))
