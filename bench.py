@@ -230,10 +230,13 @@ def config_cpu_baseline(name, system, trial, budget_s=15.0):
     return out
 
 
-def run_config(args, name, state):
-    """`--config C1|C2|C4|C5sd|C5`: the same harness on another BASELINE configuration, one GPU: W warm-up steps, then
-    `repeats` timed regions of EXACTLY --steps steps, each bracketed by synchronisation, median reported; an extra pass
-    under afq_launch_trace names every launch of the step and prices the dominant one against its roof."""
+def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
+    """`--config C1|C2|C4|C5sd|C5`: the same harness on another BASELINE configuration: W warm-up steps, then `repeats`
+    timed regions of EXACTLY --steps steps, each bracketed by barrier + synchronisation, MAX over the ranks, median
+    reported; an extra pass under afq_launch_trace names every launch of the step and prices the dominant one against its
+    roof.  `--gpus N`: weak scaling -- the configuration's population on EVERY GPU (BASELINE configs[3], [4] are 8-GPU
+    configurations: 256 walkers per GPU = 2048), population control on the library-owned communicator as in the C3 line,
+    with the device-timed cost of the exchange steps and every rank's traffic in the line."""
     import torch
     from pauxy_amd.qmc.afqmc import AFQMC
     from pauxy_amd.context import release_context
@@ -243,29 +246,57 @@ def run_config(args, name, state):
     state["phase"] = "set-up"
     system, trial = build_config(name)
     options = {'qmc': {'timestep': c["dt"], 'num_steps': NSTEPS_BLOCK, 'blocks': 10 ** 6, 'stabilise_freq': NSTBLZ,
-                       'pop_control_freq': NPOP, 'num_walkers': c["nw"], 'rng_seed': 7},
-               'propagator': {'device_rng': True, 'rng_seed': 7},
+                       'pop_control_freq': NPOP, 'num_walkers': c["nw"] * world, 'rng_seed': 7},
+               'propagator': {'device_rng': True, 'rng_seed': 7, 'rng_stream': rank},
                'estimators': {'mixed': {'verbose': False}, 'write_file': False}}
-    afqmc = AFQMC(options=options, system=system, trial=trial)
+    if os.environ.get("AFQ_BENCH_DEVICE_COMM"):
+        v = os.environ["AFQ_BENCH_DEVICE_COMM"]
+        options['walkers'] = {'device_comm': False if v == '0' else True if v == 'auto' else v}
+    afqmc = AFQMC(comm=comm, options=options, system=system, trial=trial)
     dev = afqmc.psi.dev
     state["dev"] = dev
+    device_comm = bool(getattr(afqmc.psi, 'device_comm', False))
+    comm_kind = getattr(afqmc.psi, 'device_comm_kind', '')
+    comm_note = getattr(afqmc.psi, 'device_comm_error', '') or ''
+    pc_label = population_control_label(afqmc, comm_kind, comm_note, world, backend)
+    if world > 1 and backend == "nccl" and comm_kind != 'rccl':
+        sys.stderr.write("bench.py: rank %d: population control runs as %r, not the RCCL + peer-window path (%s)\n"
+                         % (rank, comm_kind or 'host-mediated', comm_note or 'no reason recorded'))
 
     def sync():
         dev.sync()
         torch.cuda.synchronize()
+        if comm is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
     state["phase"] = "warm-up"
     eshift = afqmc.run_batched(warmup, first_step=1, eshift=0.0)
     sync()
     state["phase"] = "timed region"
     repeats = args.repeats if args.repeats else (5 if steps < 100 else 3 if steps < 500 else 1)
-    regions, first = [], warmup + 1
+    regions, own, first = [], [], warmup + 1
     for _ in range(repeats):
         t0 = time.perf_counter()
         eshift = afqmc.run_batched(steps, first_step=first, eshift=eshift)
         sync()
-        regions.append(time.perf_counter() - t0)
+        el_ = time.perf_counter() - t0
+        own.append(el_)
+        if comm is not None:
+            import torch.distributed as dist
+            t = torch.tensor([el_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_ = float(t.item())
+        regions.append(el_)
         first += steps
-    elapsed = sorted(regions)[(repeats - 1) // 2]
+    order = sorted(range(repeats), key=lambda i: regions[i])
+    imed = order[(repeats - 1) // 2]
+    elapsed = regions[imed]
+    rank_ms = [1e3 * own[imed] / steps]
+    if comm is not None:
+        gathered = numpy.zeros(world)
+        comm.Allgather(numpy.array(rank_ms), gathered)
+        rank_ms = gathered.tolist()
     state["phase"] = "launch trace"
     extra = 2 * NSTEPS_BLOCK
     flagged0 = int(dev.counters()[2])
@@ -334,16 +365,30 @@ def run_config(args, name, state):
         raise RuntimeError("no launch of this configuration has a work model: %r" % [r["launch"] for r in rows[:6]])
     dom = max(priced, key=lambda r: r["ms_per_step"])
     mixed = afqmc.estimators.estimators['mixed']
+    exchange_timing = comm_stats = comm_per_rank = None
+    if world > 1:
+        exchange_timing, comm_stats, comm_per_rank = measure_exchange(state, afqmc, dev, comm, world, device_comm,
+                                                                      first + extra, eshift,
+                                                                      stress=getattr(args, "exchange_stress", 0.0), rank=rank)
     out = {
-        "metric": "walker_steps_per_sec", "value": c["nw"] * steps / elapsed, "unit": "walker-steps/s",
-        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "metric": "walker_steps_per_sec", "value": c["nw"] * world * steps / elapsed, "unit": "walker-steps/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
         "ms_per_step_min": 1e3 * min(regions) / steps, "ms_per_step_max": 1e3 * max(regions) / steps,
         "repeats": repeats, "timed_regions_ms": [1e3 * r for r in regions],
-        "statistic": "median of %d timed regions of %d steps each" % (repeats, steps),
+        "statistic": "median of %d timed regions of %d steps each%s" % (repeats, steps, " (max over ranks per region)" if world > 1 else ""),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": c["label"] + ", dt=%g, reortho/10, comb/5, energy/10" % c["dt"], "name": name,
-                   "walkers_total": c["nw"], "rng": "device-philox",
+        "config": {"workload": c["label"] + ", dt=%g, reortho/10, comb/5, energy/10" % c["dt"] +
+                               (" -- %d walkers on each of %d GPUs" % (c["nw"], world) if world > 1 else ""), "name": name,
+                   "walkers_total": c["nw"] * world, "rng": "device-philox",
+                   "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                   "population_control": pc_label,
                    "sizes": {k: c[k] for k in ("M", "na", "nb", "K", "nw")}},
+        "population_control": pc_label,
+        "comm_stats": comm_stats, "comm_stats_per_rank": comm_per_rank,
+        "comm_probe": ("passed on every rank (%s)" % comm_kind) if device_comm else
+                      (None if world == 1 else "no device communicator: " + (comm_note or "not requested")),
+        "exchange_timing": exchange_timing,
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "last_block_ETotal": float(numpy.real(mixed.blocks[-1][5])) if mixed.blocks else None,
         "roofline": {"bound": "hbm" if dom["bound"] == "hbm" else "mfma", "kernel": dom["launch"] + " (" + dom["note"] + ")",
                      "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
@@ -357,7 +402,7 @@ def run_config(args, name, state):
         "roofline_all": rows[:16],
         "step_ms_in_traced_launches": sum(r["ms_per_step"] for r in rows),
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         state["phase"] = "cpu baseline"
         out["cpu_baseline"] = config_cpu_baseline(name, system, trial)
         if out["cpu_baseline"]["value"]:
@@ -665,6 +710,9 @@ def main():
                          "the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-rng", action="store_true", help="draw fields with numpy on the host (parity mode)")
+    ap.add_argument("--exchange-stress", type=float, default=0.0,
+                    help="N > 1: in the exchange-timing pass behind the timed regions, skew the weights between even and odd "
+                         "ranks before every comb so that about this fraction of the walkers crosses ranks (0.1 = 10 %%)")
     ap.add_argument("--open-shell", action="store_true",
                     help="C3: start every walker with its beta block perturbed by 1e-3 (open-shell walkers: none of the "
                          "closed-shell paths of the Green's function, the exchange energy and the fused propagator applies)")
@@ -719,10 +767,14 @@ def main():
             dist.init_process_group(backend=backend)
             comm = TorchComm(device=torch.device("cpu"))
     if args.config != "C3":
-        if world > 1:
-            raise SystemExit("bench.py: --config %s is one GPU's shard; the multi-GPU line is --config C3" % args.config)
-        print(json.dumps(run_config(args, args.config, state)))
-        sys.stdout.flush()
+        out = run_config(args, args.config, state, comm, world, rank, backend)
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+        if comm is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         return
     system, trial = build_inputs()
     scalings = ["weak", "strong"] if args.scaling == "both" else [args.scaling]
@@ -747,6 +799,96 @@ def last_block_energy(afqmc):
         return float(numpy.real(blocks[-1][5])) if blocks else None
     except Exception:
         return None
+
+
+def population_control_label(afqmc, comm_kind, comm_note, world, backend):
+    label = {'rccl': "device comb over the library's RCCL communicator (all-gather / all-reduce by RCCL, walkers written "
+                     "straight into the destination GPU's mapped window over xGMI, live slots only)",
+             'sendrecv': "device comb over the library's RCCL communicator (fixed-capacity ncclSend/ncclRecv slots)",
+             'ipc': "device comb over mapped peer windows (hipIpc, no RCCL; bootstrap over torch.distributed)"}.get(
+        comm_kind, "device comb (one rank)" if world == 1 else
+        "host-mediated (torch.distributed, backend %s)" % backend)
+    if comm_note and world > 1:
+        label += " [fell through: " + comm_note + "]"
+    return label
+
+
+def measure_exchange(state, afqmc, dev, comm, world, device_comm, first_step, eshift, stress=0.0, rank=0):
+    """Device-timed cost of the exchange steps (what the strong-scaling leg pays): two more blocks under
+    afq_launch_trace (an event pair around every launch, on the library's stream), every launch that belongs to a
+    population-control event or to the block reduction, averaged per event, on every rank.  A kernel that waits for a
+    peer's flag (the plan kernel on the window collectives, the unpack kernel) is timed WITH that wait.
+    ``stress`` > 0: before every comb of this pass the weights of the walkers of the even ranks are scaled up and those of
+    the odd ranks down so that about that fraction of the population has to cross ranks (the benchmark's own weights
+    hardly ever clone across ranks: an idle exchange is all the plain pass times).
+    Returns (exchange_timing, comm_stats, comm_stats_per_rank)."""
+    from pauxy_amd import _lib as L
+    state["phase"] = "exchange-step timing"
+    pc_steps = 2 * NSTEPS_BLOCK
+    stats0 = dev.comm_stats() if device_comm else None
+    dev.launch_trace(True)
+    if stress > 0.0:
+        # step by step: skew the weights right before each comb (host round trip: this pass is not a timed region)
+        step, e_ = first_step, eshift
+        for _ in range(pc_steps // NPOP):
+            e_ = afqmc.run_batched(NPOP - 1, first_step=step, eshift=e_)
+            wts = dev.get(L.F_WEIGHT)
+            # fraction f of the population must move: the giving ranks hold (1 + f') of the mean, the others (1 - f')
+            f_ = min(0.9, 2.0 * stress)
+            wts *= (1.0 + f_) if rank % 2 == 0 else (1.0 - f_)
+            dev.set(L.F_WEIGHT, wts)
+            afqmc.psi._invalidate('weight')
+            e_ = afqmc.run_batched(1, first_step=step + NPOP - 1, eshift=e_)
+            step += NPOP
+    else:
+        afqmc.run_batched(pc_steps, first_step=first_step, eshift=eshift)
+    dev.sync()
+    dev.launch_trace(False)
+    ltrace = dev.launch_trace_get()
+    pc_names = ("comm_prep_kernel", "ncclAllGather", "comb_plan_global_kernel", "comb_plan_kernel", "clone_kernel",
+                "comm_pack_kernel<true>", "ncclSend/Recv", "comm_pack_kernel<false>", "reset_kernel", "comm_plan_kernel",
+                "comm_move_kernel", "comm_unpack_kernel")
+    red_names = ("ncclAllReduce", "est_put_kernel", "est_sum_kernel", "est_reduce_kernel")
+    n_events, n_blocks = pc_steps // NPOP, pc_steps // NSTEPS_BLOCK
+    pc_us = {k: 1e3 * ms / n_events for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in pc_names)}
+    pc_launches = {k: cnt / n_events for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in pc_names)}
+    red_us = {k: 1e3 * ms / n_blocks for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in red_names)}
+    exchange_timing = {"per_popcontrol_event_us": pc_us, "popcontrol_event_us": sum(pc_us.values()),
+                       "launches_per_popcontrol_event": sum(pc_launches.values()),
+                       "per_block_reduction_us": red_us, "block_reduction_us": sum(red_us.values()),
+                       "ms_per_step_share": (sum(pc_us.values()) / NPOP + sum(red_us.values()) / NSTEPS_BLOCK) * 1e-3,
+                       "measured": "extra pass of %d steps under afq_launch_trace after the timed regions; device time of the "
+                                   "launches of one comb event (every %d steps) / one block reduction (every %d steps), "
+                                   "waits for peers' flags included" % (pc_steps, NPOP, NSTEPS_BLOCK)}
+    if stress > 0.0:
+        exchange_timing["stress"] = ("weights skewed by +-%.0f %% between even and odd ranks before every comb of this pass"
+                                     % (100.0 * min(0.9, 2.0 * stress)))
+    if comm is not None:
+        tot = numpy.zeros(2 * world)
+        comm.Allgather(numpy.array([exchange_timing["popcontrol_event_us"], exchange_timing["block_reduction_us"]]), tot)
+        exchange_timing["popcontrol_event_us_per_rank"] = tot[0::2].tolist()
+        exchange_timing["block_reduction_us_per_rank"] = tot[1::2].tolist()
+    comm_stats = dev.comm_stats() if device_comm else None
+    comm_per_rank = None
+    if device_comm and comm is not None:
+        # every rank's traffic of the run: walkers it wrote into peers' windows, events, largest per-peer transfer, flags
+        keys = ('walkers_sent', 'bytes_sent', 'events', 'max_transfer', 'overflow', 'error')
+        mine = numpy.array([float(comm_stats[k]) for k in keys])
+        allr = numpy.zeros(world * len(keys))
+        comm.Allgather(mine, allr)
+        allr = allr.reshape(world, len(keys))
+        comm_per_rank = {k: [int(x) for x in allr[:, i]] for i, k in enumerate(keys)}
+        ev = max(1, int(allr[0, 2]))
+        comm_per_rank["walkers_sent_per_event"] = float(allr[:, 0].sum()) / ev
+        if stats0 is not None:
+            # ... and of this pass alone (what the per-event times above moved)
+            d_w = float(comm_stats['walkers_sent'] - stats0['walkers_sent'])
+            d_b = float(comm_stats['bytes_sent'] - stats0['bytes_sent'])
+            tot2 = numpy.zeros(2 * world)
+            comm.Allgather(numpy.array([d_w, d_b]), tot2)
+            exchange_timing["walkers_sent_per_event_in_this_pass"] = float(tot2[0::2].sum()) / n_events
+            exchange_timing["bytes_sent_per_event_in_this_pass"] = float(tot2[1::2].sum()) / n_events
+    return exchange_timing, comm_stats, comm_per_rank
 
 
 def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, with_cpu_baseline):
@@ -796,14 +938,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
                          % (rank, comm_kind or 'host-mediated', comm_note or 'no reason recorded'))
         if os.environ.get("AFQ_BENCH_REQUIRE_DEVICE_COMM", "0") == "1":
             raise SystemExit(5)
-    pc_label = {'rccl': "device comb over the library's RCCL communicator (all-gather / all-reduce by RCCL, walkers written "
-                        "straight into the destination GPU's mapped window over xGMI, live slots only)",
-                'sendrecv': "device comb over the library's RCCL communicator (fixed-capacity ncclSend/ncclRecv slots)",
-                'ipc': "device comb over mapped peer windows (hipIpc, no RCCL; bootstrap over torch.distributed)"}.get(
-        comm_kind, "device comb (one rank)" if world == 1 else
-        "host-mediated (torch.distributed, backend %s)" % backend)
-    if comm_note and world > 1:
-        pc_label += " [fell through: " + comm_note + "]"
+    pc_label = population_control_label(afqmc, comm_kind, comm_note, world, backend)
 
     def barrier():
         dev.sync()
@@ -993,46 +1128,9 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     if traffic is None:
         traffic_source = None
 
-    # Device-timed cost of the exchange steps (what the strong-scaling leg pays): two more blocks under
-    # afq_launch_trace (an event pair around every launch, on the library's stream), every launch that belongs to a
-    # population-control event or to the block reduction, averaged per event, on every rank.  A kernel that waits for a
-    # peer's flag (the plan kernel on the window collectives, the unpack kernel) is timed WITH that wait.
-    state["phase"] = "exchange-step timing"
-    pc_steps = 2 * NSTEPS_BLOCK
-    dev.launch_trace(True)
-    afqmc.run_batched(pc_steps, first_step=first + extra_steps, eshift=eshift)
-    dev.sync()
-    dev.launch_trace(False)
-    ltrace = dev.launch_trace_get()
-    pc_names = ("comm_prep_kernel", "ncclAllGather", "comb_plan_global_kernel", "comb_plan_kernel", "clone_kernel",
-                "comm_pack_kernel<true>", "ncclSend/Recv", "comm_pack_kernel<false>", "reset_kernel")
-    red_names = ("ncclAllReduce", "est_put_kernel", "est_sum_kernel")
-    n_events, n_blocks = pc_steps // NPOP, pc_steps // NSTEPS_BLOCK
-    pc_us = {k: 1e3 * ms / n_events for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in pc_names)}
-    red_us = {k: 1e3 * ms / n_blocks for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in red_names)}
-    exchange_timing = {"per_popcontrol_event_us": pc_us, "popcontrol_event_us": sum(pc_us.values()),
-                       "per_block_reduction_us": red_us, "block_reduction_us": sum(red_us.values()),
-                       "ms_per_step_share": (sum(pc_us.values()) / NPOP + sum(red_us.values()) / NSTEPS_BLOCK) * 1e-3,
-                       "measured": "extra pass of %d steps under afq_launch_trace after the timed regions; device time of the "
-                                   "launches of one comb event (every %d steps) / one block reduction (every %d steps), "
-                                   "waits for peers' flags included" % (pc_steps, NPOP, NSTEPS_BLOCK)}
-    if comm is not None:
-        tot = numpy.zeros(2 * world)
-        comm.Allgather(numpy.array([exchange_timing["popcontrol_event_us"], exchange_timing["block_reduction_us"]]), tot)
-        exchange_timing["popcontrol_event_us_per_rank"] = tot[0::2].tolist()
-        exchange_timing["block_reduction_us_per_rank"] = tot[1::2].tolist()
-    comm_stats = dev.comm_stats() if device_comm else None
-    comm_per_rank = None
-    if device_comm and comm is not None:
-        # every rank's traffic of the run: walkers it wrote into peers' windows, events, largest per-peer transfer, flags
-        keys = ('walkers_sent', 'bytes_sent', 'events', 'max_transfer', 'overflow', 'error')
-        mine = numpy.array([float(comm_stats[k]) for k in keys])
-        allr = numpy.zeros(world * len(keys))
-        comm.Allgather(mine, allr)
-        allr = allr.reshape(world, len(keys))
-        comm_per_rank = {k: [int(x) for x in allr[:, i]] for i, k in enumerate(keys)}
-        ev = max(1, int(allr[0, 2]))
-        comm_per_rank["walkers_sent_per_event"] = float(allr[:, 0].sum()) / ev
+    exchange_timing, comm_stats, comm_per_rank = measure_exchange(state, afqmc, dev, comm, world, device_comm,
+                                                                  first + extra_steps, eshift,
+                                                                  stress=getattr(args, "exchange_stress", 0.0), rank=rank)
     exq = next((r for r in rows if "exchange energy" in r["kernel"]), None)
     out = None
     if rank == 0:

@@ -104,3 +104,35 @@ def test_bench_eight_ranks_reach_the_host_path_when_every_candidate_fails_on_one
     assert "rccl: librccl is not loadable on every rank" in out["population_control"]
     assert "ipc: probe failed on another rank" in out["population_control"] or "injected fault" in out["population_control"]
     assert out["comm_stats"] is None and out["comm_probe"].startswith("no device communicator")
+
+
+@pytest.mark.parametrize("name,walkers", [("C4", 256), ("C5", 256)])
+def test_bench_other_configurations_on_two_ranks(name, walkers):
+    """BASELINE configs[3] and [4] are 8-GPU configurations: `python bench.py --config C4|C5 --gpus N` runs the
+    configuration's population on every GPU (weak scaling) through the same multi-rank harness as the C3 line -- here two
+    ranks sharing the box's GPU over the mapped-window communicator (C4: slots of ~1 MiB per walker), with the exchange
+    timing and every rank's traffic in the line."""
+    (out,) = run_bench(["--config", name, "--gpus", "2", "--steps", "5", "--warmup", "5", "--repeats", "2"],
+                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "ipc"})
+    assert out["n_gpus"] == 2 and out["config"]["name"] == name and out["config"]["walkers_total"] == 2 * walkers
+    assert out["value"] == pytest.approx(2 * walkers * 1e3 / out["ms_per_step"], rel=1e-9)
+    assert out["population_control"].startswith("device comb over mapped peer windows")
+    assert out["comm_probe"].startswith("passed on every rank")
+    et = out["exchange_timing"]
+    assert et["popcontrol_event_us"] > 0.0 and len(et["popcontrol_event_us_per_rank"]) == 2
+    st = out["comm_stats_per_rank"]
+    assert len(st["events"]) == 2 and st["events"][0] == st["events"][1] > 0 and st["error"] == [0, 0]
+    assert len(out["rank_ms_per_step"]["per_rank"]) == 2
+    assert 0.0 < out["roofline"]["frac"] <= 1.0
+
+
+def test_bench_exchange_stress_moves_walkers_across_ranks():
+    """`--exchange-stress f`: the exchange-timing pass skews the weights between even and odd ranks before every comb, so
+    that the per-event time it reports is that of an exchange that actually moves walkers."""
+    (out,) = run_bench(["--gpus", "2", "--steps", "10", "--warmup", "10", "--exchange-stress", "0.1"],
+                       {"AFQ_BENCH_BACKEND": "gloo", "AFQ_BENCH_DEVICE_COMM": "ipc"})
+    et = out["exchange_timing"]
+    assert "stress" in et
+    assert et["walkers_sent_per_event_in_this_pass"] >= 0.05 * 512          # ~10 % of the 512 walkers cross per event
+    assert et["bytes_sent_per_event_in_this_pass"] > 0
+    assert out["comm_stats_per_rank"]["error"] == [0, 0]
