@@ -846,8 +846,7 @@ def measure_exchange(state, afqmc, dev, comm, world, device_comm, first_step, es
     dev.launch_trace(False)
     ltrace = dev.launch_trace_get()
     pc_names = ("comm_prep_kernel", "ncclAllGather", "comb_plan_global_kernel", "comb_plan_kernel", "clone_kernel",
-                "comm_pack_kernel<true>", "ncclSend/Recv", "comm_pack_kernel<false>", "reset_kernel", "comm_plan_kernel",
-                "comm_move_kernel", "comm_unpack_kernel")
+                "comm_pack_kernel<true>", "ncclSend/Recv", "comm_pack_kernel<false>", "reset_kernel", "comm_exchange_kernel")
     red_names = ("ncclAllReduce", "est_put_kernel", "est_sum_kernel", "est_reduce_kernel")
     n_events, n_blocks = pc_steps // NPOP, pc_steps // NSTEPS_BLOCK
     pc_us = {k: 1e3 * ms / n_events for k, (cnt, ms) in ltrace.items() if any(k.startswith(p_) for p_ in pc_names)}

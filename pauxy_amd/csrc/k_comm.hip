@@ -235,8 +235,7 @@ struct PackArgs {
 //  is what a rank COULD send, a comb moves a handful)
 #define COMM_GRID_Y 32
 template <bool PACK>
-__global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
-    const int peer = blockIdx.z;
+__device__ __forceinline__ void comm_pack_body(const PackArgs &a, const int peer) {
     if (peer == a.rank) return;
     const int count = a.count[peer];
     if ((int)blockIdx.y >= count) return;                         // (work-group uniform)
@@ -314,6 +313,26 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) {
         }
     }
 }
+template <bool PACK>
+__global__ __launch_bounds__(256) void comm_pack_kernel(PackArgs a) { comm_pack_body<PACK>(a, (int)blockIdx.z); }
+// Window transport, one process per rank (round 6): pack and unpack of one event in ONE launch, grid (4, y, 2 R): the blocks
+// z < R write this rank's live slots into the peers' windows and raise their flags, the blocks z >= R wait for the peers'
+// flags and move what arrived into the kill slots.  The pack blocks never wait and are dispatched first; an unpack block
+// waits for ANOTHER rank's pack blocks only.  (The in-process communicator of one host thread keeps the two launches: there
+// a rank's pack may sit behind the waiting kernel in the same hardware queue.)
+__global__ __launch_bounds__(256) void comm_exchange_kernel(PackArgs ps, PackArgs pr) {
+    if ((int)blockIdx.z < ps.nranks) comm_pack_body<true>(ps, (int)blockIdx.z);
+    else comm_pack_body<false>(pr, (int)blockIdx.z - pr.nranks);
+}
+
+__device__ __forceinline__ void comm_prep_window(const double *weight, int nw, double r, const PeerWindows &pw, const WinLayout &wl,
+                                                 int rank, unsigned long long seq, int peer) {
+    double *dst = wl.gw(pw.base[peer], (int)(seq & 1)) + (long)rank * wl.gw_n;
+    for (int i = threadIdx.x; i <= nw; i += blockDim.x) dst[i] = i < nw ? fabs(weight[i]) : r;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) flag_release(wl.flag_g(pw.base[peer]) + rank, seq);
+}
 
 // |weights| and rank 0's uniform: into the staging buffer of the RCCL all-gather, or (window collectives) straight into
 // row `rank` of every peer's gw of this event's parity, one block per peer, followed by that peer's flag
@@ -326,12 +345,7 @@ __global__ __launch_bounds__(256) void comm_prep_kernel(const double *weight, in
         if (i == nw) sendw[nw] = r;                                 // handler.py:276 (rank 0's is the one used)
         return;
     }
-    const int peer = blockIdx.x;
-    double *dst = wl.gw(pw.base[peer], (int)(seq & 1)) + (long)rank * wl.gw_n;
-    for (int i = threadIdx.x; i <= nw; i += blockDim.x) dst[i] = i < nw ? fabs(weight[i]) : r;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) flag_release(wl.flag_g(pw.base[peer]) + rank, seq);
+    comm_prep_window(weight, nw, r, pw, wl, rank, seq, (int)blockIdx.x);
 }
 
 // walkers/handler.py:225-301 for the global population, identically on every rank.  One 256-thread work-group;
@@ -349,10 +363,22 @@ struct PlanArgs {
     double *scal;
     const unsigned long long *gflag;     // window all-gather: flag_g[R] of this rank's window (else null)
     unsigned long long seq;
+    // window all-gather with one process per rank (round 6): the launch carries R more blocks, block 1 + p writes this rank's
+    // |weights| and uniform into peer p's window (comm_prep_kernel's work); block 0 -- the plan -- waits for every rank's row
+    // as before.  Nothing in this launch writes the weights (the division by the scale, handler.py:246, is overwritten by the
+    // reset to 1 of handler.py:337-338 before anything reads it), so the prep blocks may read them at any time.
+    int prep_R;
+    double prep_r;
+    PeerWindows pw;
+    WinLayout wl;
 };
 
 __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x > 0) {                                          // (only in launches with prep_R blocks behind the plan)
+        comm_prep_window(a.weight, a.nw, a.prep_r, a.pw, a.wl, a.rank, a.seq, (int)blockIdx.x - 1);
+        return;
+    }
     const int N = a.R * a.nw, nw = a.nw, R = a.R;
     double *cs = (double *)smem;
     int *pix = (int *)(cs + N);
@@ -390,10 +416,10 @@ __global__ __launch_bounds__(256) void comb_plan_global_kernel(PlanArgs a) {
         return;
     }
     const double scale = total / a.target;
-    for (int i = tid; i < nw; i += 256) {                         // handler.py:244-246, this rank's walkers
-        a.unscaled[i] = a.weight[i];
-        a.weight[i] = a.weight[i] / scale;
-    }
+    // handler.py:244-246, this rank's walkers.  (w.weight / scale is not stored: handler.py:337-338 sets every weight to 1
+    // before anything reads it -- clone and reset follow in the next launch -- and the prep blocks of a fused launch read the
+    // weights concurrently)
+    for (int i = tid; i < nw; i += 256) a.unscaled[i] = a.weight[i];
     loc = 0.0;
     for (int i = i0; i < i1; ++i) { loc += cs[i] / scale; cs[i] = loc; }     // global_weights / scale, :248
     double tot2;
@@ -650,7 +676,9 @@ void fill_pack(afq_handle *h, PackArgs &p, bool with_greens, bool send) {
     p.closed_bad = h->closed_bad; p.closed_epoch = h->closed_epoch; p.closed_half = 0;
 }
 
-int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
+// fused_prep: the launch of the plan also writes this rank's weights into the peers' windows (window all-gather, one process per
+// rank: k_comm_popcontrol); pack_now = false leaves the pack to the combined exchange launch of stage_unpack
+int stage_plan_pack(afq_handle *h, double target, bool with_greens, bool fused_prep = false, double r = 0.0, bool pack_now = true) {
     afq_comm_state *c = cs_of(h);
     const long N = (long)c->nranks * h->nw;
     const size_t lds = (sizeof(double) + 3 * sizeof(int)) * (size_t)N;
@@ -663,11 +691,12 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
     a.R = c->nranks; a.nw = h->nw; a.rank = c->rank; a.cap = c->cap; a.target = target;
     a.weight = h->weight; a.unscaled = h->unscaled; a.pix_global = c->pix; a.parent_ix = h->parent_ix;
     a.pairs = (int *)h->pack_tmp; a.lists = c->lists; a.scal = h->scal;
-    AFQ_LAUNCH(h, comb_plan_global_kernel, dim3(1), dim3(256), lds, h->stream, a);
+    a.prep_R = fused_prep ? c->nranks : 0; a.prep_r = r; a.pw = c->pw; a.wl = c->wl;
+    AFQ_LAUNCH(h, comb_plan_global_kernel, dim3(1 + a.prep_R), dim3(256), lds, h->stream, a);
     AFQ_POST(h);
-    int rc = k_clone_pairs(h, with_greens);
+    int rc = k_clone_pairs(h, with_greens, true);                 // ... and every weight back to 1 (handler.py:337-338)
     if (rc) return rc;
-    if (c->nranks > 1) {
+    if (c->nranks > 1 && pack_now) {
         PackArgs p;
         fill_pack(h, p, with_greens, true);
         AFQ_LAUNCH(h, comm_pack_kernel<true>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
@@ -676,7 +705,7 @@ int stage_plan_pack(afq_handle *h, double target, bool with_greens) {
     return AFQ_OK;
 }
 
-int stage_unpack(afq_handle *h, bool with_greens) {
+int stage_unpack(afq_handle *h, bool with_greens, bool pack_too = false) {
     // (the closed-shell verdict of this rank's population carries over when the walkers that arrive are checked too)
     const bool closed_too = with_greens && h->closed_bad && h->closed_checked_version == h->ghalf_version && h->na == h->nb;
     ++h->ghalf_version;                 // cloned / received walkers bring their Ghalf along
@@ -686,11 +715,17 @@ int stage_unpack(afq_handle *h, bool with_greens) {
         PackArgs p;
         fill_pack(h, p, with_greens, false);
         if (closed_too) p.closed_half = (long)h->na * h->M;
-        AFQ_LAUNCH(h, comm_pack_kernel<false>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
+        if (pack_too) {
+            PackArgs ps;
+            fill_pack(h, ps, with_greens, true);
+            AFQ_LAUNCH(h, comm_exchange_kernel, dim3(4, std::min(c->cap, COMM_GRID_Y), 2 * c->nranks), dim3(256), 0, h->stream, ps, p);
+        } else {
+            AFQ_LAUNCH(h, comm_pack_kernel<false>, dim3(4, std::min(c->cap, COMM_GRID_Y), c->nranks), dim3(256), 0, h->stream, p);
+        }
         AFQ_POST(h);
     }
     c->events += 1;
-    return k_reset_weights(h, true);                              // handler.py:337-338
+    return AFQ_OK;                                                // (the weights went back to 1 with the clones)
 }
 
 int check_group(afq_handle **hs, int n, std::string *err) {
@@ -764,16 +799,52 @@ __global__ __launch_bounds__(256) void est_sum_kernel(double *dst, long n, void 
     }
 }
 
+// put and sum of one chunk in ONE launch (one process per rank, round 6): blocks 0 .. R-1 write this rank's row into the
+// windows and raise the flags, the blocks behind them wait for every rank's row and sum IN PLACE.  Only the block that writes
+// this rank's OWN window reads the vector; the blocks for the other peers copy that row once its flag is up -- so when a sum
+// block has seen every flag (its own rank's included) nobody reads the vector any more and it may be overwritten.
+__global__ __launch_bounds__(256) void est_reduce_kernel(const double *src, double *dst, long n, PeerWindows pw, void *win, WinLayout wl,
+                                                         int rank, unsigned long long seq, double *scal) {
+    if ((int)blockIdx.x < wl.R) {
+        const int peer = blockIdx.x;
+        double *row = wl.est(pw.base[peer], (int)(seq & 1)) + (long)rank * wl.est_n;
+        if (peer != rank) {
+            __shared__ int s_mine;
+            if (threadIdx.x == 0) s_mine = flag_wait(wl.flag_e(win) + rank, seq) ? 1 : 0;
+            __syncthreads();
+            if (!s_mine) { if (threadIdx.x == 0) scal[6] = 1.0; return; }
+            src = wl.est(win, (int)(seq & 1)) + (long)rank * wl.est_n;
+        }
+        for (long i = threadIdx.x; i < n; i += blockDim.x) row[i] = src[i];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) flag_release(wl.flag_e(pw.base[peer]) + rank, seq);
+        return;
+    }
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    if (threadIdx.x < wl.R && !flag_wait(wl.flag_e(win) + threadIdx.x, seq)) s_ok = 0;
+    __syncthreads();
+    if (!s_ok) { if (threadIdx.x == 0 && (int)blockIdx.x == wl.R) scal[6] = 1.0; return; }
+    const double *rows = wl.est(win, (int)(seq & 1));
+    const long nb = (long)gridDim.x - wl.R;
+    for (long i = ((long)blockIdx.x - wl.R) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
+        double acc = 0.0;
+        for (int s = 0; s < wl.R; ++s) acc += rows[(long)s * wl.est_n + i];
+        dst[i] = acc;
+    }
+}
+
 // sum over ranks of the device vector v[0..n) in place, window collectives (chunks of the window's est rows)
 int window_allreduce(afq_handle *h, double *v, long n) {
     afq_comm_state *c = cs_of(h);
     for (long o = 0; o < n; o += c->wl.est_n) {
         const long m = std::min(c->wl.est_n, n - o);
         ++c->seq_e;
-        AFQ_LAUNCH(h, est_put_kernel, dim3(c->nranks), dim3(256), 0, h->stream, v + o, m, c->pw, c->wl, c->rank, c->seq_e);
-        AFQ_POST(h);
         const unsigned nblk = (unsigned)std::min<long>(64, (m + 255) / 256);
-        AFQ_LAUNCH(h, est_sum_kernel, dim3(nblk), dim3(256), 0, h->stream, v + o, m, c->win, c->wl, c->seq_e, h->scal);
+        AFQ_LAUNCH(h, est_reduce_kernel, dim3(c->nranks + nblk), dim3(256), 0, h->stream, v + o, v + o, m, c->pw, c->win, c->wl,
+                   c->rank, c->seq_e, h->scal);
         AFQ_POST(h);
     }
     return AFQ_OK;
@@ -891,15 +962,22 @@ int k_comm_popcontrol(afq_handle *h, double r, double target, bool with_greens) 
     if (c->mode == COMM_LOCAL) AFQ_FAIL(h, AFQ_ESTATE, "in-process communicator: use afq_popcontrol_comb_local for all ranks at once");
     RcclApi *api = c->mode == COMM_RCCL ? rccl_api() : nullptr;
     if (c->mode == COMM_RCCL && !api) AFQ_FAIL(h, AFQ_ESTATE, "RCCL is not loaded");
-    int rc = stage_prep(h, r);
-    if (rc) return rc;
-    if (!c->win_collectives) {
+    // Launches of one event (round 6; seven before): window collectives -- [prep + plan] [clones + reset] [pack + unpack];
+    // RCCL collectives -- [prep] ncclAllGather [plan] [clones + reset] [pack + unpack], or with the ncclSend / ncclRecv
+    // transport [pack] ncclSend/Recv [unpack]
+    int rc;
+    if (c->win_collectives) {
+        if ((rc = ensure_buffers(h))) return rc;
+        ++c->seq_g; ++c->seq_x;
+    } else {
+        if ((rc = stage_prep(h, r))) return rc;
         afq_note_launch(h, "ncclAllGather(weights)");
         AFQ_NCCL(h, api, api->AllGather(c->sendw, c->gw, (size_t)h->nw + 1, ncclDouble, c->nccl, h->stream));
     }
-    if ((rc = stage_plan_pack(h, target, with_greens))) return rc;
+    const bool one_launch = c->nranks > 1 && c->window;
+    if ((rc = stage_plan_pack(h, target, with_greens, c->win_collectives, r, !one_launch))) return rc;
     if (c->nranks > 1 && !c->window && (rc = sendrecv_slots(h, api))) return rc;
-    return stage_unpack(h, with_greens);
+    return stage_unpack(h, with_greens, one_launch);
 }
 
 extern "C" {
