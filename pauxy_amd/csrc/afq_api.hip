@@ -251,10 +251,10 @@ int afq_create(int device_id, afq_handle **out) {
     *h->retired = 0;
     h->debug_sync = getenv("AFQ_DEBUG_SYNC") != nullptr && atoi(getenv("AFQ_DEBUG_SYNC")) != 0;
     h->debug_markers = getenv("AFQ_DEBUG_MARKERS") != nullptr && atoi(getenv("AFQ_DEBUG_MARKERS")) != 0;
-    h->no_ring = afq_knob("AFQ_NO_RING") != nullptr;
-    h->no_fused = afq_knob("AFQ_NO_FUSED") != nullptr;
-    h->no_vhs_upper = afq_knob("AFQ_VHS_MIRROR") != nullptr;
-    h->greens_cache = afq_knob("AFQ_NO_GREENS_CACHE") == nullptr;
+    h->no_ring = AFQ_KNOB_SET("AFQ_NO_RING");
+    h->no_fused = AFQ_KNOB_SET("AFQ_NO_FUSED");
+    h->no_vhs_upper = AFQ_KNOB_SET("AFQ_VHS_MIRROR");
+    h->greens_cache = !AFQ_KNOB_SET("AFQ_NO_GREENS_CACHE");
     *out = h;
     return AFQ_OK;
 }
@@ -349,7 +349,7 @@ int afq_set_system_generic(afq_handle *h, int M, int K, int na, int nb, const do
     {   // hs_pot^T : [K, ld_hs] so that a VHS B-fragment is contiguous (even, zero-padded rows: the
         // LDS-DMA path moves 16-byte pairs of doubles).  Cholesky matrices of real orbitals are
         // symmetric in (p, q); then only the columns p <= q are kept and the VHS GEMM does half the work.
-        bool sym = afq_knob("AFQ_VHS_FULL") == nullptr;
+        bool sym = !AFQ_KNOB_SET("AFQ_VHS_FULL");
         for (int p = 0; p < M && sym; ++p)
             for (int q = p + 1; q < M && sym; ++q) {
                 const double *a = hs_pot + ((size_t)p * M + q) * K, *b = hs_pot + ((size_t)q * M + p) * K;
@@ -616,7 +616,7 @@ int afq_walkers_alloc(afq_handle *h, int nw) {
         // both spins share the Cholesky block: the contraction runs once over Ghalf_a + Ghalf_b (k_force_bias_generic),
         // half as long -- measured at C3: 4 slices (8 partials for fields_kernel to add) beat 8 by 1 % of the step
         if (h->rchol_same && h->rchol_real && h->ndet == 1 && h->na == h->nb && nw > 32 && sp > 1) sp = (sp + 1) / 2;
-        if (afq_knob("AFQ_FB_SPLIT")) sp = atoi(afq_knob("AFQ_FB_SPLIT"));
+        sp = AFQ_KNOB_INT("AFQ_FB_SPLIT", sp);
         const int nmax = std::max(h->na, h->nb) * h->M;
         while (sp > 1 && nmax / sp < 64) --sp;
         h->fb_split = sp;
@@ -1018,7 +1018,7 @@ int afq_propagate_finish(afq_handle *h, double eshift_re, double eshift_im) {
             const bool fb_diag = h->kind == AFQ_SYS_HUBBARD && !h->hirsch && h->psicT && k_greens_big_supported(h);
             h->ghalf_skip_store = h->fuse_est_req && h->ndet == 1 && (fb_sum || fb_diag) &&
                                   (h->flags & AFQ_PROP_HYBRID) && (h->flags & AFQ_PROP_FORCE_BIAS) && !h->rdm_on &&
-                                  h->nbp == 0 && h->psi_stride == 0 && !afq_knob("AFQ_NO_GHALF_SKIP");
+                                  h->nbp == 0 && h->psi_stride == 0 && !AFQ_KNOB_SET("AFQ_NO_GHALF_SKIP");
             h->ghalf_skipped = false;
             rc = greens_any(h, h->ovlp_new, true);
             h->fuse_weight_req = false;

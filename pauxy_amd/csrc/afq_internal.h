@@ -304,10 +304,16 @@ struct afq_handle {
 
 // tuning / A-B switches read from the environment exist only in builds made with -DAFQ_TUNING
 // (make TUNING=1); the product library has none of them
+// AFQ_KNOB_SET("X"): is switch X set?  AFQ_KNOB_INT("X", d): its integer value, d when unset.  In the product build both
+// are constants (false / d), no environment is read, and every kernel variant a switch selects sits inside an
+// `#ifdef AFQ_TUNING` region, so the product library does not even contain it.
 #ifdef AFQ_TUNING
 inline const char *afq_knob(const char *name) { return getenv(name); }
+#define AFQ_KNOB_SET(name) (afq_knob(name) != nullptr)
+#define AFQ_KNOB_INT(name, dflt) (afq_knob(name) ? atoi(afq_knob(name)) : (dflt))
 #else
-inline const char *afq_knob(const char *) { return nullptr; }
+#define AFQ_KNOB_SET(name) false
+#define AFQ_KNOB_INT(name, dflt) (dflt)
 #endif
 
 // every kernel launch goes through AFQ_LAUNCH / AFQ_GEMM + AFQ_POST: the name of the kernel is left in the

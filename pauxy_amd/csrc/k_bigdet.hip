@@ -818,13 +818,13 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
         p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
         p.phi = h->phi; p.psic = h->psic; p.psi_stride = h->psi_stride; p.O = h->big_ws; p.zero = (const cplx *)h->zero_page;
 #ifdef AFQ_TUNING
-        if (afq_knob("AFQ_OVLP_CFG")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        if (AFQ_KNOB_SET("AFQ_OVLP_CFG")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+        else if (AFQ_KNOB_SET("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+        else if (AFQ_KNOB_SET("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+        else if (AFQ_KNOB_SET("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         else
 #endif
-        if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-        else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
-        else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        AFQ_GEMM_AS(h, "k_greens_big: OvlpProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         return AFQ_OK;
     };
     {
@@ -837,16 +837,16 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
         a.O = h->big_ws; a.detm = h->detm; a.dete = h->dete;
         // blocked Gauss-Jordan on the matrix pipe for more than one block of 32; the step-by-step kernel for matrices it flags
         // as poorly conditioned block-wise (none in any test or benchmark so far) and for tuning builds that ask for it
-        const bool blocked = nmax > 32 && !afq_knob("AFQ_GJ_STEPWISE");     // (up to 32: one leaf would do all the work)
+        const bool blocked = nmax > 32 && !AFQ_KNOB_SET("AFQ_GJ_STEPWISE");     // (up to 32: one leaf would do all the work)
         if (blocked) {
             static size_t lds_set[AFQ_MAX_DEVICES] = {0};
             AFQ_HIP(h, afq_raise_lds((const void *)gj_mfma_kernel, GjMfmaLds::BYTES, lds_set));
             if (!h->gj_flag) AFQ_HIP(h, hipMalloc(&h->gj_flag, sizeof(int) * nb2));
-            a.dbg = afq_knob("AFQ_GJ_DBG") ? atoi(afq_knob("AFQ_GJ_DBG")) : 0;
+            a.dbg = AFQ_KNOB_INT("AFQ_GJ_DBG", 0);
 #ifdef AFQ_TUNING
             static unsigned long long *ts_dev = nullptr;
             static int ts_launch = 0;
-            if (afq_knob("AFQ_GJ_TS")) {
+            if (AFQ_KNOB_SET("AFQ_GJ_TS")) {
                 if (!ts_dev) { hipMalloc(&ts_dev, 512 * 8); hipMemset(ts_dev, 0, 512 * 8); }
                 a.ts = ts_dev;
             }
@@ -896,13 +896,13 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
             p.skip_store = 0;
             if (decltype(p)::COLDOT && h->ghalf_skip_store) { p.skip_store = 1; h->ghalf_skipped = true; }
 #ifdef AFQ_TUNING
-            if (afq_knob("AFQ_GHALF_CFG")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            if (AFQ_KNOB_SET("AFQ_GHALF_CFG")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<4, 2, 1, 4, 4, decltype(p), MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
             else
 #endif
-            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            AFQ_GEMM_AS(h, "k_greens_big: GhalfProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, decltype(p), MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
             return AFQ_OK;
         };
         // Hubbard, the walkers' own Ghalf, shared single-determinant trial: the diagonal of G comes along
@@ -913,7 +913,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
             // the last writer used
             const int parts16 = (nmax + 15) / 16;
             if (!h->gdiag) AFQ_HIP(h, hipMalloc(&h->gdiag, sizeof(cplx) * (size_t)nb2 * parts16 * h->M));
-            if (h->ghalf_skip_store && h->psi_real && !afq_knob("AFQ_NO_GDIAG_REAL")) {
+            if (h->ghalf_skip_store && h->psi_real && !AFQ_KNOB_SET("AFQ_NO_GDIAG_REAL")) {
                 // only diag G is wanted and the trial is real: W = conj(psi) O^-1 (real by complex), rowdot with phi
                 GdiagProbT p;
                 p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
@@ -923,7 +923,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
                 h->gdiag_parts = parts16;
                 h->ghalf_skipped = true;
 #ifdef AFQ_TUNING
-                const int gc = afq_knob("AFQ_GDIAG_CFG") ? atoi(afq_knob("AFQ_GDIAG_CFG")) : 0;
+                const int gc = AFQ_KNOB_INT("AFQ_GDIAG_CFG", 0);
                 if (gc == 1) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (gc == 2) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (gc == 3) AFQ_GEMM_AS(h, "k_greens_big: GdiagProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GdiagProbT, MAP_COLS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
@@ -941,7 +941,7 @@ int k_greens_big(afq_handle *h, cplx *ghalf, cplx *det, cplx *oinv, const Weight
                 h->gdiag_version = h->ghalf_version;
                 return AFQ_OK;
             }
-            h->gdiag_parts = afq_knob("AFQ_GHALF_CFG") ? parts16 : (nmax + 31) / 32;
+            h->gdiag_parts = AFQ_KNOB_SET("AFQ_GHALF_CFG") ? parts16 : (nmax + 31) / 32;
             const int rc = run(GhalfProbT<true>());
             if (rc) return rc;
             h->gdiag_version = h->ghalf_version;
@@ -1039,6 +1039,7 @@ struct CholArgs {
 // after step k the slots (i > k, k) hold -m_i = column k of the unit-lower inverse factor, so at the
 // end v[i][j] (j < i) = Ltilde^-1[i][j] with S = Ltilde D Ltilde^H, and
 //     T = R^-1 = Ltilde^-H D^-1/2,   Tt[i][j] = T[j][i] = conj(v[i][j]) / sqrt(D_i).
+#ifdef AFQ_TUNING      // (tuning builds only: AFQ_CHOL_STEPWISE; the product runs chol_mfma_kernel)
 __global__ __launch_bounds__(512) void chol_linv_kernel(CholArgs a) {
     __shared__ cplx colk[2][GJ_N], rowk[2][GJ_N];
     __shared__ double piv[GJ_N];
@@ -1137,6 +1138,7 @@ __global__ __launch_bounds__(512) void chol_linv_kernel(CholArgs a) {
         }
     }
 }
+#endif
 
 // Blocked version of chol_linv_kernel on the matrix pipe (round 4; the structure of gj_mfma_kernel: eight waves per matrix,
 // 16 x 16 tiles in MFMA accumulator layout, wave w > 0 owns the tiles (I, (I + w) mod 8), the pivot wave 0 keeps the
@@ -1406,20 +1408,25 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = nmax; p.cols = nmax; p.kdim = h->M;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.S = h->big_ws; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+#ifdef AFQ_TUNING
+            if (AFQ_KNOB_SET("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            else
+#endif
             // round 5: the lean loop at two work-groups per CU (mfma_gemm_wg.h, STAG = 5): 238 -> 218 us at C4.  (The overlap
             // and Ghalf GEMMs of the Green's function measured 2-3 % SLOWER that way and keep the pipelined loop.)
-            else AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            AFQ_GEMM_AS(h, "k_reortho_big: GramProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GramProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         }
         {
             CholArgs a;
             a.na = h->na; a.nb = h->nb; a.ld = nmax;
             a.S = h->big_ws; a.Tt = h->big_ws2; a.logd = h->qr_logd + (size_t)pass * nb2; a.fail = h->qr_fail;
             if (nmax <= 32) AFQ_LAUNCH(h, chol_small_kernel, dim3((nb2 + 3) / 4), dim3(256), 0, h->stream, a, nb2);
-            else if (afq_knob("AFQ_CHOL_STEPWISE")) AFQ_LAUNCH(h, chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+#ifdef AFQ_TUNING
+            else if (AFQ_KNOB_SET("AFQ_CHOL_STEPWISE")) AFQ_LAUNCH(h, chol_linv_kernel, dim3(nb2), dim3(512), 0, h->stream, a);
+#endif
             else {
                 static size_t lds_set[AFQ_MAX_DEVICES] = {0};
                 AFQ_HIP(h, afq_raise_lds((const void *)chol_mfma_kernel, CholMfmaLds::BYTES, lds_set));
@@ -1432,11 +1439,14 @@ int k_reortho_big(afq_handle *h) {
             p.batch = nb2; p.rows = h->M; p.cols = nmax; p.kdim = nmax;
             p.nt = h->nt; p.na = h->na; p.nb = h->nb; p.ld = nmax;
             p.x = src; p.Tt = h->big_ws2; p.out = dst; p.fail = h->qr_fail; p.zero = (const cplx *)h->zero_page;
-            if (afq_knob("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));   // 253 -> 230 us
+#ifdef AFQ_TUNING
+            if (AFQ_KNOB_SET("AFQ_BIG_LEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_WPE")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_NOLOADER")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_BIG_NOLEAN")) AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+            else
+#endif
+            AFQ_GEMM_AS(h, "k_reortho_big: QProb GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, QProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));   // 253 -> 230 us
         }
     }
     AFQ_LAUNCH(h, qr_finish_kernel, dim3((h->nw + 127) / 128), dim3(128), 0, h->stream, h->qr_logd,

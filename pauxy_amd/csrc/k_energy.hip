@@ -543,17 +543,17 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     if (S < 1) S = 1;
     if (S > EXQ_MAX_BATCH / 2) S = EXQ_MAX_BATCH / 2;
     while (S > 1 && nmax / S < 64) --S;
-    if (afq_knob("AFQ_EXQ_SPLIT")) S = atoi(afq_knob("AFQ_EXQ_SPLIT"));
+    S = AFQ_KNOB_INT("AFQ_EXQ_SPLIT", S);
     // Closed-shell population (every walker's Ghalf_b == Ghalf_a, verified on the device by the Green's function launch this
     // Ghalf comes from: closed_checked_version) and one Atil for both spins: the 2 S slices of the FIRST launch all belong to
     // spin alpha (every XCD busy), the second launch holds spin beta's and returns at once on the device when the flag says
     // closed; energy_finish_kernel then counts the alpha sums twice.  Nothing is decided on the host.
     const bool closed_try = h->closed_bad && h->closed_checked_version == h->ghalf_version && h->closed_checked_version != 0 &&
-                            h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !afq_knob("AFQ_NO_CLOSED_EXX");
+                            h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !AFQ_KNOB_SET("AFQ_NO_CLOSED_EXX");
     // (slices of the one-spin launch: 2 S, as many work-groups as the two-spin launch has.  C3, us per evaluation: S = 4
     //  slices 106.6, 5 100.9, 6 96.9, 7 91.4, 8 = 2 S 96.9, 10 139.8, 16 107.3; the two-spin launch 138.9)
     int SL = closed_try ? 2 * S : S;
-    if (closed_try && afq_knob("AFQ_EXQ_CLOSED_SL")) SL = atoi(afq_knob("AFQ_EXQ_CLOSED_SL"));
+    if (closed_try) SL = AFQ_KNOB_INT("AFQ_EXQ_CLOSED_SL", SL);
     if (SL > EXQ_MAX_BATCH) SL = EXQ_MAX_BATCH;
     const int NB = closed_try ? SL : 2 * S;                      // batches of one launch
     ExxQProb<RC> p;
@@ -601,7 +601,6 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
     // (round 4: the loader-wave configuration for long contractions too: C5 sizes 6.63 -> 6.36 ms per evaluation)
-    const int cfg = afq_knob("AFQ_EXQ_CFG") ? atoi(afq_knob("AFQ_EXQ_CFG")) : 1;
     {
         if (pass == 0) {   // every configuration below multiplies 64 x 64 work-group tiles; the contraction of a tile is its KCUT length
             auto klen = [&](int b, int col0, int ncols) -> long {
@@ -612,19 +611,15 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
         }
         // round 4: four compute waves with 2 x 2 tiles + four loader waves (STAG = 3: the ring refill kept out of the waves
         // that issue MFMAs; see the HS-potential GEMM in k_gemm.hip): 155 -> 139 us per evaluation at C3 against the eight
-        // compute waves with 1 x 2 tiles that refill the ring themselves (cfg 9, the round-3 choice)
+        // compute waves with 1 x 2 tiles that refill the ring themselves (the round-3 choice)
         // round 5: a complex Atil (3-multiplication products, 144 VGPRs) on the lean loop at two work-groups per CU
         // (k_apply_exponential in k_gemm.hip): 9.95 -> 9.74 ms per determinant at C5; the real one (99 VGPRs) is two per CU anyway
-        if (cfg == 1 && pass == 1) {
-            ExxQBetaProb<RC> pb;
-            static_cast<ExxQProb<RC> &>(pb) = p;
-            if (RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(pb, h->stream, h->zero_page)));
-            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(pb, h->stream, h->zero_page)));
-        }
-        else if (cfg == 1 && RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
-        else if (cfg == 1 || cfg == 16) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
-        else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        // (short contractions -- several slices: C3 sizes -- on eight waves with a 1 x 2 tile block each, the ring depths, the
+        //  pipelined loops and the two-work-groups-per-CU variants measured against these are in tuning builds: AFQ_EXQ_CFG)
 #ifdef AFQ_TUNING
+        const int cfg = AFQ_KNOB_INT("AFQ_EXQ_CFG", 1);
+        if (cfg == 16) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
+        else if (cfg == 9) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
         else if (cfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 1, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
@@ -636,13 +631,20 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
         else if (cfg == 15) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 10) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3, 4>(p, h->stream, h->zero_page)));
         else if (cfg == 11) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2, 4>(p, h->stream, h->zero_page)));
-#endif
         else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
         else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD, RC>(p, h->stream, h->zero_page)));
-#ifdef AFQ_TUNING
-        else if (afq_knob("AFQ_EXQ_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+        else if (AFQ_KNOB_SET("AFQ_EXQ_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 2>(p, h->stream, h->zero_page)));
+        else if (cfg != 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        else
 #endif
-        else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC>(p, h->stream, h->zero_page)));
+        if (pass == 1) {
+            ExxQBetaProb<RC> pb;
+            static_cast<ExxQProb<RC> &>(pb) = p;
+            if constexpr (RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(pb, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQBetaProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(pb, h->stream, h->zero_page)));
+        }
+        else if constexpr (RC) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 5, 4>(p, h->stream, h->zero_page)));
+        else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ExxQProb<RC>, MAP_BATCH_XCD_ROWS, RC, 1, 3>(p, h->stream, h->zero_page)));
     }
     }   // pass
     *S_out = closed_try ? NB : S; *two_pass = closed_try;        // (two-pass: batches per pass)

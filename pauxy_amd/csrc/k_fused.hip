@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
 }
 
 int k_prop_fused_supported(afq_handle *h) {
-    return !h->no_fused && !h->vhs_diag && h->nv == 1 && h->M <= 104 && h->na <= 32 && h->nb <= 32 && (h->nb > 0 || afq_knob("AFQ_PF_NB0"));
+    return !h->no_fused && !h->vhs_diag && h->nv == 1 && h->M <= 104 && h->na <= 32 && h->nb <= 32 && (h->nb > 0 || AFQ_KNOB_SET("AFQ_PF_NB0"));
 }
 
 int k_prop_fused(afq_handle *h) {
@@ -1263,37 +1263,37 @@ int k_prop_fused(afq_handle *h) {
     a.M = h->M; a.na = h->na; a.nb = h->nb; a.nt = h->nt; a.order = h->exp_order;
     a.vhs_upper = h->vhs_upper ? 1 : 0;
     // 4x4x4 Taylor products (tuning builds only): M <= 100 (six full row tiles + at most four remainder rows)
-    a.t4 = (h->M <= 100 && afq_knob("AFQ_T4")) ? 1 : 0;
-    a.dbg = afq_knob("AFQ_PF_DBG") ? atoi(afq_knob("AFQ_PF_DBG")) : 0;
+    a.t4 = (h->M <= 100 && AFQ_KNOB_SET("AFQ_T4")) ? 1 : 0;
+    a.dbg = AFQ_KNOB_INT("AFQ_PF_DBG", 0);
     a.ts = nullptr;
 #ifdef AFQ_TUNING
     static unsigned long long *ts_dev = nullptr;
     static int ts_launch = 0;
-    if (afq_knob("AFQ_PF_TS")) {
+    if (AFQ_KNOB_SET("AFQ_PF_TS")) {
         if (!ts_dev) { hipMalloc(&ts_dev, (256 + 512) * 8); hipMemset(ts_dev, 0, (256 + 512) * 8); }
         a.ts = ts_dev;
     }
 #endif
-    a.same_b = (h->bh1_same && !afq_knob("AFQ_NO_SAME_B")) ? 1 : 0;
-    a.b_real = (h->bh1_real && !afq_knob("AFQ_NO_REAL_B")) ? 1 : 0;
-    a.rem4 = (h->M > 96 && h->M <= 100 && !afq_knob("AFQ_PF_NOREM")) ? 1 : 0;
+    a.same_b = (h->bh1_same && !AFQ_KNOB_SET("AFQ_NO_SAME_B")) ? 1 : 0;
+    a.b_real = (h->bh1_real && !AFQ_KNOB_SET("AFQ_NO_REAL_B")) ? 1 : 0;
+    a.rem4 = (h->M > 96 && h->M <= 100 && !AFQ_KNOB_SET("AFQ_PF_NOREM")) ? 1 : 0;
     // hybrid column tiling: both spins with 17 .. 28 electrons and the same number of 4-column units in their second slot
     // (measured NEGATIVE at C3, round 4: 148.6 us against 145.5 us -- three 4x4x4 units need 9 MFMA + 3 add instructions where
     //  the padded 16x16x4 tile needs 3 + 1, and a wave that multiplies mostly units is bound by instruction issue, not by the
     //  matrix pipe; tuning builds only, AFQ_PF_HYB=1)
     a.hyb = 0;
     if (a.rem4 && h->na > 16 && h->nb > 16 && h->na <= 28 && h->nb <= 28 && (h->na - 13) / 4 == (h->nb - 13) / 4 &&
-        PF_NW == 8 && afq_knob("AFQ_PF_HYB"))
+        PF_NW == 8 && AFQ_KNOB_SET("AFQ_PF_HYB"))
         a.hyb = (h->na - 13) / 4;
     // contiguous columns: one one-body matrix for both spins (the HS potential never depends on the spin), 48 < na + nb <= 56
     // (a third unit per row tile would unbalance the deal and push wave 7 over 256 registers)
     a.contig = 0; a.symcols = 0;
     if (a.rem4 && a.same_b && h->na > 16 && h->nb > 16 && h->nt > 48 && h->nt <= 56 && PF_NW == 8 && !a.hyb &&
-        !afq_knob("AFQ_PF_NOCONTIG")) {
+        !AFQ_KNOB_SET("AFQ_PF_NOCONTIG")) {
         a.contig = 1;
         a.hyb = (h->nt - 48 + 3) / 4;
     }
-    a.symcols = (a.contig && h->na == h->nb && !afq_knob("AFQ_PF_NOSYM")) ? 1 : 0;
+    a.symcols = (a.contig && h->na == h->nb && !AFQ_KNOB_SET("AFQ_PF_NOSYM")) ? 1 : 0;
     a.closed_try = 0;           // (set below, once the deal is known)
     a.BH1 = h->BH1; a.vhs = h->vhs; a.phi = h->phi; a.alive = h->alive; a.zero16 = h->zero_page;
     a.n_closed = h->counters + 3;
@@ -1322,12 +1322,12 @@ int k_prop_fused(afq_handle *h) {
     // every tile of the deal present: wide with 5-7 row tiles (waves 4-7 own the tiles from 4 on) and two column tiles
     // per spin, or narrow with six row tiles
     const int nrt = (h->M + 15) / 16;
-    const bool nofull = PF_NW != 8 || afq_knob("AFQ_PF_NOFULL");
+    const bool nofull = PF_NW != 8 || AFQ_KNOB_SET("AFQ_PF_NOFULL");
     const int full = nofull ? 0 : narrow ? (nrt == 6 ? 6 : 0) : (nrt >= 5 && h->na > 16 && h->nb > 16 ? nrt : 0);
     // closed-shell deals: one matrix for both spins (the chain then acts on the spin blocks alike), as many electrons of
     // either spin, and a deal without holes: the contiguous-column deal with twins in like slots (symcols), or two slots per spin
     a.closed_try = (a.same_b && h->na == h->nb && h->exp_order > 0 && full != 0 && PF_NW == 8 && !a.t4 &&
-                    (a.contig ? a.symcols != 0 : a.hyb == 0) && !afq_knob("AFQ_PF_NOCLOSED")) ? 1 : 0;
+                    (a.contig ? a.symcols != 0 : a.hyb == 0) && !AFQ_KNOB_SET("AFQ_PF_NOCLOSED")) ? 1 : 0;
 #define PF_LAUNCH_(NARROW_, FULL_, SLOT_)                                                                     \
     do {                                                                                                      \
         AFQ_HIP(h, afq_raise_lds((const void *)prop_fused_kernel<NARROW_, FULL_>, lds, lds_set[SLOT_]));      \

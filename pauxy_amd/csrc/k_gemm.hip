@@ -117,23 +117,25 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // smaller shapes: twice the MFMAs per chunk and barrier (C4, 256 x 256 per walker: 302 -> 272 us, 1.84 -> 1.77 ms per step)
         const long padC = (long)((M + 127) / 128) * 128 * ((ns + 127) / 128) * 128;
 #ifdef AFQ_TUNING
-        const int ocfg = afq_knob("AFQ_OB_CFG") ? atoi(afq_knob("AFQ_OB_CFG")) : 0;
+        const int ocfg = AFQ_KNOB_INT("AFQ_OB_CFG", 0);
         if (ocfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         else if (ocfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 8, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
         else if (ocfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
-        else
-#endif
-        if (afq_knob("AFQ_OB_NOLOADER")) {
+        else if (AFQ_KNOB_SET("AFQ_OB_NOLOADER")) {
             if (padC <= padA && padC <= padB) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
             else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
         }
+        else if (AFQ_KNOB_SET("AFQ_OB_NOLEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        else
+#endif
+        (void)padA, (void)padB, (void)padC;
         // round 4: 64 x 64 tiles on four compute waves (2 x 2 MFMA tiles each) + four loader waves that do nothing but the
         // ring refill (STAG = 3): C4 (256 x 256 per walker, real BH1) 338 -> 300 us against the 128 x 128 tiles above, C5
         // sizes (400 x 100) 444 -> 384 us against 64 x 128; the small tile also pads least
         // round 5: a complex BH1 (3-multiplication products: 142 VGPRs, one work-group per CU) runs the lean loop at 122 VGPRs
         // so that two work-groups share a CU (see k_apply_exponential); the real one (97 VGPRs) is two per CU as it is
-        else if (!AR && !afq_knob("AFQ_OB_NOLEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+        if constexpr (!AR) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
         else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
@@ -249,7 +251,7 @@ __global__ void ghalf_sum_kernel(const cplx *ghalf, cplx *out, long half, long n
 // partials keep their layout (every consumer sums all of them): they become 2 * nsplit slices of the one contraction.
 bool k_fb_use_sum(afq_handle *h) {
     return h->rchol_same && h->rchol_real && h->ndet == 1 && h->na == h->nb && h->nw > 32 && !h->no_ring &&
-           !afq_knob("AFQ_FB_NOSUM");
+           !AFQ_KNOB_SET("AFQ_FB_NOSUM");
 }
 
 static int force_bias_generic_impl(afq_handle *h);
@@ -260,7 +262,7 @@ int k_force_bias_generic(afq_handle *h) {
     // (multi-determinant trial: one set of partials, and one version, per determinant -- the Coulomb vectors of an energy
     //  evaluation serve the force bias of the next step as they do for one determinant)
     unsigned long long &ver = h->ndet == 1 ? h->vbias_version : h->dets[h->cur_det].vbias_version;
-    if (ver == h->ghalf_version && !afq_knob("AFQ_FB_NOREUSE")) return AFQ_OK;
+    if (ver == h->ghalf_version && !AFQ_KNOB_SET("AFQ_FB_NOREUSE")) return AFQ_OK;
     const int rc = force_bias_generic_impl(h);
     ver = rc == AFQ_OK ? h->ghalf_version : 0;
     return rc;
@@ -268,7 +270,7 @@ int k_force_bias_generic(afq_handle *h) {
 
 // every determinant's partials are current (left behind by the energy evaluation on the same Green's functions)
 bool k_msd_vbias_current(afq_handle *h) {
-    if (h->ndet <= 1 || afq_knob("AFQ_FB_NOREUSE")) return false;
+    if (h->ndet <= 1 || AFQ_KNOB_SET("AFQ_FB_NOREUSE")) return false;
     for (int d = 0; d < h->ndet; ++d) if (h->dets[d].vbias_version != h->ghalf_version) return false;
     return true;
 }
@@ -302,35 +304,38 @@ static int force_bias_generic_impl(afq_handle *h) {
             // work-group tile 64 walkers x 64 fields (cfg 2), operands shared through the LDS ring.  Measured at C3
             // together with the reduction of the split-K partial sums in fields_kernel (step time, us):
             // 64x128 tile / 16 slices 553.7, 64x64 / 8 slices 545.4, 32x64 / 8 slices 545.3, 64x64 / 4 slices 553.6
-            static const int cfg = afq_knob("AFQ_FB_CFG") ? atoi(afq_knob("AFQ_FB_CFG")) : 2;
-            static const int kc = afq_knob("AFQ_GEMM_KC") ? atoi(afq_knob("AFQ_GEMM_KC")) : 1;
+#ifdef AFQ_TUNING
+            static const int cfg = AFQ_KNOB_INT("AFQ_FB_CFG", 2);
+            static const int kc = AFQ_KNOB_INT("AFQ_GEMM_KC", 1);
             if (cfg == 1) {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
                 if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 2>(p, h->stream, h->zero_page)));
                 else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
             }
-            else if (cfg == 2) {
+            else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else if (cfg != 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+            else
+#endif
+            {
                 KernelTrace kt(h, AFQ_K_FORCE_BIAS);
                 h->issued_flops[AFQ_K_FORCE_BIAS] = mfma_gemm_wg_issued_flops<4, 2, 1, 2, ForceBiasProb<false>>(
                     p, [&](int, int, int) -> long { return p.kdim; });
                 // half-chunk pipelined loop (STAG = 2): 56 us at C3 against 58 (staggered halves) / 61 (plain loop)
 #ifdef AFQ_TUNING
-                if (afq_knob("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
-                else if (afq_knob("AFQ_GEMM_STAG1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 1>(p, h->stream, h->zero_page)));
-                else if (afq_knob("AFQ_FB_LOADER")) {
-                    const int v = atoi(afq_knob("AFQ_FB_LOADER"));
+                if (AFQ_KNOB_SET("AFQ_GEMM_NOSTAG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
+                else if (AFQ_KNOB_SET("AFQ_GEMM_STAG1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 1>(p, h->stream, h->zero_page)));
+                else if (AFQ_KNOB_SET("AFQ_FB_LOADER")) {
+                    const int v = AFQ_KNOB_INT("AFQ_FB_LOADER", 0);
                     if (v == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                     else if (v == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 4, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                     else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                 }
-                else if (afq_knob("AFQ_FB_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
+                else if (AFQ_KNOB_SET("AFQ_FB_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
                 else
 #endif
                 // round 4: the ring refill on eight loader waves of its own (STAG = 3; see the HS-potential GEMM): 32.9 -> 31.8 us
                 AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
             }
-            else if (cfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
-            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, ForceBiasProb<false>, MAP_BATCH_XCD>(p, h->stream, h->zero_page)));
         } else {
             DISPATCH_TILES(h, p, tc, MAP_BATCH_XCD, 4);
         }
@@ -475,7 +480,7 @@ int k_force_bias_msd_gbar(afq_handle *h) {
         p.batch = nw; p.rows = M; p.cols = M; p.kdim = 2 * KK; p.KK = KK; p.M = M; p.ldS = h->ld_hs;
         p.psicT = h->msd_psicT; p.gs = h->msd_gs; p.S = h->msd_S;
 #ifdef AFQ_TUNING
-        const int gcfg = afq_knob("AFQ_GBAR_CFG") ? atoi(afq_knob("AFQ_GBAR_CFG")) : 0;
+        const int gcfg = AFQ_KNOB_INT("AFQ_GBAR_CFG", 0);
         if (gcfg == 1) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
         else if (gcfg == 2) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<2, 2, 2, 2, 4, GbarSymProb, MAP_BATCH_XCD_ROWS, true, 1, 3>(p, h->stream, h->zero_page)));
         else if (gcfg == 3) AFQ_GEMM_AS(h, "msd_gbar_fold GEMM", (launch_mfma_gemm_wg<4, 2, 2, 4, 4, GbarSymProb, MAP_BATCH_XCD, true>(p, h->stream, h->zero_page)));
@@ -567,7 +572,7 @@ struct VhsProb {
 static void gemm_ts_dump(afq_handle *h, const char *what) {
     static unsigned long long *buf = nullptr;
     static int n = 0;
-    if (!afq_knob("AFQ_GEMM_TS")) return;
+    if (!AFQ_KNOB_SET("AFQ_GEMM_TS")) return;
     if (!buf) {
         hipMalloc(&buf, (64 * 4 + 64) * 8);
         hipMemset(buf, 0, (64 * 4 + 64) * 8);
@@ -588,7 +593,7 @@ int k_vhs_generic(afq_handle *h) {
 #ifdef AFQ_TUNING
     struct Dump { afq_handle *h; ~Dump() { gemm_ts_dump(h, "after VHS"); } } dump_{h};
     // timing ablations of the ring loop (mfma_gemm_wg.h: afq_gemm_abl), for this GEMM only: set and cleared in stream order
-    static const int vhs_abl = afq_knob("AFQ_VHS_ABL") ? atoi(afq_knob("AFQ_VHS_ABL")) : 0;
+    static const int vhs_abl = AFQ_KNOB_INT("AFQ_VHS_ABL", 0);
     static const int abl_zero = 0;
     struct Abl {
         afq_handle *h;
@@ -605,7 +610,8 @@ int k_vhs_generic(afq_handle *h) {
         // work-group tile 64 walkers x 160 (p,q) pairs; hs_pot^T panels shared through the LDS ring
         // measured at C3 (tools/sweep_vhs_cfg.sh): packed symmetric columns 75.8 us with the 32 x 160 tile
         // (cfg 7), 116 us with the 64 x 160 tile that is best for the full M^2 columns (100 us)
-        static const int cfg_env = afq_knob("AFQ_VHS_CFG") ? atoi(afq_knob("AFQ_VHS_CFG")) : -1;
+#ifdef AFQ_TUNING
+        static const int cfg_env = AFQ_KNOB_INT("AFQ_VHS_CFG", -1);
         const int cfg = cfg_env >= 0 ? cfg_env : (h->hs_sym ? 7 : 0);
         if (cfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 4, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
@@ -614,13 +620,12 @@ int k_vhs_generic(afq_handle *h) {
         else if (cfg == 5) AFQ_GEMM(h, (launch_mfma_gemm_wg<1, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 1, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         else if (cfg == 7) {
-            static const int kc = afq_knob("AFQ_GEMM_KC") ? atoi(afq_knob("AFQ_GEMM_KC")) : 1;
+            static const int kc = AFQ_KNOB_INT("AFQ_GEMM_KC", 1);
             KernelTrace kt(h, AFQ_K_VHS);
-            static const int xmap = afq_knob("AFQ_VHS_XCD") ? atoi(afq_knob("AFQ_VHS_XCD")) : 0;   // measured: 77.8 vs 75.8 us
-#ifdef AFQ_TUNING
-            if (afq_knob("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_LOADER")) {
-                const int v = atoi(afq_knob("AFQ_VHS_LOADER"));
+            static const int xmap = AFQ_KNOB_INT("AFQ_VHS_XCD", 0);   // measured: 77.8 vs 75.8 us
+            if (AFQ_KNOB_SET("AFQ_GEMM_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_LOADER")) {
+                const int v = AFQ_KNOB_INT("AFQ_VHS_LOADER", 0);
                 if (v == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (v == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
                 else if (v == 4) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
@@ -636,16 +641,15 @@ int k_vhs_generic(afq_handle *h) {
                 else if (v == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 5, 4>(p, h->stream, h->zero_page)));
                 else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 3>(p, h->stream, h->zero_page)));
             }
-            else if (afq_knob("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_RREG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_RREG8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_D8X")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_D8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_D8P")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 2>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_RREG")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_RREG8")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_ROWS_FAST, false, 1, 4>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_D8X")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 8, VhsProb, MAP_COLPANEL_XCD, false, 1, 2>(p, h->stream, h->zero_page)));
             else
-#endif
             if (kc == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST, false, 2>(p, h->stream, h->zero_page)));
             else if (xmap) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD>(p, h->stream, h->zero_page)));
-            else if (afq_knob("AFQ_VHS_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+            else if (AFQ_KNOB_SET("AFQ_VHS_NOLOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
             // Round 4: four LOADER waves beside the four compute waves (STAG = 3) and the column panels pinned to XCDs.
             // Timing ablations of the plain loop (tools/vhs_ablate.sh, cycles per chunk of 8 contraction indices at C3):
             // 1938 as it was = 1385 for the 20 MFMAs alone + 790 for refill, fragment reads and barrier alone, of which
@@ -665,6 +669,20 @@ int k_vhs_generic(afq_handle *h) {
             h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 2, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
             AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
         }
+#else
+        // (the variants measured against these two are in tuning builds only: NEGATIVES.md, profiles/r04_vhs_variants.txt)
+        if (h->hs_sym) {
+            // packed symmetric columns: 32 walkers x 160 (p,q) pairs, four compute + four loader waves (STAG = 3), column
+            // panels pinned to XCDs
+            KernelTrace kt(h, AFQ_K_VHS);
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 1, 5, 4, VhsProb, MAP_COLPANEL_XCD, false, 1, 3>(p, h->stream, h->zero_page)));
+            h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 1, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
+        } else {
+            KernelTrace kt(h, AFQ_K_VHS);
+            h->issued_flops[AFQ_K_VHS] = mfma_gemm_wg_issued_flops<2, 2, 2, 5, VhsProb>(p, [&](int, int, int) -> long { return p.kdim; });
+            AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 5, 4, VhsProb, MAP_ROWS_FAST>(p, h->stream, h->zero_page)));
+        }
+#endif
         return AFQ_OK;
     }
     static const TileChoice cand[] = {{2, 4}, {2, 2}, {1, 4}, {1, 2}};       // (2 x 5 does not fit two fragment sets)
@@ -733,8 +751,9 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             if (!h->no_ring && M > 128 && p.cols > 32 && h->nw >= 64) {
                 // large systems: 128 x 64 work-group tiles, 3M complex products
 #ifdef AFQ_TUNING
-                const int tcfg = afq_knob("AFQ_TAYLOR_CFG") ? atoi(afq_knob("AFQ_TAYLOR_CFG")) : 0;
-                if (afq_knob("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                const int tcfg = AFQ_KNOB_INT("AFQ_TAYLOR_CFG", 0);
+                bool done = true;
+                if (AFQ_KNOB_SET("AFQ_BIG_PIPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                 else if (tcfg == 1) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 else if (tcfg == 2) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                 else if (tcfg == 3) AFQ_GEMM(h, (launch_mfma_gemm_wg<8, 1, 1, 7, 2, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
@@ -743,36 +762,39 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                 else if (tcfg == 6) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                 else if (tcfg == 7) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 1, 8, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                 else if (tcfg == 8) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
-                else
-#endif
-                {
+                else {
                     // 128 x 64 or 64 x 128 tiles, whichever pads the M x ncols output less; the 64 x 128 shape with the
                     // half-chunk pipelined loop (C5, 400 x 100: 813 -> 683 us per product)
                     const long padA = (long)((M + 127) / 128) * 128 * ((p.cols + 63) / 64) * 64;
                     const long padB = (long)((M + 63) / 64) * 64 * ((p.cols + 127) / 128) * 128;
-                    if (afq_knob("AFQ_TAYLOR_NOLOADER")) {
+                    if (AFQ_KNOB_SET("AFQ_TAYLOR_NOLOADER")) {
                         if (padB <= padA) AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 1, 4, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
                         else AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
                     }
                     // round 4: 64 x 64 tiles, four compute + four loader waves (STAG = 3; see k_vhs_generic): C5 sizes 689 -> 627 us
-                    else if (afq_knob("AFQ_TAYLOR_LEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_LEAN1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 1>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_WPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_WPE2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_S2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_S2C")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_XCD")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
-                    else if (afq_knob("AFQ_TAYLOR_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_LEAN")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_LEAN1")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 1>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_WPE")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3, 4>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_WPE2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2, 4>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_S2")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_S2C")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_XCD")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_BATCH_XCD, true, 1, 3>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_LOADER")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
                     // round 5: the same 64 x 64 tiles from four waves that refill the ring themselves inside the half-chunk
                     // pipelined loop (STAG = 2): 627-633 -> 612-616 us (C5 sizes).  Forcing two work-groups per CU
                     // (128 VGPRs, WPE = 4) spills 65-98 registers into the chunk loop: 2102 us
-                    else if (afq_knob("AFQ_TAYLOR_S2DEF")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else if (AFQ_KNOB_SET("AFQ_TAYLOR_S2DEF")) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 2>(p, h->stream, h->zero_page)));
+                    else done = false;
+                }
+                if (done) continue;
+#endif
+                {
                     // ... and TWO work-groups per CU: the 3-multiplication kernels of this engine hold 142-160 VGPRs, i.e. one
                     // work-group of 4 + 4 waves per CU.  Forcing 128 registers on the pipelined loops spills (2102 us);
                     // the lean loop of STAG = 5 -- loader waves, compute waves that read the fragments of ONE sub-step at a
                     // time into one set of registers -- needs 122, and what its own waves no longer overlap the second
                     // work-group does: 613 -> 589 us
-                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+                    AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
                 }
                 continue;
             }

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(1024) void energy_ueg_q_kernel(const cplx *G, cplx 
 
 int k_energy_ueg(afq_handle *h) {
     const size_t lds = sizeof(cplx) * 2 * (size_t)h->ueg_nrows * h->M;
-    if (lds <= 120 * 1024 && h->ueg_kp && !afq_knob("AFQ_UEG_WAVE_Q")) {
+    if (lds <= 120 * 1024 && h->ueg_kp && !AFQ_KNOB_SET("AFQ_UEG_WAVE_Q")) {
         static size_t lds_set[AFQ_MAX_DEVICES] = {0};
         AFQ_HIP(h, afq_raise_lds((const void *)energy_ueg_q_kernel, lds, lds_set));
         AFQ_LAUNCH(h, energy_ueg_q_kernel, dim3(h->nw), dim3(1024), lds, h->stream, h->G, h->energy, h->M, h->nq,

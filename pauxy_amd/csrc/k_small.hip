@@ -790,7 +790,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
     a.phi = h->phi; a.psi = h->psi; a.psi_stride = h->psi_stride; a.ghalf = ghalf; a.det = det; a.ws = h->lu_ws;
     a.det_a = h->det_a_out;
     a.psi_real = h->psi_real && h->psi_stride == 0 && h->ndet <= 1;
-    a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !afq_knob("AFQ_NO_CLOSED_GREENS");
+    a.psi_closed = h->psi_closed && h->psi_stride == 0 && h->ndet <= 1 && !AFQ_KNOB_SET("AFQ_NO_CLOSED_GREENS");
     a.closed_bad = nullptr; a.closed_epoch = 0; a.counters = h->counters;
     if (ghalf == h->ghalf) h->closed_checked_version = 0;       // (set again below when THIS launch checks every walker)
     a.skip_spin = 0;
@@ -818,11 +818,11 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
             h->fuse_weight_done = true;
         }
         h->fuse_weight_req = false;
-        static const int dbg = afq_knob("AFQ_GREENS_DBG") ? atoi(afq_knob("AFQ_GREENS_DBG")) : 0;
+        static const int dbg = AFQ_KNOB_INT("AFQ_GREENS_DBG", 0);
         a.dbg = dbg;
 #ifdef AFQ_TUNING
         static bool nopiv_set = false;
-        if (!nopiv_set && afq_knob("AFQ_GJ_NOPIV")) {
+        if (!nopiv_set && AFQ_KNOB_SET("AFQ_GJ_NOPIV")) {
             const int one = 1;
             hipMemcpyToSymbol(HIP_SYMBOL(afq_gj_nopiv), &one, sizeof(int));
             nopiv_set = true;
@@ -831,7 +831,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
 #ifdef AFQ_TUNING
         static unsigned long long *gsts = nullptr;
         static int gs_launch = 0;
-        if (afq_knob("AFQ_GS_TS")) {
+        if (AFQ_KNOB_SET("AFQ_GS_TS")) {
             if (!gsts) { hipMalloc(&gsts, 96 * 8); hipMemset(gsts, 0, 96 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_gs_ts), &gsts, sizeof(gsts)); }
             if (++gs_launch == 30) {
                 unsigned long long t[96];
@@ -859,7 +859,7 @@ static int launch_greens(afq_handle *h, cplx *ghalf, cplx *det, int only_alive, 
         // at most 8 electrons per spin, walker + trial in LDS: the vector-ALU kernel above
         const size_t lds_tiny = sizeof(cplx) * 2 * (size_t)h->M * h->nt;
         static size_t lds_set_tiny[2][AFQ_MAX_DEVICES] = {{0}};
-        const bool tiny = nmax <= 8 && h->nt >= 1 && lds_tiny <= 150 * 1024 && !dbg && !afq_knob("AFQ_NO_GREENS_TINY");
+        const bool tiny = nmax <= 8 && h->nt >= 1 && lds_tiny <= 150 * 1024 && !dbg && !AFQ_KNOB_SET("AFQ_NO_GREENS_TINY");
         if (ghalf || oinv) {
             // the spin sum the force bias contracts (every walker written: not on the only_alive path)
             const bool want_sum = ghalf && ghalf == h->ghalf && !only_alive && k_fb_use_sum(h) && h->psi_stride == 0;
@@ -1714,7 +1714,7 @@ static bool reortho_fused_supported(afq_handle *h, size_t *lds_out) {
     const int nmax = h->na > h->nb ? h->na : h->nb;
     const size_t lds = sizeof(cplx) * ((size_t)h->M * h->nt + 2 * 32 * RF_LD);
     *lds_out = lds;
-    static const bool off = afq_knob("AFQ_NO_REORTHO_FUSED") != nullptr;
+    static const bool off = AFQ_KNOB_SET("AFQ_NO_REORTHO_FUSED");
     return !off && nmax <= 32 && h->nb > 0 && h->M >= 16 && lds <= 150 * 1024;
 }
 
@@ -1733,7 +1733,7 @@ static int k_reortho_fused(afq_handle *h, size_t lds, cplx *keep) {
 #ifdef AFQ_TUNING
     static unsigned long long *rfts = nullptr;
     static int rf_launch = 0;
-    if (afq_knob("AFQ_RF_TS")) {
+    if (AFQ_KNOB_SET("AFQ_RF_TS")) {
         if (!rfts) { hipMalloc(&rfts, 13 * 8); hipMemset(rfts, 0, 13 * 8); hipMemcpyToSymbol(HIP_SYMBOL(afq_rf_ts), &rfts, sizeof(rfts)); }
         if (++rf_launch == 20) {
             unsigned long long t[13];
@@ -1765,7 +1765,7 @@ int k_reortho(afq_handle *h, cplx *keep, bool *keep_done) {
     a.only = nullptr; a.keep = nullptr;
     if (keep_done) *keep_done = false;
     const int nmax = h->na > h->nb ? h->na : h->nb;
-    static const bool no_cholqr = afq_knob("AFQ_NO_CHOLQR") != nullptr;
+    static const bool no_cholqr = AFQ_KNOB_SET("AFQ_NO_CHOLQR");
     // Cholesky-QR2 on the GEMM engines: always for 45 < N <= 128; for smaller N once the population is
     // large enough that seven launches beat the one latency-bound Gram-Schmidt work-group per walker
     const bool small_ok = nmax <= 45 && h->nb > 0 && !h->no_ring && h->nw >= 64 && h->M >= 32;

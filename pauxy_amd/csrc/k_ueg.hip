@@ -672,17 +672,17 @@ static int ueg_field_args(afq_handle *h, UegFieldArgs &a, FieldRng &rng, size_t 
     const size_t fb_bytes = (size_t)f->nfb * 16 + (((size_t)f->nfb + 3) & ~(size_t)3) * 4;
     const size_t ncq = (size_t)f->ncoef * f->nterms, cq_bytes = ncq * 16 + ((ncq + 3) & ~(size_t)3) * 4;
     a.nfb = f->nfb;
-    a.abl = afq_knob("AFQ_UEG_ABL") ? atoi(afq_knob("AFQ_UEG_ABL")) : 0;
+    a.abl = AFQ_KNOB_INT("AFQ_UEG_ABL", 0);
     // (the work-group is alone on its CU: everything but 2 KB of the 160 KB for the kernel's static arrays may be used)
     const size_t cap = 158 * 1024;
-    a.fb_lds = lds + fb_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
+    a.fb_lds = lds + fb_bytes <= cap && !AFQ_KNOB_SET("AFQ_UEG_NO_TABLE_LDS");
     if (a.fb_lds) lds += fb_bytes;
     live_end = lds;                     // what lies beyond is still read while the coefficients are written
-    a.coef_lds = lds + cq_bytes <= cap && !afq_knob("AFQ_UEG_NO_TABLE_LDS");
+    a.coef_lds = lds + cq_bytes <= cap && !AFQ_KNOB_SET("AFQ_UEG_NO_TABLE_LDS");
     if (a.coef_lds) lds += cq_bytes;
 #ifdef AFQ_TUNING
     static bool said = false;
-    if (!said && afq_knob("AFQ_UEG_SAY")) {
+    if (!said && AFQ_KNOB_SET("AFQ_UEG_SAY")) {
         said = true;
         fprintf(stderr, "ueg_fields: nrows %d nfb %d ncoef %d nterms %d lds %zu fb_lds %d coef_lds %d\n", f->nrows, f->nfb, f->ncoef, f->nterms, lds, a.fb_lds, a.coef_lds);
     }
@@ -748,7 +748,7 @@ int k_ueg_step(afq_handle *h) {
     FieldRng rng;
     PropUegArgs pa;
     size_t lds_f, live_end, lds_p;
-    if (afq_knob("AFQ_UEG_NO_STEP_FUSION")) { const int rc = k_ueg_fields(h); return rc ? rc : k_prop_ueg(h); }
+    if (AFQ_KNOB_SET("AFQ_UEG_NO_STEP_FUSION")) { const int rc = k_ueg_fields(h); return rc ? rc : k_prop_ueg(h); }
     const bool was_inline = h->rng_inline;
     int rc = ueg_field_args(h, fa, rng, lds_f, live_end);
     if (rc) return rc;

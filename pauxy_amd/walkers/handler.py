@@ -189,6 +189,7 @@ class Walkers(object):
     comm = hidden()
     system = hidden()
     trial = hidden()
+    _device_comm_fault = hidden()       # (test hook of the communicator bring-up, see _init_device_comm)
 
     def __init__(self, system, trial, qmc, walker_opts={}, verbose=False, comm=None, nprop_tot=None,
                  nbp=None, device_id=None):

@@ -21,7 +21,7 @@ while True:
             with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
                 f.write(data[i + eo: i + eo + es]); name = f.name
             out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '-s', '-W', name], capture_output=True, text=True).stdout
-            k = len([l for l in out.splitlines() if l.rstrip().endswith('.kd')])
+            k = len(set(l.split()[-1] for l in out.splitlines() if l.rstrip().endswith('.kd')))   # (.dynsym and .symtab list each)
             n += k; total += es
             os.unlink(name)
     pos = i + 24
