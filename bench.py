@@ -301,7 +301,7 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
     extra = 2 * NSTEPS_BLOCK
     flagged0 = int(dev.counters()[2])
     dev.launch_trace(True)
-    afqmc.run_batched(extra, first_step=first, eshift=eshift)
+    eshift = afqmc.run_batched(extra, first_step=first, eshift=eshift)
     dev.sync()
     dev.launch_trace(False)
     trace = dev.launch_trace_get()
@@ -1007,7 +1007,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     extra_steps = 4 * NSTEPS_BLOCK
     dev.counters(reset=True)
     dev.kernel_trace(True)
-    afqmc.run_batched(extra_steps, first_step=first, eshift=eshift)
+    eshift = afqmc.run_batched(extra_steps, first_step=first, eshift=eshift)
     dev.sync()
     dev.kernel_trace(False)
     # walker steps the fused propagator took through its closed-shell deal (spin blocks bitwise equal, checked per walker in

@@ -13,7 +13,26 @@ import pytest
 from oracle import afqmc_ref as ref
 
 pytestmark = pytest.mark.gpu
-MODEL = None          # set before the pool forks: the workers inherit it
+MODEL = None          # the oracle's model: built by every worker for itself (_init_worker), and by the parent
+
+
+def _build_model():
+    import bench
+    from pauxy_amd import systems, trial as trial_mod
+    from pauxy_amd.propagation.setup import generic_propagator_arrays
+    system = systems.synthetic_generic(bench.M, bench.K, (bench.N, bench.N), seed=7)
+    trial = trial_mod.rhf_trial_generic(system)
+    BH1, mf_shift = generic_propagator_arrays(system, trial, bench.DT)
+    # (the HS potential as complex numbers: the oracle's V = chol . x then needs no conversion per call)
+    return ref.RefModel('generic', bench.M, bench.N, bench.N, trial.psi, BH1, mf_shift, bench.DT,
+                        hs_pot=system.hs_pot.astype(numpy.complex128), rchol=trial._rchol,
+                        H1=system.H1.astype(complex), ecore=system.ecore), system, trial
+
+
+def _init_worker():
+    """Spawned (not forked: the parent holds a GPU context) single-threaded numpy process with its own copy of the model."""
+    global MODEL
+    MODEL = _build_model()[0]
 
 
 def _propagate_segment(args):
@@ -50,20 +69,18 @@ def _estimate_chunk(args):
     return est
 
 
+@pytest.mark.timeout(1500)
 def test_bench_population_against_the_oracle_block_by_block(monkeypatch):
     global MODEL
     import bench
-    from pauxy_amd import systems, trial as trial_mod
     from pauxy_amd.context import release_context
-    from pauxy_amd.propagation.setup import generic_propagator_arrays
     from pauxy_amd.qmc.afqmc import AFQMC
     from tests.philox_ref import device_normals_fast
     nsteps_total = int(os.environ.get("AFQ_BENCH_ORACLE_STEPS", "60"))
     M, K, N, nw = bench.M, bench.K, bench.N, bench.NW_PER_GPU
     nsteps, nstblz, npop = bench.NSTEPS_BLOCK, bench.NSTBLZ, bench.NPOP
     assert nsteps_total % nsteps == 0
-    system = systems.synthetic_generic(M, K, (N, N), seed=7)
-    trial = trial_mod.rhf_trial_generic(system)
+    MODEL, system, trial = _build_model()
     options = {'qmc': {'timestep': bench.DT, 'num_steps': nsteps, 'blocks': 10 ** 6, 'stabilise_freq': nstblz,
                        'pop_control_freq': npop, 'num_walkers': nw, 'rng_seed': 7},
                'propagator': {'device_rng': True, 'rng_seed': 7, 'rng_stream': 0},
@@ -83,14 +100,13 @@ def test_bench_population_against_the_oracle_block_by_block(monkeypatch):
     afqmc.finalise()
     release_context(system, trial)
     # ---- the oracle
-    BH1, mf_shift = generic_propagator_arrays(system, trial, bench.DT)
-    MODEL = ref.RefModel('generic', M, N, N, trial.psi, BH1, mf_shift, bench.DT, hs_pot=system.hs_pot, rchol=trial._rchol,
-                         H1=system.H1.astype(complex), ecore=system.ecore)
     walkers = [ref.new_walker(MODEL, numpy.asarray(trial.psi, dtype=complex).copy()) for _ in range(nw)]
     for w in walkers:
         w['total_weight'] = nw
     nproc = max(1, min(64, (os.cpu_count() or 2) - 1, nw))
-    ctx = multiprocessing.get_context("fork")
+    ctx = multiprocessing.get_context("spawn")
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # inherited by the spawned workers
+        monkeypatch.setenv(var, "1")
     neqlb = int(2.0 / bench.DT)
     est = numpy.zeros(10, dtype=numpy.complex128)
     eshift_pair = numpy.array([0, 0], dtype=numpy.complex128)
@@ -98,7 +114,7 @@ def test_bench_population_against_the_oracle_block_by_block(monkeypatch):
     blocks = []
     rs = iter(drawn)
     chunks = numpy.array_split(numpy.arange(nw), nproc)
-    with ctx.Pool(nproc) as pool:
+    with ctx.Pool(nproc, initializer=_init_worker) as pool:
         # step-0 pass (qmc/afqmc.py:214-221; folded into the first block: the driver is not verbose)
         for e_ in pool.map(_estimate_chunk, [([walkers[i] for i in c], 0, nsteps) for c in chunks]):
             est += e_
