@@ -441,7 +441,7 @@ def committed_traffic(config_name):
     """HBM-side bytes per launch of this configuration's kernels from the newest committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, tools/profile_round.sh + tools/publish_profiles.py: separate FETCH_SIZE / WRITE_SIZE
     passes of this same command, FETCH_SIZE doubled on gfx950) -- ({kernel: bytes}, source) or ({}, None)."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")
         if not os.path.exists(path):
             continue
