@@ -236,51 +236,20 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     };
     issueA(); issueA();                                          // PF_D - 1 chunks in flight
     prepare();
-    // ---- phi[w] -> T (B-fragment order), padding zeroed: one sweep over the ENTRIES of T (16 bytes each; entry index =
-    // ((chunk * 4 + slot) * 2 + (p & 1)) * 64 + ((p & 7) >> 1) * 16 + column in the slot, i.e. shifts and masks only), each
-    // either a walker element or a zero -- instead of a zero fill, a barrier and a sweep over the walker with a division
-    // by the column count per element.
-    // T column -> walker column of the contiguous-column layout with twins in like slots (a.symcols: see PropFusedArgs; slots 0
-    // and 1 are multiplied by the same code (taylor), slot 2 by taylor_h's full tile, slot 3 as 4x4x4 units -- three summation
-    // orders: a column and its twin must sit in the same KIND of slot: [a 0..15 | b 0..15 | a 16..23, b 16..23 | a 24.., b 24..])
-    auto fill_T = [&](const int contig_, const int sym_n_) __attribute__((always_inline)) {
-        auto wcol_ = [&](const int c) -> int {
-            if (!sym_n_) return c;
-            if (c < 16) return c;
-            if (c < 32) return sym_n_ + (c - 16);
-            if (c < 40) return 16 + (c - 32);
-            if (c < 48) return sym_n_ + 16 + (c - 40);
-            const int e = c - 48, extra = sym_n_ - 24;
-            return e < extra ? 24 + e : sym_n_ + 24 + (e - extra);
-        };
-        PF_UNLESS((32 | 128))
-        for (int e = tid; e < NCH * 512; e += PF_NT) {
-            const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
-            const int p = ch * 8 + 2 * kk + pb, sp = contig_ ? 0 : slot >> 1, col = (contig_ ? slot : slot & 1) * 16 + j;
-            const int ns_ = contig_ ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
-            const bool ok = p < M && col < ns_;
-            const cplx v = phi[ok ? p * nt + off_ + wcol_(col) : 0];
-            ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
-        }
-    };
     // ---- Closed-shell walker?  (spin blocks bitwise equal: checked on the walker itself, every launch, no state.)  Every
     // matrix of the chain acts on both spins alike (closed_try: one one-body matrix, as many electrons of either spin), so the
     // beta half would stay the bitwise copy of the alpha half through all the products: the Taylor stage multiplies the
     // alpha half only (closed-shell deals below) and copies it into the beta half ahead of the closing one-body pass.
-    // Round 6: the walker is read ONCE.  Where a closed-shell deal exists it is laid out as [a0 a1 b0 b1] straight away -- the
-    // layout a closed-shell walker takes -- and the spin blocks are compared on that copy in LDS (entry e of an alpha slot
-    // against entry e + 256); only an open-shell walker of the contiguous-column shape is then read a second time, into its own
-    // layout (two passes over the walker as before: the compare, then the fill).
     bool closed = false;
     if (a.closed_try) {
-        fill_T(0, 0);
-        __syncthreads();
         bool same = true;
-        for (int e = tid; e < NCH * 256; e += PF_NT) {
-            const int ea = (e >> 8) * 512 + (e & 255);
-            const d2_t x = ((const d2_t *)Tf)[ea], y = ((const d2_t *)Tf)[ea + 256];
-            same = same && __double_as_longlong(x[0]) == __double_as_longlong(y[0]) &&
-                   __double_as_longlong(x[1]) == __double_as_longlong(y[1]);
+        for (int p = tid >> 5; p < M; p += PF_NT / 32) {
+            const int c = tid & 31;
+            if (c < a.na) {
+                const cplx x = phi[p * nt + c], y = phi[p * nt + a.na + c];
+                same = same && __double_as_longlong(x.x) == __double_as_longlong(y.x) &&
+                       __double_as_longlong(x.y) == __double_as_longlong(y.y);
+            }
         }
         closed = __builtin_amdgcn_readfirstlane(__syncthreads_and(same ? 1 : 0)) != 0;
         if (closed && tid == 0) atomicAdd(a.n_closed, 1ULL);
@@ -290,8 +259,11 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
     // 126.7 us; keeping the contiguous layout and leaving out its one wholly redundant slot [b 0..15] 145.3; neither 162.3.)
     const bool relayout = closed && a.contig;
     const int contig = relayout ? 0 : a.contig, hyb = relayout ? 0 : a.hyb;
-    // T column -> walker column (identity unless a.symcols)
+    // T column -> walker column (identity unless a.symcols: see PropFusedArgs)
     const int sym_n = (a.symcols && !relayout) ? a.na : 0;
+    // (slots 0 and 1 are multiplied by the same code (taylor), slot 2 by taylor_h's full tile, slot 3 as 4x4x4 units -- three
+    //  summation orders: a column and its twin must sit in the same KIND of slot: [a 0..15 | b 0..15 | a 16..23, b 16..23 |
+    //  a 24.., b 24..])
     auto wcol = [&](const int c) -> int {
         if (!sym_n) return c;
         if (c < 16) return c;
@@ -301,10 +273,21 @@ __global__ __launch_bounds__(PF_NT) void prop_fused_kernel(PropFusedArgs a) {
         const int e = c - 48, extra = sym_n - 24;
         return e < extra ? 24 + e : sym_n + 24 + (e - extra);
     };
-    if (!a.closed_try || (!closed && contig)) {
-        fill_T(contig, sym_n);
-        __syncthreads();
+
+    // ---- phi[w] -> T (B-fragment order), padding zeroed: one sweep over the ENTRIES of T (16 bytes each; entry index =
+    // ((chunk * 4 + slot) * 2 + (p & 1)) * 64 + ((p & 7) >> 1) * 16 + column in the slot, i.e. shifts and masks only), each
+    // either a walker element or a zero -- instead of a zero fill, a barrier and a sweep over the walker with a division
+    // by the column count per element
+    PF_UNLESS((32 | 128))
+    for (int e = tid; e < NCH * 512; e += PF_NT) {
+        const int j = e & 15, kk = (e >> 4) & 3, pb = (e >> 6) & 1, slot = (e >> 7) & 3, ch = e >> 9;
+        const int p = ch * 8 + 2 * kk + pb, sp = contig ? 0 : slot >> 1, col = (contig ? slot : slot & 1) * 16 + j;
+        const int ns_ = contig ? nt : sp ? a.nb : a.na, off_ = sp ? a.na : 0;
+        const bool ok = p < M && col < ns_;
+        const cplx v = phi[ok ? p * nt + off_ + wcol(col) : 0];
+        ((d2_t *)Tf)[e] = ok ? (d2_t){v.x, v.y} : (d2_t){0.0, 0.0};
     }
+    __syncthreads();
 
     // accumulator-layout address of element (row tile ti, reg r) of column slot cs for this lane
     auto t_ok = [&](int ti, int r) -> bool { return 2 * ti + (r >> 1) < NCH; };   // rows past the last chunk do not exist
