@@ -1451,10 +1451,13 @@ int afq_estimates_get(afq_handle *h, double *est_out, int zero) {
 // memset sequence this replaces cost ~25 us of idle device per block (rocprofv3 kernel trace: 6 us ahead of the fill
 // kernel, 17 us behind it) although more work was already queued.
 __global__ void est_publish_kernel(cplx *est, const double *scal, double *host_out, unsigned long long *host_seq,
-                                   unsigned long long seq, int nest, int zero) {
+                                   unsigned long long seq, int nest, int zero, const unsigned long long *closed_bad) {
     const int t = threadIdx.x;
     if (t < nest) host_out[t] = ((const double *)est)[t];
     if (t < AFQ_NSCAL) host_out[nest + t] = scal[t];
+    // the closed-shell word rides along (afq_internal.h: closed_bad): a HINT for the host's choice between the one-spin-first
+    // and the one-launch two-spin form of the exchange energy -- never a decision about results
+    if (t == 0) host_seq[1] = closed_bad ? *closed_bad : 0ull;
     __threadfence_system();
     __syncthreads();
     if (t < nest && zero) ((double *)est)[t] = 0.0;
@@ -1470,17 +1473,18 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
         // [nest sums | scal[AFQ_NSCAL] | sequence number], written by the device, polled by the host
-        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + AFQ_NSCAL + 1),
+        AFQ_HIP(h, hipHostMalloc((void **)&h->est_stage, sizeof(double) * (nest + AFQ_NSCAL + 2),
                                  hipHostMallocMapped | hipHostMallocCoherent));
-        memset(h->est_stage, 0, sizeof(double) * (nest + AFQ_NSCAL + 1));
+        memset(h->est_stage, 0, sizeof(double) * (nest + AFQ_NSCAL + 2));
     }
     // the one host synchronisation of a block of steps also reports a population that collapsed in an
     // asynchronous comb (scal[2], set by comb_plan_kernel; walkers/handler.py:236-241 exits there)
     double *dev_view = nullptr;
     AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
     ++h->est_seq;
+    h->closed_epoch_pub = h->closed_epoch;                   // the newest launch whose verdict the published word can hold
     AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
-               (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero);
+               (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero, h->closed_bad);
     AFQ_POST(h);
     h->est_pending = true;
     return AFQ_OK;
@@ -1508,6 +1512,10 @@ int afq_estimates_get_end(afq_handle *h, double *est_out) {
             AFQ_FAIL(h, AFQ_EHIP, "estimator sums were not published by the device");
     }
     memcpy(est_out, h->est_stage, sizeof(double) * nest);
+    {   // at the time of the publish, had the newest checking Green's function launch found an open-shell walker?
+        const unsigned long long bad = ((const unsigned long long *)(h->est_stage + nest + AFQ_NSCAL))[1];
+        h->exx_open_hint = h->closed_epoch_pub != 0 && bad >= h->closed_epoch_pub;
+    }
     const double *sc = h->est_stage + nest;
     // the population-control scalars of the block ride along: afq_comm_stats right behind this call needs no synchronisation
     memcpy(h->scal_cache, sc, sizeof(double) * AFQ_NSCAL);

@@ -105,6 +105,11 @@ struct afq_handle {
     // walker, and the exchange energy evaluates one spin (k_energy.hip).  The host never reads the flag.
     unsigned long long *closed_bad = nullptr;
     unsigned long long closed_epoch = 0, closed_checked_version = 0;
+    // host-side HINT read with every block's sums (est_publish_kernel): the population held an open-shell walker at the last
+    // block end.  launch_exx_quadratic then skips the one-spin-first form (two launches when the population is open: 181
+    // against 135 us at C3) for the one-launch two-spin form; results are the same either way, a stale hint costs time only
+    unsigned long long closed_epoch_pub = 0;
+    bool exx_open_hint = false;
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one

@@ -551,7 +551,7 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     // spin alpha (every XCD busy), the second launch holds spin beta's and returns at once on the device when the flag says
     // closed; energy_finish_kernel then counts the alpha sums twice.  Nothing is decided on the host.
     const bool closed_try = h->closed_bad && h->closed_checked_version == h->ghalf_version && h->closed_checked_version != 0 &&
-                            h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !AFQ_KNOB_SET("AFQ_NO_CLOSED_EXX");
+                            h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !h->exx_open_hint && !AFQ_KNOB_SET("AFQ_NO_CLOSED_EXX");
     // (slices of the one-spin launch: 2 S, as many work-groups as the two-spin launch has.  C3, us per evaluation: S = 4
     //  slices 106.6, 5 100.9, 6 96.9, 7 91.4, 8 = 2 S 96.9, 10 139.8, 16 107.3; the two-spin launch 138.9)
     int SL = closed_try ? 2 * S : S;
