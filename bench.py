@@ -89,7 +89,7 @@ def build_config(name):
     return s, trial_mod.MultiDetTrial(s, (numpy.array([0.8, 0.3, 0.2, 0.1], dtype=complex), dets), init=t0.psi)
 
 
-def work_table(c, b_real=False, psi_real=False, rchol_same=False):
+def work_table(c, b_real=False, psi_real=False, rchol_same=False, closed_large=0.0):
     """The ONE work model of both bench modes (the headline line and --config): for every launch afq_launch_trace can
     name (kernel names for plain launches, the launching function for the GEMM engines) the algorithmic work of ONE
     launch, SURVEY 8d conventions -- 8 flops per complex MAC, 4 per real-by-complex MAC, no padding.
@@ -97,6 +97,9 @@ def work_table(c, b_real=False, psi_real=False, rchol_same=False):
       real_operands  the same with 4 flops per MAC wherever one operand is real in THIS run (real BH1, real trial)
       cmac           flops one complex-by-complex MAC is priced at in both: 8, or 6 for a launch that executes
                      3-multiplication products AND would otherwise be priced above the peak (stated in its note)
+    ``closed_large``: share of the walker steps that went through the large-system GEMM chain as closed-shell walkers (the
+    device's count, afq_counters_ext [7]): their one-body and Taylor products multiply the alpha columns only, and that is the
+    work priced (the survey count stays what the reference does for the same walkers).
     Launches that are bookkeeping have no entry."""
     M, na, nb, K, nw = c["M"], c["na"], c["nb"], c["K"], c["nw"]
     nt, ndet = na + nb, c.get("ndet", 1)
@@ -108,6 +111,8 @@ def work_table(c, b_real=False, psi_real=False, rchol_same=False):
     P = M * (M + 1) // 2
     fb_len = na if (ndet == 1 and na == nb and rchol_same) else nt
     exq_pairs = na * M * (na * M + 1) / 2.0 + nb * M * (nb * M + 1) / 2.0
+    cl_note = ("; closed-shell walkers (%.0f %% of the walker steps): the alpha columns only, copied over the beta block behind "
+               "the chain -- the executed columns are priced" % (100.0 * closed_large)) if closed_large > 0.0 else ""
     t = {
         "prop_fused_kernel": ("mfma", 8.0 * M * M * nt * 8 * nw, M * M * nt * (8.0 * 6 + ob * 2) * nw,
                               "B exp(V) B: 2 one-body + 6 Taylor products of M x M by M x (na+nb) per walker"),
@@ -115,9 +120,11 @@ def work_table(c, b_real=False, psi_real=False, rchol_same=False):
         "ueg_step_kernel": ("mfma", 8.0 * M * M * nt * 6 * nw, None,
                             "force bias + fields + coefficients + B exp(V) B in one launch: the 6 products are the priced work, the "
                             "field part (latency bound) is in the time"),
-        "k_apply_exponential": ("mfma", 8.0 * M * M * nt * nw, None, "one Taylor product V T, both spins"),
+        "k_apply_exponential": ("mfma", 8.0 * M * M * (nt - closed_large * nb) * nw, None,
+                                "one Taylor product V T, both spins" + cl_note),
         # (one launch for both spins when they share one real matrix, else one per spin: the caller divides by the count)
-        "onebody_spin": ("mfma", 8.0 * M * M * nt * nw, ob * M * M * nt * nw, "BH1 phi: one application to both spins"),
+        "onebody_spin": ("mfma", 8.0 * M * M * nt * nw, ob * M * M * (nt - closed_large * nb) * nw,
+                         "BH1 phi: one application to both spins" + cl_note),
         "k_vhs_generic": ("mfma", 4.0 * P * K * nw, None, "HS potential, packed symmetric columns"),
         "force_bias_generic_impl": ("mfma", 4.0 * K * fb_len * M * nw, None,
                                     "force bias / Coulomb vectors, one real-B pass over %s" %
@@ -152,9 +159,9 @@ def work_table(c, b_real=False, psi_real=False, rchol_same=False):
     return t
 
 
-def launch_work(name, c, b_real=False, psi_real=False, rchol_same=False):
+def launch_work(name, c, b_real=False, psi_real=False, rchol_same=False, closed_large=0.0):
     """(bound, survey work, real-operand work or None, note) of the launch `name`, or None (bookkeeping)."""
-    table = work_table(c, b_real, psi_real, rchol_same)
+    table = work_table(c, b_real, psi_real, rchol_same, closed_large)
     for key in sorted(table, key=len, reverse=True):      # longest key first: "gj_big_kernel (fallback pass)" before "gj_big_kernel"
         if key in name:
             return table[key]
@@ -300,12 +307,15 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
     state["phase"] = "launch trace"
     extra = 2 * NSTEPS_BLOCK
     flagged0 = int(dev.counters()[2])
+    closed_large0 = int(dev.counters(n=8)[7])
     dev.launch_trace(True)
     eshift = afqmc.run_batched(extra, first_step=first, eshift=eshift)
     dev.sync()
     dev.launch_trace(False)
     trace = dev.launch_trace_get()
     flagged = int(dev.counters()[2]) - flagged0     # matrices the blocked Gauss-Jordan handed to the step-by-step kernel
+    # walker steps that went through the large-system GEMM chain as closed-shell walkers (alpha columns only)
+    closed_large = (int(dev.counters(n=8)[7]) - closed_large0) / float(extra * c["nw"])
     b_real = bool(numpy.abs(numpy.imag(afqmc.propagators.propagator.BH1)).max() == 0.0)
     psi_real = bool(numpy.abs(numpy.imag(numpy.asarray(trial.psi))).max() == 0.0)
     rc_ = numpy.asarray(getattr(trial, '_rchol', numpy.zeros((0, 1))))
@@ -316,7 +326,7 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
     rows = []
     for lname, (count, ms) in sorted(trace.items(), key=lambda kv: -kv[1][1]):
         row = {"launch": lname, "launches": count, "avg_ms": ms / count, "ms_per_step": ms / extra}
-        w = launch_work(lname, c, b_real=b_real, psi_real=psi_real, rchol_same=rchol_same)
+        w = launch_work(lname, c, b_real=b_real, psi_real=psi_real, rchol_same=rchol_same, closed_large=closed_large)
         if w and "fallback pass" in lname:
             # priced by the matrices it actually processed: every other work-group of the launch returns at once
             nmat = 2 * c["nw"] * count

@@ -431,7 +431,8 @@ int afq_counters(afq_handle *h, int64_t *out, int reset);
  * counted twice (closed-shell population, decided on the device: energy_finish_kernel), [5]=walker Green's functions
  * computed for one spin (closed-shell walker, greens_small_kernel), [6]=per-determinant overlaps of a multi-determinant
  * trial that came out as NaN (0 x inf behind a zero pivot of a singular overlap matrix) and were taken as zero overlaps,
- * [7] reserved (0)                                                                                                  */
+ * [7]=walker steps that went through the large-system GEMM chain (M > 128) as closed-shell walkers: alpha columns only in the
+ * one-body and Taylor products, copied over the beta block behind the chain (closed_flags_kernel)                      */
 int afq_counters_ext(afq_handle *h, int64_t *out, int n, int reset);
 /* accumulated device ms per phase: [0] greens [1] one-body [2] force bias+fields
  * [3] vhs [4] exponential [5] overlap+weight [6] reortho [7] energy            */

@@ -111,6 +111,7 @@ void free_walkers(afq_handle *h) {
     dev_free(h->gj_flag); dev_free(h->big_ws); dev_free(h->big_ws2); dev_free(h->detm); dev_free(h->dete); dev_free(h->qr_logd); dev_free(h->qr_fail);
     dev_free(h->energy); dev_free(h->exx_part); dev_free(h->gfrag); dev_free(h->exq_y); h->exq_y_len = 0;
     dev_free(h->alive); dev_free(h->parent_ix); dev_free(h->rdm_acc); h->rdm_on = false;
+    dev_free(h->closed_w); h->closed_w_n = 0;
     if (h->pack_tmp) { hipFree(h->pack_tmp); h->pack_tmp = nullptr; }
     h->exx_part_len = 0; h->gfrag_bytes = 0; h->nw = 0;
 }
@@ -966,6 +967,14 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     // The force bias reads Ghalf of the un-propagated walker, so building the HS potential commutes
     // with the first one-body product; the fused path uses that to run B exp(V) B in one launch.
     const bool fused = k_prop_fused_supported(h);
+    // Large systems (the GEMM chain): one matrix serves both spins and the HS potential never depends on the spin, so a walker
+    // whose spin blocks are bitwise equal -- every walker of a run that starts closed-shell -- keeps them equal through
+    // B exp(V) B.  Checked on the walkers themselves at every step (closed_flags_kernel); the GEMMs then leave out the tiles of
+    // the beta columns of such walkers and the alpha block is copied over the beta block behind the closing one-body product.
+    h->closed_large = !fused && h->kind == AFQ_SYS_GENERIC && h->nv == 1 && h->bh1_same && h->na == h->nb && h->na > 0 &&
+                      h->M > 128 && h->nt > 32 && h->nw >= 64 && !h->no_ring && !AFQ_KNOB_SET("AFQ_NO_CLOSED_LARGE");
+    struct ClosedLargeOff { afq_handle *h; ~ClosedLargeOff() { h->closed_large = false; } } closed_large_off{h};   // on every way out
+    if (h->closed_large && (rc = k_closed_flags(h))) return rc;
     if (!fused) { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }   // :251
     {
         PhaseTimer t(h, T_FB);                                                      // :133-158
@@ -985,6 +994,7 @@ int afq_propagate_begin(afq_handle *h, const double *xi) {
     } else {
         { PhaseTimer t(h, T_EXP); if ((rc = apply_exp(h, h->vhs))) return rc; }    // :162-171
         { PhaseTimer t(h, T_ONEBODY); if ((rc = k_onebody(h))) return rc; }        // :258
+        if (h->closed_large && (rc = k_closed_copy_beta(h))) return rc;
     }
     h->prop_pending = true;
     return AFQ_OK;

@@ -110,6 +110,13 @@ struct afq_handle {
     // against 135 us at C3) for the one-launch two-spin form; results are the same either way, a stale hint costs time only
     unsigned long long closed_epoch_pub = 0;
     bool exx_open_hint = false;
+    // Large-system propagation (the GEMM chain of k_onebody / k_apply_exponential: M > 128), round 6: closed_w[w] = 1 when walker
+    // w's spin blocks are bitwise equal (closed_flags_kernel, every step, on the walkers themselves: no state to keep valid).
+    // While closed_large is set the one-body and Taylor GEMMs leave out the work-group tiles that lie wholly in the beta columns
+    // of such a walker; closed_copy_beta_kernel copies the propagated alpha block over the beta block at the end of the step.
+    int *closed_w = nullptr;
+    int closed_w_n = 0;
+    bool closed_large = false;
 
     // multi-determinant trial: the trial-dependent operands of every determinant;
     // psi / psic / rchol_* / rchol_frag* / rH1 above and ghalf / vbias below are VIEWS of the selected one
@@ -453,6 +460,8 @@ int k_reortho(afq_handle *h, cplx *keep = nullptr, bool *keep_done = nullptr);
 int k_cap_weights(afq_handle *h, double frac, double total_weight);
 int k_comb(afq_handle *h, double r, double target, bool with_greens = false);
 int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights = false);
+int k_closed_flags(afq_handle *h);          // closed_w[w] for every walker
+int k_closed_copy_beta(afq_handle *h);      // phi[w][:, na:] = phi[w][:, :na] where closed_w[w]
 int k_scale_by_inverse(afq_handle *h, cplx *x, const double *d);   // x[w] /= d[w]
 int k_log_shift_reortho(afq_handle *h);                            // detR -> exp(log det R - detR_shift), log_detR += log
 int k_log_ovlp_sums(afq_handle *h, double *out3);                  // sums of |ot|, |detR|, |log_detR| (device -> host)

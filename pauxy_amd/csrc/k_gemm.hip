@@ -55,6 +55,14 @@ struct OneBodyProbT {
     // Taylor propagator of the Hubbard HS potential folded into the one-body product ahead of it)
     const cplx *rowscale;
     long rs_stride;
+    // closed-shell walkers on the large-system path (round 6; afq_internal.h: closed_large): closed_w[b] != 0 says walker b's
+    // spin blocks are bitwise equal; the work-group tiles that lie wholly in its beta columns (col0 >= na_cols) are not
+    // computed -- every column of the product depends on its own input column only, and the propagated alpha block is
+    // copied over the beta block at the end of the step (closed_copy_beta_kernel)
+    const int *closed_w;
+    int na_cols;
+    static constexpr bool BTILE_SKIP = true;
+    __device__ bool skip_tile_b(int b, int, int col0) const { return closed_w && col0 >= na_cols && closed_w[b] != 0; }
     __device__ bool active(int b) const { return alive[b] != 0; }
     // dead walkers are not propagated (qmc/afqmc.py:232) but source and destination are ping-pong buffers: their columns
     // are copied through by the work-groups / waves that would have multiplied them (a separate copy launch before)
@@ -105,6 +113,9 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
     // rowscale: [nw, nv, M] factors; spin s takes its own row of them when there are two (spin decomposition)
     p.rowscale = rowscale ? rowscale + (h->nv == 2 ? (long)s * M : 0L) : nullptr;
     p.rs_stride = (long)h->nv * M;
+    // (only the launch over the columns of both spins can leave the beta tiles of closed-shell walkers out)
+    p.closed_w = (h->closed_large && p.off == 0 && ns == h->nt && !rowscale) ? h->closed_w : nullptr;
+    p.na_cols = h->na;
     if (!h->no_ring && M > 64 && M <= 128 && ns > 16 && ns <= 32 && h->nw >= 64) {
         // one work-group = one walker-spin: BH1 and phi fragments through the LDS ring once
         AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 1, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
@@ -135,12 +146,19 @@ static int onebody_spin(afq_handle *h, int s, const cplx *rowscale) {
         // sizes (400 x 100) 444 -> 384 us against 64 x 128; the small tile also pads least
         // round 5: a complex BH1 (3-multiplication products: 142 VGPRs, one work-group per CU) runs the lean loop at 122 VGPRs
         // so that two work-groups share a CU (see k_apply_exponential); the real one (97 VGPRs) is two per CU as it is
-        if constexpr (!AR) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
-        else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        if constexpr (!AR) {
+            if (p.closed_w) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLTILE_SLOW, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+        } else {
+            // (closed-shell walkers: column tile slowest, see k_apply_exponential)
+            if (p.closed_w) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLTILE_SLOW, true, 1, 3>(p, h->stream, h->zero_page)));
+            else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, OneBodyProbT<AR>, MAP_COLS_FAST, true, 1, 3>(p, h->stream, h->zero_page)));
+        }
     } else {
         OneBodyProb q;          // (small shapes: the register engine, which has no real-operand variant)
         q.batch = p.batch; q.rows = p.rows; q.cols = p.cols; q.kdim = p.kdim; q.nt = p.nt; q.off = p.off;
         q.B1 = p.B1; q.src = p.src; q.dst = p.dst; q.alive = p.alive; q.rowscale = p.rowscale; q.rs_stride = p.rs_stride;
+        q.closed_w = nullptr; q.na_cols = 0;
         const TileChoice tc = pick_tiles(q.batch, q.rows, q.cols, kCplxTiles, 4);
         DISPATCH_TILES(h, q, tc, MAP_COLS_FAST, 4);
     }
@@ -706,6 +724,10 @@ struct TaylorProb {
     cplx *tout, *phi;
     double inv_n;
     const int *alive;
+    const int *closed_w;             // closed-shell walkers: see OneBodyProbT
+    int na_cols;
+    static constexpr bool BTILE_SKIP = true;
+    __device__ bool skip_tile_b(int b, int, int col0) const { return closed_w && col0 >= na_cols && closed_w[b] != 0; }
     __device__ bool active(int b) const { return alive[b] != 0; }
     __device__ cplx loadA(int b, int row, int k) const { return vhs[b * vstride + (long)row * kdim + k]; }
     __device__ cplx loadB(int b, int k, int col) const { return tin[((long)b * kdim + k) * nt + off + col]; }
@@ -743,6 +765,8 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
             p.vstride = (long)h->nv * M * M;
             p.vhs = vhs + (long)s * M * M;
             p.tin = tin; p.tout = tout; p.phi = h->phi; p.inv_n = 1.0 / n; p.alive = h->alive;
+            p.closed_w = (h->closed_large && h->nv == 1) ? h->closed_w : nullptr;
+            p.na_cols = h->na;
             if (!h->no_ring && M > 64 && M <= 128 && p.cols > 32 && p.cols <= 64 && h->nw >= 64) {
                 // one work-group (8 waves, 128 x 64 tile) = one walker: VHS[w] and T[w] pass the LDS ring once
                 AFQ_GEMM(h, (launch_mfma_gemm_wg<4, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true>(p, h->stream, h->zero_page)));
@@ -794,7 +818,10 @@ int k_apply_exponential(afq_handle *h, const cplx *vhs) {
                     // the lean loop of STAG = 5 -- loader waves, compute waves that read the fragments of ONE sub-step at a
                     // time into one set of registers -- needs 122, and what its own waves no longer overlap the second
                     // work-group does: 613 -> 589 us
-                    AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+                    // (closed-shell walkers: with the column tile as the fast index the tiles that are left out are every
+                    //  other work-group, i.e. every other XCD gets nothing but work-groups that return at once -- the column tile as the slowest index of the launch)
+                    if (p.closed_w) AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLTILE_SLOW, true, 1, 5, 4>(p, h->stream, h->zero_page)));
+                    else AFQ_GEMM(h, (launch_mfma_gemm_wg<2, 2, 2, 2, 4, TaylorProb, MAP_COLS_FAST, true, 1, 5, 4>(p, h->stream, h->zero_page)));
                 }
                 continue;
             }

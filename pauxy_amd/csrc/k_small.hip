@@ -2056,6 +2056,55 @@ int k_clone_pairs(afq_handle *h, bool with_greens, bool reset_weights) {
     return AFQ_OK;
 }
 
+// ---- closed-shell walkers on the large-system path (afq_internal.h: closed_large) ----
+// one work-group per walker: are the alpha and the beta block bitwise equal?  (na == nb)
+__global__ __launch_bounds__(256) void closed_flags_kernel(const cplx *phi, int M, int na, int nt, const int *alive, int *flags,
+                                                           unsigned long long *counters) {
+    const int w = blockIdx.x;
+    if (alive && !alive[w]) { if (threadIdx.x == 0) flags[w] = 0; return; }
+    const cplx *p = phi + (long)w * M * nt;
+    int same = 1;
+    for (int e = threadIdx.x; e < M * na; e += 256) {
+        const int r = e / na, c = e - r * na;
+        const cplx x = p[r * nt + c], y = p[r * nt + na + c];
+        same &= (int)((__double_as_longlong(x.x) == __double_as_longlong(y.x)) & (__double_as_longlong(x.y) == __double_as_longlong(y.y)));
+    }
+    const int all = __syncthreads_and(same);
+    if (threadIdx.x == 0) {
+        flags[w] = all ? 1 : 0;
+        if (all && counters) atomicAdd(&counters[7], 1ull);       // afq_counters_ext [7]
+    }
+}
+
+__global__ __launch_bounds__(256) void closed_copy_beta_kernel(cplx *phi, int M, int na, int nt, const int *flags) {
+    const int w = blockIdx.x;
+    if (!flags[w]) return;
+    cplx *p = phi + (long)w * M * nt;
+    for (int e = threadIdx.x; e < M * na; e += 256) {
+        const int r = e / na, c = e - r * na;
+        p[r * nt + na + c] = p[r * nt + c];
+    }
+}
+
+int k_closed_flags(afq_handle *h) {
+    if (!h->closed_w || h->closed_w_n < h->nw) {
+        if (h->closed_w) hipFree(h->closed_w);
+        h->closed_w = nullptr;
+        AFQ_HIP(h, hipMalloc(&h->closed_w, sizeof(int) * (size_t)h->nw));
+        h->closed_w_n = h->nw;
+    }
+    AFQ_LAUNCH(h, closed_flags_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->phi, h->M, h->na, h->nt, h->alive, h->closed_w, h->counters);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
+int k_closed_copy_beta(afq_handle *h) {
+
+    AFQ_LAUNCH(h, closed_copy_beta_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->phi, h->M, h->na, h->nt, h->closed_w);
+    AFQ_POST(h);
+    return AFQ_OK;
+}
+
 int k_comb(afq_handle *h, double r, double target, bool with_greens) {
     if (k_comm_size(h) > 1 || h->comm) return k_comm_popcontrol(h, r, target, with_greens);
     int *pairs = (int *)h->pack_tmp;

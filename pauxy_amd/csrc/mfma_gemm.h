@@ -58,7 +58,10 @@ struct FragSet {
 //   MAP_COLPANEL_XCD  (work-group engine, batch == 1) column panel c and all its row tiles run on XCD c % 8
 //   MAP_BATCH_XCD_ROWS  (work-group engine) as MAP_BATCH_XCD, tile rows fastest inside a batch: the row tiles of one
 //                       B column panel run back to back on one XCD
-enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3, MAP_BATCH_XCD_ROWS = 4 };
+//   MAP_COLTILE_SLOW  (work-group engine) the column tile is the SLOWEST index of the whole launch (then the batch, then the row
+//                  tile): a problem that leaves out whole column tiles of most batches (BTILE_SKIP: the beta columns of
+//                  closed-shell walkers) keeps its live work-groups contiguous, i.e. spread evenly over the XCDs
+enum { MAP_COLS_FAST = 0, MAP_ROWS_FAST = 1, MAP_BATCH_XCD = 2, MAP_COLPANEL_XCD = 3, MAP_BATCH_XCD_ROWS = 4, MAP_COLTILE_SLOW = 5 };
 // optional problem trait: static constexpr bool INACTIVE_COPY = true -- inactive_tile(b, row0, nrows, col0, ncols, t, nthr)
 // is called by the nthr threads that would have computed the tile of an inactive batch (both GEMM engines)
 template <class P, class = void> struct gemm_inactive_copy { static constexpr bool value = false; };

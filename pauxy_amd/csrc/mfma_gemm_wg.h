@@ -91,6 +91,11 @@ template <class P> struct gemm_tileskip<P, decltype((void)P::TILE_SKIP)> { stati
 // (the sources of index kseg()) when it reaches kseg(), a multiple of 8
 template <class P, class = void> struct gemm_incr_seg { static constexpr bool value = false; };
 template <class P> struct gemm_incr_seg<P, decltype((void)P::INCR_SEG)> { static constexpr bool value = P::INCR_SEG; };
+// optional problem trait: static constexpr bool BTILE_SKIP = true -- skip_tile_b(b, row0, col0) is true for work-group tiles of
+// batch b whose output nobody wants (the beta columns of a closed-shell walker, whose propagated alpha block is copied over them
+// afterwards: k_gemm.hip): such a work-group returns before its first barrier
+template <class P, class = void> struct gemm_btileskip { static constexpr bool value = false; };
+template <class P> struct gemm_btileskip<P, decltype((void)P::BTILE_SKIP)> { static constexpr bool value = P::BTILE_SKIP; };
 template <class P, bool I> struct gemm_incr_types { using A = const void *; using B = const void *; };
 template <class P> struct gemm_incr_types<P, true> {
     using A = decltype(((const P *)nullptr)->baseA(0, 0));
@@ -153,6 +158,11 @@ __global__ __launch_bounds__(WM *WN * 64 * ((STAG == 3 || STAG == 5) ? 2 : 1), W
         b = 0;
         tn = (j / tiles_m) * 8 + x; tm = j % tiles_m;
         if (tn >= tiles_n) return;
+    } else if (MAP == MAP_COLTILE_SLOW) {
+        const long t = blockIdx.x, per_tn = (long)p.batch * tiles_m;
+        tn = (int)(t / per_tn);
+        const long rem = t % per_tn;
+        b = (int)(rem / tiles_m); tm = (int)(rem % tiles_m);
     } else {
         const long t = blockIdx.x;
         b = (int)(t / per_batch);
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(WM *WN * 64 * ((STAG == 3 || STAG == 5) ? 2 : 1), W
     }
     const int row0 = tm * 16 * RT, col0 = tn * 16 * CT;
     if constexpr (gemm_tileskip<P>::value) { if (p.skip_tile(row0, col0)) return; }   // uniform over the work-group
+    if constexpr (gemm_btileskip<P>::value) { if (p.skip_tile_b(b, row0, col0)) return; }
     const int lr = lane & 15, lk = lane >> 4;
     unsigned char *scratch = smem + (size_t)D * CHUNK + (size_t)wave * 1024;
     const unsigned ring_l = lds_addr(smem);

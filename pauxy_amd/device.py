@@ -483,7 +483,8 @@ class AfqDevice(object):
 
     def counters(self, reset=False, n=4):
         """[nfb_trig, nhe_trig, flagged overlap matrices, closed-deal propagator walker steps] and with n = 8 also
-        [.., one-spin exchange-energy walker evaluations, one-spin Green's functions, 0, 0] (afq_counters_ext)."""
+        [.., one-spin exchange-energy walker evaluations, one-spin Green's functions, NaN determinant overlaps taken as zero,
+        closed-shell walker steps of the large-system GEMM chain] (afq_counters_ext)."""
         out = numpy.zeros(max(4, n), dtype=numpy.int64)
         self._ck(self.lib.afq_counters_ext(self.h, _p(out), int(max(4, n)), int(reset)))
         return out

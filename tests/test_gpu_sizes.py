@@ -761,3 +761,44 @@ def test_fused_propagator_closed_shell_deals(M, N, deal):
             assert numpy.array_equal(out_phi[i, :, :N], out_phi[i, :, N:]) == (not is_open[i]), (step, i)
         assert int(dev.counters()[3]) == (live_closed * (step + 1) if deal else 0)
     dev.close()
+
+
+@pytest.mark.parametrize("M,N", [(136, 40), (200, 50), (150, 70)])
+def test_large_system_chain_leaves_out_the_beta_tiles_of_closed_shell_walkers(M, N):
+    """The GEMM chain of the large systems (M > 128: k_onebody / k_apply_exponential) checks at every step which walkers have
+    bitwise equal spin blocks and does not compute the work-group tiles that lie wholly in their beta columns; the propagated
+    alpha block is copied over the beta block behind the closing one-body product.  A population of closed, open and dead
+    walkers (at least 64: the ring path), two steps against the oracle (propagation/continuous.py:232-262); closed walkers stay
+    closed bit for bit, open ones open, dead ones untouched."""
+    K, nw = 16, 66
+    model, rng = build(M, K, N, N, False, seed=37)
+    assert numpy.array_equal(model.BH1[0], model.BH1[1])
+    half = model.psi[None, :, :N] + 0.1 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    phis = numpy.concatenate([half, half], axis=2)
+    is_open = numpy.arange(nw) % 3 == 1
+    phis[is_open, :, N:] += 0.05 * (rng.rand(int(is_open.sum()), M, N) + 1j * rng.rand(int(is_open.sum()), M, N))
+    w0 = numpy.ones(nw)
+    w0[4::7] = 0.0
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, numpy.array([ref.calc_overlap(p, model.psi, N, N) for p in phis]))
+    sample = [i for i in range(nw) if i % 5 in (0, 1)]              # oracle on a sample (closed, open and dead ones in it)
+    walkers = {i: ref.new_walker(model, phis[i]) for i in sample}
+    dev.counters(reset=True, n=8)
+    for step in range(2):
+        xi = rng.normal(size=(nw, K))
+        dev.propagate(xi, 0.2)
+        out_phi, out_w = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+        for i in range(nw):
+            if w0[i] == 0.0:
+                assert numpy.array_equal(out_phi[i], phis[i]) and out_w[i] == 0.0
+                continue
+            assert numpy.array_equal(out_phi[i, :, :N], out_phi[i, :, N:]) == (not is_open[i]), (step, i)
+            if i in walkers:
+                ref.propagate_walker_phaseless(model, walkers[i], xi[i], 0.2)
+                close(out_phi[i], walkers[i]['phi'], 1e-10 * (step + 1))
+                close(out_w[i], walkers[i]['weight'], 1e-10 * (step + 1))
+    # afq_counters_ext [7]: every step of every live closed walker went through the chain as a closed-shell walker
+    assert int(dev.counters(n=8)[7]) == 2 * int(((w0 > 0) & ~is_open).sum())
+    dev.close()
