@@ -308,6 +308,7 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
     extra = 2 * NSTEPS_BLOCK
     flagged0 = int(dev.counters()[2])
     closed_large0 = int(dev.counters(n=8)[7])
+    one_spin0 = int(dev.counters(n=8)[4])
     dev.launch_trace(True)
     eshift = afqmc.run_batched(extra, first_step=first, eshift=eshift)
     dev.sync()
@@ -316,6 +317,9 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
     flagged = int(dev.counters()[2]) - flagged0     # matrices the blocked Gauss-Jordan handed to the step-by-step kernel
     # walker steps that went through the large-system GEMM chain as closed-shell walkers (alpha columns only)
     closed_large = (int(dev.counters(n=8)[7]) - closed_large0) / float(extra * c["nw"])
+    # exchange-energy evaluations that found the population closed-shell on the device and evaluated one spin (afq_counters_ext
+    # [4] counts their walkers): two launches each, the second one returns at once
+    one_spin_evals = (int(dev.counters(n=8)[4]) - one_spin0) // c["nw"]
     b_real = bool(numpy.abs(numpy.imag(afqmc.propagators.propagator.BH1)).max() == 0.0)
     psi_real = bool(numpy.abs(numpy.imag(numpy.asarray(trial.psi))).max() == 0.0)
     rc_ = numpy.asarray(getattr(trial, '_rchol', numpy.zeros((0, 1))))
@@ -341,6 +345,16 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
                 work = work * 2.0 * extra / count
                 work_real = work_real * 2.0 * extra / count if work_real else None
             t = ms / count * 1e-3
+            if lname == "launch_exx_quadratic" and one_spin_evals > 0:
+                # priced per EVALUATION: an evaluation of a closed-shell population is the alpha launch (one spin's work, counted
+                # twice by energy_finish_kernel) plus the beta launch whose work-groups return at once
+                evals = count - one_spin_evals
+                share = 1.0 - 0.5 * one_spin_evals / evals
+                work, work_real = work * share, (work_real * share if work_real else None)
+                t = ms / evals * 1e-3
+                row.update(evaluations=evals, avg_ms=ms / evals)
+                note += ("; closed-shell population in %d of %d evaluations: one spin evaluated, counted twice (avg_ms = the alpha "
+                         "launch + the beta launch that returns at once)" % (one_spin_evals, evals))
             if bound == "hbm":
                 row.update(bound="hbm", achieved=work / t / 1e9, peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                            frac=work / t / 1e12 / PEAK_HBM_TBS, bytes_per_launch=work, note=note)

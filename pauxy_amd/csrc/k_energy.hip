@@ -534,6 +534,22 @@ static int ensure_atil(afq_handle *h) {
     return AFQ_OK;
 }
 
+// Closed-shell verdict for a Ghalf no Green's function launch has checked (the large-system path, k_bigdet.hip: three GEMM-shaped
+// launches, none of which holds a whole walker): one work-group per walker compares the two spin blocks of the stored Ghalf
+// bit for bit -- EVERY walker, the energy is evaluated for every one -- and raises closed_bad to this launch's epoch when they
+// differ (afq_internal.h: closed_bad).  nw * nt * M * 16 bytes read once (C5 sizes: 164 MB, ~45 us) ahead of an exchange
+// evaluation whose beta half (3 ms there) it can spare.
+__global__ __launch_bounds__(256) void ghalf_closed_check_kernel(const cplx *ghalf, long half, unsigned long long *closed_bad,
+                                                                 unsigned long long epoch) {
+    const double2 *a = (const double2 *)(ghalf + (long)blockIdx.x * 2 * half), *b = a + half;
+    int same = 1;
+    for (long e = threadIdx.x; e < half; e += 256) {
+        const double2 x = a[e], y = b[e];
+        same &= (int)((__double_as_longlong(x.x) == __double_as_longlong(y.x)) & (__double_as_longlong(x.y) == __double_as_longlong(y.y)));
+    }
+    if (!__syncthreads_and(same) && threadIdx.x == 0) atomicMax(closed_bad, epoch);
+}
+
 // (*S_out: contraction slices per spin of the un-split scheme; *two_pass: alpha and beta in two launches of 2 S slices each)
 template <bool RC>
 static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
@@ -550,6 +566,14 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     // Ghalf comes from: closed_checked_version) and one Atil for both spins: the 2 S slices of the FIRST launch all belong to
     // spin alpha (every XCD busy), the second launch holds spin beta's and returns at once on the device when the flag says
     // closed; energy_finish_kernel then counts the alpha sums twice.  Nothing is decided on the host.
+    if (h->closed_bad && h->closed_checked_version != h->ghalf_version && k_greens_big_supported(h) && h->ndet == 1 &&
+        h->na == h->nb && h->atil[0] == h->atil[1] && !h->exx_open_hint && !AFQ_KNOB_SET("AFQ_NO_CLOSED_EXX")) {
+        // (an open-shell population is found out by the first evaluation's published verdict, exx_open_hint: no check, and
+        //  the two-spin launch, from then on)
+        AFQ_LAUNCH(h, ghalf_closed_check_kernel, dim3(h->nw), dim3(256), 0, h->stream, h->ghalf, nma, h->closed_bad, ++h->closed_epoch);
+        AFQ_POST(h);
+        h->closed_checked_version = h->ghalf_version;
+    }
     const bool closed_try = h->closed_bad && h->closed_checked_version == h->ghalf_version && h->closed_checked_version != 0 &&
                             h->ndet == 1 && h->na == h->nb && h->atil[0] == h->atil[1] && !h->exx_open_hint && !AFQ_KNOB_SET("AFQ_NO_CLOSED_EXX");
     // (slices of the one-spin launch: 2 S, as many work-groups as the two-spin launch has.  C3, us per evaluation: S = 4

@@ -802,3 +802,46 @@ def test_large_system_chain_leaves_out_the_beta_tiles_of_closed_shell_walkers(M,
     # afq_counters_ext [7]: every step of every live closed walker went through the chain as a closed-shell walker
     assert int(dev.counters(n=8)[7]) == 2 * int(((w0 > 0) & ~is_open).sum())
     dev.close()
+
+
+@pytest.mark.parametrize("M,N", [(136, 40), (150, 70)])
+def test_large_system_exchange_energy_evaluates_one_spin_of_a_closed_shell_population(M, N):
+    """The Green's function of the large systems (k_greens_big: three GEMM-shaped launches) holds no whole walker anywhere, so
+    the exchange energy compares the spin blocks of the Ghalf it is about to contract itself (ghalf_closed_check_kernel) and
+    evaluates ONE spin when every walker's are bitwise equal (estimators/generic.py:84-119 contracts each spin alike).  A closed
+    population, then one with an open walker in it, against the oracle; the two-spin evaluation of the same closed walkers (the
+    T-intermediate algorithm) agrees; afq_counters_ext [4] counts the one-spin walker evaluations."""
+    K, nw = 12, 40
+    model, rng = build(M, K, N, N, False, seed=41)
+    half = model.psi[None, :, :N] + 0.1 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    closed_phis = numpy.concatenate([half, half], axis=2)
+    dev = make_device(model, nw)
+    dev.set_exchange_algorithm(2)                                   # the quadratic form (the automatic choice wants K >= M)
+    dev.set(L.F_PHI, closed_phis)
+    dev.greens(want_G=False)
+    gh = dev.get(L.F_GHALF).reshape(nw, 2 * N, M)
+    assert all(numpy.array_equal(g[:N], g[N:]) for g in gh)         # the launches of the large-system path treat both spins alike
+    dev.counters(reset=True, n=8)
+    E_closed = dev.local_energy()
+    assert int(dev.counters(n=8)[4]) == nw
+    for w in (0, 3, nw - 1):
+        _, gh_ref, G_ref = ref.greens_function(closed_phis[w], model.psi, N, N)
+        close(E_closed[w], numpy.array(model.local_energy(G_ref, gh_ref)), 1e-10)
+    dev.set_exchange_algorithm(1)
+    dev.greens(want_G=False)
+    close(dev.local_energy(), E_closed, 1e-11)
+    dev.set_exchange_algorithm(2)
+    # one open walker: the verdict is the population's, both spins are evaluated for everybody
+    phis = closed_phis.copy()
+    phis[5, :, N:] += 0.05 * (rng.rand(M, N) + 1j * rng.rand(M, N))
+    dev.set(L.F_PHI, phis)
+    dev.greens(want_G=False)
+    dev.counters(reset=True, n=8)
+    E = dev.local_energy()
+    assert int(dev.counters(n=8)[4]) == 0
+    for w in (0, 5, nw - 1):
+        _, gh_ref, G_ref = ref.greens_function(phis[w], model.psi, N, N)
+        close(E[w], numpy.array(model.local_energy(G_ref, gh_ref)), 1e-10)
+    mask = numpy.arange(nw) != 5
+    close(E[mask], E_closed[mask], 1e-13)                          # one spin counted twice == both spins evaluated
+    dev.close()
