@@ -414,6 +414,8 @@ def run_config(args, name, state, comm=None, world=1, rank=0, backend="nccl"):
         "exchange_timing": exchange_timing,
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "last_block_ETotal": float(numpy.real(mixed.blocks[-1][5])) if mixed.blocks else None,
+        # what the device counted in the traced pass (afq_counters_ext [7], [4]): tools/roofline_configs.py reads it
+        "closed_shell": {"large_chain_walker_step_share": closed_large, "exchange_one_spin": one_spin_evals > 0},
         "roofline": {"bound": "hbm" if dom["bound"] == "hbm" else "mfma", "kernel": dom["launch"] + " (" + dom["note"] + ")",
                      "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                      "frac_survey": dom.get("frac_survey"),
@@ -1036,7 +1038,8 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     dev.kernel_trace(False)
     # walker steps the fused propagator took through its closed-shell deal (spin blocks bitwise equal, checked per walker in
     # the kernel: column slot 1 = [beta 0..15], the twin of slot 0, left out of the Taylor products)
-    closed_prop = float(dev.counters()[3]) / (extra_steps * nw)
+    counted = dev.counters(n=8)
+    closed_prop = float(counted[3]) / (extra_steps * nw)
     nt = 2 * N
     rc = numpy.asarray(trial._rchol)
     fb_same_spin_block = bool(numpy.array_equal(rc[:N * M], rc[N * M:2 * N * M]))
@@ -1046,10 +1049,13 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     wt = work_table(dict(M=M, na=N, nb=N, K=K, nw=nw), b_real=b_real, psi_real=psi_real, rchol_same=fb_same_spin_block)
     quad = dev.exchange_algorithm() == 2
     # closed-shell population (every walker's spin blocks bitwise equal, RHF trial): the library evaluates the exchange energy
-    # of one spin and counts it twice (verified on the device per evaluation) -- the executed work is one spin's
-    phi_now = dev.get(L.F_PHI)
-    closed_pop = bool(quad and fb_same_spin_block and numpy.array_equal(numpy.asarray(trial.psi)[:, :N], numpy.asarray(trial.psi)[:, N:])
-                      and numpy.array_equal(phi_now[:, :, :N], phi_now[:, :, N:]))
+    # of one spin and counts it twice (verified on the device per evaluation) -- the executed work is one spin's.  The device
+    # says so itself: afq_counters_ext [4] counts the walkers of every evaluation that took one spin
+    one_spin_evals = int(counted[4]) // nw
+    closed_pop = bool(quad and one_spin_evals > 0)
+    if closed_pop and one_spin_evals != extra_steps // NSTEPS_BLOCK:
+        raise RuntimeError("%d of the pass's %d exchange-energy evaluations took one spin: a population that changes kind inside "
+                           "the traced pass has no one work model" % (one_spin_evals, extra_steps // NSTEPS_BLOCK))
     if closed_pop:
         b_, w_, wr_, n_ = wt["launch_exx_quadratic"]
         wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice "
@@ -1189,6 +1195,10 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
             # (device Philox streams: the same library gives the same number every run; kernel variants that claim
             #  bit-equal results can be held against it)
             "last_block_ETotal": last_block_energy(afqmc),
+            # what the device counted in the traced pass (afq_counters_ext [3], [4]): tools/roofline_configs.py prices the
+            # profiler's launches of the same run with it
+            "closed_shell": {"propagator_walker_step_share": closed_prop, "exchange_one_spin": closed_pop,
+                             "propagator_issued_flops_per_walker": dict(zip(("open", "closed"), dev.propagator_issued_flops()))},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"],
                          "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "frac_survey": dom.get("frac_survey"),

@@ -37,13 +37,19 @@ CONFIGS = {
 }
 
 
-def work(name, c):
-    """(bound, algorithmic work per launch, unit, note) of a kernel, or None."""
+def work(name, c, cs=None):
+    """(bound, algorithmic work per launch, unit, note) of a kernel, or None.  cs: the `closed_shell` object of the bench line the
+    same run printed (what the device counted: the share of the walker steps that went through a closed-shell deal of the
+    propagator / of the large-system GEMM chain, and whether the exchange energy evaluated one spin) -- executed work is priced."""
     M, na, nb, K, nw = c['M'], c['na'], c['nb'], c['K'], c['nw']
     nt = na + nb
     cx = 2.0 if c.get('cplx') else 1.0
+    cs = cs or {}
+    s_prop, s_chain = float(cs.get('propagator_walker_step_share') or 0.0), float(cs.get('large_chain_walker_step_share') or 0.0)
+    closed_note = lambda s: '; closed-shell walkers (%.0f %% of the walker steps): alpha columns only' % (100.0 * s) if s > 0 else ''
     if 'prop_fused_kernel' in name:
-        return 'mfma', 8.0 * M * M * nt * 8 * nw, 'flop', 'B exp(V) B: 2 + 6 products of M x M by M x (na+nb), 8 flops per complex MAC'
+        return ('mfma', 8.0 * M * M * (6 * (nt - nb * s_prop) + 2 * nt) * nw, 'flop',
+                'B exp(V) B: 2 + 6 products of M x M by M x (na+nb), 8 flops per complex MAC' + closed_note(s_prop).replace('alpha columns only', 'Taylor products on the alpha columns only'))
     if 'VhsProb' in name:
         cols = M * (M + 1) // 2 if c['kind'] == 'generic' else M * M
         return 'mfma', 4.0 * cols * K * nw, 'flop', 'HS potential, packed symmetric columns'
@@ -56,12 +62,15 @@ def work(name, c):
         return 'mfma', 4.0 * cx * K * nt * M * nw, 'flop', 'force bias / Coulomb vectors'
     if 'ExxQProb' in name:
         tri = lambda n: n * (n + 1) / 2.0
+        if cs.get('exchange_one_spin'):
+            return 'mfma', 4.0 * cx * tri(na * M) * nw, 'flop', 'exchange energy, quadratic form on the upper triangle of Atil: closed-shell population, one spin evaluated and counted twice (the beta launch returns at once)'
         return 'mfma', 4.0 * cx * (tri(na * M) + tri(nb * M)) * nw, 'flop', 'exchange energy, quadratic form on the upper triangle of Atil (per determinant)'
     if name.startswith('void exx_kernel'):
         return 'mfma', 4.0 * cx * K * M * (na * na + nb * nb) * nw, 'flop', 'exchange energy, T intermediate (per determinant)'
     if 'TaylorProb' in name:
-        return 'mfma', 8.0 * M * M * nt * nw, 'flop', 'one Taylor product V T (both spins)'
+        return 'mfma', 8.0 * M * M * (nt - nb * s_chain) * nw, 'flop', 'one Taylor product V T (both spins)' + closed_note(s_chain)
     if 'OneBodyProb' in name:
+        # (one spin: doubled below for a launch that holds both -- the closed-shell walkers of such a launch execute alpha's)
         return 'mfma', 8.0 * M * M * na * nw, 'flop', 'BH1 phi, one spin'
     if 'OvlpProb' in name:
         return 'mfma', 8.0 * na * na * M * nw * 2, 'flop', 'phi^T conj(psi), both spins'
@@ -88,7 +97,7 @@ def work(name, c):
     return None
 
 
-def gemm_issued(name, c, merged=False):
+def gemm_issued(name, c, merged=False, cs=None):
     """Matrix-pipe flops of one launch of the ring GEMM engine from its template arguments
     mfma_gemm_wg_kernel<WM, WN, TM, TN, D, Prob, MAP, K3M, KC, STAG> and the problem shape; None when unknown."""
     m = re.match(r'void mfma_gemm_wg_kernel<(\d+), (\d+), (\d+), (\d+), \d+, (\w+)(<(\w+)>)?, \d+, (true|false)', name)
@@ -99,17 +108,22 @@ def gemm_issued(name, c, merged=False):
     M, na, nb, K, nw = c['M'], c['na'], c['nb'], c['K'], c['nw']
     nt, nmax = na + nb, max(na, nb)
     tri = False
+    cs = cs or {}
+    s_chain = float(cs.get('large_chain_walker_step_share') or 0.0)
+    closed_cols = None          # columns whose tiles a closed-shell walker of the large-system chain executes
     if prob == 'VhsProb':
         batch, rows, cols, kdim, mults = 1, nw, (M * (M + 1) // 2 if c['kind'] == 'generic' else M * M), K, 2
     elif prob == 'ForceBiasProb':
         contr = (na if (c.get('ndet', 1) == 1 and not c.get('cplx') and na == nb) else nt) * M
         batch, rows, cols, kdim, mults = 1, nw, K, contr, 2
     elif prob == 'ExxQProb':
-        batch, rows, cols, kdim, mults, tri = 2, nw, na * M, na * M, (3 if targ == 'true' else 2), True
+        batch, rows, cols, kdim, mults, tri = (1 if cs.get('exchange_one_spin') else 2), nw, na * M, na * M, (3 if targ == 'true' else 2), True
     elif prob == 'TaylorProb':
         batch, rows, cols, kdim, mults = nw, M, nt, M, 3 if k3m else 4
+        closed_cols = na
     elif prob in ('OneBodyProb', 'OneBodyProbT'):
         batch, rows, cols, kdim, mults = nw, M, (nt if merged else na), M, (2 if targ == 'true' else 3 if k3m else 4)
+        closed_cols = na if merged else None
     elif prob in ('OvlpProb', 'OvlpProbT', 'GramProb'):
         batch, rows, cols, kdim, mults = 2 * nw, nmax, nmax, M, (2 if targ == 'true' else 3 if k3m else 4)
     elif prob in ('GhalfProb', 'GhalfProbT'):
@@ -124,11 +138,20 @@ def gemm_issued(name, c, merged=False):
         ksum = sum(-(-min(kdim, tc * (tn + 1)) // 8) * 8 for tn in range(tiles_n))
         return 2.0 * mults * batch * tiles_m * tr * tc * ksum
     kpad = -(-kdim // 8) * 8
+    if closed_cols is not None and s_chain > 0.0:
+        # a tile is left out when it lies wholly in the beta columns: the tiles that START below na run
+        tiles_n = (1.0 - s_chain) * tiles_n + s_chain * -(-closed_cols // tc)
     return 2.0 * mults * batch * tiles_m * tiles_n * tr * tc * kpad
 
 
-def issued_flops(name, c, merged=False):
+def issued_flops(name, c, merged=False, cs=None):
     M, na, nb, nw = c['M'], c['na'], c['nb'], c['nw']
+    cs = cs or {}
+    per = cs.get('propagator_issued_flops_per_walker')
+    if 'prop_fused_kernel' in name and per:
+        # the library's own count for either deal (afq_propagator_issued_flops), mixed by the device's count of the walker steps
+        s = float(cs.get('propagator_walker_step_share') or 0.0)
+        return ((1.0 - s) * per['open'] + s * per['closed']) * nw
     if 'prop_fused_kernel' in name:
         nrt, ct, nch = -(-M // 16), -(-na // 16) + -(-nb // 16), -(-M // 8)
         rem4 = 96 < M <= 100
@@ -137,7 +160,7 @@ def issued_flops(name, c, merged=False):
     if 'prop_ueg_kernel' in name:
         mp = -(-M // 16) * 16
         return 3.0 * 6 * 2.0 * (mp // 16) * (mp // 8) * 2048.0 * nw
-    return gemm_issued(name, c, merged)
+    return gemm_issued(name, c, merged, cs)
 
 
 def trace_averages(path):
@@ -191,7 +214,8 @@ def main():
         # per step instead of four) -- the template arguments do not show it, the launch count per step does
         nsteps = next((int(r['Calls']) for r in rows if 'fields_kernel' in r['Name']), 0)
         for r in rows[:14]:
-            w = work(r['Name'], c)
+            cs = (line or {}).get('closed_shell')
+            w = work(r['Name'], c, cs)
             avg = float(r['AverageNs'])
             merged = 'OneBodyProb' in r['Name'] and nsteps > 0 and int(r['Calls']) / float(nsteps) < 3.0
             e = {"kernel": r['Name'][:110], "calls": int(r['Calls']), "avg_us": avg / 1e3,
@@ -203,7 +227,9 @@ def main():
             if w:
                 bound, amount, unit, note = w
                 if merged:
-                    amount, note = 2.0 * amount, 'BH1 phi, both spins in one launch'
+                    s_chain = float((cs or {}).get('large_chain_walker_step_share') or 0.0)
+                    amount, note = (2.0 - s_chain) * amount, 'BH1 phi, both spins in one launch' + (
+                        '; closed-shell walkers (%.0f %% of the walker steps): alpha columns only' % (100.0 * s_chain) if s_chain > 0 else '')
                 e["bound"] = bound
                 e["work_per_launch"] = amount
                 e["work_unit"] = unit
@@ -213,7 +239,7 @@ def main():
                     e["peak"] = PEAK_TF
                     e["unit"] = "TFLOP/s"
                     e["frac_algorithmic"] = e["achieved"] / PEAK_TF
-                    iss = issued_flops(r['Name'], c, merged) if bound == 'mfma' else None
+                    iss = issued_flops(r['Name'], c, merged, cs) if bound == 'mfma' else None
                     if iss:
                         e["issued_flops_per_launch"] = iss
                         e["frac_issued"] = iss / (avg * 1e-9) / 1e12 / PEAK_TF
