@@ -1132,6 +1132,9 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
                                                       FieldRng rng) {
     __shared__ double red[NTHR / 64][8];
     const int w = blockIdx.x;
+#ifdef AFQ_TUNING
+    if (rng.dbg & 8) return;
+#endif
     if (rng.on) {
         const bool live = fabs(rng.weight[w]) > 1e-8;
         if (threadIdx.x == 0) rng.alive_out[w] = live ? 1 : 0;
@@ -1146,8 +1149,13 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
         if (ab > 1.0) { b.x /= ab; b.y /= ab; acc[6] += 1.0; }
         const double x = rng.on ? xdev : xi[e];
         const cplx sft = cmake(x - b.x, -b.y);
+#ifdef AFQ_TUNING
+        if (!(rng.dbg & 4))
+#endif
+        {
         xbar[e] = b;
         xs[e] = sft;
+        }
         if (FUSED && xa.hub_fac) {
             // propagation/hubbard.py:409-413 / :475-480, continuous.py:104-107 with a diagonal potential: one factor per site
             auto taylor = [&](const cplx d) {
@@ -1187,15 +1195,58 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
         // a thread takes the two members of one Philox pair (elements 2 p, 2 p + 1 of the stream: consecutive fields of
         // this walker, or its first / last field alone when the walker's K fields start or end inside a pair), so that a
         // pair is generated once -- with a thread per field every pair was generated twice and one normal of each thrown away
+        // Generic Hamiltonian, one determinant, force bias on (the C3 step): the 2 x 2 nsplit split-K partial sums of the pair's
+        // two fields and their mean-field shifts are loaded in ONE flight, no branch between them -- the partials come from the
+        // other XCDs' force-bias work-groups (16 MB at C3), and this kernel is their round trips: 5.3 of its 10.7 us with the
+        // loads of one field at a time, four in flight (round 6; the sums keep xbar_value's order: bit-identical)
+        const bool flight = FUSED && xa.kind == AFQ_SYS_GENERIC && xa.ndet <= 1 && (xa.flags & AFQ_PROP_FORCE_BIAS) && !xa.hub_fac;
         for (long pr = (e0 >> 1) + threadIdx.x; pr <= ((e0 + K - 1) >> 1); pr += NTHR) {
             cplx bb[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)}, mm[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+            if (flight) {
+                int nn[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int n = (int)(2 * pr + m - e0);
+                    nn[m] = n < 0 ? 0 : n >= K ? K - 1 : n;          // (a pair that straddles the walker: a valid address, value unused)
+                }
+                const int nb2 = 2 * xa.nsplit;
+                const long bs = (long)xa.nw * K;
+                const cplx *vb0 = xa.vbias + (long)w * K + nn[0], *vb1 = xa.vbias + (long)w * K + nn[1];
+                mm[0] = mf[nn[0]]; mm[1] = mf[nn[1]];
+                cplx v0 = cmake(0.0, 0.0), v1 = cmake(0.0, 0.0);
+                int b = 0;
+                for (; b + 7 < nb2; b += 8) {
+                    cplx t0[8], t1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { t0[j] = vb0[(b + j) * bs]; t1[j] = vb1[(b + j) * bs]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v0 = cadd(v0, t0[j]); v1 = cadd(v1, t1[j]); }
+                }
+                for (; b + 3 < nb2; b += 4) {
+                    cplx t0[4], t1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t0[j] = vb0[(b + j) * bs]; t1[j] = vb1[(b + j) * bs]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0 = cadd(v0, t0[j]); v1 = cadd(v1, t1[j]); }
+                }
+                for (; b < nb2; ++b) { v0 = cadd(v0, vb0[b * bs]); v1 = cadd(v1, vb1[b * bs]); }
+                // propagation/generic.py:150-152 (xbar_value): -sqrt(dt) (i vbias - mf_shift)
+                bb[0] = cmake(-xa.sqrt_dt * (-v0.y - mm[0].x), -xa.sqrt_dt * (v0.x - mm[0].y));
+                bb[1] = cmake(-xa.sqrt_dt * (-v1.y - mm[1].x), -xa.sqrt_dt * (v1.x - mm[1].y));
+            } else
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const long e = 2 * pr + m;
                 const int n = (int)(e - e0);
+#ifdef AFQ_TUNING
+                if (rng.dbg & 2) { if (n >= 0 && n < K) { bb[m] = cmake(0.01 * n, 0.02); mm[m] = cmake(0.5, 0.1); } continue; }
+#endif
                 if (n >= 0 && n < K) { bb[m] = FUSED ? xbar_value(xa, w, n) : xbar[e]; mm[m] = mf[n]; }
             }
             double xn[2] = {0.0, 0.0};
+#ifdef AFQ_TUNING
+            if (rng.dbg & 1) { xn[0] = 0.3 + 1e-3 * threadIdx.x; xn[1] = -0.2; } else
+#endif
             if (rng.on) philox_normal_pair(pr, rng.seed, rng.stream, rng.counter, xn[0], xn[1]);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -1205,6 +1256,9 @@ __global__ __launch_bounds__(NTHR) void fields_kernel(int K, double sqrt_dt, con
             }
         }
     }
+#ifdef AFQ_TUNING
+    if (rng.dbg & 16) { if (threadIdx.x == 0) { cmf[w] = cmake(acc[0], acc[1]); cfb[w] = cmake(acc[2], acc[3] + acc[4] + acc[5] + acc[6]); } return; }
+#endif
     // one reduction for all seven sums: wave shuffles, one barrier
 #pragma unroll
     for (int q = 0; q < 7; ++q)
@@ -1237,6 +1291,9 @@ int k_fields(afq_handle *h) {
 // force bias from the contraction output + clip + shift in one launch (the step's hot path)
 int k_xbar_fields(afq_handle *h, cplx *hubbard_factors) {
     FieldRng rng = FieldRng();
+#ifdef AFQ_TUNING
+    rng.dbg = AFQ_KNOB_INT("AFQ_FIELDS_DBG", 0);
+#endif
     if (h->rng_inline) {
         rng.on = 1; rng.seed = h->rng_seed; rng.stream = h->rng_stream; rng.counter = h->rng_inline_counter;
         rng.weight = h->weight; rng.alive_out = h->alive;

@@ -43,4 +43,8 @@ struct FieldRng {
     unsigned long long seed, stream, counter;
     const double *weight;
     int *alive_out;
+#ifdef AFQ_TUNING
+    int dbg;            // timing ablations of fields_kernel (AFQ_FIELDS_DBG; wrong results): 1 no Philox / Box-Muller, 2 no loads of
+                        // the force-bias partials, 4 no stores of xbar / xs, 8 return at once, 16 no reduction of the seven sums
+#endif
 };
