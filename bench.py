@@ -1059,7 +1059,7 @@ def run_bench(args, scaling, comm, world, rank, backend, system, trial, state, w
     if closed_pop:
         b_, w_, wr_, n_ = wt["launch_exx_quadratic"]
         wt["launch_exx_quadratic"] = (b_, 0.5 * w_, wr_, n_ + "; closed-shell population: one spin evaluated, counted twice "
-                                        "(kernel_ms = the alpha launch + the ExxQBetaProb launch that returns at once, ~3.4 us)")
+                                        "(the beta slices ride in the same launch as work-groups that return at once)")
     prop_note = ""
     prop_issued_scale = 0.0
     if closed_prop > 0.0:

@@ -240,9 +240,12 @@ struct ExxQProb {
     const cplx *zero;
     // closed-shell populations (afq_internal.h: closed_bad): the launch that holds the beta spin's slices returns at once when
     // every walker's Ghalf_b equals its Ghalf_a -- the finish kernel then takes the alpha sums twice
+    // (skip_from: the first batch that belongs to the beta spin -- 0 for a launch of its own, the alpha batch count when both
+    //  spins' slices share one launch)
     const unsigned long long *skip_flag;
     unsigned long long skip_epoch;
-    __device__ bool active(int) const { return !(skip_flag && *skip_flag < skip_epoch); }
+    int skip_from;
+    __device__ bool active(int b) const { return !(skip_flag && b >= skip_from && *skip_flag < skip_epoch); }
     __device__ const cplx *ptrA(int b, int row, int k) const {
         return k < len[b] ? ghalf + row * astride + goff[b] + k : zero;
     }
@@ -382,7 +385,7 @@ struct EFinArgs {
 // Y partials of its walker once; 16 waves per CU keep enough loads in flight
 #define EF_THR 1024
 __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
-    __shared__ double red[EF_THR / 64];
+    __shared__ double red[EF_THR / 64][6];
     const int w = blockIdx.x, tid = threadIdx.x;
     // one-body
     double e1r = 0, e1i = 0;
@@ -411,8 +414,20 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
     // Coulomb
     double ecr = 0, eci = 0;
     for (int n = tid; n < a.K; n += EF_THR) {
+        // (the split-K partial sums of a field in flights of eight, summed in the order of the plain loop)
         cplx x = cmake(0.0, 0.0);
-        for (int b = 0; b < 2 * a.nsplit; ++b) x = cadd(x, a.vbias[((long)b * a.nw + w) * a.K + n]);
+        const cplx *vb = a.vbias + (long)w * a.K + n;
+        const long bs = (long)a.nw * a.K;
+        const int nb2 = 2 * a.nsplit;
+        int b = 0;
+        for (; b + 7 < nb2; b += 8) {
+            cplx t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = vb[(b + j) * bs];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x = cadd(x, t[j]);
+        }
+        for (; b < nb2; ++b) x = cadd(x, vb[b * bs]);
         ecr += x.x * x.x - x.y * x.y;
         eci += 2.0 * x.x * x.y;
     }
@@ -427,19 +442,23 @@ __global__ __launch_bounds__(EF_THR) void energy_finish_kernel(EFinArgs a) {
         const cplx v = a.part[task * 16 + wl];
         exr += v.x; exi += v.y;
     }
-    // block sums
+    // block sums: one reduction for all six (wave shuffles, one barrier; the order of the sums is that of six separate ones)
     double v[6] = {e1r, e1i, ecr, eci, exr, exi};
-    for (int k = 0; k < 6; ++k) {
-        double x = v[k];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = x;
-        __syncthreads();
-        double tot = 0.0;
-        for (int i = 0; i < EF_THR / 64; ++i) tot += red[i];
-        v[k] = tot;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[tid >> 6][k] = v[k];
     }
+    __syncthreads();
     if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double tot = 0.0;
+            for (int i = 0; i < EF_THR / 64; ++i) tot += red[i][k];
+            v[k] = tot;
+        }
         const double e2r = 0.5 * (v[2] - v[4]), e2i = 0.5 * (v[3] - v[5]);
         a.energy[3 * w + 0] = cmake(v[0] + e2r + a.ecore, v[1] + e2i);
         a.energy[3 * w + 1] = cmake(v[0] + a.ecore, v[1]);
@@ -585,15 +604,22 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     ExxQProb<RC> p;
     p.batch = NB; p.rows = h->nw; p.cols = (int)nmax; p.astride = (long)h->nt * M;
     p.ghalf = h->ghalf; p.zero = (const cplx *)h->zero_page;
-    p.skip_flag = nullptr; p.skip_epoch = 0;
-    const int npass = closed_try ? 2 : 1;
+    p.skip_flag = nullptr; p.skip_epoch = 0; p.skip_from = 0;
+    // a whole number of rounds over the eight XCDs per spin (C3: 8 slices): the beta slices ride in the alpha launch, behind
+    // the alpha slices in every XCD's queue -- work-groups that return at once instead of a launch that returns at once
+    // (5.0 us per evaluation in the kernel trace); otherwise (C5 sizes: 2 slices) the beta launch keeps the alpha launch's
+    // spread over the XCDs
+    const bool merged = closed_try && NB % 8 == 0 && 2 * NB <= EXQ_MAX_BATCH && !AFQ_KNOB_SET("AFQ_EXQ_TWO_LAUNCHES");
+    const int npass = closed_try && !merged ? 2 : 1;
+    const int nbat = merged ? 2 * NB : NB;
+    p.batch = nbat;
     // (ONE event pair around both launches: with a closed-shell population the second is a few microseconds of work-groups
     //  that return at once, and the pair times what the evaluation costs)
     KernelTrace kt(h, AFQ_K_EXCHANGE);
     for (int pass = 0; pass < npass; ++pass) {
     int kmax = 0;
-    for (int b = 0; b < NB; ++b) {
-        const int s = closed_try ? pass : b / S, sl = closed_try ? b : b % S;
+    for (int b = 0; b < nbat; ++b) {
+        const int s = closed_try ? (merged ? b / NB : pass) : b / S, sl = closed_try ? b % NB : b % S;
         const long tot = s == 0 ? nma : nmb;
         if (tot == 0) { p.goff[b] = 0; p.soff[b] = 0; p.len[b] = 0; p.ncol[b] = 0; p.B[b] = h->zero_page; p.ldq[b] = 0; p.k0[b] = 0; continue; }
         const long ldq = (tot + 1) & ~1L;
@@ -616,14 +642,14 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
     }
     p.kdim = kmax;
     p.ncb = (int)((nmax + 15) / 16);
-    const size_t per_pass = (size_t)NB * h->nw * p.ncb, need = per_pass * npass;
+    const size_t per_pass = (size_t)NB * h->nw * p.ncb, need = per_pass * (closed_try ? 2 : 1);
     if (h->exq_y_len < need) {
         if (h->exq_y) hipFree(h->exq_y);
         AFQ_HIP(h, hipMalloc(&h->exq_y, sizeof(cplx) * need));
         h->exq_y_len = need;
     }
     p.E = h->exq_y + per_pass * pass;
-    if (pass == 1) { p.skip_flag = h->closed_bad; p.skip_epoch = h->closed_epoch; }
+    if (pass == 1 || merged) { p.skip_flag = h->closed_bad; p.skip_epoch = h->closed_epoch; p.skip_from = merged ? NB : 0; }
     // short contractions (several slices: C3 sizes) run better on eight waves with a 1 x 2 tile block each (146 vs 165 us),
     // long ones (one slice: C5 sizes) on four waves with 2 x 2 (11.53 vs 11.61 ms per step)
     // (round 4: the loader-wave configuration for long contractions too: C5 sizes 6.63 -> 6.36 ms per evaluation)
@@ -633,7 +659,9 @@ static int launch_exx_quadratic(afq_handle *h, int *S_out, bool *two_pass) {
                 const long need = (long)col0 + ncols - p.k0[b];
                 return need <= 0 ? 0 : (need < p.len[b] ? need : p.len[b]);
             };
-            h->issued_flops[AFQ_K_EXCHANGE] = mfma_gemm_wg_issued_flops<2, 2, 2, 2, ExxQProb<RC>, RC>(p, klen);
+            ExxQProb<RC> pa = p;
+            pa.batch = NB;             // (the alpha slices, or both spins' of the plain launch: what a closed-shell population executes)
+            h->issued_flops[AFQ_K_EXCHANGE] = mfma_gemm_wg_issued_flops<2, 2, 2, 2, ExxQProb<RC>, RC>(pa, klen);
         }
         // round 4: four compute waves with 2 x 2 tiles + four loader waves (STAG = 3: the ring refill kept out of the waves
         // that issue MFMAs; see the HS-potential GEMM in k_gemm.hip): 155 -> 139 us per evaluation at C3 against the eight
