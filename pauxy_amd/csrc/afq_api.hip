@@ -1479,7 +1479,6 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     if (!h) return AFQ_EINVAL;
     hipSetDevice(h->device);
     if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
-    { const int rc = k_estimates(h, 0, true); if (rc) return rc; }     // sums still sitting in the per-walker accumulators
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
         // [nest sums | scal[AFQ_NSCAL] | sequence number], written by the device, polled by the host
@@ -1493,9 +1492,18 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
     ++h->est_seq;
     h->closed_epoch_pub = h->closed_epoch;                   // the newest launch whose verdict the published word can hold
-    AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
-               (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero, h->closed_bad);
-    AFQ_POST(h);
+    if (h->est_acc_pending) {
+        // sums still sitting in the per-walker accumulators: the launch that folds them in hands the block over too
+        EstPublish pub;
+        pub.host_out = dev_view; pub.host_seq = (unsigned long long *)(dev_view + nest + AFQ_NSCAL); pub.seq = h->est_seq;
+        pub.scal = h->scal; pub.closed_bad = h->closed_bad; pub.nest = (int)nest; pub.zero = zero;
+        const int rc = k_estimates(h, 0, true, &pub);
+        if (rc) return rc;
+    } else {
+        AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
+                   (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero, h->closed_bad);
+        AFQ_POST(h);
+    }
     h->est_pending = true;
     return AFQ_OK;
 }

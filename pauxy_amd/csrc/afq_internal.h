@@ -467,7 +467,18 @@ int k_log_shift_reortho(afq_handle *h);                            // detR -> ex
 int k_log_ovlp_sums(afq_handle *h, double *out3);                  // sums of |ot|, |detR|, |log_detR| (device -> host)
 int k_scale_weights(afq_handle *h, double scale);
 int k_reset_weights(afq_handle *h, bool after_comb = false);
-int k_estimates(afq_handle *h, int have_energy, bool fold_only = false);
+// the hand-over of a block's sums to the host (afq_estimates_get_begin): written into mapped host memory, zeroed, sequence
+// number published -- by est_publish_kernel, or by the estimates_kernel launch that folds the last accumulators in (host_out
+// null: no hand-over)
+struct EstPublish {
+    double *host_out = nullptr;
+    unsigned long long *host_seq = nullptr;
+    unsigned long long seq = 0;
+    const double *scal = nullptr;
+    const unsigned long long *closed_bad = nullptr;
+    int nest = 0, zero = 0;
+};
+int k_estimates(afq_handle *h, int have_energy, bool fold_only = false, const EstPublish *pub = nullptr);
 int k_rdm_accumulate(afq_handle *h);
 int k_rng_normal(afq_handle *h);
 int k_rng_normal_into(afq_handle *h, double *out_d, long n);

@@ -2177,7 +2177,7 @@ int k_comb(afq_handle *h, double r, double target, bool with_greens) {
 __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy, int fp, const double *weight,
                                                          const double *unscaled, const cplx *ot,
                                                          const cplx *ehyb, const cplx *phase, const cplx *energy,
-                                                         cplx *est, double *acc, int fold_only) {
+                                                         cplx *est, double *acc, int fold_only, EstPublish pub) {
     __shared__ double red[NTHR / 64][18];
     // v[0]=uweight  v[1..2]=weight  v[3]=ovlp  v[4..5]=ehyb  v[6..7]=enumer  v[8..9]=e1b  v[10..11]=e2b
     // v[12..17] = the first six again for the steps whose sums rode on their weight update (afq_estimates_fuse_next):
@@ -2236,6 +2236,19 @@ __global__ __launch_bounds__(NTHR) void estimates_kernel(int nw, int have_energy
             est[AFQ_EST_EDENOM].x += v[1]; est[AFQ_EST_EDENOM].y += v[2];
         }
     }
+    if (pub.host_out) {
+        // the block's sums go to the host from this launch (afq_api.hip: est_publish_kernel, the same steps): one launch less
+        // at every block boundary
+        __syncthreads();                                 // thread 0's sums, for the threads that copy them out
+        const int t = threadIdx.x;
+        if (t < pub.nest) pub.host_out[t] = ((const double *)est)[t];
+        if (t < AFQ_NSCAL) pub.host_out[pub.nest + t] = pub.scal[t];
+        if (t == 0) pub.host_seq[1] = pub.closed_bad ? *pub.closed_bad : 0ull;
+        __threadfence_system();
+        __syncthreads();
+        if (t < pub.nest && pub.zero) ((double *)est)[t] = 0.0;
+        if (t == 0) __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // estimators/mixed.py:226-229: estimates[one_rdm] += weight * walker.G.real, summed over walkers in a fixed order
@@ -2255,12 +2268,12 @@ int k_rdm_accumulate(afq_handle *h) {
     return AFQ_OK;
 }
 
-int k_estimates(afq_handle *h, int have_energy, bool fold_only) {
+int k_estimates(afq_handle *h, int have_energy, bool fold_only, const EstPublish *pub) {
     const int fp = (h->flags & AFQ_PROP_FREE_PROJECTION) ? 1 : 0;
     if (fold_only && !h->est_acc_pending) return AFQ_OK;
     AFQ_LAUNCH(h, estimates_kernel, dim3(1), dim3(NTHR), 0, h->stream, h->nw, have_energy, fp, h->weight,
                        h->unscaled, h->ot, h->ehyb, h->phase, h->energy, h->estimates,
-                       h->est_acc_pending ? h->est_acc : (double *)nullptr, fold_only ? 1 : 0);
+                       h->est_acc_pending ? h->est_acc : (double *)nullptr, fold_only ? 1 : 0, pub ? *pub : EstPublish());
     AFQ_POST(h);
     h->est_acc_pending = false;
     return AFQ_OK;
