@@ -402,6 +402,10 @@ int afq_estimates_get(afq_handle *h, double *est_out /* c128[10] */, int zero);
  * Continuous propagator, not with afq_estimates_rdm on.                                                            */
 int afq_estimates_fuse_next(afq_handle *h);
 int afq_estimates_get_begin(afq_handle *h, int zero);
+/* afq_estimates_update(h, eval_energy) followed by afq_estimates_get_begin(h, zero) as ONE call: the summation launch of the
+ * update writes the block's sums into the mapped host buffer itself (estimators/mixed.py:211-225 + :261-273 of the step
+ * that ends a block) -- one launch less at every block boundary; afq_estimates_get_end collects them as after _get_begin. */
+int afq_estimates_update_publish(afq_handle *h, int eval_energy, int zero);
 int afq_estimates_get_end(afq_handle *h, double *est_out /* c128[10] */);
 
 /* ---- misc ------------------------------------------------------------------ */

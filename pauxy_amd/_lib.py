@@ -71,6 +71,7 @@ SIGNATURES = {
     "afq_estimates_get": [_h, _dp, c_int],
     "afq_estimates_fuse_next": [_h],
     "afq_estimates_get_begin": [_h, c_int],
+    "afq_estimates_update_publish": [_h, c_int, c_int],
     "afq_estimates_get_end": [_h, _dp],
     "afq_estimates_rdm": [_h, c_int],
     "afq_estimates_rdm_get": [_h, _dp, c_int],

@@ -1393,11 +1393,14 @@ int afq_walkers_copy(afq_handle *h, int src, int dst) {
     return AFQ_OK;
 }
 
-int afq_estimates_update(afq_handle *h, int eval_energy) {
-    AFQ_API(h, "afq_estimates_update");
-    if (!h) return AFQ_EINVAL;
+static int est_publish_args(afq_handle *h, int zero, EstPublish *pub);
+
+// (publish_zero < 0: plain update; 0 / 1: the block's sums are handed to the host by the same summation launch, see
+//  afq_estimates_update_publish)
+static int estimates_update_impl(afq_handle *h, int eval_energy, int publish_zero) {
     int rc = need_ready(h, false);
     if (rc) return rc;
+    if (publish_zero >= 0 && h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_update_publish: a fetch is already in flight");
     if (eval_energy) {
         {
             PhaseTimer t(h, T_GREENS);
@@ -1417,12 +1420,31 @@ int afq_estimates_update(afq_handle *h, int eval_energy) {
         PhaseTimer t(h, T_ENERGY);
         if ((rc = local_energy(h))) return rc;
     }
-    if ((rc = k_estimates(h, eval_energy))) return rc;
+    if (publish_zero >= 0) {
+        // (the arguments are made HERE, behind the energy evaluation: the closed-shell word that rides along is the one of
+        //  the newest checking launch)
+        EstPublish pub;
+        if ((rc = est_publish_args(h, publish_zero, &pub))) return rc;
+        if ((rc = k_estimates(h, eval_energy, false, &pub))) return rc;
+        h->est_pending = true;
+    } else if ((rc = k_estimates(h, eval_energy))) return rc;
     if (h->rdm_on && !(h->flags & AFQ_PROP_FREE_PROJECTION)) {   // the free-projection branch has no RDM (mixed.py:151-175)
         if (!h->G) AFQ_FAIL(h, AFQ_ESTATE, "one_rdm: no Green's function evaluated yet");
         return k_rdm_accumulate(h);
     }
     return AFQ_OK;
+}
+
+int afq_estimates_update(afq_handle *h, int eval_energy) {
+    AFQ_API(h, "afq_estimates_update");
+    if (!h) return AFQ_EINVAL;
+    return estimates_update_impl(h, eval_energy, -1);
+}
+
+int afq_estimates_update_publish(afq_handle *h, int eval_energy, int zero) {
+    AFQ_API(h, "afq_estimates_update_publish");
+    if (!h) return AFQ_EINVAL;
+    return estimates_update_impl(h, eval_energy, zero ? 1 : 0);
 }
 
 int afq_estimates_rdm(afq_handle *h, int on) {
@@ -1479,6 +1501,23 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     if (!h) return AFQ_EINVAL;
     hipSetDevice(h->device);
     if (h->est_pending) AFQ_FAIL(h, AFQ_ESTATE, "afq_estimates_get_begin: a fetch is already in flight");
+    EstPublish pub;
+    { const int rc = est_publish_args(h, zero, &pub); if (rc) return rc; }
+    if (h->est_acc_pending) {
+        // sums still sitting in the per-walker accumulators: the launch that folds them in hands the block over too
+        const int rc = k_estimates(h, 0, true, &pub);
+        if (rc) return rc;
+    } else {
+        AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, pub.host_out,
+                   pub.host_seq, pub.seq, pub.nest, pub.zero, pub.closed_bad);
+        AFQ_POST(h);
+    }
+    h->est_pending = true;
+    return AFQ_OK;
+}
+
+// the mapped staging area, the next sequence number and the closed-shell epoch of one hand-over
+static int est_publish_args(afq_handle *h, int zero, EstPublish *pub) {
     const size_t nest = 2 * (size_t)AFQ_EST_COUNT_;
     if (!h->est_stage) {
         // [nest sums | scal[AFQ_NSCAL] | sequence number], written by the device, polled by the host
@@ -1492,19 +1531,8 @@ int afq_estimates_get_begin(afq_handle *h, int zero) {
     AFQ_HIP(h, hipHostGetDevicePointer((void **)&dev_view, h->est_stage, 0));
     ++h->est_seq;
     h->closed_epoch_pub = h->closed_epoch;                   // the newest launch whose verdict the published word can hold
-    if (h->est_acc_pending) {
-        // sums still sitting in the per-walker accumulators: the launch that folds them in hands the block over too
-        EstPublish pub;
-        pub.host_out = dev_view; pub.host_seq = (unsigned long long *)(dev_view + nest + AFQ_NSCAL); pub.seq = h->est_seq;
-        pub.scal = h->scal; pub.closed_bad = h->closed_bad; pub.nest = (int)nest; pub.zero = zero;
-        const int rc = k_estimates(h, 0, true, &pub);
-        if (rc) return rc;
-    } else {
-        AFQ_LAUNCH(h, est_publish_kernel, dim3(1), dim3(64), 0, h->stream, h->estimates, h->scal, dev_view,
-                   (unsigned long long *)(dev_view + nest + AFQ_NSCAL), h->est_seq, (int)nest, zero, h->closed_bad);
-        AFQ_POST(h);
-    }
-    h->est_pending = true;
+    pub->host_out = dev_view; pub->host_seq = (unsigned long long *)(dev_view + nest + AFQ_NSCAL); pub->seq = h->est_seq;
+    pub->scal = h->scal; pub->closed_bad = h->closed_bad; pub->nest = (int)nest; pub->zero = zero;
     return AFQ_OK;
 }
 

@@ -377,6 +377,10 @@ class AfqDevice(object):
         """The next propagate / propagate_finish takes the step's estimator terms along (no estimates_update(False))."""
         self._ck(self.lib.afq_estimates_fuse_next(self.h))
 
+    def estimates_update_publish(self, eval_energy, zero=False):
+        """estimates_update + estimates_get_begin in one summation launch (the step that ends a block)."""
+        self._ck(self.lib.afq_estimates_update_publish(self.h, int(bool(eval_energy)), int(bool(zero))))
+
     def estimates_get_begin(self, zero=False):
         """Enqueue the fetch; work enqueued afterwards keeps running while estimates_get_end waits for the sums."""
         self._ck(self.lib.afq_estimates_get_begin(self.h, int(bool(zero))))

@@ -144,7 +144,7 @@ class AFQMC(object):
             psi._invalidate('ot', 'detR', 'weight')
         self.propagators.propagate_walkers_begin(psi)
 
-    def step_batched(self, step, eshift, fetch_popcontrol=False, begun=False):
+    def step_batched(self, step, eshift, fetch_popcontrol=False, begun=False, publish=False):
         """One step of run() with batched device calls only (qmc/afqmc.py:223-246).  ``begun``: step_batched_begin(step)
         has been called already."""
         psi, dev = self.psi, self.psi.dev
@@ -179,6 +179,8 @@ class AFQMC(object):
             psi.pop_control(self.comm, fetch=fetch_popcontrol or not on_device)
         if do_energy and not mixed.eval_energy:
             mixed.update(self.system, self.qmc, self.trial, psi, step, self.propagators.free_projection)
+        elif not ride and publish:
+            dev.estimates_update_publish(do_energy, zero=True)   # (the block's sums leave with this launch: run_batched)
         elif not ride:
             dev.estimates_update(do_energy)
 
@@ -222,7 +224,11 @@ class AFQMC(object):
         begun = False
         try:
             for step in range(first_step, first_step + n):
-                self.step_batched(step, eshift, fetch_popcontrol, begun=begun)
+                # one rank, a block ends here and the next step's head is enqueued before the host waits: the update's summation
+                # launch hands the sums over itself (afq_estimates_update_publish)
+                publish = (overlap and not dcomm and step % self.qmc.nsteps == 0 and step + 1 < first_step + n
+                           and not (step % mixed.energy_eval_freq == 0 and not mixed.eval_energy))
+                self.step_batched(step, eshift, fetch_popcontrol, begun=begun, publish=publish)
                 begun = False
                 for est in others:                      # back-propagation: estimators/handler.py:156-162
                     est.update(self.system, self.qmc, self.trial, self.psi, step, fp)
@@ -232,7 +238,8 @@ class AFQMC(object):
                     if dcomm:
                         dev.estimates_allreduce()       # mixed.py:261 on the device, 20 doubles over RCCL
                     if overlap and step + 1 < first_step + n:
-                        dev.estimates_get_begin(zero=True)
+                        if not publish:
+                            dev.estimates_get_begin(zero=True)
                         self.step_batched_begin(step + 1)
                         begun = True
                         est = dev.estimates_get_end()
