@@ -114,3 +114,46 @@ def test_per_spin_ghalf_not_stored_on_announced_steps_is_recomputed_on_demand():
     assert numpy.allclose(devs[0].estimates_get(), devs[1].estimates_get(), rtol=1e-12, atol=0)
     for d in devs:
         d.close()
+
+
+def test_update_that_hands_the_block_over_equals_update_plus_fetch():
+    """afq_estimates_update_publish: the summation launch of the update writes the block's sums into the mapped host buffer
+    itself (estimators/mixed.py:211-225 + :261-273 at the step that ends a block).  Against afq_estimates_update followed by
+    afq_estimates_get_begin on a second handle: the same sums bit for bit, zeroed alike, and a second hand-over while one is
+    in flight is refused (AFQ_ESTATE)."""
+    from oracle import afqmc_ref as ref
+    from pauxy_amd import _lib as L
+    from pauxy_amd.propagation.setup import generic_propagator_arrays
+    from tests.helpers import make_device
+    M, K, N, nw = 24, 30, 5, 64
+    s = systems.synthetic_generic(M, K, (N, N), seed=13)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = generic_propagator_arrays(s, t, 0.01)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, 0.01, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=s.ecore)
+    rng = numpy.random.RandomState(4)
+    phi = numpy.array([t.psi + 0.05 * (rng.rand(M, 2 * N) + 1j * rng.rand(M, 2 * N)) for _ in range(nw)])
+    devs = [make_device(model, nw) for _ in range(2)]
+    for d in devs:
+        d.set(L.F_PHI, phi)
+        d.set(L.F_OT, d.calc_overlap())
+    for block in range(3):
+        for step in range(3):
+            xi = rng.normal(size=(nw, K))
+            last = step == 2
+            if not last:
+                devs[0].estimates_fuse_next()                # (the ride steps' accumulators are folded in by the same launch)
+                devs[1].estimates_fuse_next()
+            for d in devs:
+                d.propagate(xi, 0.1)
+            if last:
+                devs[0].estimates_update_publish(True, zero=True)
+                with pytest.raises(L.AfqError) as err:
+                    devs[0].estimates_update_publish(True, zero=True)
+                assert err.value.code == -2                  # AFQ_ESTATE
+                devs[1].estimates_update(True)
+                devs[1].estimates_get_begin(zero=True)
+        a, b = devs[0].estimates_get_end(), devs[1].estimates_get_end()
+        assert numpy.array_equal(a, b) and numpy.abs(a).max() > 0.0, block
+    for d in devs:
+        d.close()
