@@ -845,3 +845,48 @@ def test_large_system_exchange_energy_evaluates_one_spin_of_a_closed_shell_popul
     mask = numpy.arange(nw) != 5
     close(E[mask], E_closed[mask], 1e-13)                          # one spin counted twice == both spins evaluated
     dev.close()
+
+
+def test_exchange_energy_with_both_spins_slices_in_one_launch():
+    """256 walkers at the benchmark's shape (M = 100, 25 + 25): each spin's contraction slices make one whole round over the eight
+    XCDs, so the closed-shell try puts the beta slices behind the alpha slices of ONE launch (launch_exx_quadratic: `merged`) --
+    work-groups that return at once for a closed population, that multiply for an open one.  Both populations against the oracle
+    (estimators/generic.py:156-221) and against the T-intermediate algorithm; afq_counters_ext [4] says which form ran."""
+    M, N, K, nw = 100, 25, 30, 256
+    s = systems.synthetic_generic(M, K, (N, N), seed=19)
+    t = trial_mod.rhf_trial_generic(s)
+    BH1, mf = setup.generic_propagator_arrays(s, t, 0.005)
+    model = ref.RefModel('generic', M, N, N, t.psi, BH1, mf, 0.005, hs_pot=s.hs_pot, rchol=t._rchol,
+                         H1=s.H1.astype(complex), ecore=s.ecore)
+    rng = numpy.random.RandomState(23)
+    half = t.psi[None, :, :N] + 0.05 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    closed_phis = numpy.concatenate([half, half], axis=2)
+    dev = make_device(model, nw)
+    dev.set_exchange_algorithm(2)
+    sample = (0, 7, 100, nw - 1)
+
+    def check(phis, E, which):
+        for w in which:
+            _, gh_ref, G_ref = ref.greens_function(phis[w], model.psi, N, N)
+            close(E[w], numpy.array(model.local_energy(G_ref, gh_ref)), 1e-10)
+    dev.set(L.F_PHI, closed_phis)
+    dev.greens(want_G=False)
+    dev.counters(reset=True, n=8)
+    E_closed = dev.local_energy()
+    assert int(dev.counters(n=8)[4]) == nw
+    check(closed_phis, E_closed, sample)
+    dev.set_exchange_algorithm(1)
+    dev.greens(want_G=False)
+    close(dev.local_energy(), E_closed, 1e-11)
+    dev.set_exchange_algorithm(2)
+    phis = closed_phis.copy()
+    phis[100, :, N:] += 0.03 * (rng.rand(M, N) + 1j * rng.rand(M, N))
+    dev.set(L.F_PHI, phis)
+    dev.greens(want_G=False)
+    dev.counters(reset=True, n=8)
+    E = dev.local_energy()
+    assert int(dev.counters(n=8)[4]) == 0
+    check(phis, E, sample)
+    mask = numpy.arange(nw) != 100
+    close(E[mask], E_closed[mask], 1e-13)
+    dev.close()
