@@ -284,6 +284,48 @@ def test_c5_sizes_single_determinant_256_walkers():
     run_fullsize(generic_c5(), 256, [0, 130, 255])
 
 
+def test_c5_sizes_closed_shell_walkers_take_the_alpha_columns_through_the_gemm_chain():
+    """The same sizes with walkers whose spin blocks are bitwise equal (what the RHF run of `bench.py --config C5sd` holds): the
+    GEMM chain multiplies their alpha columns only and copies them over beta (afq_counters_ext [7]), the exchange energy evaluates
+    one spin ([4]).  Three walkers against the oracle for the energy and for one full step (propagation/continuous.py:232-262),
+    dead walkers untouched, live ones closed bit for bit afterwards."""
+    model = generic_c5()
+    nw, N, M, K = 256, model.na, model.M, model.nfields
+    assert numpy.array_equal(model.psi[:, :N], model.psi[:, N:]) and numpy.array_equal(model.BH1[0], model.BH1[1])
+    rng = numpy.random.RandomState(8)
+    half = model.psi[None, :, :N] + 0.05 * (rng.rand(nw, M, N) + 1j * rng.rand(nw, M, N))
+    phis = numpy.concatenate([half, half], axis=2)
+    dev = make_device(model, nw)
+    dev.set(L.F_PHI, phis)
+    det = dev.greens(want_G=False)
+    dev.counters(reset=True, n=8)
+    E = dev.local_energy()
+    assert int(dev.counters(n=8)[4]) == (nw if dev.exchange_algorithm() == 2 else 0)
+    sample = [0, 130, 255]
+    for w in sample:
+        d, gh, Gr = ref.greens_function(phis[w], model.psi, N, N)
+        close(det[w], d, 1e-10)
+        close(E[w], numpy.array(model.local_energy(Gr, gh)), 1e-10)
+    xi = rng.normal(size=(nw, K))
+    w0 = numpy.ones(nw)
+    w0[1::5] = 0.0
+    dev.set(L.F_WEIGHT, w0)
+    dev.set(L.F_OT, det)
+    dev.counters(reset=True, n=8)
+    dev.propagate(xi, 0.0)
+    assert int(dev.counters(n=8)[7]) == int((w0 > 0).sum())
+    out_phi, out_w = dev.get(L.F_PHI), dev.get(L.F_WEIGHT)
+    dead = numpy.nonzero(w0 == 0.0)[0]
+    assert numpy.array_equal(out_phi[dead], phis[dead]) and numpy.all(out_w[dead] == 0.0)
+    assert numpy.array_equal(out_phi[:, :, :N], out_phi[:, :, N:])
+    for w in sample:
+        wk = ref.new_walker(model, phis[w])
+        ref.propagate_walker_phaseless(model, wk, xi[w], 0.0)
+        close(out_phi[w], wk['phi'], 1e-9)
+        close(out_w[w], wk['weight'], 1e-9)
+    dev.close()
+
+
 @pytest.mark.parametrize("M,K,N,nw", [(400, 2000, 50, 32), (130, 24, 20, 33), (100, 20, 45, 9), (40, 16, 33, 65)],
                          ids=["C5", "M130-20e", "M100-45e", "M40-33e"])
 def test_c5_sizes_multi_determinant_consistency(M, K, N, nw):
